@@ -1,0 +1,302 @@
+/*
+ * pxg.h -- C ABI of the MI355X-native poreplex raw-signal hot path (libpxg.so).
+ *
+ * The reference (hyeshik/poreplex) has no FFI for this path: the per-read
+ * processor is Python (poreplex/signal_analyzer.py:46-134) calling NumPy,
+ * TensorFlow/Keras, pomegranate and one in-tree C extension
+ * (src/csupport.c:70-124).  This header is the boundary a maintainer would
+ * bind with ctypes (INTEGRATION.md shows the stub) so that
+ * `process_batch(batchid, reads, config)` keeps its signature while every
+ * stage between "int16 DAQ samples" and "per-read result record" runs on the
+ * GPU.  Each entry point cites the reference code it replaces.
+ *
+ * Conventions (mirroring src/csupport.c:92-121): caller owns every host
+ * buffer; nothing is retained after return; functions return 0 or a negative
+ * pxg_error and never throw; per-read domain failures are DATA (the `status`
+ * field), not errors.  A context is bound to one GPU and one host thread.
+ * Plain pointers and sizes only -- no torch / HIP types in any signature.
+ */
+#ifndef PXG_H
+#define PXG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PXG_ABI_VERSION 1
+
+#define PXG_MAX_STATES      8   /* HMM states per model (reference uses 6)        */
+#define PXG_MAX_MIXTURE     4   /* Gaussian components per state (reference <= 2) */
+#define PXG_N_SEGMENTS      8   /* seg_first/seg_last slots (= PXG_MAX_STATES)     */
+#define PXG_MAX_CLASSES     8   /* softmax width (reference: 1 decoy + 4 barcodes) */
+#define PXG_MAX_CALIBRATION 64  /* phred calibration table rows (reference: 29)    */
+#define PXG_MAX_SPIKES      8   /* poly(A) spike records kept per read             */
+
+/* ---- error codes (function return values) -------------------------------- */
+enum pxg_error {
+    PXG_OK = 0,
+    PXG_E_INVALID = -1,     /* bad argument / inconsistent config          */
+    PXG_E_NODEVICE = -2,    /* no usable HIP device                        */
+    PXG_E_HIP = -3,         /* a HIP runtime call failed (see last_error)  */
+    PXG_E_NOMEM = -4,
+    PXG_E_STATE = -5,       /* call order violated (e.g. run before upload) */
+    PXG_E_UNSUPPORTED = -6
+};
+
+/* ---- per-read status: the reference's status strings ----- *
+ * signal_loader.py:123,206,221,109; signal_analyzer.py:90-92,240,273,279,342 */
+enum pxg_status {
+    PXG_ST_OKAY = 0,
+    PXG_ST_DISAPPEARED = 1,
+    PXG_ST_IRREGULAR_FAST5 = 2,
+    PXG_ST_SCALER_SIGNAL_TOO_SHORT = 3,
+    PXG_ST_SCALING_QC_FAIL = 4,
+    PXG_ST_ADAPTER_NOT_DETECTED = 5,
+    PXG_ST_NOT_BASECALLED = 6,
+    PXG_ST_BASECALL_TABLE_INCOMPLETE = 7,
+    PXG_ST_UNSPLIT_READ = 8,
+    PXG_ST_SEQUENCE_TOO_SHORT = 9,
+    PXG_ST_UNKNOWN_ERROR = 10,
+    PXG_N_STATUS = 11
+};
+
+/* ---- stage selection bits for pxg_process_batch / pxg_batch_run ---------- */
+enum pxg_stage {
+    PXG_STAGE_SCALER   = 1u << 0, /* a2-a4: head pool + scaler LSTM + QC        */
+    PXG_STAGE_SEGMENT  = 1u << 1, /* a1,a5,a7,a8: pA + pool + scale + Viterbi   */
+    PXG_STAGE_BARCODE  = 1u << 2, /* a9-a13: window, robust z, demux LSTM       */
+    PXG_STAGE_POLYA    = 1u << 3, /* a14-a17: event detection + interval DP     */
+    PXG_STAGE_ALL_DEMUX = (1u << 0) | (1u << 1) | (1u << 2)
+};
+
+/* indices into pxg_stage_times.ms[] */
+enum pxg_timer {
+    PXG_T_HEAD_POOL = 0, PXG_T_SCALER_LSTM, PXG_T_SEGMENT, PXG_T_BARCODE_WINDOW,
+    PXG_T_DEMUX_BIDIR, PXG_T_DEMUX_TOP, PXG_T_POLYA, PXG_T_FINALIZE, PXG_T_TOTAL,
+    PXG_N_TIMERS
+};
+
+/* DAQ calibration of one read: fast5_file.py:110-115 (channel_id attrs). */
+typedef struct {
+    double range;
+    double digitisation;
+    double offset;
+    double sampling_rate;
+} pxg_calib;
+
+/* One HMM (worker_persistence.py:95-121 + rna-r941.cfg:61-151), states in the
+ * order the preset lists them.  trans[i][j] = P(i -> j); 0 means "no edge". */
+typedef struct {
+    int32_t n_states;
+    int32_t adapter_state;                 /* index of 'adapter', -1 if none   */
+    int32_t polya_state;                   /* index of 'polya-tail', -1 if none*/
+    int32_t reserved;
+    int32_t name_rank[PXG_MAX_STATES];     /* rank of the state name in sorted
+                                              order (pomegranate tie order)    */
+    int32_t n_mix[PXG_MAX_STATES];
+    double start_prob[PXG_MAX_STATES];
+    double mix_mu[PXG_MAX_STATES][PXG_MAX_MIXTURE];
+    double mix_sigma[PXG_MAX_STATES][PXG_MAX_MIXTURE];
+    double mix_weight[PXG_MAX_STATES][PXG_MAX_MIXTURE];
+    double trans[PXG_MAX_STATES][PXG_MAX_STATES];
+} pxg_hmm;
+
+/* Keras LSTM layer, Keras layout: kernel [in, 4*units], recurrent
+ * [units, 4*units], bias [4*units]; gate blocks ordered i, f, c, o. */
+typedef struct {
+    int32_t input_dim;
+    int32_t units;
+    const float* kernel;
+    const float* recurrent;
+    const float* bias;
+} pxg_lstm_layer;
+
+typedef struct {
+    int32_t in_dim;
+    int32_t out_dim;
+    const float* kernel; /* [in_dim, out_dim] */
+    const float* bias;   /* [out_dim] */
+} pxg_dense_layer;
+
+/* Flattened numeric image of the reference's config dict (keys
+ * read at signal_analyzer.py:231-278,347; signal_loader.py:50-65,93;
+ * barcoding.py:52-53,84-90,107; polya.py:32-48). */
+typedef struct {
+    uint32_t abi_version;       /* must be PXG_ABI_VERSION                       */
+    int32_t device_id;          /* HIP device ordinal (rank -> GPU)              */
+
+    /* signal_processing (rna-r941.cfg:8-12) + scaler-r3 attrs */
+    int32_t stride;             /* rough_signal_stride = 15                      */
+    int32_t scaler_length;      /* input_defs.length = 30000                     */
+    int32_t scaler_min_length;  /* input_defs.min_length = 9000                  */
+    int32_t reserved0;
+    double scaler_xfrm[4];      /* scale_mean, scale_std, shift_mean, shift_std  */
+    double scaler_qc_scale[2];  /* inclusive bounds, norm.ppf (signal_loader.py:65-68) */
+    double scaler_qc_shift[2];
+    pxg_lstm_layer scaler_lstm1, scaler_lstm2;
+    pxg_dense_layer scaler_dense;
+
+    /* segmentation (rna-r941.cfg:14-15,61-101) */
+    int32_t segmentation_scan_limit;  /* raw samples, 100000 */
+    int32_t reserved1;
+    pxg_hmm segmentation_model;
+    pxg_hmm unsplit_model;            /* carried for the chimera filter (a19)    */
+
+    /* demultiplexing (rna-r941.cfg:29-36) */
+    int32_t number_of_decoy_labels;
+    int32_t number_of_barcodes;
+    int32_t minimum_dna_length;
+    int32_t maximum_dna_length;
+    int32_t signal_trim_length;
+    int32_t n_calibration;
+    double calibration[PXG_MAX_CALIBRATION];
+    double score_threshold;           /* calibration[barcoding_quality_filter]   */
+    float pad_filler;                 /* barcoding.py:32  (-1000.0)              */
+    int32_t reserved2;
+    pxg_lstm_layer demux_fwd, demux_bwd, demux_top;
+    pxg_dense_layer demux_dense;
+
+    /* polya_dwell (rna-r941.cfg:38-59) */
+    int32_t polya_refinement_expansion;
+    int32_t polya_openend_expansion;
+    int32_t polya_median_pre_filter;
+    int32_t polya_maximum_openend_extension;
+    int32_t ed_window_length1, ed_window_length2;
+    float ed_threshold1, ed_threshold2, ed_peak_height;
+    int32_t polya_spike_tolerance;
+    double polya_mean_dist[2];
+    double polya_mean_z_cutoff;
+    double polya_stdv_max;
+    double polya_stdv_range[2];
+    double polya_spike_weight;
+    double polya_mean_trigger_recalibration;
+    int32_t recal_max_dist_from_adapter;
+    int32_t recal_min_length;
+    double recal_max_stdv;
+} pxg_config;
+
+/* Per-read result record: what NanoporeRead carries out of the hot path
+ * (signal_loader.py:114-155,165-198).  POD, 8-byte aligned, also the unit of
+ * the multi-GPU all-gather. */
+typedef struct {
+    int32_t status;                       /* enum pxg_status                     */
+    int32_t n_pooled;                     /* P = N // stride                     */
+    int32_t seg_first[PXG_N_SEGMENTS];    /* pooled, right-inclusive; -1 absent  */
+    int32_t seg_last[PXG_N_SEGMENTS];
+    float scale, shift;                   /* scaling_params (float32)            */
+    float scaler_pred[2];                 /* raw network output                  */
+    int8_t bc_pushed;                     /* adapter window passed the length gate */
+    int8_t bc_called;                     /* barcode != None                     */
+    int8_t bc_label;                      /* argmax - n_decoy (barcode_guess)    */
+    uint8_t bc_phred;                     /* calibrated score                    */
+    float bc_score;                       /* max softmax                         */
+    float probs[PXG_MAX_CLASSES];
+    int8_t polya_called;
+    int8_t polya_n_spikes;
+    int16_t reserved;
+    int32_t polya_dwell_samples;          /* sum of poly(A)-event lengths        */
+    int64_t polya_begin, polya_end;       /* raw-sample coordinates              */
+    float polya_spikes[PXG_MAX_SPIKES][4];/* (length, mean-1, mean, mean+1)      */
+} pxg_read_result;
+
+/* scrappie event record (src/contrib/scrappie/scrappie_structures.h:8-15,
+ * as exported by src/csupport.c:156-159). */
+typedef struct {
+    uint64_t start;
+    float length;
+    float mean;
+    float stdv;
+    int32_t pos;
+    int32_t state;
+} pxg_event;
+
+typedef struct {
+    float ms[PXG_N_TIMERS];      /* HIP-event time of each stage, last run       */
+    int64_t n_launches[PXG_N_TIMERS];
+} pxg_stage_times;
+
+typedef struct {
+    char name[128];
+    char arch[32];
+    int32_t compute_units;
+    int32_t wavefront_size;
+    int64_t total_mem;
+    int32_t lds_per_cu;
+    int32_t clock_khz;
+} pxg_device_info;
+
+typedef struct pxg_ctx pxg_ctx;
+
+/* ---- lifetime: replaces WorkerPersistenceStorage.init_persistence_objects
+ * (worker_persistence.py:60-90): load models once per worker process. ------ */
+int pxg_create(const pxg_config* cfg, pxg_ctx** out);
+void pxg_destroy(pxg_ctx* ctx);
+const char* pxg_last_error(const pxg_ctx* ctx_or_null);
+int pxg_abi_version(void);
+int pxg_get_device_info(pxg_ctx* ctx, pxg_device_info* out);
+
+/* ---- the hot path: replaces SignalAnalyzer.process for the numeric part
+ * (signal_analyzer.py:82-134 phases 1-4).  raw_offsets has n_reads+1 entries
+ * (sample indices into raw_arena).  scale_shift_or_null: n_reads x 2 float32
+ * to INJECT scaling_params and skip the scaler network (test hook). --------- */
+int pxg_process_batch(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
+                      const int64_t* raw_offsets, const pxg_calib* calib,
+                      const float* scale_shift_or_null, uint32_t stage_mask,
+                      pxg_read_result* out);
+
+/* Split form for device-resident batches (loader overlap, benchmarking):
+ * upload = H2D copy into context-owned HBM arenas; run = enqueue all kernels
+ * on the context stream (asynchronous); sync = wait; download = D2H results. */
+int pxg_batch_upload(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
+                     const int64_t* raw_offsets, const pxg_calib* calib,
+                     const float* scale_shift_or_null);
+int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask);
+int pxg_batch_sync(pxg_ctx* ctx);
+int pxg_batch_download(pxg_ctx* ctx, pxg_read_result* out);
+int pxg_batch_times(pxg_ctx* ctx, pxg_stage_times* out);
+/* Fill the resident batch on the device from a seed (bench configs that are
+ * too large to stage through the host). */
+int pxg_batch_synthesize(pxg_ctx* ctx, int64_t n_reads, int64_t samples_per_read,
+                         uint64_t seed);
+
+/* ---- per-stage hooks (parity tests call these through the same ABI) ------ */
+/* a1: Fast5Reader.get_raw_data (fast5_file.py:122-131) */
+int pxg_raw_to_pa(pxg_ctx* ctx, int64_t n, const int16_t* raw, const pxg_calib* calib,
+                  float* out);
+/* a2: NanoporeRead.load_padded_signal_head (signal_loader.py:212-231);
+ * out: n_reads x (scaler_length/stride) float32; status: n_reads int32 */
+int pxg_head_pool(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
+                  const int64_t* raw_offsets, const pxg_calib* calib, float* out,
+                  int32_t* status);
+/* a4: scaler_model.predict (signal_loader.py:96-97); head n x T, pred n x 2 */
+int pxg_scaler_lstm(pxg_ctx* ctx, int64_t n_reads, const float* head, float* pred);
+/* a4: de-standardise + QC (signal_loader.py:98-109); status 0 or SCALING_QC_FAIL */
+int pxg_scaler_transform(pxg_ctx* ctx, int64_t n_reads, const float* pred,
+                         float* scale_shift, int32_t* status);
+/* a5: NanoporeRead.load_signal(pool=stride) (signal_loader.py:233-264);
+ * pooled_offsets n+1 (in pooled samples) describes the caller's out arena */
+int pxg_pool_scale(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
+                   const int64_t* raw_offsets, const pxg_calib* calib,
+                   const float* scale_shift, const int64_t* pooled_offsets, float* out);
+/* a7+a8: segmodel.viterbi + detect_segments (signal_analyzer.py:346-364) on
+ * already pooled+scaled signals; path_or_null receives state ids per step */
+int pxg_viterbi(pxg_ctx* ctx, int which_model, int64_t n_reads, const float* signal_arena,
+                const int64_t* signal_offsets, int32_t* seg_first, int32_t* seg_last,
+                int32_t* path_or_null, double* logp_or_null);
+/* a10+a11: BarcodeDemultiplexer.push/normalize_signal (barcoding.py:77-101);
+ * out n x signal_trim_length, pushed n int8 */
+int pxg_barcode_window(pxg_ctx* ctx, int64_t n_reads, const float* signal_arena,
+                       const int64_t* signal_offsets, float* out, int8_t* pushed);
+/* a12: demuxer.model.predict (barcoding.py:106-107); win n x T, probs n x classes */
+int pxg_demux_lstm(pxg_ctx* ctx, int64_t n_reads, const float* win, float* probs);
+/* a15: csupport.detect_events (src/csupport.c:70-124) on a batch of windows */
+int pxg_detect_events(pxg_ctx* ctx, int64_t n_windows, const float* signal_arena,
+                      const int64_t* signal_offsets, int64_t max_events_per_window,
+                      pxg_event* events, int64_t* n_events);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PXG_H */

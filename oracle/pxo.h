@@ -1,0 +1,112 @@
+/*
+ * pxo.h -- ORACLE: CPU restatement of poreplex's raw-signal hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the timed CPU baseline.  The
+ * product (poreplex_amd/, libpxg.so) never links, imports or calls it.
+ *
+ * Every function restates one row of SURVEY.md section 8(a) and cites the
+ * reference file:line it follows.  Struct layouts are taken from the ABI
+ * contract header include/pxg.h (types only) so results compare field by
+ * field with the HIP path.
+ *
+ * PARITY PINNING (see DESIGN.md "Oracle"):
+ *   pinned by reference outputs generated in the build container
+ *     (tools/make_golden.py, /opt/conda/bin/python3.9, real reference glue +
+ *     compiled reference C): a1 a2 a5 a8 a9 a10 a11 a13 a14 a15 a16 a17 and the
+ *     scaler de-standardise/QC arithmetic of a4;
+ *   PARITY UNPINNED (TensorFlow and pomegranate are not installable here and
+ *     the reference ships no tests): the LSTM forward passes (a4, a12) and the
+ *     HMM Viterbi (a6, a7) are restated from Keras 2.2.4 / pomegranate>=0.10
+ *     documented semantics and cross-checked against independent float64 /
+ *     torch-CPU implementations and exhaustive path enumeration.
+ */
+#ifndef PXO_H
+#define PXO_H
+
+#include <stdint.h>
+#include "../include/pxg.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* a1  fast5_file.py:122-131 */
+void pxo_raw_to_pa(const int16_t* raw, int64_t n, const pxg_calib* cal, float* out);
+
+/* numpy float32 add.reduce over a contiguous run (pairwise, 8 accumulators) */
+float pxo_np_sum_f32(const float* a, int64_t n);
+
+/* a2  signal_loader.py:212-231; returns 0 or PXG_ST_SCALER_SIGNAL_TOO_SHORT */
+int pxo_head_pool(const int16_t* raw, int64_t n_raw, const pxg_calib* cal,
+                  int length_limit, int stride, int min_length, float* out);
+
+/* a5  signal_loader.py:233-264 (pool=stride, scale=True); returns P */
+int64_t pxo_pool_scale(const int16_t* raw, int64_t n_raw, const pxg_calib* cal,
+                       int stride, float scale, float shift, float* out);
+
+/* canonical float32 transcendental kit shared (by specification, not by code)
+ * with the HIP kernels: DESIGN.md "Canonical LSTM arithmetic" */
+float pxo_expf(float x);
+float pxo_sigmoid(float x);
+float pxo_tanh(float x);
+
+/* a4  signal_loader.py:96-97 + scaler-r3.hdf5; x[T] -> pred[2] */
+void pxo_scaler_forward(const pxg_config* cfg, const float* x, int T, float* pred);
+/* a4  signal_loader.py:98-109; returns 0 or PXG_ST_SCALING_QC_FAIL */
+int pxo_scaler_transform(const pxg_config* cfg, const float* pred, float* scale_shift);
+
+/* a12 barcoding.py:106-107 + demux-tetra-r4.hdf5; x[T] -> probs[n_classes] */
+void pxo_demux_forward(const pxg_config* cfg, const float* x, int T, float* probs);
+/* intermediate access for layer-by-layer tests: runs one LSTM layer over a
+ * sequence; seq_out may be NULL; reverse!=0 consumes x back to front and
+ * stores outputs at their original time index (Keras Bidirectional). */
+void pxo_lstm_layer(const pxg_lstm_layer* L, const float* x, int T, int reverse,
+                    float* seq_out, float* h_last);
+
+/* a6+a7 worker_persistence.py:95-121 + pomegranate viterbi; returns logp */
+double pxo_viterbi(const pxg_hmm* hmm, const float* x, int T, int32_t* path);
+/* log emission density of state s at x (pomegranate Normal / GMM) */
+double pxo_hmm_emission(const pxg_hmm* hmm, int s, double x);
+/* a8  signal_analyzer.py:346-364 (run-length summary, last run wins) */
+void pxo_segments(const int32_t* path, int T, int32_t* seg_first, int32_t* seg_last);
+
+/* a11 barcoding.py:77-81 (in place on a copy) */
+void pxo_normalize_signal(const float* sig, int n, float* out);
+/* a9+a10 signal_analyzer.py:445-448, barcoding.py:83-101; returns pushed flag */
+int pxo_barcode_window(const pxg_config* cfg, const float* adapter_signal, int len,
+                       float* out);
+/* a13 barcoding.py:72-75 */
+int pxo_phred(const pxg_config* cfg, float score);
+/* a12 tail: barcoding.py:108-118 */
+void pxo_barcode_call(const pxg_config* cfg, const float* probs, pxg_read_result* r);
+
+/* a15 src/csupport.c:70-124 -> scrappie event_detection.c; returns n events */
+int64_t pxo_detect_events(const float* sig, int64_t n, int64_t w1, int64_t w2,
+                          float thr1, float thr2, float peak_height,
+                          pxg_event* out, int64_t max_out);
+/* scipy.signal.medfilt(x, k) for odd k, zero padded (polya.py:62-63) */
+void pxo_medfilt(const float* x, int64_t n, int k, float* out);
+
+/* a14+a16+a17 polya.py:50-187 on one read; fills polya_* fields of r */
+void pxo_polya(const pxg_config* cfg, const float* scaled_full, int64_t n_raw,
+               int rough_begin, int rough_end_or_neg, double sampling_rate,
+               pxg_read_result* r);
+/* a16 polya.py:156-187; is_polya/length per event; returns 1 and (i,j) or 0 */
+int pxo_best_polya_interval(const pxg_config* cfg, const uint8_t* is_polya,
+                            const float* length, int n_events, int* out_i, int* out_j);
+
+/* whole per-read path (signal_analyzer.py:82-134 phases 1-4, numeric part) */
+void pxo_process_read(const pxg_config* cfg, const int16_t* raw, int64_t n_raw,
+                      const pxg_calib* cal, const float* scale_shift_or_null,
+                      uint32_t stage_mask, pxg_read_result* out);
+void pxo_process_batch(const pxg_config* cfg, int64_t n_reads, const int16_t* raw_arena,
+                       const int64_t* raw_offsets, const pxg_calib* calib,
+                       const float* scale_shift_or_null, uint32_t stage_mask,
+                       pxg_read_result* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,532 @@
+/*
+ * pxo_core.c -- ORACLE (test infrastructure, never shipped): signal
+ * conversion/pooling, recurrent nets, HMM Viterbi, barcode window.
+ * See pxo.h for the pinning status of each row.
+ *
+ * Build: gcc -std=c11 -O2 -ffp-contract=off -mavx2 -mfma (oracle/Makefile).
+ * -ffp-contract=off is REQUIRED: every fused multiply-add below is an explicit
+ * fmaf(); everything written a*b+c is two roundings, as NumPy/TF do it.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include "pxo.h"
+
+/* ------------------------------------------------------------------------ *
+ * a1  DAQ counts -> pA.  fast5_file.py:130-131:
+ *     np.array(range / digitisation * (rawsignal + offset), dtype=float32)
+ *     int16 + python float -> float64; product in float64; one cast.
+ * ------------------------------------------------------------------------ */
+static inline float raw2pa(int16_t raw, double k, double offset)
+{
+    return (float)(k * ((double)raw + offset));
+}
+
+void pxo_raw_to_pa(const int16_t* raw, int64_t n, const pxg_calib* cal, float* out)
+{
+    const double k = cal->range / cal->digitisation;
+    for (int64_t i = 0; i < n; i++)
+        out[i] = raw2pa(raw[i], k, cal->offset);
+}
+
+/* ------------------------------------------------------------------------ *
+ * NumPy's float32 add.reduce along a contiguous axis (pairwise_sum in
+ * numpy/core/src/umath/loops_utils.h.src): n < 8 plain loop; n <= 128 eight
+ * running partial sums, combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the
+ * tail added one by one; larger n split in halves (multiple of 8).
+ * Used by mean(axis=1, dtype=float32) at signal_loader.py:224-225,246-247.
+ * ------------------------------------------------------------------------ */
+float pxo_np_sum_f32(const float* a, int64_t n)
+{
+    if (n < 8) {
+        float res = 0.0f;
+        for (int64_t i = 0; i < n; i++)
+            res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        float r[8];
+        for (int k = 0; k < 8; k++)
+            r[k] = a[k];
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; k++)
+                r[k] += a[i + k];
+        float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++)
+            res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return pxo_np_sum_f32(a, n2) + pxo_np_sum_f32(a + n2, n - n2);
+}
+
+/* mean of one stride-block of raw samples: float32 add.reduce then a float32
+ * true-divide by the count (numpy _methods._mean) */
+static float block_mean(const int16_t* raw, int stride, double k, double offset)
+{
+    float pa[128];
+    for (int j = 0; j < stride; j++)
+        pa[j] = raw2pa(raw[j], k, offset);
+    /* the reduction result starts from the additive identity 0.0f */
+    float s = 0.0f + pxo_np_sum_f32(pa, stride);
+    return s / (float)stride;
+}
+
+/* ------------------------------------------------------------------------ *
+ * a2  signal_loader.py:212-231  load_padded_signal_head(30000, 15, 9000)
+ * ------------------------------------------------------------------------ */
+int pxo_head_pool(const int16_t* raw, int64_t n_raw, const pxg_calib* cal,
+                  int length_limit, int stride, int min_length, float* out)
+{
+    const double k = cal->range / cal->digitisation;
+    int64_t L = n_raw < length_limit ? n_raw : length_limit; /* :213 */
+    L -= L % stride;                                         /* :214 */
+    const int n_out = length_limit / stride;
+    for (int i = 0; i < n_out; i++)
+        out[i] = 0.0f;
+    if (L < min_length)                                      /* :220-222 */
+        return PXG_ST_SCALER_SIGNAL_TOO_SHORT;
+    const int n_means = (int)(L / stride);
+    const int pad = n_out - n_means;                         /* left pad :227-229 */
+    for (int i = 0; i < n_means; i++)
+        out[pad + i] = block_mean(raw + (int64_t)i * stride, stride, k, cal->offset);
+    return PXG_ST_OKAY;
+}
+
+/* ------------------------------------------------------------------------ *
+ * a5  signal_loader.py:233-264  load_signal(pool=15): block means then
+ *     np.poly1d(float32[scale, shift])(x) = fl(fl(scale*x) + shift)  (:262)
+ * ------------------------------------------------------------------------ */
+int64_t pxo_pool_scale(const int16_t* raw, int64_t n_raw, const pxg_calib* cal,
+                       int stride, float scale, float shift, float* out)
+{
+    const double k = cal->range / cal->digitisation;
+    const int64_t P = n_raw / stride;
+    for (int64_t p = 0; p < P; p++) {
+        float m = block_mean(raw + p * stride, stride, k, cal->offset);
+        float y = scale * m;
+        out[p] = y + shift;
+    }
+    return P;
+}
+
+/* ------------------------------------------------------------------------ *
+ * Canonical float32 transcendental kit (DESIGN.md "Canonical LSTM
+ * arithmetic").  Only IEEE +,*,/,fma and integer ops, so the HIP kernels
+ * reproduce it bit for bit.  expf: Cody-Waite reduction by ln2 (hi/lo),
+ * degree-7 Taylor/Horner in fma form, exponent insertion.
+ * ------------------------------------------------------------------------ */
+static inline float bits2f(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
+static inline int32_t f2bits(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
+
+float pxo_expf(float x)
+{
+    if (x > 88.0f)
+        return INFINITY;
+    if (x < -87.0f)
+        return 0.0f;
+    const float magic = 12582912.0f; /* 1.5 * 2^23: round-to-nearest-even */
+    float t = fmaf(x, 1.44269504088896341f, magic);
+    float n = t - magic;
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.98412698412698413e-4f;           /* 1/5040 */
+    p = fmaf(p, r, 1.38888888888888894e-3f);     /* 1/720  */
+    p = fmaf(p, r, 8.33333333333333322e-3f);     /* 1/120  */
+    p = fmaf(p, r, 4.16666666666666644e-2f);     /* 1/24   */
+    p = fmaf(p, r, 1.66666666666666657e-1f);     /* 1/6    */
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    return bits2f(f2bits(p) + ((int32_t)n << 23));
+}
+
+float pxo_sigmoid(float x)
+{
+    return 1.0f / (1.0f + pxo_expf(-x));
+}
+
+float pxo_tanh(float x)
+{
+    /* 2*sigmoid(2x) - 1, each step rounded */
+    float s = 1.0f / (1.0f + pxo_expf(-(2.0f * x)));
+    return 2.0f * s - 1.0f;
+}
+
+/* ------------------------------------------------------------------------ *
+ * One Keras LSTM cell step (recurrent_v2 / LSTMCell.call; gate blocks
+ * i,f,c,o; activation tanh, recurrent_activation sigmoid):
+ *     z = x.W + h.U + b ; i,f,o = sigmoid ; g = tanh(z_c)
+ *     c' = f*c + i*g ; h' = o*tanh(c')
+ * Canonical evaluation order (what the MFMA kernels reproduce):
+ *   accumulator start  scalar input: fl(fl(x*W_j) + b_j)
+ *                      vector input: b_j
+ *   then ONE fma chain over the input rows k = 0.. (vector input only)
+ *   followed by the recurrent rows k = 0..units-1.
+ *   c' = fl(fl(f*c) + fl(i*g)),  h' = fl(o * tanh(c')).
+ * ------------------------------------------------------------------------ */
+static void lstm_step(const pxg_lstm_layer* L, const float* x, float* h, float* c,
+                      float* z)
+{
+    const int H = L->units, G = 4 * H, I = L->input_dim;
+    if (I == 1) {
+        const float xv = x[0];
+        for (int j = 0; j < G; j++) {
+            float xw = xv * L->kernel[j];
+            z[j] = xw + L->bias[j];
+        }
+    } else {
+        for (int j = 0; j < G; j++)
+            z[j] = L->bias[j];
+        for (int k = 0; k < I; k++) {
+            const float xk = x[k];
+            const float* w = L->kernel + (size_t)k * G;
+            for (int j = 0; j < G; j++)
+                z[j] = fmaf(xk, w[j], z[j]);
+        }
+    }
+    for (int k = 0; k < H; k++) {
+        const float hk = h[k];
+        const float* u = L->recurrent + (size_t)k * G;
+        for (int j = 0; j < G; j++)
+            z[j] = fmaf(hk, u[j], z[j]);
+    }
+    for (int u = 0; u < H; u++) {
+        float ig = pxo_sigmoid(z[u]);
+        float fg = pxo_sigmoid(z[H + u]);
+        float gg = pxo_tanh(z[2 * H + u]);
+        float og = pxo_sigmoid(z[3 * H + u]);
+        float fc = fg * c[u];
+        float in = ig * gg;
+        float cn = fc + in;
+        c[u] = cn;
+        h[u] = og * pxo_tanh(cn);
+    }
+}
+
+void pxo_lstm_layer(const pxg_lstm_layer* L, const float* x, int T, int reverse,
+                    float* seq_out, float* h_last)
+{
+    const int H = L->units, I = L->input_dim;
+    float* h = (float*)calloc(H, sizeof(float));
+    float* c = (float*)calloc(H, sizeof(float));
+    float* z = (float*)malloc(sizeof(float) * 4 * H);
+    for (int s = 0; s < T; s++) {
+        const int t = reverse ? T - 1 - s : s;
+        lstm_step(L, x + (size_t)t * I, h, c, z);
+        if (seq_out)
+            memcpy(seq_out + (size_t)t * H, h, sizeof(float) * H);
+    }
+    if (h_last)
+        memcpy(h_last, h, sizeof(float) * H);
+    free(h); free(c); free(z);
+}
+
+static void dense_forward(const pxg_dense_layer* D, const float* x, float* out)
+{
+    for (int j = 0; j < D->out_dim; j++) {
+        float acc = D->bias[j];
+        for (int k = 0; k < D->in_dim; k++)
+            acc = fmaf(x[k], D->kernel[(size_t)k * D->out_dim + j], acc);
+        out[j] = acc;
+    }
+}
+
+/* a4  scaler-r3: LSTM(48, seq) -> LSTM(48) -> Dense(2, linear); Dropout is
+ *     identity at inference */
+void pxo_scaler_forward(const pxg_config* cfg, const float* x, int T, float* pred)
+{
+    const int H1 = cfg->scaler_lstm1.units, H2 = cfg->scaler_lstm2.units;
+    float* seq = (float*)malloc(sizeof(float) * (size_t)T * H1);
+    float* h2 = (float*)malloc(sizeof(float) * H2);
+    pxo_lstm_layer(&cfg->scaler_lstm1, x, T, 0, seq, NULL);
+    pxo_lstm_layer(&cfg->scaler_lstm2, seq, T, 0, NULL, h2);
+    dense_forward(&cfg->scaler_dense, h2, pred);
+    free(seq); free(h2);
+}
+
+/* a4  signal_loader.py:98-109.  poly1d([std, mean]) with float64 coefficients
+ *     applied to a float32 array under NumPy-1.x value-based casting stays
+ *     float32: fl(fl(fl32(std)*p) + fl32(mean)); the QC bounds are float64
+ *     scalars compared against a float32 ARRAY, hence rounded to float32
+ *     first; both ends inclusive (:70-73). */
+int pxo_scaler_transform(const pxg_config* cfg, const float* pred, float* ss)
+{
+    const float s_mean = (float)cfg->scaler_xfrm[0], s_std = (float)cfg->scaler_xfrm[1];
+    const float h_mean = (float)cfg->scaler_xfrm[2], h_std = (float)cfg->scaler_xfrm[3];
+    float a = s_std * pred[0];
+    float scale = a + s_mean;
+    float b = h_std * pred[1];
+    float shift = b + h_mean;
+    ss[0] = scale;
+    ss[1] = shift;
+    const int ok = scale >= (float)cfg->scaler_qc_scale[0] &&
+                   scale <= (float)cfg->scaler_qc_scale[1] &&
+                   shift >= (float)cfg->scaler_qc_shift[0] &&
+                   shift <= (float)cfg->scaler_qc_shift[1];
+    return ok ? PXG_ST_OKAY : PXG_ST_SCALING_QC_FAIL;
+}
+
+/* a12 demux-tetra-r4: Bidirectional(LSTMCell48, concat, seq) -> LSTMCell64 ->
+ *     Dense(5, softmax); GaussianNoise/Dropout identity.
+ *     softmax = exp(z - max) / sum, sum taken left to right. */
+void pxo_demux_forward(const pxg_config* cfg, const float* x, int T, float* probs)
+{
+    const int Hf = cfg->demux_fwd.units, Hb = cfg->demux_bwd.units;
+    const int Ht = cfg->demux_top.units, C = cfg->demux_dense.out_dim;
+    float* sf = (float*)malloc(sizeof(float) * (size_t)T * Hf);
+    float* sb = (float*)malloc(sizeof(float) * (size_t)T * Hb);
+    float* cat = (float*)malloc(sizeof(float) * (size_t)T * (Hf + Hb));
+    float* ht = (float*)malloc(sizeof(float) * Ht);
+    float z[PXG_MAX_CLASSES], e[PXG_MAX_CLASSES];
+    pxo_lstm_layer(&cfg->demux_fwd, x, T, 0, sf, NULL);
+    pxo_lstm_layer(&cfg->demux_bwd, x, T, 1, sb, NULL);
+    for (int t = 0; t < T; t++) {
+        memcpy(cat + (size_t)t * (Hf + Hb), sf + (size_t)t * Hf, sizeof(float) * Hf);
+        memcpy(cat + (size_t)t * (Hf + Hb) + Hf, sb + (size_t)t * Hb, sizeof(float) * Hb);
+    }
+    pxo_lstm_layer(&cfg->demux_top, cat, T, 0, NULL, ht);
+    dense_forward(&cfg->demux_dense, ht, z);
+    float m = z[0];
+    for (int j = 1; j < C; j++)
+        if (z[j] > m)
+            m = z[j];
+    float s = 0.0f;
+    for (int j = 0; j < C; j++) {
+        e[j] = pxo_expf(z[j] - m);
+        s = (j == 0) ? e[0] : s + e[j];
+    }
+    for (int j = 0; j < C; j++)
+        probs[j] = e[j] / s;
+    free(sf); free(sb); free(cat); free(ht);
+}
+
+/* ------------------------------------------------------------------------ *
+ * a6/a7  HMM + Viterbi, pomegranate >= 0.10 semantics:
+ *   NormalDistribution.log_probability(x) =
+ *        -log(sigma*sqrt(2*pi)) - (x-mu)^2 * (1/(2*sigma^2))        (float64)
+ *   GeneralMixtureModel: lp = NEGINF; for each component
+ *        lp = pair_lse(lp, logpdf_k(x) + log(w_k / sum w))
+ *   pair_lse(a,b) = b if a==-inf; a if b==-inf;
+ *                   a + log(exp(b-a)+1) if a > b else b + log(exp(a-b)+1)
+ *   viterbi: v[0][s] = log(pi_s) + e_s(x_0);
+ *            v[t][s] = max_k(v[t-1][k] + log a_ks)  (strict '>' scanning the
+ *            in-edges in name-sorted source order, start from -inf) + e_s(x_t)
+ *   no end state: terminate at the first maximum of the last column scanned in
+ *   name-sorted order; trace back.
+ * ------------------------------------------------------------------------ */
+#define SQRT_2_PI 2.50662827463
+
+static double pair_lse(double a, double b)
+{
+    if (a == INFINITY || b == INFINITY)
+        return INFINITY;
+    if (a == -INFINITY)
+        return b;
+    if (b == -INFINITY)
+        return a;
+    if (a > b)
+        return a + log(exp(b - a) + 1.0);
+    return b + log(exp(a - b) + 1.0);
+}
+
+double pxo_hmm_emission(const pxg_hmm* hmm, int s, double x)
+{
+    const int nm = hmm->n_mix[s];
+    if (nm == 1) {
+        const double sd = hmm->mix_sigma[s][0];
+        const double lssp = -log(sd * SQRT_2_PI);
+        const double tss = 1.0 / (2.0 * sd * sd);
+        const double d = x - hmm->mix_mu[s][0];
+        return lssp - (d * d) * tss;
+    }
+    double wsum = 0.0;
+    for (int k = 0; k < nm; k++)
+        wsum += hmm->mix_weight[s][k];
+    double lp = -INFINITY;
+    for (int k = 0; k < nm; k++) {
+        const double sd = hmm->mix_sigma[s][k];
+        const double lssp = -log(sd * SQRT_2_PI);
+        const double tss = 1.0 / (2.0 * sd * sd);
+        const double d = x - hmm->mix_mu[s][k];
+        const double l = lssp - (d * d) * tss;
+        lp = pair_lse(lp, l + log(hmm->mix_weight[s][k] / wsum));
+    }
+    return lp;
+}
+
+double pxo_viterbi(const pxg_hmm* hmm, const float* x, int T, int32_t* path)
+{
+    const int S = hmm->n_states;
+    int order[PXG_MAX_STATES]; /* states in name-sorted order */
+    for (int s = 0; s < S; s++)
+        order[hmm->name_rank[s]] = s;
+    double logtr[PXG_MAX_STATES][PXG_MAX_STATES];
+    for (int i = 0; i < S; i++)
+        for (int j = 0; j < S; j++)
+            logtr[i][j] = hmm->trans[i][j] > 0.0 ? log(hmm->trans[i][j]) : -INFINITY;
+    int8_t* bp = (int8_t*)malloc((size_t)(T > 0 ? T : 1) * S);
+    double v[PXG_MAX_STATES], nv[PXG_MAX_STATES];
+    if (T <= 0) {
+        free(bp);
+        return -INFINITY;
+    }
+    for (int s = 0; s < S; s++) {
+        double lp = hmm->start_prob[s] > 0.0 ? log(hmm->start_prob[s]) : -INFINITY;
+        double best = -INFINITY;
+        if (lp > best)
+            best = lp;
+        v[s] = best + pxo_hmm_emission(hmm, s, (double)x[0]);
+        bp[s] = -1;
+    }
+    for (int t = 1; t < T; t++) {
+        const double xt = (double)x[t];
+        for (int s = 0; s < S; s++) {
+            double best = -INFINITY;
+            int arg = -1;
+            for (int r = 0; r < S; r++) {
+                const int k = order[r];
+                if (hmm->trans[k][s] <= 0.0)
+                    continue;
+                const double cand = v[k] + logtr[k][s];
+                if (cand > best) {
+                    best = cand;
+                    arg = k;
+                }
+            }
+            nv[s] = best + pxo_hmm_emission(hmm, s, xt);
+            bp[(size_t)t * S + s] = (int8_t)arg;
+        }
+        memcpy(v, nv, sizeof(double) * S);
+    }
+    int end = order[0];
+    for (int r = 1; r < S; r++)
+        if (v[order[r]] > v[end])
+            end = order[r];
+    const double logp = v[end];
+    int s = end;
+    for (int t = T - 1; t >= 0; t--) {
+        path[t] = s;
+        if (t > 0) {
+            int p = bp[(size_t)t * S + s];
+            s = p < 0 ? s : p;
+        }
+    }
+    free(bp);
+    return logp;
+}
+
+/* a8  signal_analyzer.py:354-362: groupby runs of equal states; dict
+ *     name -> (first, last) right-inclusive; a later run overwrites. */
+void pxo_segments(const int32_t* path, int T, int32_t* seg_first, int32_t* seg_last)
+{
+    for (int s = 0; s < PXG_N_SEGMENTS; s++)
+        seg_first[s] = seg_last[s] = -1;
+    int t = 0;
+    while (t < T) {
+        int e = t;
+        while (e + 1 < T && path[e + 1] == path[t])
+            e++;
+        seg_first[path[t]] = t;
+        seg_last[path[t]] = e;
+        t = e + 1;
+    }
+}
+
+/* ------------------------------------------------------------------------ *
+ * a11 barcoding.py:77-81
+ *     med = np.median(sig)  (float32; even n: fl(fl(a+b)/2))
+ *     mad = np.median(|sig - med|)
+ *     (sig - med) / max(0.01, mad * 1.4826)
+ *       mad*1.4826 is float32-scalar * python-float = float64 (NumPy 1.x);
+ *       max() keeps the double; array / double-scalar casts it to float32.
+ * ------------------------------------------------------------------------ */
+static int cmp_f32(const void* a, const void* b)
+{
+    const float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+
+static float median_f32(const float* v, int n, float* tmp)
+{
+    memcpy(tmp, v, sizeof(float) * n);
+    qsort(tmp, n, sizeof(float), cmp_f32);
+    if (n & 1)
+        return tmp[n / 2];
+    float s = tmp[n / 2 - 1] + tmp[n / 2];
+    return s / 2.0f;
+}
+
+void pxo_normalize_signal(const float* sig, int n, float* out)
+{
+    float* tmp = (float*)malloc(sizeof(float) * (n > 0 ? n : 1));
+    float* dev = (float*)malloc(sizeof(float) * (n > 0 ? n : 1));
+    const float med = median_f32(sig, n, tmp);
+    for (int i = 0; i < n; i++)
+        dev[i] = fabsf(sig[i] - med);
+    const float mad = median_f32(dev, n, tmp);
+    const double dd = fmax(0.01, (double)mad * 1.4826);
+    const float div = (float)dd;
+    for (int i = 0; i < n; i++)
+        out[i] = (sig[i] - med) / div;
+    free(tmp); free(dev);
+}
+
+/* a9+a10  signal_analyzer.py:445-448 + barcoding.py:83-101 */
+int pxo_barcode_window(const pxg_config* cfg, const float* sig, int len, float* out)
+{
+    const int trim = cfg->signal_trim_length;
+    if (len <= 0)                                              /* :447 */
+        return 0;
+    if (!(cfg->minimum_dna_length <= len && len <= cfg->maximum_dna_length))
+        return 0;                                              /* :87-88 */
+    if (len > trim) {
+        pxo_normalize_signal(sig + (len - trim), trim, out);   /* :91-92 */
+    } else if (len < trim) {
+        const int pad = trim - len;                            /* :93-96 */
+        for (int i = 0; i < pad; i++)
+            out[i] = cfg->pad_filler;
+        pxo_normalize_signal(sig, len, out + pad);
+    } else {
+        pxo_normalize_signal(sig, len, out);
+    }
+    return 1;
+}
+
+/* a13 barcoding.py:72-75: bisect_right over the float64 calibration list,
+ *     the float32 score promoted to double for every comparison. */
+int pxo_phred(const pxg_config* cfg, float score)
+{
+    if (score <= 0.0f)
+        return 0;
+    const double x = (double)score;
+    int lo = 0, hi = cfg->n_calibration;
+    while (lo < hi) {
+        int mid = (lo + hi) / 2;
+        if (x < cfg->calibration[mid])
+            hi = mid;
+        else
+            lo = mid + 1;
+    }
+    return lo;
+}
+
+/* a12 tail  barcoding.py:108-118 */
+void pxo_barcode_call(const pxg_config* cfg, const float* probs, pxg_read_result* r)
+{
+    const int C = cfg->demux_dense.out_dim;
+    int arg = 0;
+    for (int j = 1; j < C; j++)
+        if (probs[j] > probs[arg])
+            arg = j;
+    const int label = arg - cfg->number_of_decoy_labels;
+    const float score = probs[arg];
+    for (int j = 0; j < PXG_MAX_CLASSES; j++)
+        r->probs[j] = j < C ? probs[j] : 0.0f;
+    r->bc_label = (int8_t)label;
+    r->bc_score = score;
+    r->bc_called = (label >= 0 && (double)score >= cfg->score_threshold) ? 1 : 0;
+    r->bc_phred = (uint8_t)pxo_phred(cfg, score);
+}

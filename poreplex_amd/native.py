@@ -1,0 +1,569 @@
+"""ctypes binding of the C ABI in include/pxg.h (libpxg.so).
+
+This is the thin host layer north_star asks for: Python marshals arrays, every
+numeric stage runs in HIP behind ``pxg_*``.  The library is built in-tree by
+``__graft_entry__.build()`` (hipcc --offload-arch=gfx950); if it is missing or
+no GPU is usable this module fails LOUDLY -- there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import config as _config
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'csrc', 'libpxg.so')
+
+PXG_ABI_VERSION = 1
+PXG_MAX_STATES = 8
+PXG_MAX_MIXTURE = 4
+PXG_N_SEGMENTS = 8
+PXG_MAX_CLASSES = 8
+PXG_MAX_CALIBRATION = 64
+PXG_MAX_SPIKES = 8
+
+STATUS_NAMES = (
+    'okay', 'disappeared', 'irregular_fast5', 'scaler_signal_too_short',
+    'scaling_qc_fail', 'adapter_not_detected', 'not_basecalled',
+    'basecall_table_incomplete', 'unsplit_read', 'sequence_too_short',
+    'unknown_error')
+STATUS_CODE = {name: i for i, name in enumerate(STATUS_NAMES)}
+
+STAGE_SCALER = 1
+STAGE_SEGMENT = 2
+STAGE_BARCODE = 4
+STAGE_POLYA = 8
+STAGE_ALL_DEMUX = 7
+
+TIMER_NAMES = ('head_pool', 'scaler_lstm', 'segment', 'barcode_window',
+               'demux_bidir', 'demux_top', 'polya', 'finalize', 'total')
+
+
+class PxgError(RuntimeError):
+    pass
+
+
+class PxgCalib(C.Structure):
+    _fields_ = [('range', C.c_double), ('digitisation', C.c_double),
+                ('offset', C.c_double), ('sampling_rate', C.c_double)]
+
+
+class PxgHmm(C.Structure):
+    _fields_ = [
+        ('n_states', C.c_int32), ('adapter_state', C.c_int32),
+        ('polya_state', C.c_int32), ('reserved', C.c_int32),
+        ('name_rank', C.c_int32 * PXG_MAX_STATES),
+        ('n_mix', C.c_int32 * PXG_MAX_STATES),
+        ('start_prob', C.c_double * PXG_MAX_STATES),
+        ('mix_mu', (C.c_double * PXG_MAX_MIXTURE) * PXG_MAX_STATES),
+        ('mix_sigma', (C.c_double * PXG_MAX_MIXTURE) * PXG_MAX_STATES),
+        ('mix_weight', (C.c_double * PXG_MAX_MIXTURE) * PXG_MAX_STATES),
+        ('trans', (C.c_double * PXG_MAX_STATES) * PXG_MAX_STATES),
+    ]
+
+
+class PxgLstmLayer(C.Structure):
+    _fields_ = [('input_dim', C.c_int32), ('units', C.c_int32),
+                ('kernel', C.POINTER(C.c_float)), ('recurrent', C.POINTER(C.c_float)),
+                ('bias', C.POINTER(C.c_float))]
+
+
+class PxgDenseLayer(C.Structure):
+    _fields_ = [('in_dim', C.c_int32), ('out_dim', C.c_int32),
+                ('kernel', C.POINTER(C.c_float)), ('bias', C.POINTER(C.c_float))]
+
+
+class PxgConfig(C.Structure):
+    _fields_ = [
+        ('abi_version', C.c_uint32), ('device_id', C.c_int32),
+        ('stride', C.c_int32), ('scaler_length', C.c_int32),
+        ('scaler_min_length', C.c_int32), ('reserved0', C.c_int32),
+        ('scaler_xfrm', C.c_double * 4),
+        ('scaler_qc_scale', C.c_double * 2), ('scaler_qc_shift', C.c_double * 2),
+        ('scaler_lstm1', PxgLstmLayer), ('scaler_lstm2', PxgLstmLayer),
+        ('scaler_dense', PxgDenseLayer),
+        ('segmentation_scan_limit', C.c_int32), ('reserved1', C.c_int32),
+        ('segmentation_model', PxgHmm), ('unsplit_model', PxgHmm),
+        ('number_of_decoy_labels', C.c_int32), ('number_of_barcodes', C.c_int32),
+        ('minimum_dna_length', C.c_int32), ('maximum_dna_length', C.c_int32),
+        ('signal_trim_length', C.c_int32), ('n_calibration', C.c_int32),
+        ('calibration', C.c_double * PXG_MAX_CALIBRATION),
+        ('score_threshold', C.c_double),
+        ('pad_filler', C.c_float), ('reserved2', C.c_int32),
+        ('demux_fwd', PxgLstmLayer), ('demux_bwd', PxgLstmLayer),
+        ('demux_top', PxgLstmLayer), ('demux_dense', PxgDenseLayer),
+        ('polya_refinement_expansion', C.c_int32), ('polya_openend_expansion', C.c_int32),
+        ('polya_median_pre_filter', C.c_int32),
+        ('polya_maximum_openend_extension', C.c_int32),
+        ('ed_window_length1', C.c_int32), ('ed_window_length2', C.c_int32),
+        ('ed_threshold1', C.c_float), ('ed_threshold2', C.c_float),
+        ('ed_peak_height', C.c_float), ('polya_spike_tolerance', C.c_int32),
+        ('polya_mean_dist', C.c_double * 2), ('polya_mean_z_cutoff', C.c_double),
+        ('polya_stdv_max', C.c_double), ('polya_stdv_range', C.c_double * 2),
+        ('polya_spike_weight', C.c_double),
+        ('polya_mean_trigger_recalibration', C.c_double),
+        ('recal_max_dist_from_adapter', C.c_int32), ('recal_min_length', C.c_int32),
+        ('recal_max_stdv', C.c_double),
+    ]
+
+
+class PxgReadResult(C.Structure):
+    _fields_ = [
+        ('status', C.c_int32), ('n_pooled', C.c_int32),
+        ('seg_first', C.c_int32 * PXG_N_SEGMENTS), ('seg_last', C.c_int32 * PXG_N_SEGMENTS),
+        ('scale', C.c_float), ('shift', C.c_float), ('scaler_pred', C.c_float * 2),
+        ('bc_pushed', C.c_int8), ('bc_called', C.c_int8), ('bc_label', C.c_int8),
+        ('bc_phred', C.c_uint8), ('bc_score', C.c_float),
+        ('probs', C.c_float * PXG_MAX_CLASSES),
+        ('polya_called', C.c_int8), ('polya_n_spikes', C.c_int8), ('reserved', C.c_int16),
+        ('polya_dwell_samples', C.c_int32),
+        ('polya_begin', C.c_int64), ('polya_end', C.c_int64),
+        ('polya_spikes', (C.c_float * 4) * PXG_MAX_SPIKES),
+    ]
+
+
+class PxgEvent(C.Structure):
+    _fields_ = [('start', C.c_uint64), ('length', C.c_float), ('mean', C.c_float),
+                ('stdv', C.c_float), ('pos', C.c_int32), ('state', C.c_int32)]
+
+
+class PxgStageTimes(C.Structure):
+    _fields_ = [('ms', C.c_float * len(TIMER_NAMES)),
+                ('n_launches', C.c_int64 * len(TIMER_NAMES))]
+
+
+class PxgDeviceInfo(C.Structure):
+    _fields_ = [('name', C.c_char * 128), ('arch', C.c_char * 32),
+                ('compute_units', C.c_int32), ('wavefront_size', C.c_int32),
+                ('total_mem', C.c_int64), ('lds_per_cu', C.c_int32),
+                ('clock_khz', C.c_int32)]
+
+
+# numpy views of the POD records (same layout, checked against ctypes sizes)
+RESULT_DTYPE = np.dtype([
+    ('status', '<i4'), ('n_pooled', '<i4'),
+    ('seg_first', '<i4', (PXG_N_SEGMENTS,)), ('seg_last', '<i4', (PXG_N_SEGMENTS,)),
+    ('scale', '<f4'), ('shift', '<f4'), ('scaler_pred', '<f4', (2,)),
+    ('bc_pushed', 'i1'), ('bc_called', 'i1'), ('bc_label', 'i1'), ('bc_phred', 'u1'),
+    ('bc_score', '<f4'), ('probs', '<f4', (PXG_MAX_CLASSES,)),
+    ('polya_called', 'i1'), ('polya_n_spikes', 'i1'), ('reserved', '<i2'),
+    ('polya_dwell_samples', '<i4'), ('polya_begin', '<i8'), ('polya_end', '<i8'),
+    ('polya_spikes', '<f4', (PXG_MAX_SPIKES, 4)),
+], align=True)
+CALIB_DTYPE = np.dtype([('range', '<f8'), ('digitisation', '<f8'),
+                        ('offset', '<f8'), ('sampling_rate', '<f8')])
+EVENT_DTYPE = np.dtype([('start', '<u8'), ('length', '<f4'), ('mean', '<f4'),
+                        ('stdv', '<f4'), ('pos', '<i4'), ('state', '<i4')], align=True)
+assert RESULT_DTYPE.itemsize == C.sizeof(PxgReadResult), \
+    (RESULT_DTYPE.itemsize, C.sizeof(PxgReadResult))
+assert EVENT_DTYPE.itemsize == C.sizeof(PxgEvent)
+assert CALIB_DTYPE.itemsize == C.sizeof(PxgCalib)
+
+
+# --------------------------------------------------------------------------
+# config dict -> pxg_config
+# --------------------------------------------------------------------------
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _fill_hmm(hmm, modeldata):
+    """worker_persistence.py:95-121 load_segmentation_model, as tables."""
+    names = [s['name'] for s in modeldata]
+    if len(names) > PXG_MAX_STATES:
+        raise ValueError('HMM has more than {} states'.format(PXG_MAX_STATES))
+    index = {n: i for i, n in enumerate(names)}
+    hmm.n_states = len(names)
+    hmm.adapter_state = index.get('adapter', -1)
+    hmm.polya_state = index.get('polya-tail', -1)
+    for rank, name in enumerate(sorted(names)):
+        hmm.name_rank[index[name]] = rank
+    for i, s in enumerate(modeldata):
+        em = s['emission']
+        if len(em) > PXG_MAX_MIXTURE:
+            raise ValueError('too many mixture components')
+        hmm.n_mix[i] = len(em)
+        for k, row in enumerate(em):
+            hmm.mix_mu[i][k] = float(row[0])
+            hmm.mix_sigma[i][k] = float(row[1])
+            hmm.mix_weight[i][k] = float(row[2]) if len(row) > 2 else 1.0
+        hmm.start_prob[i] = float(s.get('start_prob', 0.0))
+        for nextstate, prob in s['transition']:
+            hmm.trans[i][index[nextstate]] = float(prob)
+    return names
+
+
+def _lstm(layer, kernel, recurrent, bias, keep):
+    kernel, recurrent, bias = _f32(kernel), _f32(recurrent), _f32(bias)
+    keep += [kernel, recurrent, bias]
+    layer.input_dim = kernel.shape[0]
+    layer.units = recurrent.shape[0]
+    assert kernel.shape[1] == 4 * layer.units == recurrent.shape[1] == bias.shape[0]
+    layer.kernel, layer.recurrent, layer.bias = _fptr(kernel), _fptr(recurrent), _fptr(bias)
+
+
+def _dense(layer, kernel, bias, keep):
+    kernel, bias = _f32(kernel), _f32(bias)
+    keep += [kernel, bias]
+    layer.in_dim, layer.out_dim = kernel.shape
+    layer.kernel, layer.bias = _fptr(kernel), _fptr(bias)
+
+
+class NativeConfig:
+    """pxg_config plus the NumPy arrays its pointers reference."""
+
+    def __init__(self, config, device_id=0):
+        self.keep = []
+        self.struct = cfg = PxgConfig()
+        cfg.abi_version = PXG_ABI_VERSION
+        cfg.device_id = device_id
+
+        sp = config['signal_processing']
+        scaler = _config.load_model_arrays(sp['scaler_model'])
+        cfg.stride = int(sp['rough_signal_stride'])
+        cfg.scaler_length = int(scaler['input_length'])
+        cfg.scaler_min_length = int(scaler['input_min_length'])
+        if int(scaler['input_stride']) != cfg.stride:
+            raise ValueError('scaler stride differs from rough_signal_stride')
+        xfrm = [float(v) for v in scaler['output_transform']]
+        for i, v in enumerate(xfrm):
+            cfg.scaler_xfrm[i] = v
+        q = float(sp['scaler_qc_threshold'])          # signal_loader.py:65-68
+        for i, qq in enumerate((q, 1 - q)):
+            cfg.scaler_qc_scale[i] = _config.norm_ppf(qq, xfrm[0], xfrm[1])
+            cfg.scaler_qc_shift[i] = _config.norm_ppf(qq, xfrm[2], xfrm[3])
+        _lstm(cfg.scaler_lstm1, scaler['lstm1_kernel'], scaler['lstm1_recurrent'],
+              scaler['lstm1_bias'], self.keep)
+        _lstm(cfg.scaler_lstm2, scaler['lstm2_kernel'], scaler['lstm2_recurrent'],
+              scaler['lstm2_bias'], self.keep)
+        _dense(cfg.scaler_dense, scaler['dense_kernel'], scaler['dense_bias'], self.keep)
+
+        cfg.segmentation_scan_limit = int(config['segmentation']['segmentation_scan_limit'])
+        self.state_names = _fill_hmm(cfg.segmentation_model, config['segmentation_model'])
+        self.unsplit_state_names = _fill_hmm(cfg.unsplit_model,
+                                             config['unsplit_read_detection_model'])
+
+        dm = config['demultiplexing']
+        demux = _config.load_model_arrays(dm['demux_model'])
+        cfg.number_of_decoy_labels = int(dm['number_of_decoy_labels'])
+        cfg.number_of_barcodes = int(dm['number_of_barcodes'])
+        cfg.minimum_dna_length = int(dm['minimum_dna_length'])
+        cfg.maximum_dna_length = int(dm['maximum_dna_length'])
+        cfg.signal_trim_length = int(dm['signal_trim_length'])
+        calib = np.asarray(demux['calibration'], dtype=np.float64)
+        if len(calib) > PXG_MAX_CALIBRATION:
+            raise ValueError('calibration table too long')
+        cfg.n_calibration = len(calib)
+        for i, v in enumerate(calib):
+            cfg.calibration[i] = float(v)
+        qfilter = int(config.get('barcoding_quality_filter', 18))
+        if len(calib) - 1 < qfilter:                  # barcoding.py:41-45
+            raise ValueError('The current demultiplexer does not support calibrated score '
+                             'of {}. Consider lowering --barcoding-quality-filter value.'
+                             .format(qfilter))
+        cfg.score_threshold = float(calib[qfilter])
+        cfg.pad_filler = -1000.0                      # barcoding.py:32
+        _lstm(cfg.demux_fwd, demux['fwd_kernel'], demux['fwd_recurrent'],
+              demux['fwd_bias'], self.keep)
+        _lstm(cfg.demux_bwd, demux['bwd_kernel'], demux['bwd_recurrent'],
+              demux['bwd_bias'], self.keep)
+        _lstm(cfg.demux_top, demux['top_kernel'], demux['top_recurrent'],
+              demux['top_bias'], self.keep)
+        _dense(cfg.demux_dense, demux['dense_kernel'], demux['dense_bias'], self.keep)
+        self.calibration = calib
+
+        pa = config['polya_dwell']                    # polya.py:32-48
+        cfg.polya_refinement_expansion = int(pa['refinement_expansion'])
+        cfg.polya_openend_expansion = int(pa['openend_expansion'])
+        cfg.polya_median_pre_filter = int(pa['median_pre_filter'])
+        cfg.polya_maximum_openend_extension = int(pa['maximum_openend_extension'])
+        ed = pa['event_detection']
+        cfg.ed_window_length1 = int(ed['window_length1'])
+        cfg.ed_window_length2 = int(ed['window_length2'])
+        cfg.ed_threshold1 = float(ed['threshold1'])
+        cfg.ed_threshold2 = float(ed['threshold2'])
+        cfg.ed_peak_height = float(ed['peak_height'])
+        cfg.polya_spike_tolerance = int(pa['spike_tolerance'])
+        cfg.polya_mean_dist[0], cfg.polya_mean_dist[1] = map(float, pa['polya_mean_dist'])
+        cfg.polya_mean_z_cutoff = float(pa['polya_mean_z_cutoff'])
+        cfg.polya_stdv_max = float(pa['polya_stdv_max'])
+        cfg.polya_stdv_range[0], cfg.polya_stdv_range[1] = map(float, pa['polya_stdv_range'])
+        cfg.polya_spike_weight = float(pa['spike_weight'])
+        cfg.polya_mean_trigger_recalibration = float(pa['polya_mean_trigger_recalibration'])
+        rc = pa['recalibrate_shifted_signal']
+        cfg.recal_max_dist_from_adapter = int(rc['max_dist_from_adapter'])
+        cfg.recal_min_length = int(rc['min_length'])
+        cfg.recal_max_stdv = float(rc['max_stdv'])
+
+
+# --------------------------------------------------------------------------
+# library loading
+# --------------------------------------------------------------------------
+_lib = None
+
+_SIGNATURES = {
+    'pxg_create': (C.c_int, [C.POINTER(PxgConfig), C.POINTER(C.c_void_p)]),
+    'pxg_destroy': (None, [C.c_void_p]),
+    'pxg_last_error': (C.c_char_p, [C.c_void_p]),
+    'pxg_abi_version': (C.c_int, []),
+    'pxg_get_device_info': (C.c_int, [C.c_void_p, C.POINTER(PxgDeviceInfo)]),
+    'pxg_process_batch': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
+    'pxg_batch_upload': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    'pxg_batch_run': (C.c_int, [C.c_void_p, C.c_uint32]),
+    'pxg_batch_sync': (C.c_int, [C.c_void_p]),
+    'pxg_batch_download': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'pxg_batch_times': (C.c_int, [C.c_void_p, C.POINTER(PxgStageTimes)]),
+    'pxg_batch_synthesize': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64]),
+    'pxg_raw_to_pa': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'pxg_head_pool': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p]),
+    'pxg_scaler_lstm': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'pxg_scaler_transform': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]),
+    'pxg_pool_scale': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]),
+    'pxg_viterbi': (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'pxg_barcode_window': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    'pxg_demux_lstm': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'pxg_detect_events': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.c_int64, C.c_void_p, C.c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load_library(path=None):
+    """Load libpxg.so; raise PxgError (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.isfile(path):
+        raise PxgError(
+            'HIP extension {} is missing: run `python -c "import __graft_entry__ as g; '
+            'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU fallback.'.format(path))
+    lib = C.CDLL(path)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError => ABI mismatch, also loud
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.pxg_abi_version() != PXG_ABI_VERSION:
+        raise PxgError('libpxg.so ABI {} != binding ABI {}'.format(
+            lib.pxg_abi_version(), PXG_ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def pack_reads(signals):
+    """list of int16 arrays -> (arena, offsets[n+1])."""
+    offsets = np.zeros(len(signals) + 1, dtype=np.int64)
+    if signals:
+        offsets[1:] = np.cumsum([len(s) for s in signals])
+    arena = np.empty(int(offsets[-1]), dtype=np.int16)
+    for i, s in enumerate(signals):
+        arena[offsets[i]:offsets[i + 1]] = s
+    return arena, offsets
+
+
+class NativeContext:
+    """One pxg_ctx: models resident on one GPU for the life of a worker
+    (the role of WorkerPersistenceStorage, worker_persistence.py:46-90)."""
+
+    def __init__(self, config, device_id=0):
+        self.lib = load_library()
+        self.ncfg = NativeConfig(config, device_id)
+        self.cfg = self.ncfg.struct
+        self.state_names = self.ncfg.state_names
+        handle = C.c_void_p()
+        rc = self.lib.pxg_create(C.byref(self.cfg), C.byref(handle))
+        if rc != 0:
+            raise PxgError('pxg_create failed ({}): {}'.format(
+                rc, (self.lib.pxg_last_error(None) or b'').decode()))
+        self.handle = handle
+        self.n_resident = 0
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.pxg_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise PxgError('{} failed ({}): {}'.format(
+                what, rc, (self.lib.pxg_last_error(self.handle) or b'').decode()))
+
+    def device_info(self):
+        info = PxgDeviceInfo()
+        self._check(self.lib.pxg_get_device_info(self.handle, C.byref(info)), 'device_info')
+        return {'name': info.name.decode(), 'arch': info.arch.decode(),
+                'compute_units': info.compute_units, 'wavefront_size': info.wavefront_size,
+                'total_mem': info.total_mem, 'lds_per_cu': info.lds_per_cu,
+                'clock_khz': info.clock_khz}
+
+    # ---- whole path ------------------------------------------------------
+    @staticmethod
+    def _prep(arena, offsets, calib, scale_shift):
+        arena = np.ascontiguousarray(arena, dtype=np.int16)
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        calib = np.ascontiguousarray(calib, dtype=CALIB_DTYPE)
+        n = len(offsets) - 1
+        if len(calib) != n:
+            raise ValueError('calib must have one row per read')
+        if scale_shift is not None:
+            scale_shift = np.ascontiguousarray(scale_shift, dtype=np.float32).reshape(n, 2)
+        return arena, offsets, calib, scale_shift, n
+
+    def process_batch(self, arena, offsets, calib, scale_shift=None,
+                      stage_mask=STAGE_ALL_DEMUX):
+        arena, offsets, calib, scale_shift, n = self._prep(arena, offsets, calib, scale_shift)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        self._check(self.lib.pxg_process_batch(
+            self.handle, n, _ptr(arena), _ptr(offsets), _ptr(calib), _ptr(scale_shift),
+            stage_mask, _ptr(out)), 'pxg_process_batch')
+        return out
+
+    def upload(self, arena, offsets, calib, scale_shift=None):
+        arena, offsets, calib, scale_shift, n = self._prep(arena, offsets, calib, scale_shift)
+        self._check(self.lib.pxg_batch_upload(
+            self.handle, n, _ptr(arena), _ptr(offsets), _ptr(calib), _ptr(scale_shift)),
+            'pxg_batch_upload')
+        self.n_resident = n
+
+    def synthesize(self, n_reads, samples_per_read, seed):
+        self._check(self.lib.pxg_batch_synthesize(self.handle, n_reads, samples_per_read,
+                                                  seed), 'pxg_batch_synthesize')
+        self.n_resident = n_reads
+
+    def run(self, stage_mask=STAGE_ALL_DEMUX):
+        self._check(self.lib.pxg_batch_run(self.handle, stage_mask), 'pxg_batch_run')
+
+    def sync(self):
+        self._check(self.lib.pxg_batch_sync(self.handle), 'pxg_batch_sync')
+
+    def download(self):
+        out = np.zeros(self.n_resident, dtype=RESULT_DTYPE)
+        self._check(self.lib.pxg_batch_download(self.handle, _ptr(out)), 'pxg_batch_download')
+        return out
+
+    def stage_times(self):
+        t = PxgStageTimes()
+        self._check(self.lib.pxg_batch_times(self.handle, C.byref(t)), 'pxg_batch_times')
+        return ({name: float(t.ms[i]) for i, name in enumerate(TIMER_NAMES)},
+                {name: int(t.n_launches[i]) for i, name in enumerate(TIMER_NAMES)})
+
+    # ---- stage hooks -----------------------------------------------------
+    def raw_to_pa(self, raw, calib_row):
+        raw = np.ascontiguousarray(raw, dtype=np.int16)
+        cal = np.ascontiguousarray(calib_row, dtype=CALIB_DTYPE).reshape(1)
+        out = np.empty(len(raw), dtype=np.float32)
+        self._check(self.lib.pxg_raw_to_pa(self.handle, len(raw), _ptr(raw), _ptr(cal),
+                                           _ptr(out)), 'pxg_raw_to_pa')
+        return out
+
+    def head_pool(self, arena, offsets, calib):
+        arena, offsets, calib, _, n = self._prep(arena, offsets, calib, None)
+        width = self.cfg.scaler_length // self.cfg.stride
+        out = np.zeros((n, width), dtype=np.float32)
+        status = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.pxg_head_pool(self.handle, n, _ptr(arena), _ptr(offsets),
+                                           _ptr(calib), _ptr(out), _ptr(status)),
+                    'pxg_head_pool')
+        return out, status
+
+    def scaler_lstm(self, head):
+        head = np.ascontiguousarray(head, dtype=np.float32)
+        n = head.shape[0]
+        if head.shape[1] != self.cfg.scaler_length // self.cfg.stride:
+            raise ValueError('head must be n x (scaler_length/stride)')
+        pred = np.zeros((n, 2), dtype=np.float32)
+        self._check(self.lib.pxg_scaler_lstm(self.handle, n, _ptr(head), _ptr(pred)),
+                    'pxg_scaler_lstm')
+        return pred
+
+    def scaler_transform(self, pred):
+        pred = np.ascontiguousarray(pred, dtype=np.float32)
+        n = pred.shape[0]
+        ss = np.zeros((n, 2), dtype=np.float32)
+        status = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.pxg_scaler_transform(self.handle, n, _ptr(pred), _ptr(ss),
+                                                  _ptr(status)), 'pxg_scaler_transform')
+        return ss, status
+
+    def pool_scale(self, arena, offsets, calib, scale_shift):
+        arena, offsets, calib, scale_shift, n = self._prep(arena, offsets, calib, scale_shift)
+        lens = np.diff(offsets) // self.cfg.stride
+        poff = np.zeros(n + 1, dtype=np.int64)
+        poff[1:] = np.cumsum(lens)
+        out = np.zeros(int(poff[-1]), dtype=np.float32)
+        self._check(self.lib.pxg_pool_scale(self.handle, n, _ptr(arena), _ptr(offsets),
+                                            _ptr(calib), _ptr(scale_shift), _ptr(poff),
+                                            _ptr(out)), 'pxg_pool_scale')
+        return out, poff
+
+    def viterbi(self, signals, which_model=0, want_path=False):
+        sigs = [np.ascontiguousarray(s, dtype=np.float32) for s in signals]
+        n = len(sigs)
+        off = np.zeros(n + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(s) for s in sigs])
+        arena = np.concatenate(sigs) if n else np.zeros(0, np.float32)
+        first = np.zeros((n, PXG_N_SEGMENTS), dtype=np.int32)
+        last = np.zeros((n, PXG_N_SEGMENTS), dtype=np.int32)
+        path = np.zeros(int(off[-1]), dtype=np.int32) if want_path else None
+        logp = np.zeros(n, dtype=np.float64)
+        self._check(self.lib.pxg_viterbi(self.handle, which_model, n, _ptr(arena), _ptr(off),
+                                         _ptr(first), _ptr(last), _ptr(path), _ptr(logp)),
+                    'pxg_viterbi')
+        paths = [path[off[i]:off[i + 1]] for i in range(n)] if want_path else None
+        return first, last, paths, logp
+
+    def barcode_window(self, signals):
+        sigs = [np.ascontiguousarray(s, dtype=np.float32) for s in signals]
+        n = len(sigs)
+        off = np.zeros(n + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(s) for s in sigs])
+        arena = np.concatenate(sigs) if n else np.zeros(0, np.float32)
+        out = np.zeros((n, self.cfg.signal_trim_length), dtype=np.float32)
+        pushed = np.zeros(n, dtype=np.int8)
+        self._check(self.lib.pxg_barcode_window(self.handle, n, _ptr(arena), _ptr(off),
+                                                _ptr(out), _ptr(pushed)),
+                    'pxg_barcode_window')
+        return out, pushed
+
+    def demux_lstm(self, win):
+        win = np.ascontiguousarray(win, dtype=np.float32)
+        n = win.shape[0]
+        if win.shape[1] != self.cfg.signal_trim_length:
+            raise ValueError('win must be n x signal_trim_length')
+        probs = np.zeros((n, self.cfg.demux_dense.out_dim), dtype=np.float32)
+        self._check(self.lib.pxg_demux_lstm(self.handle, n, _ptr(win), _ptr(probs)),
+                    'pxg_demux_lstm')
+        return probs
+
+    def detect_events(self, signals, max_events=None):
+        sigs = [np.ascontiguousarray(s, dtype=np.float32) for s in signals]
+        if any(s.ndim != 1 for s in sigs):
+            raise ValueError('Expects an 1-dimensional array.')   # csupport.c:97-101
+        n = len(sigs)
+        off = np.zeros(n + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(s) for s in sigs])
+        arena = np.concatenate(sigs) if n else np.zeros(0, np.float32)
+        cap = int(max_events or (max(len(s) for s in sigs) // 4 + 2))
+        ev = np.zeros((n, cap), dtype=EVENT_DTYPE)
+        cnt = np.zeros(n, dtype=np.int64)
+        self._check(self.lib.pxg_detect_events(self.handle, n, _ptr(arena), _ptr(off), cap,
+                                               _ptr(ev), _ptr(cnt)), 'pxg_detect_events')
+        return [ev[i, :min(cnt[i], cap)] for i in range(n)], cnt
