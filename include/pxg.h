@@ -32,7 +32,7 @@ extern "C" {
 #define PXG_N_SEGMENTS      8   /* seg_first/seg_last slots (= PXG_MAX_STATES)     */
 #define PXG_MAX_CLASSES     8   /* softmax width (reference: 1 decoy + 4 barcodes) */
 #define PXG_MAX_CALIBRATION 64  /* phred calibration table rows (reference: 29)    */
-#define PXG_MAX_SPIKES      8   /* poly(A) spike records kept per read             */
+#define PXG_MAX_SPIKES      64  /* poly(A) spike records kept per read             */
 
 /* ---- error codes (function return values) -------------------------------- */
 enum pxg_error {

@@ -21,7 +21,7 @@ PXG_MAX_MIXTURE = 4
 PXG_N_SEGMENTS = 8
 PXG_MAX_CLASSES = 8
 PXG_MAX_CALIBRATION = 64
-PXG_MAX_SPIKES = 8
+PXG_MAX_SPIKES = 64
 
 STATUS_NAMES = (
     'okay', 'disappeared', 'irregular_fast5', 'scaler_signal_too_short',

@@ -1,0 +1,57 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
+
+
+@pytest.fixture(scope='session')
+def config():
+    from poreplex_amd.config import default_config
+    return default_config()
+
+
+@pytest.fixture(scope='session')
+def oracle(config):
+    from oracle.pxo import Oracle
+    return Oracle(config)
+
+
+@pytest.fixture(scope='session')
+def bundle():
+    return dict(np.load(os.path.join(GOLDEN, 'batch0.pxr.npz')))
+
+
+@pytest.fixture(scope='session')
+def stages():
+    return dict(np.load(os.path.join(GOLDEN, 'batch0.stages.npz')))
+
+
+@pytest.fixture(scope='session')
+def unit():
+    return dict(np.load(os.path.join(GOLDEN, 'unit.npz')))
+
+
+@pytest.fixture(scope='session')
+def ref_results():
+    with open(os.path.join(GOLDEN, 'batch0.results.json')) as fh:
+        return json.load(fh)
+
+
+@pytest.fixture(scope='session')
+def ctx(config):
+    """One GPU context for the whole -m gpu session (fails loudly, no fallback)."""
+    from poreplex_amd.native import NativeContext
+    c = NativeContext(config, device_id=0)
+    yield c
+    c.close()
