@@ -198,8 +198,14 @@ typedef struct {
     int16_t reserved;
     int32_t polya_dwell_samples;          /* sum of poly(A)-event lengths        */
     int64_t polya_begin, polya_end;       /* raw-sample coordinates              */
-    float polya_spikes[PXG_MAX_SPIKES][4];/* (length, mean-1, mean, mean+1)      */
 } pxg_read_result;
+
+/* poly(A) spike detail, kept OUT of the gathered record: one row per spike,
+ * (length, mean of the event before, of the spike, of the event after) --
+ * polya.py:111-114.  Arrays of PXG_MAX_SPIKES rows per read. */
+typedef struct {
+    float v[4];
+} pxg_polya_spike;
 
 /* scrappie event record (src/contrib/scrappie/scrappie_structures.h:8-15,
  * as exported by src/csupport.c:156-159). */
@@ -255,6 +261,8 @@ int pxg_batch_upload(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
 int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask);
 int pxg_batch_sync(pxg_ctx* ctx);
 int pxg_batch_download(pxg_ctx* ctx, pxg_read_result* out);
+/* n_reads x PXG_MAX_SPIKES spike rows of the last run (poly(A) stage only) */
+int pxg_batch_download_spikes(pxg_ctx* ctx, pxg_polya_spike* out);
 int pxg_batch_times(pxg_ctx* ctx, pxg_stage_times* out);
 /* Fill the resident batch on the device from a seed (bench configs that are
  * too large to stage through the host). */

@@ -65,10 +65,10 @@ def lib():
             'pxo_barcode_call': (None, [cfgp, vp, vp]),
             'pxo_detect_events': (i64, [vp, i64, i64, i64, f32, f32, f32, vp, i64]),
             'pxo_medfilt': (None, [vp, i64, i32, vp]),
-            'pxo_polya': (None, [cfgp, vp, i64, i32, i32, f64, vp]),
+            'pxo_polya': (None, [cfgp, vp, i64, i32, i32, f64, vp, vp]),
             'pxo_best_polya_interval': (i32, [cfgp, vp, vp, i32, vp, vp]),
-            'pxo_process_read': (None, [cfgp, vp, i64, vp, vp, C.c_uint32, vp]),
-            'pxo_process_batch': (None, [cfgp, i64, vp, vp, vp, vp, C.c_uint32, vp]),
+            'pxo_process_read': (None, [cfgp, vp, i64, vp, vp, C.c_uint32, vp, vp]),
+            'pxo_process_batch': (None, [cfgp, i64, vp, vp, vp, vp, C.c_uint32, vp, vp]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(_lib, name)
@@ -228,14 +228,15 @@ class Oracle:
     def polya(self, scaled_full, rough_begin, rough_end, sampling_rate):
         x = np.ascontiguousarray(scaled_full, dtype=np.float32)
         r = np.zeros(1, dtype=N.RESULT_DTYPE)
+        sp = np.zeros((N.PXG_MAX_SPIKES, 4), dtype=np.float32)
         self.L.pxo_polya(C.byref(self.cfg), _p(x), len(x), int(rough_begin),
                          -1 if rough_end is None else int(rough_end),
-                         float(sampling_rate), _p(r))
-        return r[0]
+                         float(sampling_rate), _p(r), _p(sp))
+        return r[0], sp
 
     # ---- whole path ------------------------------------------------------
     def process_batch(self, arena, offsets, calib, scale_shift=None,
-                      stage_mask=N.STAGE_ALL_DEMUX):
+                      stage_mask=N.STAGE_ALL_DEMUX, want_spikes=False):
         arena = np.ascontiguousarray(arena, dtype=np.int16)
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         calib = np.ascontiguousarray(calib, dtype=N.CALIB_DTYPE)
@@ -243,9 +244,10 @@ class Oracle:
         if scale_shift is not None:
             scale_shift = np.ascontiguousarray(scale_shift, dtype=np.float32).reshape(n, 2)
         out = np.zeros(n, dtype=N.RESULT_DTYPE)
+        spikes = np.zeros((n, N.PXG_MAX_SPIKES, 4), dtype=np.float32) if want_spikes else None
         self.L.pxo_process_batch(C.byref(self.cfg), n, _p(arena), _p(offsets), _p(calib),
-                                 _p(scale_shift), stage_mask, _p(out))
-        return out
+                                 _p(scale_shift), stage_mask, _p(out), _p(spikes))
+        return (out, spikes) if want_spikes else out
 
 
 def reference_detect_events(sig, w1=7, w2=20, t1=3.0, t2=8.0, ph=4.0):

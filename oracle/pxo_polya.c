@@ -227,6 +227,7 @@ typedef struct {
     int64_t n_full;
     double sampling_rate;
     pxg_read_result* r;
+    pxg_polya_spike* spikes;
 } polya_ctx;
 
 typedef struct {
@@ -337,11 +338,11 @@ static void call_polya(polya_ctx* C, polya_win* W, int64_t sig_begin, int64_t si
             if (W->is_polya[k]) {
                 pl[np_++] = len[k];
             } else {
-                if (ns < PXG_MAX_SPIKES) {
-                    r->polya_spikes[ns][0] = len[k];
-                    r->polya_spikes[ns][1] = k - 1 >= pi ? W->ev[k - 1].mean : NAN;
-                    r->polya_spikes[ns][2] = W->ev[k].mean;
-                    r->polya_spikes[ns][3] = k + 1 <= pj ? W->ev[k + 1].mean : NAN;
+                if (ns < PXG_MAX_SPIKES && C->spikes) {
+                    C->spikes[ns].v[0] = len[k];
+                    C->spikes[ns].v[1] = k - 1 >= pi ? W->ev[k - 1].mean : NAN;
+                    C->spikes[ns].v[2] = W->ev[k].mean;
+                    C->spikes[ns].v[3] = k + 1 <= pj ? W->ev[k + 1].mean : NAN;
                 }
                 ns++;
             }
@@ -450,14 +451,14 @@ static void polya_entry(polya_ctx* C, int rough_begin, int rough_end, int has_en
 
 void pxo_polya(const pxg_config* cfg, const float* scaled_full, int64_t n_raw,
                int rough_begin, int rough_end_or_neg, double sampling_rate,
-               pxg_read_result* r)
+               pxg_read_result* r, pxg_polya_spike* spikes)
 {
-    polya_ctx C = { cfg, scaled_full, n_raw, sampling_rate, r };
+    polya_ctx C = { cfg, scaled_full, n_raw, sampling_rate, r, spikes };
     r->polya_called = 0;
     r->polya_n_spikes = 0;
     r->polya_begin = r->polya_end = 0;
     r->polya_dwell_samples = 0;
-    memset(r->polya_spikes, 0, sizeof(r->polya_spikes));
+    if (spikes) memset(spikes, 0, sizeof(pxg_polya_spike) * PXG_MAX_SPIKES);
     polya_entry(&C, rough_begin, rough_end_or_neg < 0 ? 0 : rough_end_or_neg,
                 rough_end_or_neg >= 0, 0, 0.0, 0.0, 0);
 }

@@ -1,0 +1,609 @@
+// k_lstm.hip -- K2/K5: the two recurrent networks on fp32 MFMA (gfx950).
+//   K2  scaler  LSTM(48,seq) -> LSTM(48) -> Dense(2)          a4  (signal_loader.py:96-97)
+//   K5a demux   Bidirectional(LSTMCell 48) over 300 steps      a12 (barcoding.py:106-107)
+//   K5b demux   LSTMCell(64) -> Dense(5) -> softmax            a12
+//
+// Why this shape (DESIGN.md "LSTM kernels"): per read the nets cost 148 MFLOP
+// of strictly sequential small GEMMs, so the bound is fp32 matrix throughput
+// and step latency, not HBM.  A workgroup owns 16*MTB reads for the whole
+// sequence.  Gate columns are split over waves so every wave keeps ITS weight
+// slice in VGPRs for all 2000 steps (B operand of v_mfma_f32_16x16x4_f32, one
+// VGPR per 4x16 block); hidden states are exchanged through LDS once per step
+// (A operand, read as 3-4 ds_read_b128 per tile thanks to a k-major row
+// layout); c-state never leaves registers.  Layer 2 of the scaler runs one step
+// behind layer 1 inside the same step, so both matmuls share the A fragments.
+//
+// Canonical arithmetic (bit-exact with oracle/pxo_core.c lstm_step): the MFMA
+// is a k-ordered fmaf chain, accumulator start = fl(fl(x*W)+b) (scalar input)
+// or b, chain over input rows then recurrent rows; gates via pxg_expf and IEEE
+// division; c' = fl(fl(f*c)+fl(i*g)); h = fl(o*tanh(c')).
+//
+// Tile geometry: an N-tile is 16 gate columns = 4 units x 4 gates
+// (col = unit_local*4 + gate), so after the MFMA the four gates of one
+// (read, unit) sit in one lane quad; a 4x4 quad transpose (8 DPP moves) then
+// gives every lane one complete (read, unit) cell to update.
+#include "pxg_common.h"
+
+#define LSTM_THREADS 512
+#define XCH 64          // scaler: steps of x staged per LDS refill
+#define XS (XCH + 4)    // padded row stride (floats)
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// quad-lane exchange via DPP quad_perm (no LDS)
+__device__ __forceinline__ float quad_xor1(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float quad_xor2(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+}
+
+// k-major position of unit u inside a hidden-state row of H floats: lane
+// (row, k) of an A fragment then reads H/4 consecutive floats.
+template <int H>
+__device__ __forceinline__ int hpos(int u)
+{
+    return (u & 3) * (H / 4) + (u >> 2);
+}
+
+// Gate activations + cell update for one 16x16 gate tile.
+//   acc[r]: pre-activation of gate (lane&3) of unit ((lane>>2)&3) for row
+//           (lane>>4)*4 + r.   Returns h for row (lane>>4)*4 + (lane&3).
+__device__ __forceinline__ float cell_update(f32x4 acc, float& c, int lane)
+{
+    const int g = lane & 3;
+    const bool is_tanh = (g == 2);
+    const float sc = is_tanh ? 2.0f : 1.0f;
+    float a[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float z = acc[r] * sc;
+        const float s = 1.0f / (1.0f + pxg_expf(-z));
+        const float t2 = 2.0f * s - 1.0f;
+        a[r] = is_tanh ? t2 : s;
+    }
+    // 4x4 transpose inside the lane quad: afterwards a[j] = gate j of row g
+    const bool b1 = (g & 2) != 0, b0 = (g & 1) != 0;
+#pragma unroll
+    for (int r0 = 0; r0 < 2; r0++) {
+        const float lo = a[r0], hi = a[2 + r0];
+        const float recv = quad_xor2(b1 ? lo : hi);
+        a[r0] = b1 ? recv : lo;
+        a[2 + r0] = b1 ? hi : recv;
+    }
+#pragma unroll
+    for (int r1 = 0; r1 < 2; r1++) {
+        const float ev = a[2 * r1], od = a[2 * r1 + 1];
+        const float recv = quad_xor1(b0 ? ev : od);
+        a[2 * r1] = b0 ? recv : ev;
+        a[2 * r1 + 1] = b0 ? od : recv;
+    }
+    const float fc = a[1] * c;
+    const float ig = a[0] * a[2];
+    const float cn = fc + ig;
+    c = cn;
+    return a[3] * pxg_tanh(cn);
+}
+
+// Load the B fragments (weights) of one gate tile: rows [row0, row0+4*KB) of a
+// Keras [rows, 4H] matrix, columns = 4 units x 4 gates of this tile.
+template <int H, int KB>
+__device__ __forceinline__ void load_wfrag(float (&w)[KB], const float* __restrict__ mat,
+                                           int row0, int unit0, int lane)
+{
+    const int k = lane >> 4, j = lane & 15;
+    const int col = (j & 3) * H + unit0 + (j >> 2);
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) w[kb] = mat[(size_t)(row0 + kb * 4 + k) * (4 * H) + col];
+}
+
+// Load the A fragments of one 16-row tile: hidden row (lane&15), k = lane>>4.
+template <int H>
+__device__ __forceinline__ void load_afrag(float (&a)[H / 4], const float* hrow_base, int lane)
+{
+    const float* p = hrow_base + (lane & 15) * H + (lane >> 4) * (H / 4);
+#pragma unroll
+    for (int q = 0; q < H / 16; q++) {
+        const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
+        a[4 * q + 0] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+    }
+}
+
+// ===========================================================================
+// K2: scaler.  block = 8 waves: slice = wave&3 owns units [12*slice, +12) of
+// BOTH layers; parity = wave>>2 picks the M-tiles {parity, parity+2}.
+// ===========================================================================
+template <int MTW>
+__global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
+    int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count,
+    int mtb, int T, const float* __restrict__ head, const float* __restrict__ W1,
+    const float* __restrict__ U1, const float* __restrict__ b1, const float* __restrict__ W2,
+    const float* __restrict__ U2, const float* __restrict__ b2, const float* __restrict__ Wd,
+    const float* __restrict__ bd, float* __restrict__ pred)
+{
+    constexpr int H = 48, NT = 3, KB = 12;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lim = count ? min(*count, n_rows) : n_rows;
+    const int row_base = blockIdx.x * 16 * mtb;
+    if (row_base >= lim) return;
+
+    float* h1 = smem;                                  // [2][mtb][16][H]
+    float* h2 = h1 + 2 * mtb * 16 * H;                 // [2][mtb][16][H]
+    float* xb = h2 + 2 * mtb * 16 * H;                 // [16*mtb][XS]
+    int* ridx = reinterpret_cast<int*>(xb + 16 * mtb * XS);   // [16*mtb]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slice = wave & 3, par = wave >> 2;
+    const int R = lane >> 4, q = lane & 3, ul = (lane >> 2) & 3;
+
+    for (int i = tid; i < 4 * mtb * 16 * H; i += LSTM_THREADS) smem[i] = 0.0f;
+    for (int i = tid; i < 16 * mtb; i += LSTM_THREADS) {
+        const int row = row_base + i;
+        ridx[i] = row < lim ? (idx ? idx[row] : row) : -1;
+    }
+
+    // ---- this wave's weight slice -> registers ------------------------------
+    float wA[NT][KB], wB[NT][2 * KB], bias1[NT], bias2[NT], wx[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int unit0 = slice * 12 + nt * 4;
+        load_wfrag<H, KB>(wA[nt], U1, 0, unit0, lane);
+        float tmp[KB];
+        load_wfrag<H, KB>(tmp, W2, 0, unit0, lane);
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++) wB[nt][kb] = tmp[kb];
+        load_wfrag<H, KB>(tmp, U2, 0, unit0, lane);
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++) wB[nt][KB + kb] = tmp[kb];
+        const int col = (lane & 3) * H + unit0 + ((lane & 15) >> 2);
+        bias1[nt] = b1[col];
+        bias2[nt] = b2[col];
+        wx[nt] = W1[col];
+    }
+    float c1[MTW][NT], c2[MTW][NT];
+#pragma unroll
+    for (int m = 0; m < MTW; m++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) c1[m][nt] = c2[m][nt] = 0.0f;
+    __syncthreads();
+
+    for (int t = 0; t <= T; t++) {
+        if ((t % XCH) == 0 && t < T) {        // refill the x tile (rows x XCH steps)
+            __syncthreads();
+            for (int i = tid; i < 16 * mtb * (XCH / 4); i += LSTM_THREADS) {
+                const int row = i / (XCH / 4), c4 = i % (XCH / 4);
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int rd = ridx[row];
+                if (rd >= 0 && t + c4 * 4 < T)
+                    v = *reinterpret_cast<const float4*>(head + (size_t)rd * T + t + c4 * 4);
+                *reinterpret_cast<float4*>(xb + row * XS + c4 * 4) = v;
+            }
+            __syncthreads();
+        }
+        const int rdb = t & 1, wrb = (t + 1) & 1;
+#pragma unroll
+        for (int m = 0; m < MTW; m++) {
+            const int mt = 2 * m + par;
+            if (mt < mtb) {
+                float a1[KB], a2[KB];
+                load_afrag<H>(a1, h1 + (rdb * mtb + mt) * 16 * H, lane);
+                load_afrag<H>(a2, h2 + (rdb * mtb + mt) * 16 * H, lane);
+                f32x4 acc1[NT], acc2[NT];
+                float xr[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) xr[r] = xb[(mt * 16 + R * 4 + r) * XS + (t % XCH)];
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float xw = xr[r] * wx[nt];
+                        acc1[nt][r] = xw + bias1[nt];
+                        acc2[nt][r] = bias2[nt];
+                    }
+                }
+#pragma unroll
+                for (int kb = 0; kb < KB; kb++) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {
+                        acc1[nt] = mfma4(a1[kb], wA[nt][kb], acc1[nt]);
+                        acc2[nt] = mfma4(a1[kb], wB[nt][kb], acc2[nt]);
+                    }
+                }
+#pragma unroll
+                for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++)
+                        acc2[nt] = mfma4(a2[kb], wB[nt][KB + kb], acc2[nt]);
+                if (t < T) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {
+                        const float h = cell_update(acc1[nt], c1[m][nt], lane);
+                        h1[((wrb * mtb + mt) * 16 + R * 4 + q) * H + hpos<H>(slice * 12 + nt * 4 + ul)] = h;
+                    }
+                }
+                if (t >= 1) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {
+                        const float h = cell_update(acc2[nt], c2[m][nt], lane);
+                        h2[((wrb * mtb + mt) * 16 + R * 4 + q) * H + hpos<H>(slice * 12 + nt * 4 + ul)] = h;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- Dense(2): chain over k = 0..47 from the bias ----------------------
+    const int fin = (T + 1) & 1;
+    for (int i = tid; i < 16 * mtb * 2; i += LSTM_THREADS) {
+        const int row = i >> 1, j = i & 1;
+        const int rd = ridx[row];
+        if (rd < 0) continue;
+        const float* hr = h2 + ((fin * mtb + (row >> 4)) * 16 + (row & 15)) * H;
+        float acc = bd[j];
+        for (int k = 0; k < H; k++) acc = __builtin_fmaf(hr[hpos<H>(k)], Wd[k * 2 + j], acc);
+        pred[(size_t)rd * 2 + j] = acc;
+    }
+}
+
+// ===========================================================================
+// K5a: demux bidirectional layer.  Same slicing as K2; the two "cells" are the
+// forward net at step t and the backward net at step T-1-t.  Every step's
+// hidden rows are streamed to HBM (k-major layout) for K5b.
+// ===========================================================================
+template <int MTW>
+__global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
+    int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int mtb,
+    int T, const float* __restrict__ win, const float* __restrict__ Wf,
+    const float* __restrict__ Uf, const float* __restrict__ bf, const float* __restrict__ Wb,
+    const float* __restrict__ Ub, const float* __restrict__ bb, float* __restrict__ bidir)
+{
+    constexpr int H = 48, NT = 3, KB = 12;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lim = count ? min(*count, n_rows) : n_rows;
+    const int row_base = blockIdx.x * 16 * mtb;
+    if (row_base >= lim) return;
+    const int TS = T + 4;                               // padded x row stride
+
+    float* hf = smem;                                  // [2][mtb][16][H]
+    float* hb = hf + 2 * mtb * 16 * H;
+    float* xb = hb + 2 * mtb * 16 * H;                 // [16*mtb][TS]
+    int* ridx = reinterpret_cast<int*>(xb + 16 * mtb * TS);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slice = wave & 3, par = wave >> 2;
+    const int R = lane >> 4, q = lane & 3, ul = (lane >> 2) & 3;
+
+    for (int i = tid; i < 4 * mtb * 16 * H; i += LSTM_THREADS) smem[i] = 0.0f;
+    for (int i = tid; i < 16 * mtb; i += LSTM_THREADS) {
+        const int row = row_base + i;
+        ridx[i] = row < lim ? (idx ? idx[row] : row) : -1;
+    }
+    __syncthreads();
+    for (int i = tid; i < 16 * mtb * T; i += LSTM_THREADS) {
+        const int row = i / T, tt = i % T;
+        const int rd = ridx[row];
+        xb[row * TS + tt] = rd >= 0 ? win[(size_t)rd * T + tt] : 0.0f;
+    }
+
+    float wF[NT][KB], wBk[NT][KB], biasf[NT], biasb[NT], wxf[NT], wxb[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int unit0 = slice * 12 + nt * 4;
+        load_wfrag<H, KB>(wF[nt], Uf, 0, unit0, lane);
+        load_wfrag<H, KB>(wBk[nt], Ub, 0, unit0, lane);
+        const int col = (lane & 3) * H + unit0 + ((lane & 15) >> 2);
+        biasf[nt] = bf[col];
+        biasb[nt] = bb[col];
+        wxf[nt] = Wf[col];
+        wxb[nt] = Wb[col];
+    }
+    float cf[MTW][NT], cb[MTW][NT];
+#pragma unroll
+    for (int m = 0; m < MTW; m++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) cf[m][nt] = cb[m][nt] = 0.0f;
+    __syncthreads();
+
+    for (int t = 0; t <= T; t++) {
+        const int rdb = t & 1, wrb = (t + 1) & 1;
+        // stream the rows written in the previous step to HBM
+        if (t >= 1) {
+            const int tf = t - 1, tb = T - t;
+            for (int i = tid; i < 16 * mtb * 2 * (H / 4); i += LSTM_THREADS) {
+                const int c4 = i % (H / 4);
+                const int dir = (i / (H / 4)) & 1;
+                const int row = i / (2 * (H / 4));
+                const int rd = ridx[row];
+                if (rd < 0) continue;
+                const float* src = (dir ? hb : hf) + ((rdb * mtb + (row >> 4)) * 16 + (row & 15)) * H + c4 * 4;
+                float* dst = bidir + ((size_t)rd * T + (dir ? tb : tf)) * (2 * H) + dir * H + c4 * 4;
+                *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+            }
+        }
+        if (t == T) break;
+#pragma unroll
+        for (int m = 0; m < MTW; m++) {
+            const int mt = 2 * m + par;
+            if (mt < mtb) {
+                float a1[KB], a2[KB];
+                load_afrag<H>(a1, hf + (rdb * mtb + mt) * 16 * H, lane);
+                load_afrag<H>(a2, hb + (rdb * mtb + mt) * 16 * H, lane);
+                f32x4 acc1[NT], acc2[NT];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float xf = xb[(mt * 16 + R * 4 + r) * TS + t];
+                    const float xr = xb[(mt * 16 + R * 4 + r) * TS + (T - 1 - t)];
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {
+                        const float p1 = xf * wxf[nt];
+                        acc1[nt][r] = p1 + biasf[nt];
+                        const float p2 = xr * wxb[nt];
+                        acc2[nt][r] = p2 + biasb[nt];
+                    }
+                }
+#pragma unroll
+                for (int kb = 0; kb < KB; kb++) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {
+                        acc1[nt] = mfma4(a1[kb], wF[nt][kb], acc1[nt]);
+                        acc2[nt] = mfma4(a2[kb], wBk[nt][kb], acc2[nt]);
+                    }
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    const int hp = ((wrb * mtb + mt) * 16 + R * 4 + q) * H + hpos<H>(slice * 12 + nt * 4 + ul);
+                    hf[hp] = cell_update(acc1[nt], cf[m][nt], lane);
+                    hb[hp] = cell_update(acc2[nt], cb[m][nt], lane);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ===========================================================================
+// K5b: demux top cell (H=64, input 96) + Dense(5) + softmax.  8 slices of 8
+// units (2 gate tiles each); every wave walks all M-tiles of the block.
+// ===========================================================================
+__global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
+    int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int mtb,
+    int T, const float* __restrict__ bidir, const float* __restrict__ W3,
+    const float* __restrict__ U3, const float* __restrict__ b3, const float* __restrict__ Wd,
+    const float* __restrict__ bd, int n_classes, float* __restrict__ probs)
+{
+    constexpr int H = 64, HI = 48, NT = 2, KBI = 24, KBR = 16, MAXMT = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lim = count ? min(*count, n_rows) : n_rows;
+    const int row_base = blockIdx.x * 16 * mtb;
+    if (row_base >= lim) return;
+
+    float* h3 = smem;                                  // [2][mtb][16][H]
+    float* inb = h3 + 2 * mtb * 16 * H;                // [2][mtb*16][2*HI]
+    int* ridx = reinterpret_cast<int*>(inb + 2 * mtb * 16 * 2 * HI);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slice = wave;                             // 8 units per slice
+    const int R = lane >> 4, q = lane & 3, ul = (lane >> 2) & 3;
+
+    for (int i = tid; i < 2 * mtb * 16 * H; i += LSTM_THREADS) smem[i] = 0.0f;
+    for (int i = tid; i < 16 * mtb; i += LSTM_THREADS) {
+        const int row = row_base + i;
+        ridx[i] = row < lim ? (idx ? idx[row] : row) : -1;
+    }
+    float wI[NT][KBI], wR[NT][KBR], bias[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int unit0 = slice * 8 + nt * 4;
+        load_wfrag<H, KBI>(wI[nt], W3, 0, unit0, lane);
+        load_wfrag<H, KBR>(wR[nt], U3, 0, unit0, lane);
+        bias[nt] = b3[(lane & 3) * H + unit0 + ((lane & 15) >> 2)];
+    }
+    float c3[MAXMT][NT];
+#pragma unroll
+    for (int m = 0; m < MAXMT; m++)
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) c3[m][nt] = 0.0f;
+    __syncthreads();
+
+    // input rows of step 0 -> inb[0]
+    const int n_f4 = 16 * mtb * (2 * HI / 4);
+    for (int i = tid; i < n_f4; i += LSTM_THREADS) {
+        const int row = i / (2 * HI / 4), c4 = i % (2 * HI / 4);
+        const int rd = ridx[row];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rd >= 0) v = *reinterpret_cast<const float4*>(bidir + ((size_t)rd * T) * (2 * HI) + c4 * 4);
+        *reinterpret_cast<float4*>(inb + row * (2 * HI) + c4 * 4) = v;
+    }
+    __syncthreads();
+
+    for (int t = 0; t < T; t++) {
+        const int rdb = t & 1, wrb = (t + 1) & 1;
+        // prefetch next step's input rows into registers
+        float4 pf[3];
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const int i = tid + p * LSTM_THREADS;
+            pf[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < n_f4 && t + 1 < T) {
+                const int row = i / (2 * HI / 4), c4 = i % (2 * HI / 4);
+                const int rd = ridx[row];
+                if (rd >= 0)
+                    pf[p] = *reinterpret_cast<const float4*>(
+                        bidir + ((size_t)rd * T + t + 1) * (2 * HI) + c4 * 4);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MAXMT; mt++) {
+            if (mt < mtb) {
+                f32x4 acc[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[nt][r] = bias[nt];
+                const float* irow = inb + (rdb * mtb * 16 + mt * 16) * (2 * HI);
+                {
+                    // forward half then backward half: rows of 96 floats
+                    float a[HI / 4];
+                    const float* p = irow + (lane & 15) * (2 * HI) + (lane >> 4) * (HI / 4);
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+#pragma unroll
+                        for (int v4 = 0; v4 < HI / 16; v4++) {
+                            const float4 v = *reinterpret_cast<const float4*>(p + half * HI + 4 * v4);
+                            a[4 * v4] = v.x; a[4 * v4 + 1] = v.y; a[4 * v4 + 2] = v.z; a[4 * v4 + 3] = v.w;
+                        }
+#pragma unroll
+                        for (int kb = 0; kb < HI / 4; kb++)
+#pragma unroll
+                            for (int nt = 0; nt < NT; nt++)
+                                acc[nt] = mfma4(a[kb], wI[nt][half * (HI / 4) + kb], acc[nt]);
+                    }
+                }
+                {
+                    float a[KBR];
+                    load_afrag<H>(a, h3 + (rdb * mtb + mt) * 16 * H, lane);
+#pragma unroll
+                    for (int kb = 0; kb < KBR; kb++)
+#pragma unroll
+                        for (int nt = 0; nt < NT; nt++) acc[nt] = mfma4(a[kb], wR[nt][kb], acc[nt]);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    const float h = cell_update(acc[nt], c3[mt][nt], lane);
+                    h3[((wrb * mtb + mt) * 16 + R * 4 + q) * H + hpos<H>(slice * 8 + nt * 4 + ul)] = h;
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const int i = tid + p * LSTM_THREADS;
+            if (i < n_f4) {
+                const int row = i / (2 * HI / 4), c4 = i % (2 * HI / 4);
+                *reinterpret_cast<float4*>(inb + (wrb * mtb * 16 + row) * (2 * HI) + c4 * 4) = pf[p];
+            }
+        }
+        __syncthreads();
+    }
+    // ---- Dense(n_classes) + softmax ----------------------------------------
+    const int fin = T & 1;
+    for (int row = tid; row < 16 * mtb; row += LSTM_THREADS) {
+        const int rd = ridx[row];
+        if (rd < 0) continue;
+        const float* hr = h3 + ((fin * mtb + (row >> 4)) * 16 + (row & 15)) * H;
+        float z[PXG_MAX_CLASSES], e[PXG_MAX_CLASSES];
+        for (int j = 0; j < n_classes; j++) {
+            float acc = bd[j];
+            for (int k = 0; k < H; k++) acc = __builtin_fmaf(hr[hpos<H>(k)], Wd[k * n_classes + j], acc);
+            z[j] = acc;
+        }
+        float m = z[0];
+        for (int j = 1; j < n_classes; j++) m = z[j] > m ? z[j] : m;
+        float s = 0.0f;
+        for (int j = 0; j < n_classes; j++) {
+            e[j] = pxg_expf(z[j] - m);
+            s = (j == 0) ? e[0] : s + e[j];
+        }
+        for (int j = 0; j < PXG_MAX_CLASSES; j++)
+            probs[(size_t)rd * PXG_MAX_CLASSES + j] = j < n_classes ? e[j] / s : 0.0f;
+    }
+}
+
+// ===========================================================================
+// launchers
+// ===========================================================================
+static int pick_mtb(pxg_ctx* ctx, int64_t n_rows)
+{
+    const int64_t tiles = (n_rows + 15) / 16;
+    int64_t mtb = (tiles + ctx->n_cu - 1) / ctx->n_cu;
+    if (mtb < 1) mtb = 1;
+    if (mtb > 4) mtb = 4;
+    return (int)mtb;
+}
+
+int pxg_lstm_upload(pxg_ctx* ctx)
+{
+    const pxg_config& c = ctx->cfg;
+    const bool ok = c.scaler_lstm1.input_dim == 1 && c.scaler_lstm1.units == 48 &&
+                    c.scaler_lstm2.input_dim == 48 && c.scaler_lstm2.units == 48 &&
+                    c.scaler_dense.in_dim == 48 && c.scaler_dense.out_dim == 2 &&
+                    c.demux_fwd.input_dim == 1 && c.demux_fwd.units == 48 &&
+                    c.demux_bwd.input_dim == 1 && c.demux_bwd.units == 48 &&
+                    c.demux_top.input_dim == 96 && c.demux_top.units == 64 &&
+                    c.demux_dense.in_dim == 64 && c.demux_dense.out_dim <= PXG_MAX_CLASSES &&
+                    c.signal_trim_length <= 508 && (c.scaler_length / c.stride) % 4 == 0;
+    if (!ok) {
+        ctx->err = "LSTM kernels are specialised for the MIN106-RNA001 model shapes "
+                   "(scaler 1-48-48-2, demux 1-2x48-64-5)";
+        return PXG_E_UNSUPPORTED;
+    }
+    return PXG_OK;
+}
+
+int pxg_launch_scaler_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
+                           const int32_t* count, const float* head, float* pred)
+{
+    if (n_rows <= 0) return PXG_OK;
+    const int T = ctx->cfg.scaler_length / ctx->cfg.stride;
+    const int mtb = pick_mtb(ctx, n_rows);
+    const int blocks = (int)((n_rows + 16 * mtb - 1) / (16 * mtb));
+    const size_t lds = sizeof(float) * (4 * mtb * 16 * 48 + 16 * mtb * XS) + sizeof(int) * 16 * mtb;
+    const PxgLstmDev &l1 = ctx->scaler1, &l2 = ctx->scaler2;
+#define LAUNCH_SC(MTW)                                                                       \
+    do {                                                                                     \
+        PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_scaler_lstm<MTW>,                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k_scaler_lstm<MTW>, dim3(blocks), dim3(LSTM_THREADS), lds,        \
+                           ctx->stream, (int)n_rows, idx, count, mtb, T, head, l1.kernel,    \
+                           l1.recurrent, l1.bias, l2.kernel, l2.recurrent, l2.bias,          \
+                           ctx->scaler_dense.kernel, ctx->scaler_dense.bias, pred);          \
+    } while (0)
+    if (mtb <= 2) LAUNCH_SC(1); else LAUNCH_SC(2);
+#undef LAUNCH_SC
+    PXG_HIP(ctx, hipGetLastError());
+    return PXG_OK;
+}
+
+int pxg_launch_demux_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
+                          const int32_t* count, const float* win, float* bidir, float* probs,
+                          int timer_a, int timer_b)
+{
+    if (n_rows <= 0) return PXG_OK;
+    const int T = ctx->cfg.signal_trim_length;
+    const int mtb = pick_mtb(ctx, n_rows);
+    const int blocks = (int)((n_rows + 16 * mtb - 1) / (16 * mtb));
+    {
+        const size_t lds = sizeof(float) * (4 * mtb * 16 * 48 + 16 * mtb * (T + 4)) + sizeof(int) * 16 * mtb;
+        const PxgLstmDev &f = ctx->demux_fwd, &b = ctx->demux_bwd;
+        pxg_timer_begin(ctx, timer_a);
+#define LAUNCH_BI(MTW)                                                                       \
+    do {                                                                                     \
+        PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_demux_bidir<MTW>,                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(k_demux_bidir<MTW>, dim3(blocks), dim3(LSTM_THREADS), lds,        \
+                           ctx->stream, (int)n_rows, idx, count, mtb, T, win, f.kernel,      \
+                           f.recurrent, f.bias, b.kernel, b.recurrent, b.bias, bidir);       \
+    } while (0)
+        if (mtb <= 2) LAUNCH_BI(1); else LAUNCH_BI(2);
+#undef LAUNCH_BI
+        pxg_timer_end(ctx, timer_a);
+    }
+    {
+        const size_t lds = sizeof(float) * (2 * mtb * 16 * 64 + 2 * mtb * 16 * 96) + sizeof(int) * 16 * mtb;
+        const PxgLstmDev& t3 = ctx->demux_top;
+        pxg_timer_begin(ctx, timer_b);
+        PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_demux_top,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_demux_top, dim3(blocks), dim3(LSTM_THREADS), lds, ctx->stream,
+                           (int)n_rows, idx, count, mtb, T, bidir, t3.kernel, t3.recurrent, t3.bias,
+                           ctx->demux_dense.kernel, ctx->demux_dense.bias,
+                           ctx->demux_dense.out_dim, probs);
+        pxg_timer_end(ctx, timer_b);
+    }
+    PXG_HIP(ctx, hipGetLastError());
+    return PXG_OK;
+}

@@ -1,0 +1,389 @@
+// k_signal.hip -- HBM-bound per-read signal kernels (gfx950):
+//   K1  head pool            a1+a2  fast5_file.py:122-131, signal_loader.py:212-231
+//       pool+scale           a1+a5  signal_loader.py:233-264      (test hook)
+//       scaler transform+QC  a4     signal_loader.py:98-109
+//   K4  barcode window       a9-a11 signal_analyzer.py:445-448, barcoding.py:77-101
+//       finalize             a12 tail + a13  barcoding.py:72-75,108-118
+// All byte/float work here is bit-exact against the oracle: float64 pA
+// conversion, NumPy's 15-element pairwise float32 sum, two-rounding Horner.
+#include "pxg_common.h"
+
+// ---------------------------------------------------------------------------
+__global__ void k_raw_to_pa(int64_t n, const int16_t* __restrict__ raw, pxg_calib cal,
+                            float* __restrict__ out)
+{
+    const double k = cal.range / cal.digitisation;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = pxg_raw2pa(raw[i], k, cal.offset);
+}
+
+int pxg_launch_raw_to_pa(pxg_ctx* ctx, int64_t n, const int16_t* raw, const pxg_calib* cal,
+                         float* out)
+{
+    if (n <= 0) return PXG_OK;
+    int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_raw_to_pa, dim3(blocks), dim3(256), 0, ctx->stream, n, raw, *cal, out);
+    return PXG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// K1: one thread per output element of the left-padded head (width = 2000).
+// ---------------------------------------------------------------------------
+__global__ void k_head_pool(int64_t n_reads, const int16_t* __restrict__ raw,
+                            const int64_t* __restrict__ off, const pxg_calib* __restrict__ cal,
+                            int length_limit, int stride, int min_length, int width,
+                            float* __restrict__ head, int32_t* __restrict__ status)
+{
+    const int64_t r = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads || j >= width) return;
+    const int64_t n_raw = off[r + 1] - off[r];
+    int64_t L = n_raw < length_limit ? n_raw : length_limit;
+    L -= L % stride;
+    float* out = head + r * (int64_t)width;
+    if (L < min_length) {
+        out[j] = 0.0f;
+        if (j == 0) status[r] = PXG_ST_SCALER_SIGNAL_TOO_SHORT;
+        return;
+    }
+    if (j == 0) status[r] = PXG_ST_OKAY;
+    const int n_means = (int)(L / stride);
+    const int pad = width - n_means;
+    if (j < pad) {
+        out[j] = 0.0f;
+        return;
+    }
+    const pxg_calib c = cal[r];
+    const double k = c.range / c.digitisation;
+    out[j] = pxg_block_mean(raw + off[r] + (int64_t)(j - pad) * stride, stride, k, c.offset);
+}
+
+int pxg_launch_head_pool(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
+                         const pxg_calib* cal, float* head, int32_t* status)
+{
+    if (n <= 0) return PXG_OK;
+    const int width = ctx->cfg.scaler_length / ctx->cfg.stride;
+    dim3 grid((width + 255) / 256, (unsigned)n);
+    hipLaunchKernelGGL(k_head_pool, grid, dim3(256), 0, ctx->stream, n, raw, off, cal,
+                       ctx->cfg.scaler_length, ctx->cfg.stride, ctx->cfg.scaler_min_length,
+                       width, head, status);
+    return PXG_OK;
+}
+
+// ---------------------------------------------------------------------------
+__global__ void k_pool_scale(int64_t n_reads, const int16_t* __restrict__ raw,
+                             const int64_t* __restrict__ off, const pxg_calib* __restrict__ cal,
+                             const float* __restrict__ ss, const int64_t* __restrict__ poff,
+                             int stride, float* __restrict__ out)
+{
+    const int64_t r = blockIdx.y;
+    if (r >= n_reads) return;
+    const int64_t P = (off[r + 1] - off[r]) / stride;
+    const pxg_calib c = cal[r];
+    const double k = c.range / c.digitisation;
+    const float scale = ss[2 * r], shift = ss[2 * r + 1];
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < P;
+         p += (int64_t)gridDim.x * blockDim.x) {
+        float m = pxg_block_mean(raw + off[r] + p * stride, stride, k, c.offset);
+        float y = scale * m;
+        out[poff[r] + p] = y + shift;
+    }
+}
+
+int pxg_launch_pool_scale(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
+                          const pxg_calib* cal, const float* ss, const int64_t* poff,
+                          float* out)
+{
+    if (n <= 0) return PXG_OK;
+    dim3 grid(16, (unsigned)n);
+    hipLaunchKernelGGL(k_pool_scale, grid, dim3(256), 0, ctx->stream, n, raw, off, cal, ss, poff,
+                       ctx->cfg.stride, out);
+    return PXG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// a4: fl(fl(fl32(std)*p) + fl32(mean)); QC against float32-rounded bounds,
+// inclusive.  Rows come from the compacted index list (idx == nullptr: identity).
+// ---------------------------------------------------------------------------
+struct XfrmParams {
+    float s_mean, s_std, h_mean, h_std;
+    float qs0, qs1, qh0, qh1;
+};
+
+__global__ void k_scaler_transform(int64_t n_rows, const int32_t* __restrict__ idx,
+                                   const int32_t* __restrict__ count,
+                                   const float* __restrict__ pred, XfrmParams xp,
+                                   float* __restrict__ ss, int32_t* __restrict__ status)
+{
+    const int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t lim = count ? (int64_t)*count : n_rows;
+    if (row >= n_rows || row >= lim) return;
+    const int64_t r = idx ? idx[row] : row;
+    float a = xp.s_std * pred[2 * r];
+    float scale = a + xp.s_mean;
+    float b = xp.h_std * pred[2 * r + 1];
+    float shift = b + xp.h_mean;
+    ss[2 * r] = scale;
+    ss[2 * r + 1] = shift;
+    const bool ok = scale >= xp.qs0 && scale <= xp.qs1 && shift >= xp.qh0 && shift <= xp.qh1;
+    status[r] = ok ? PXG_ST_OKAY : PXG_ST_SCALING_QC_FAIL;
+}
+
+int pxg_launch_scaler_transform(pxg_ctx* ctx, int64_t n, const float* pred, float* ss,
+                                int32_t* status, const int32_t* idx, const int32_t* count)
+{
+    if (n <= 0) return PXG_OK;
+    const pxg_config& c = ctx->cfg;
+    XfrmParams xp = { (float)c.scaler_xfrm[0], (float)c.scaler_xfrm[1], (float)c.scaler_xfrm[2],
+                      (float)c.scaler_xfrm[3], (float)c.scaler_qc_scale[0],
+                      (float)c.scaler_qc_scale[1], (float)c.scaler_qc_shift[0],
+                      (float)c.scaler_qc_shift[1] };
+    hipLaunchKernelGGL(k_scaler_transform, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, n, idx, count, pred, xp, ss, status);
+    return PXG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// compaction of reads that go on to the scaler network
+// ---------------------------------------------------------------------------
+__global__ void k_compact_ok(int64_t n, const int32_t* __restrict__ status,
+                             int32_t* __restrict__ idx, int32_t* __restrict__ counter)
+{
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const bool keep = r < n && status[r] == PXG_ST_OKAY;
+    const unsigned long long m = __ballot(keep);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && m) base = atomicAdd(counter, __popcll(m));
+    base = __shfl(base, 0);
+    if (keep) idx[base + __popcll(m & ((1ull << lane) - 1))] = (int32_t)r;
+}
+
+int pxg_launch_compact_scaler(pxg_ctx* ctx, int64_t n, const int32_t* status, int32_t* idx,
+                              int32_t* counter)
+{
+    if (n <= 0) return PXG_OK;
+    hipLaunchKernelGGL(k_compact_ok, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                       n, status, idx, counter);
+    return PXG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// K4: barcode window.  One wave per read; the (<= trim) window lives in LDS;
+// median by rank counting with a (value, index) total order, which selects the
+// same order statistics np.median's partition does.
+// ---------------------------------------------------------------------------
+#define PXG_MAX_TRIM 512
+
+__device__ __forceinline__ void wave_median(const float* v, int n, float* sel, int lane)
+{
+    // sel[0], sel[1] <- the two middle order statistics (equal slots for odd n)
+    const int k1 = n / 2, k0 = (n & 1) ? k1 : k1 - 1;
+    for (int i = lane; i < n; i += PXG_WAVE) {
+        const float x = v[i];
+        int rank = 0;
+        for (int j = 0; j < n; j++) {
+            const float y = v[j];
+            rank += (y < x) || (y == x && j < i);
+        }
+        if (rank == k0) sel[0] = x;
+        if (rank == k1) sel[1] = x;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void window_normalize(float* xs, float* ys, float* sel, int n,
+                                                 int trim, float pad_filler,
+                                                 float* __restrict__ out, int lane)
+{
+    wave_median(xs, n, sel, lane);
+    float med;
+    {
+        float s = sel[0] + sel[1];
+        med = (n & 1) ? sel[1] : s / 2.0f;
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += PXG_WAVE) ys[i] = __builtin_fabsf(xs[i] - med);
+    __syncthreads();
+    wave_median(ys, n, sel, lane);
+    float mad;
+    {
+        float s = sel[0] + sel[1];
+        mad = (n & 1) ? sel[1] : s / 2.0f;
+    }
+    const double dd = fmax(0.01, (double)mad * 1.4826);
+    const float div = (float)dd;
+    const int pad = trim - n;
+    for (int i = lane; i < pad; i += PXG_WAVE) out[i] = pad_filler;
+    for (int i = lane; i < n; i += PXG_WAVE) out[pad + i] = (xs[i] - med) / div;
+}
+
+__global__ __launch_bounds__(64) void k_barcode_window_raw(
+    int64_t n_reads, const int16_t* __restrict__ raw, const int64_t* __restrict__ off,
+    const pxg_calib* __restrict__ cal, const float* __restrict__ ss,
+    const int32_t* __restrict__ status, const int32_t* __restrict__ segs, int adapter_state,
+    int stride, int minlen, int maxlen, int trim, float pad_filler, float* __restrict__ win,
+    int32_t* __restrict__ idx_demux, int32_t* __restrict__ counter)
+{
+    __shared__ float xs[PXG_MAX_TRIM], ys[PXG_MAX_TRIM], sel[2];
+    const int64_t r = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (status[r] != PXG_ST_OKAY) return;
+    const int a0 = segs[r * 2 * PXG_N_SEGMENTS + adapter_state];
+    const int a1 = segs[r * 2 * PXG_N_SEGMENTS + PXG_N_SEGMENTS + adapter_state];
+    if (a0 < 0) return;
+    const int len = a1 - a0 + 1;
+    if (len <= 0 || len < minlen || len > maxlen) return;
+    const int n = len < trim ? len : trim;
+    const int start = a1 + 1 - n;
+    const pxg_calib c = cal[r];
+    const double k = c.range / c.digitisation;
+    const float scale = ss[2 * r], shift = ss[2 * r + 1];
+    for (int i = lane; i < n; i += PXG_WAVE) {
+        float m = pxg_block_mean(raw + off[r] + (int64_t)(start + i) * stride, stride, k, c.offset);
+        float y = scale * m;
+        xs[i] = y + shift;
+    }
+    __syncthreads();
+    window_normalize(xs, ys, sel, n, trim, pad_filler, win + r * (int64_t)trim, lane);
+    if (lane == 0) idx_demux[atomicAdd(counter, 1)] = (int32_t)r;
+}
+
+int pxg_launch_barcode_window_raw(pxg_ctx* ctx, int64_t n, const int16_t* raw,
+                                  const int64_t* off, const pxg_calib* cal, const float* ss,
+                                  const int32_t* status, const int32_t* segs, float* win,
+                                  int32_t* idx_demux, int32_t* counter)
+{
+    if (n <= 0) return PXG_OK;
+    const pxg_config& c = ctx->cfg;
+    hipLaunchKernelGGL(k_barcode_window_raw, dim3((unsigned)n), dim3(64), 0, ctx->stream, n, raw,
+                       off, cal, ss, status, segs, c.segmentation_model.adapter_state, c.stride,
+                       c.minimum_dna_length, c.maximum_dna_length, c.signal_trim_length,
+                       c.pad_filler, win, idx_demux, counter);
+    return PXG_OK;
+}
+
+__global__ __launch_bounds__(64) void k_barcode_window_f32(
+    int64_t n_reads, const float* __restrict__ sig, const int64_t* __restrict__ off, int minlen,
+    int maxlen, int trim, float pad_filler, float* __restrict__ win, int8_t* __restrict__ pushed)
+{
+    __shared__ float xs[PXG_MAX_TRIM], ys[PXG_MAX_TRIM], sel[2];
+    const int64_t r = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t len = off[r + 1] - off[r];
+    if (len <= 0 || len < minlen || len > maxlen) {
+        if (lane == 0) pushed[r] = 0;
+        return;
+    }
+    const int n = len < trim ? (int)len : trim;
+    const float* src = sig + off[r] + (len - n);
+    for (int i = lane; i < n; i += PXG_WAVE) xs[i] = src[i];
+    __syncthreads();
+    window_normalize(xs, ys, sel, n, trim, pad_filler, win + r * (int64_t)trim, lane);
+    if (lane == 0) pushed[r] = 1;
+}
+
+int pxg_launch_barcode_window_f32(pxg_ctx* ctx, int64_t n, const float* sig,
+                                  const int64_t* off, float* win, int8_t* pushed)
+{
+    if (n <= 0) return PXG_OK;
+    const pxg_config& c = ctx->cfg;
+    hipLaunchKernelGGL(k_barcode_window_f32, dim3((unsigned)n), dim3(64), 0, ctx->stream, n, sig,
+                       off, c.minimum_dna_length, c.maximum_dna_length, c.signal_trim_length,
+                       c.pad_filler, win, pushed);
+    return PXG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// finalize: assemble the per-read result record (signal_loader.py:165-198
+// numeric fields; barcoding.py:72-75,108-118)
+// ---------------------------------------------------------------------------
+struct FinalizeParams {
+    int stride, n_classes, n_decoy, n_calibration, adapter_state, trim;
+    double score_threshold;
+    uint32_t stage_mask;
+};
+
+__global__ void k_finalize(int64_t n, FinalizeParams fp, const int64_t* __restrict__ off,
+                           const int32_t* __restrict__ status, const float* __restrict__ ss,
+                           const float* __restrict__ pred, const int32_t* __restrict__ segs,
+                           const float* __restrict__ probs, const int8_t* __restrict__ pushed,
+                           const double* __restrict__ calibration,
+                           pxg_read_result* __restrict__ out)
+{
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    pxg_read_result o;
+    memset(&o, 0, sizeof(o));
+    o.status = status[r];
+    o.n_pooled = (int32_t)((off[r + 1] - off[r]) / fp.stride);
+    for (int s = 0; s < PXG_N_SEGMENTS; s++) o.seg_first[s] = o.seg_last[s] = -1;
+    o.bc_label = -1;
+    const bool scaled = o.status != PXG_ST_SCALER_SIGNAL_TOO_SHORT;
+    if (scaled) {
+        o.scale = ss[2 * r];
+        o.shift = ss[2 * r + 1];
+        o.scaler_pred[0] = pred[2 * r];
+        o.scaler_pred[1] = pred[2 * r + 1];
+    }
+    if ((fp.stage_mask & PXG_STAGE_SEGMENT) &&
+        (o.status == PXG_ST_OKAY || o.status == PXG_ST_ADAPTER_NOT_DETECTED)) {
+        for (int s = 0; s < PXG_N_SEGMENTS; s++) {
+            o.seg_first[s] = segs[r * 2 * PXG_N_SEGMENTS + s];
+            o.seg_last[s] = segs[r * 2 * PXG_N_SEGMENTS + PXG_N_SEGMENTS + s];
+        }
+    }
+    if ((fp.stage_mask & PXG_STAGE_BARCODE) && o.status == PXG_ST_OKAY && pushed[r]) {
+        o.bc_pushed = 1;
+        const float* p = probs + r * PXG_MAX_CLASSES;
+        int arg = 0;
+        for (int j = 1; j < fp.n_classes; j++)
+            if (p[j] > p[arg]) arg = j;
+        for (int j = 0; j < fp.n_classes; j++) o.probs[j] = p[j];
+        const int label = arg - fp.n_decoy;
+        const float score = p[arg];
+        o.bc_label = (int8_t)label;
+        o.bc_score = score;
+        o.bc_called = (label >= 0 && (double)score >= fp.score_threshold) ? 1 : 0;
+        int ph = 0;
+        if (!(score <= 0.0f)) {            // bisect_right over the float64 table
+            const double x = (double)score;
+            int lo = 0, hi = fp.n_calibration;
+            while (lo < hi) {
+                const int mid = (lo + hi) / 2;
+                if (x < calibration[mid]) hi = mid; else lo = mid + 1;
+            }
+            ph = lo;
+        }
+        o.bc_phred = (uint8_t)ph;
+    }
+    out[r] = o;
+}
+
+__global__ void k_mark_pushed(const int32_t* __restrict__ idx, const int32_t* __restrict__ count,
+                              int8_t* __restrict__ pushed)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < *count) pushed[idx[i]] = 1;
+}
+
+int pxg_launch_finalize(pxg_ctx* ctx, int64_t n, uint32_t stage_mask)
+{
+    if (n <= 0) return PXG_OK;
+    const pxg_config& c = ctx->cfg;
+    // pushed flags live in the first n bytes of the (reused) bidir scratch? no:
+    // keep them in the tail of the status arena (int8 view of n extra int32s)
+    int8_t* pushed = (int8_t*)(ctx->status.p + n);
+    (void)hipMemsetAsync(pushed, 0, (size_t)n, ctx->stream);
+    if (stage_mask & PXG_STAGE_BARCODE)
+        hipLaunchKernelGGL(k_mark_pushed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                           ctx->stream, ctx->idx_demux.p, ctx->counters.p + 1, pushed);
+    FinalizeParams fp = { c.stride, c.demux_dense.out_dim, c.number_of_decoy_labels,
+                          c.n_calibration, c.segmentation_model.adapter_state,
+                          c.signal_trim_length, c.score_threshold, stage_mask };
+    hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, n,
+                       fp, ctx->offsets.p, ctx->status.p, ctx->ss.p, ctx->pred.p, ctx->segs.p,
+                       ctx->probs.p, pushed, ctx->d_calibration, ctx->results.p);
+    return PXG_OK;
+}

@@ -1,0 +1,264 @@
+// k_viterbi.hip -- K3: pool + scale + 6-state HMM Viterbi + run-length summary
+// (a1, a5, a7, a8: signal_loader.py:233-264; pomegranate viterbi called at
+// signal_analyzer.py:352; run summary signal_analyzer.py:354-362).
+//
+// Layout: one wave = 8 reads x 8 state-lanes.  Per 64-step chunk
+//   (1) emission phase, all 64 lanes: lane (read, sub) pools 15 int16 samples
+//       (NumPy pairwise order), applies fl(fl(scale*x)+shift), evaluates the
+//       float64 log-densities of every state and parks them in LDS;
+//   (2) recurrence phase: lane (read, state) keeps v[state] in a register and
+//       pulls its in-edge sources with wave shuffles (max-plus, strict '>' in
+//       pomegranate's name-sorted source order).
+// No back-pointer table: the segmentation model is left-to-right (every edge
+// i->j has j >= i), so a path is fully described by the step at which it
+// entered each state.  Each lane carries those entry steps packed 16 bit per
+// state; taking an in-edge copies the source lane's vector and stamps the
+// current step.  The run-length summary falls out without a traceback.
+#include "pxg_common.h"
+
+#define VIT_READS 8
+#define VIT_CHUNK 64
+
+__device__ __forceinline__ double hmm_emission(const PxgHmmDev& H, int s, double x)
+{
+    // pomegranate Normal: lssp - (x-mu)^2 * tss ; mixture: pair_lse fold
+    double lp;
+    {
+        const double d = x - H.mu[s][0];
+        lp = H.lssp[s][0] - (d * d) * H.tss[s][0];
+    }
+    if (H.n_mix[s] > 1) {
+        lp = lp + H.logw[s][0];   // pair_lse(-inf, y) = y
+        for (int k = 1; k < H.n_mix[s]; k++) {
+            const double d = x - H.mu[s][k];
+            const double l = (H.lssp[s][k] - (d * d) * H.tss[s][k]) + H.logw[s][k];
+            const double a = lp, b = l;
+            if (a == __builtin_inf() || b == __builtin_inf()) lp = __builtin_inf();
+            else if (a == -__builtin_inf()) lp = b;
+            else if (b == -__builtin_inf()) lp = a;
+            else if (a > b) lp = a + log(exp(b - a) + 1.0);
+            else lp = b + log(exp(a - b) + 1.0);
+        }
+    }
+    return lp;
+}
+
+__device__ __forceinline__ double shfl_f64(double v, int src)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl(lo, src);
+    hi = __shfl(hi, src);
+    return __hiloint2double(hi, lo);
+}
+
+// stamp a 16-bit field (state q) of the packed entry vector without dynamic
+// register indexing
+__device__ __forceinline__ void ent_stamp(unsigned (&e)[4], int q, unsigned val16)
+{
+    const unsigned sh = (unsigned)(q & 1) * 16u;
+    const int w = q >> 1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const unsigned nv = (e[i] & ~(0xFFFFu << sh)) | (val16 << sh);
+        e[i] = (i == w) ? nv : e[i];
+    }
+}
+
+#define EM_STRIDE (VIT_CHUNK * PXG_MAX_STATES + 8)   // +8 doubles: spread reads over banks
+
+// RAW=true : signal is pooled on the fly from int16 DAQ samples
+// RAW=false: signal is an already pooled+scaled float arena (test hook)
+template <bool RAW>
+__global__ __launch_bounds__(64) void k_viterbi_ltr(
+    int64_t n_reads, PxgHmmDev H, const int16_t* __restrict__ raw, const float* __restrict__ sig,
+    const int64_t* __restrict__ off, const pxg_calib* __restrict__ cal,
+    const float* __restrict__ ss, int stride, int scan_pooled, int32_t* __restrict__ status,
+    int32_t* __restrict__ segs, double* __restrict__ logp_out)
+{
+    __shared__ double em[VIT_READS * EM_STRIDE];
+    const int lane = threadIdx.x;
+    const int rr = lane >> 3, s = lane & 7;
+    const int64_t r = blockIdx.x * (int64_t)VIT_READS + rr;
+    const int S = H.n_states;
+    const bool valid_read = r < n_reads && (status == nullptr || status[r] == PXG_ST_OKAY);
+
+    int T = 0;
+    int64_t base = 0;
+    double k = 0.0, offset = 0.0;
+    float scale = 1.0f, shift = 0.0f;
+    if (valid_read) {
+        base = off[r];
+        const int64_t len = off[r + 1] - off[r];
+        const int64_t P = RAW ? len / stride : len;
+        T = (int)(P < scan_pooled ? P : scan_pooled);
+        if (RAW) {
+            const pxg_calib c = cal[r];
+            k = c.range / c.digitisation;
+            offset = c.offset;
+            scale = ss[2 * r];
+            shift = ss[2 * r + 1];
+        }
+    }
+    // longest read of this wave
+    int Tmax = T;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const int o = __shfl_xor(Tmax, d);
+        Tmax = o > Tmax ? o : Tmax;
+    }
+
+    // per-lane in-edge table (sources as lane ids inside this read's octet)
+    int src_lane[PXG_MAX_STATES];
+    double src_lp[PXG_MAX_STATES];
+#pragma unroll
+    for (int d = 0; d < PXG_MAX_STATES; d++) {
+        const int sidx = (s < S) ? H.in_src[s][d] : -1;
+        src_lane[d] = sidx >= 0 ? (rr * 8 + sidx) : lane;
+        src_lp[d] = sidx >= 0 ? H.in_logp[s][d] : -__builtin_inf();
+    }
+    const double lstart = (s < S) ? H.log_start[s] : -__builtin_inf();
+
+    double v = -__builtin_inf();
+    unsigned ent[4] = { 0u, 0u, 0u, 0u };   // 16-bit entry step + 1 per state
+
+    for (int c0 = 0; c0 < Tmax; c0 += VIT_CHUNK) {
+        // ---- emission phase ------------------------------------------------
+        __syncthreads();
+#pragma unroll 1
+        for (int p = 0; p < VIT_CHUNK / 8; p++) {
+            const int tt = p * 8 + s;          // here `s` is the sub-lane
+            const int t = c0 + tt;
+            if (t < T) {
+                float x;
+                if (RAW) {
+                    float m = pxg_block_mean(raw + base + (int64_t)t * stride, stride, k, offset);
+                    float y = scale * m;
+                    x = y + shift;
+                } else {
+                    x = sig[base + t];
+                }
+                const double xd = (double)x;
+#pragma unroll
+                for (int q = 0; q < PXG_MAX_STATES; q++)
+                    if (q < S) em[rr * EM_STRIDE + tt * PXG_MAX_STATES + q] = hmm_emission(H, q, xd);
+            }
+        }
+        __syncthreads();
+        // ---- recurrence phase ---------------------------------------------
+        const int tend = (Tmax - c0) < VIT_CHUNK ? (Tmax - c0) : VIT_CHUNK;
+#pragma unroll 1
+        for (int tt = 0; tt < tend; tt++) {
+            const int t = c0 + tt;
+            const bool act = (t < T) && (s < S);
+            const double e = act ? em[rr * EM_STRIDE + tt * PXG_MAX_STATES + s] : 0.0;
+            double best = -__builtin_inf();
+            int arg = lane;
+#pragma unroll
+            for (int d = 0; d < PXG_MAX_STATES; d++) {
+                if (d < H.max_in) {             // wave-uniform
+                    const double vk = shfl_f64(v, src_lane[d]);
+                    const double cand = vk + src_lp[d];
+                    if (cand > best) {
+                        best = cand;
+                        arg = src_lane[d];
+                    }
+                }
+            }
+            unsigned ne[4];
+#pragma unroll
+            for (int w = 0; w < 4; w++) ne[w] = (unsigned)__shfl((int)ent[w], arg);
+            if (t == 0) {
+                if (act) {
+                    v = lstart + e;
+                    ent_stamp(ent, s, 1u);
+                }
+            } else if (act) {
+                v = best + e;
+                if (arg != lane) {
+                    ent_stamp(ne, s, (unsigned)(t + 1));
+#pragma unroll
+                    for (int w = 0; w < 4; w++) ent[w] = ne[w];
+                }
+            }
+        }
+    }
+
+    // ---- termination: first maximum of the last column in name-sorted order -
+    double bestv = -__builtin_inf();
+    int end_lane = rr * 8 + H.order[0];
+    for (int q = 0; q < S; q++) {
+        const int ln = rr * 8 + H.order[q];
+        const double vk = shfl_f64(v, ln);
+        if (q == 0 || vk > bestv) {
+            bestv = vk;
+            end_lane = ln;
+        }
+    }
+    unsigned fe[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) fe[w] = (unsigned)__shfl((int)ent[w], end_lane);
+
+    if (s == 0 && r < n_reads) {
+        int32_t* first = segs + r * 2 * PXG_N_SEGMENTS;
+        int32_t* last = first + PXG_N_SEGMENTS;
+        for (int q = 0; q < PXG_N_SEGMENTS; q++) first[q] = last[q] = -1;
+        if (valid_read && T > 0) {
+            int prev = -1;
+#pragma unroll
+            for (int q = 0; q < PXG_MAX_STATES; q++) {
+                const int en = (int)((fe[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu);
+                if (q >= S || en == 0) continue;
+                first[q] = en - 1;
+                if (prev >= 0) last[prev] = en - 2;
+                prev = q;
+            }
+            if (prev >= 0) last[prev] = T - 1;
+            if (logp_out) logp_out[r] = bestv;
+            if (status != nullptr && H.adapter_state >= 0 && first[H.adapter_state] < 0)
+                status[r] = PXG_ST_ADAPTER_NOT_DETECTED;
+        } else if (logp_out) {
+            logp_out[r] = -__builtin_inf();
+        }
+    }
+}
+
+static int check_supported(pxg_ctx* ctx, int which)
+{
+    const PxgHmmDev& H = ctx->hmm[which];
+    if (!H.left_to_right) {
+        ctx->err = "Viterbi kernel: HMM is not left-to-right (back-edges need the "
+                   "back-pointer kernel, not built yet)";
+        return PXG_E_UNSUPPORTED;
+    }
+    if (ctx->cfg.segmentation_scan_limit / ctx->cfg.stride >= 65535) {
+        ctx->err = "segmentation_scan_limit/stride must be < 65535";
+        return PXG_E_UNSUPPORTED;
+    }
+    return PXG_OK;
+}
+
+int pxg_launch_segment_raw(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
+                           const pxg_calib* cal, const float* ss, const int32_t* status,
+                           int32_t* segs)
+{
+    if (n <= 0) return PXG_OK;
+    int rc = check_supported(ctx, 0);
+    if (rc) return rc;
+    const int scan = ctx->cfg.segmentation_scan_limit / ctx->cfg.stride;
+    hipLaunchKernelGGL(k_viterbi_ltr<true>, dim3((unsigned)((n + VIT_READS - 1) / VIT_READS)),
+                       dim3(64), 0, ctx->stream, n, ctx->hmm[0], raw, (const float*)nullptr, off,
+                       cal, ss, ctx->cfg.stride, scan, (int32_t*)status, segs, (double*)nullptr);
+    return PXG_OK;
+}
+
+int pxg_launch_viterbi_f32(pxg_ctx* ctx, int which, int64_t n, const float* sig,
+                           const int64_t* off, int32_t* segs, double* logp)
+{
+    if (n <= 0) return PXG_OK;
+    int rc = check_supported(ctx, which);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_viterbi_ltr<false>, dim3((unsigned)((n + VIT_READS - 1) / VIT_READS)),
+                       dim3(64), 0, ctx->stream, n, ctx->hmm[which], (const int16_t*)nullptr, sig,
+                       off, (const pxg_calib*)nullptr, (const float*)nullptr, 1, 65534,
+                       (int32_t*)nullptr, segs, logp);
+    return PXG_OK;
+}

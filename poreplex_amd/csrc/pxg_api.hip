@@ -1,0 +1,621 @@
+// pxg_api.hip -- C ABI of libpxg.so (include/pxg.h): context lifetime, batch
+// residency, stage orchestration on one HIP stream, per-stage HIP-event timers.
+#include <math.h>
+#include <string.h>
+#include <algorithm>
+#include "pxg_common.h"
+
+static std::string g_last_error;
+
+static int fail(pxg_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->err = msg;
+    g_last_error = msg;
+    return code;
+}
+
+void pxg_timer_begin(pxg_ctx* ctx, int t)
+{
+    (void)hipEventRecord(ctx->ev_start[t], ctx->stream);
+    ctx->ev_used[t] = true;
+    ctx->launches[t]++;
+}
+
+void pxg_timer_end(pxg_ctx* ctx, int t)
+{
+    (void)hipEventRecord(ctx->ev_stop[t], ctx->stream);
+}
+
+// ---------------------------------------------------------------------------
+// HMM tables (worker_persistence.py:95-121 -> device image).  All logs are
+// taken on the host with the same libm the oracle uses.
+// ---------------------------------------------------------------------------
+#define PXG_SQRT_2_PI 2.50662827463   /* pomegranate's constant */
+
+static int build_hmm(pxg_ctx* ctx, const pxg_hmm& h, PxgHmmDev& d)
+{
+    memset(&d, 0, sizeof(d));
+    if (h.n_states < 1 || h.n_states > PXG_MAX_STATES)
+        return fail(ctx, PXG_E_INVALID, "HMM: bad state count");
+    d.n_states = h.n_states;
+    d.adapter_state = h.adapter_state;
+    d.polya_state = h.polya_state;
+    const int S = h.n_states;
+    for (int s = 0; s < S; s++) {
+        if (h.name_rank[s] < 0 || h.name_rank[s] >= S)
+            return fail(ctx, PXG_E_INVALID, "HMM: bad name_rank");
+        d.order[h.name_rank[s]] = s;
+    }
+    d.left_to_right = 1;
+    d.max_in = 0;
+    for (int s = 0; s < S; s++) {
+        d.log_start[s] = h.start_prob[s] > 0.0 ? log(h.start_prob[s]) : -INFINITY;
+        int nin = 0;
+        for (int r = 0; r < S; r++) {               // sources in name-sorted order
+            const int k = d.order[r];
+            if (h.trans[k][s] > 0.0) {
+                d.in_src[s][nin] = k;
+                d.in_logp[s][nin] = log(h.trans[k][s]);
+                nin++;
+                if (k > s) d.left_to_right = 0;
+            }
+        }
+        for (int q = nin; q < PXG_MAX_STATES; q++) {
+            d.in_src[s][q] = -1;
+            d.in_logp[s][q] = -INFINITY;
+        }
+        d.max_in = std::max(d.max_in, nin);
+        const int nm = h.n_mix[s];
+        if (nm < 1 || nm > PXG_MAX_MIXTURE) return fail(ctx, PXG_E_INVALID, "HMM: bad mixture");
+        d.n_mix[s] = nm;
+        double wsum = 0.0;
+        for (int k = 0; k < nm; k++) wsum += h.mix_weight[s][k];
+        for (int k = 0; k < nm; k++) {
+            const double sd = h.mix_sigma[s][k];
+            d.mu[s][k] = h.mix_mu[s][k];
+            d.lssp[s][k] = -log(sd * PXG_SQRT_2_PI);
+            d.tss[s][k] = 1.0 / (2.0 * sd * sd);
+            d.logw[s][k] = nm > 1 ? log(h.mix_weight[s][k] / wsum) : 0.0;
+        }
+    }
+    return PXG_OK;
+}
+
+template <typename T>
+static int upload(pxg_ctx* ctx, T** dst, const T* src, size_t n)
+{
+    if (!src || !n) return fail(ctx, PXG_E_INVALID, "missing weight array");
+    PXG_HIP(ctx, hipMalloc((void**)dst, n * sizeof(T)));
+    PXG_HIP(ctx, hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return PXG_OK;
+}
+
+static int upload_lstm(pxg_ctx* ctx, const pxg_lstm_layer& h, PxgLstmDev& d)
+{
+    d.input_dim = h.input_dim;
+    d.units = h.units;
+    if (h.input_dim < 1 || h.units < 1) return fail(ctx, PXG_E_INVALID, "bad LSTM dims");
+    int rc;
+    if ((rc = upload(ctx, &d.kernel, h.kernel, (size_t)h.input_dim * 4 * h.units))) return rc;
+    if ((rc = upload(ctx, &d.recurrent, h.recurrent, (size_t)h.units * 4 * h.units))) return rc;
+    return upload(ctx, &d.bias, h.bias, (size_t)4 * h.units);
+}
+
+static int upload_dense(pxg_ctx* ctx, const pxg_dense_layer& h, PxgDenseDev& d)
+{
+    d.in_dim = h.in_dim;
+    d.out_dim = h.out_dim;
+    int rc;
+    if ((rc = upload(ctx, &d.kernel, h.kernel, (size_t)h.in_dim * h.out_dim))) return rc;
+    return upload(ctx, &d.bias, h.bias, (size_t)h.out_dim);
+}
+
+extern "C" int pxg_abi_version(void) { return PXG_ABI_VERSION; }
+
+extern "C" const char* pxg_last_error(const pxg_ctx* ctx)
+{
+    return ctx ? ctx->err.c_str() : g_last_error.c_str();
+}
+
+extern "C" int pxg_create(const pxg_config* cfg, pxg_ctx** out)
+{
+    if (!cfg || !out) return fail(nullptr, PXG_E_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->abi_version != PXG_ABI_VERSION)
+        return fail(nullptr, PXG_E_INVALID, "pxg_config.abi_version mismatch");
+    if (cfg->stride < 1 || cfg->stride > 128 || cfg->signal_trim_length < 1 ||
+        cfg->n_calibration < 0 || cfg->n_calibration > PXG_MAX_CALIBRATION)
+        return fail(nullptr, PXG_E_INVALID, "config out of range");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, PXG_E_NODEVICE, "no HIP device visible (this library has no CPU path)");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev)
+        return fail(nullptr, PXG_E_NODEVICE, "device_id out of range");
+    pxg_ctx* ctx = new pxg_ctx();
+    ctx->cfg = *cfg;
+    ctx->device = cfg->device_id;
+    memset(ctx->ev_used, 0, sizeof(ctx->ev_used));
+    memset(ctx->launches, 0, sizeof(ctx->launches));
+    int rc = PXG_OK;
+    do {
+        if (hipSetDevice(ctx->device) != hipSuccess) { rc = fail(ctx, PXG_E_HIP, "hipSetDevice"); break; }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) { rc = fail(ctx, PXG_E_HIP, "props"); break; }
+        ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            rc = fail(ctx, PXG_E_HIP, "hipStreamCreate"); break;
+        }
+        for (int t = 0; t < PXG_N_TIMERS; t++) {
+            (void)hipEventCreate(&ctx->ev_start[t]);
+            (void)hipEventCreate(&ctx->ev_stop[t]);
+        }
+        if ((rc = build_hmm(ctx, cfg->segmentation_model, ctx->hmm[0]))) break;
+        if ((rc = build_hmm(ctx, cfg->unsplit_model, ctx->hmm[1]))) break;
+        if ((rc = upload_lstm(ctx, cfg->scaler_lstm1, ctx->scaler1))) break;
+        if ((rc = upload_lstm(ctx, cfg->scaler_lstm2, ctx->scaler2))) break;
+        if ((rc = upload_dense(ctx, cfg->scaler_dense, ctx->scaler_dense))) break;
+        if ((rc = upload_lstm(ctx, cfg->demux_fwd, ctx->demux_fwd))) break;
+        if ((rc = upload_lstm(ctx, cfg->demux_bwd, ctx->demux_bwd))) break;
+        if ((rc = upload_lstm(ctx, cfg->demux_top, ctx->demux_top))) break;
+        if ((rc = upload_dense(ctx, cfg->demux_dense, ctx->demux_dense))) break;
+        if ((rc = upload(ctx, &ctx->d_calibration, cfg->calibration, PXG_MAX_CALIBRATION))) break;
+        if ((rc = pxg_lstm_upload(ctx))) break;
+    } while (0);
+    // host pointers in the copied config are not retained
+    ctx->cfg.scaler_lstm1.kernel = ctx->cfg.scaler_lstm1.recurrent = ctx->cfg.scaler_lstm1.bias = nullptr;
+    ctx->cfg.scaler_lstm2.kernel = ctx->cfg.scaler_lstm2.recurrent = ctx->cfg.scaler_lstm2.bias = nullptr;
+    ctx->cfg.demux_fwd.kernel = ctx->cfg.demux_fwd.recurrent = ctx->cfg.demux_fwd.bias = nullptr;
+    ctx->cfg.demux_bwd.kernel = ctx->cfg.demux_bwd.recurrent = ctx->cfg.demux_bwd.bias = nullptr;
+    ctx->cfg.demux_top.kernel = ctx->cfg.demux_top.recurrent = ctx->cfg.demux_top.bias = nullptr;
+    ctx->cfg.scaler_dense.kernel = ctx->cfg.scaler_dense.bias = nullptr;
+    ctx->cfg.demux_dense.kernel = ctx->cfg.demux_dense.bias = nullptr;
+    if (rc != PXG_OK) {
+        g_last_error = ctx->err;
+        pxg_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return PXG_OK;
+}
+
+template <typename T>
+static void release(DevBuf<T>& b)
+{
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+static void free_lstm(PxgLstmDev& d)
+{
+    if (d.kernel) (void)hipFree(d.kernel);
+    if (d.recurrent) (void)hipFree(d.recurrent);
+    if (d.bias) (void)hipFree(d.bias);
+}
+
+extern "C" void pxg_destroy(pxg_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    release(ctx->raw); release(ctx->offsets); release(ctx->calib); release(ctx->inject);
+    release(ctx->head); release(ctx->pred); release(ctx->ss); release(ctx->status);
+    release(ctx->segs); release(ctx->idx_scaler); release(ctx->idx_demux);
+    release(ctx->counters); release(ctx->win); release(ctx->bidir); release(ctx->probs);
+    release(ctx->results);
+    free_lstm(ctx->scaler1); free_lstm(ctx->scaler2); free_lstm(ctx->demux_fwd);
+    free_lstm(ctx->demux_bwd); free_lstm(ctx->demux_top);
+    if (ctx->scaler_dense.kernel) (void)hipFree(ctx->scaler_dense.kernel);
+    if (ctx->scaler_dense.bias) (void)hipFree(ctx->scaler_dense.bias);
+    if (ctx->demux_dense.kernel) (void)hipFree(ctx->demux_dense.kernel);
+    if (ctx->demux_dense.bias) (void)hipFree(ctx->demux_dense.bias);
+    if (ctx->d_calibration) (void)hipFree(ctx->d_calibration);
+    if (ctx->stream) {
+        for (int t = 0; t < PXG_N_TIMERS; t++) {
+            (void)hipEventDestroy(ctx->ev_start[t]);
+            (void)hipEventDestroy(ctx->ev_stop[t]);
+        }
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    delete ctx;
+}
+
+extern "C" int pxg_get_device_info(pxg_ctx* ctx, pxg_device_info* out)
+{
+    if (!ctx || !out) return PXG_E_INVALID;
+    hipDeviceProp_t prop;
+    PXG_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    memset(out, 0, sizeof(*out));
+    strncpy(out->name, prop.name, sizeof(out->name) - 1);
+    strncpy(out->arch, prop.gcnArchName, sizeof(out->arch) - 1);
+    out->compute_units = prop.multiProcessorCount;
+    out->wavefront_size = prop.warpSize;
+    out->total_mem = (int64_t)prop.totalGlobalMem;
+    out->lds_per_cu = (int32_t)prop.maxSharedMemoryPerMultiProcessor;
+    out->clock_khz = prop.clockRate;
+    return PXG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// batch residency
+// ---------------------------------------------------------------------------
+static int reserve_batch(pxg_ctx* ctx, int64_t n, int64_t n_samples)
+{
+    const pxg_config& c = ctx->cfg;
+    const size_t width = (size_t)(c.scaler_length / c.stride);
+    int rc;
+    if ((rc = pxg_reserve(ctx, ctx->raw, (size_t)n_samples + 64))) return rc;
+    if ((rc = pxg_reserve(ctx, ctx->offsets, (size_t)n + 1))) return rc;
+    if ((rc = pxg_reserve(ctx, ctx->calib, (size_t)n))) return rc;
+    if ((rc = pxg_reserve(ctx, ctx->inject, (size_t)n * 2))) return rc;
+    if ((rc = pxg_reserve(ctx, ctx->head, (size_t)n * width))) return rc;
+    if ((rc = pxg_reserve(ctx, ctx->pred, (size_t)n * 2))) return rc;
+    if ((rc = pxg_reserve(ctx, ctx->ss, (size_t)n * 2))) return rc;
+    if ((rc = pxg_reserve(ctx, ctx->status, (size_t)n * 2 + 16))) return rc;
+    if ((rc = pxg_reserve(ctx, ctx->segs, (size_t)n * 2 * PXG_N_SEGMENTS))) return rc;
+    if ((rc = pxg_reserve(ctx, ctx->idx_scaler, (size_t)n))) return rc;
+    if ((rc = pxg_reserve(ctx, ctx->idx_demux, (size_t)n))) return rc;
+    if ((rc = pxg_reserve(ctx, ctx->counters, 8))) return rc;
+    if ((rc = pxg_reserve(ctx, ctx->win, (size_t)n * c.signal_trim_length))) return rc;
+    if ((rc = pxg_reserve(ctx, ctx->bidir, (size_t)n * c.signal_trim_length * 96))) return rc;
+    if ((rc = pxg_reserve(ctx, ctx->probs, (size_t)n * PXG_MAX_CLASSES))) return rc;
+    if ((rc = pxg_reserve(ctx, ctx->results, (size_t)n))) return rc;
+    return PXG_OK;
+}
+
+extern "C" int pxg_batch_upload(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
+                                const int64_t* raw_offsets, const pxg_calib* calib,
+                                const float* scale_shift_or_null)
+{
+    if (!ctx) return PXG_E_INVALID;
+    if (n_reads < 0 || (n_reads > 0 && (!raw_offsets || !calib)))
+        return fail(ctx, PXG_E_INVALID, "pxg_batch_upload: bad arguments");
+    PXG_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->n_reads = 0;
+    if (n_reads == 0) return PXG_OK;
+    for (int64_t i = 0; i < n_reads; i++)
+        if (raw_offsets[i + 1] < raw_offsets[i])
+            return fail(ctx, PXG_E_INVALID, "raw_offsets must be non-decreasing");
+    if (raw_offsets[0] != 0) return fail(ctx, PXG_E_INVALID, "raw_offsets[0] must be 0");
+    const int64_t n_samples = raw_offsets[n_reads];
+    if (n_samples > 0 && !raw_arena) return fail(ctx, PXG_E_INVALID, "raw_arena is null");
+    if (n_reads > (1LL << 30)) return fail(ctx, PXG_E_INVALID, "too many reads");
+    int rc = reserve_batch(ctx, n_reads, n_samples);
+    if (rc) return rc;
+    if (n_samples)
+        PXG_HIP(ctx, hipMemcpyAsync(ctx->raw.p, raw_arena, (size_t)n_samples * sizeof(int16_t),
+                                    hipMemcpyHostToDevice, ctx->stream));
+    PXG_HIP(ctx, hipMemcpyAsync(ctx->offsets.p, raw_offsets, (size_t)(n_reads + 1) * sizeof(int64_t),
+                                hipMemcpyHostToDevice, ctx->stream));
+    PXG_HIP(ctx, hipMemcpyAsync(ctx->calib.p, calib, (size_t)n_reads * sizeof(pxg_calib),
+                                hipMemcpyHostToDevice, ctx->stream));
+    ctx->have_inject = scale_shift_or_null != nullptr;
+    if (ctx->have_inject)
+        PXG_HIP(ctx, hipMemcpyAsync(ctx->inject.p, scale_shift_or_null, (size_t)n_reads * 2 * sizeof(float),
+                                    hipMemcpyHostToDevice, ctx->stream));
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host buffers may be reused on return
+    ctx->n_reads = n_reads;
+    ctx->n_samples = n_samples;
+    return PXG_OK;
+}
+
+extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
+{
+    if (!ctx) return PXG_E_INVALID;
+    const int64_t n = ctx->n_reads;
+    if (n <= 0) return fail(ctx, PXG_E_STATE, "pxg_batch_run: no resident batch");
+    if (stage_mask & PXG_STAGE_POLYA)
+        return fail(ctx, PXG_E_UNSUPPORTED, "poly(A) stage is not built into the GPU path yet");
+    if ((stage_mask & PXG_STAGE_BARCODE) && !(stage_mask & PXG_STAGE_SEGMENT))
+        return fail(ctx, PXG_E_INVALID, "barcode stage needs the segment stage");
+    if ((stage_mask & PXG_STAGE_SEGMENT) && !(stage_mask & PXG_STAGE_SCALER) && !ctx->have_inject)
+        return fail(ctx, PXG_E_INVALID, "segment stage needs the scaler stage or injected scaling");
+    PXG_HIP(ctx, hipSetDevice(ctx->device));
+    memset(ctx->ev_used, 0, sizeof(ctx->ev_used));
+    memset(ctx->launches, 0, sizeof(ctx->launches));
+    int rc;
+    pxg_timer_begin(ctx, PXG_T_TOTAL);
+    PXG_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 8 * sizeof(int32_t), ctx->stream));
+    PXG_HIP(ctx, hipMemsetAsync(ctx->status.p, 0, (size_t)n * sizeof(int32_t), ctx->stream));
+    PXG_HIP(ctx, hipMemsetAsync(ctx->pred.p, 0, (size_t)n * 2 * sizeof(float), ctx->stream));
+    PXG_HIP(ctx, hipMemsetAsync(ctx->ss.p, 0, (size_t)n * 2 * sizeof(float), ctx->stream));
+    PXG_HIP(ctx, hipMemsetAsync(ctx->segs.p, 0xFF, (size_t)n * 2 * PXG_N_SEGMENTS * sizeof(int32_t), ctx->stream));
+
+    if (stage_mask & PXG_STAGE_SCALER) {
+        pxg_timer_begin(ctx, PXG_T_HEAD_POOL);
+        if ((rc = pxg_launch_head_pool(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->head.p,
+                                       ctx->status.p))) return rc;
+        pxg_timer_end(ctx, PXG_T_HEAD_POOL);
+        if (ctx->have_inject) {
+            PXG_HIP(ctx, hipMemcpyAsync(ctx->ss.p, ctx->inject.p, (size_t)n * 2 * sizeof(float),
+                                        hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+            if ((rc = pxg_launch_compact_scaler(ctx, n, ctx->status.p, ctx->idx_scaler.p, ctx->counters.p)))
+                return rc;
+            pxg_timer_begin(ctx, PXG_T_SCALER_LSTM);
+            if ((rc = pxg_launch_scaler_lstm(ctx, n, ctx->idx_scaler.p, ctx->counters.p, ctx->head.p,
+                                             ctx->pred.p))) return rc;
+            pxg_timer_end(ctx, PXG_T_SCALER_LSTM);
+            if ((rc = pxg_launch_scaler_transform(ctx, n, ctx->pred.p, ctx->ss.p, ctx->status.p,
+                                                  ctx->idx_scaler.p, ctx->counters.p))) return rc;
+        }
+    } else if (ctx->have_inject) {
+        PXG_HIP(ctx, hipMemcpyAsync(ctx->ss.p, ctx->inject.p, (size_t)n * 2 * sizeof(float),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (stage_mask & PXG_STAGE_SEGMENT) {
+        pxg_timer_begin(ctx, PXG_T_SEGMENT);
+        if ((rc = pxg_launch_segment_raw(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p,
+                                         ctx->status.p, ctx->segs.p))) return rc;
+        pxg_timer_end(ctx, PXG_T_SEGMENT);
+    }
+    if (stage_mask & PXG_STAGE_BARCODE) {
+        pxg_timer_begin(ctx, PXG_T_BARCODE_WINDOW);
+        if ((rc = pxg_launch_barcode_window_raw(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p,
+                                                ctx->ss.p, ctx->status.p, ctx->segs.p, ctx->win.p,
+                                                ctx->idx_demux.p, ctx->counters.p + 1))) return rc;
+        pxg_timer_end(ctx, PXG_T_BARCODE_WINDOW);
+        if ((rc = pxg_launch_demux_lstm(ctx, n, ctx->idx_demux.p, ctx->counters.p + 1, ctx->win.p,
+                                        ctx->bidir.p, ctx->probs.p, PXG_T_DEMUX_BIDIR,
+                                        PXG_T_DEMUX_TOP))) return rc;
+    }
+    pxg_timer_begin(ctx, PXG_T_FINALIZE);
+    if ((rc = pxg_launch_finalize(ctx, n, stage_mask))) return rc;
+    pxg_timer_end(ctx, PXG_T_FINALIZE);
+    pxg_timer_end(ctx, PXG_T_TOTAL);
+    PXG_HIP(ctx, hipGetLastError());
+    return PXG_OK;
+}
+
+extern "C" int pxg_batch_sync(pxg_ctx* ctx)
+{
+    if (!ctx) return PXG_E_INVALID;
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PXG_OK;
+}
+
+extern "C" int pxg_batch_download(pxg_ctx* ctx, pxg_read_result* out)
+{
+    if (!ctx || (!out && ctx->n_reads)) return PXG_E_INVALID;
+    if (ctx->n_reads <= 0) return PXG_OK;
+    PXG_HIP(ctx, hipMemcpyAsync(out, ctx->results.p, (size_t)ctx->n_reads * sizeof(pxg_read_result),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PXG_OK;
+}
+
+extern "C" int pxg_batch_download_spikes(pxg_ctx* ctx, pxg_polya_spike*)
+{
+    return fail(ctx, PXG_E_UNSUPPORTED, "poly(A) stage is not built into the GPU path yet");
+}
+
+extern "C" int pxg_batch_times(pxg_ctx* ctx, pxg_stage_times* out)
+{
+    if (!ctx || !out) return PXG_E_INVALID;
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int t = 0; t < PXG_N_TIMERS; t++) {
+        out->ms[t] = 0.0f;
+        out->n_launches[t] = ctx->launches[t];
+        if (ctx->ev_used[t]) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, ctx->ev_start[t], ctx->ev_stop[t]) == hipSuccess)
+                out->ms[t] = ms;
+        }
+    }
+    return PXG_OK;
+}
+
+extern "C" int pxg_batch_synthesize(pxg_ctx* ctx, int64_t, int64_t, uint64_t)
+{
+    return fail(ctx, PXG_E_UNSUPPORTED, "pxg_batch_synthesize: device-side generator not built yet");
+}
+
+extern "C" int pxg_process_batch(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
+                                 const int64_t* raw_offsets, const pxg_calib* calib,
+                                 const float* scale_shift_or_null, uint32_t stage_mask,
+                                 pxg_read_result* out)
+{
+    if (!ctx) return PXG_E_INVALID;
+    if (n_reads == 0) return PXG_OK;
+    int rc = pxg_batch_upload(ctx, n_reads, raw_arena, raw_offsets, calib, scale_shift_or_null);
+    if (rc) return rc;
+    if ((rc = pxg_batch_run(ctx, stage_mask))) return rc;
+    return pxg_batch_download(ctx, out);
+}
+
+// ---------------------------------------------------------------------------
+// stage hooks: host arrays in, host arrays out, through the same kernels
+// ---------------------------------------------------------------------------
+struct Scratch {               // RAII device temporaries for the hooks
+    std::vector<void*> ptrs;
+    ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+    template <typename T>
+    T* alloc(size_t n)
+    {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return (T*)p;
+    }
+    template <typename T>
+    T* put(const T* src, size_t n, hipStream_t s)
+    {
+        T* d = alloc<T>(n);
+        if (d && n) (void)hipMemcpyAsync(d, src, n * sizeof(T), hipMemcpyHostToDevice, s);
+        return d;
+    }
+};
+
+#define HOOK_BEGIN                                           \
+    if (!ctx) return PXG_E_INVALID;                          \
+    PXG_HIP(ctx, hipSetDevice(ctx->device));                 \
+    Scratch S;
+#define HOOK_CHECK(p) if (!(p)) return fail(ctx, PXG_E_NOMEM, "hook scratch allocation failed")
+#define HOOK_GET(dst, src, n) \
+    PXG_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(*(dst)), hipMemcpyDeviceToHost, ctx->stream))
+#define HOOK_END                                             \
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));         \
+    PXG_HIP(ctx, hipGetLastError());                         \
+    return PXG_OK;
+
+extern "C" int pxg_raw_to_pa(pxg_ctx* ctx, int64_t n, const int16_t* raw, const pxg_calib* calib,
+                             float* out)
+{
+    HOOK_BEGIN
+    if (n <= 0) return PXG_OK;
+    int16_t* d_raw = S.put(raw, (size_t)n, ctx->stream);
+    float* d_out = S.alloc<float>((size_t)n);
+    HOOK_CHECK(d_raw && d_out);
+    int rc = pxg_launch_raw_to_pa(ctx, n, d_raw, calib, d_out);
+    if (rc) return rc;
+    HOOK_GET(out, d_out, n);
+    HOOK_END
+}
+
+extern "C" int pxg_head_pool(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
+                             const pxg_calib* calib, float* out, int32_t* status)
+{
+    HOOK_BEGIN
+    if (n <= 0) return PXG_OK;
+    const size_t width = (size_t)(ctx->cfg.scaler_length / ctx->cfg.stride);
+    int16_t* d_raw = S.put(raw, (size_t)off[n], ctx->stream);
+    int64_t* d_off = S.put(off, (size_t)n + 1, ctx->stream);
+    pxg_calib* d_cal = S.put(calib, (size_t)n, ctx->stream);
+    float* d_out = S.alloc<float>((size_t)n * width);
+    int32_t* d_st = S.alloc<int32_t>((size_t)n);
+    HOOK_CHECK(d_raw && d_off && d_cal && d_out && d_st);
+    int rc = pxg_launch_head_pool(ctx, n, d_raw, d_off, d_cal, d_out, d_st);
+    if (rc) return rc;
+    HOOK_GET(out, d_out, (size_t)n * width);
+    HOOK_GET(status, d_st, n);
+    HOOK_END
+}
+
+extern "C" int pxg_scaler_lstm(pxg_ctx* ctx, int64_t n, const float* head, float* pred)
+{
+    HOOK_BEGIN
+    if (n <= 0) return PXG_OK;
+    const size_t width = (size_t)(ctx->cfg.scaler_length / ctx->cfg.stride);
+    float* d_head = S.put(head, (size_t)n * width, ctx->stream);
+    float* d_pred = S.alloc<float>((size_t)n * 2);
+    HOOK_CHECK(d_head && d_pred);
+    int rc = pxg_launch_scaler_lstm(ctx, n, nullptr, nullptr, d_head, d_pred);
+    if (rc) return rc;
+    HOOK_GET(pred, d_pred, (size_t)n * 2);
+    HOOK_END
+}
+
+extern "C" int pxg_scaler_transform(pxg_ctx* ctx, int64_t n, const float* pred, float* scale_shift,
+                                    int32_t* status)
+{
+    HOOK_BEGIN
+    if (n <= 0) return PXG_OK;
+    float* d_pred = S.put(pred, (size_t)n * 2, ctx->stream);
+    float* d_ss = S.alloc<float>((size_t)n * 2);
+    int32_t* d_st = S.alloc<int32_t>((size_t)n);
+    HOOK_CHECK(d_pred && d_ss && d_st);
+    int rc = pxg_launch_scaler_transform(ctx, n, d_pred, d_ss, d_st, nullptr, nullptr);
+    if (rc) return rc;
+    HOOK_GET(scale_shift, d_ss, (size_t)n * 2);
+    HOOK_GET(status, d_st, n);
+    HOOK_END
+}
+
+extern "C" int pxg_pool_scale(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
+                              const pxg_calib* calib, const float* scale_shift,
+                              const int64_t* pooled_offsets, float* out)
+{
+    HOOK_BEGIN
+    if (n <= 0) return PXG_OK;
+    int16_t* d_raw = S.put(raw, (size_t)off[n], ctx->stream);
+    int64_t* d_off = S.put(off, (size_t)n + 1, ctx->stream);
+    pxg_calib* d_cal = S.put(calib, (size_t)n, ctx->stream);
+    float* d_ss = S.put(scale_shift, (size_t)n * 2, ctx->stream);
+    int64_t* d_poff = S.put(pooled_offsets, (size_t)n + 1, ctx->stream);
+    float* d_out = S.alloc<float>((size_t)pooled_offsets[n]);
+    HOOK_CHECK(d_raw && d_off && d_cal && d_ss && d_poff && d_out);
+    int rc = pxg_launch_pool_scale(ctx, n, d_raw, d_off, d_cal, d_ss, d_poff, d_out);
+    if (rc) return rc;
+    HOOK_GET(out, d_out, (size_t)pooled_offsets[n]);
+    HOOK_END
+}
+
+extern "C" int pxg_viterbi(pxg_ctx* ctx, int which_model, int64_t n, const float* signal_arena,
+                           const int64_t* off, int32_t* seg_first, int32_t* seg_last,
+                           int32_t* path_or_null, double* logp_or_null)
+{
+    HOOK_BEGIN
+    if (n <= 0) return PXG_OK;
+    if (which_model < 0 || which_model > 1) return fail(ctx, PXG_E_INVALID, "which_model");
+    for (int64_t i = 0; i < n; i++)
+        if (off[i + 1] - off[i] >= 65535)
+            return fail(ctx, PXG_E_UNSUPPORTED, "pxg_viterbi: sequences must be < 65535 steps");
+    float* d_sig = S.put(signal_arena, (size_t)off[n], ctx->stream);
+    int64_t* d_off = S.put(off, (size_t)n + 1, ctx->stream);
+    int32_t* d_segs = S.alloc<int32_t>((size_t)n * 2 * PXG_N_SEGMENTS);
+    double* d_logp = S.alloc<double>((size_t)n);
+    HOOK_CHECK(d_sig && d_off && d_segs && d_logp);
+    int rc = pxg_launch_viterbi_f32(ctx, which_model, n, d_sig, d_off, d_segs, d_logp);
+    if (rc) return rc;
+    std::vector<int32_t> segs((size_t)n * 2 * PXG_N_SEGMENTS);
+    HOOK_GET(segs.data(), d_segs, segs.size());
+    if (logp_or_null) HOOK_GET(logp_or_null, d_logp, n);
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < n; i++) {
+        const int32_t* f = &segs[(size_t)i * 2 * PXG_N_SEGMENTS];
+        const int32_t* l = f + PXG_N_SEGMENTS;
+        for (int s = 0; s < PXG_N_SEGMENTS; s++) {
+            seg_first[i * PXG_N_SEGMENTS + s] = f[s];
+            seg_last[i * PXG_N_SEGMENTS + s] = l[s];
+            if (path_or_null && f[s] >= 0)     // left-to-right: runs ARE the path
+                for (int t = f[s]; t <= l[s]; t++) path_or_null[off[i] + t] = s;
+        }
+    }
+    HOOK_END
+}
+
+extern "C" int pxg_barcode_window(pxg_ctx* ctx, int64_t n, const float* signal_arena,
+                                  const int64_t* off, float* out, int8_t* pushed)
+{
+    HOOK_BEGIN
+    if (n <= 0) return PXG_OK;
+    const size_t trim = (size_t)ctx->cfg.signal_trim_length;
+    float* d_sig = S.put(signal_arena, (size_t)off[n], ctx->stream);
+    int64_t* d_off = S.put(off, (size_t)n + 1, ctx->stream);
+    float* d_out = S.alloc<float>((size_t)n * trim);
+    int8_t* d_push = S.alloc<int8_t>((size_t)n);
+    HOOK_CHECK(d_sig && d_off && d_out && d_push);
+    PXG_HIP(ctx, hipMemsetAsync(d_out, 0, (size_t)n * trim * sizeof(float), ctx->stream));
+    int rc = pxg_launch_barcode_window_f32(ctx, n, d_sig, d_off, d_out, d_push);
+    if (rc) return rc;
+    HOOK_GET(out, d_out, (size_t)n * trim);
+    HOOK_GET(pushed, d_push, n);
+    HOOK_END
+}
+
+extern "C" int pxg_demux_lstm(pxg_ctx* ctx, int64_t n, const float* win, float* probs)
+{
+    HOOK_BEGIN
+    if (n <= 0) return PXG_OK;
+    const size_t trim = (size_t)ctx->cfg.signal_trim_length;
+    const int C = ctx->cfg.demux_dense.out_dim;
+    float* d_win = S.put(win, (size_t)n * trim, ctx->stream);
+    float* d_bidir = S.alloc<float>((size_t)n * trim * 96);
+    float* d_probs = S.alloc<float>((size_t)n * PXG_MAX_CLASSES);
+    HOOK_CHECK(d_win && d_bidir && d_probs);
+    int rc = pxg_launch_demux_lstm(ctx, n, nullptr, nullptr, d_win, d_bidir, d_probs,
+                                   PXG_T_DEMUX_BIDIR, PXG_T_DEMUX_TOP);
+    if (rc) return rc;
+    std::vector<float> tmp((size_t)n * PXG_MAX_CLASSES);
+    HOOK_GET(tmp.data(), d_probs, tmp.size());
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < n; i++)
+        for (int j = 0; j < C; j++) probs[i * C + j] = tmp[(size_t)i * PXG_MAX_CLASSES + j];
+    HOOK_END
+}
+
+extern "C" int pxg_detect_events(pxg_ctx* ctx, int64_t, const float*, const int64_t*, int64_t,
+                                 pxg_event*, int64_t*)
+{
+    return fail(ctx, PXG_E_UNSUPPORTED, "pxg_detect_events: event-detection kernel not built yet");
+}

@@ -1,0 +1,227 @@
+// pxg_common.h -- internal declarations shared by the HIP translation units of
+// libpxg.so (gfx950 only).  Public ABI: include/pxg.h.
+//
+// Compile flags that are part of the numerics:
+//   -ffp-contract=off   every fused multiply-add is an explicit __builtin_fmaf;
+//                       a*b+c written as two operations stays two roundings,
+//                       exactly as the reference's NumPy/TF expressions do.
+//   default f32 denormal mode (preserve) and correctly rounded f32 division.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/pxg.h"
+
+#define PXG_WAVE 64
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------
+// Canonical float32 transcendental kit (DESIGN.md "Canonical LSTM
+// arithmetic"): only IEEE +,*,/,fma and integer ops, so results are bitwise
+// reproducible on any IEEE machine.  exp: Cody-Waite reduction by ln2 (hi/lo),
+// degree-7 Taylor/Horner in fma form, exponent insertion.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float pxg_expf(float x)
+{
+    const float magic = 12582912.0f;  // 1.5 * 2^23
+    float t = __builtin_fmaf(x, 1.44269504088896341f, magic);
+    float n = t - magic;
+    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.98412698412698413e-4f;
+    p = __builtin_fmaf(p, r, 1.38888888888888894e-3f);
+    p = __builtin_fmaf(p, r, 8.33333333333333322e-3f);
+    p = __builtin_fmaf(p, r, 4.16666666666666644e-2f);
+    p = __builtin_fmaf(p, r, 1.66666666666666657e-1f);
+    p = __builtin_fmaf(p, r, 0.5f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    p = __builtin_fmaf(p, r, 1.0f);
+    float res = __int_as_float(__float_as_int(p) + ((int)n << 23));
+    res = x > 88.0f ? __builtin_inff() : res;
+    res = x < -87.0f ? 0.0f : res;
+    return res;
+}
+
+__device__ __forceinline__ float pxg_sigmoid(float x)
+{
+    return 1.0f / (1.0f + pxg_expf(-x));
+}
+
+__device__ __forceinline__ float pxg_tanh(float x)
+{
+    float s = 1.0f / (1.0f + pxg_expf(-(2.0f * x)));
+    return 2.0f * s - 1.0f;
+}
+
+// DAQ counts -> pA (fast5_file.py:130-131): float64 product, one cast.
+__device__ __forceinline__ float pxg_raw2pa(int16_t raw, double k, double offset)
+{
+    return (float)(k * ((double)raw + offset));
+}
+
+// NumPy float32 pairwise add.reduce of exactly `stride` pA values starting at
+// raw[0] (n < 8: sequential; 8..128: eight partial sums + tail), then the
+// float32 true-divide of numpy's mean (signal_loader.py:224-225).
+__device__ __forceinline__ float pxg_block_mean(const int16_t* __restrict__ raw, int stride,
+                                                double k, double offset)
+{
+    float s;
+    if (stride < 8) {
+        s = 0.0f;
+        for (int i = 0; i < stride; i++) s += pxg_raw2pa(raw[i], k, offset);
+    } else {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) r[j] = pxg_raw2pa(raw[j], k, offset);
+        int i = 8;
+        for (; i < stride - (stride % 8); i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) r[j] += pxg_raw2pa(raw[i + j], k, offset);
+        }
+        s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < stride; i++) s += pxg_raw2pa(raw[i], k, offset);
+    }
+    s = 0.0f + s;
+    return s / (float)stride;
+}
+
+// ---------------------------------------------------------------------------
+// host-side context
+// ---------------------------------------------------------------------------
+struct PxgHmmDev {           // device image of one HMM (by-value kernel argument)
+    int n_states;
+    int adapter_state, polya_state;
+    int left_to_right;       // every edge i->j has j >= i (config order)
+    int max_in;              // largest in-degree
+    int n_mix[PXG_MAX_STATES];
+    int order[PXG_MAX_STATES];                 // states in name-sorted order
+    int in_src[PXG_MAX_STATES][PXG_MAX_STATES]; // in-edge sources, name-sorted; -1 unused
+    double in_logp[PXG_MAX_STATES][PXG_MAX_STATES];
+    double log_start[PXG_MAX_STATES];
+    double mu[PXG_MAX_STATES][PXG_MAX_MIXTURE];
+    double lssp[PXG_MAX_STATES][PXG_MAX_MIXTURE];   // -log(sigma*sqrt(2pi))
+    double tss[PXG_MAX_STATES][PXG_MAX_MIXTURE];    // 1/(2 sigma^2)
+    double logw[PXG_MAX_STATES][PXG_MAX_MIXTURE];   // log(w/sum w)
+};
+
+struct PxgLstmDev {          // one LSTM layer's weights in HBM (Keras layout)
+    int input_dim = 0, units = 0;
+    float* kernel = nullptr;
+    float* recurrent = nullptr;
+    float* bias = nullptr;
+};
+
+struct PxgDenseDev {
+    int in_dim = 0, out_dim = 0;
+    float* kernel = nullptr;
+    float* bias = nullptr;
+};
+
+template <typename T>
+struct DevBuf {              // grow-only device arena
+    T* p = nullptr;
+    size_t cap = 0;
+};
+
+struct pxg_ctx {
+    pxg_config cfg;
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    PxgHmmDev hmm[2];
+    PxgLstmDev scaler1, scaler2, demux_fwd, demux_bwd, demux_top;
+    PxgDenseDev scaler_dense, demux_dense;
+    double* d_calibration = nullptr;
+
+    // resident batch
+    int64_t n_reads = 0;
+    int64_t n_samples = 0;
+    bool have_inject = false;
+    DevBuf<int16_t> raw;
+    DevBuf<int64_t> offsets;
+    DevBuf<pxg_calib> calib;
+    DevBuf<float> inject;        // n x 2
+    DevBuf<float> head;          // n x head_width
+    DevBuf<float> pred;          // n x 2
+    DevBuf<float> ss;            // n x 2
+    DevBuf<int32_t> status;      // n
+    DevBuf<int32_t> segs;        // n x 2 x PXG_N_SEGMENTS
+    DevBuf<int32_t> idx_scaler;  // compacted read indices
+    DevBuf<int32_t> idx_demux;
+    DevBuf<int32_t> counters;    // [0] scaler count, [1] demux count
+    DevBuf<float> win;           // n x trim
+    DevBuf<float> bidir;         // n x trim x (Hf+Hb), permuted layout
+    DevBuf<float> probs;         // n x PXG_MAX_CLASSES
+    DevBuf<pxg_read_result> results;
+
+    hipEvent_t ev_start[PXG_N_TIMERS];
+    hipEvent_t ev_stop[PXG_N_TIMERS];
+    bool ev_used[PXG_N_TIMERS];
+    int64_t launches[PXG_N_TIMERS];
+};
+
+#define PXG_HIP(ctx, call)                                                          \
+    do {                                                                            \
+        hipError_t e__ = (call);                                                    \
+        if (e__ != hipSuccess) {                                                    \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);        \
+            return PXG_E_HIP;                                                       \
+        }                                                                           \
+    } while (0)
+
+template <typename T>
+static inline int pxg_reserve(pxg_ctx* ctx, DevBuf<T>& b, size_t n)
+{
+    if (n <= b.cap && b.p) return PXG_OK;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc((void**)&b.p, want * sizeof(T));
+    if (e != hipSuccess) {
+        ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        return PXG_E_NOMEM;
+    }
+    b.cap = want;
+    return PXG_OK;
+}
+
+// ---- kernel launchers (defined in the k_*.hip units) -----------------------
+int pxg_launch_head_pool(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
+                         const pxg_calib* cal, float* head, int32_t* status);
+int pxg_launch_raw_to_pa(pxg_ctx* ctx, int64_t n, const int16_t* raw, const pxg_calib* cal,
+                         float* out);
+int pxg_launch_pool_scale(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
+                          const pxg_calib* cal, const float* ss, const int64_t* poff,
+                          float* out);
+int pxg_launch_scaler_transform(pxg_ctx* ctx, int64_t n, const float* pred, float* ss,
+                                int32_t* status, const int32_t* idx, const int32_t* count);
+// segmentation of raw reads (pool + scale + Viterbi + run summary)
+int pxg_launch_segment_raw(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
+                           const pxg_calib* cal, const float* ss, const int32_t* status,
+                           int32_t* segs);
+// Viterbi on already pooled float signals (test hook)
+int pxg_launch_viterbi_f32(pxg_ctx* ctx, int which, int64_t n, const float* sig,
+                           const int64_t* off, int32_t* segs, double* logp);
+int pxg_launch_barcode_window_raw(pxg_ctx* ctx, int64_t n, const int16_t* raw,
+                                  const int64_t* off, const pxg_calib* cal, const float* ss,
+                                  const int32_t* status, const int32_t* segs, float* win,
+                                  int32_t* idx_demux, int32_t* counter);
+int pxg_launch_barcode_window_f32(pxg_ctx* ctx, int64_t n, const float* sig,
+                                  const int64_t* off, float* win, int8_t* pushed);
+int pxg_launch_compact_scaler(pxg_ctx* ctx, int64_t n, const int32_t* status, int32_t* idx,
+                              int32_t* counter);
+int pxg_launch_scaler_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
+                           const int32_t* count, const float* head, float* pred);
+int pxg_launch_demux_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
+                          const int32_t* count, const float* win, float* bidir, float* probs,
+                          int timer_a, int timer_b);
+int pxg_launch_finalize(pxg_ctx* ctx, int64_t n, uint32_t stage_mask);
+int pxg_lstm_upload(pxg_ctx* ctx);   // weight repacking, if any
+
+void pxg_timer_begin(pxg_ctx* ctx, int t);
+void pxg_timer_end(pxg_ctx* ctx, int t);

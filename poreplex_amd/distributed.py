@@ -1,0 +1,100 @@
+"""Multi-GPU sharding of a run: reads are independent units.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, gloo on
+CPU for tests).  The data path has NO collective: rank r owns the contiguous
+block of reads [floor(r*n/R), floor((r+1)*n/R)).  Only the end-of-batch
+bookkeeping is exchanged: an all-gather of fixed-size label records
+(LABEL_DTYPE, 16 B/read) and an all-reduce(sum) of the int64 count table
+[label x barcode slot x status] that the summary writers consume
+(reference: io.py:236-332 FinalSummaryTracker counts the same keys).
+"""
+import numpy as np
+
+from . import native as N
+
+LABEL_DTYPE = np.dtype([('read_index', '<i4'), ('status', 'i1'), ('label', 'i1'),
+                        ('barcode', 'i1'), ('phred', 'u1'), ('score', '<f4'),
+                        ('adapter_end', '<i4')])
+assert LABEL_DTYPE.itemsize == 16
+
+LABEL_NAMES = ('pass', 'fail', 'artifact')
+N_BARCODE_SLOTS = 5     # undetermined + BC1..BC4 (commandline.py:137-159)
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous block of rank `rank` among `world` ranks."""
+    return (rank * n_items) // world, ((rank + 1) * n_items) // world
+
+
+def shard_by_samples(lengths, world, cap=100000, fixed_cost=30000):
+    """Balanced contiguous split when read lengths are skewed: cost of a read =
+    min(len, scan limit) + a constant for the fixed-size recurrent nets."""
+    cost = np.minimum(np.asarray(lengths, dtype=np.int64), cap) + fixed_cost
+    csum = np.concatenate([[0], np.cumsum(cost)])
+    bounds = [int(np.searchsorted(csum, csum[-1] * r / world)) for r in range(world)] + [len(cost)]
+    bounds[0] = 0
+    return [(bounds[r], max(bounds[r], bounds[r + 1])) for r in range(world)]
+
+
+def label_records(results, first_index=0, adapter_state=3):
+    """Compact per-read label records from pxg_read_result rows.  `label`
+    here is the numeric-stage verdict (0 pass / 1 fail); the facade refines it
+    with base-space checks (signal_analyzer.py:275-286)."""
+    rec = np.zeros(len(results), dtype=LABEL_DTYPE)
+    rec['read_index'] = first_index + np.arange(len(results), dtype=np.int32)
+    rec['status'] = results['status']
+    rec['label'] = np.where(results['status'] == 0, 0, 1)
+    rec['barcode'] = np.where(results['bc_called'] == 1, results['bc_label'], -1)
+    rec['phred'] = results['bc_phred']
+    rec['score'] = results['bc_score']
+    rec['adapter_end'] = results['seg_last'][:, adapter_state]
+    return rec
+
+
+def count_table(records):
+    """int64 [3 labels, 5 barcode slots, n statuses] histogram."""
+    tbl = np.zeros((len(LABEL_NAMES), N_BARCODE_SLOTS, len(N.STATUS_NAMES)), dtype=np.int64)
+    np.add.at(tbl, (records['label'].astype(np.int64), records['barcode'].astype(np.int64) + 1,
+                    records['status'].astype(np.int64)), 1)
+    return tbl
+
+
+def _device_for(dist):
+    import torch
+    return torch.device('cuda', torch.cuda.current_device()) \
+        if dist.get_backend() == 'nccl' else torch.device('cpu')
+
+
+def gather_labels(results, dist=None, first_index=0):
+    """All-gather the label records of every rank (ragged shards are padded to
+    the largest shard).  dist=None or world 1: local records only."""
+    rec = label_records(results, first_index)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return rec
+    import torch
+    world = dist.get_world_size()
+    dev = _device_for(dist)
+    n_local = torch.tensor([len(rec)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n_local)
+    sizes = [int(s.item()) for s in sizes]
+    nmax = max(sizes)
+    buf = np.zeros(nmax, dtype=LABEL_DTYPE)
+    buf[:len(rec)] = rec
+    mine = torch.from_numpy(buf.view(np.uint8).reshape(nmax, LABEL_DTYPE.itemsize)).to(dev)
+    out = torch.empty((world * nmax, LABEL_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, mine)
+    allrec = out.cpu().numpy().reshape(world, nmax * LABEL_DTYPE.itemsize)
+    parts = [np.frombuffer(allrec[r].tobytes(), dtype=LABEL_DTYPE)[:sizes[r]] for r in range(world)]
+    return np.concatenate(parts)
+
+
+def reduce_counts(records, dist=None):
+    """All-reduce(sum) of the local count table."""
+    tbl = count_table(records)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return tbl
+    import torch
+    t = torch.from_numpy(tbl).to(_device_for(dist))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()

@@ -119,7 +119,6 @@ class PxgReadResult(C.Structure):
         ('polya_called', C.c_int8), ('polya_n_spikes', C.c_int8), ('reserved', C.c_int16),
         ('polya_dwell_samples', C.c_int32),
         ('polya_begin', C.c_int64), ('polya_end', C.c_int64),
-        ('polya_spikes', (C.c_float * 4) * PXG_MAX_SPIKES),
     ]
 
 
@@ -149,7 +148,6 @@ RESULT_DTYPE = np.dtype([
     ('bc_score', '<f4'), ('probs', '<f4', (PXG_MAX_CLASSES,)),
     ('polya_called', 'i1'), ('polya_n_spikes', 'i1'), ('reserved', '<i2'),
     ('polya_dwell_samples', '<i4'), ('polya_begin', '<i8'), ('polya_end', '<i8'),
-    ('polya_spikes', '<f4', (PXG_MAX_SPIKES, 4)),
 ], align=True)
 CALIB_DTYPE = np.dtype([('range', '<f8'), ('digitisation', '<f8'),
                         ('offset', '<f8'), ('sampling_rate', '<f8')])
@@ -319,6 +317,7 @@ _SIGNATURES = {
     'pxg_batch_run': (C.c_int, [C.c_void_p, C.c_uint32]),
     'pxg_batch_sync': (C.c_int, [C.c_void_p]),
     'pxg_batch_download': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'pxg_batch_download_spikes': (C.c_int, [C.c_void_p, C.c_void_p]),
     'pxg_batch_times': (C.c_int, [C.c_void_p, C.POINTER(PxgStageTimes)]),
     'pxg_batch_synthesize': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64]),
     'pxg_raw_to_pa': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -1,0 +1,202 @@
+"""HIP path (through the C ABI, libpxg.so) vs the oracle and the reference
+goldens.  Everything here needs a real MI355X: run with `-m gpu`.
+
+Bar (north_star): bit-exact for integer/byte/index work -- and, because the
+LSTM arithmetic is canonical, bit-exact for the float outputs too;
+the 1e-4 softmax tolerance is kept as the documented fallback bound.
+"""
+import numpy as np
+import pytest
+
+from poreplex_amd import native as N
+from poreplex_amd.synth import synth_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def reads_of(bundle):
+    o = bundle['offsets']
+    return [bundle['arena'][o[i]:o[i + 1]] for i in range(len(o) - 1)]
+
+
+def assert_records_equal(got, want, fields=None, ctxmsg=''):
+    for f in fields or got.dtype.names:
+        a, b = got[f], want[f]
+        if not np.array_equal(a, b, equal_nan=True):
+            bad = np.nonzero([not np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b)])[0]
+            raise AssertionError('{} field {!r}: {} reads differ, first {}: got {} want {}'.format(
+                ctxmsg, f, len(bad), bad[0], a[bad[0]], b[bad[0]]))
+
+
+# ---- a1 / a2 / a5 -----------------------------------------------------------
+def test_raw_to_pa_bit_exact(ctx, oracle, bundle, stages):
+    for i, raw in enumerate(reads_of(bundle)[:8]):
+        got = ctx.raw_to_pa(raw, bundle['calib'][i])
+        assert np.array_equal(got, oracle.raw_to_pa(raw, bundle['calib'][i]))
+        assert np.array_equal(got[:64], stages['pa64'][i, :min(64, len(got))])
+
+
+def test_head_pool_vs_reference_golden(ctx, bundle, stages):
+    head, status = ctx.head_pool(bundle['arena'], bundle['offsets'], bundle['calib'])
+    for i in range(len(status)):
+        if stages['head_ok'][i]:
+            assert status[i] == 0
+            assert np.array_equal(head[i], stages['head'][i]), i
+        else:
+            assert status[i] == N.STATUS_CODE['scaler_signal_too_short']
+
+
+def test_pool_scale_vs_oracle(ctx, oracle, bundle):
+    ss = bundle['true_scale_shift']
+    out, poff = ctx.pool_scale(bundle['arena'], bundle['offsets'], bundle['calib'], ss)
+    for i, raw in enumerate(reads_of(bundle)):
+        want = oracle.pool_scale(raw, bundle['calib'][i], ss[i, 0], ss[i, 1])
+        assert np.array_equal(out[poff[i]:poff[i + 1]], want), i
+
+
+def test_empty_and_tiny_reads(ctx, oracle, config):
+    # ragged edge cases: empty read, shorter than one stride, exactly the gate
+    rng = np.random.default_rng(1)
+    lens = [0, 7, 15, 8999, 9000, 9014, 9015, 30000, 30001]
+    sigs = [rng.integers(300, 700, n).astype(np.int16) for n in lens]
+    arena, off = N.pack_reads(sigs)
+    calib = np.zeros(len(lens), N.CALIB_DTYPE)
+    calib['range'], calib['digitisation'], calib['offset'], calib['sampling_rate'] = 1200, 8192, 7, 3012
+    got = ctx.process_batch(arena, off, calib)
+    want = oracle.process_batch(arena, off, calib)
+    assert_records_equal(got, want, ctxmsg='edge')
+    assert (got['status'][:4] == N.STATUS_CODE['scaler_signal_too_short']).all()
+
+
+# ---- a4: scaler network ------------------------------------------------------
+@pytest.mark.parametrize('n', [1, 16, 17, 70])
+def test_scaler_lstm_bit_exact(ctx, oracle, stages, n):
+    heads = stages['scaler_in']
+    rng = np.random.default_rng(n)
+    rows = np.stack([heads[i % len(heads)] for i in range(n)]).copy()
+    rows[n // 2:] += rng.normal(0, 2, rows[n // 2:].shape).astype(np.float32)
+    got = ctx.scaler_lstm(rows)
+    want = np.stack([oracle.scaler_forward(r) for r in rows])
+    assert np.array_equal(got, want), np.abs(got - want).max()
+
+
+def test_scaler_transform_vs_reference_golden(ctx, unit):
+    ss, status = ctx.scaler_transform(unit['xfrm_pred'])
+    ok = status == 0
+    assert np.array_equal(ok, unit['xfrm_ok'].astype(bool))
+    assert np.array_equal(ss[ok], unit['xfrm_ss'][ok])
+
+
+# ---- a7 / a8: Viterbi ----------------------------------------------------------
+def test_viterbi_segments_vs_oracle(ctx, oracle, stages):
+    po = stages['pooled_offsets']
+    scan = oracle.cfg.segmentation_scan_limit // oracle.cfg.stride
+    sigs, idx = [], []
+    for i in range(len(po) - 1):
+        if stages['has_seg'][i]:
+            sigs.append(stages['pooled_arena'][po[i]:po[i + 1]][:scan])
+            idx.append(i)
+    first, last, paths, logp = ctx.viterbi(sigs, want_path=True)
+    for k, i in enumerate(idx):
+        assert np.array_equal(first[k], stages['seg_first'][i]), i
+        assert np.array_equal(last[k], stages['seg_last'][i]), i
+        olp, opath = oracle.viterbi(sigs[k])
+        assert np.array_equal(paths[k], opath)
+        assert abs(logp[k] - olp) <= 1e-9 * abs(olp)
+
+
+def test_viterbi_short_sequences(ctx, oracle):
+    rng = np.random.default_rng(4)
+    sigs = [rng.choice([71.5, 102, 112, 80, 109, 95], n).astype(np.float32) +
+            rng.normal(0, 2, n).astype(np.float32) for n in (1, 2, 3, 5, 9, 63, 64, 65, 129)]
+    first, last, paths, logp = ctx.viterbi(sigs, want_path=True)
+    for k, s in enumerate(sigs):
+        olp, opath = oracle.viterbi(s)
+        assert np.array_equal(paths[k], opath), k
+        assert abs(logp[k] - olp) <= 1e-9 * max(1.0, abs(olp))
+
+
+# ---- a9-a12 ------------------------------------------------------------------------
+def test_barcode_window_vs_reference_golden(ctx, unit):
+    off = np.concatenate([[0], np.cumsum(unit['ns_len'])])
+    sigs = [unit['ns_in'][off[k]:off[k + 1]] for k in range(len(unit['ns_len']))]
+    out, pushed = ctx.barcode_window(sigs)
+    assert np.array_equal(pushed.astype(bool), unit['push_flag'].astype(bool))
+    for k in range(len(sigs)):
+        if pushed[k]:
+            assert np.array_equal(out[k], unit['push_out'][k]), k
+
+
+@pytest.mark.parametrize('n', [1, 15, 33, 64])
+def test_demux_lstm_bit_exact(ctx, oracle, stages, n):
+    wins = stages['demux_in']
+    rng = np.random.default_rng(n)
+    rows = np.stack([wins[i % len(wins)] for i in range(n)]).copy()
+    rows[n // 2:] = np.roll(rows[n // 2:], 3, axis=1)
+    got = ctx.demux_lstm(rows)
+    want = np.stack([oracle.demux_forward(r) for r in rows])
+    assert np.abs(got - want).max() <= 1e-4          # north_star bound
+    assert np.array_equal(got, want), np.abs(got - want).max()
+    assert np.array_equal(got.argmax(1), want.argmax(1))
+
+
+# ---- whole path ------------------------------------------------------------------
+def test_process_batch_golden_bundle(ctx, oracle, bundle):
+    for inject in (None, bundle['true_scale_shift']):
+        got = ctx.process_batch(bundle['arena'], bundle['offsets'], bundle['calib'], inject)
+        want = oracle.process_batch(bundle['arena'], bundle['offsets'], bundle['calib'], inject)
+        assert_records_equal(got, want, ctxmsg='golden inject=%s' % (inject is not None))
+    assert set(N.STATUS_NAMES[s] for s in got['status']) >= {'okay', 'scaler_signal_too_short'}
+
+
+def test_process_batch_reference_statuses(ctx, bundle, ref_results):
+    """Statuses / barcode calls against what the REAL reference process_batch
+    reported for the same reads (tests/golden/batch0.results.json)."""
+    got = ctx.process_batch(bundle['arena'], bundle['offsets'], bundle['calib'])
+    by_id = {r.get('read_id'): r for r in ref_results['results'] if 'read_id' in r}
+    for i, rid in enumerate(bundle['read_id']):
+        want = by_id[str(rid)]
+        st = want['status']
+        if st in ('not_basecalled', 'sequence_too_short', 'okay'):
+            st = 'okay'
+        assert N.STATUS_NAMES[got['status'][i]] == st, (i, want['status'])
+        assert ('barcode' in want) == bool(got['bc_called'][i])
+
+
+def test_process_batch_synthetic_300(ctx, oracle):
+    b = synth_batch(300, seed=924, samples_per_read=40000, jitter=0.4, short_fraction=0.03)
+    got = ctx.process_batch(b['arena'], b['offsets'], b['calib'])
+    want = oracle.process_batch(b['arena'], b['offsets'], b['calib'])
+    assert_records_equal(got, want, ctxmsg='synthetic')
+    assert (got['status'] == 0).sum() > 250 and got['bc_pushed'].sum() > 200
+
+
+def test_stage_masks(ctx, oracle):
+    b = synth_batch(40, seed=925, samples_per_read=30000)
+    for mask, inj in ((N.STAGE_SCALER, None), (N.STAGE_SEGMENT, b['scale_shift']),
+                      (N.STAGE_SCALER | N.STAGE_SEGMENT, None),
+                      (N.STAGE_SEGMENT | N.STAGE_BARCODE, b['scale_shift'])):
+        got = ctx.process_batch(b['arena'], b['offsets'], b['calib'], inj, mask)
+        want = oracle.process_batch(b['arena'], b['offsets'], b['calib'], inj, mask)
+        assert_records_equal(got, want, ctxmsg='mask %d' % mask)
+
+
+# ---- BASELINE-size properties (no oracle at this size) ------------------------------
+def test_full_size_determinism_and_order_invariance(ctx):
+    b = synth_batch(4000, seed=926, samples_per_read=60000, short_fraction=0.01)
+    r1 = ctx.process_batch(b['arena'], b['offsets'], b['calib'])
+    r2 = ctx.process_batch(b['arena'], b['offsets'], b['calib'])
+    assert_records_equal(r1, r2, ctxmsg='rerun')
+    # per-read results must not depend on batch composition / tile placement
+    perm = np.random.default_rng(0).permutation(len(r1))[:1500]
+    sigs = [b['arena'][b['offsets'][i]:b['offsets'][i + 1]] for i in perm]
+    arena, off = N.pack_reads(sigs)
+    r3 = ctx.process_batch(arena, off, b['calib'][perm])
+    assert_records_equal(r3, r1[perm], ctxmsg='permuted')
+    ok = r1['status'] == 0
+    assert ok.mean() > 0.9
+    A = 3
+    assert (r1['seg_first'][ok, A] >= 0).all()
+    assert (r1['seg_last'][ok] < r1['n_pooled'][ok, None]).all()
+    p = r1['probs'][r1['bc_pushed'] == 1, :5]
+    assert np.abs(p.sum(1) - 1).max() < 1e-5

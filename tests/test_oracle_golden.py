@@ -179,8 +179,9 @@ def test_medfilt_matches_scipy(oracle):
 def test_full_path_matches_reference_process_batch(oracle, bundle, ref_results):
     """a14-a17, a20: statuses, segments-derived fields and poly(A) dicts of the
     real process_batch (measure_polya on) vs the oracle's whole-read path."""
-    res = oracle.process_batch(bundle['arena'], bundle['offsets'], bundle['calib'],
-                               stage_mask=N.STAGE_ALL_DEMUX | N.STAGE_POLYA)
+    res, spikes = oracle.process_batch(bundle['arena'], bundle['offsets'], bundle['calib'],
+                                       stage_mask=N.STAGE_ALL_DEMUX | N.STAGE_POLYA,
+                                       want_spikes=True)
     by_id = {r.get('read_id'): r for r in ref_results['results'] if 'read_id' in r}
     n_polya = n_spike_reads = 0
     for i, rid in enumerate(bundle['read_id']):
@@ -199,7 +200,7 @@ def test_full_path_matches_reference_process_batch(oracle, bundle, ref_results):
             assert got['polya_dwell_samples'] / rate == p['dwell_time']
             assert got['polya_n_spikes'] == len(p['spikes'])
             for k, sp in enumerate(p['spikes'][:N.PXG_MAX_SPIKES]):
-                assert np.array_equal(np.float32(sp), got['polya_spikes'][k]), (i, k)
+                assert np.array_equal(np.float32(sp), spikes[i, k]), (i, k)
             n_polya += 1
             n_spike_reads += len(p['spikes']) > 0
         else:
