@@ -5,26 +5,30 @@
 //
 // Why this shape (DESIGN.md "LSTM kernels"): per read the nets cost 148 MFLOP
 // of strictly sequential small GEMMs, so the bound is fp32 matrix throughput
-// and step latency, not HBM.  A workgroup owns 16*MTB reads for the whole
-// sequence.  Gate columns are split over waves so every wave keeps ITS weight
-// slice in VGPRs for all 2000 steps (B operand of v_mfma_f32_16x16x4_f32, one
-// VGPR per 4x16 block); hidden states are exchanged through LDS once per step
-// (A operand, read as 3-4 ds_read_b128 per tile thanks to a k-major row
-// layout); c-state never leaves registers.  Layer 2 of the scaler runs one step
-// behind layer 1 inside the same step, so both matmuls share the A fragments.
+// and step latency, not HBM.  A 4-wave workgroup owns 16..64 reads (1-4
+// "M-tiles" of 16 rows) for the whole sequence.  Gate columns are split over
+// the four waves so every wave keeps ITS weight slice in VGPRs for all steps (B
+// operand of v_mfma_f32_16x16x4_f32, one VGPR per 4x16 block); hidden states
+// are exchanged through LDS once per step (A operand, 3-4 ds_read_b128 per
+// tile thanks to a k-major row layout); c-state never leaves registers.  Layer 2
+// of the scaler runs one step behind layer 1 inside the same step so both
+// matmuls share their A fragments.  Two workgroups are resident per CU and
+// share no barrier, so one group's gate math (VALU) runs under the other's
+// MFMAs -- measured: a single 8-wave group per CU serialises the two pipes.
 //
 // Canonical arithmetic (bit-exact with oracle/pxo_core.c lstm_step): the MFMA
 // is a k-ordered fmaf chain, accumulator start = fl(fl(x*W)+b) (scalar input)
-// or b, chain over input rows then recurrent rows; gates via pxg_expf and IEEE
-// division; c' = fl(fl(f*c)+fl(i*g)); h = fl(o*tanh(c')).
+// or b, chain over input rows then recurrent rows; gates via pxg_expf/pxg_rcp;
+// c' = fl(fl(f*c)+fl(i*g)); h = fl(o*tanh(c')).
 //
 // Tile geometry: an N-tile is 16 gate columns = 4 units x 4 gates
 // (col = unit_local*4 + gate), so after the MFMA the four gates of one
-// (read, unit) sit in one lane quad; a 4x4 quad transpose (8 DPP moves) then
-// gives every lane one complete (read, unit) cell to update.
+// (read, unit) sit in one lane quad; a 4x4 quad transpose (DPP) then gives
+// every lane one complete (read, unit) cell to update.
 #include "pxg_common.h"
 
-#define LSTM_THREADS 512
+#define LSTM_THREADS 256
+#define LSTM_MAXT 4     // M-tiles per workgroup
 #define XCH 64          // scaler: steps of x staged per LDS refill
 #define XS (XCH + 4)    // padded row stride (floats)
 
@@ -33,7 +37,6 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-// quad-lane exchange via DPP quad_perm (no LDS)
 __device__ __forceinline__ float quad_xor1(float v)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
@@ -43,45 +46,58 @@ __device__ __forceinline__ float quad_xor2(float v)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
 }
 
-// k-major position of unit u inside a hidden-state row of H floats: lane
-// (row, k) of an A fragment then reads H/4 consecutive floats.
+// k-major position of unit u inside a hidden-state row of H floats
 template <int H>
 __device__ __forceinline__ int hpos(int u)
 {
     return (u & 3) * (H / 4) + (u >> 2);
 }
 
-// Gate activations + cell update for one 16x16 gate tile.
-//   acc[r]: pre-activation of gate (lane&3) of unit ((lane>>2)&3) for row
-//           (lane>>4)*4 + r.   Returns h for row (lane>>4)*4 + (lane&3).
-__device__ __forceinline__ float cell_update(f32x4 acc, float& c, int lane)
+// per-lane constants of the gate this lane activates in phase 1
+struct GateLane {
+    float nsc;   // -1 (sigmoid gates) or -2 (candidate gate: tanh(z) = 2*sigmoid(2z)-1)
+    float m2;    //  1 or 2
+    float sub;   //  0 or -1
+    bool b0, b1; // lane bits inside the quad
+};
+
+__device__ __forceinline__ GateLane gate_lane(int lane)
 {
-    const int g = lane & 3;
-    const bool is_tanh = (g == 2);
-    const float sc = is_tanh ? 2.0f : 1.0f;
+    GateLane g;
+    const bool is_tanh = (lane & 3) == 2;
+    g.nsc = is_tanh ? -2.0f : -1.0f;
+    g.m2 = is_tanh ? 2.0f : 1.0f;
+    g.sub = is_tanh ? -1.0f : 0.0f;
+    g.b0 = (lane & 1) != 0;
+    g.b1 = (lane & 2) != 0;
+    return g;
+}
+
+// Gate activations + cell update for one 16x16 gate tile.
+//   acc[r]: pre-activation of gate (lane&3) of unit ((lane>>2)&3), row (lane>>4)*4 + r.
+//   Returns h for row (lane>>4)*4 + (lane&3) of that unit.
+__device__ __forceinline__ float cell_update(f32x4 acc, float& c, const GateLane& g)
+{
     float a[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const float z = acc[r] * sc;
-        const float s = 1.0f / (1.0f + pxg_expf(-z));
-        const float t2 = 2.0f * s - 1.0f;
-        a[r] = is_tanh ? t2 : s;
+        const float s = pxg_rcp(1.0f + pxg_expf(acc[r] * g.nsc));
+        a[r] = __builtin_fmaf(s, g.m2, g.sub);     // s, or fl(2s-1) for the candidate gate
     }
-    // 4x4 transpose inside the lane quad: afterwards a[j] = gate j of row g
-    const bool b1 = (g & 2) != 0, b0 = (g & 1) != 0;
+    // 4x4 transpose inside the lane quad: afterwards a[j] = gate j of row (lane&3)
 #pragma unroll
     for (int r0 = 0; r0 < 2; r0++) {
         const float lo = a[r0], hi = a[2 + r0];
-        const float recv = quad_xor2(b1 ? lo : hi);
-        a[r0] = b1 ? recv : lo;
-        a[2 + r0] = b1 ? hi : recv;
+        const float recv = quad_xor2(g.b1 ? lo : hi);
+        a[r0] = g.b1 ? recv : lo;
+        a[2 + r0] = g.b1 ? hi : recv;
     }
 #pragma unroll
     for (int r1 = 0; r1 < 2; r1++) {
         const float ev = a[2 * r1], od = a[2 * r1 + 1];
-        const float recv = quad_xor1(b0 ? ev : od);
-        a[2 * r1] = b0 ? recv : ev;
-        a[2 * r1 + 1] = b0 ? od : recv;
+        const float recv = quad_xor1(g.b0 ? ev : od);
+        a[2 * r1] = g.b0 ? recv : ev;
+        a[2 * r1 + 1] = g.b0 ? od : recv;
     }
     const float fc = a[1] * c;
     const float ig = a[0] * a[2];
@@ -90,8 +106,8 @@ __device__ __forceinline__ float cell_update(f32x4 acc, float& c, int lane)
     return a[3] * pxg_tanh(cn);
 }
 
-// Load the B fragments (weights) of one gate tile: rows [row0, row0+4*KB) of a
-// Keras [rows, 4H] matrix, columns = 4 units x 4 gates of this tile.
+// B fragments (weights) of one gate tile: rows [row0, row0+4*KB) of a Keras
+// [rows, 4H] matrix, columns = 4 units x 4 gates of this tile.
 template <int H, int KB>
 __device__ __forceinline__ void load_wfrag(float (&w)[KB], const float* __restrict__ mat,
                                            int row0, int unit0, int lane)
@@ -102,7 +118,7 @@ __device__ __forceinline__ void load_wfrag(float (&w)[KB], const float* __restri
     for (int kb = 0; kb < KB; kb++) w[kb] = mat[(size_t)(row0 + kb * 4 + k) * (4 * H) + col];
 }
 
-// Load the A fragments of one 16-row tile: hidden row (lane&15), k = lane>>4.
+// A fragments of one 16-row tile: hidden row (lane&15), k = lane>>4.
 template <int H>
 __device__ __forceinline__ void load_afrag(float (&a)[H / 4], const float* hrow_base, int lane)
 {
@@ -114,37 +130,53 @@ __device__ __forceinline__ void load_afrag(float (&a)[H / 4], const float* hrow_
     }
 }
 
+// Balanced static split of the row tiles over the launched workgroups: the
+// first `rem` groups take one tile more.  With grid = 2 x #CU and dispatch
+// order b -> CU (b mod #CU) this pairs a heavy group with a light one per CU
+// (placement only affects speed, never results).
+__device__ __forceinline__ bool my_tiles(int lim_rows, int& tile0, int& ntile)
+{
+    const int n_tiles = (lim_rows + 15) >> 4;
+    const int nb = min((int)gridDim.x, n_tiles);
+    if ((int)blockIdx.x >= nb) return false;
+    const int base = n_tiles / nb, rem = n_tiles % nb;
+    const int b = blockIdx.x;
+    ntile = base + (b < rem ? 1 : 0);
+    tile0 = b * base + min(b, rem);
+    return true;
+}
+
 // ===========================================================================
-// K2: scaler.  block = 8 waves: slice = wave&3 owns units [12*slice, +12) of
-// BOTH layers; parity = wave>>2 picks the M-tiles {parity, parity+2}.
+// K2: scaler.  wave = slice: units [12*slice, +12) of BOTH layers.
 // ===========================================================================
 template <int MTW>
 __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
-    int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count,
-    int mtb, int T, const float* __restrict__ head, const float* __restrict__ W1,
-    const float* __restrict__ U1, const float* __restrict__ b1, const float* __restrict__ W2,
-    const float* __restrict__ U2, const float* __restrict__ b2, const float* __restrict__ Wd,
-    const float* __restrict__ bd, float* __restrict__ pred)
+    int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int T,
+    const float* __restrict__ head, const float* __restrict__ W1, const float* __restrict__ U1,
+    const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ U2,
+    const float* __restrict__ b2, const float* __restrict__ Wd, const float* __restrict__ bd,
+    float* __restrict__ pred)
 {
     constexpr int H = 48, NT = 3, KB = 12;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lim = count ? min(*count, n_rows) : n_rows;
-    const int row_base = blockIdx.x * 16 * mtb;
-    if (row_base >= lim) return;
+    int tile0, ntile;
+    if (!my_tiles(lim, tile0, ntile)) return;
+    const int row_base = tile0 * 16;
 
-    float* h1 = smem;                                  // [2][mtb][16][H]
-    float* h2 = h1 + 2 * mtb * 16 * H;                 // [2][mtb][16][H]
-    float* xb = h2 + 2 * mtb * 16 * H;                 // [16*mtb][XS]
-    int* ridx = reinterpret_cast<int*>(xb + 16 * mtb * XS);   // [16*mtb]
+    float* h1 = smem;                                  // [2][MTW][16][H]
+    float* h2 = h1 + 2 * MTW * 16 * H;                 // [2][MTW][16][H]
+    float* xb = h2 + 2 * MTW * 16 * H;                 // [16*MTW][XS]
+    int* ridx = reinterpret_cast<int*>(xb + 16 * MTW * XS);   // [16*MTW]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slice = wave & 3, par = wave >> 2;
+    const int tid = threadIdx.x, lane = tid & 63, slice = tid >> 6;
     const int R = lane >> 4, q = lane & 3, ul = (lane >> 2) & 3;
+    const GateLane gl = gate_lane(lane);
 
-    for (int i = tid; i < 4 * mtb * 16 * H; i += LSTM_THREADS) smem[i] = 0.0f;
-    for (int i = tid; i < 16 * mtb; i += LSTM_THREADS) {
+    for (int i = tid; i < 4 * MTW * 16 * H; i += LSTM_THREADS) smem[i] = 0.0f;
+    for (int i = tid; i < 16 * MTW; i += LSTM_THREADS) {
         const int row = row_base + i;
-        ridx[i] = row < lim ? (idx ? idx[row] : row) : -1;
+        ridx[i] = (i < 16 * ntile && row < lim) ? (idx ? idx[row] : row) : -1;
     }
 
     // ---- this wave's weight slice -> registers ------------------------------
@@ -175,7 +207,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
     for (int t = 0; t <= T; t++) {
         if ((t % XCH) == 0 && t < T) {        // refill the x tile (rows x XCH steps)
             __syncthreads();
-            for (int i = tid; i < 16 * mtb * (XCH / 4); i += LSTM_THREADS) {
+            for (int i = tid; i < 16 * MTW * (XCH / 4); i += LSTM_THREADS) {
                 const int row = i / (XCH / 4), c4 = i % (XCH / 4);
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 const int rd = ridx[row];
@@ -188,15 +220,14 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
         const int rdb = t & 1, wrb = (t + 1) & 1;
 #pragma unroll
         for (int m = 0; m < MTW; m++) {
-            const int mt = 2 * m + par;
-            if (mt < mtb) {
+            if (m < ntile) {
                 float a1[KB], a2[KB];
-                load_afrag<H>(a1, h1 + (rdb * mtb + mt) * 16 * H, lane);
-                load_afrag<H>(a2, h2 + (rdb * mtb + mt) * 16 * H, lane);
+                load_afrag<H>(a1, h1 + (rdb * MTW + m) * 16 * H, lane);
+                load_afrag<H>(a2, h2 + (rdb * MTW + m) * 16 * H, lane);
                 f32x4 acc1[NT], acc2[NT];
                 float xr[4];
 #pragma unroll
-                for (int r = 0; r < 4; r++) xr[r] = xb[(mt * 16 + R * 4 + r) * XS + (t % XCH)];
+                for (int r = 0; r < 4; r++) xr[r] = xb[(m * 16 + R * 4 + r) * XS + (t % XCH)];
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
 #pragma unroll
@@ -222,15 +253,15 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
                 if (t < T) {
 #pragma unroll
                     for (int nt = 0; nt < NT; nt++) {
-                        const float h = cell_update(acc1[nt], c1[m][nt], lane);
-                        h1[((wrb * mtb + mt) * 16 + R * 4 + q) * H + hpos<H>(slice * 12 + nt * 4 + ul)] = h;
+                        const float h = cell_update(acc1[nt], c1[m][nt], gl);
+                        h1[((wrb * MTW + m) * 16 + R * 4 + q) * H + hpos<H>(slice * 12 + nt * 4 + ul)] = h;
                     }
                 }
                 if (t >= 1) {
 #pragma unroll
                     for (int nt = 0; nt < NT; nt++) {
-                        const float h = cell_update(acc2[nt], c2[m][nt], lane);
-                        h2[((wrb * mtb + mt) * 16 + R * 4 + q) * H + hpos<H>(slice * 12 + nt * 4 + ul)] = h;
+                        const float h = cell_update(acc2[nt], c2[m][nt], gl);
+                        h2[((wrb * MTW + m) * 16 + R * 4 + q) * H + hpos<H>(slice * 12 + nt * 4 + ul)] = h;
                     }
                 }
             }
@@ -239,11 +270,11 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
     }
     // ---- Dense(2): chain over k = 0..47 from the bias ----------------------
     const int fin = (T + 1) & 1;
-    for (int i = tid; i < 16 * mtb * 2; i += LSTM_THREADS) {
+    for (int i = tid; i < 16 * ntile * 2; i += LSTM_THREADS) {
         const int row = i >> 1, j = i & 1;
         const int rd = ridx[row];
         if (rd < 0) continue;
-        const float* hr = h2 + ((fin * mtb + (row >> 4)) * 16 + (row & 15)) * H;
+        const float* hr = h2 + ((fin * MTW + (row >> 4)) * 16 + (row & 15)) * H;
         float acc = bd[j];
         for (int k = 0; k < H; k++) acc = __builtin_fmaf(hr[hpos<H>(k)], Wd[k * 2 + j], acc);
         pred[(size_t)rd * 2 + j] = acc;
@@ -251,40 +282,41 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
 }
 
 // ===========================================================================
-// K5a: demux bidirectional layer.  Same slicing as K2; the two "cells" are the
-// forward net at step t and the backward net at step T-1-t.  Every step's
-// hidden rows are streamed to HBM (k-major layout) for K5b.
+// K5a: demux bidirectional layer.  The two "cells" are the forward net at step
+// t and the backward net at step T-1-t.  Every step's hidden rows are streamed
+// to HBM (k-major layout) for K5b.
 // ===========================================================================
 template <int MTW>
 __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
-    int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int mtb,
-    int T, const float* __restrict__ win, const float* __restrict__ Wf,
-    const float* __restrict__ Uf, const float* __restrict__ bf, const float* __restrict__ Wb,
-    const float* __restrict__ Ub, const float* __restrict__ bb, float* __restrict__ bidir)
+    int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int T,
+    const float* __restrict__ win, const float* __restrict__ Wf, const float* __restrict__ Uf,
+    const float* __restrict__ bf, const float* __restrict__ Wb, const float* __restrict__ Ub,
+    const float* __restrict__ bb, float* __restrict__ bidir)
 {
     constexpr int H = 48, NT = 3, KB = 12;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lim = count ? min(*count, n_rows) : n_rows;
-    const int row_base = blockIdx.x * 16 * mtb;
-    if (row_base >= lim) return;
+    int tile0, ntile;
+    if (!my_tiles(lim, tile0, ntile)) return;
+    const int row_base = tile0 * 16;
     const int TS = T + 4;                               // padded x row stride
 
-    float* hf = smem;                                  // [2][mtb][16][H]
-    float* hb = hf + 2 * mtb * 16 * H;
-    float* xb = hb + 2 * mtb * 16 * H;                 // [16*mtb][TS]
-    int* ridx = reinterpret_cast<int*>(xb + 16 * mtb * TS);
+    float* hf = smem;                                  // [2][MTW][16][H]
+    float* hb = hf + 2 * MTW * 16 * H;
+    float* xb = hb + 2 * MTW * 16 * H;                 // [16*MTW][TS]
+    int* ridx = reinterpret_cast<int*>(xb + 16 * MTW * TS);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slice = wave & 3, par = wave >> 2;
+    const int tid = threadIdx.x, lane = tid & 63, slice = tid >> 6;
     const int R = lane >> 4, q = lane & 3, ul = (lane >> 2) & 3;
+    const GateLane gl = gate_lane(lane);
 
-    for (int i = tid; i < 4 * mtb * 16 * H; i += LSTM_THREADS) smem[i] = 0.0f;
-    for (int i = tid; i < 16 * mtb; i += LSTM_THREADS) {
+    for (int i = tid; i < 4 * MTW * 16 * H; i += LSTM_THREADS) smem[i] = 0.0f;
+    for (int i = tid; i < 16 * MTW; i += LSTM_THREADS) {
         const int row = row_base + i;
-        ridx[i] = row < lim ? (idx ? idx[row] : row) : -1;
+        ridx[i] = (i < 16 * ntile && row < lim) ? (idx ? idx[row] : row) : -1;
     }
     __syncthreads();
-    for (int i = tid; i < 16 * mtb * T; i += LSTM_THREADS) {
+    for (int i = tid; i < 16 * ntile * T; i += LSTM_THREADS) {
         const int row = i / T, tt = i % T;
         const int rd = ridx[row];
         xb[row * TS + tt] = rd >= 0 ? win[(size_t)rd * T + tt] : 0.0f;
@@ -311,16 +343,15 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
 
     for (int t = 0; t <= T; t++) {
         const int rdb = t & 1, wrb = (t + 1) & 1;
-        // stream the rows written in the previous step to HBM
-        if (t >= 1) {
+        if (t >= 1) {    // stream the rows written in the previous step to HBM
             const int tf = t - 1, tb = T - t;
-            for (int i = tid; i < 16 * mtb * 2 * (H / 4); i += LSTM_THREADS) {
+            for (int i = tid; i < 16 * ntile * 2 * (H / 4); i += LSTM_THREADS) {
                 const int c4 = i % (H / 4);
                 const int dir = (i / (H / 4)) & 1;
                 const int row = i / (2 * (H / 4));
                 const int rd = ridx[row];
                 if (rd < 0) continue;
-                const float* src = (dir ? hb : hf) + ((rdb * mtb + (row >> 4)) * 16 + (row & 15)) * H + c4 * 4;
+                const float* src = (dir ? hb : hf) + ((rdb * MTW + (row >> 4)) * 16 + (row & 15)) * H + c4 * 4;
                 float* dst = bidir + ((size_t)rd * T + (dir ? tb : tf)) * (2 * H) + dir * H + c4 * 4;
                 *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
             }
@@ -328,16 +359,15 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
         if (t == T) break;
 #pragma unroll
         for (int m = 0; m < MTW; m++) {
-            const int mt = 2 * m + par;
-            if (mt < mtb) {
+            if (m < ntile) {
                 float a1[KB], a2[KB];
-                load_afrag<H>(a1, hf + (rdb * mtb + mt) * 16 * H, lane);
-                load_afrag<H>(a2, hb + (rdb * mtb + mt) * 16 * H, lane);
+                load_afrag<H>(a1, hf + (rdb * MTW + m) * 16 * H, lane);
+                load_afrag<H>(a2, hb + (rdb * MTW + m) * 16 * H, lane);
                 f32x4 acc1[NT], acc2[NT];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const float xf = xb[(mt * 16 + R * 4 + r) * TS + t];
-                    const float xr = xb[(mt * 16 + R * 4 + r) * TS + (T - 1 - t)];
+                    const float xf = xb[(m * 16 + R * 4 + r) * TS + t];
+                    const float xr = xb[(m * 16 + R * 4 + r) * TS + (T - 1 - t)];
 #pragma unroll
                     for (int nt = 0; nt < NT; nt++) {
                         const float p1 = xf * wxf[nt];
@@ -356,9 +386,9 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
-                    const int hp = ((wrb * mtb + mt) * 16 + R * 4 + q) * H + hpos<H>(slice * 12 + nt * 4 + ul);
-                    hf[hp] = cell_update(acc1[nt], cf[m][nt], lane);
-                    hb[hp] = cell_update(acc2[nt], cb[m][nt], lane);
+                    const int hp = ((wrb * MTW + m) * 16 + R * 4 + q) * H + hpos<H>(slice * 12 + nt * 4 + ul);
+                    hf[hp] = cell_update(acc1[nt], cf[m][nt], gl);
+                    hb[hp] = cell_update(acc2[nt], cb[m][nt], gl);
                 }
             }
         }
@@ -367,51 +397,52 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
 }
 
 // ===========================================================================
-// K5b: demux top cell (H=64, input 96) + Dense(5) + softmax.  8 slices of 8
-// units (2 gate tiles each); every wave walks all M-tiles of the block.
+// K5b: demux top cell (H=64, input 96) + Dense(5) + softmax.  wave = slice of
+// 16 units (4 gate tiles, K = 96 input rows + 64 recurrent rows).
 // ===========================================================================
+template <int MTW>
 __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
-    int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int mtb,
-    int T, const float* __restrict__ bidir, const float* __restrict__ W3,
-    const float* __restrict__ U3, const float* __restrict__ b3, const float* __restrict__ Wd,
-    const float* __restrict__ bd, int n_classes, float* __restrict__ probs)
+    int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int T,
+    const float* __restrict__ bidir, const float* __restrict__ W3, const float* __restrict__ U3,
+    const float* __restrict__ b3, const float* __restrict__ Wd, const float* __restrict__ bd,
+    int n_classes, float* __restrict__ probs)
 {
-    constexpr int H = 64, HI = 48, NT = 2, KBI = 24, KBR = 16, MAXMT = 4;
+    constexpr int H = 64, HI = 48, NT = 4, KBI = 24, KBR = 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lim = count ? min(*count, n_rows) : n_rows;
-    const int row_base = blockIdx.x * 16 * mtb;
-    if (row_base >= lim) return;
+    int tile0, ntile;
+    if (!my_tiles(lim, tile0, ntile)) return;
+    const int row_base = tile0 * 16;
 
-    float* h3 = smem;                                  // [2][mtb][16][H]
-    float* inb = h3 + 2 * mtb * 16 * H;                // [2][mtb*16][2*HI]
-    int* ridx = reinterpret_cast<int*>(inb + 2 * mtb * 16 * 2 * HI);
+    float* h3 = smem;                                  // [2][MTW][16][H]
+    float* inb = h3 + 2 * MTW * 16 * H;                // [2][MTW*16][2*HI]
+    int* ridx = reinterpret_cast<int*>(inb + 2 * MTW * 16 * 2 * HI);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slice = wave;                             // 8 units per slice
+    const int tid = threadIdx.x, lane = tid & 63, slice = tid >> 6;
     const int R = lane >> 4, q = lane & 3, ul = (lane >> 2) & 3;
+    const GateLane gl = gate_lane(lane);
 
-    for (int i = tid; i < 2 * mtb * 16 * H; i += LSTM_THREADS) smem[i] = 0.0f;
-    for (int i = tid; i < 16 * mtb; i += LSTM_THREADS) {
+    for (int i = tid; i < 2 * MTW * 16 * H; i += LSTM_THREADS) smem[i] = 0.0f;
+    for (int i = tid; i < 16 * MTW; i += LSTM_THREADS) {
         const int row = row_base + i;
-        ridx[i] = row < lim ? (idx ? idx[row] : row) : -1;
+        ridx[i] = (i < 16 * ntile && row < lim) ? (idx ? idx[row] : row) : -1;
     }
     float wI[NT][KBI], wR[NT][KBR], bias[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
-        const int unit0 = slice * 8 + nt * 4;
+        const int unit0 = slice * 16 + nt * 4;
         load_wfrag<H, KBI>(wI[nt], W3, 0, unit0, lane);
         load_wfrag<H, KBR>(wR[nt], U3, 0, unit0, lane);
         bias[nt] = b3[(lane & 3) * H + unit0 + ((lane & 15) >> 2)];
     }
-    float c3[MAXMT][NT];
+    float c3[MTW][NT];
 #pragma unroll
-    for (int m = 0; m < MAXMT; m++)
+    for (int m = 0; m < MTW; m++)
 #pragma unroll
         for (int nt = 0; nt < NT; nt++) c3[m][nt] = 0.0f;
     __syncthreads();
 
-    // input rows of step 0 -> inb[0]
-    const int n_f4 = 16 * mtb * (2 * HI / 4);
+    const int n_f4 = 16 * ntile * (2 * HI / 4);     // float4 per step of input rows
     for (int i = tid; i < n_f4; i += LSTM_THREADS) {
         const int row = i / (2 * HI / 4), c4 = i % (2 * HI / 4);
         const int rd = ridx[row];
@@ -423,10 +454,13 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
 
     for (int t = 0; t < T; t++) {
         const int rdb = t & 1, wrb = (t + 1) & 1;
-        // prefetch next step's input rows into registers
-        float4 pf[3];
+        // next step's input rows: issue the global loads now, park them in
+        // registers while the MFMAs run, write them to the other LDS buffer
+        // just before the barrier
+        constexpr int NPF = (MTW * 16 * (2 * HI / 4) + LSTM_THREADS - 1) / LSTM_THREADS;
+        float4 pf[NPF];
 #pragma unroll
-        for (int p = 0; p < 3; p++) {
+        for (int p = 0; p < NPF; p++) {
             const int i = tid + p * LSTM_THREADS;
             pf[p] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < n_f4 && t + 1 < T) {
@@ -438,35 +472,32 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
             }
         }
 #pragma unroll
-        for (int mt = 0; mt < MAXMT; mt++) {
-            if (mt < mtb) {
+        for (int m = 0; m < MTW; m++) {
+            if (m < ntile) {
                 f32x4 acc[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) acc[nt][r] = bias[nt];
-                const float* irow = inb + (rdb * mtb * 16 + mt * 16) * (2 * HI);
-                {
-                    // forward half then backward half: rows of 96 floats
+                const float* p = inb + (rdb * MTW * 16 + m * 16) * (2 * HI) + (lane & 15) * (2 * HI) +
+                                 (lane >> 4) * (HI / 4);
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
                     float a[HI / 4];
-                    const float* p = irow + (lane & 15) * (2 * HI) + (lane >> 4) * (HI / 4);
 #pragma unroll
-                    for (int half = 0; half < 2; half++) {
-#pragma unroll
-                        for (int v4 = 0; v4 < HI / 16; v4++) {
-                            const float4 v = *reinterpret_cast<const float4*>(p + half * HI + 4 * v4);
-                            a[4 * v4] = v.x; a[4 * v4 + 1] = v.y; a[4 * v4 + 2] = v.z; a[4 * v4 + 3] = v.w;
-                        }
-#pragma unroll
-                        for (int kb = 0; kb < HI / 4; kb++)
-#pragma unroll
-                            for (int nt = 0; nt < NT; nt++)
-                                acc[nt] = mfma4(a[kb], wI[nt][half * (HI / 4) + kb], acc[nt]);
+                    for (int v4 = 0; v4 < HI / 16; v4++) {
+                        const float4 v = *reinterpret_cast<const float4*>(p + half * HI + 4 * v4);
+                        a[4 * v4] = v.x; a[4 * v4 + 1] = v.y; a[4 * v4 + 2] = v.z; a[4 * v4 + 3] = v.w;
                     }
+#pragma unroll
+                    for (int kb = 0; kb < HI / 4; kb++)
+#pragma unroll
+                        for (int nt = 0; nt < NT; nt++)
+                            acc[nt] = mfma4(a[kb], wI[nt][half * (HI / 4) + kb], acc[nt]);
                 }
                 {
                     float a[KBR];
-                    load_afrag<H>(a, h3 + (rdb * mtb + mt) * 16 * H, lane);
+                    load_afrag<H>(a, h3 + (rdb * MTW + m) * 16 * H, lane);
 #pragma unroll
                     for (int kb = 0; kb < KBR; kb++)
 #pragma unroll
@@ -474,40 +505,47 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
-                    const float h = cell_update(acc[nt], c3[mt][nt], lane);
-                    h3[((wrb * mtb + mt) * 16 + R * 4 + q) * H + hpos<H>(slice * 8 + nt * 4 + ul)] = h;
+                    const float h = cell_update(acc[nt], c3[m][nt], gl);
+                    h3[((wrb * MTW + m) * 16 + R * 4 + q) * H + hpos<H>(slice * 16 + nt * 4 + ul)] = h;
                 }
             }
         }
 #pragma unroll
-        for (int p = 0; p < 3; p++) {
+        for (int p = 0; p < NPF; p++) {
             const int i = tid + p * LSTM_THREADS;
             if (i < n_f4) {
                 const int row = i / (2 * HI / 4), c4 = i % (2 * HI / 4);
-                *reinterpret_cast<float4*>(inb + (wrb * mtb * 16 + row) * (2 * HI) + c4 * 4) = pf[p];
+                *reinterpret_cast<float4*>(inb + (wrb * MTW * 16 + row) * (2 * HI) + c4 * 4) = pf[p];
             }
         }
         __syncthreads();
     }
     // ---- Dense(n_classes) + softmax ----------------------------------------
     const int fin = T & 1;
-    for (int row = tid; row < 16 * mtb; row += LSTM_THREADS) {
+    for (int row = tid; row < 16 * ntile; row += LSTM_THREADS) {
         const int rd = ridx[row];
         if (rd < 0) continue;
-        const float* hr = h3 + ((fin * mtb + (row >> 4)) * 16 + (row & 15)) * H;
+        const float* hr = h3 + ((fin * MTW + (row >> 4)) * 16 + (row & 15)) * H;
         float z[PXG_MAX_CLASSES], e[PXG_MAX_CLASSES];
-        for (int j = 0; j < n_classes; j++) {
-            float acc = bd[j];
-            for (int k = 0; k < H; k++) acc = __builtin_fmaf(hr[hpos<H>(k)], Wd[k * n_classes + j], acc);
-            z[j] = acc;
+#pragma unroll
+        for (int j = 0; j < PXG_MAX_CLASSES; j++) {
+            z[j] = -__builtin_inff();
+            if (j < n_classes) {
+                float acc = bd[j];
+                for (int k = 0; k < H; k++) acc = __builtin_fmaf(hr[hpos<H>(k)], Wd[k * n_classes + j], acc);
+                z[j] = acc;
+            }
         }
-        float m = z[0];
-        for (int j = 1; j < n_classes; j++) m = z[j] > m ? z[j] : m;
+        float mx = z[0];
+#pragma unroll
+        for (int j = 1; j < PXG_MAX_CLASSES; j++) mx = (j < n_classes && z[j] > mx) ? z[j] : mx;
         float s = 0.0f;
-        for (int j = 0; j < n_classes; j++) {
-            e[j] = pxg_expf(z[j] - m);
-            s = (j == 0) ? e[0] : s + e[j];
+#pragma unroll
+        for (int j = 0; j < PXG_MAX_CLASSES; j++) {
+            e[j] = j < n_classes ? pxg_expf(z[j] - mx) : 0.0f;
+            if (j < n_classes) s = (j == 0) ? e[0] : s + e[j];
         }
+#pragma unroll
         for (int j = 0; j < PXG_MAX_CLASSES; j++)
             probs[(size_t)rd * PXG_MAX_CLASSES + j] = j < n_classes ? e[j] / s : 0.0f;
     }
@@ -516,13 +554,18 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
 // ===========================================================================
 // launchers
 // ===========================================================================
-static int pick_mtb(pxg_ctx* ctx, int64_t n_rows)
+struct LstmGrid { int blocks, mtw; };
+
+static LstmGrid pick_grid(pxg_ctx* ctx, int64_t n_rows, int maxt = LSTM_MAXT)
 {
     const int64_t tiles = (n_rows + 15) / 16;
-    int64_t mtb = (tiles + ctx->n_cu - 1) / ctx->n_cu;
-    if (mtb < 1) mtb = 1;
-    if (mtb > 4) mtb = 4;
-    return (int)mtb;
+    int64_t blocks = std::min<int64_t>(tiles, 2 * (int64_t)ctx->n_cu);   // 2 groups per CU
+    int64_t mtw = (tiles + blocks - 1) / blocks;
+    if (mtw > maxt) {                 // more than one round of groups
+        mtw = maxt;
+        blocks = (tiles + mtw - 1) / mtw;
+    }
+    return { (int)blocks, (int)mtw };
 }
 
 int pxg_lstm_upload(pxg_ctx* ctx)
@@ -544,26 +587,31 @@ int pxg_lstm_upload(pxg_ctx* ctx)
     return PXG_OK;
 }
 
+#define LSTM_DISPATCH(MTWVAR, CALL)  \
+    switch (MTWVAR) {                \
+    case 1: { CALL(1); } break;      \
+    case 2: { CALL(2); } break;      \
+    case 3: { CALL(3); } break;      \
+    default: { CALL(4); } break;     \
+    }
+
 int pxg_launch_scaler_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
                            const int32_t* count, const float* head, float* pred)
 {
     if (n_rows <= 0) return PXG_OK;
     const int T = ctx->cfg.scaler_length / ctx->cfg.stride;
-    const int mtb = pick_mtb(ctx, n_rows);
-    const int blocks = (int)((n_rows + 16 * mtb - 1) / (16 * mtb));
-    const size_t lds = sizeof(float) * (4 * mtb * 16 * 48 + 16 * mtb * XS) + sizeof(int) * 16 * mtb;
+    const LstmGrid g = pick_grid(ctx, n_rows);
     const PxgLstmDev &l1 = ctx->scaler1, &l2 = ctx->scaler2;
-#define LAUNCH_SC(MTW)                                                                       \
-    do {                                                                                     \
-        PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_scaler_lstm<MTW>,                    \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(k_scaler_lstm<MTW>, dim3(blocks), dim3(LSTM_THREADS), lds,        \
-                           ctx->stream, (int)n_rows, idx, count, mtb, T, head, l1.kernel,    \
-                           l1.recurrent, l1.bias, l2.kernel, l2.recurrent, l2.bias,          \
-                           ctx->scaler_dense.kernel, ctx->scaler_dense.bias, pred);          \
-    } while (0)
-    if (mtb <= 2) LAUNCH_SC(1); else LAUNCH_SC(2);
-#undef LAUNCH_SC
+#define CALL(M)                                                                                  \
+    const size_t lds = sizeof(float) * (4 * M * 16 * 48 + 16 * M * XS) + sizeof(int) * 16 * M;    \
+    PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_scaler_lstm<M>,                              \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
+    hipLaunchKernelGGL(k_scaler_lstm<M>, dim3(g.blocks), dim3(LSTM_THREADS), lds, ctx->stream,   \
+                       (int)n_rows, idx, count, T, head, l1.kernel, l1.recurrent, l1.bias,       \
+                       l2.kernel, l2.recurrent, l2.bias, ctx->scaler_dense.kernel,               \
+                       ctx->scaler_dense.bias, pred);
+    LSTM_DISPATCH(g.mtw, CALL)
+#undef CALL
     PXG_HIP(ctx, hipGetLastError());
     return PXG_OK;
 }
@@ -574,34 +622,35 @@ int pxg_launch_demux_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
 {
     if (n_rows <= 0) return PXG_OK;
     const int T = ctx->cfg.signal_trim_length;
-    const int mtb = pick_mtb(ctx, n_rows);
-    const int blocks = (int)((n_rows + 16 * mtb - 1) / (16 * mtb));
+    const LstmGrid g = pick_grid(ctx, n_rows);
     {
-        const size_t lds = sizeof(float) * (4 * mtb * 16 * 48 + 16 * mtb * (T + 4)) + sizeof(int) * 16 * mtb;
         const PxgLstmDev &f = ctx->demux_fwd, &b = ctx->demux_bwd;
         pxg_timer_begin(ctx, timer_a);
-#define LAUNCH_BI(MTW)                                                                       \
-    do {                                                                                     \
-        PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_demux_bidir<MTW>,                    \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL(k_demux_bidir<MTW>, dim3(blocks), dim3(LSTM_THREADS), lds,        \
-                           ctx->stream, (int)n_rows, idx, count, mtb, T, win, f.kernel,      \
-                           f.recurrent, f.bias, b.kernel, b.recurrent, b.bias, bidir);       \
-    } while (0)
-        if (mtb <= 2) LAUNCH_BI(1); else LAUNCH_BI(2);
-#undef LAUNCH_BI
+#define CALL(M)                                                                                  \
+    const size_t lds = sizeof(float) * (4 * M * 16 * 48 + 16 * M * (T + 4)) + sizeof(int) * 16 * M; \
+    PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_demux_bidir<M>,                              \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
+    hipLaunchKernelGGL(k_demux_bidir<M>, dim3(g.blocks), dim3(LSTM_THREADS), lds, ctx->stream,   \
+                       (int)n_rows, idx, count, T, win, f.kernel, f.recurrent, f.bias, b.kernel, \
+                       b.recurrent, b.bias, bidir);
+        LSTM_DISPATCH(g.mtw, CALL)
+#undef CALL
         pxg_timer_end(ctx, timer_a);
     }
     {
-        const size_t lds = sizeof(float) * (2 * mtb * 16 * 64 + 2 * mtb * 16 * 96) + sizeof(int) * 16 * mtb;
         const PxgLstmDev& t3 = ctx->demux_top;
+        const LstmGrid g = pick_grid(ctx, n_rows, 2);   // 160 weight VGPRs: 2 tiles max
         pxg_timer_begin(ctx, timer_b);
-        PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_demux_top,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_demux_top, dim3(blocks), dim3(LSTM_THREADS), lds, ctx->stream,
-                           (int)n_rows, idx, count, mtb, T, bidir, t3.kernel, t3.recurrent, t3.bias,
-                           ctx->demux_dense.kernel, ctx->demux_dense.bias,
-                           ctx->demux_dense.out_dim, probs);
+#define CALL(M)                                                                                  \
+    const size_t lds = sizeof(float) * (2 * M * 16 * 64 + 2 * M * 16 * 96) + sizeof(int) * 16 * M; \
+    PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_demux_top<M>,                                \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
+    hipLaunchKernelGGL(k_demux_top<M>, dim3(g.blocks), dim3(LSTM_THREADS), lds, ctx->stream,     \
+                       (int)n_rows, idx, count, T, bidir, t3.kernel, t3.recurrent, t3.bias,      \
+                       ctx->demux_dense.kernel, ctx->demux_dense.bias,                           \
+                       ctx->demux_dense.out_dim, probs);
+        if (g.mtw == 1) { CALL(1); } else { CALL(2); }
+#undef CALL
         pxg_timer_end(ctx, timer_b);
     }
     PXG_HIP(ctx, hipGetLastError());

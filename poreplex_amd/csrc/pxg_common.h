@@ -25,6 +25,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float pxg_expf(float x)
 {
+    x = __builtin_amdgcn_fmed3f(x, -87.0f, 87.0f);   // clamp: result always finite normal
     const float magic = 12582912.0f;  // 1.5 * 2^23
     float t = __builtin_fmaf(x, 1.44269504088896341f, magic);
     float n = t - magic;
@@ -38,21 +39,30 @@ __device__ __forceinline__ float pxg_expf(float x)
     p = __builtin_fmaf(p, r, 0.5f);
     p = __builtin_fmaf(p, r, 1.0f);
     p = __builtin_fmaf(p, r, 1.0f);
-    float res = __int_as_float(__float_as_int(p) + ((int)n << 23));
-    res = x > 88.0f ? __builtin_inff() : res;
-    res = x < -87.0f ? 0.0f : res;
-    return res;
+    return __int_as_float(__float_as_int(p) + ((int)n << 23));
+}
+
+// 1/d for d in [1, 2^126): integer seed + three fma Newton steps (<= 0.5005 ulp)
+__device__ __forceinline__ float pxg_rcp(float d)
+{
+    float r = __int_as_float((int)(0x7EF311C7u - (unsigned)__float_as_int(d)));
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float e = __builtin_fmaf(-d, r, 1.0f);
+        r = __builtin_fmaf(r, e, r);
+    }
+    return r;
 }
 
 __device__ __forceinline__ float pxg_sigmoid(float x)
 {
-    return 1.0f / (1.0f + pxg_expf(-x));
+    return pxg_rcp(1.0f + pxg_expf(-x));
 }
 
 __device__ __forceinline__ float pxg_tanh(float x)
 {
-    float s = 1.0f / (1.0f + pxg_expf(-(2.0f * x)));
-    return 2.0f * s - 1.0f;
+    const float s = pxg_rcp(1.0f + pxg_expf(-2.0f * x));
+    return __builtin_fmaf(2.0f, s, -1.0f);
 }
 
 // DAQ counts -> pA (fast5_file.py:130-131): float64 product, one cast.
