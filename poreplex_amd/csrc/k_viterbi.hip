@@ -7,8 +7,10 @@
 //       (NumPy pairwise order), applies fl(fl(scale*x)+shift), evaluates the
 //       float64 log-densities of every state and parks them in LDS;
 //   (2) recurrence phase: lane (read, state) keeps v[state] in a register and
-//       pulls its in-edge sources with wave shuffles (max-plus, strict '>' in
-//       pomegranate's name-sorted source order).
+//       pulls its in-edge sources from the lanes below it with DPP row shifts
+//       (no LDS round trip; the model is left-to-right so a source is always
+//       0..7 lanes down), max-plus with strict '>' in pomegranate's name-sorted
+//       source order.
 // No back-pointer table: the segmentation model is left-to-right (every edge
 // i->j has j >= i), so a path is fully described by the step at which it
 // entered each state.  Each lane carries those entry steps packed 16 bit per
@@ -17,7 +19,7 @@
 #include "pxg_common.h"
 
 #define VIT_READS 8
-#define VIT_CHUNK 64
+#define VIT_CHUNK 32
 
 __device__ __forceinline__ double hmm_emission(const PxgHmmDev& H, int s, double x)
 {
@@ -66,9 +68,32 @@ __device__ __forceinline__ void ent_stamp(unsigned (&e)[4], int q, unsigned val1
 
 #define EM_STRIDE (VIT_CHUNK * PXG_MAX_STATES + 8)   // +8 doubles: spread reads over banks
 
+// value of the lane `k` below inside a 16-lane row (DPP row_shr:k)
+template <typename T>
+__device__ __forceinline__ int dpp_shr_i32(int v, T k)
+{
+    switch (k) {
+    case 1: return __builtin_amdgcn_update_dpp(v, v, 0x111, 0xF, 0xF, false);
+    case 2: return __builtin_amdgcn_update_dpp(v, v, 0x112, 0xF, 0xF, false);
+    case 3: return __builtin_amdgcn_update_dpp(v, v, 0x113, 0xF, 0xF, false);
+    case 4: return __builtin_amdgcn_update_dpp(v, v, 0x114, 0xF, 0xF, false);
+    case 5: return __builtin_amdgcn_update_dpp(v, v, 0x115, 0xF, 0xF, false);
+    case 6: return __builtin_amdgcn_update_dpp(v, v, 0x116, 0xF, 0xF, false);
+    default: return __builtin_amdgcn_update_dpp(v, v, 0x117, 0xF, 0xF, false);
+    }
+}
+__device__ __forceinline__ unsigned dpp_shr_u32(unsigned v, int k) { return (unsigned)dpp_shr_i32((int)v, k); }
+__device__ __forceinline__ double dpp_shr_f64(double v, int k)
+{
+    const int lo = dpp_shr_i32(__double2loint(v), k), hi = dpp_shr_i32(__double2hiint(v), k);
+    return __hiloint2double(hi, lo);
+}
+
 // RAW=true : signal is pooled on the fly from int16 DAQ samples
 // RAW=false: signal is an already pooled+scaled float arena (test hook)
-template <bool RAW>
+// SPANS: bit k set = some edge goes from state s-k to state s (k >= 1);
+// NW: packed entry words in use = ceil(n_states / 2)
+template <bool RAW, unsigned SPANS, int NW>
 __global__ __launch_bounds__(64) void k_viterbi_ltr(
     int64_t n_reads, PxgHmmDev H, const int16_t* __restrict__ raw, const float* __restrict__ sig,
     const int64_t* __restrict__ off, const pxg_calib* __restrict__ cal,
@@ -106,16 +131,37 @@ __global__ __launch_bounds__(64) void k_viterbi_ltr(
         Tmax = o > Tmax ? o : Tmax;
     }
 
-    // per-lane in-edge table (sources as lane ids inside this read's octet)
-    int src_lane[PXG_MAX_STATES];
-    double src_lp[PXG_MAX_STATES];
+    // per-lane edge table by SPAN: the source of span k is the lane k below.
+    // lpk[k] = log P(state s-k -> s) (-inf if no such edge); prk[k] = position of
+    // that source in pomegranate's name-sorted in-edge order (first maximum wins)
+    double lpk[PXG_MAX_STATES];
+    int prk[PXG_MAX_STATES];
+#pragma unroll
+    for (int k = 0; k < PXG_MAX_STATES; k++) {
+        lpk[k] = -__builtin_inf();
+        prk[k] = 99;
+    }
 #pragma unroll
     for (int d = 0; d < PXG_MAX_STATES; d++) {
         const int sidx = (s < S) ? H.in_src[s][d] : -1;
-        src_lane[d] = sidx >= 0 ? (rr * 8 + sidx) : lane;
-        src_lp[d] = sidx >= 0 ? H.in_logp[s][d] : -__builtin_inf();
+        const double lp = (s < S) ? H.in_logp[s][d] : -__builtin_inf();
+#pragma unroll
+        for (int k = 0; k < PXG_MAX_STATES; k++) {
+            const bool hit = sidx >= 0 && (s - sidx) == k;
+            lpk[k] = hit ? lp : lpk[k];
+            prk[k] = hit ? d : prk[k];
+        }
     }
     const double lstart = (s < S) ? H.log_start[s] : -__builtin_inf();
+    // lane-constant masks to stamp the 16-bit entry field of state s
+    unsigned keep[4], put[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const unsigned field = 0xFFFFu << ((unsigned)(s & 1) * 16u);
+        put[w] = (w == (s >> 1)) ? field : 0u;
+        keep[w] = ~put[w];
+    }
+    const unsigned stamp_sh = (unsigned)(s & 1) * 16u;
 
     double v = -__builtin_inf();
     unsigned ent[4] = { 0u, 0u, 0u, 0u };   // 16-bit entry step + 1 per state
@@ -150,34 +196,55 @@ __global__ __launch_bounds__(64) void k_viterbi_ltr(
             const int t = c0 + tt;
             const bool act = (t < T) && (s < S);
             const double e = act ? em[rr * EM_STRIDE + tt * PXG_MAX_STATES + s] : 0.0;
-            double best = -__builtin_inf();
-            int arg = lane;
+            // v and the entry vectors of the lanes below, for the spans in use
+            double vs[PXG_MAX_STATES];
+            unsigned es[PXG_MAX_STATES][NW];
 #pragma unroll
-            for (int d = 0; d < PXG_MAX_STATES; d++) {
-                if (d < H.max_in) {             // wave-uniform
-                    const double vk = shfl_f64(v, src_lane[d]);
-                    const double cand = vk + src_lp[d];
-                    if (cand > best) {
-                        best = cand;
-                        arg = src_lane[d];
-                    }
+            for (int k = 1; k < PXG_MAX_STATES; k++) {
+                if ((SPANS >> k) & 1u) {
+                    vs[k] = dpp_shr_f64(v, k);
+#pragma unroll
+                    for (int w = 0; w < NW; w++) es[k][w] = dpp_shr_u32(ent[w], k);
                 }
             }
-            unsigned ne[4];
-#pragma unroll
-            for (int w = 0; w < 4; w++) ne[w] = (unsigned)__shfl((int)ent[w], arg);
-            if (t == 0) {
+            if (t == 0) {                       // wave-uniform
                 if (act) {
                     v = lstart + e;
-                    ent_stamp(ent, s, 1u);
-                }
-            } else if (act) {
-                v = best + e;
-                if (arg != lane) {
-                    ent_stamp(ne, s, (unsigned)(t + 1));
 #pragma unroll
-                    for (int w = 0; w < 4; w++) ent[w] = ne[w];
+                    for (int w = 0; w < NW; w++) ent[w] = (ent[w] & keep[w]) | ((1u << stamp_sh) & put[w]);
                 }
+            } else {
+                double best = v + lpk[0];       // span 0 = self loop (or -inf)
+                int bd = 0, bpr = prk[0];
+#pragma unroll
+                for (int k = 1; k < PXG_MAX_STATES; k++) {
+                    if ((SPANS >> k) & 1u) {
+                        const double cand = vs[k] + lpk[k];
+                        const unsigned long long take =
+                            __ballot((cand > best) || (cand == best && prk[k] < bpr));
+                        best = pxg_sel_f64(take, best, cand);
+                        bd = (int)pxg_sel_u32(take, (unsigned)bd, (unsigned)k);
+                        bpr = (int)pxg_sel_u32(take, (unsigned)bpr, (unsigned)prk[k]);
+                    }
+                }
+                const unsigned long long mact = __ballot(act);
+                v = pxg_sel_f64(mact, v, best + e);
+                unsigned ne[NW];
+#pragma unroll
+                for (int w = 0; w < NW; w++) ne[w] = ent[w];
+#pragma unroll
+                for (int k = 1; k < PXG_MAX_STATES; k++) {
+                    if ((SPANS >> k) & 1u) {
+                        const unsigned long long mk = __ballot(bd == k);
+#pragma unroll
+                        for (int w = 0; w < NW; w++) ne[w] = pxg_sel_u32(mk, ne[w], es[k][w]);
+                    }
+                }
+                const unsigned long long mmove = __ballot(act && bd != 0);
+                const unsigned stamp = (unsigned)(t + 1) << stamp_sh;
+#pragma unroll
+                for (int w = 0; w < NW; w++)
+                    ent[w] = pxg_sel_u32(mmove, ent[w], (ne[w] & keep[w]) | (stamp & put[w]));
             }
         }
     }
@@ -193,9 +260,9 @@ __global__ __launch_bounds__(64) void k_viterbi_ltr(
             end_lane = ln;
         }
     }
-    unsigned fe[4];
+    unsigned fe[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll
-    for (int w = 0; w < 4; w++) fe[w] = (unsigned)__shfl((int)ent[w], end_lane);
+    for (int w = 0; w < NW; w++) fe[w] = (unsigned)__shfl((int)ent[w], end_lane);
 
     if (s == 0 && r < n_reads) {
         int32_t* first = segs + r * 2 * PXG_N_SEGMENTS;
@@ -244,9 +311,16 @@ int pxg_launch_segment_raw(pxg_ctx* ctx, int64_t n, const int16_t* raw, const in
     int rc = check_supported(ctx, 0);
     if (rc) return rc;
     const int scan = ctx->cfg.segmentation_scan_limit / ctx->cfg.stride;
-    hipLaunchKernelGGL(k_viterbi_ltr<true>, dim3((unsigned)((n + VIT_READS - 1) / VIT_READS)),
-                       dim3(64), 0, ctx->stream, n, ctx->hmm[0], raw, (const float*)nullptr, off,
-                       cal, ss, ctx->cfg.stride, scan, (int32_t*)status, segs, (double*)nullptr);
+    const dim3 grid((unsigned)((n + VIT_READS - 1) / VIT_READS));
+    const PxgHmmDev& H = ctx->hmm[0];
+    if ((H.shift_mask & ~7u) == 0 && H.n_states <= 6)      // spans {1,2}: the shipped model
+        hipLaunchKernelGGL((k_viterbi_ltr<true, 0x6u, 3>), grid, dim3(64), 0, ctx->stream, n, H, raw,
+                           (const float*)nullptr, off, cal, ss, ctx->cfg.stride, scan,
+                           (int32_t*)status, segs, (double*)nullptr);
+    else
+        hipLaunchKernelGGL((k_viterbi_ltr<true, 0xFEu, 4>), grid, dim3(64), 0, ctx->stream, n, H, raw,
+                           (const float*)nullptr, off, cal, ss, ctx->cfg.stride, scan,
+                           (int32_t*)status, segs, (double*)nullptr);
     return PXG_OK;
 }
 
@@ -256,9 +330,15 @@ int pxg_launch_viterbi_f32(pxg_ctx* ctx, int which, int64_t n, const float* sig,
     if (n <= 0) return PXG_OK;
     int rc = check_supported(ctx, which);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_viterbi_ltr<false>, dim3((unsigned)((n + VIT_READS - 1) / VIT_READS)),
-                       dim3(64), 0, ctx->stream, n, ctx->hmm[which], (const int16_t*)nullptr, sig,
-                       off, (const pxg_calib*)nullptr, (const float*)nullptr, 1, 65534,
-                       (int32_t*)nullptr, segs, logp);
+    const dim3 grid((unsigned)((n + VIT_READS - 1) / VIT_READS));
+    const PxgHmmDev& H = ctx->hmm[which];
+    if ((H.shift_mask & ~7u) == 0 && H.n_states <= 6)
+        hipLaunchKernelGGL((k_viterbi_ltr<false, 0x6u, 3>), grid, dim3(64), 0, ctx->stream, n, H,
+                           (const int16_t*)nullptr, sig, off, (const pxg_calib*)nullptr,
+                           (const float*)nullptr, 1, 65534, (int32_t*)nullptr, segs, logp);
+    else
+        hipLaunchKernelGGL((k_viterbi_ltr<false, 0xFEu, 4>), grid, dim3(64), 0, ctx->stream, n, H,
+                           (const int16_t*)nullptr, sig, off, (const pxg_calib*)nullptr,
+                           (const float*)nullptr, 1, 65534, (int32_t*)nullptr, segs, logp);
     return PXG_OK;
 }

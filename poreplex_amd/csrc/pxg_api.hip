@@ -58,6 +58,7 @@ static int build_hmm(pxg_ctx* ctx, const pxg_hmm& h, PxgHmmDev& d)
                 d.in_logp[s][nin] = log(h.trans[k][s]);
                 nin++;
                 if (k > s) d.left_to_right = 0;
+                else d.shift_mask |= 1u << (s - k);
             }
         }
         for (int q = nin; q < PXG_MAX_STATES; q++) {

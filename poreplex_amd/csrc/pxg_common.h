@@ -65,6 +65,27 @@ __device__ __forceinline__ float pxg_tanh(float x)
     return __builtin_fmaf(2.0f, s, -1.0f);
 }
 
+// Lane select with the mask in an SGPR pair (v_cndmask_b32_e64).  Measured on
+// gfx950: a second v_cndmask that re-reads the SAME vcc costs ~8 ns instead of
+// ~2 ns, so every multi-word select (f64, packed vectors) goes through these
+// helpers with a ballot mask instead of the compiler's vcc form.
+__device__ __forceinline__ unsigned pxg_sel_u32(unsigned long long take, unsigned if0, unsigned if1)
+{
+    unsigned d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(if0), "v"(if1), "s"(take));
+    return d;
+}
+__device__ __forceinline__ float pxg_sel_f32(unsigned long long take, float if0, float if1)
+{
+    return __uint_as_float(pxg_sel_u32(take, __float_as_uint(if0), __float_as_uint(if1)));
+}
+__device__ __forceinline__ double pxg_sel_f64(unsigned long long take, double if0, double if1)
+{
+    const unsigned lo = pxg_sel_u32(take, (unsigned)__double2loint(if0), (unsigned)__double2loint(if1));
+    const unsigned hi = pxg_sel_u32(take, (unsigned)__double2hiint(if0), (unsigned)__double2hiint(if1));
+    return __hiloint2double((int)hi, (int)lo);
+}
+
 // DAQ counts -> pA (fast5_file.py:130-131): float64 product, one cast.
 __device__ __forceinline__ float pxg_raw2pa(int16_t raw, double k, double offset)
 {
@@ -105,6 +126,7 @@ struct PxgHmmDev {           // device image of one HMM (by-value kernel argumen
     int adapter_state, polya_state;
     int left_to_right;       // every edge i->j has j >= i (config order)
     int max_in;              // largest in-degree
+    unsigned shift_mask;     // bit k: some edge i->j has j - i == k (left-to-right models)
     int n_mix[PXG_MAX_STATES];
     int order[PXG_MAX_STATES];                 // states in name-sorted order
     int in_src[PXG_MAX_STATES][PXG_MAX_STATES]; // in-edge sources, name-sorted; -1 unused

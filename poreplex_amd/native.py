@@ -344,7 +344,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get('PXG_LIBRARY') or LIB_PATH   # A/B builds for profiling
     if not os.path.isfile(path):
         raise PxgError(
             'HIP extension {} is missing: run `python -c "import __graft_entry__ as g; '
