@@ -51,6 +51,8 @@ int64_t pxo_pool_scale(const int16_t* raw, int64_t n_raw, const pxg_calib* cal,
 float pxo_expf(float x);
 float pxo_sigmoid(float x);
 float pxo_tanh(float x);
+/* the 1024 x 4 spline coefficients both sides must agree on */
+void pxo_sigmoid_table(float* out);
 
 /* a4  signal_loader.py:96-97 + scaler-r3.hdf5; x[T] -> pred[2] */
 void pxo_scaler_forward(const pxg_config* cfg, const float* x, int T, float* pred);

@@ -51,6 +51,7 @@ def lib():
             'pxo_np_sum_f32': (f32, [vp, i64]),
             'pxo_head_pool': (i32, [vp, i64, vp, i32, i32, i32, vp]),
             'pxo_pool_scale': (i64, [vp, i64, vp, i32, f32, f32, vp]),
+            'pxo_sigmoid_table': (None, [vp]),
             'pxo_expf': (f32, [f32]), 'pxo_sigmoid': (f32, [f32]), 'pxo_tanh': (f32, [f32]),
             'pxo_scaler_forward': (None, [cfgp, vp, i32, vp]),
             'pxo_scaler_transform': (i32, [cfgp, vp, vp]),
@@ -128,6 +129,11 @@ class Oracle:
 
     def tanh(self, x):
         return np.array([self.L.pxo_tanh(float(v)) for v in np.atleast_1d(x)], np.float32)
+
+    def sigmoid_table(self):
+        tab = np.zeros((1024, 4), dtype=np.float32)
+        self.L.pxo_sigmoid_table(_p(tab))
+        return tab
 
     def scaler_forward(self, head):
         head = np.ascontiguousarray(head, dtype=np.float32)

@@ -113,18 +113,90 @@ int64_t pxo_pool_scale(const int16_t* raw, int64_t n_raw, const pxg_calib* cal,
 }
 
 /* ------------------------------------------------------------------------ *
- * Canonical float32 transcendental kit (DESIGN.md "Canonical LSTM
- * arithmetic").  Only IEEE +,*,/,fma and integer ops, so the HIP kernels
- * reproduce it bit for bit.  expf: Cody-Waite reduction by ln2 (hi/lo),
- * degree-7 Taylor/Horner in fma form, exponent insertion.
+ * Canonical float32 activation kit (DESIGN.md "Canonical LSTM arithmetic").
+ * Only IEEE +,*,fma, floor and integer ops, so the HIP kernels reproduce it bit
+ * for bit.
+ *   sigmoid: cubic Hermite spline on 1024 segments of width 1/16 over
+ *            [-32, 32); coefficients from a deterministic float64 exp (no
+ *            libm), rounded to float32; interpolation error < 1e-8.
+ *            u = 16*z (exact), seg = floor(u), s = u - seg (exact),
+ *            sigma = c0 + s*(c1 + s*(c2 + s*c3))   (three fma)
+ *   tanh(x) = fl(2*sigmoid(2x) - 1)               (one fma)
+ *   expf:    Cody-Waite + degree-7 Taylor, only used by the final softmax.
  * ------------------------------------------------------------------------ */
 static inline float bits2f(int32_t i) { float f; memcpy(&f, &i, 4); return f; }
 static inline int32_t f2bits(float f) { int32_t i; memcpy(&i, &f, 4); return i; }
 
+#define SIG_NSEG 1024
+#define SIG_HALF 512
+static float g_sig_tab[SIG_NSEG][4];
+static int g_sig_ready = 0;
+
+/* exp(x) for |x| <= 40 in float64 from +,*,fma only: identical on every IEEE
+ * machine (the table must be the same in the library and in this oracle) */
+static double det_exp(double x)
+{
+    const double magic = 6755399441055744.0;        /* 1.5 * 2^52 */
+    double kf = (x * 1.4426950408889634 + magic) - magic;
+    double r = fma(-kf, 6.93147180369123816490e-01, x);
+    r = fma(-kf, 1.90821492927058770002e-10, r);
+    double fact = 6227020800.0;                      /* 13! */
+    double p = 1.0 / fact;
+    for (int n = 13; n >= 1; n--) {
+        fact /= (double)n;
+        p = fma(p, r, 1.0 / fact);
+    }
+    int64_t bits;
+    memcpy(&bits, &p, 8);
+    bits += (int64_t)kf << 52;
+    memcpy(&p, &bits, 8);
+    return p;
+}
+
+void pxo_sigmoid_table(float* out)
+{
+    const double h = 1.0 / 16.0;
+    for (int i = 0; i < SIG_NSEG; i++) {
+        const double z0 = (double)(i - SIG_HALF) * h, z1 = z0 + h;
+        const double s0 = 1.0 / (1.0 + det_exp(-z0)), s1 = 1.0 / (1.0 + det_exp(-z1));
+        const double d0 = s0 * (1.0 - s0), d1 = s1 * (1.0 - s1);
+        out[4 * i + 0] = (float)s0;
+        out[4 * i + 1] = (float)(h * d0);
+        out[4 * i + 2] = (float)(3.0 * (s1 - s0) - h * (2.0 * d0 + d1));
+        out[4 * i + 3] = (float)(2.0 * (s0 - s1) + h * (d0 + d1));
+    }
+}
+
+/* sigmoid(zscale/16 * z): zscale = 16 for the gates, 32 inside tanh */
+static inline float sig_lookup(float z, float zscale, float zlo, float zhi)
+{
+    if (!g_sig_ready) {
+        pxo_sigmoid_table(&g_sig_tab[0][0]);
+        g_sig_ready = 1;
+    }
+    z = fminf(fmaxf(z, zlo), zhi);
+    const float u = z * zscale;
+    const float fl = floorf(u);
+    const float s = u - fl;
+    const float* c = g_sig_tab[(int)fl + SIG_HALF];
+    float p = fmaf(c[3], s, c[2]);
+    p = fmaf(p, s, c[1]);
+    return fmaf(p, s, c[0]);
+}
+
+float pxo_sigmoid(float x)
+{
+    return sig_lookup(x, 16.0f, -32.0f, 31.999998f);
+}
+
+float pxo_tanh(float x)
+{
+    const float s = sig_lookup(x, 32.0f, -16.0f, 15.999999f);
+    return fmaf(2.0f, s, -1.0f);
+}
+
 float pxo_expf(float x)
 {
-    /* input clamped to [-87, 87]: the result is always a finite normal float,
-     * so 1/(1+exp) needs no special cases (exp(87) = 6.1e37) */
     x = fminf(fmaxf(x, -87.0f), 87.0f);
     const float magic = 12582912.0f; /* 1.5 * 2^23: round-to-nearest-even */
     float t = fmaf(x, 1.44269504088896341f, magic);
@@ -140,31 +212,6 @@ float pxo_expf(float x)
     p = fmaf(p, r, 1.0f);
     p = fmaf(p, r, 1.0f);
     return bits2f(f2bits(p) + ((int32_t)n << 23));
-}
-
-/* reciprocal of d in [1, 2^126): integer seed (error < 5.1%) refined by three
- * Newton steps in fma form; within 0.5005 ulp of 1/d, no division unit, no
- * denormal-mode switching on the GPU */
-static inline float pxo_rcp(float d)
-{
-    float r = bits2f((int32_t)(0x7EF311C7u - (uint32_t)f2bits(d)));
-    for (int i = 0; i < 3; i++) {
-        float e = fmaf(-d, r, 1.0f);
-        r = fmaf(r, e, r);
-    }
-    return r;
-}
-
-float pxo_sigmoid(float x)
-{
-    return pxo_rcp(1.0f + pxo_expf(-x));
-}
-
-float pxo_tanh(float x)
-{
-    /* 2*sigmoid(2x) - 1: 2*s is exact, one rounding */
-    float s = pxo_rcp(1.0f + pxo_expf(-2.0f * x));
-    return fmaf(2.0f, s, -1.0f);
 }
 
 /* ------------------------------------------------------------------------ *

@@ -5,26 +5,30 @@
 //
 // Why this shape (DESIGN.md "LSTM kernels"): per read the nets cost 148 MFLOP
 // of strictly sequential small GEMMs, so the bound is fp32 matrix throughput
-// and step latency, not HBM.  A 4-wave workgroup owns 16..64 reads (1-4
-// "M-tiles" of 16 rows) for the whole sequence.  Gate columns are split over
-// the four waves so every wave keeps ITS weight slice in VGPRs for all steps (B
-// operand of v_mfma_f32_16x16x4_f32, one VGPR per 4x16 block); hidden states
-// are exchanged through LDS once per step (A operand, 3-4 ds_read_b128 per
-// tile thanks to a k-major row layout); c-state never leaves registers.  Layer 2
-// of the scaler runs one step behind layer 1 inside the same step so both
-// matmuls share their A fragments.  Two workgroups are resident per CU and
-// share no barrier, so one group's gate math (VALU) runs under the other's
-// MFMAs -- measured: a single 8-wave group per CU serialises the two pipes.
+// and step latency, not HBM.  A 4-wave workgroup owns 16..64 reads (1-4 read
+// tiles of 16) for the whole sequence.  The gate rows are split over the four
+// waves so every wave keeps ITS weight slice in VGPRs for all steps (A operand
+// of v_mfma_f32_16x16x4_f32: one VGPR per 16x4 block); hidden states are
+// exchanged through LDS once per step (B operand, 3-4 ds_read_b128 per tile
+// thanks to a k-major row layout); the c-state never leaves registers.  Layer
+// 2 of the scaler runs one step behind layer 1 inside the same step so both
+// matmuls share their B fragments.
+//
+// Z^T = W^T . [x|h]^T : the MFMA rows are gate rows and the columns are reads.
+// A gate tile is 16 rows = 4 units x 4 gates (row = unit_local*4 + gate), and
+// the C/D layout of the 16x16 MFMA gives lane l the rows 4*(l>>4)+{0..3} of
+// column l&15 -- i.e. the FOUR GATES of unit (l>>4) for read (l&15) land in
+// the four accumulator registers of one lane.  No cross-lane traffic at all:
+// every lane activates i,f,g,o and updates one (read, unit) cell.
+//
+// Measured on MI355X (profiles/r01): the f32 MFMA shares the FP32 lanes with
+// the VALU (busy cycles add up, they do not overlap), so the gate math is kept
+// to ~60 VALU instructions per tile by a spline table in LDS (pxg_common.h).
 //
 // Canonical arithmetic (bit-exact with oracle/pxo_core.c lstm_step): the MFMA
 // is a k-ordered fmaf chain, accumulator start = fl(fl(x*W)+b) (scalar input)
-// or b, chain over input rows then recurrent rows; gates via pxg_expf/pxg_rcp;
-// c' = fl(fl(f*c)+fl(i*g)); h = fl(o*tanh(c')).
-//
-// Tile geometry: an N-tile is 16 gate columns = 4 units x 4 gates
-// (col = unit_local*4 + gate), so after the MFMA the four gates of one
-// (read, unit) sit in one lane quad; a 4x4 quad transpose (DPP) then gives
-// every lane one complete (read, unit) cell to update.
+// or b, chain over input rows then recurrent rows; c' = fl(fl(f*c)+fl(i*g));
+// h = fl(o*tanh(c')).
 #include "pxg_common.h"
 
 #define LSTM_THREADS 256
@@ -37,15 +41,6 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float quad_xor1(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float quad_xor2(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
-}
-
 // k-major position of unit u inside a hidden-state row of H floats
 template <int H>
 __device__ __forceinline__ int hpos(int u)
@@ -53,72 +48,48 @@ __device__ __forceinline__ int hpos(int u)
     return (u & 3) * (H / 4) + (u >> 2);
 }
 
-// per-lane constants of the gate this lane activates in phase 1
-struct GateLane {
-    float nsc;   // -1 (sigmoid gates) or -2 (candidate gate: tanh(z) = 2*sigmoid(2z)-1)
-    float m2;    //  1 or 2
-    float sub;   //  0 or -1
-    bool b0, b1; // lane bits inside the quad
-};
-
-__device__ __forceinline__ GateLane gate_lane(int lane)
+// acc = (i, f, g, o) pre-activations of one (read, unit); returns h, updates c
+__device__ __forceinline__ float cell_update(const float4* tab, f32x4 acc, float& c)
 {
-    GateLane g;
-    const bool is_tanh = (lane & 3) == 2;
-    g.nsc = is_tanh ? -2.0f : -1.0f;
-    g.m2 = is_tanh ? 2.0f : 1.0f;
-    g.sub = is_tanh ? -1.0f : 0.0f;
-    g.b0 = (lane & 1) != 0;
-    g.b1 = (lane & 2) != 0;
-    return g;
-}
-
-// Gate activations + cell update for one 16x16 gate tile.
-//   acc[r]: pre-activation of gate (lane&3) of unit ((lane>>2)&3), row (lane>>4)*4 + r.
-//   Returns h for row (lane>>4)*4 + (lane&3) of that unit.
-__device__ __forceinline__ float cell_update(f32x4 acc, float& c, const GateLane& g)
-{
-    float a[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const float s = pxg_rcp(1.0f + pxg_expf(acc[r] * g.nsc));
-        a[r] = __builtin_fmaf(s, g.m2, g.sub);     // s, or fl(2s-1) for the candidate gate
-    }
-    // 4x4 transpose inside the lane quad: afterwards a[j] = gate j of row (lane&3)
-#pragma unroll
-    for (int r0 = 0; r0 < 2; r0++) {
-        const float lo = a[r0], hi = a[2 + r0];
-        const float recv = quad_xor2(g.b1 ? lo : hi);
-        a[r0] = g.b1 ? recv : lo;
-        a[2 + r0] = g.b1 ? hi : recv;
-    }
-#pragma unroll
-    for (int r1 = 0; r1 < 2; r1++) {
-        const float ev = a[2 * r1], od = a[2 * r1 + 1];
-        const float recv = quad_xor1(g.b0 ? ev : od);
-        a[2 * r1] = g.b0 ? recv : ev;
-        a[2 * r1 + 1] = g.b0 ? od : recv;
-    }
-    const float fc = a[1] * c;
-    const float ig = a[0] * a[2];
-    const float cn = fc + ig;
+    const float ig = pxg_sigmoid(tab, acc[0]);
+    const float fg = pxg_sigmoid(tab, acc[1]);
+    const float gg = pxg_tanh(tab, acc[2]);
+    const float og = pxg_sigmoid(tab, acc[3]);
+    const float fc = fg * c;
+    const float in = ig * gg;
+    const float cn = fc + in;
     c = cn;
-    return a[3] * pxg_tanh(cn);
+    return og * pxg_tanh(tab, cn);
 }
 
-// B fragments (weights) of one gate tile: rows [row0, row0+4*KB) of a Keras
-// [rows, 4H] matrix, columns = 4 units x 4 gates of this tile.
+// A fragments (weights) of one gate tile: rows [row0, row0+4*KB) of a Keras
+// [rows, 4H] matrix; MFMA row i = lane&15 <-> column gate(i&3)*H + unit0 + (i>>2)
 template <int H, int KB>
 __device__ __forceinline__ void load_wfrag(float (&w)[KB], const float* __restrict__ mat,
                                            int row0, int unit0, int lane)
 {
-    const int k = lane >> 4, j = lane & 15;
-    const int col = (j & 3) * H + unit0 + (j >> 2);
+    const int k = lane >> 4, i = lane & 15;
+    const int col = (i & 3) * H + unit0 + (i >> 2);
 #pragma unroll
     for (int kb = 0; kb < KB; kb++) w[kb] = mat[(size_t)(row0 + kb * 4 + k) * (4 * H) + col];
 }
 
-// A fragments of one 16-row tile: hidden row (lane&15), k = lane>>4.
+// per-lane bias / scalar-input weight of the 4 gate rows this lane accumulates
+template <int H>
+__device__ __forceinline__ void load_gate4(float (&v)[4], const float* __restrict__ vec, int unit0,
+                                           int lane)
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = vec[r * H + unit0 + (lane >> 4)];
+}
+
+__device__ __forceinline__ void load_sigtab(float4* dst, const float* __restrict__ src, int tid)
+{
+    for (int i = tid; i < PXG_SIG_NSEG; i += 256)
+        dst[i] = reinterpret_cast<const float4*>(src)[i];
+}
+
+// B fragments of one 16-read tile: hidden row (lane&15), k = lane>>4.
 template <int H>
 __device__ __forceinline__ void load_afrag(float (&a)[H / 4], const float* hrow_base, int lane)
 {
@@ -130,10 +101,10 @@ __device__ __forceinline__ void load_afrag(float (&a)[H / 4], const float* hrow_
     }
 }
 
-// Balanced static split of the row tiles over the launched workgroups: the
-// first `rem` groups take one tile more.  With grid = 2 x #CU and dispatch
-// order b -> CU (b mod #CU) this pairs a heavy group with a light one per CU
-// (placement only affects speed, never results).
+// Balanced static split of the read tiles over the launched workgroups: the
+// first `rem` groups take one tile more.  With grid = 2 x #CU the dispatcher
+// (measured: block b -> the CU of b mod #CU) pairs a heavy group with a light
+// one per CU; placement only affects speed, never results.
 __device__ __forceinline__ bool my_tiles(int lim_rows, int& tile0, int& ntile)
 {
     const int n_tiles = (lim_rows + 15) >> 4;
@@ -152,10 +123,10 @@ __device__ __forceinline__ bool my_tiles(int lim_rows, int& tile0, int& ntile)
 template <int MTW>
 __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
     int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int T,
-    const float* __restrict__ head, const float* __restrict__ W1, const float* __restrict__ U1,
-    const float* __restrict__ b1, const float* __restrict__ W2, const float* __restrict__ U2,
-    const float* __restrict__ b2, const float* __restrict__ Wd, const float* __restrict__ bd,
-    float* __restrict__ pred)
+    const float* __restrict__ head, const float* __restrict__ sigtab,
+    const float* __restrict__ W1, const float* __restrict__ U1, const float* __restrict__ b1,
+    const float* __restrict__ W2, const float* __restrict__ U2, const float* __restrict__ b2,
+    const float* __restrict__ Wd, const float* __restrict__ bd, float* __restrict__ pred)
 {
     constexpr int H = 48, NT = 3, KB = 12;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -164,23 +135,24 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
     if (!my_tiles(lim, tile0, ntile)) return;
     const int row_base = tile0 * 16;
 
-    float* h1 = smem;                                  // [2][MTW][16][H]
+    float4* tab = reinterpret_cast<float4*>(smem);     // [1024] sigmoid spline
+    float* h1 = smem + 4 * PXG_SIG_NSEG;               // [2][MTW][16][H]
     float* h2 = h1 + 2 * MTW * 16 * H;                 // [2][MTW][16][H]
     float* xb = h2 + 2 * MTW * 16 * H;                 // [16*MTW][XS]
     int* ridx = reinterpret_cast<int*>(xb + 16 * MTW * XS);   // [16*MTW]
 
     const int tid = threadIdx.x, lane = tid & 63, slice = tid >> 6;
-    const int R = lane >> 4, q = lane & 3, ul = (lane >> 2) & 3;
-    const GateLane gl = gate_lane(lane);
+    const int rd_l = lane & 15, ul = lane >> 4;        // read column, unit inside the tile
 
-    for (int i = tid; i < 4 * MTW * 16 * H; i += LSTM_THREADS) smem[i] = 0.0f;
+    load_sigtab(tab, sigtab, tid);
+    for (int i = tid; i < 4 * MTW * 16 * H; i += LSTM_THREADS) h1[i] = 0.0f;
     for (int i = tid; i < 16 * MTW; i += LSTM_THREADS) {
         const int row = row_base + i;
         ridx[i] = (i < 16 * ntile && row < lim) ? (idx ? idx[row] : row) : -1;
     }
 
     // ---- this wave's weight slice -> registers ------------------------------
-    float wA[NT][KB], wB[NT][2 * KB], bias1[NT], bias2[NT], wx[NT];
+    float wA[NT][KB], wB[NT][2 * KB], bias1[NT][4], bias2[NT][4], wx[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
         const int unit0 = slice * 12 + nt * 4;
@@ -192,10 +164,9 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
         load_wfrag<H, KB>(tmp, U2, 0, unit0, lane);
 #pragma unroll
         for (int kb = 0; kb < KB; kb++) wB[nt][KB + kb] = tmp[kb];
-        const int col = (lane & 3) * H + unit0 + ((lane & 15) >> 2);
-        bias1[nt] = b1[col];
-        bias2[nt] = b2[col];
-        wx[nt] = W1[col];
+        load_gate4<H>(bias1[nt], b1, unit0, lane);
+        load_gate4<H>(bias2[nt], b2, unit0, lane);
+        load_gate4<H>(wx[nt], W1, unit0, lane);
     }
     float c1[MTW][NT], c2[MTW][NT];
 #pragma unroll
@@ -225,44 +196,40 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
                 load_afrag<H>(a1, h1 + (rdb * MTW + m) * 16 * H, lane);
                 load_afrag<H>(a2, h2 + (rdb * MTW + m) * 16 * H, lane);
                 f32x4 acc1[NT], acc2[NT];
-                float xr[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) xr[r] = xb[(m * 16 + R * 4 + r) * XS + (t % XCH)];
+                const float x = xb[(m * 16 + rd_l) * XS + (t % XCH)];
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
-                        const float xw = xr[r] * wx[nt];
-                        acc1[nt][r] = xw + bias1[nt];
-                        acc2[nt][r] = bias2[nt];
+                        const float xw = x * wx[nt][r];
+                        acc1[nt][r] = xw + bias1[nt][r];
+                        acc2[nt][r] = bias2[nt][r];
                     }
                 }
 #pragma unroll
                 for (int kb = 0; kb < KB; kb++) {
 #pragma unroll
                     for (int nt = 0; nt < NT; nt++) {
-                        acc1[nt] = mfma4(a1[kb], wA[nt][kb], acc1[nt]);
-                        acc2[nt] = mfma4(a1[kb], wB[nt][kb], acc2[nt]);
+                        acc1[nt] = mfma4(wA[nt][kb], a1[kb], acc1[nt]);
+                        acc2[nt] = mfma4(wB[nt][kb], a1[kb], acc2[nt]);
                     }
                 }
 #pragma unroll
                 for (int kb = 0; kb < KB; kb++)
 #pragma unroll
                     for (int nt = 0; nt < NT; nt++)
-                        acc2[nt] = mfma4(a2[kb], wB[nt][KB + kb], acc2[nt]);
+                        acc2[nt] = mfma4(wB[nt][KB + kb], a2[kb], acc2[nt]);
+                float* o1 = h1 + ((wrb * MTW + m) * 16 + rd_l) * H;
+                float* o2 = h2 + ((wrb * MTW + m) * 16 + rd_l) * H;
                 if (t < T) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; nt++) {
-                        const float h = cell_update(acc1[nt], c1[m][nt], gl);
-                        h1[((wrb * MTW + m) * 16 + R * 4 + q) * H + hpos<H>(slice * 12 + nt * 4 + ul)] = h;
-                    }
+                    for (int nt = 0; nt < NT; nt++)
+                        o1[hpos<H>(slice * 12 + nt * 4 + ul)] = cell_update(tab, acc1[nt], c1[m][nt]);
                 }
                 if (t >= 1) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; nt++) {
-                        const float h = cell_update(acc2[nt], c2[m][nt], gl);
-                        h2[((wrb * MTW + m) * 16 + R * 4 + q) * H + hpos<H>(slice * 12 + nt * 4 + ul)] = h;
-                    }
+                    for (int nt = 0; nt < NT; nt++)
+                        o2[hpos<H>(slice * 12 + nt * 4 + ul)] = cell_update(tab, acc2[nt], c2[m][nt]);
                 }
             }
         }
@@ -289,9 +256,10 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
 template <int MTW>
 __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
     int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int T,
-    const float* __restrict__ win, const float* __restrict__ Wf, const float* __restrict__ Uf,
-    const float* __restrict__ bf, const float* __restrict__ Wb, const float* __restrict__ Ub,
-    const float* __restrict__ bb, float* __restrict__ bidir)
+    const float* __restrict__ win, const float* __restrict__ sigtab,
+    const float* __restrict__ Wf, const float* __restrict__ Uf, const float* __restrict__ bf,
+    const float* __restrict__ Wb, const float* __restrict__ Ub, const float* __restrict__ bb,
+    float* __restrict__ bidir)
 {
     constexpr int H = 48, NT = 3, KB = 12;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -299,40 +267,34 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
     int tile0, ntile;
     if (!my_tiles(lim, tile0, ntile)) return;
     const int row_base = tile0 * 16;
-    const int TS = T + 4;                               // padded x row stride
 
-    float* hf = smem;                                  // [2][MTW][16][H]
+    float4* tab = reinterpret_cast<float4*>(smem);
+    float* hf = smem + 4 * PXG_SIG_NSEG;               // [2][MTW][16][H]
     float* hb = hf + 2 * MTW * 16 * H;
-    float* xb = hb + 2 * MTW * 16 * H;                 // [16*MTW][TS]
-    int* ridx = reinterpret_cast<int*>(xb + 16 * MTW * TS);
+    float* xf = hb + 2 * MTW * 16 * H;                 // [16*MTW][XS]  x[t0 + c]
+    float* xr = xf + 16 * MTW * XS;                    // [16*MTW][XS]  x[T-1-(t0+c)]
+    int* ridx = reinterpret_cast<int*>(xr + 16 * MTW * XS);
 
     const int tid = threadIdx.x, lane = tid & 63, slice = tid >> 6;
-    const int R = lane >> 4, q = lane & 3, ul = (lane >> 2) & 3;
-    const GateLane gl = gate_lane(lane);
+    const int rd_l = lane & 15, ul = lane >> 4;
 
-    for (int i = tid; i < 4 * MTW * 16 * H; i += LSTM_THREADS) smem[i] = 0.0f;
+    load_sigtab(tab, sigtab, tid);
+    for (int i = tid; i < 4 * MTW * 16 * H; i += LSTM_THREADS) hf[i] = 0.0f;
     for (int i = tid; i < 16 * MTW; i += LSTM_THREADS) {
         const int row = row_base + i;
         ridx[i] = (i < 16 * ntile && row < lim) ? (idx ? idx[row] : row) : -1;
     }
-    __syncthreads();
-    for (int i = tid; i < 16 * ntile * T; i += LSTM_THREADS) {
-        const int row = i / T, tt = i % T;
-        const int rd = ridx[row];
-        xb[row * TS + tt] = rd >= 0 ? win[(size_t)rd * T + tt] : 0.0f;
-    }
 
-    float wF[NT][KB], wBk[NT][KB], biasf[NT], biasb[NT], wxf[NT], wxb[NT];
+    float wF[NT][KB], wBk[NT][KB], biasf[NT][4], biasb[NT][4], wxf[NT][4], wxb[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
         const int unit0 = slice * 12 + nt * 4;
         load_wfrag<H, KB>(wF[nt], Uf, 0, unit0, lane);
         load_wfrag<H, KB>(wBk[nt], Ub, 0, unit0, lane);
-        const int col = (lane & 3) * H + unit0 + ((lane & 15) >> 2);
-        biasf[nt] = bf[col];
-        biasb[nt] = bb[col];
-        wxf[nt] = Wf[col];
-        wxb[nt] = Wb[col];
+        load_gate4<H>(biasf[nt], bf, unit0, lane);
+        load_gate4<H>(biasb[nt], bb, unit0, lane);
+        load_gate4<H>(wxf[nt], Wf, unit0, lane);
+        load_gate4<H>(wxb[nt], Wb, unit0, lane);
     }
     float cf[MTW][NT], cb[MTW][NT];
 #pragma unroll
@@ -357,6 +319,18 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
             }
         }
         if (t == T) break;
+        if ((t % XCH) == 0) {                 // refill both x tiles
+            __syncthreads();
+            for (int i = tid; i < 16 * ntile * XCH; i += LSTM_THREADS) {
+                const int row = i / XCH, c = i % XCH;
+                const int rd = ridx[row];
+                const int tt = t + c;
+                const bool ok = rd >= 0 && tt < T;
+                xf[row * XS + c] = ok ? win[(size_t)rd * T + tt] : 0.0f;
+                xr[row * XS + c] = ok ? win[(size_t)rd * T + (T - 1 - tt)] : 0.0f;
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int m = 0; m < MTW; m++) {
             if (m < ntile) {
@@ -364,31 +338,32 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
                 load_afrag<H>(a1, hf + (rdb * MTW + m) * 16 * H, lane);
                 load_afrag<H>(a2, hb + (rdb * MTW + m) * 16 * H, lane);
                 f32x4 acc1[NT], acc2[NT];
+                const float x1 = xf[(m * 16 + rd_l) * XS + (t % XCH)];
+                const float x2 = xr[(m * 16 + rd_l) * XS + (t % XCH)];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float xf = xb[(m * 16 + R * 4 + r) * TS + t];
-                    const float xr = xb[(m * 16 + R * 4 + r) * TS + (T - 1 - t)];
+                for (int nt = 0; nt < NT; nt++) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; nt++) {
-                        const float p1 = xf * wxf[nt];
-                        acc1[nt][r] = p1 + biasf[nt];
-                        const float p2 = xr * wxb[nt];
-                        acc2[nt][r] = p2 + biasb[nt];
+                    for (int r = 0; r < 4; r++) {
+                        const float p1 = x1 * wxf[nt][r];
+                        acc1[nt][r] = p1 + biasf[nt][r];
+                        const float p2 = x2 * wxb[nt][r];
+                        acc2[nt][r] = p2 + biasb[nt][r];
                     }
                 }
 #pragma unroll
                 for (int kb = 0; kb < KB; kb++) {
 #pragma unroll
                     for (int nt = 0; nt < NT; nt++) {
-                        acc1[nt] = mfma4(a1[kb], wF[nt][kb], acc1[nt]);
-                        acc2[nt] = mfma4(a2[kb], wBk[nt][kb], acc2[nt]);
+                        acc1[nt] = mfma4(wF[nt][kb], a1[kb], acc1[nt]);
+                        acc2[nt] = mfma4(wBk[nt][kb], a2[kb], acc2[nt]);
                     }
                 }
+                const int ob = ((wrb * MTW + m) * 16 + rd_l) * H;
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
-                    const int hp = ((wrb * MTW + m) * 16 + R * 4 + q) * H + hpos<H>(slice * 12 + nt * 4 + ul);
-                    hf[hp] = cell_update(acc1[nt], cf[m][nt], gl);
-                    hb[hp] = cell_update(acc2[nt], cb[m][nt], gl);
+                    const int hp = ob + hpos<H>(slice * 12 + nt * 4 + ul);
+                    hf[hp] = cell_update(tab, acc1[nt], cf[m][nt]);
+                    hb[hp] = cell_update(tab, acc2[nt], cb[m][nt]);
                 }
             }
         }
@@ -403,9 +378,10 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
 template <int MTW>
 __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
     int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int T,
-    const float* __restrict__ bidir, const float* __restrict__ W3, const float* __restrict__ U3,
-    const float* __restrict__ b3, const float* __restrict__ Wd, const float* __restrict__ bd,
-    int n_classes, float* __restrict__ probs)
+    const float* __restrict__ bidir, const float* __restrict__ sigtab,
+    const float* __restrict__ W3, const float* __restrict__ U3, const float* __restrict__ b3,
+    const float* __restrict__ Wd, const float* __restrict__ bd, int n_classes,
+    float* __restrict__ probs)
 {
     constexpr int H = 64, HI = 48, NT = 4, KBI = 24, KBR = 16;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -414,26 +390,28 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
     if (!my_tiles(lim, tile0, ntile)) return;
     const int row_base = tile0 * 16;
 
-    float* h3 = smem;                                  // [2][MTW][16][H]
+    float4* tab = reinterpret_cast<float4*>(smem);
+    float* h3 = smem + 4 * PXG_SIG_NSEG;               // [2][MTW][16][H]
     float* inb = h3 + 2 * MTW * 16 * H;                // [2][MTW*16][2*HI]
-    int* ridx = reinterpret_cast<int*>(inb + 2 * MTW * 16 * 2 * HI);
+    float* bl = inb + 2 * MTW * 16 * 2 * HI;           // [H][4] bias, (i,f,g,o) per unit
+    int* ridx = reinterpret_cast<int*>(bl + 4 * H);
 
     const int tid = threadIdx.x, lane = tid & 63, slice = tid >> 6;
-    const int R = lane >> 4, q = lane & 3, ul = (lane >> 2) & 3;
-    const GateLane gl = gate_lane(lane);
+    const int rd_l = lane & 15, ul = lane >> 4;
 
-    for (int i = tid; i < 2 * MTW * 16 * H; i += LSTM_THREADS) smem[i] = 0.0f;
+    load_sigtab(tab, sigtab, tid);
+    for (int i = tid; i < 2 * MTW * 16 * H; i += LSTM_THREADS) h3[i] = 0.0f;
+    for (int i = tid; i < 4 * H; i += LSTM_THREADS) bl[i] = b3[(i & 3) * H + (i >> 2)];
     for (int i = tid; i < 16 * MTW; i += LSTM_THREADS) {
         const int row = row_base + i;
         ridx[i] = (i < 16 * ntile && row < lim) ? (idx ? idx[row] : row) : -1;
     }
-    float wI[NT][KBI], wR[NT][KBR], bias[NT];
+    float wI[NT][KBI], wR[NT][KBR];
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
         const int unit0 = slice * 16 + nt * 4;
         load_wfrag<H, KBI>(wI[nt], W3, 0, unit0, lane);
         load_wfrag<H, KBR>(wR[nt], U3, 0, unit0, lane);
-        bias[nt] = b3[(lane & 3) * H + unit0 + ((lane & 15) >> 2)];
     }
     float c3[MTW][NT];
 #pragma unroll
@@ -476,10 +454,11 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
             if (m < ntile) {
                 f32x4 acc[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) acc[nt][r] = bias[nt];
-                const float* p = inb + (rdb * MTW * 16 + m * 16) * (2 * HI) + (lane & 15) * (2 * HI) +
+                for (int nt = 0; nt < NT; nt++) {
+                    const float4 bv = *reinterpret_cast<const float4*>(bl + (slice * 16 + nt * 4 + ul) * 4);
+                    acc[nt][0] = bv.x; acc[nt][1] = bv.y; acc[nt][2] = bv.z; acc[nt][3] = bv.w;
+                }
+                const float* p = inb + (rdb * MTW * 16 + m * 16) * (2 * HI) + rd_l * (2 * HI) +
                                  (lane >> 4) * (HI / 4);
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
@@ -493,7 +472,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
                     for (int kb = 0; kb < HI / 4; kb++)
 #pragma unroll
                         for (int nt = 0; nt < NT; nt++)
-                            acc[nt] = mfma4(a[kb], wI[nt][half * (HI / 4) + kb], acc[nt]);
+                            acc[nt] = mfma4(wI[nt][half * (HI / 4) + kb], a[kb], acc[nt]);
                 }
                 {
                     float a[KBR];
@@ -501,13 +480,12 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
 #pragma unroll
                     for (int kb = 0; kb < KBR; kb++)
 #pragma unroll
-                        for (int nt = 0; nt < NT; nt++) acc[nt] = mfma4(a[kb], wR[nt][kb], acc[nt]);
+                        for (int nt = 0; nt < NT; nt++) acc[nt] = mfma4(wR[nt][kb], a[kb], acc[nt]);
                 }
+                float* o3 = h3 + ((wrb * MTW + m) * 16 + rd_l) * H;
 #pragma unroll
-                for (int nt = 0; nt < NT; nt++) {
-                    const float h = cell_update(acc[nt], c3[m][nt], gl);
-                    h3[((wrb * MTW + m) * 16 + R * 4 + q) * H + hpos<H>(slice * 16 + nt * 4 + ul)] = h;
-                }
+                for (int nt = 0; nt < NT; nt++)
+                    o3[hpos<H>(slice * 16 + nt * 4 + ul)] = cell_update(tab, acc[nt], c3[m][nt]);
             }
         }
 #pragma unroll
@@ -578,7 +556,7 @@ int pxg_lstm_upload(pxg_ctx* ctx)
                     c.demux_bwd.input_dim == 1 && c.demux_bwd.units == 48 &&
                     c.demux_top.input_dim == 96 && c.demux_top.units == 64 &&
                     c.demux_dense.in_dim == 64 && c.demux_dense.out_dim <= PXG_MAX_CLASSES &&
-                    c.signal_trim_length <= 508 && (c.scaler_length / c.stride) % 4 == 0;
+                    (c.scaler_length / c.stride) % 4 == 0;
     if (!ok) {
         ctx->err = "LSTM kernels are specialised for the MIN106-RNA001 model shapes "
                    "(scaler 1-48-48-2, demux 1-2x48-64-5)";
@@ -586,6 +564,8 @@ int pxg_lstm_upload(pxg_ctx* ctx)
     }
     return PXG_OK;
 }
+
+static const size_t kTabBytes = sizeof(float) * 4 * PXG_SIG_NSEG;
 
 #define LSTM_DISPATCH(MTWVAR, CALL)  \
     switch (MTWVAR) {                \
@@ -603,12 +583,13 @@ int pxg_launch_scaler_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
     const LstmGrid g = pick_grid(ctx, n_rows);
     const PxgLstmDev &l1 = ctx->scaler1, &l2 = ctx->scaler2;
 #define CALL(M)                                                                                  \
-    const size_t lds = sizeof(float) * (4 * M * 16 * 48 + 16 * M * XS) + sizeof(int) * 16 * M;    \
+    const size_t lds = kTabBytes + sizeof(float) * (4 * M * 16 * 48 + 16 * M * XS) +             \
+                       sizeof(int) * 16 * M;                                                     \
     PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_scaler_lstm<M>,                              \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
     hipLaunchKernelGGL(k_scaler_lstm<M>, dim3(g.blocks), dim3(LSTM_THREADS), lds, ctx->stream,   \
-                       (int)n_rows, idx, count, T, head, l1.kernel, l1.recurrent, l1.bias,       \
-                       l2.kernel, l2.recurrent, l2.bias, ctx->scaler_dense.kernel,               \
+                       (int)n_rows, idx, count, T, head, ctx->d_sigtab, l1.kernel, l1.recurrent, \
+                       l1.bias, l2.kernel, l2.recurrent, l2.bias, ctx->scaler_dense.kernel,      \
                        ctx->scaler_dense.bias, pred);
     LSTM_DISPATCH(g.mtw, CALL)
 #undef CALL
@@ -627,12 +608,13 @@ int pxg_launch_demux_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
         const PxgLstmDev &f = ctx->demux_fwd, &b = ctx->demux_bwd;
         pxg_timer_begin(ctx, timer_a);
 #define CALL(M)                                                                                  \
-    const size_t lds = sizeof(float) * (4 * M * 16 * 48 + 16 * M * (T + 4)) + sizeof(int) * 16 * M; \
+    const size_t lds = kTabBytes + sizeof(float) * (4 * M * 16 * 48 + 2 * 16 * M * XS) +         \
+                       sizeof(int) * 16 * M;                                                     \
     PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_demux_bidir<M>,                              \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
     hipLaunchKernelGGL(k_demux_bidir<M>, dim3(g.blocks), dim3(LSTM_THREADS), lds, ctx->stream,   \
-                       (int)n_rows, idx, count, T, win, f.kernel, f.recurrent, f.bias, b.kernel, \
-                       b.recurrent, b.bias, bidir);
+                       (int)n_rows, idx, count, T, win, ctx->d_sigtab, f.kernel, f.recurrent,    \
+                       f.bias, b.kernel, b.recurrent, b.bias, bidir);
         LSTM_DISPATCH(g.mtw, CALL)
 #undef CALL
         pxg_timer_end(ctx, timer_a);
@@ -642,12 +624,13 @@ int pxg_launch_demux_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
         const LstmGrid g = pick_grid(ctx, n_rows, 2);   // 160 weight VGPRs: 2 tiles max
         pxg_timer_begin(ctx, timer_b);
 #define CALL(M)                                                                                  \
-    const size_t lds = sizeof(float) * (2 * M * 16 * 64 + 2 * M * 16 * 96) + sizeof(int) * 16 * M; \
+    const size_t lds = kTabBytes + sizeof(float) * (2 * M * 16 * 64 + 2 * M * 16 * 96 + 256) +   \
+                       sizeof(int) * 16 * M;                                                     \
     PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_demux_top<M>,                                \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
     hipLaunchKernelGGL(k_demux_top<M>, dim3(g.blocks), dim3(LSTM_THREADS), lds, ctx->stream,     \
-                       (int)n_rows, idx, count, T, bidir, t3.kernel, t3.recurrent, t3.bias,      \
-                       ctx->demux_dense.kernel, ctx->demux_dense.bias,                           \
+                       (int)n_rows, idx, count, T, bidir, ctx->d_sigtab, t3.kernel,              \
+                       t3.recurrent, t3.bias, ctx->demux_dense.kernel, ctx->demux_dense.bias,    \
                        ctx->demux_dense.out_dim, probs);
         if (g.mtw == 1) { CALL(1); } else { CALL(2); }
 #undef CALL

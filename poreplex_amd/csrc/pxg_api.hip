@@ -82,6 +82,42 @@ static int build_hmm(pxg_ctx* ctx, const pxg_hmm& h, PxgHmmDev& d)
     return PXG_OK;
 }
 
+// Sigmoid spline table: float64 construction from +,*,fma only (no libm), so
+// the oracle and this library hold bit-identical coefficients on any host.
+static double det_exp(double x)
+{
+    const double magic = 6755399441055744.0;        /* 1.5 * 2^52 */
+    double kf = (x * 1.4426950408889634 + magic) - magic;
+    double r = fma(-kf, 6.93147180369123816490e-01, x);
+    r = fma(-kf, 1.90821492927058770002e-10, r);
+    double fact = 6227020800.0;                      /* 13! */
+    double p = 1.0 / fact;
+    for (int n = 13; n >= 1; n--) {
+        fact /= (double)n;
+        p = fma(p, r, 1.0 / fact);
+    }
+    int64_t bits;
+    memcpy(&bits, &p, 8);
+    bits += (int64_t)kf << 52;
+    memcpy(&p, &bits, 8);
+    return p;
+}
+
+static void build_sigmoid_table(std::vector<float>& tab)
+{
+    tab.resize((size_t)PXG_SIG_NSEG * 4);
+    const double h = 1.0 / 16.0;
+    for (int i = 0; i < PXG_SIG_NSEG; i++) {
+        const double z0 = (double)(i - PXG_SIG_HALF) * h, z1 = z0 + h;
+        const double s0 = 1.0 / (1.0 + det_exp(-z0)), s1 = 1.0 / (1.0 + det_exp(-z1));
+        const double d0 = s0 * (1.0 - s0), d1 = s1 * (1.0 - s1);
+        tab[4 * i + 0] = (float)s0;
+        tab[4 * i + 1] = (float)(h * d0);
+        tab[4 * i + 2] = (float)(3.0 * (s1 - s0) - h * (2.0 * d0 + d1));
+        tab[4 * i + 3] = (float)(2.0 * (s0 - s1) + h * (d0 + d1));
+    }
+}
+
 template <typename T>
 static int upload(pxg_ctx* ctx, T** dst, const T* src, size_t n)
 {
@@ -160,6 +196,11 @@ extern "C" int pxg_create(const pxg_config* cfg, pxg_ctx** out)
         if ((rc = upload_lstm(ctx, cfg->demux_top, ctx->demux_top))) break;
         if ((rc = upload_dense(ctx, cfg->demux_dense, ctx->demux_dense))) break;
         if ((rc = upload(ctx, &ctx->d_calibration, cfg->calibration, PXG_MAX_CALIBRATION))) break;
+        {
+            std::vector<float> tab;
+            build_sigmoid_table(tab);
+            if ((rc = upload(ctx, &ctx->d_sigtab, tab.data(), tab.size()))) break;
+        }
         if ((rc = pxg_lstm_upload(ctx))) break;
     } while (0);
     // host pointers in the copied config are not retained
@@ -211,6 +252,7 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     if (ctx->demux_dense.kernel) (void)hipFree(ctx->demux_dense.kernel);
     if (ctx->demux_dense.bias) (void)hipFree(ctx->demux_dense.bias);
     if (ctx->d_calibration) (void)hipFree(ctx->d_calibration);
+    if (ctx->d_sigtab) (void)hipFree(ctx->d_sigtab);
     if (ctx->stream) {
         for (int t = 0; t < PXG_N_TIMERS; t++) {
             (void)hipEventDestroy(ctx->ev_start[t]);

@@ -18,14 +18,44 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------
-// Canonical float32 transcendental kit (DESIGN.md "Canonical LSTM
-// arithmetic"): only IEEE +,*,/,fma and integer ops, so results are bitwise
-// reproducible on any IEEE machine.  exp: Cody-Waite reduction by ln2 (hi/lo),
-// degree-7 Taylor/Horner in fma form, exponent insertion.
+// Canonical float32 activation kit (DESIGN.md "Canonical LSTM arithmetic"),
+// bit-exact with oracle/pxo_core.c:
+//   sigmoid: cubic Hermite spline, 1024 segments of width 1/16 on [-32, 32),
+//            float4 coefficients in LDS (`tab`), u = 16 z, seg = floor(u),
+//            s = u - seg (exact), three fma.   9 VALU + one ds_read_b128.
+//   tanh(x) = fl(2*sigmoid(2x) - 1).
+//   expf (softmax only): Cody-Waite + degree-7 Taylor in fma form.
 // ---------------------------------------------------------------------------
+#define PXG_SIG_NSEG 1024
+#define PXG_SIG_HALF 512
+
+__device__ __forceinline__ float pxg_sig_lookup(const float4* tab, float z, float zscale,
+                                                float zlo, float zhi)
+{
+    z = __builtin_amdgcn_fmed3f(z, zlo, zhi);
+    const float u = z * zscale;
+    const float fl = __builtin_floorf(u);
+    const float s = u - fl;
+    const float4 c = tab[(int)fl + PXG_SIG_HALF];
+    float p = __builtin_fmaf(c.w, s, c.z);
+    p = __builtin_fmaf(p, s, c.y);
+    return __builtin_fmaf(p, s, c.x);
+}
+
+__device__ __forceinline__ float pxg_sigmoid(const float4* tab, float x)
+{
+    return pxg_sig_lookup(tab, x, 16.0f, -32.0f, 31.999998f);
+}
+
+__device__ __forceinline__ float pxg_tanh(const float4* tab, float x)
+{
+    const float s = pxg_sig_lookup(tab, x, 32.0f, -16.0f, 15.999999f);
+    return __builtin_fmaf(2.0f, s, -1.0f);
+}
+
 __device__ __forceinline__ float pxg_expf(float x)
 {
-    x = __builtin_amdgcn_fmed3f(x, -87.0f, 87.0f);   // clamp: result always finite normal
+    x = __builtin_amdgcn_fmed3f(x, -87.0f, 87.0f);
     const float magic = 12582912.0f;  // 1.5 * 2^23
     float t = __builtin_fmaf(x, 1.44269504088896341f, magic);
     float n = t - magic;
@@ -40,29 +70,6 @@ __device__ __forceinline__ float pxg_expf(float x)
     p = __builtin_fmaf(p, r, 1.0f);
     p = __builtin_fmaf(p, r, 1.0f);
     return __int_as_float(__float_as_int(p) + ((int)n << 23));
-}
-
-// 1/d for d in [1, 2^126): integer seed + three fma Newton steps (<= 0.5005 ulp)
-__device__ __forceinline__ float pxg_rcp(float d)
-{
-    float r = __int_as_float((int)(0x7EF311C7u - (unsigned)__float_as_int(d)));
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const float e = __builtin_fmaf(-d, r, 1.0f);
-        r = __builtin_fmaf(r, e, r);
-    }
-    return r;
-}
-
-__device__ __forceinline__ float pxg_sigmoid(float x)
-{
-    return pxg_rcp(1.0f + pxg_expf(-x));
-}
-
-__device__ __forceinline__ float pxg_tanh(float x)
-{
-    const float s = pxg_rcp(1.0f + pxg_expf(-2.0f * x));
-    return __builtin_fmaf(2.0f, s, -1.0f);
 }
 
 // Lane select with the mask in an SGPR pair (v_cndmask_b32_e64).  Measured on
@@ -168,6 +175,7 @@ struct pxg_ctx {
     PxgLstmDev scaler1, scaler2, demux_fwd, demux_bwd, demux_top;
     PxgDenseDev scaler_dense, demux_dense;
     double* d_calibration = nullptr;
+    float* d_sigtab = nullptr;   // PXG_SIG_NSEG x 4 spline coefficients
 
     // resident batch
     int64_t n_reads = 0;

@@ -49,17 +49,28 @@ def demux_f64(win):
 
 
 def test_transcendental_kit_accuracy(oracle):
-    x = np.linspace(-30, 30, 6001).astype(np.float32)
-    assert np.abs(oracle.sigmoid(x) - _sig(x.astype(np.float64))).max() < 1.5e-7
-    assert np.abs(oracle.tanh(x) - np.tanh(x.astype(np.float64))).max() < 3e-7
+    rng = np.random.default_rng(0)
+    x = np.concatenate([np.linspace(-40, 40, 8001), rng.normal(0, 3, 20000)]).astype(np.float32)
+    assert np.abs(oracle.sigmoid(x) - _sig(x.astype(np.float64))).max() < 1.0e-7
+    assert np.abs(oracle.tanh(x) - np.tanh(x.astype(np.float64))).max() < 2.0e-7
     xe = np.linspace(-80, 80, 4001).astype(np.float32)
     rel = np.abs(oracle.expf(xe) / np.exp(xe.astype(np.float64)) - 1)
     assert rel.max() < 2.0 ** -23
     # saturation: -1000 pad steps must not produce NaN (SURVEY K5 note); the
-    # exp argument is clamped to +-87 so the low end is 1/(1+e^87), not 0
-    lo, hi = oracle.sigmoid(np.float32([-1e4, 1e4]))
-    assert 0.0 < lo < 2e-38 and hi == 1.0
-    assert oracle.tanh(np.float32([-1e4, 1e4])).tolist() == [-1.0, 1.0]
+    # spline saturates at sigmoid(+-32)
+    lo, hi, mid = oracle.sigmoid(np.float32([-1e4, 1e4, 0.0]))
+    assert 0.0 < lo < 2e-14 and hi == 1.0 and mid == 0.5
+    assert oracle.tanh(np.float32([-1e4, 1e4, 0.0])).tolist() == [-1.0, 1.0, 0.0]
+
+
+def test_sigmoid_table_is_platform_independent(oracle):
+    # the 1024 x 4 coefficients are built from +,*,fma only; pin a few and the
+    # whole table against float64 libm to 1 ulp
+    tab = oracle.sigmoid_table()
+    assert tab.shape == (1024, 4)
+    z0 = (np.arange(1024) - 512) / 16.0
+    assert np.abs(tab[:, 0] - _sig(z0)).max() < 6e-8
+    assert tab[512].tolist() == [0.5, 0.015625, -3.970503481554033e-09, -5.080306436866522e-06]
 
 
 def test_scaler_net_vs_float64(oracle, stages):
