@@ -458,6 +458,12 @@ class NativeContext:
         self._check(self.lib.pxg_batch_download(self.handle, _ptr(out)), 'pxg_batch_download')
         return out
 
+    def download_spikes(self):
+        out = np.zeros((self.n_resident, PXG_MAX_SPIKES, 4), dtype=np.float32)
+        self._check(self.lib.pxg_batch_download_spikes(self.handle, _ptr(out)),
+                    'pxg_batch_download_spikes')
+        return out
+
     def stage_times(self):
         t = PxgStageTimes()
         self._check(self.lib.pxg_batch_times(self.handle, C.byref(t)), 'pxg_batch_times')

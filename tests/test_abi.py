@@ -1,0 +1,51 @@
+"""The C-ABI library loads and exports every symbol include/pxg.h declares
+(no compute calls: this runs without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from poreplex_amd import native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, 'include', 'pxg.h')).read()
+    return sorted(set(re.findall(r'^\s*(?:int|void|const char\*)\s+(pxg_\w+)\s*\(', text, re.M)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(N.EXPORTED_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.isfile(N.LIB_PATH):
+        pytest.skip('libpxg.so not built (run __graft_entry__.build())')
+    lib = ctypes.CDLL(N.LIB_PATH)
+    for name in declared_symbols():
+        getattr(lib, name)
+    lib.pxg_abi_version.restype = ctypes.c_int
+    assert lib.pxg_abi_version() == N.PXG_ABI_VERSION
+
+
+def test_struct_layouts_match_the_header_sizes():
+    # sizes the C compiler gives the ABI structs (computed from the header by gcc)
+    import subprocess, tempfile
+    src = '#include <stdio.h>\n#include "pxg.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu", sizeof(pxg_config), sizeof(pxg_read_result), sizeof(pxg_hmm), sizeof(pxg_event), sizeof(pxg_calib), sizeof(pxg_stage_times));return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, 'sz.c')
+        open(c, 'w').write(src)
+        exe = os.path.join(d, 'sz')
+        subprocess.check_call(['gcc', '-I' + os.path.join(ROOT, 'include'), c, '-o', exe])
+        sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    want = [ctypes.sizeof(N.PxgConfig), ctypes.sizeof(N.PxgReadResult), ctypes.sizeof(N.PxgHmm),
+            ctypes.sizeof(N.PxgEvent), ctypes.sizeof(N.PxgCalib), ctypes.sizeof(N.PxgStageTimes)]
+    assert sizes == want
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    monkeypatch.setattr(N, '_lib', None)
+    with pytest.raises(N.PxgError, match='no CPU fallback'):
+        N.load_library(str(tmp_path / 'absent.so'))

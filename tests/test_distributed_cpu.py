@@ -1,0 +1,95 @@
+"""N>1 path on CPU: 2 ranks over gloo (the GPU run uses the same code over
+RCCL).  Reads shard contiguously; only label records and the count table are
+exchanged."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+from poreplex_amd import native as N
+from poreplex_amd import distributed as D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_ranges_cover_everything():
+    for n in (0, 1, 7, 10000, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [D.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_shard_by_samples_balances_cost():
+    rng = np.random.default_rng(0)
+    lens = np.concatenate([rng.integers(9000, 20000, 500), rng.integers(200000, 900000, 500)])
+    spans = D.shard_by_samples(lens, 4)
+    assert spans[0][0] == 0 and spans[-1][1] == len(lens)
+    cost = np.minimum(lens, 100000) + 30000
+    per = [cost[a:b].sum() for a, b in spans]
+    assert max(per) / min(per) < 1.15
+
+
+def test_label_records_and_count_table():
+    r = np.zeros(6, N.RESULT_DTYPE)
+    r['status'] = [0, 0, 3, 5, 0, 4]
+    r['bc_called'] = [1, 0, 0, 0, 1, 0]
+    r['bc_label'] = [2, -1, -1, -1, 0, -1]
+    r['seg_last'][:, 3] = [400, 380, -1, -1, 500, -1]
+    rec = D.label_records(r, first_index=100)
+    assert rec['read_index'].tolist() == list(range(100, 106))
+    assert rec['barcode'].tolist() == [2, -1, -1, -1, 0, -1]
+    tbl = D.count_table(rec)
+    assert tbl.sum() == 6 and tbl[0, 3, 0] == 1 and tbl[0, 1, 0] == 1 and tbl[1, 0, 3] == 1
+
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, {root!r})
+    import numpy as np
+    import torch.distributed as dist
+    from poreplex_amd import native as N
+    from poreplex_amd import distributed as D
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n_total = 1001
+    a, b = D.shard_range(n_total, rank, world)
+    # deterministic fake per-read records for this rank's shard
+    res = np.zeros(b - a, N.RESULT_DTYPE)
+    gi = np.arange(a, b)
+    res['status'] = np.where(gi % 17 == 0, 3, 0)
+    res['bc_called'] = (gi % 3 == 0) & (res['status'] == 0)
+    res['bc_label'] = np.where(res['bc_called'] == 1, gi % 4, -1)
+    res['bc_score'] = (gi % 100) / 100.0
+    res['seg_last'][:, 3] = gi % 600
+    allrec = D.gather_labels(res, dist, first_index=a)
+    tbl = D.reduce_counts(D.label_records(res, a), dist)
+    assert len(allrec) == n_total and allrec['read_index'].tolist() == list(range(n_total))
+    g = allrec['read_index']
+    assert np.array_equal(allrec['status'], np.where(g % 17 == 0, 3, 0))
+    assert np.array_equal(allrec['barcode'], np.where((g % 3 == 0) & (g % 17 != 0), g % 4, -1))
+    assert np.array_equal(tbl, D.count_table(allrec)) and tbl.sum() == n_total
+    dist.barrier()
+    dist.destroy_process_group()
+    print('rank', rank, 'ok')
+''')
+
+
+def test_two_rank_gloo_gather_and_reduce(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER.format(root=ROOT))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    out = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
+        env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert 'rank 0 ok' in out.stdout and 'rank 1 ok' in out.stdout

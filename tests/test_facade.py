@@ -1,0 +1,154 @@
+"""The reference's operator surface (process_batch / SignalAnalyzer /
+SignalAnalysis / NanoporeRead.report) against what the REAL reference's
+process_batch returned for the same reads (tests/golden/batch0.results.json).
+
+CPU leg: the host logic (ordering, status/label rules, dict schema) is driven
+with a test double of the GPU context that answers from the oracle -- test
+infrastructure only, injected here, never reachable from the product.
+GPU leg (-m gpu): the real context.
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+from poreplex_amd import native as N
+from poreplex_amd.config import default_config
+from poreplex_amd.worker_persistence import WorkerPersistenceStorage
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+BUNDLE = os.path.join(GOLDEN, 'batch0.pxr.npz')
+
+
+def facade_config(ref_results, **kw):
+    flags = dict(ref_results['config_flags'])
+    flags.update(kw)
+    return default_config(inputdir='/nonexistent-inputdir', outputdir='/tmp',
+                          read_bundle=BUNDLE, **flags)
+
+
+def canon(o):
+    """JSON-ify like tools/make_golden.py did for the reference's dicts."""
+    if isinstance(o, dict):
+        return {str(k): canon(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [canon(v) for v in o]
+    if isinstance(o, np.floating):
+        return float(o)
+    if isinstance(o, np.integer):
+        return int(o)
+    return o
+
+
+def compare_results(got, want, check_polya):
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        g, w = canon(g), copy.deepcopy(w)
+        if g['status'] == 'unknown_error':
+            # same status, same keys; the traceback text names other files
+            assert w['status'] == 'unknown_error' and set(g) == set(w)
+            assert g['filename'] == w['filename'] and g['read_id'] == w['read_id']
+            continue
+        if not check_polya:
+            g.pop('polya', None)
+            w.pop('polya', None)
+        assert list(g.keys()) == list(w.keys()), (g.get('read_id'), list(g), list(w))
+        for k in w:
+            assert g[k] == w[k], (g.get('read_id'), k, g[k], w[k])
+
+
+class OracleBackedContext:
+    """Test double of NativeContext for the CPU leg: same methods the facade
+    uses, answers computed by oracle/libpxo.so."""
+
+    def __init__(self, config, device_id=0):
+        from oracle.pxo import Oracle
+        self.oracle = Oracle(config)
+        self.ncfg = self.oracle.ncfg
+        self.cfg = self.oracle.cfg
+        self.state_names = self.oracle.state_names
+
+    def upload(self, arena, offsets, calib, scale_shift=None):
+        self.batch = (arena, offsets, calib, scale_shift)
+
+    def run(self, mask):
+        self.res, self.spk = self.oracle.process_batch(*self.batch, stage_mask=mask,
+                                                       want_spikes=True)
+
+    def download(self):
+        return self.res
+
+    def download_spikes(self):
+        return self.spk
+
+    def close(self):
+        pass
+
+
+@pytest.fixture()
+def oracle_backed(monkeypatch):
+    WorkerPersistenceStorage.reset()
+    monkeypatch.setattr(N, 'NativeContext', OracleBackedContext)
+    yield
+    WorkerPersistenceStorage.reset()
+
+
+def test_process_batch_host_logic_vs_reference(oracle_backed, ref_results):
+    from poreplex_amd.signal_analyzer import process_batch
+    reads = [tuple(r) for r in ref_results['reads']]
+    got = process_batch(ref_results['batchid'], reads, facade_config(ref_results))
+    assert not (isinstance(got, tuple) and got[0] == -1), got
+    compare_results(got, ref_results['results'], check_polya=True)
+    # early failures first (encounter order), then loaded reads in input order
+    assert [r['status'] for r in got[:3]] == ['unknown_error', 'disappeared',
+                                             'scaler_signal_too_short']
+    assert 'read_id' not in got[1]
+
+
+def test_operator_surface(oracle_backed, ref_results):
+    from poreplex_amd import signal_analyzer as SA
+    assert SA.__all__ == ['SignalAnalyzer', 'SignalAnalysis', 'process_batch']
+    cfg = facade_config(ref_results, measure_polya=False)
+    with SA.SignalAnalyzer(cfg, 3) as an:
+        for name in ('segmodel', 'unsplitmodel', 'kmersize', 'loader', 'demuxer', 'ctx'):
+            assert hasattr(an, name)
+        assert an.formatted_batchid == '00000003' and an.kmersize == 5
+        res = an.process([tuple(r) for r in ref_results['reads'][:6]])
+        assert all({'filename', 'status'} <= set(r) for r in res)
+    for meth in ('process', 'detect_segments', 'push_barcode_signal', 'trim_adapter',
+                 'load_events', 'is_stopped', 'set_error', 'clear_cache'):
+        assert hasattr(SA.SignalAnalysis, meth)
+
+
+def test_missing_gpu_is_fatal_tuple_not_fallback(ref_results, monkeypatch):
+    """No library / no device -> the (-1, msg, tb) tuple (signal_analyzer.py:50-58);
+    never a silent CPU path."""
+    from poreplex_amd.signal_analyzer import process_batch
+    WorkerPersistenceStorage.reset()
+
+    def boom(config, device_id=0):
+        raise N.PxgError('pxg_create failed (-2): no HIP device visible')
+    monkeypatch.setattr(N, 'NativeContext', boom)
+    out = process_batch(1, [tuple(r) for r in ref_results['reads'][:2]],
+                        facade_config(ref_results))
+    assert isinstance(out, tuple) and out[0] == -1 and 'PxgError' in out[1]
+    WorkerPersistenceStorage.reset()
+
+
+def test_barcoding_quality_filter_guard(oracle_backed, ref_results):
+    from poreplex_amd.signal_analyzer import process_batch
+    out = process_batch(1, [], facade_config(ref_results, barcoding_quality_filter=40))
+    assert isinstance(out, tuple) and out[0] == -1 and 'barcoding-quality-filter' in out[1]
+
+
+@pytest.mark.gpu
+def test_process_batch_gpu_vs_reference(ref_results):
+    from poreplex_amd.signal_analyzer import process_batch
+    WorkerPersistenceStorage.reset()
+    reads = [tuple(r) for r in ref_results['reads']]
+    cfg = facade_config(ref_results, measure_polya=False)
+    got = process_batch(ref_results['batchid'], reads, cfg)
+    assert not (isinstance(got, tuple) and got[0] == -1), got
+    compare_results(got, ref_results['results'], check_polya=False)
+    WorkerPersistenceStorage.reset()

@@ -359,7 +359,7 @@ def main():
             first = int(rng.integers(0, 40))
             bc = make_basecall(rng, len(r['raw']), first, r['seq_len'])
         write_fast5(os.path.join(inputdir, fn), rid, r['raw'], r['cal'], meta, bc)
-        items.append({'filename': fn, 'read_id': rid, 'meta': meta, 'basecall': bc, **r})
+        items.append({**r, 'filename': fn, 'read_id': rid, 'meta': meta, 'basecall': bc})
     # a corrupt file and a vanished file
     with open(os.path.join(inputdir, 'broken.fast5'), 'wb') as fh:
         fh.write(b'this is not an HDF5 file')
@@ -457,6 +457,7 @@ def main():
         true_scale_shift=np.array([it['ss'] for it in items], dtype=np.float32),
         true_barcode=np.array([it['barcode'] for it in items], dtype=np.int8),
         tag=np.array([it['tag'] for it in items]),
+        broken_files=np.array(['broken.fast5']),   # present on disk but not HDF5
     )
 
     # ---- per-stage captures ------------------------------------------------
