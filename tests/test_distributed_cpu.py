@@ -76,13 +76,13 @@ WORKER = textwrap.dedent('''
     assert np.array_equal(tbl, D.count_table(allrec)) and tbl.sum() == n_total
     dist.barrier()
     dist.destroy_process_group()
-    print('rank', rank, 'ok')
+    open(os.path.join({out!r}, 'rank%d.ok' % rank), 'w').write('ok')
 ''')
 
 
 def test_two_rank_gloo_gather_and_reduce(tmp_path):
     script = tmp_path / 'worker.py'
-    script.write_text(WORKER.format(root=ROOT))
+    script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
@@ -92,4 +92,4 @@ def test_two_rank_gloo_gather_and_reduce(tmp_path):
          '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
         env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert 'rank 0 ok' in out.stdout and 'rank 1 ok' in out.stdout
+    assert (tmp_path / 'rank0.ok').exists() and (tmp_path / 'rank1.ok').exists()
