@@ -310,6 +310,7 @@ __global__ void k_finalize(int64_t n, FinalizeParams fp, const int64_t* __restri
                            const float* __restrict__ pred, const int32_t* __restrict__ segs,
                            const float* __restrict__ probs, const int8_t* __restrict__ pushed,
                            const double* __restrict__ calibration,
+                           const int32_t* __restrict__ polya,
                            pxg_read_result* __restrict__ out)
 {
     const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -358,6 +359,14 @@ __global__ void k_finalize(int64_t n, FinalizeParams fp, const int64_t* __restri
         }
         o.bc_phred = (uint8_t)ph;
     }
+    if ((fp.stage_mask & PXG_STAGE_POLYA) && polya && o.status == PXG_ST_OKAY) {
+        const int32_t* po = polya + r * 8;
+        o.polya_called = (int8_t)po[0];
+        o.polya_n_spikes = (int8_t)po[1];
+        o.polya_dwell_samples = po[2];
+        o.polya_begin = (int64_t)(((uint64_t)(uint32_t)po[4] << 32) | (uint32_t)po[3]);
+        o.polya_end = (int64_t)(((uint64_t)(uint32_t)po[6] << 32) | (uint32_t)po[5]);
+    }
     out[r] = o;
 }
 
@@ -384,6 +393,7 @@ int pxg_launch_finalize(pxg_ctx* ctx, int64_t n, uint32_t stage_mask)
                           c.signal_trim_length, c.score_threshold, stage_mask };
     hipLaunchKernelGGL(k_finalize, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream, n,
                        fp, ctx->offsets.p, ctx->status.p, ctx->ss.p, ctx->pred.p, ctx->segs.p,
-                       ctx->probs.p, pushed, ctx->d_calibration, ctx->results.p);
+                       ctx->probs.p, pushed, ctx->d_calibration,
+                       (stage_mask & PXG_STAGE_POLYA) ? ctx->polya_out.p : nullptr, ctx->results.p);
     return PXG_OK;
 }

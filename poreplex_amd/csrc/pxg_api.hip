@@ -244,7 +244,7 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     release(ctx->head); release(ctx->pred); release(ctx->ss); release(ctx->status);
     release(ctx->segs); release(ctx->idx_scaler); release(ctx->idx_demux);
     release(ctx->counters); release(ctx->win); release(ctx->bidir); release(ctx->probs);
-    release(ctx->results);
+    release(ctx->results); release(ctx->polya_ev); release(ctx->polya_out); release(ctx->spikes);
     free_lstm(ctx->scaler1); free_lstm(ctx->scaler2); free_lstm(ctx->demux_fwd);
     free_lstm(ctx->demux_bwd); free_lstm(ctx->demux_top);
     if (ctx->scaler_dense.kernel) (void)hipFree(ctx->scaler_dense.kernel);
@@ -347,8 +347,8 @@ extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
     if (!ctx) return PXG_E_INVALID;
     const int64_t n = ctx->n_reads;
     if (n <= 0) return fail(ctx, PXG_E_STATE, "pxg_batch_run: no resident batch");
-    if (stage_mask & PXG_STAGE_POLYA)
-        return fail(ctx, PXG_E_UNSUPPORTED, "poly(A) stage is not built into the GPU path yet");
+    if ((stage_mask & PXG_STAGE_POLYA) && !(stage_mask & PXG_STAGE_SEGMENT))
+        return fail(ctx, PXG_E_INVALID, "poly(A) stage needs the segment stage");
     if ((stage_mask & PXG_STAGE_BARCODE) && !(stage_mask & PXG_STAGE_SEGMENT))
         return fail(ctx, PXG_E_INVALID, "barcode stage needs the segment stage");
     if ((stage_mask & PXG_STAGE_SEGMENT) && !(stage_mask & PXG_STAGE_SCALER) && !ctx->have_inject)
@@ -402,6 +402,17 @@ extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
                                         ctx->bidir.p, ctx->probs.p, PXG_T_DEMUX_BIDIR,
                                         PXG_T_DEMUX_TOP))) return rc;
     }
+    ctx->polya_ran = false;
+    if (stage_mask & PXG_STAGE_POLYA) {
+        if ((rc = pxg_reserve(ctx, ctx->polya_out, (size_t)n * 8))) return rc;
+        if ((rc = pxg_reserve(ctx, ctx->spikes, (size_t)n * PXG_MAX_SPIKES))) return rc;
+        PXG_HIP(ctx, hipMemsetAsync(ctx->spikes.p, 0, (size_t)n * PXG_MAX_SPIKES * sizeof(pxg_polya_spike), ctx->stream));
+        pxg_timer_begin(ctx, PXG_T_POLYA);
+        if ((rc = pxg_launch_polya(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p,
+                                   ctx->status.p, ctx->segs.p, ctx->polya_out.p, ctx->spikes.p))) return rc;
+        pxg_timer_end(ctx, PXG_T_POLYA);
+        ctx->polya_ran = true;
+    }
     pxg_timer_begin(ctx, PXG_T_FINALIZE);
     if ((rc = pxg_launch_finalize(ctx, n, stage_mask))) return rc;
     pxg_timer_end(ctx, PXG_T_FINALIZE);
@@ -427,9 +438,15 @@ extern "C" int pxg_batch_download(pxg_ctx* ctx, pxg_read_result* out)
     return PXG_OK;
 }
 
-extern "C" int pxg_batch_download_spikes(pxg_ctx* ctx, pxg_polya_spike*)
+extern "C" int pxg_batch_download_spikes(pxg_ctx* ctx, pxg_polya_spike* out)
 {
-    return fail(ctx, PXG_E_UNSUPPORTED, "poly(A) stage is not built into the GPU path yet");
+    if (!ctx || (!out && ctx->n_reads)) return PXG_E_INVALID;
+    if (ctx->n_reads <= 0) return PXG_OK;
+    if (!ctx->polya_ran) return fail(ctx, PXG_E_STATE, "the last run had no poly(A) stage");
+    PXG_HIP(ctx, hipMemcpyAsync(out, ctx->spikes.p, (size_t)ctx->n_reads * PXG_MAX_SPIKES * sizeof(pxg_polya_spike),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PXG_OK;
 }
 
 extern "C" int pxg_batch_times(pxg_ctx* ctx, pxg_stage_times* out)
@@ -657,8 +674,35 @@ extern "C" int pxg_demux_lstm(pxg_ctx* ctx, int64_t n, const float* win, float* 
     HOOK_END
 }
 
-extern "C" int pxg_detect_events(pxg_ctx* ctx, int64_t, const float*, const int64_t*, int64_t,
-                                 pxg_event*, int64_t*)
+extern "C" int pxg_detect_events(pxg_ctx* ctx, int64_t n, const float* signal_arena,
+                                 const int64_t* off, int64_t cap, pxg_event* events,
+                                 int64_t* n_events)
 {
-    return fail(ctx, PXG_E_UNSUPPORTED, "pxg_detect_events: event-detection kernel not built yet");
+    HOOK_BEGIN
+    if (n <= 0) return PXG_OK;
+    if (cap < 1) return fail(ctx, PXG_E_INVALID, "max_events_per_window must be >= 1");
+    struct EvRec { uint32_t start; float length, mean, stdv; };
+    const size_t blocks = (size_t)(n + 63) / 64;
+    float* d_sig = S.put(signal_arena, (size_t)off[n], ctx->stream);
+    int64_t* d_off = S.put(off, (size_t)n + 1, ctx->stream);
+    EvRec* d_ev = S.alloc<EvRec>(blocks * (size_t)cap * 64);
+    int64_t* d_cnt = S.alloc<int64_t>((size_t)n);
+    HOOK_CHECK(d_sig && d_off && d_ev && d_cnt);
+    int rc = pxg_launch_detect_events(ctx, n, d_sig, d_off, cap, d_ev, d_cnt);
+    if (rc) return rc;
+    std::vector<EvRec> ev(blocks * (size_t)cap * 64);
+    HOOK_GET(ev.data(), d_ev, ev.size());
+    HOOK_GET(n_events, d_cnt, n);
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t r = 0; r < n; r++) {
+        const size_t blk = (size_t)r / 64, lane = (size_t)r % 64;
+        const int64_t m = std::min<int64_t>(n_events[r], cap);
+        for (int64_t q = 0; q < m; q++) {
+            const EvRec& e = ev[(blk * (size_t)cap + (size_t)q) * 64 + lane];
+            pxg_event& o = events[r * cap + q];
+            o.start = e.start; o.length = e.length; o.mean = e.mean; o.stdv = e.stdv;
+            o.pos = -1; o.state = -1;               // csupport.c:156-159 defaults
+        }
+    }
+    HOOK_END
 }

@@ -197,6 +197,10 @@ struct pxg_ctx {
     DevBuf<float> bidir;         // n x trim x (Hf+Hb), permuted layout
     DevBuf<float> probs;         // n x PXG_MAX_CLASSES
     DevBuf<pxg_read_result> results;
+    DevBuf<char> polya_ev;       // event scratch, [wave][event][lane]
+    DevBuf<int32_t> polya_out;   // n x 8: called, n_spikes, dwell, begin lo/hi, end lo/hi
+    DevBuf<pxg_polya_spike> spikes;   // n x PXG_MAX_SPIKES
+    bool polya_ran = false;
 
     hipEvent_t ev_start[PXG_N_TIMERS];
     hipEvent_t ev_stop[PXG_N_TIMERS];
@@ -261,7 +265,13 @@ int pxg_launch_demux_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
                           const int32_t* count, const float* win, float* bidir, float* probs,
                           int timer_a, int timer_b);
 int pxg_launch_finalize(pxg_ctx* ctx, int64_t n, uint32_t stage_mask);
-int pxg_lstm_upload(pxg_ctx* ctx);   // weight repacking, if any
+int pxg_lstm_upload(pxg_ctx* ctx);   // shape checks
+int pxg_polya_supported(pxg_ctx* ctx);
+int pxg_launch_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
+                     const pxg_calib* cal, const float* ss, const int32_t* status,
+                     const int32_t* segs, int32_t* pout, pxg_polya_spike* spikes);
+int pxg_launch_detect_events(pxg_ctx* ctx, int64_t n, const float* sig, const int64_t* off,
+                             int64_t cap, void* evbuf, int64_t* n_events);
 
 void pxg_timer_begin(pxg_ctx* ctx, int t);
 void pxg_timer_end(pxg_ctx* ctx, int t);

@@ -147,8 +147,8 @@ def test_process_batch_gpu_vs_reference(ref_results):
     from poreplex_amd.signal_analyzer import process_batch
     WorkerPersistenceStorage.reset()
     reads = [tuple(r) for r in ref_results['reads']]
-    cfg = facade_config(ref_results, measure_polya=False)
+    cfg = facade_config(ref_results)        # measure_polya on, as the reference ran it
     got = process_batch(ref_results['batchid'], reads, cfg)
     assert not (isinstance(got, tuple) and got[0] == -1), got
-    compare_results(got, ref_results['results'], check_polya=False)
+    compare_results(got, ref_results['results'], check_polya=True)
     WorkerPersistenceStorage.reset()

@@ -140,6 +140,74 @@ def test_demux_lstm_bit_exact(ctx, oracle, stages, n):
     assert np.array_equal(got.argmax(1), want.argmax(1))
 
 
+# ---- a14-a17: events + poly(A) ----------------------------------------------------
+def test_detect_events_vs_reference_extension(ctx, oracle, unit):
+    # src/csupport.c:70-124 outputs captured from the real CPython extension
+    off = np.concatenate([[0], np.cumsum(unit['ev_len'])])
+    eo = np.concatenate([[0], np.cumsum(unit['ev_cnt'])])
+    sigs = [unit['ev_in'][off[k]:off[k + 1]] for k in range(len(unit['ev_len']))]
+    evs, cnt = ctx.detect_events(sigs, max_events=int(unit['ev_cnt'].max()) + 4)
+    assert np.array_equal(cnt, unit['ev_cnt'])
+    for k, ev in enumerate(evs):
+        for f in ('start', 'length', 'mean', 'stdv'):
+            assert np.array_equal(ev[f], unit['ev_' + f][eo[k]:eo[k + 1]], equal_nan=True), (k, f)
+        assert (ev['pos'] == -1).all() and (ev['state'] == -1).all()
+
+
+def test_detect_events_many_windows_vs_oracle(ctx, oracle):
+    rng = np.random.default_rng(8)
+    sigs = []
+    for k in range(150):                      # > 2 waves of lanes, ragged lengths
+        n = int(rng.integers(1, 4000))
+        lv = rng.normal(95, 15, n // 6 + 2)
+        x = np.repeat(lv, rng.geometric(1 / 8., len(lv)))[:n]
+        sigs.append((x + rng.normal(0, rng.uniform(0.2, 3), len(x))).astype(np.float32))
+    evs, cnt = ctx.detect_events(sigs, max_events=1200)
+    for k, s in enumerate(sigs):
+        want = oracle.detect_events(s)
+        assert cnt[k] == len(want), k
+        for f in ('start', 'length', 'mean', 'stdv'):
+            assert np.array_equal(evs[k][f], want[f], equal_nan=True), (k, f)
+
+
+def test_polya_golden_bundle_vs_reference(ctx, oracle, bundle, ref_results):
+    """a14-a17 on the GPU vs the REAL polya.py results (begin/end/dwell/spikes)."""
+    mask = N.STAGE_ALL_DEMUX | N.STAGE_POLYA
+    ctx.upload(bundle['arena'], bundle['offsets'], bundle['calib'])
+    ctx.run(mask)
+    got, spikes = ctx.download(), ctx.download_spikes()
+    want, wspk = oracle.process_batch(bundle['arena'], bundle['offsets'], bundle['calib'],
+                                      stage_mask=mask, want_spikes=True)
+    assert_records_equal(got, want, ctxmsg='polya golden')
+    assert np.array_equal(spikes, wspk, equal_nan=True)
+    by_id = {r.get('read_id'): r for r in ref_results['results'] if 'read_id' in r}
+    n = 0
+    for i, rid in enumerate(bundle['read_id']):
+        p = by_id[str(rid)].get('polya')
+        assert bool(got['polya_called'][i]) == (p is not None), (i, bundle['tag'][i])
+        if p is not None:
+            assert (got['polya_begin'][i], got['polya_end'][i]) == (p['begin'], p['end'])
+            assert got['polya_dwell_samples'][i] / float(bundle['calib'][i]['sampling_rate']) == p['dwell_time']
+            assert got['polya_n_spikes'][i] == len(p['spikes'])
+            for k, sp in enumerate(p['spikes'][:N.PXG_MAX_SPIKES]):
+                assert np.array_equal(np.float32(sp), spikes[i, k]), (i, k)
+            n += 1
+    assert n >= 15
+
+
+def test_polya_synthetic_200_vs_oracle(ctx, oracle):
+    b = synth_batch(200, seed=927, samples_per_read=36000, jitter=0.3)
+    mask = N.STAGE_SEGMENT | N.STAGE_POLYA
+    ctx.upload(b['arena'], b['offsets'], b['calib'], b['scale_shift'])
+    ctx.run(mask)
+    got, spikes = ctx.download(), ctx.download_spikes()
+    want, wspk = oracle.process_batch(b['arena'], b['offsets'], b['calib'], b['scale_shift'],
+                                      stage_mask=mask, want_spikes=True)
+    assert_records_equal(got, want, ctxmsg='polya synthetic')
+    assert np.array_equal(spikes, wspk, equal_nan=True)
+    assert got['polya_called'].sum() > 100
+
+
 # ---- whole path ------------------------------------------------------------------
 def test_process_batch_golden_bundle(ctx, oracle, bundle):
     for inject in (None, bundle['true_scale_shift']):
