@@ -41,7 +41,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--reads', type=int, default=10000, help='reads per GPU per step')
     ap.add_argument('--samples', type=int, default=60000, help='nominal samples per read')
-    ap.add_argument('--workload', choices=['demux', 'segment'], default='demux')
+    ap.add_argument('--workload', choices=['demux', 'segment', 'polya'], default='demux')
     ap.add_argument('--cpu-sample', type=int, default=1024,
                     help='reads timed on the host for cpu_baseline (0 = skip)')
     ap.add_argument('--check', type=int, default=64, help='reads compared with the oracle')
@@ -73,6 +73,8 @@ def main():
     batch = synth_batch(args.reads, seed=args.seed + 1000 * rank, samples_per_read=args.samples)
     if args.workload == 'demux':
         mask, inject = N.STAGE_ALL_DEMUX, None
+    elif args.workload == 'polya':
+        mask, inject = N.STAGE_ALL_DEMUX | N.STAGE_POLYA, None
     else:
         mask, inject = N.STAGE_SEGMENT, batch['scale_shift']
     t_up0 = time.perf_counter()
@@ -121,7 +123,7 @@ def main():
     n_pushed = int(res['bc_pushed'].sum())
 
     # ---- roofline of the dominant kernel ------------------------------------
-    if args.workload == 'demux':
+    if args.workload in ('demux', 'polya'):
         dur = stage_ms['scaler_lstm'] * 1e-3
         flops = n_scaled * FLOP_SCALER
         roofline = {'kernel': 'k_scaler_lstm', 'bound': 'mfma',
@@ -175,16 +177,17 @@ def main():
         }
 
     line = {
-        'metric': 'reads/s (segment+barcode)' if args.workload == 'demux'
-                  else 'reads/s (normalise+segment)',
+        'metric': {'demux': 'reads/s (segment+barcode)', 'polya': 'reads/s (segment+barcode+polyA)',
+                   'segment': 'reads/s (normalise+segment)'}[args.workload],
         'value': value, 'unit': 'reads/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32 (LSTM MFMA) / f64 (Viterbi) / i16 in', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[{}]: {} reads/GPU x ~{} int16 samples, stages {}'.format(
-                       2 if args.workload == 'demux' else 1, args.reads, args.samples,
-                       'a1-a13 (scaler LSTM + Viterbi + barcode LSTMs)' if args.workload == 'demux'
-                       else 'a1,a5,a7,a8 (injected scaling)'),
+                       {'demux': 2, 'polya': 3, 'segment': 1}[args.workload], args.reads, args.samples,
+                       {'demux': 'a1-a13 (scaler LSTM + Viterbi + barcode LSTMs)',
+                        'polya': 'a1-a17 (+ poly(A) events/DP)',
+                        'segment': 'a1,a5,a7,a8 (injected scaling)'}[args.workload]),
                    'reads_per_gpu': args.reads, 'samples_per_read': args.samples,
                    'parallelism': 'reads sharded x{}'.format(world), 'device': info['name'],
                    'arch': info['arch'], 'compute_units': info['compute_units']},

@@ -137,40 +137,69 @@ __device__ __forceinline__ Ev make_event(unsigned long long b, unsigned long lon
     return ev;
 }
 
-// Streaming detect_events over one window; returns the event count (>= 1);
-// events beyond `cap` are counted but not stored.
-__device__ int detect_events_stream(const WindowSrc& S, const PolyaParams& P, double2* ring,
-                                    int lane, Ev* ev /* [cap][64] */, int cap)
+// Resumable streaming state of detect_events for one lane.
+struct Stream {
+    Detector det[2];
+    double cs, cq;
+    int64_t filled;            // prefix indices [0, filled] are in the ring
+    int64_t i;                 // next sample the peak detector will visit
+    float x0, x1, x2, x3, x4, x5, x6;   // scaled samples filled-3 .. filled+3
+    int ne;
+    unsigned long long prev_pos;
+    double prev_cs, prev_cq;
+};
+
+__device__ __forceinline__ void stream_init(Stream& st, const WindowSrc& S, const PolyaParams& P,
+                                            double2* ring, int lane)
+{
+    st.det[0] = { P.thr1, (unsigned)P.w1, 0ull, -1, FLT_MAX, 0, 0.0, 0.0 };
+    st.det[1] = { P.thr2, (unsigned)P.w2, 0ull, -1, FLT_MAX, 0, 0.0, 0.0 };
+    st.cs = 0.0; st.cq = 0.0; st.filled = 0; st.i = 0;
+    st.x0 = st.x1 = st.x2 = 0.0f;
+    st.x3 = S.scaled(0); st.x4 = S.scaled(1); st.x5 = S.scaled(2); st.x6 = S.scaled(3);
+    st.ne = 0; st.prev_pos = 0; st.prev_cs = 0.0; st.prev_cq = 0.0;
+    ring[0 * 64 + lane] = make_double2(0.0, 0.0);
+}
+
+// Streaming detect_events over the window S (event_detection.c:273-324);
+// returns the event count (>= 1); events beyond `cap` are counted, not stored.
+// When `snap` is given, the state at step n - PA_SAFE (everything before it is
+// independent of where the window ends: the median filter looks 3 samples
+// ahead, the t-statistics 20) is saved so that an open-end retry with a longer
+// window resumes there instead of starting over.
+#define PA_SAFE 28
+__device__ int detect_events_stream(Stream& st, const WindowSrc& S, const PolyaParams& P,
+                                    double2* ring, int lane, Ev* ev /* [cap][64] */, int cap,
+                                    Stream* snap, double2* snap_ring /* [PA_RING][64] */,
+                                    int64_t* snap_n)
 {
     const int64_t n = S.W;
     const int mpf = P.median_pre_filter;
-    Detector det[2];
-    det[0] = { P.thr1, (unsigned)P.w1, 0ull, -1, FLT_MAX, 0, 0.0, 0.0 };
-    det[1] = { P.thr2, (unsigned)P.w2, 0ull, -1, FLT_MAX, 0, 0.0, 0.0 };
     const int64_t look = P.w1 > P.w2 ? P.w1 : P.w2;    // prefix look-ahead (<= 31)
-
-    double cs = 0.0, cq = 0.0;
-    int64_t filled = 0;                                  // prefix indices [0, filled] are in the ring
-    ring[0 * 64 + lane] = make_double2(0.0, 0.0);
-    int ne = 0;
-    unsigned long long prev_pos = 0;
-    double prev_cs = 0.0, prev_cq = 0.0;
-
-    for (int64_t i = 0; i < n; i++) {
+    const int64_t snap_at = n - PA_SAFE;
+    for (int64_t i = st.i; i < n; i++) {
+        if (snap && i == snap_at && i > 0) {
+            st.i = i;
+            *snap = st;
+            *snap_n = n;
+            for (int q = 0; q < PA_RING; q++) snap_ring[q * 64 + lane] = ring[q * 64 + lane];
+        }
         // extend the prefix sums to index min(i + look, n), strictly in order
         const int64_t need = (i + look) < n ? (i + look) : n;
-        while (filled < need) {
-            const float f = filtered_at(S, filled, mpf);
+        while (st.filled < need) {
+            const float f = mpf <= 1 ? st.x3 : median7(st.x0, st.x1, st.x2, st.x3, st.x4, st.x5, st.x6);
+            st.x0 = st.x1; st.x1 = st.x2; st.x2 = st.x3; st.x3 = st.x4; st.x4 = st.x5; st.x5 = st.x6;
+            st.x6 = S.scaled(st.filled + 4);
             const float sq = f * f;
-            cs = cs + (double)f;
-            cq = cq + (double)sq;
-            filled++;
-            ring[(filled & (PA_RING - 1)) * 64 + lane] = make_double2(cs, cq);
+            st.cs = st.cs + (double)f;
+            st.cq = st.cq + (double)sq;
+            st.filled++;
+            ring[(st.filled & (PA_RING - 1)) * 64 + lane] = make_double2(st.cs, st.cq);
         }
         const double2 here = ring[(i & (PA_RING - 1)) * 64 + lane];
 #pragma unroll
         for (int d = 0; d < 2; d++) {
-            Detector& D = det[d];
+            Detector& D = st.det[d];
             if (D.masked_to >= (unsigned long long)i) continue;
             const float cur = tstat_at(ring, lane, i, D.window, n);
             if (D.peak_pos == -1) {
@@ -190,19 +219,20 @@ __device__ int detect_events_stream(const WindowSrc& S, const PolyaParams& P, do
                     D.pk_cq = here.y;
                 }
                 if (d == 0 && D.peak_val > D.threshold) {
-                    det[1].masked_to = (unsigned long long)D.peak_pos + D.window;
-                    det[1].peak_pos = -1;
-                    det[1].peak_val = FLT_MAX;
-                    det[1].valid = 0;
+                    st.det[1].masked_to = (unsigned long long)D.peak_pos + D.window;
+                    st.det[1].peak_pos = -1;
+                    st.det[1].peak_val = FLT_MAX;
+                    st.det[1].valid = 0;
                 }
                 if (D.peak_val - cur > P.peak_height && D.peak_val > D.threshold) D.valid = 1;
                 if (D.valid && ((unsigned long long)i - (unsigned long long)D.peak_pos) > D.window / 2) {
                     const unsigned long long p = (unsigned long long)D.peak_pos;
-                    if (ne < cap) ev[(size_t)ne * 64 + lane] = make_event(prev_pos, p, prev_cs, prev_cq, D.pk_cs, D.pk_cq);
-                    ne++;
-                    prev_pos = p;
-                    prev_cs = D.pk_cs;
-                    prev_cq = D.pk_cq;
+                    if (st.ne < cap)
+                        ev[(size_t)st.ne * 64 + lane] = make_event(st.prev_pos, p, st.prev_cs, st.prev_cq, D.pk_cs, D.pk_cq);
+                    st.ne++;
+                    st.prev_pos = p;
+                    st.prev_cs = D.pk_cs;
+                    st.prev_cq = D.pk_cq;
                     D.peak_pos = -1;
                     D.peak_val = cur;
                     D.valid = 0;
@@ -210,14 +240,14 @@ __device__ int detect_events_stream(const WindowSrc& S, const PolyaParams& P, do
             }
         }
     }
+    st.i = n;
     // last event [prev, n); with no peak at all scrappie emits the single
     // zero-length event [0, peaks[0] = 0)  (event_detection.c:261-268)
-    const unsigned long long en = ne > 0 ? (unsigned long long)n : 0ull;
+    int ne = st.ne;
     if (ne < cap)
-        ev[(size_t)ne * 64 + lane] = ne > 0 ? make_event(prev_pos, en, prev_cs, prev_cq, cs, cq)
+        ev[(size_t)ne * 64 + lane] = ne > 0 ? make_event(st.prev_pos, (unsigned long long)n, st.prev_cs, st.prev_cq, st.cs, st.cq)
                                             : make_event(0, 0, 0.0, 0.0, 0.0, 0.0);
-    ne++;
-    return ne;
+    return ne + 1;
 }
 
 // ---------------------------------------------------------------------------
@@ -280,6 +310,42 @@ __device__ float np_sum_f32(const F& v, int64_t n)
     return ret;
 }
 
+// Resolve "the idx-th event in [lo, hi] that satisfies pred" for the
+// monotonically increasing idx sequence np_sum_f32 produces (amortised O(1)).
+struct NthCursor {
+    int q, seen;
+};
+template <typename Pred>
+__device__ __forceinline__ int nth_matching(const Pred& pred, int lo, int hi, int idx, NthCursor& c)
+{
+    if (idx < c.seen || c.q < lo) { c.q = lo - 1; c.seen = -1; }
+    while (c.seen < idx && c.q < hi) {
+        c.q++;
+        if (pred(c.q)) c.seen++;
+    }
+    return c.q;
+}
+
+// filtered sample j through a sliding 7-sample register window: one pA
+// conversion per step when j advances by one (the QC reductions do)
+struct FiltCursor {
+    int64_t j;
+    float x0, x1, x2, x3, x4, x5, x6;
+};
+__device__ __forceinline__ float filtered_seq(const WindowSrc& S, int mpf, int64_t j, FiltCursor& c)
+{
+    if (mpf <= 1) return S.scaled(j);
+    if (j == c.j + 1) {
+        c.x0 = c.x1; c.x1 = c.x2; c.x2 = c.x3; c.x3 = c.x4; c.x4 = c.x5; c.x5 = c.x6;
+        c.x6 = S.scaled(j + 3);
+    } else if (j != c.j) {
+        c.x0 = S.scaled(j - 3); c.x1 = S.scaled(j - 2); c.x2 = S.scaled(j - 1); c.x3 = S.scaled(j);
+        c.x4 = S.scaled(j + 1); c.x5 = S.scaled(j + 2); c.x6 = S.scaled(j + 3);
+    }
+    c.j = j;
+    return median7(c.x0, c.x1, c.x2, c.x3, c.x4, c.x5, c.x6);
+}
+
 // ---------------------------------------------------------------------------
 // per-lane poly(A) state machine (oracle/pxo_polya.c polya_entry / call_polya /
 // try_recalibrate, recursion flattened)
@@ -292,7 +358,7 @@ struct PolyaOut {
 __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t n_full, double k,
                                double offset, float scale, float shift, int rough_begin,
                                int rough_end, int has_end0, double2* ring, int lane, Ev* ev,
-                               PolyaOut& out, pxg_polya_spike* spikes)
+                               double2* snap_ring, PolyaOut& out, pxg_polya_spike* spikes)
 {
     out.called = 0; out.n_spikes = 0; out.dwell = 0; out.begin = 0; out.end = 0;
     const int stride = P.stride;
@@ -308,6 +374,8 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
     S.raw = raw; S.sig = nullptr; S.k = k; S.offset = offset; S.scale = scale; S.shift = shift;
     S.ib = 0; S.W = 0;
     int ne = 0;
+    Stream st, snap;
+    int64_t snap_n = -1;           // window length the snapshot was taken for (-1: none)
     int64_t ib = 0, ie = 0, adapter_end = 0;
     float flo = 0.0f, fhi = 0.0f;          // float32-rounded poly(A) mean range in force
     const int cap = P.ev_cap;
@@ -329,26 +397,84 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
             adapter_end = (int64_t)rb * stride - ib;
             if (ie - ib <= 0) { state = DONE; break; }
             S.ib = ib; S.W = ie - ib;
-            ne = detect_events_stream(S, P, ring, lane, ev, cap);
+            if (snap_n > 0 && S.W > snap_n) {
+                // open-end retry: same window start, longer window -> resume the
+                // detector where the shorter window stopped being final
+                st = snap;
+                for (int q = 0; q < PA_RING; q++) ring[q * 64 + lane] = snap_ring[q * 64 + lane];
+            } else {
+                stream_init(st, S, P, ring, lane);
+            }
+            snap_n = -1;
+            ne = detect_events_stream(st, S, P, ring, lane, ev, cap, &snap, snap_ring, &snap_n);
             if (ne > cap) { state = DONE; break; }         // scratch overflow: not called
             if (has_range) { flo = (float)rlo; fhi = (float)rhi; }
             else { flo = (float)(P.mean_loc - half); fhi = (float)(P.mean_loc + half); }
             state = has_end ? CALL : RECAL;
         } else if (state == CALL) {
             // ---- find_best_polya_interval (polya.py:156-187) -----------------
+            // The reference fills an E x E table: cell (i,j) = sum of weights i..j
+            // if the spike budget is still positive at j, else 0, and takes the
+            // FIRST maximum in row-major order.  The budget only depends on the
+            // trailing run of non-poly(A) events (reset to `tolerance` by every
+            // poly(A) event, dead for the rest of the row once a run exceeds
+            // it), so for a row that starts on a poly(A) event the valid columns
+            // are the same for every row of a dead-free segment.  One backward
+            // sweep with suffix sums Q[j] = sum_{k>=j} w_k therefore finds, for
+            // each start i, max_j (Q[i] - Q[j+1]); ties prefer the smaller j, then
+            // (across starts) the smaller i -- exactly np.argmax's first maximum.
             int64_t best = 0;
             int pi = 0, pj = -1;
-            for (int i = 0; i < ne; i++) {
-                int64_t match = 0, spike = 0;
-                for (int j = i; j < ne; j++) {
-                    const Ev e = ev_at(j);
-                    const bool ip = e.mean >= flo && e.mean <= fhi;
-                    const double v = (ip ? 1.0 : -1.0) * (double)e.length;
-                    match += (int64_t)(v > 0 ? v : v * P.spike_weight);
-                    const int64_t sp = ip ? 1 : (int64_t)(-(double)e.length);
-                    spike = spike < 0 ? -1 : (sp > 0 ? (int64_t)P.spike_tolerance : spike + sp);
-                    const int64_t fin = spike > 0 ? match : 0;
-                    if (fin > best) { best = fin; pi = i; pj = j; }
+            if (ne == 1) {
+                const Ev e = ev_at(0);
+                const bool ip = e.mean >= flo && e.mean <= fhi;
+                if (ip && (int64_t)(double)e.length > 0) { best = (int64_t)(double)e.length; pi = 0; pj = 0; }
+            } else {
+                const int64_t tol = (int64_t)P.spike_tolerance;
+                int64_t Q = 0;                 // Q[j+1] while visiting j
+                int64_t minQ = 0; int minJ = -1;   // best column of the current segment
+                bool have = false;
+                int j = ne - 1;
+                while (j >= 0) {
+                    const Ev ej = ev_at(j);
+                    const bool ipj = ej.mean >= flo && ej.mean <= fhi;
+                    if (ipj) {
+                        // column j is valid (budget = tolerance > 0)
+                        if (!have || Q <= minQ) { minQ = Q; minJ = j; have = true; }
+                        const int64_t wj = (int64_t)((double)ej.length);
+                        const int64_t Qi = Q + wj;          // Q[j]
+                        const int64_t V = Qi - minQ;         // best cell of row j
+                        if (V >= best && V > 0) { best = V; pi = j; pj = minJ; }
+                        Q = Qi;
+                        j--;
+                    } else {
+                        // a run of non-poly(A) events [rs, j]: cumulative length g
+                        int rs = j;
+                        int64_t total = 0;
+                        while (rs >= 0) {
+                            const Ev er = ev_at(rs);
+                            if (er.mean >= flo && er.mean <= fhi) break;
+                            total += (int64_t)((double)er.length);
+                            rs--;
+                        }
+                        rs++;
+                        // walk the run backwards; g = cumulative length up to column c
+                        int64_t g = total;
+                        for (int c = j; c >= rs; c--) {
+                            const Ev ec = ev_at(c);
+                            const int64_t lc = (int64_t)((double)ec.length);
+                            if (g > tol) {
+                                // dead column: rows to the left cannot reach past it
+                                have = false;
+                            } else if (g < tol) {
+                                if (!have || Q <= minQ) { minQ = Q; minJ = c; have = true; }
+                            }           // g == tol: budget 0 -> cell is 0, row goes on
+                            const double v = -(double)ec.length;
+                            Q += (int64_t)(v * P.spike_weight);
+                            g -= lc;
+                        }
+                        j = rs - 1;
+                    }
                 }
             }
             const bool found = best > 0;
@@ -384,9 +510,12 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
                 if (ee > bb) {
                     const int64_t cnt = ee - bb;
                     const int mpf = P.median_pre_filter;
-                    auto fv = [&](int64_t q) -> float { return filtered_at(S, bb + q, mpf); };
+                    FiltCursor fc;
+                    fc.j = -100;
+                    auto fv = [&](int64_t q) -> float { return filtered_seq(S, mpf, bb + q, fc); };
                     const float mean = np_sum_f32(fv, cnt) / (float)cnt;
-                    auto dv = [&](int64_t q) -> float { const float x = filtered_at(S, bb + q, mpf) - mean; return x * x; };
+                    fc.j = -100;
+                    auto dv = [&](int64_t q) -> float { const float x = filtered_seq(S, mpf, bb + q, fc) - mean; return x * x; };
                     const float ss = np_sum_f32(dv, cnt);
                     const float sd = sqrtf(ss / (float)cnt);
                     qc_ok = (double)sd < P.stdv_max;
@@ -401,15 +530,9 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
                 // virtual array of the np_ poly(A) lengths: walk with a cursor
                 // (np_sum_f32 reads indices in non-decreasing blocks, but not
                 // strictly sequentially) -> resolve index -> event by scan
+                NthCursor pc = { pi - 1, -1 };
                 auto pl = [&](int64_t idx) -> float {
-                    int seen = -1;
-                    for (int q = pi; q <= pj; q++) {
-                        if (is_polya(q)) {
-                            seen++;
-                            if (seen == (int)idx) return ev_at(q).length;
-                        }
-                    }
-                    return 0.0f;
+                    return ev_at(nth_matching(is_polya, pi, pj, (int)idx, pc)).length;
                 };
                 const float dwell = np_sum_f32(pl, np_);
                 int ns = 0;
@@ -442,34 +565,26 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
             };
             for (int q = 0; q < ne; q++) m += anchor(q) ? 1 : 0;
             if (m == 0) { state = DONE; continue; }
-            auto nth_anchor = [&](int64_t idx) -> int {
-                int seen = -1;
-                for (int q = 0; q < ne; q++) {
-                    if (anchor(q)) {
-                        seen++;
-                        if (seen == (int)idx) return q;
-                    }
-                }
-                return 0;
+            NthCursor ac = { -1, -1 };
+            auto aml = [&](int64_t idx) -> float {
+                const Ev e = ev_at(nth_matching(anchor, 0, ne - 1, (int)idx, ac));
+                return e.mean * e.length;
             };
-            auto aml = [&](int64_t idx) -> float { const Ev e = ev_at(nth_anchor(idx)); return e.mean * e.length; };
-            auto aln = [&](int64_t idx) -> float { return ev_at(nth_anchor(idx)).length; };
-            const float pm = np_sum_f32(aml, m) / np_sum_f32(aln, m);
+            const float asum = np_sum_f32(aml, m);
+            ac = { -1, -1 };
+            auto aln = [&](int64_t idx) -> float {
+                return ev_at(nth_matching(anchor, 0, ne - 1, (int)idx, ac)).length;
+            };
+            const float pm = asum / np_sum_f32(aln, m);
             rlo = (double)pm - half;
             rhi = (double)pm + half;
             flo = (float)rlo;
             fhi = (float)rhi;
             int np_ = 0;
             for (int q = 0; q < ne; q++) np_ += is_polya(q) ? 1 : 0;
+            NthCursor pc = { -1, -1 };
             auto pl = [&](int64_t idx) -> float {
-                int seen = -1;
-                for (int q = 0; q < ne; q++) {
-                    if (is_polya(q)) {
-                        seen++;
-                        if (seen == (int)idx) return ev_at(q).length;
-                    }
-                }
-                return 0.0f;
+                return ev_at(nth_matching(is_polya, 0, ne - 1, (int)idx, pc)).length;
             };
             const float tot = np_sum_f32(pl, np_);
             if ((double)tot >= (double)P.recal_min_length) {
@@ -490,6 +605,7 @@ __global__ __launch_bounds__(64) void k_polya(int64_t n_reads, PolyaParams P,
                                               const float* __restrict__ ss,
                                               const int32_t* __restrict__ status,
                                               const int32_t* __restrict__ segs, Ev* __restrict__ evbuf,
+                                              double2* __restrict__ snapbuf,
                                               int32_t* __restrict__ pout /* n x 8 */,
                                               pxg_polya_spike* __restrict__ spikes)
 {
@@ -513,8 +629,9 @@ __global__ __launch_bounds__(64) void k_polya(int64_t n_reads, PolyaParams P,
     const pxg_calib c = cal[r];
     PolyaOut out;
     Ev* ev = evbuf + (size_t)blockIdx.x * P.ev_cap * 64;
+    double2* snap_ring = snapbuf + (size_t)blockIdx.x * PA_RING * 64;
     polya_one_read(P, raw + off[r], off[r + 1] - off[r], c.range / c.digitisation, c.offset,
-                   ss[2 * r], ss[2 * r + 1], rb, re, has_end, ring, lane, ev, out, sp);
+                   ss[2 * r], ss[2 * r + 1], rb, re, has_end, ring, lane, ev, snap_ring, out, sp);
     po[0] = out.called;
     po[1] = out.n_spikes;
     po[2] = out.dwell;
@@ -540,7 +657,9 @@ __global__ __launch_bounds__(64) void k_detect_events(int64_t n_windows, PolyaPa
     S.k = 0; S.offset = 0; S.scale = 1; S.shift = 0;
     if (S.W <= 0) { n_events[r] = 0; return; }
     Ev* ev = evbuf + (size_t)blockIdx.x * P.ev_cap * 64;
-    n_events[r] = detect_events_stream(S, P, ring, lane, ev, P.ev_cap);
+    Stream st;
+    stream_init(st, S, P, ring, lane);
+    n_events[r] = detect_events_stream(st, S, P, ring, lane, ev, P.ev_cap, nullptr, nullptr, nullptr);
 }
 
 static PolyaParams make_params(const pxg_config& c, int ev_cap, int mpf)
@@ -588,10 +707,13 @@ int pxg_launch_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t*
     int rc = pxg_polya_supported(ctx);
     if (rc) return rc;
     const int64_t blocks = (n + 63) / 64;
-    if ((rc = pxg_reserve(ctx, ctx->polya_ev, (size_t)blocks * PA_EV_CAP * 64 * sizeof(Ev)))) return rc;
+    const size_t ev_bytes = (size_t)blocks * PA_EV_CAP * 64 * sizeof(Ev);
+    const size_t snap_bytes = (size_t)blocks * PA_RING * 64 * sizeof(double2);
+    if ((rc = pxg_reserve(ctx, ctx->polya_ev, ev_bytes + snap_bytes))) return rc;
     const PolyaParams P = make_params(ctx->cfg, PA_EV_CAP, ctx->cfg.polya_median_pre_filter);
     hipLaunchKernelGGL(k_polya, dim3((unsigned)blocks), dim3(64), 0, ctx->stream, n, P, raw, off, cal,
-                       ss, status, segs, (Ev*)ctx->polya_ev.p, pout, spikes);
+                       ss, status, segs, (Ev*)ctx->polya_ev.p, (double2*)(ctx->polya_ev.p + ev_bytes),
+                       pout, spikes);
     return PXG_OK;
 }
 

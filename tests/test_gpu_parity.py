@@ -195,8 +195,10 @@ def test_polya_golden_bundle_vs_reference(ctx, oracle, bundle, ref_results):
     assert n >= 15
 
 
-def test_polya_synthetic_200_vs_oracle(ctx, oracle):
-    b = synth_batch(200, seed=927, samples_per_read=36000, jitter=0.3)
+@pytest.mark.parametrize('seed,noise,dwell', [(927, 1.5, 9.0), (928, 0.6, 25.0), (929, 2.5, 5.0)])
+def test_polya_synthetic_vs_oracle(ctx, oracle, seed, noise, dwell):
+    b = synth_batch(200, seed=seed, samples_per_read=36000, jitter=0.3, sample_noise=noise,
+                    mean_dwell=dwell)
     mask = N.STAGE_SEGMENT | N.STAGE_POLYA
     ctx.upload(b['arena'], b['offsets'], b['calib'], b['scale_shift'])
     ctx.run(mask)
@@ -205,7 +207,7 @@ def test_polya_synthetic_200_vs_oracle(ctx, oracle):
                                       stage_mask=mask, want_spikes=True)
     assert_records_equal(got, want, ctxmsg='polya synthetic')
     assert np.array_equal(spikes, wspk, equal_nan=True)
-    assert got['polya_called'].sum() > 100
+    assert got['polya_called'].sum() > 60
 
 
 # ---- whole path ------------------------------------------------------------------
