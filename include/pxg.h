@@ -33,6 +33,7 @@ extern "C" {
 #define PXG_MAX_CLASSES     8   /* softmax width (reference: 1 decoy + 4 barcodes) */
 #define PXG_MAX_CALIBRATION 64  /* phred calibration table rows (reference: 29)    */
 #define PXG_MAX_SPIKES      64  /* poly(A) spike records kept per read             */
+#define PXG_MAX_UNSPLIT     64  /* in-read adapter candidates kept per read        */
 
 /* ---- error codes (function return values) -------------------------------- */
 enum pxg_error {
@@ -92,6 +93,8 @@ typedef struct {
     int32_t n_states;
     int32_t adapter_state;                 /* index of 'adapter', -1 if none   */
     int32_t polya_state;                   /* index of 'polya-tail', -1 if none*/
+    int32_t leader_low_state;              /* index of 'leader-low', -1 if none */
+    int32_t leader_high_state;             /* index of 'leader-high', -1 if none*/
     int32_t reserved;
     int32_t name_rank[PXG_MAX_STATES];     /* rank of the state name in sorted
                                               order (pomegranate tie order)    */
@@ -143,6 +146,11 @@ typedef struct {
     int32_t reserved1;
     pxg_hmm segmentation_model;
     pxg_hmm unsplit_model;            /* carried for the chimera filter (a19)    */
+
+    /* unsplit_read_detection (rna-r941.cfg:17-27), seconds / fractions */
+    double unsplit_window_size, unsplit_window_step, unsplit_strict_duration;
+    double unsplit_strict_full_length, unsplit_strict_dna_length;
+    double unsplit_loosen_full_length, unsplit_loosen_dna_length;
 
     /* demultiplexing (rna-r941.cfg:29-36) */
     int32_t number_of_decoy_labels;
@@ -299,6 +307,21 @@ int pxg_barcode_window(pxg_ctx* ctx, int64_t n_reads, const float* signal_arena,
                        const int64_t* signal_offsets, float* out, int8_t* pushed);
 /* a12: demuxer.model.predict (barcoding.py:106-107); win n x T, probs n x classes */
 int pxg_demux_lstm(pxg_ctx* ctx, int64_t n_reads, const float* win, float* probs);
+/* a18: Guppy event table means (fast5_file.py:210-230: medfilt(5) of the pA
+ * samples [first, first + 15*n_events), block means) and their scaled values
+ * (signal_analyzer.py:318); events_offsets has n+1 entries into mean/scaled */
+int pxg_guppy_event_means(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
+                          const int64_t* raw_offsets, const pxg_calib* calib,
+                          const float* scale_shift, const int64_t* first_sample,
+                          const int64_t* events_offsets, int32_t block_stride,
+                          float* mean, float* scaled_mean);
+/* a19 (numeric part): the window scan of detect_unsplit_read
+ * (signal_analyzer.py:366-418) on the RESIDENT batch after a run with the
+ * segment stage: per read first_sample_template and the number of Guppy
+ * blocks; out_intervals n x PXG_MAX_UNSPLIT x 2 (leader start, adapter end + 1,
+ * raw-sample coordinates), out_count n (may exceed PXG_MAX_UNSPLIT) */
+int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample, const int64_t* n_blocks,
+                           int32_t block_stride, int64_t* out_intervals, int32_t* out_count);
 /* a15: csupport.detect_events (src/csupport.c:70-124) on a batch of windows */
 int pxg_detect_events(pxg_ctx* ctx, int64_t n_windows, const float* signal_arena,
                       const int64_t* signal_offsets, int64_t max_events_per_window,

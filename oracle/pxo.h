@@ -99,6 +99,19 @@ void pxo_polya(const pxg_config* cfg, const float* scaled_full, int64_t n_raw,
 int pxo_best_polya_interval(const pxg_config* cfg, const uint8_t* is_polya,
                             const float* length, int n_events, int* out_i, int* out_j);
 
+/* a18 fast5_file.py:210-230 (Guppy): medfilt(5) of pA[first, first+stride*n) ->
+ * block means (float32 pairwise), NaN where the read ends early; scaled =
+ * fl(fl(scale*mean)+shift) (signal_analyzer.py:318).  Returns 0, or -1 when the
+ * reference would raise 'Numbers of events and raw data strides does not match' */
+int pxo_guppy_event_means(const int16_t* raw, int64_t n_raw, const pxg_calib* cal,
+                          int64_t first_sample, int64_t n_events, int stride, float scale,
+                          float shift, float* mean, float* scaled);
+/* a19 signal_analyzer.py:366-418: window scan -> candidate [leader start,
+ * adapter end + 1] intervals; returns their number (stores at most cap) */
+int pxo_unsplit_scan(const pxg_config* cfg, const float* scaled_mean, int64_t n_events,
+                     int64_t first_sample, int stride, int64_t payload_start,
+                     double sampling_rate, int64_t* intervals, int cap);
+
 /* whole per-read path (signal_analyzer.py:82-134 phases 1-4, numeric part) */
 void pxo_process_read(const pxg_config* cfg, const int16_t* raw, int64_t n_raw,
                       const pxg_calib* cal, const float* scale_shift_or_null,

@@ -68,6 +68,8 @@ def lib():
             'pxo_medfilt': (None, [vp, i64, i32, vp]),
             'pxo_polya': (None, [cfgp, vp, i64, i32, i32, f64, vp, vp]),
             'pxo_best_polya_interval': (i32, [cfgp, vp, vp, i32, vp, vp]),
+            'pxo_guppy_event_means': (i32, [vp, i64, vp, i64, i64, i32, f32, f32, vp, vp]),
+            'pxo_unsplit_scan': (i32, [cfgp, vp, i64, i64, i32, i64, f64, vp, i32]),
             'pxo_process_read': (None, [cfgp, vp, i64, vp, vp, C.c_uint32, vp, vp]),
             'pxo_process_batch': (None, [cfgp, i64, vp, vp, vp, vp, C.c_uint32, vp, vp]),
         }
@@ -239,6 +241,26 @@ class Oracle:
                          -1 if rough_end is None else int(rough_end),
                          float(sampling_rate), _p(r), _p(sp))
         return r[0], sp
+
+    # ---- events table / pseudo-fusion ------------------------------------
+    def guppy_event_means(self, raw, calib_row, first_sample, n_events, scale, shift, stride=15):
+        raw = np.ascontiguousarray(raw, dtype=np.int16)
+        mean = np.zeros(n_events, dtype=np.float32)
+        scaled = np.zeros(n_events, dtype=np.float32)
+        rc = self.L.pxo_guppy_event_means(_p(raw), len(raw), _p(_cal(calib_row)), int(first_sample),
+                                          int(n_events), stride, np.float32(scale),
+                                          np.float32(shift), _p(mean), _p(scaled))
+        if rc != 0:
+            raise Exception('Numbers of events and raw data strides does not match.')
+        return mean, scaled
+
+    def unsplit_scan(self, scaled_mean, first_sample, payload_start, sampling_rate, stride=15):
+        sm = np.ascontiguousarray(scaled_mean, dtype=np.float32)
+        iv = np.zeros((N.PXG_MAX_UNSPLIT, 2), dtype=np.int64)
+        n = self.L.pxo_unsplit_scan(C.byref(self.cfg), _p(sm), len(sm), int(first_sample), stride,
+                                    int(payload_start), float(sampling_rate), _p(iv),
+                                    N.PXG_MAX_UNSPLIT)
+        return iv[:min(n, N.PXG_MAX_UNSPLIT)], n
 
     # ---- whole path ------------------------------------------------------
     def process_batch(self, arena, offsets, calib, scale_shift=None,

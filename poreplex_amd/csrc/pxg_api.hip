@@ -706,3 +706,74 @@ extern "C" int pxg_detect_events(pxg_ctx* ctx, int64_t n, const float* signal_ar
     }
     HOOK_END
 }
+
+extern "C" int pxg_guppy_event_means(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
+                                     const pxg_calib* calib, const float* scale_shift,
+                                     const int64_t* first_sample, const int64_t* events_offsets,
+                                     int32_t block_stride, float* mean, float* scaled_mean)
+{
+    HOOK_BEGIN
+    if (n <= 0) return PXG_OK;
+    for (int64_t i = 0; i < n; i++)
+        if (first_sample[i] < 0 || events_offsets[i + 1] < events_offsets[i])
+            return fail(ctx, PXG_E_INVALID, "pxg_guppy_event_means: bad first_sample / offsets");
+    const size_t ne = (size_t)events_offsets[n];
+    int16_t* d_raw = S.put(raw, (size_t)off[n], ctx->stream);
+    int64_t* d_off = S.put(off, (size_t)n + 1, ctx->stream);
+    pxg_calib* d_cal = S.put(calib, (size_t)n, ctx->stream);
+    float* d_ss = S.put(scale_shift, (size_t)n * 2, ctx->stream);
+    int64_t* d_first = S.put(first_sample, (size_t)n, ctx->stream);
+    int64_t* d_eoff = S.put(events_offsets, (size_t)n + 1, ctx->stream);
+    float* d_mean = S.alloc<float>(ne);
+    float* d_scaled = S.alloc<float>(ne);
+    HOOK_CHECK(d_raw && d_off && d_cal && d_ss && d_first && d_eoff && d_mean && d_scaled);
+    int rc = pxg_launch_guppy_event_means(ctx, n, d_raw, d_off, d_cal, d_ss, d_first, d_eoff,
+                                          block_stride, d_mean, d_scaled);
+    if (rc) return rc;
+    if (ne) {
+        HOOK_GET(mean, d_mean, ne);
+        HOOK_GET(scaled_mean, d_scaled, ne);
+    }
+    HOOK_END
+}
+
+extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
+                                      const int64_t* n_blocks, int32_t block_stride,
+                                      int64_t* out_intervals, int32_t* out_count)
+{
+    HOOK_BEGIN
+    const int64_t n = ctx->n_reads;
+    if (n <= 0) return PXG_OK;
+    const pxg_hmm& U = ctx->cfg.unsplit_model;
+    if (U.n_states < 1 || U.adapter_state < 0 || U.leader_low_state < 0 || U.leader_high_state < 0)
+        return fail(ctx, PXG_E_INVALID, "unsplit model lacks adapter / leader states");
+    std::vector<int64_t> eoff((size_t)n + 1, 0);
+    for (int64_t i = 0; i < n; i++) {
+        if (first_sample[i] < 0 || n_blocks[i] < 0)
+            return fail(ctx, PXG_E_INVALID, "pxg_batch_unsplit_scan: negative first_sample / n_blocks");
+        eoff[i + 1] = eoff[i] + n_blocks[i];
+    }
+    const size_t ne = (size_t)eoff[n];
+    int64_t* d_first = S.put(first_sample, (size_t)n, ctx->stream);
+    int64_t* d_eoff = S.put(eoff.data(), (size_t)n + 1, ctx->stream);
+    float* d_mean = S.alloc<float>(ne);
+    float* d_scaled = S.alloc<float>(ne);
+    char* d_scr = S.alloc<char>(pxg_unsplit_scratch_bytes(n));
+    int64_t* d_iv = S.alloc<int64_t>((size_t)n * PXG_MAX_UNSPLIT * 2);
+    int32_t* d_cnt = S.alloc<int32_t>((size_t)n);
+    HOOK_CHECK(d_first && d_eoff && d_mean && d_scaled && d_scr && d_iv && d_cnt);
+    PXG_HIP(ctx, hipMemsetAsync(d_iv, 0, (size_t)n * PXG_MAX_UNSPLIT * 2 * sizeof(int64_t), ctx->stream));
+    int rc = pxg_launch_guppy_event_means(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p,
+                                          d_first, d_eoff, block_stride, d_mean, d_scaled);
+    if (rc) return rc;
+    rc = pxg_launch_unsplit_scan(ctx, n, ctx->calib.p, ctx->status.p, ctx->segs.p, d_first, d_eoff,
+                                 d_scaled, block_stride, d_scr, d_iv, d_cnt);
+    if (rc) return rc;
+    HOOK_GET(out_intervals, d_iv, (size_t)n * PXG_MAX_UNSPLIT * 2);
+    HOOK_GET(out_count, d_cnt, n);
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < n; i++)
+        if (out_count[i] < 0)
+            return fail(ctx, PXG_E_UNSUPPORTED, "pxg_batch_unsplit_scan: a window exceeds 4096 event blocks");
+    HOOK_END
+}

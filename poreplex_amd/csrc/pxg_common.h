@@ -273,5 +273,15 @@ int pxg_launch_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t*
 int pxg_launch_detect_events(pxg_ctx* ctx, int64_t n, const float* sig, const int64_t* off,
                              int64_t cap, void* evbuf, int64_t* n_events);
 
+// K7: Guppy event means + pseudo-fusion window scan (k_unsplit.hip)
+int pxg_launch_guppy_event_means(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
+                                 const pxg_calib* cal, const float* ss, const int64_t* first,
+                                 const int64_t* ev_off, int stride, float* mean, float* scaled);
+size_t pxg_unsplit_scratch_bytes(int64_t n);
+int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, const pxg_calib* cal, const int32_t* status,
+                            const int32_t* segs, const int64_t* first_sample, const int64_t* ev_off,
+                            const float* scaled, int stride, void* scratch, int64_t* out_iv,
+                            int32_t* out_cnt);
+
 void pxg_timer_begin(pxg_ctx* ctx, int t);
 void pxg_timer_end(pxg_ctx* ctx, int t);

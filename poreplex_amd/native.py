@@ -22,6 +22,7 @@ PXG_N_SEGMENTS = 8
 PXG_MAX_CLASSES = 8
 PXG_MAX_CALIBRATION = 64
 PXG_MAX_SPIKES = 64
+PXG_MAX_UNSPLIT = 64
 
 STATUS_NAMES = (
     'okay', 'disappeared', 'irregular_fast5', 'scaler_signal_too_short',
@@ -52,7 +53,8 @@ class PxgCalib(C.Structure):
 class PxgHmm(C.Structure):
     _fields_ = [
         ('n_states', C.c_int32), ('adapter_state', C.c_int32),
-        ('polya_state', C.c_int32), ('reserved', C.c_int32),
+        ('polya_state', C.c_int32), ('leader_low_state', C.c_int32),
+        ('leader_high_state', C.c_int32), ('reserved', C.c_int32),
         ('name_rank', C.c_int32 * PXG_MAX_STATES),
         ('n_mix', C.c_int32 * PXG_MAX_STATES),
         ('start_prob', C.c_double * PXG_MAX_STATES),
@@ -85,6 +87,10 @@ class PxgConfig(C.Structure):
         ('scaler_dense', PxgDenseLayer),
         ('segmentation_scan_limit', C.c_int32), ('reserved1', C.c_int32),
         ('segmentation_model', PxgHmm), ('unsplit_model', PxgHmm),
+        ('unsplit_window_size', C.c_double), ('unsplit_window_step', C.c_double),
+        ('unsplit_strict_duration', C.c_double), ('unsplit_strict_full_length', C.c_double),
+        ('unsplit_strict_dna_length', C.c_double), ('unsplit_loosen_full_length', C.c_double),
+        ('unsplit_loosen_dna_length', C.c_double),
         ('number_of_decoy_labels', C.c_int32), ('number_of_barcodes', C.c_int32),
         ('minimum_dna_length', C.c_int32), ('maximum_dna_length', C.c_int32),
         ('signal_trim_length', C.c_int32), ('n_calibration', C.c_int32),
@@ -179,6 +185,8 @@ def _fill_hmm(hmm, modeldata):
     hmm.n_states = len(names)
     hmm.adapter_state = index.get('adapter', -1)
     hmm.polya_state = index.get('polya-tail', -1)
+    hmm.leader_low_state = index.get('leader-low', -1)
+    hmm.leader_high_state = index.get('leader-high', -1)
     for rank, name in enumerate(sorted(names)):
         hmm.name_rank[index[name]] = rank
     for i, s in enumerate(modeldata):
@@ -245,6 +253,11 @@ class NativeConfig:
         self.state_names = _fill_hmm(cfg.segmentation_model, config['segmentation_model'])
         self.unsplit_state_names = _fill_hmm(cfg.unsplit_model,
                                              config['unsplit_read_detection_model'])
+
+        ur = config['unsplit_read_detection']        # signal_analyzer.py:374-383
+        for key in ('window_size', 'window_step', 'strict_duration', 'strict_full_length',
+                    'strict_dna_length', 'loosen_full_length', 'loosen_dna_length'):
+            setattr(cfg, 'unsplit_' + key, float(ur[key]))
 
         dm = config['demultiplexing']
         demux = _config.load_model_arrays(dm['demux_model'])
@@ -333,6 +346,11 @@ _SIGNATURES = {
     'pxg_barcode_window': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
     'pxg_demux_lstm': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'pxg_guppy_event_means': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                                        C.c_void_p]),
+    'pxg_batch_unsplit_scan': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                         C.c_void_p, C.c_void_p]),
     'pxg_detect_events': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_int64, C.c_void_p, C.c_void_p]),
 }
@@ -557,6 +575,34 @@ class NativeContext:
         self._check(self.lib.pxg_demux_lstm(self.handle, n, _ptr(win), _ptr(probs)),
                     'pxg_demux_lstm')
         return probs
+
+    def guppy_event_means(self, arena, offsets, calib, scale_shift, first_sample, n_blocks,
+                          block_stride=15):
+        arena, offsets, calib, scale_shift, n = self._prep(arena, offsets, calib, scale_shift)
+        first = np.ascontiguousarray(first_sample, dtype=np.int64)
+        eoff = np.zeros(n + 1, dtype=np.int64)
+        eoff[1:] = np.cumsum(n_blocks)
+        mean = np.zeros(int(eoff[-1]), dtype=np.float32)
+        scaled = np.zeros(int(eoff[-1]), dtype=np.float32)
+        self._check(self.lib.pxg_guppy_event_means(
+            self.handle, n, _ptr(arena), _ptr(offsets), _ptr(calib), _ptr(scale_shift),
+            _ptr(first), _ptr(eoff), block_stride, _ptr(mean), _ptr(scaled)),
+            'pxg_guppy_event_means')
+        return mean, scaled, eoff
+
+    def unsplit_scan(self, first_sample, n_blocks, block_stride=15):
+        """Window scan of detect_unsplit_read on the resident batch."""
+        n = self.n_resident
+        first = np.ascontiguousarray(first_sample, dtype=np.int64)
+        nb = np.ascontiguousarray(n_blocks, dtype=np.int64)
+        if len(first) != n or len(nb) != n:
+            raise ValueError('one first_sample / n_blocks entry per resident read')
+        iv = np.zeros((n, PXG_MAX_UNSPLIT, 2), dtype=np.int64)
+        cnt = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.pxg_batch_unsplit_scan(self.handle, _ptr(first), _ptr(nb),
+                                                    block_stride, _ptr(iv), _ptr(cnt)),
+                    'pxg_batch_unsplit_scan')
+        return iv, cnt
 
     def detect_events(self, signals, max_events=None):
         sigs = [np.ascontiguousarray(s, dtype=np.float32) for s in signals]

@@ -15,6 +15,8 @@ import traceback
 from io import StringIO
 from weakref import proxy
 
+import numpy as np
+
 from . import native
 from .signal_loader import SignalAnalysisError
 from .utils import union_intervals  # noqa: F401  (re-exported like the reference)
@@ -49,14 +51,13 @@ class SignalAnalyzer:
         self.formatted_batchid = format(batchid, '08d')
         if config.get('dump_adapter_signals') or config.get('dump_basecalls'):
             raise NotImplementedError('HDF5 dump outputs are outside the hot path')
-        if config.get('filter_unsplit_reads'):
-            raise NotImplementedError('the pseudo-fusion filter (a19) is not built yet')
         mask = native.STAGE_SCALER | native.STAGE_SEGMENT
         if config['barcoding']:
             mask |= native.STAGE_BARCODE
         if config['measure_polya']:
             mask |= native.STAGE_POLYA
         self.loader.stage_mask = mask
+        self.loader.scan_unsplit = bool(config.get('filter_unsplit_reads'))
 
     def process(self, reads):
         results, loaded = [], []
@@ -154,9 +155,12 @@ class SignalAnalysis:
                 self.push_barcode_signal(None, segments)
             if self.config['measure_polya']:
                 self.analyzer.polyaanalyzer(self.npread)
-            self.load_events()
+            events = self.load_events()
             if self.config['trim_adapter']:
-                self.trim_adapter(None, segments, stride)
+                self.trim_adapter(events, segments, stride)
+            if self.config['filter_unsplit_reads']:
+                if self.detect_unsplit_read(events, segments, stride):
+                    raise SignalAnalysisError('unsplit_read')
             if self.npread.sequence is not None:
                 readlength = len(self.npread.sequence[0]) - self.npread.sequence[2]
                 if readlength < self.config['minimum_sequence_length']:
@@ -174,7 +178,28 @@ class SignalAnalysis:
         bcall = self.npread.load_fast5_events()
         if self.npread.scaling_params is None:
             raise Exception('Signal scaling is not available yet.')
-        return bcall
+        if not self.config['filter_unsplit_reads']:
+            return bcall            # nothing downstream reads the table itself
+        return self.event_frame(bcall)
+
+    def event_frame(self, bcall):
+        """Base-space columns of the Guppy event table (fast5_file.py:183-208,
+        signal_analyzer.py:319-324).  The signal-space columns (mean,
+        scaled_mean) live on the GPU: SignalLoader.scan_unsplit_candidates."""
+        first, n_blocks, stride = self.npread.guppy_event_geometry()
+        moves = np.asarray(bcall['move'], dtype=np.uint8)
+        pos = moves.cumsum() - 1
+        kmer_size = len(bcall['sequence']) - int(moves.sum()) + 1
+        qual = 1 - 10 ** -((np.frombuffer(bcall['qstring'].encode(), 'B') - 33) / 10)
+        if kmer_size == 5:          # Guppy old models
+            posshift = 2
+        elif kmer_size == 1:        # Guppy flip-flop models
+            posshift = 0
+        else:
+            raise Exception('Move table is encoded with an unknown kmer-size.')
+        start = np.arange(first, first + stride * n_blocks, stride)
+        return {'start': start, 'end': start + np.hstack((np.diff(start), [1])).astype(np.int64),
+                'move': moves, 'pos': np.cumsum(moves), 'p_model_state': qual[pos + posshift]}
 
     def trim_adapter(self, events, segments, elspan):
         # signal_analyzer.py:328-331: returns as soon as a sequence is present,
@@ -182,6 +207,42 @@ class SignalAnalysis:
         # this revision of the reference.
         if self.npread.sequence is not None:
             return
+
+    def detect_unsplit_read(self, events, segments, elspan):
+        """Decision rule of signal_analyzer.py:366-443 over the candidate
+        in-read adapters the GPU window scan found for this read."""
+        try:
+            payload_start = (segments['adapter'][1] + 1) * elspan
+        except (KeyError, IndexError):
+            return False            # must be an adapter-only read
+        if self.npread.native_unsplit_count > native.PXG_MAX_UNSPLIT:
+            raise Exception('more than {} in-read adapter candidates'.format(native.PXG_MAX_UNSPLIT))
+        excessive_adapters = self.npread.native_unsplit
+        if not excessive_adapters:
+            return False
+
+        config = self.config['unsplit_read_detection']
+        adapter_intervals = ([[0, payload_start]] + union_intervals(excessive_adapters)
+                             + [[np.inf, np.inf]])
+        basequality_cutoff = config['basecount_quality_limit']
+        start, pos, pms = events['start'], events['pos'], events['p_model_state']
+
+        def count_high_quality_reads(left, right):
+            # events[start.between(left, right)].groupby('pos')['p_model_state'].max() > cutoff
+            sel = (start >= left) & (start <= right)
+            if not sel.any():
+                return 0
+            p, q = pos[sel], pms[sel]
+            heads = np.nonzero(np.r_[True, p[1:] != p[:-1]])[0]
+            return int((np.maximum.reduceat(q, heads) > basequality_cutoff).sum())
+
+        subread_lengths = [count_high_quality_reads(left, right)
+                           for (_, left), (right, _) in zip(adapter_intervals[0:],
+                                                            adapter_intervals[1:])]
+        subread_hq_length_total = sum(subread_lengths[1:])
+        return bool(subread_hq_length_total > config['subread_basecount_limit'] or
+                    (subread_hq_length_total + 1) / (subread_lengths[0] + 1)
+                    > config['subread_baseratio_limit'])
 
     def detect_segments(self, signal, elspan):
         """Single-read debug path (signal_analyzer.py:346-364) through the GPU hook."""

@@ -35,6 +35,7 @@ class SignalLoader:
         }
         self.batch_reads = []
         self.stage_mask = native.STAGE_ALL_DEMUX
+        self.scan_unsplit = False      # --filter-chimera: also run the a19 window scan
 
     def clear(self):
         del self.batch_reads[:]
@@ -76,7 +77,33 @@ class SignalLoader:
             else:
                 r.set_scaling_params(np.array([records[i]['scale'], records[i]['shift']],
                                               dtype=np.float32))
+        if self.scan_unsplit:
+            self.scan_unsplit_candidates(offsets)
+        for r in self.batch_reads:
             r.raw = None
+
+    def scan_unsplit_candidates(self, offsets):
+        """a18+a19 numeric part for the resident batch: Guppy block means of
+        every basecalled read and the windowed Viterbi scan, on the GPU
+        (signal_analyzer.py:366-418).  Reads whose event table cannot be built
+        are skipped here; SignalAnalysis.load_events raises for them."""
+        n = len(self.batch_reads)
+        first = np.zeros(n, dtype=np.int64)
+        blocks = np.zeros(n, dtype=np.int64)
+        strides = np.zeros(n, dtype=np.int64)
+        for i, r in enumerate(self.batch_reads):
+            try:
+                table = r.guppy_event_geometry(int(offsets[i + 1] - offsets[i]))
+            except Exception:
+                continue
+            first[i], blocks[i], strides[i] = table
+        for stride in sorted(set(strides[blocks > 0].tolist())):
+            sel = (strides == stride) & (blocks > 0)
+            iv, cnt = self.ctx.unsplit_scan(first, np.where(sel, blocks, 0), int(stride))
+            for i in np.nonzero(sel)[0]:
+                r = self.batch_reads[i]
+                r.native_unsplit_count = int(cnt[i])
+                r.native_unsplit = iv[i, :min(int(cnt[i]), iv.shape[1])].tolist()
 
 
 class NanoporeRead:
@@ -86,6 +113,8 @@ class NanoporeRead:
     sequence = scaling_params = label = barcode = polya = None
     barcode_bestguess = barcode_quality = None
     native = native_spikes = raw = None
+    native_unsplit = None
+    native_unsplit_count = 0
 
     def __init__(self, filename, srcdir, read_id, bundle=None):
         self.fullpath = os.path.join(srcdir, filename)
@@ -188,3 +217,23 @@ class NanoporeRead:
         self.num_events = bcall['num_events']
         self.sequence = bcall['sequence'], bcall['qstring'], 0
         return bcall
+
+    def guppy_event_geometry(self, n_raw=None):
+        """(first_sample, n_blocks, block_stride) of the Move-table event
+        frame, with the size rule of convert_events_guppy (fast5_file.py:
+        210-223): the raw slice, NaN-padded to whole blocks, must hold exactly
+        one block per move."""
+        bcall = self.fast5.get_basecall()
+        if bcall is None:
+            raise SignalAnalysisError('not_basecalled')
+        if bcall.get('move') is None:
+            raise Exception("Neither `Events' or `Move' table found in the basecall.")
+        if n_raw is None:
+            n_raw = len(self.fast5.get_raw_int16())
+        first, stride = int(bcall['first_sample_template']), int(bcall['block_stride'])
+        n_blocks = len(bcall['move'])
+        length = max(min(first + stride * n_blocks, n_raw) - first, 0)
+        padded = length + (stride - length % stride if length % stride else 0)
+        if padded // stride != n_blocks:
+            raise Exception('Numbers of events and raw data strides does not match.')
+        return first, n_blocks, stride

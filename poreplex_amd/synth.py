@@ -62,7 +62,8 @@ def _draw_levels(rng, state_idx):
 
 def synth_batch(n_reads, seed=922, samples_per_read=60000, jitter=0.1, barcodes=None,
                 prototypes='auto', mean_dwell=9.0, sample_noise=1.5, with_polya=True,
-                short_fraction=0.0, scale_sigma=0.05, shift_mu=-5.0, shift_sigma=3.0):
+                short_fraction=0.0, scale_sigma=0.05, shift_mu=-5.0, shift_sigma=3.0,
+                fixed_calib=False):
     """Generate a ragged batch.
 
     Returns dict(arena int16, offsets int64[n+1], calib CALIB_DTYPE[n],
@@ -110,6 +111,8 @@ def synth_batch(n_reads, seed=922, samples_per_read=60000, jitter=0.1, barcodes=
     calib['digitisation'] = 8192.0
     calib['offset'] = np.floor(rng.uniform(-5, 25, n_reads))
     calib['sampling_rate'] = 3012.0
+    if fixed_calib:      # same DAQ settings for every read (reads can be concatenated)
+        calib['range'], calib['offset'] = 1200.0, 10.0
 
     chunk = 512
     for c0 in range(0, n_reads, chunk):

@@ -82,6 +82,26 @@ class OracleBackedContext:
     def download_spikes(self):
         return self.spk
 
+    def unsplit_scan(self, first_sample, n_blocks, block_stride=15):
+        arena, offsets, calib, _ = self.batch
+        n = len(offsets) - 1
+        iv = np.zeros((n, N.PXG_MAX_UNSPLIT, 2), dtype=np.int64)
+        cnt = np.zeros(n, dtype=np.int32)
+        a = int(self.cfg.segmentation_model.adapter_state)
+        for i in range(n):
+            r = self.res[i]
+            if n_blocks[i] <= 0 or r['status'] != 0 or r['seg_first'][a] < 0:
+                continue
+            _, scaled = self.oracle.guppy_event_means(
+                arena[offsets[i]:offsets[i + 1]], calib[i], first_sample[i], n_blocks[i],
+                r['scale'], r['shift'], block_stride)
+            got, c = self.oracle.unsplit_scan(scaled, first_sample[i],
+                                              (int(r['seg_last'][a]) + 1) * int(self.cfg.stride),
+                                              float(calib[i]['sampling_rate']), block_stride)
+            iv[i, :len(got)] = got
+            cnt[i] = c
+        return iv, cnt
+
     def close(self):
         pass
 
@@ -151,4 +171,63 @@ def test_process_batch_gpu_vs_reference(ref_results):
     got = process_batch(ref_results['batchid'], reads, cfg)
     assert not (isinstance(got, tuple) and got[0] == -1), got
     compare_results(got, ref_results['results'], check_polya=True)
+    WorkerPersistenceStorage.reset()
+
+
+# ---- a18/a19: --filter-chimera against the real reference's process_batch ------
+CHIMERA_BUNDLE = os.path.join(GOLDEN, 'chimera.pxr.npz')
+
+
+def chimera_case():
+    import json
+    with open(os.path.join(GOLDEN, 'chimera.results.json')) as fh:
+        ref = json.load(fh)
+    cfg = default_config(inputdir='/nonexistent-inputdir', outputdir='/tmp',
+                         read_bundle=CHIMERA_BUNDLE, **ref['config_flags'])
+    return ref, cfg
+
+
+def check_chimera(got, ref):
+    assert not (isinstance(got, tuple) and got[0] == -1), got
+    compare_results(got, ref['results'], check_polya=True)
+    by_status = {}
+    for r in got:
+        by_status.setdefault(r['status'], []).append(r['label'])
+    assert set(by_status) == {'okay', 'unsplit_read'}
+    assert set(by_status['unsplit_read']) == {'artifact'} and len(by_status['unsplit_read']) == 6
+
+
+def test_filter_unsplit_reads_host_logic_vs_reference(oracle_backed):
+    from poreplex_amd.signal_analyzer import process_batch
+    ref, cfg = chimera_case()
+    assert cfg['filter_unsplit_reads']
+    check_chimera(process_batch(ref['batchid'], [tuple(r) for r in ref['reads']], cfg), ref)
+
+
+def test_event_frame_base_space_columns_vs_reference(oracle_backed):
+    """pos / p_model_state of the Move-table frame equal the reference's load_events."""
+    from poreplex_amd import signal_analyzer as SA
+    ref, cfg = chimera_case()
+    st = np.load(os.path.join(GOLDEN, 'chimera.stages.npz'))
+    eo = st['ev_offsets']
+    with SA.SignalAnalyzer(cfg, 8) as an:
+        for i, (fn, rid) in enumerate(ref['reads'][:4]):
+            npread = an.loader.prepare_loading(fn, rid)
+            npread.set_scaling_params(np.float32([1, 0]))
+            ev = SA.SignalAnalysis(npread, an).load_events()
+            assert np.array_equal(ev['pos'], st['ev_pos'][eo[i]:eo[i + 1]])
+            # 10 ** x differs by <= 1 ulp between NumPy builds (py3.9 reference vs here);
+            # the only consumer compares it with basecount_quality_limit = 0.4
+            want = st['ev_pms'][eo[i]:eo[i + 1]]
+            assert np.abs(ev['p_model_state'] - want).max() <= 2.3e-16
+            assert np.array_equal(ev['p_model_state'] > 0.4, want > 0.4)
+        an.loader.clear()
+
+
+@pytest.mark.gpu
+def test_filter_unsplit_reads_gpu_vs_reference():
+    from poreplex_amd.signal_analyzer import process_batch
+    WorkerPersistenceStorage.reset()
+    ref, cfg = chimera_case()
+    check_chimera(process_batch(ref['batchid'], [tuple(r) for r in ref['reads']], cfg), ref)
     WorkerPersistenceStorage.reset()

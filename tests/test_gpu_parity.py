@@ -270,3 +270,99 @@ def test_full_size_determinism_and_order_invariance(ctx):
     assert (r1['seg_last'][ok] < r1['n_pooled'][ok, None]).all()
     p = r1['probs'][r1['bc_pushed'] == 1, :5]
     assert np.abs(p.sum(1) - 1).max() < 1e-5
+
+
+# ---- a18 / a19 ---------------------------------------------------------------
+def _chimera():
+    import json
+    b = dict(np.load(os.path.join(GOLDEN, 'chimera.pxr.npz')))
+    st = dict(np.load(os.path.join(GOLDEN, 'chimera.stages.npz')))
+    with open(os.path.join(GOLDEN, 'chimera.results.json')) as fh:
+        res = json.load(fh)
+    bc = [json.loads(str(x)) for x in b['basecall']]
+    return b, st, res, bc
+
+
+def test_guppy_event_means_vs_reference_golden(ctx):
+    """a18: block means of the medfilt(5) pA signal and their scaled values,
+    bit-exact against the REAL reference's event table."""
+    b, st, res, bc = _chimera()
+    ctx.upload(b['arena'], b['offsets'], b['calib'])
+    ctx.run(N.STAGE_SCALER | N.STAGE_SEGMENT)
+    recs = ctx.download()
+    ss = np.stack([recs['scale'], recs['shift']], axis=1).astype(np.float32)
+    first = [c['first_sample_template'] for c in bc]
+    nb = [len(c['move']) for c in bc]
+    mean, scaled, eo = ctx.guppy_event_means(b['arena'], b['offsets'], b['calib'], ss, first, nb)
+    assert np.array_equal(eo, st['ev_offsets'])
+    assert np.array_equal(mean, st['ev_mean'], equal_nan=True)
+    assert np.array_equal(scaled, st['ev_scaled'], equal_nan=True)
+
+
+def test_guppy_event_means_ragged_tail_vs_oracle(ctx, oracle):
+    """Reads that end inside the last block (NaN-padded mean), first_sample 0 and
+    a block count of 0."""
+    b, st, res, bc = _chimera()
+    raw = b['arena'][b['offsets'][0]:b['offsets'][1]]
+    cases = [(raw[:3007], 10, 200), (raw[:3000], 0, 200), (raw[:45], 0, 3), (raw[:100], 7, 0),
+             (raw[:64], 3, 5)]
+    arena, off = N.pack_reads([c[0] for c in cases])
+    calib = np.array([tuple(b['calib'][0])] * len(cases), dtype=N.CALIB_DTYPE)
+    ss = np.float32([[0.97, -3.5]] * len(cases))
+    mean, scaled, eo = ctx.guppy_event_means(arena, off, calib, ss, [c[1] for c in cases],
+                                             [c[2] for c in cases])
+    for i, (r, f, n) in enumerate(cases):
+        wm, wsc = oracle.guppy_event_means(r, calib[i], f, n, ss[i, 0], ss[i, 1])
+        assert np.array_equal(mean[eo[i]:eo[i + 1]], wm, equal_nan=True), i
+        assert np.array_equal(scaled[eo[i]:eo[i + 1]], wsc, equal_nan=True), i
+    assert np.isnan(mean[eo[0]:eo[1]][-1])
+
+
+def test_unsplit_scan_vs_reference_candidates(ctx):
+    """a19: the candidate in-read adapters of every window equal the list the REAL
+    reference handed to union_intervals."""
+    b, st, res, bc = _chimera()
+    ctx.upload(b['arena'], b['offsets'], b['calib'])
+    ctx.run(N.STAGE_SCALER | N.STAGE_SEGMENT)
+    iv, cnt = ctx.unsplit_scan([c['first_sample_template'] for c in bc],
+                               [len(c['move']) for c in bc])
+    for i, want in enumerate(res['candidates']):
+        assert cnt[i] == len(want), (i, str(b['tag'][i]))
+        assert iv[i, :cnt[i]].tolist() == want, (i, str(b['tag'][i]))
+    assert (cnt > 0).sum() >= 6
+
+
+def test_unsplit_scan_synthetic_vs_oracle(ctx, oracle, config):
+    """Random chimeras / plain reads of very different lengths in one wave: ragged
+    window counts, reads without events, reads without an adapter."""
+    from poreplex_amd.synth import synth_batch
+    sb = synth_batch(40, seed=4141, samples_per_read=22000, jitter=0.5, fixed_calib=True,
+                     scale_sigma=0.0, shift_sigma=0.0, short_fraction=0.1)
+    parts = [sb['arena'][sb['offsets'][i]:sb['offsets'][i + 1]] for i in range(40)]
+    reads = [np.concatenate([parts[i], parts[i + 1]]) for i in range(0, 16, 2)]
+    reads += [np.concatenate([parts[16], parts[17], parts[18]])] + parts[19:40]
+    rng = np.random.default_rng(5)
+    first = rng.integers(0, 60, len(reads))
+    nb = np.array([(len(r) - f) // 15 for r, f in zip(reads, first)])
+    nb[3] = 0                                   # not basecalled
+    nb[5] = max(nb[5] - 700, 1)                 # table ends long before the read does
+    arena, off = N.pack_reads(reads)
+    calib = np.array([tuple(sb['calib'][0])] * len(reads), dtype=N.CALIB_DTYPE)
+    ctx.upload(arena, off, calib)
+    ctx.run(N.STAGE_SCALER | N.STAGE_SEGMENT)
+    recs = ctx.download()
+    iv, cnt = ctx.unsplit_scan(first, nb)
+    a = 3
+    n_cand = 0
+    for i, r in enumerate(reads):
+        if nb[i] <= 0 or recs[i]['status'] != 0 or recs[i]['seg_first'][a] < 0:
+            assert cnt[i] == 0
+            continue
+        _, scaled = oracle.guppy_event_means(r, calib[i], first[i], nb[i], recs[i]['scale'],
+                                             recs[i]['shift'])
+        want, c = oracle.unsplit_scan(scaled, first[i], (int(recs[i]['seg_last'][a]) + 1) * 15,
+                                      3012.0)
+        assert cnt[i] == c, i
+        assert iv[i, :min(c, N.PXG_MAX_UNSPLIT)].tolist() == want.tolist(), i
+        n_cand += c
+    assert n_cand >= 8

@@ -621,6 +621,105 @@ def main():
     with open(os.path.join(OUT, 'unit.json'), 'w') as fh:
         json.dump(jsonable(ui), fh)
 
+    # ---- a18/a19: Guppy event table + pseudo-fusion filter -----------------
+    # chimeric reads = two synthetic reads back to back with one DAQ setting
+    # and one scaling; real process_batch with --filter-chimera
+    cb = synth_batch(16, seed=9330, samples_per_read=26000, jitter=0.2, fixed_calib=True,
+                     scale_sigma=0.0, shift_sigma=0.0)
+    parts = [cb['arena'][cb['offsets'][i]:cb['offsets'][i + 1]] for i in range(16)]
+    chim = []
+    for k in range(6):                      # 6 chimeras (A|B), 4 plain reads
+        chim.append(('chimera%d' % k, np.concatenate([parts[2 * k], parts[2 * k + 1]])))
+    for k in range(12, 16):
+        chim.append(('plain%d' % k, parts[k]))
+    # a chimera whose second part is cut right after its adapter (few bases follow)
+    cut = int(cb['truth'][1, 3, 1]) + 300
+    chim.append(('chimera_short_tail', np.concatenate([parts[0], parts[1][:cut]])))
+    cinput = os.path.join(TMP, 'in2')
+    os.makedirs(cinput)
+    citems = []
+    for i, (tag, raw) in enumerate(chim):
+        rid = '%08x-0000-4000-8000-%012x' % (0x9330 + i, i)
+        fn = 'c%03d.fast5' % i
+        meta = {'read_number': 500 + i, 'start_time': int(rng.integers(10**5, 10**8)),
+                'channel_number': int(rng.integers(1, 513)), 'run_id': 'run' + 'cd' * 19,
+                'sample_id': 'synthetic'}
+        bc = make_basecall(rng, len(raw), int(rng.integers(0, 40)))
+        write_fast5(os.path.join(cinput, fn), rid, raw, cb['calib'][0], meta, bc)
+        citems.append({'tag': tag, 'raw': raw, 'filename': fn, 'read_id': rid, 'meta': meta,
+                       'basecall': bc})
+    ccfg = dict(refcfg)
+    ccfg.update({'inputdir': cinput, 'measure_polya': False, 'filter_unsplit_reads': True,
+                 'trim_adapter': False})
+    ccap = {'events': {}, 'cands': {}, 'unsplit': {}}
+    orig_load = SA.SignalAnalysis.load_events
+    orig_det = SA.SignalAnalysis.detect_unsplit_read
+    orig_union = SA.union_intervals
+    current = {}
+
+    def cload(self):
+        ev = orig_load(self)
+        ccap['events'][self.npread.read_id] = (np.array(ev['mean'], np.float32),
+                                                np.array(ev['scaled_mean'], np.float32),
+                                                np.array(ev['start'], np.int64),
+                                                np.array(ev['pos'], np.int64),
+                                                np.array(ev['p_model_state'], np.float64))
+        return ev
+
+    def cdet(self, events, segments, elspan):
+        current['rid'] = self.npread.read_id
+        ccap['cands'][current['rid']] = []
+        out = orig_det(self, events, segments, elspan)
+        ccap['unsplit'][current['rid']] = bool(out)
+        return out
+
+    def cunion(iset):
+        ccap['cands'][current['rid']] = [list(map(int, x)) for x in iset]
+        return orig_union(iset)
+
+    SA.SignalAnalysis.load_events = cload
+    SA.SignalAnalysis.detect_unsplit_read = cdet
+    SA.union_intervals = cunion
+    WPS = sys.modules.pop('__poreplex_persistence', None)     # new inputdir -> new loader
+    cres = SA.process_batch(8, [(it['filename'], it['read_id']) for it in citems], ccfg)
+    assert not (isinstance(cres, tuple) and cres[0] == -1), cres
+    SA.SignalAnalysis.load_events = orig_load
+    SA.SignalAnalysis.detect_unsplit_read = orig_det
+    SA.union_intervals = orig_union
+    print('chimera batch:', [(it['tag'], r['status'], r.get('label')) for it, r in zip(citems, cres)])
+    carena, coff = N.pack_reads([it['raw'] for it in citems])
+    nc = len(citems)
+    np.savez_compressed(
+        os.path.join(OUT, 'chimera.pxr.npz'),
+        arena=carena, offsets=coff, calib=np.array([tuple(cb['calib'][0])] * nc, dtype=N.CALIB_DTYPE),
+        filename=np.array([it['filename'] for it in citems]),
+        read_id=np.array([it['read_id'] for it in citems]),
+        duration=np.array([len(it['raw']) for it in citems], dtype=np.int64),
+        start_time=np.array([it['meta']['start_time'] for it in citems], dtype=np.int64),
+        channel_number=np.array([str(it['meta']['channel_number']) for it in citems]),
+        run_id=np.array([it['meta']['run_id'] for it in citems]),
+        sample_id=np.array([it['meta']['sample_id'] for it in citems]),
+        basecall=np.array([json.dumps(it['basecall']) for it in citems]),
+        tag=np.array([it['tag'] for it in citems]), broken_files=np.array([], dtype='U1'))
+    ev_off = np.zeros(nc + 1, np.int64)
+    ev_mean, ev_scaled, ev_pos, ev_pms, cand_list, unsplit = [], [], [], [], [], []
+    for i, it in enumerate(citems):
+        m, sm, st, ps, pm = ccap['events'][it['read_id']]
+        ev_off[i + 1] = ev_off[i] + len(m)
+        ev_mean.append(m); ev_scaled.append(sm); ev_pos.append(ps); ev_pms.append(pm)
+        cand_list.append(ccap['cands'].get(it['read_id'], []))
+        unsplit.append(ccap['unsplit'].get(it['read_id'], False))
+    np.savez_compressed(os.path.join(OUT, 'chimera.stages.npz'), ev_offsets=ev_off,
+                        ev_mean=np.concatenate(ev_mean), ev_scaled=np.concatenate(ev_scaled),
+                        ev_pos=np.concatenate(ev_pos), ev_pms=np.concatenate(ev_pms),
+                        unsplit=np.array(unsplit, np.int8))
+    with open(os.path.join(OUT, 'chimera.results.json'), 'w') as fh:
+        json.dump({'batchid': 8, 'reads': [(it['filename'], it['read_id']) for it in citems],
+                   'config_flags': {k: ccfg[k] for k in (
+                       'barcoding', 'measure_polya', 'trim_adapter', 'filter_unsplit_reads',
+                       'minimum_sequence_length', 'barcoding_quality_filter')},
+                   'candidates': cand_list, 'results': jsonable(cres)}, fh, indent=1)
+
     # ---- a14/a17 poly(A): real PolyASignalAnalyzer on full-resolution reads
     class _PRead:
         def __init__(self, sig, rate):
