@@ -5,6 +5,8 @@ Bar (north_star): bit-exact for integer/byte/index work -- and, because the
 LSTM arithmetic is canonical (DESIGN.md), bit-exact for the float outputs too;
 the 1e-4 softmax tolerance is kept as the documented fallback bound.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -12,6 +14,7 @@ from poreplex_amd import native as N
 from poreplex_amd.synth import synth_batch
 
 pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
 def reads_of(bundle):
