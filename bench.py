@@ -41,7 +41,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--reads', type=int, default=10000, help='reads per GPU per step')
     ap.add_argument('--samples', type=int, default=60000, help='nominal samples per read')
-    ap.add_argument('--workload', choices=['demux', 'segment', 'polya'], default='demux')
+    ap.add_argument('--workload', choices=['demux', 'segment', 'polya', 'chimera'], default='demux')
     ap.add_argument('--cpu-sample', type=int, default=1024,
                     help='reads timed on the host for cpu_baseline (0 = skip)')
     ap.add_argument('--check', type=int, default=64, help='reads compared with the oracle')
@@ -75,8 +75,18 @@ def main():
         mask, inject = N.STAGE_ALL_DEMUX, None
     elif args.workload == 'polya':
         mask, inject = N.STAGE_ALL_DEMUX | N.STAGE_POLYA, None
+    elif args.workload == 'chimera':
+        mask, inject = N.STAGE_ALL_DEMUX, None
     else:
         mask, inject = N.STAGE_SEGMENT, batch['scale_shift']
+    # --filter-chimera: Guppy block frame of every read (first sample 0, stride 15)
+    ev_first = np.zeros(args.reads, dtype=np.int64)
+    ev_blocks = np.diff(batch['offsets']) // 15
+
+    def step():
+        ctx.run(mask)
+        if args.workload == 'chimera':
+            ctx.unsplit_scan(ev_first, ev_blocks)
     t_up0 = time.perf_counter()
     ctx.upload(batch['arena'], batch['offsets'], batch['calib'], inject)
     t_upload = time.perf_counter() - t_up0
@@ -90,14 +100,14 @@ def main():
 
     from poreplex_amd.distributed import gather_labels
     for _ in range(args.warmup):
-        ctx.run(mask)
+        step()
         res = ctx.download()
         gather_labels(res, dist)
     barrier()
     stage_acc = {k: 0.0 for k in N.TIMER_NAMES}
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ctx.run(mask)
+        step()
         res = ctx.download()             # D2H of the result records is part of a step
         labels = gather_labels(res, dist)   # RCCL all-gather of label records (N>1)
         times, _ = ctx.stage_times()
@@ -123,7 +133,7 @@ def main():
     n_pushed = int(res['bc_pushed'].sum())
 
     # ---- roofline of the dominant kernel ------------------------------------
-    if args.workload in ('demux', 'polya'):
+    if args.workload in ('demux', 'polya', 'chimera'):
         dur = stage_ms['scaler_lstm'] * 1e-3
         flops = n_scaled * FLOP_SCALER
         roofline = {'kernel': 'k_scaler_lstm', 'bound': 'mfma',
@@ -159,6 +169,20 @@ def main():
         inj = None if inject is None else inject[:ns]
         c0 = time.perf_counter()
         want = orc.process_batch(batch['arena'][:o[-1]], o, batch['calib'][:ns], inj, mask)
+        cand_mismatch = None
+        if args.workload == 'chimera':
+            iv, cnt = ctx.unsplit_scan(ev_first, ev_blocks)
+            cand_mismatch = 0
+            for i in range(ns):
+                w = want[i]
+                if w['status'] != 0 or w['seg_first'][3] < 0 or ev_blocks[i] <= 0:
+                    cand_mismatch += int(cnt[i] != 0)
+                    continue
+                _, sc = orc.guppy_event_means(batch['arena'][o[i]:o[i + 1]], batch['calib'][i], 0,
+                                              int(ev_blocks[i]), w['scale'], w['shift'])
+                wiv, wc = orc.unsplit_scan(sc, 0, (int(w['seg_last'][3]) + 1) * 15,
+                                           float(batch['calib'][i]['sampling_rate']))
+                cand_mismatch += int(wc != cnt[i] or wiv.tolist() != iv[i, :min(wc, iv.shape[1])].tolist())
         cpu_s = time.perf_counter() - c0
         cpu = {'value': ns / cpu_s, 'unit': 'reads/s', 'cores': 1, 'kind': 'port',
                'sample': 'first {} reads of the same batch, same stages, oracle/libpxo.so '
@@ -175,18 +199,22 @@ def main():
             'softmax_max_abs_diff': float(np.abs(got['probs'] - want['probs']).max()),
             'all_fields_bit_exact': len(same) == len(got.dtype.names),
         }
+        if cand_mismatch is not None:
+            concordance['unsplit_candidate_mismatch'] = cand_mismatch
 
     line = {
         'metric': {'demux': 'reads/s (segment+barcode)', 'polya': 'reads/s (segment+barcode+polyA)',
+                   'chimera': 'reads/s (segment+barcode+chimera filter)',
                    'segment': 'reads/s (normalise+segment)'}[args.workload],
         'value': value, 'unit': 'reads/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32 (LSTM MFMA) / f64 (Viterbi) / i16 in', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[{}]: {} reads/GPU x ~{} int16 samples, stages {}'.format(
-                       {'demux': 2, 'polya': 3, 'segment': 1}[args.workload], args.reads, args.samples,
+                       {'demux': 2, 'polya': 3, 'chimera': 3, 'segment': 1}[args.workload], args.reads, args.samples,
                        {'demux': 'a1-a13 (scaler LSTM + Viterbi + barcode LSTMs)',
                         'polya': 'a1-a17 (+ poly(A) events/DP)',
+                        'chimera': 'a1-a13 + a18/a19 (Guppy block means + window scan)',
                         'segment': 'a1,a5,a7,a8 (injected scaling)'}[args.workload]),
                    'reads_per_gpu': args.reads, 'samples_per_read': args.samples,
                    'parallelism': 'reads sharded x{}'.format(world), 'device': info['name'],

@@ -75,7 +75,8 @@ enum pxg_stage {
 /* indices into pxg_stage_times.ms[] */
 enum pxg_timer {
     PXG_T_HEAD_POOL = 0, PXG_T_SCALER_LSTM, PXG_T_SEGMENT, PXG_T_BARCODE_WINDOW,
-    PXG_T_DEMUX_BIDIR, PXG_T_DEMUX_TOP, PXG_T_POLYA, PXG_T_FINALIZE, PXG_T_TOTAL,
+    PXG_T_DEMUX_BIDIR, PXG_T_DEMUX_TOP, PXG_T_POLYA, PXG_T_EVENT_MEANS, PXG_T_UNSPLIT,
+    PXG_T_FINALIZE, PXG_T_TOTAL,
     PXG_N_TIMERS
 };
 

@@ -245,6 +245,8 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     release(ctx->segs); release(ctx->idx_scaler); release(ctx->idx_demux);
     release(ctx->counters); release(ctx->win); release(ctx->bidir); release(ctx->probs);
     release(ctx->results); release(ctx->polya_ev); release(ctx->polya_out); release(ctx->spikes);
+    release(ctx->ev_first); release(ctx->ev_off); release(ctx->ev_mean); release(ctx->ev_scaled);
+    release(ctx->unsplit_scr); release(ctx->unsplit_iv); release(ctx->unsplit_cnt);
     free_lstm(ctx->scaler1); free_lstm(ctx->scaler2); free_lstm(ctx->demux_fwd);
     free_lstm(ctx->demux_bwd); free_lstm(ctx->demux_top);
     if (ctx->scaler_dense.kernel) (void)hipFree(ctx->scaler_dense.kernel);
@@ -754,21 +756,34 @@ extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
         eoff[i + 1] = eoff[i] + n_blocks[i];
     }
     const size_t ne = (size_t)eoff[n];
-    int64_t* d_first = S.put(first_sample, (size_t)n, ctx->stream);
-    int64_t* d_eoff = S.put(eoff.data(), (size_t)n + 1, ctx->stream);
-    float* d_mean = S.alloc<float>(ne);
-    float* d_scaled = S.alloc<float>(ne);
-    char* d_scr = S.alloc<char>(pxg_unsplit_scratch_bytes(n));
-    int64_t* d_iv = S.alloc<int64_t>((size_t)n * PXG_MAX_UNSPLIT * 2);
-    int32_t* d_cnt = S.alloc<int32_t>((size_t)n);
-    HOOK_CHECK(d_first && d_eoff && d_mean && d_scaled && d_scr && d_iv && d_cnt);
+    int rc;
+    if ((rc = pxg_reserve(ctx, ctx->ev_first, (size_t)n)) || (rc = pxg_reserve(ctx, ctx->ev_off, (size_t)n + 1)) ||
+        (rc = pxg_reserve(ctx, ctx->ev_mean, ne)) || (rc = pxg_reserve(ctx, ctx->ev_scaled, ne)) ||
+        (rc = pxg_reserve(ctx, ctx->unsplit_scr, pxg_unsplit_scratch_bytes(n))) ||
+        (rc = pxg_reserve(ctx, ctx->unsplit_iv, (size_t)n * PXG_MAX_UNSPLIT * 2)) ||
+        (rc = pxg_reserve(ctx, ctx->unsplit_cnt, (size_t)n)))
+        return rc;
+    int64_t* d_first = ctx->ev_first.p;
+    int64_t* d_eoff = ctx->ev_off.p;
+    float* d_mean = ctx->ev_mean.p;
+    float* d_scaled = ctx->ev_scaled.p;
+    char* d_scr = ctx->unsplit_scr.p;
+    int64_t* d_iv = ctx->unsplit_iv.p;
+    int32_t* d_cnt = ctx->unsplit_cnt.p;
+    PXG_HIP(ctx, hipMemcpyAsync(d_first, first_sample, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    PXG_HIP(ctx, hipMemcpyAsync(d_eoff, eoff.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));     // eoff is a stack-lifetime host vector
     PXG_HIP(ctx, hipMemsetAsync(d_iv, 0, (size_t)n * PXG_MAX_UNSPLIT * 2 * sizeof(int64_t), ctx->stream));
-    int rc = pxg_launch_guppy_event_means(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p,
+    pxg_timer_begin(ctx, PXG_T_EVENT_MEANS);
+    rc = pxg_launch_guppy_event_means(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p,
                                           d_first, d_eoff, block_stride, d_mean, d_scaled);
     if (rc) return rc;
+    pxg_timer_end(ctx, PXG_T_EVENT_MEANS);
+    pxg_timer_begin(ctx, PXG_T_UNSPLIT);
     rc = pxg_launch_unsplit_scan(ctx, n, ctx->calib.p, ctx->status.p, ctx->segs.p, d_first, d_eoff,
                                  d_scaled, block_stride, d_scr, d_iv, d_cnt);
     if (rc) return rc;
+    pxg_timer_end(ctx, PXG_T_UNSPLIT);
     HOOK_GET(out_intervals, d_iv, (size_t)n * PXG_MAX_UNSPLIT * 2);
     HOOK_GET(out_count, d_cnt, n);
     PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -201,6 +201,11 @@ struct pxg_ctx {
     DevBuf<int32_t> polya_out;   // n x 8: called, n_spikes, dwell, begin lo/hi, end lo/hi
     DevBuf<pxg_polya_spike> spikes;   // n x PXG_MAX_SPIKES
     bool polya_ran = false;
+    DevBuf<int64_t> ev_first, ev_off;   // K7: per-read first sample / event offsets
+    DevBuf<float> ev_mean, ev_scaled;   // K7: Guppy block means
+    DevBuf<char> unsplit_scr;           // K7: back-pointer + path scratch
+    DevBuf<int64_t> unsplit_iv;         // n x PXG_MAX_UNSPLIT x 2
+    DevBuf<int32_t> unsplit_cnt;
 
     hipEvent_t ev_start[PXG_N_TIMERS];
     hipEvent_t ev_stop[PXG_N_TIMERS];

@@ -38,7 +38,8 @@ STAGE_POLYA = 8
 STAGE_ALL_DEMUX = 7
 
 TIMER_NAMES = ('head_pool', 'scaler_lstm', 'segment', 'barcode_window',
-               'demux_bidir', 'demux_top', 'polya', 'finalize', 'total')
+               'demux_bidir', 'demux_top', 'polya', 'event_means', 'unsplit',
+               'finalize', 'total')
 
 
 class PxgError(RuntimeError):
