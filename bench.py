@@ -146,6 +146,16 @@ def main():
         roofline = {'kernel': 'k_viterbi_ltr', 'bound': 'hbm', 'achieved': nbytes / dur / 1e9,
                     'peak': PEAK_HBM / 1e9, 'unit': 'GB/s', 'frac': nbytes / dur / PEAK_HBM,
                     'traffic': None, 'algorithmic_bytes_per_read': nbytes / args.reads}
+    # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes
+    # (profiles/r01/e_hbm_traffic.json, collected with tools/prof.sh on this exact
+    # default workload); None for any other workload size
+    if args.reads == 10000 and args.samples == 60000 and args.seed == 924:
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r01', 'e_hbm_traffic.json')) as fh:
+                roofline['traffic'] = json.load(fh)['kernels'][roofline['kernel']]['hbm_bytes']
+            roofline['traffic_source'] = 'profiles/r01/e_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)'
+        except (OSError, KeyError):
+            pass
     # secondary figures for DESIGN.md (not part of the contract)
     alg_bytes = float(np.minimum(np.diff(batch['offsets']), 100000).sum() * 2 + args.reads * 88)
     extra = {

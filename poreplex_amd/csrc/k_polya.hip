@@ -2,7 +2,9 @@
 // hook (a15).  Reference: poreplex/polya.py:50-187, src/csupport.c:70-124 ->
 // src/contrib/scrappie/event_detection.c:36-324.
 //
-// One LANE per read (64 reads per wave): the peak detector is a sequential
+// One LANE per read, PXG_PA_LANES reads per wave (the control flow is data
+// dependent, so narrow waves lose less to divergence and more of them hide the
+// serial latency): the peak detector is a sequential
 // two-detector state machine and the retry / recalibration logic is data
 // dependent, so reads are the parallel axis.  The event detector STREAMS: it
 // never materialises the filtered window, prefix sums or t-statistics --
@@ -100,9 +102,9 @@ __device__ __forceinline__ float tstat_at(const double2* ring, int lane, int64_t
                                           int64_t n)
 {
     if (n < 2 * w || w < 2 || i < w || i > n - w) return 0.0f;
-    const double2 c0 = ring[((i - w) & (PA_RING - 1)) * 64 + lane];
-    const double2 c1 = ring[(i & (PA_RING - 1)) * 64 + lane];
-    const double2 c2 = ring[((i + w) & (PA_RING - 1)) * 64 + lane];
+    const double2 c0 = ring[((i - w) & (PA_RING - 1)) * PXG_PA_LANES + lane];
+    const double2 c1 = ring[(i & (PA_RING - 1)) * PXG_PA_LANES + lane];
+    const double2 c2 = ring[((i + w) & (PA_RING - 1)) * PXG_PA_LANES + lane];
     const float wf = (float)w;
     double s1 = c1.x, q1 = c1.y;
     if (i > w) {
@@ -158,7 +160,7 @@ __device__ __forceinline__ void stream_init(Stream& st, const WindowSrc& S, cons
     st.x0 = st.x1 = st.x2 = 0.0f;
     st.x3 = S.scaled(0); st.x4 = S.scaled(1); st.x5 = S.scaled(2); st.x6 = S.scaled(3);
     st.ne = 0; st.prev_pos = 0; st.prev_cs = 0.0; st.prev_cq = 0.0;
-    ring[0 * 64 + lane] = make_double2(0.0, 0.0);
+    ring[0 * PXG_PA_LANES + lane] = make_double2(0.0, 0.0);
 }
 
 // Streaming detect_events over the window S (event_detection.c:273-324);
@@ -169,8 +171,8 @@ __device__ __forceinline__ void stream_init(Stream& st, const WindowSrc& S, cons
 // window resumes there instead of starting over.
 #define PA_SAFE 28
 __device__ int detect_events_stream(Stream& st, const WindowSrc& S, const PolyaParams& P,
-                                    double2* ring, int lane, Ev* ev /* [cap][64] */, int cap,
-                                    Stream* snap, double2* snap_ring /* [PA_RING][64] */,
+                                    double2* ring, int lane, Ev* ev /* [cap][PXG_PA_LANES] */, int cap,
+                                    Stream* snap, double2* snap_ring /* [PA_RING][PXG_PA_LANES] */,
                                     int64_t* snap_n)
 {
     const int64_t n = S.W;
@@ -182,7 +184,7 @@ __device__ int detect_events_stream(Stream& st, const WindowSrc& S, const PolyaP
             st.i = i;
             *snap = st;
             *snap_n = n;
-            for (int q = 0; q < PA_RING; q++) snap_ring[q * 64 + lane] = ring[q * 64 + lane];
+            for (int q = 0; q < PA_RING; q++) snap_ring[q * PXG_PA_LANES + lane] = ring[q * PXG_PA_LANES + lane];
         }
         // extend the prefix sums to index min(i + look, n), strictly in order
         const int64_t need = (i + look) < n ? (i + look) : n;
@@ -194,9 +196,9 @@ __device__ int detect_events_stream(Stream& st, const WindowSrc& S, const PolyaP
             st.cs = st.cs + (double)f;
             st.cq = st.cq + (double)sq;
             st.filled++;
-            ring[(st.filled & (PA_RING - 1)) * 64 + lane] = make_double2(st.cs, st.cq);
+            ring[(st.filled & (PA_RING - 1)) * PXG_PA_LANES + lane] = make_double2(st.cs, st.cq);
         }
-        const double2 here = ring[(i & (PA_RING - 1)) * 64 + lane];
+        const double2 here = ring[(i & (PA_RING - 1)) * PXG_PA_LANES + lane];
 #pragma unroll
         for (int d = 0; d < 2; d++) {
             Detector& D = st.det[d];
@@ -228,7 +230,7 @@ __device__ int detect_events_stream(Stream& st, const WindowSrc& S, const PolyaP
                 if (D.valid && ((unsigned long long)i - (unsigned long long)D.peak_pos) > D.window / 2) {
                     const unsigned long long p = (unsigned long long)D.peak_pos;
                     if (st.ne < cap)
-                        ev[(size_t)st.ne * 64 + lane] = make_event(st.prev_pos, p, st.prev_cs, st.prev_cq, D.pk_cs, D.pk_cq);
+                        ev[(size_t)st.ne * PXG_PA_LANES + lane] = make_event(st.prev_pos, p, st.prev_cs, st.prev_cq, D.pk_cs, D.pk_cq);
                     st.ne++;
                     st.prev_pos = p;
                     st.prev_cs = D.pk_cs;
@@ -245,7 +247,7 @@ __device__ int detect_events_stream(Stream& st, const WindowSrc& S, const PolyaP
     // zero-length event [0, peaks[0] = 0)  (event_detection.c:261-268)
     int ne = st.ne;
     if (ne < cap)
-        ev[(size_t)ne * 64 + lane] = ne > 0 ? make_event(st.prev_pos, (unsigned long long)n, st.prev_cs, st.prev_cq, st.cs, st.cq)
+        ev[(size_t)ne * PXG_PA_LANES + lane] = ne > 0 ? make_event(st.prev_pos, (unsigned long long)n, st.prev_cs, st.prev_cq, st.cs, st.cq)
                                             : make_event(0, 0, 0.0, 0.0, 0.0, 0.0);
     return ne + 1;
 }
@@ -380,7 +382,7 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
     float flo = 0.0f, fhi = 0.0f;          // float32-rounded poly(A) mean range in force
     const int cap = P.ev_cap;
 
-    auto ev_at = [&](int q) -> Ev { return ev[(size_t)q * 64 + lane]; };
+    auto ev_at = [&](int q) -> Ev { return ev[(size_t)q * PXG_PA_LANES + lane]; };
     auto is_polya = [&](int q) -> bool { const float m = ev_at(q).mean; return m >= flo && m <= fhi; };
     auto ev_end = [&](int q) -> int64_t {
         const Ev e = ev_at(q);
@@ -401,7 +403,7 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
                 // open-end retry: same window start, longer window -> resume the
                 // detector where the shorter window stopped being final
                 st = snap;
-                for (int q = 0; q < PA_RING; q++) ring[q * 64 + lane] = snap_ring[q * 64 + lane];
+                for (int q = 0; q < PA_RING; q++) ring[q * PXG_PA_LANES + lane] = snap_ring[q * PXG_PA_LANES + lane];
             } else {
                 stream_init(st, S, P, ring, lane);
             }
@@ -609,10 +611,10 @@ __global__ __launch_bounds__(64) void k_polya(int64_t n_reads, PolyaParams P,
                                               int32_t* __restrict__ pout /* n x 8 */,
                                               pxg_polya_spike* __restrict__ spikes)
 {
-    __shared__ double2 ring[PA_RING * 64];
+    __shared__ double2 ring[PA_RING * PXG_PA_LANES];
     const int lane = threadIdx.x;
-    const int64_t r = blockIdx.x * 64LL + lane;
-    if (r >= n_reads) return;
+    const int64_t r = blockIdx.x * (int64_t)PXG_PA_LANES + lane;
+    if (lane >= PXG_PA_LANES || r >= n_reads) return;
     int32_t* po = pout + r * 8;
     for (int q = 0; q < 8; q++) po[q] = 0;
     pxg_polya_spike* sp = spikes + r * PXG_MAX_SPIKES;
@@ -628,8 +630,8 @@ __global__ __launch_bounds__(64) void k_polya(int64_t n_reads, PolyaParams P,
     }
     const pxg_calib c = cal[r];
     PolyaOut out;
-    Ev* ev = evbuf + (size_t)blockIdx.x * P.ev_cap * 64;
-    double2* snap_ring = snapbuf + (size_t)blockIdx.x * PA_RING * 64;
+    Ev* ev = evbuf + (size_t)blockIdx.x * P.ev_cap * PXG_PA_LANES;
+    double2* snap_ring = snapbuf + (size_t)blockIdx.x * PA_RING * PXG_PA_LANES;
     polya_one_read(P, raw + off[r], off[r + 1] - off[r], c.range / c.digitisation, c.offset,
                    ss[2 * r], ss[2 * r + 1], rb, re, has_end, ring, lane, ev, snap_ring, out, sp);
     po[0] = out.called;
@@ -648,15 +650,15 @@ __global__ __launch_bounds__(64) void k_detect_events(int64_t n_windows, PolyaPa
                                                       Ev* __restrict__ evbuf,
                                                       int64_t* __restrict__ n_events)
 {
-    __shared__ double2 ring[PA_RING * 64];
+    __shared__ double2 ring[PA_RING * PXG_PA_LANES];
     const int lane = threadIdx.x;
-    const int64_t r = blockIdx.x * 64LL + lane;
-    if (r >= n_windows) return;
+    const int64_t r = blockIdx.x * (int64_t)PXG_PA_LANES + lane;
+    if (lane >= PXG_PA_LANES || r >= n_windows) return;
     WindowSrc S;
     S.raw = nullptr; S.sig = sig + off[r]; S.ib = 0; S.W = off[r + 1] - off[r];
     S.k = 0; S.offset = 0; S.scale = 1; S.shift = 0;
     if (S.W <= 0) { n_events[r] = 0; return; }
-    Ev* ev = evbuf + (size_t)blockIdx.x * P.ev_cap * 64;
+    Ev* ev = evbuf + (size_t)blockIdx.x * P.ev_cap * PXG_PA_LANES;
     Stream st;
     stream_init(st, S, P, ring, lane);
     n_events[r] = detect_events_stream(st, S, P, ring, lane, ev, P.ev_cap, nullptr, nullptr, nullptr);
@@ -706,9 +708,9 @@ int pxg_launch_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t*
     if (n <= 0) return PXG_OK;
     int rc = pxg_polya_supported(ctx);
     if (rc) return rc;
-    const int64_t blocks = (n + 63) / 64;
-    const size_t ev_bytes = (size_t)blocks * PA_EV_CAP * 64 * sizeof(Ev);
-    const size_t snap_bytes = (size_t)blocks * PA_RING * 64 * sizeof(double2);
+    const int64_t blocks = (n + PXG_PA_LANES - 1) / PXG_PA_LANES;
+    const size_t ev_bytes = (size_t)blocks * PA_EV_CAP * PXG_PA_LANES * sizeof(Ev);
+    const size_t snap_bytes = (size_t)blocks * PA_RING * PXG_PA_LANES * sizeof(double2);
     if ((rc = pxg_reserve(ctx, ctx->polya_ev, ev_bytes + snap_bytes))) return rc;
     const PolyaParams P = make_params(ctx->cfg, PA_EV_CAP, ctx->cfg.polya_median_pre_filter);
     hipLaunchKernelGGL(k_polya, dim3((unsigned)blocks), dim3(64), 0, ctx->stream, n, P, raw, off, cal,
@@ -724,7 +726,7 @@ int pxg_launch_detect_events(pxg_ctx* ctx, int64_t n, const float* sig, const in
     int rc = pxg_polya_supported(ctx);
     if (rc) return rc;
     const PolyaParams P = make_params(ctx->cfg, (int)cap, 1);     // hook: no pre-filter
-    hipLaunchKernelGGL(k_detect_events, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, ctx->stream, n, P,
+    hipLaunchKernelGGL(k_detect_events, dim3((unsigned)((n + PXG_PA_LANES - 1) / PXG_PA_LANES)), dim3(64), 0, ctx->stream, n, P,
                        sig, off, (Ev*)evbuf, n_events);
     return PXG_OK;
 }

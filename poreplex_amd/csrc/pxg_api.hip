@@ -684,23 +684,23 @@ extern "C" int pxg_detect_events(pxg_ctx* ctx, int64_t n, const float* signal_ar
     if (n <= 0) return PXG_OK;
     if (cap < 1) return fail(ctx, PXG_E_INVALID, "max_events_per_window must be >= 1");
     struct EvRec { uint32_t start; float length, mean, stdv; };
-    const size_t blocks = (size_t)(n + 63) / 64;
+    const size_t blocks = (size_t)(n + PXG_PA_LANES - 1) / PXG_PA_LANES;
     float* d_sig = S.put(signal_arena, (size_t)off[n], ctx->stream);
     int64_t* d_off = S.put(off, (size_t)n + 1, ctx->stream);
-    EvRec* d_ev = S.alloc<EvRec>(blocks * (size_t)cap * 64);
+    EvRec* d_ev = S.alloc<EvRec>(blocks * (size_t)cap * PXG_PA_LANES);
     int64_t* d_cnt = S.alloc<int64_t>((size_t)n);
     HOOK_CHECK(d_sig && d_off && d_ev && d_cnt);
     int rc = pxg_launch_detect_events(ctx, n, d_sig, d_off, cap, d_ev, d_cnt);
     if (rc) return rc;
-    std::vector<EvRec> ev(blocks * (size_t)cap * 64);
+    std::vector<EvRec> ev(blocks * (size_t)cap * PXG_PA_LANES);
     HOOK_GET(ev.data(), d_ev, ev.size());
     HOOK_GET(n_events, d_cnt, n);
     PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int64_t r = 0; r < n; r++) {
-        const size_t blk = (size_t)r / 64, lane = (size_t)r % 64;
+        const size_t blk = (size_t)r / PXG_PA_LANES, lane = (size_t)r % PXG_PA_LANES;
         const int64_t m = std::min<int64_t>(n_events[r], cap);
         for (int64_t q = 0; q < m; q++) {
-            const EvRec& e = ev[(blk * (size_t)cap + (size_t)q) * 64 + lane];
+            const EvRec& e = ev[(blk * (size_t)cap + (size_t)q) * PXG_PA_LANES + lane];
             pxg_event& o = events[r * cap + q];
             o.start = e.start; o.length = e.length; o.mean = e.mean; o.stdv = e.stdv;
             o.pos = -1; o.state = -1;               // csupport.c:156-159 defaults

@@ -278,6 +278,10 @@ int pxg_launch_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t*
 int pxg_launch_detect_events(pxg_ctx* ctx, int64_t n, const float* sig, const int64_t* off,
                              int64_t cap, void* evbuf, int64_t* n_events);
 
+#ifndef PXG_PA_LANES
+#define PXG_PA_LANES 16   // reads per wave in k_polya / k_detect_events
+#endif
+
 // K7: Guppy event means + pseudo-fusion window scan (k_unsplit.hip)
 int pxg_launch_guppy_event_means(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
                                  const pxg_calib* cal, const float* ss, const int64_t* first,
