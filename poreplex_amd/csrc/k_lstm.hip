@@ -89,11 +89,17 @@ __device__ __forceinline__ void load_sigtab(float4* dst, const float* __restrict
         dst[i] = reinterpret_cast<const float4*>(src)[i];
 }
 
+// Hidden-state rows live in LDS with a stride of H+4 floats: 16 lanes reading 16
+// consecutive rows with ds_read_b128 then touch 16 distinct bank quads (a stride
+// of 48 or 64 floats maps them onto 4 resp. 1 quad: measured 64 % of the LDS
+// cycles of K2 were bank conflicts, profiles/r01/e_*).
+#define HSTRIDE(H) ((H) + 4)
+
 // B fragments of one 16-read tile: hidden row (lane&15), k = lane>>4.
 template <int H>
 __device__ __forceinline__ void load_afrag(float (&a)[H / 4], const float* hrow_base, int lane)
 {
-    const float* p = hrow_base + (lane & 15) * H + (lane >> 4) * (H / 4);
+    const float* p = hrow_base + (lane & 15) * HSTRIDE(H) + (lane >> 4) * (H / 4);
 #pragma unroll
     for (int q = 0; q < H / 16; q++) {
         const float4 v = *reinterpret_cast<const float4*>(p + 4 * q);
@@ -136,16 +142,17 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
     const int row_base = tile0 * 16;
 
     float4* tab = reinterpret_cast<float4*>(smem);     // [1024] sigmoid spline
-    float* h1 = smem + 4 * PXG_SIG_NSEG;               // [2][MTW][16][H]
-    float* h2 = h1 + 2 * MTW * 16 * H;                 // [2][MTW][16][H]
-    float* xb = h2 + 2 * MTW * 16 * H;                 // [16*MTW][XS]
+    constexpr int HS = HSTRIDE(H);
+    float* h1 = smem + 4 * PXG_SIG_NSEG;               // [2][MTW][16][HS]
+    float* h2 = h1 + 2 * MTW * 16 * HS;                // [2][MTW][16][HS]
+    float* xb = h2 + 2 * MTW * 16 * HS;                // [16*MTW][XS]
     int* ridx = reinterpret_cast<int*>(xb + 16 * MTW * XS);   // [16*MTW]
 
     const int tid = threadIdx.x, lane = tid & 63, slice = tid >> 6;
     const int rd_l = lane & 15, ul = lane >> 4;        // read column, unit inside the tile
 
     load_sigtab(tab, sigtab, tid);
-    for (int i = tid; i < 4 * MTW * 16 * H; i += LSTM_THREADS) h1[i] = 0.0f;
+    for (int i = tid; i < 4 * MTW * 16 * HS; i += LSTM_THREADS) h1[i] = 0.0f;
     for (int i = tid; i < 16 * MTW; i += LSTM_THREADS) {
         const int row = row_base + i;
         ridx[i] = (i < 16 * ntile && row < lim) ? (idx ? idx[row] : row) : -1;
@@ -193,8 +200,8 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
         for (int m = 0; m < MTW; m++) {
             if (m < ntile) {
                 float a1[KB], a2[KB];
-                load_afrag<H>(a1, h1 + (rdb * MTW + m) * 16 * H, lane);
-                load_afrag<H>(a2, h2 + (rdb * MTW + m) * 16 * H, lane);
+                load_afrag<H>(a1, h1 + (rdb * MTW + m) * 16 * HS, lane);
+                load_afrag<H>(a2, h2 + (rdb * MTW + m) * 16 * HS, lane);
                 f32x4 acc1[NT], acc2[NT];
                 const float x = xb[(m * 16 + rd_l) * XS + (t % XCH)];
 #pragma unroll
@@ -219,8 +226,8 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
 #pragma unroll
                     for (int nt = 0; nt < NT; nt++)
                         acc2[nt] = mfma4(wB[nt][KB + kb], a2[kb], acc2[nt]);
-                float* o1 = h1 + ((wrb * MTW + m) * 16 + rd_l) * H;
-                float* o2 = h2 + ((wrb * MTW + m) * 16 + rd_l) * H;
+                float* o1 = h1 + ((wrb * MTW + m) * 16 + rd_l) * HS;
+                float* o2 = h2 + ((wrb * MTW + m) * 16 + rd_l) * HS;
                 if (t < T) {
 #pragma unroll
                     for (int nt = 0; nt < NT; nt++)
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
         const int row = i >> 1, j = i & 1;
         const int rd = ridx[row];
         if (rd < 0) continue;
-        const float* hr = h2 + ((fin * MTW + (row >> 4)) * 16 + (row & 15)) * H;
+        const float* hr = h2 + ((fin * MTW + (row >> 4)) * 16 + (row & 15)) * HS;
         float acc = bd[j];
         for (int k = 0; k < H; k++) acc = __builtin_fmaf(hr[hpos<H>(k)], Wd[k * 2 + j], acc);
         pred[(size_t)rd * 2 + j] = acc;
@@ -269,9 +276,10 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
     const int row_base = tile0 * 16;
 
     float4* tab = reinterpret_cast<float4*>(smem);
-    float* hf = smem + 4 * PXG_SIG_NSEG;               // [2][MTW][16][H]
-    float* hb = hf + 2 * MTW * 16 * H;
-    float* xf = hb + 2 * MTW * 16 * H;                 // [16*MTW][XS]  x[t0 + c]
+    constexpr int HS = HSTRIDE(H);
+    float* hf = smem + 4 * PXG_SIG_NSEG;               // [2][MTW][16][HS]
+    float* hb = hf + 2 * MTW * 16 * HS;
+    float* xf = hb + 2 * MTW * 16 * HS;                // [16*MTW][XS]  x[t0 + c]
     float* xr = xf + 16 * MTW * XS;                    // [16*MTW][XS]  x[T-1-(t0+c)]
     int* ridx = reinterpret_cast<int*>(xr + 16 * MTW * XS);
 
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
     const int rd_l = lane & 15, ul = lane >> 4;
 
     load_sigtab(tab, sigtab, tid);
-    for (int i = tid; i < 4 * MTW * 16 * H; i += LSTM_THREADS) hf[i] = 0.0f;
+    for (int i = tid; i < 4 * MTW * 16 * HS; i += LSTM_THREADS) hf[i] = 0.0f;
     for (int i = tid; i < 16 * MTW; i += LSTM_THREADS) {
         const int row = row_base + i;
         ridx[i] = (i < 16 * ntile && row < lim) ? (idx ? idx[row] : row) : -1;
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
                 const int row = i / (2 * (H / 4));
                 const int rd = ridx[row];
                 if (rd < 0) continue;
-                const float* src = (dir ? hb : hf) + ((rdb * MTW + (row >> 4)) * 16 + (row & 15)) * H + c4 * 4;
+                const float* src = (dir ? hb : hf) + ((rdb * MTW + (row >> 4)) * 16 + (row & 15)) * HS + c4 * 4;
                 float* dst = bidir + ((size_t)rd * T + (dir ? tb : tf)) * (2 * H) + dir * H + c4 * 4;
                 *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
             }
@@ -335,8 +343,8 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
         for (int m = 0; m < MTW; m++) {
             if (m < ntile) {
                 float a1[KB], a2[KB];
-                load_afrag<H>(a1, hf + (rdb * MTW + m) * 16 * H, lane);
-                load_afrag<H>(a2, hb + (rdb * MTW + m) * 16 * H, lane);
+                load_afrag<H>(a1, hf + (rdb * MTW + m) * 16 * HS, lane);
+                load_afrag<H>(a2, hb + (rdb * MTW + m) * 16 * HS, lane);
                 f32x4 acc1[NT], acc2[NT];
                 const float x1 = xf[(m * 16 + rd_l) * XS + (t % XCH)];
                 const float x2 = xr[(m * 16 + rd_l) * XS + (t % XCH)];
@@ -358,7 +366,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
                         acc2[nt] = mfma4(wBk[nt][kb], a2[kb], acc2[nt]);
                     }
                 }
-                const int ob = ((wrb * MTW + m) * 16 + rd_l) * H;
+                const int ob = ((wrb * MTW + m) * 16 + rd_l) * HS;
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
                     const int hp = ob + hpos<H>(slice * 12 + nt * 4 + ul);
@@ -391,16 +399,17 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
     const int row_base = tile0 * 16;
 
     float4* tab = reinterpret_cast<float4*>(smem);
-    float* h3 = smem + 4 * PXG_SIG_NSEG;               // [2][MTW][16][H]
-    float* inb = h3 + 2 * MTW * 16 * H;                // [2][MTW*16][2*HI]
-    float* bl = inb + 2 * MTW * 16 * 2 * HI;           // [H][4] bias, (i,f,g,o) per unit
+    constexpr int HS = HSTRIDE(H), IS = HSTRIDE(2 * HI);
+    float* h3 = smem + 4 * PXG_SIG_NSEG;               // [2][MTW][16][HS]
+    float* inb = h3 + 2 * MTW * 16 * HS;               // [2][MTW*16][IS]
+    float* bl = inb + 2 * MTW * 16 * IS;               // [H][4] bias, (i,f,g,o) per unit
     int* ridx = reinterpret_cast<int*>(bl + 4 * H);
 
     const int tid = threadIdx.x, lane = tid & 63, slice = tid >> 6;
     const int rd_l = lane & 15, ul = lane >> 4;
 
     load_sigtab(tab, sigtab, tid);
-    for (int i = tid; i < 2 * MTW * 16 * H; i += LSTM_THREADS) h3[i] = 0.0f;
+    for (int i = tid; i < 2 * MTW * 16 * HS; i += LSTM_THREADS) h3[i] = 0.0f;
     for (int i = tid; i < 4 * H; i += LSTM_THREADS) bl[i] = b3[(i & 3) * H + (i >> 2)];
     for (int i = tid; i < 16 * MTW; i += LSTM_THREADS) {
         const int row = row_base + i;
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
         const int rd = ridx[row];
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (rd >= 0) v = *reinterpret_cast<const float4*>(bidir + ((size_t)rd * T) * (2 * HI) + c4 * 4);
-        *reinterpret_cast<float4*>(inb + row * (2 * HI) + c4 * 4) = v;
+        *reinterpret_cast<float4*>(inb + row * IS + c4 * 4) = v;
     }
     __syncthreads();
 
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
                     const float4 bv = *reinterpret_cast<const float4*>(bl + (slice * 16 + nt * 4 + ul) * 4);
                     acc[nt][0] = bv.x; acc[nt][1] = bv.y; acc[nt][2] = bv.z; acc[nt][3] = bv.w;
                 }
-                const float* p = inb + (rdb * MTW * 16 + m * 16) * (2 * HI) + rd_l * (2 * HI) +
+                const float* p = inb + (rdb * MTW * 16 + m * 16) * IS + rd_l * IS +
                                  (lane >> 4) * (HI / 4);
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
@@ -476,13 +485,13 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
                 }
                 {
                     float a[KBR];
-                    load_afrag<H>(a, h3 + (rdb * MTW + m) * 16 * H, lane);
+                    load_afrag<H>(a, h3 + (rdb * MTW + m) * 16 * HS, lane);
 #pragma unroll
                     for (int kb = 0; kb < KBR; kb++)
 #pragma unroll
                         for (int nt = 0; nt < NT; nt++) acc[nt] = mfma4(wR[nt][kb], a[kb], acc[nt]);
                 }
-                float* o3 = h3 + ((wrb * MTW + m) * 16 + rd_l) * H;
+                float* o3 = h3 + ((wrb * MTW + m) * 16 + rd_l) * HS;
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++)
                     o3[hpos<H>(slice * 16 + nt * 4 + ul)] = cell_update(tab, acc[nt], c3[m][nt]);
@@ -493,7 +502,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
             const int i = tid + p * LSTM_THREADS;
             if (i < n_f4) {
                 const int row = i / (2 * HI / 4), c4 = i % (2 * HI / 4);
-                *reinterpret_cast<float4*>(inb + (wrb * MTW * 16 + row) * (2 * HI) + c4 * 4) = pf[p];
+                *reinterpret_cast<float4*>(inb + (wrb * MTW * 16 + row) * IS + c4 * 4) = pf[p];
             }
         }
         __syncthreads();
@@ -503,7 +512,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
     for (int row = tid; row < 16 * ntile; row += LSTM_THREADS) {
         const int rd = ridx[row];
         if (rd < 0) continue;
-        const float* hr = h3 + ((fin * MTW + (row >> 4)) * 16 + (row & 15)) * H;
+        const float* hr = h3 + ((fin * MTW + (row >> 4)) * 16 + (row & 15)) * HS;
         float z[PXG_MAX_CLASSES], e[PXG_MAX_CLASSES];
 #pragma unroll
         for (int j = 0; j < PXG_MAX_CLASSES; j++) {
@@ -583,7 +592,7 @@ int pxg_launch_scaler_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
     const LstmGrid g = pick_grid(ctx, n_rows);
     const PxgLstmDev &l1 = ctx->scaler1, &l2 = ctx->scaler2;
 #define CALL(M)                                                                                  \
-    const size_t lds = kTabBytes + sizeof(float) * (4 * M * 16 * 48 + 16 * M * XS) +             \
+    const size_t lds = kTabBytes + sizeof(float) * (4 * M * 16 * HSTRIDE(48) + 16 * M * XS) +             \
                        sizeof(int) * 16 * M;                                                     \
     PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_scaler_lstm<M>,                              \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
@@ -608,7 +617,7 @@ int pxg_launch_demux_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
         const PxgLstmDev &f = ctx->demux_fwd, &b = ctx->demux_bwd;
         pxg_timer_begin(ctx, timer_a);
 #define CALL(M)                                                                                  \
-    const size_t lds = kTabBytes + sizeof(float) * (4 * M * 16 * 48 + 2 * 16 * M * XS) +         \
+    const size_t lds = kTabBytes + sizeof(float) * (4 * M * 16 * HSTRIDE(48) + 2 * 16 * M * XS) +         \
                        sizeof(int) * 16 * M;                                                     \
     PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_demux_bidir<M>,                              \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \
@@ -624,7 +633,7 @@ int pxg_launch_demux_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
         const LstmGrid g = pick_grid(ctx, n_rows, 2);   // 160 weight VGPRs: 2 tiles max
         pxg_timer_begin(ctx, timer_b);
 #define CALL(M)                                                                                  \
-    const size_t lds = kTabBytes + sizeof(float) * (2 * M * 16 * 64 + 2 * M * 16 * 96 + 256) +   \
+    const size_t lds = kTabBytes + sizeof(float) * (2 * M * 16 * HSTRIDE(64) + 2 * M * 16 * HSTRIDE(96) + 256) +   \
                        sizeof(int) * 16 * M;                                                     \
     PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_demux_top<M>,                                \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \

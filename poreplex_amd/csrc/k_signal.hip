@@ -35,8 +35,8 @@ __global__ void k_head_pool(int64_t n_reads, const int16_t* __restrict__ raw,
                             int length_limit, int stride, int min_length, int width,
                             float* __restrict__ head, int32_t* __restrict__ status)
 {
-    const int64_t r = blockIdx.y;
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t r = blockIdx.x;            // reads on x: gridDim.y stops at 65535
+    const int j = blockIdx.y * blockDim.x + threadIdx.x;
     if (r >= n_reads || j >= width) return;
     const int64_t n_raw = off[r + 1] - off[r];
     int64_t L = n_raw < length_limit ? n_raw : length_limit;
@@ -64,7 +64,7 @@ int pxg_launch_head_pool(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int6
 {
     if (n <= 0) return PXG_OK;
     const int width = ctx->cfg.scaler_length / ctx->cfg.stride;
-    dim3 grid((width + 255) / 256, (unsigned)n);
+    dim3 grid((unsigned)n, (width + 255) / 256);
     hipLaunchKernelGGL(k_head_pool, grid, dim3(256), 0, ctx->stream, n, raw, off, cal,
                        ctx->cfg.scaler_length, ctx->cfg.stride, ctx->cfg.scaler_min_length,
                        width, head, status);
@@ -77,14 +77,14 @@ __global__ void k_pool_scale(int64_t n_reads, const int16_t* __restrict__ raw,
                              const float* __restrict__ ss, const int64_t* __restrict__ poff,
                              int stride, float* __restrict__ out)
 {
-    const int64_t r = blockIdx.y;
+    const int64_t r = blockIdx.x;
     if (r >= n_reads) return;
     const int64_t P = (off[r + 1] - off[r]) / stride;
     const pxg_calib c = cal[r];
     const double k = c.range / c.digitisation;
     const float scale = ss[2 * r], shift = ss[2 * r + 1];
-    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < P;
-         p += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t p = blockIdx.y * (int64_t)blockDim.x + threadIdx.x; p < P;
+         p += (int64_t)gridDim.y * blockDim.x) {
         float m = pxg_block_mean(raw + off[r] + p * stride, stride, k, c.offset);
         float y = scale * m;
         out[poff[r] + p] = y + shift;
@@ -96,7 +96,7 @@ int pxg_launch_pool_scale(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int
                           float* out)
 {
     if (n <= 0) return PXG_OK;
-    dim3 grid(16, (unsigned)n);
+    dim3 grid((unsigned)n, 16);
     hipLaunchKernelGGL(k_pool_scale, grid, dim3(256), 0, ctx->stream, n, raw, off, cal, ss, poff,
                        ctx->cfg.stride, out);
     return PXG_OK;

@@ -37,7 +37,7 @@ __global__ void k_guppy_event_means(int64_t n_reads, const int16_t* __restrict__
                                     const int64_t* __restrict__ ev_off, int stride,
                                     float* __restrict__ mean, float* __restrict__ scaled)
 {
-    const int64_t r = blockIdx.y;
+    const int64_t r = blockIdx.x;            // reads on x: gridDim.y stops at 65535
     if (r >= n_reads) return;
     const int64_t n_ev = ev_off[r + 1] - ev_off[r];
     const int64_t n_raw = off[r + 1] - off[r];
@@ -48,8 +48,8 @@ __global__ void k_guppy_event_means(int64_t n_reads, const int16_t* __restrict__
     const double k = c.range / c.digitisation;
     const float scale = ss[2 * r], shift = ss[2 * r + 1];
     const int16_t* base = raw + off[r] + first;
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n_ev;
-         e += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t e = blockIdx.y * (int64_t)blockDim.x + threadIdx.x; e < n_ev;
+         e += (int64_t)gridDim.y * blockDim.x) {
         float blk[16];
         float rsum[8];
         // pA of samples q-2 .. q+2 around each of the 15 block samples, zero outside [0, len)
@@ -100,7 +100,7 @@ int pxg_launch_guppy_event_means(pxg_ctx* ctx, int64_t n, const int16_t* raw, co
         ctx->err = "block_stride must be 1..16";
         return PXG_E_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(k_guppy_event_means, dim3(8, (unsigned)n), dim3(256), 0, ctx->stream, n, raw, off,
+    hipLaunchKernelGGL(k_guppy_event_means, dim3((unsigned)n, 8), dim3(256), 0, ctx->stream, n, raw, off,
                        cal, ss, first, ev_off, stride, mean, scaled);
     return PXG_OK;
 }
