@@ -6,17 +6,18 @@
 //        table, Viterbi of the "unsplit" HMM (has back-edges), leader*/adapter run
 //        analysis with duration cut-offs -> candidate in-read adapters.
 //
-// The unsplit HMM is not left-to-right, so this Viterbi keeps real back
-// pointers: lane (read, state) packs its chosen source (4 bit/step) into a
-// register and spills one dword per 8 steps to a wave-interleaved arena;
-// the traceback walks it with one cross-lane read per step, the run analysis is
-// a forward scan of the recovered path by one lane per read.
+// The windows of a read are independent, so the parallel unit is the (read,
+// window) pair: a plan kernel counts each read's windows, the host prefix-sums
+// them, one 8-lane group scans one window, a gather kernel restores the
+// reference's append order.  The unsplit HMM is not left-to-right, so this
+// Viterbi keeps real back pointers (see k_unsplit_scan).
 #include "pxg_common.h"
 
 #define UN_READS 8
-#define UN_CHUNK 32
+#define UN_CHUNK 16
 #define UN_TMAX 4096                       // steps per window the scratch holds
 #define UN_EM_STRIDE (UN_CHUNK * PXG_MAX_STATES + 8)
+#define UN_WCAND 8                         // candidate adapters kept per window
 
 // ---------------------------------------------------------------------------
 // a18: one thread per event block
@@ -52,22 +53,18 @@ __global__ void k_guppy_event_means(int64_t n_reads, const int16_t* __restrict__
          e += (int64_t)gridDim.y * blockDim.x) {
         float blk[16];
         float rsum[8];
-        // pA of samples q-2 .. q+2 around each of the 15 block samples, zero outside [0, len)
-        for (int j = 0; j < stride && j < 16; j++) {
-            const int64_t q = e * stride + j;
-            float v;
-            if (q >= len) {
-                v = __builtin_nanf("");
-            } else {
-                float w[5];
+        // pA of the stride + 4 samples this block's medians touch, zero outside [0, len)
+        float w[20];
+        const int64_t q0 = e * stride;
 #pragma unroll
-                for (int d = -2; d <= 2; d++) {
-                    const int64_t p = q + d;
-                    w[d + 2] = (p >= 0 && p < len) ? pxg_raw2pa(base[p], k, c.offset) : 0.0f;
-                }
-                v = med5(w[0], w[1], w[2], w[3], w[4]);
-            }
-            blk[j] = v;
+        for (int j = 0; j < 20; j++) {
+            const int64_t p = q0 + j - 2;
+            w[j] = (j < stride + 4 && p >= 0 && p < len) ? pxg_raw2pa(base[p], k, c.offset) : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (j < stride)
+                blk[j] = (q0 + j >= len) ? __builtin_nanf("") : med5(w[j], w[j + 1], w[j + 2], w[j + 3], w[j + 4]);
         }
         // NumPy pairwise float32 sum of `stride` (= 15) values, then / stride
         float s;
@@ -147,84 +144,139 @@ __device__ __forceinline__ double un_shfl_f64(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
+// per-read window geometry (signal_analyzer.py:369-388)
+struct UnsplitGeom {
+    int64_t first, n_ev, payload_start, last_end, window_size, window_step, strict_duration;
+    int64_t cut_total[2], cut_adapter[2];
+    bool valid;
+};
+
+__device__ __forceinline__ UnsplitGeom unsplit_geometry(int64_t r, int64_t n_reads, const UnsplitParams& P,
+                                                        const pxg_calib* cal, const int32_t* status,
+                                                        const int32_t* segs, const int64_t* first_sample,
+                                                        const int64_t* ev_off)
+{
+    UnsplitGeom g;
+    g.valid = r < n_reads && status[r] == PXG_ST_OKAY;
+    g.first = g.n_ev = g.payload_start = g.last_end = 0;
+    g.window_size = 0; g.window_step = 1; g.strict_duration = 0;
+    g.cut_total[0] = g.cut_total[1] = g.cut_adapter[0] = g.cut_adapter[1] = 0;
+    if (!g.valid) return g;
+    const int32_t* sf = segs + r * 2 * PXG_N_SEGMENTS;
+    const int a_last = sf[PXG_N_SEGMENTS + P.seg_adapter_state];
+    g.n_ev = ev_off[r + 1] - ev_off[r];
+    if (sf[P.seg_adapter_state] < 0 || g.n_ev <= 0) { g.valid = false; return g; }
+    const double rate = cal[r].sampling_rate;
+    g.first = first_sample[r];
+    g.payload_start = (int64_t)(a_last + 1) * P.pool_stride;          // :369
+    g.last_end = g.first + (int64_t)P.stride * (g.n_ev - 1) + 1;      // events.iloc[-1]['end']
+    g.window_size = (int64_t)(P.window_size * rate);                  // :374-383 int(config * rate)
+    g.window_step = (int64_t)(P.window_step * rate);
+    g.strict_duration = (int64_t)(P.strict_duration * rate);
+    g.cut_total[0] = (int64_t)(P.loosen_full * rate); g.cut_total[1] = (int64_t)(P.strict_full * rate);
+    g.cut_adapter[0] = (int64_t)(P.loosen_dna * rate); g.cut_adapter[1] = (int64_t)(P.strict_dna * rate);
+    if (g.window_step <= 0) g.valid = false;
+    return g;
+}
+
+// events with left <= start <= left + window_size (both ends inclusive)
+__device__ __forceinline__ bool unsplit_window(const UnsplitGeom& g, int stride, int64_t left,
+                                               int64_t& k0, int64_t& k1)
+{
+    k0 = (left - g.first) <= 0 ? 0 : (left - g.first + stride - 1) / stride;
+    k1 = (left + g.window_size - g.first) < 0 ? -1 : (left + g.window_size - g.first) / stride;
+    if (k1 > g.n_ev - 1) k1 = g.n_ev - 1;
+    return k1 >= k0;
+}
+
+// plan: number of windows the reference visits before its first empty block
+__global__ void k_unsplit_plan(int64_t n_reads, UnsplitParams P, const pxg_calib* __restrict__ cal,
+                               const int32_t* __restrict__ status, const int32_t* __restrict__ segs,
+                               const int64_t* __restrict__ first_sample,
+                               const int64_t* __restrict__ ev_off, int32_t* __restrict__ n_win)
+{
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const UnsplitGeom g = unsplit_geometry(r, n_reads, P, cal, status, segs, first_sample, ev_off);
+    int cnt = 0;
+    if (g.valid) {
+        for (int64_t left = g.payload_start; left < g.last_end; left += g.window_step) {
+            int64_t k0, k1;
+            if (!unsplit_window(g, P.stride, left, k0, k1)) break;               // :387-388
+            if (k1 - k0 + 1 > UN_TMAX) { cnt = -1; break; }
+            cnt++;
+        }
+    }
+    n_win[r] = cnt;
+}
+
+// scan: one 8-lane group per (read, window) unit; unit_off[r] = first unit of read r.
+// Back pointers: the 3-bit sources of a group's states are OR-combined over its 8
+// lanes (three DPP steps) into one 24-bit table word per step, so the traceback
+// of a group is a chain of bit-field extractions -- no cross-lane read on the
+// serial path.
+// The leader/adapter run analysis runs inside the traceback (backwards: an
+// adapter run, then the leader runs that precede it), so no path is stored;
+// candidates come out last-first and k_unsplit_gather reverses them.
+template <int NIN>
 __global__ __launch_bounds__(64) void k_unsplit_scan(
-    int64_t n_reads, PxgHmmDev H, UnsplitParams P, const pxg_calib* __restrict__ cal,
+    int64_t n_reads, int64_t n_units, PxgHmmDev H, UnsplitParams P, const pxg_calib* __restrict__ cal,
     const int32_t* __restrict__ status, const int32_t* __restrict__ segs,
     const int64_t* __restrict__ first_sample, const int64_t* __restrict__ ev_off,
-    const float* __restrict__ scaled, unsigned* __restrict__ bpbuf /* [wave][UN_TMAX/8][64] */,
-    unsigned char* __restrict__ pathbuf /* [wave][UN_TMAX][8] */,
-    int64_t* __restrict__ out_iv /* n x PXG_MAX_UNSPLIT x 2 */, int32_t* __restrict__ out_cnt)
+    const int64_t* __restrict__ unit_off, const float* __restrict__ scaled,
+    unsigned* __restrict__ bpbuf /* [wave][UN_TMAX][8 groups] */,
+    int64_t* __restrict__ cand /* n_units x UN_WCAND x 2 */, int32_t* __restrict__ cand_cnt)
 {
     __shared__ double em[UN_READS * UN_EM_STRIDE];
     const int lane = threadIdx.x;
     const int rr = lane >> 3, s = lane & 7;
-    const int64_t r = blockIdx.x * (int64_t)UN_READS + rr;
     const int S = H.n_states;
-    unsigned* bpw = bpbuf + (size_t)blockIdx.x * (UN_TMAX / 8) * 64;
-    unsigned char* path = pathbuf + (size_t)blockIdx.x * UN_TMAX * 8;
+    unsigned* bpm = bpbuf + (size_t)blockIdx.x * UN_TMAX * UN_READS;
 
-    // ---- per-read window geometry ------------------------------------------
-    bool valid = r < n_reads && status[r] == PXG_ST_OKAY;
-    int64_t first = 0, n_ev = 0, payload_start = 0, last_end = 0;
-    int64_t window_size = 0, window_step = 1, strict_duration = 0;
-    int64_t cut_total[2] = { 0, 0 }, cut_adapter[2] = { 0, 0 };
-    const float* x = scaled;
-    if (valid) {
-        const int32_t* sf = segs + r * 2 * PXG_N_SEGMENTS;
-        const int a_last = sf[PXG_N_SEGMENTS + P.seg_adapter_state];
-        n_ev = ev_off[r + 1] - ev_off[r];
-        if (sf[P.seg_adapter_state] < 0 || n_ev <= 0) valid = false;
-        const double rate = cal[r].sampling_rate;
-        first = first_sample[r];
-        payload_start = (int64_t)(a_last + 1) * P.pool_stride;          // :369
-        last_end = first + (int64_t)P.stride * (n_ev - 1) + 1;
-        window_size = (int64_t)(P.window_size * rate);
-        window_step = (int64_t)(P.window_step * rate);
-        strict_duration = (int64_t)(P.strict_duration * rate);
-        cut_total[0] = (int64_t)(P.loosen_full * rate); cut_total[1] = (int64_t)(P.strict_full * rate);
-        cut_adapter[0] = (int64_t)(P.loosen_dna * rate); cut_adapter[1] = (int64_t)(P.strict_dna * rate);
-        if (window_step <= 0) valid = false;
-        x = scaled + ev_off[r];
-    }
-    if (s == 0 && r < n_reads) out_cnt[r] = 0;
-
-    // per-lane in-edge table (name-sorted slots)
-    int src_lane[PXG_MAX_STATES], src_state[PXG_MAX_STATES];
-    double src_lp[PXG_MAX_STATES];
+    // per-lane in-edge table (name-sorted slots); unused slots never win
+    int src_lane[NIN];
+    unsigned src_state[NIN];
+    double src_lp[NIN];
 #pragma unroll
-    for (int d = 0; d < PXG_MAX_STATES; d++) {
+    for (int d = 0; d < NIN; d++) {
         const int sidx = (s < S) ? H.in_src[s][d] : -1;
-        src_state[d] = sidx >= 0 ? sidx : 7;
+        src_state[d] = sidx >= 0 ? (unsigned)sidx : 7u;
         src_lane[d] = sidx >= 0 ? (rr * 8 + sidx) : lane;
         src_lp[d] = sidx >= 0 ? H.in_logp[s][d] : -__builtin_inf();
     }
     const double lstart = (s < S) ? H.log_start[s] : -__builtin_inf();
 
-    int count = 0;
-    bool overflow = false;
-    int64_t left = payload_start;
-    bool more = valid && left < last_end;
-    while (__any(more)) {
-        // ---- this window's event range -------------------------------------
+    for (int64_t ubase = (int64_t)blockIdx.x * UN_READS; ubase < n_units;
+         ubase += (int64_t)gridDim.x * UN_READS) {
+        // ---- which (read, window) is this 8-lane group's unit --------------------
+        const int64_t u = ubase + rr;
+        int64_t r = 0;
+        bool more = u < n_units;
+        if (more) {              // largest r with unit_off[r] <= u
+            int64_t lo = 0, hi = n_reads;
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (unit_off[mid] <= u) lo = mid; else hi = mid;
+            }
+            r = lo;
+        }
+        const UnsplitGeom g = unsplit_geometry(more ? r : n_reads, n_reads, P, cal, status, segs,
+                                               first_sample, ev_off);
         int64_t k0 = 0, k1 = -1;
         if (more) {
-            k0 = (left - first) <= 0 ? 0 : (left - first + P.stride - 1) / P.stride;
-            k1 = (left + window_size - first) < 0 ? -1 : (left + window_size - first) / P.stride;
-            if (k1 > n_ev - 1) k1 = n_ev - 1;
-            if (k1 < k0) more = false;                      // empty block: stop this read (:387-388)
+            const int64_t left = g.payload_start + (u - unit_off[r]) * g.window_step;
+            more = g.valid && unsplit_window(g, P.stride, left, k0, k1);
         }
-        int T = more ? (int)(k1 - k0 + 1) : 0;
-        if (T > UN_TMAX) { T = 0; more = false; overflow = true; }   // window longer than the scratch
+        const int T = more ? (int)(k1 - k0 + 1) : 0;
+        const float* x = scaled + (more ? ev_off[r] : 0);
         int Tmax = T;
         for (int d = 32; d >= 1; d >>= 1) {
             const int o = __shfl_xor(Tmax, d);
             Tmax = o > Tmax ? o : Tmax;
         }
-        if (Tmax == 0) break;
 
         // ---- forward pass ---------------------------------------------------
         double v = -__builtin_inf();
-        unsigned bpacc = 0;
         for (int c0 = 0; c0 < Tmax; c0 += UN_CHUNK) {
             __syncthreads();
 #pragma unroll 1
@@ -235,7 +287,11 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
                     const double xd = (double)x[k0 + t];
 #pragma unroll
                     for (int q = 0; q < PXG_MAX_STATES; q++)
+#ifdef UN_EXP_NOEMIT
+                        if (q < S) em[rr * UN_EM_STRIDE + tt * PXG_MAX_STATES + q] = xd * 0.01 * q;
+#else
                         if (q < S) em[rr * UN_EM_STRIDE + tt * PXG_MAX_STATES + q] = un_emission(H, q, xd);
+#endif
                 }
             }
             __syncthreads();
@@ -245,97 +301,112 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
                 const int t = c0 + tt;
                 const bool act = (t < T) && (s < S);
                 const double e = act ? em[rr * UN_EM_STRIDE + tt * PXG_MAX_STATES + s] : 0.0;
+                double vk[NIN];
+#pragma unroll
+                for (int d = 0; d < NIN; d++) vk[d] = un_shfl_f64(v, src_lane[d]);   // issue all, wait once
                 double best = -__builtin_inf();
                 unsigned arg = 7u;
 #pragma unroll
-                for (int d = 0; d < PXG_MAX_STATES; d++) {
-                    if (d < H.max_in) {                     // wave-uniform
-                        const double vk = un_shfl_f64(v, src_lane[d]);
-                        const double cand = vk + src_lp[d];
-                        const unsigned long long take = __ballot(cand > best);
-                        best = pxg_sel_f64(take, best, cand);
-                        arg = pxg_sel_u32(take, arg, (unsigned)src_state[d]);
-                    }
+                for (int d = 0; d < NIN; d++) {
+                    const double cand_v = vk[d] + src_lp[d];
+                    const unsigned long long take = __ballot(cand_v > best);
+                    best = pxg_sel_f64(take, best, cand_v);
+                    arg = pxg_sel_u32(take, arg, src_state[d]);
                 }
                 const unsigned long long mact = __ballot(act);
                 const double nv = (t == 0) ? (lstart + e) : (best + e);
                 v = pxg_sel_f64(mact, v, nv);
-                bpacc |= (arg & 7u) << ((t & 7) * 4);
-                if ((t & 7) == 7 || t == Tmax - 1) {
-                    bpw[(t >> 3) * 64 + lane] = bpacc;
-                    bpacc = 0;
-                }
+                // back-pointer table of the group: source of state q at bits [3q, 3q+3)
+                unsigned tbl = arg << (3 * s);
+                tbl |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)tbl, 0xB1, 0xF, 0xF, false);   // quad_perm [1,0,3,2]
+                tbl |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)tbl, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+                tbl |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)tbl, 0x141, 0xF, 0xF, false);  // row_half_mirror
+                if (s == 0) bpm[(size_t)t * UN_READS + rr] = tbl;
             }
         }
-        // ---- termination + traceback ------------------------------------------
+        // ---- termination ------------------------------------------------------
         double bestv = -__builtin_inf();
         int cur = H.order[0];
         for (int q = 0; q < S; q++) {
             const double vk = un_shfl_f64(v, rr * 8 + H.order[q]);
             if (q == 0 || vk > bestv) { bestv = vk; cur = H.order[q]; }
         }
-        __syncthreads();      // bp words of this wave are visible to its own lanes
-        for (int g = (Tmax - 1) >> 3; g >= 0; g--) {
-            const unsigned w = bpw[g * 64 + lane];
-            for (int q = 7; q >= 0; q--) {
-                const int t = g * 8 + q;
-                if (t >= Tmax) continue;
-                const bool in = t < T;
-                if (in && s == 0) path[(size_t)t * 8 + rr] = (unsigned char)cur;
-                const int mine = (int)((w >> (q * 4)) & 7u);
-                const int src = __shfl(mine, rr * 8 + cur);
-                if (in && t > 0 && src != 7) cur = src;
-            }
-        }
-        __syncthreads();
-        // ---- run analysis (signal_analyzer.py:393-418), one lane per read ---------
-        if (s == 0 && T > 0) {
-            int leader_start = -1;
-            int t = 0;
-            while (t < T) {
-                const int st = path[(size_t)t * 8 + rr];
-                int e2 = t;
-                while (e2 + 1 < T && path[(size_t)(e2 + 1) * 8 + rr] == st) e2++;
-                if (st != P.adapter_state && st != P.lh_state && st != P.ll_state) {
-                    leader_start = -1;
-                } else {
-                    if (leader_start < 0) leader_start = t;
-                    if (st == P.adapter_state) {
-                        const int64_t ev_last = k0 + e2, ev_lead = k0 + leader_start, ev_first = k0 + t;
-                        const int64_t adapter_end = (ev_last == n_ev - 1)
-                            ? first + (int64_t)P.stride * ev_last + 1
-                            : first + (int64_t)P.stride * (ev_last + 1);
-                        const int64_t leader_in_read = first + (int64_t)P.stride * ev_lead;
-                        const int64_t total_duration = adapter_end - leader_in_read;
-                        const int64_t adapter_duration = adapter_end - (first + (int64_t)P.stride * ev_first);
-                        const int strict = (leader_in_read - payload_start) <= strict_duration ? 1 : 0;
-                        if (total_duration >= cut_total[strict] && adapter_duration >= cut_adapter[strict]) {
-                            if (count < PXG_MAX_UNSPLIT) {
-                                out_iv[(r * PXG_MAX_UNSPLIT + count) * 2] = leader_in_read;
-                                out_iv[(r * PXG_MAX_UNSPLIT + count) * 2 + 1] = 1 + adapter_end;
-                            }
-                            count++;
-                        }
-                        leader_start = -1;
-                    }
+        // ---- traceback + run analysis (signal_analyzer.py:393-418, backwards) --------
+        int phase = 0;                   // 0 none, 1 inside an adapter run, 2 leader runs before it
+        int a_last = -1, a_first = -1, lead = -1, count = 0;
+        auto finalize = [&](int lead_t) {
+            const int64_t ev_last = k0 + a_last, ev_lead = k0 + lead_t, ev_first = k0 + a_first;
+            const int64_t adapter_end = (ev_last == g.n_ev - 1)
+                ? g.first + (int64_t)P.stride * ev_last + 1
+                : g.first + (int64_t)P.stride * (ev_last + 1);
+            const int64_t leader_in_read = g.first + (int64_t)P.stride * ev_lead;
+            const int64_t total_duration = adapter_end - leader_in_read;
+            const int64_t adapter_duration = adapter_end - (g.first + (int64_t)P.stride * ev_first);
+            const int strict = (leader_in_read - g.payload_start) <= g.strict_duration ? 1 : 0;
+            if (total_duration >= g.cut_total[strict] && adapter_duration >= g.cut_adapter[strict]) {
+                if (s == 0 && count < UN_WCAND) {
+                    cand[(u * UN_WCAND + count) * 2] = leader_in_read;
+                    cand[(u * UN_WCAND + count) * 2 + 1] = 1 + adapter_end;
                 }
-                t = e2 + 1;
+                count++;
+            }
+        };
+        __syncthreads();     // this wave's table stores (lanes s == 0) before the group's loads
+#ifndef UN_EXP_NOTRACE
+        for (int tb = ((Tmax - 1) >> 3) << 3; tb >= 0; tb -= 8) {
+            unsigned m[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) m[q] = (tb + q < Tmax) ? bpm[(size_t)(tb + q) * UN_READS + rr] : 0u;
+#pragma unroll
+            for (int q = 7; q >= 0; q--) {
+                const int t = tb + q;
+                if (t >= T) continue;                // also skips t >= Tmax
+                const bool isA = cur == P.adapter_state;
+                const bool isL = cur == P.ll_state || cur == P.lh_state;
+                // a candidate closes when the runs in front of its adapter stop being leaders
+                if ((phase == 1 && !isA && !isL) || (phase == 2 && !isL))
+                    finalize(phase == 1 ? a_first : lead);
+                if (isA && phase != 1) a_last = t;
+                if (isA) a_first = t;
+                if (isL && phase != 0) lead = t;
+                phase = isA ? 1 : ((isL && phase != 0) ? 2 : 0);
+                const int src = (int)((m[q] >> (3 * cur)) & 7u);
+                if (t > 0 && src != 7) cur = src;
             }
         }
-        if (more) {
-            left += window_step;
-            more = left < last_end;
-        }
+#endif
+        if (phase == 1) finalize(a_first);
+        else if (phase == 2) finalize(lead);
+        if (s == 0 && more) cand_cnt[u] = count;
     }
-    if (s == 0 && r < n_reads) out_cnt[r] = overflow ? -1 : count;
 }
 
-int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, const pxg_calib* cal, const int32_t* status,
-                            const int32_t* segs, const int64_t* first_sample, const int64_t* ev_off,
-                            const float* scaled, int stride, void* scratch, int64_t* out_iv,
-                            int32_t* out_cnt)
+// gather: candidates of a read's windows, in window order (the order the reference appends them)
+__global__ void k_unsplit_gather(int64_t n_reads, const int64_t* __restrict__ unit_off,
+                                 const int32_t* __restrict__ n_win, const int64_t* __restrict__ cand,
+                                 const int32_t* __restrict__ cand_cnt, int64_t* __restrict__ out_iv,
+                                 int32_t* __restrict__ out_cnt)
 {
-    if (n <= 0) return PXG_OK;
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    int total = 0;
+    bool overflow = n_win[r] < 0;
+    for (int64_t u = unit_off[r]; u < unit_off[r + 1]; u++) {
+        const int c = cand_cnt[u];
+        if (c > UN_WCAND) overflow = true;
+        for (int q = (c < UN_WCAND ? c : UN_WCAND) - 1; q >= 0; q--) {   // stored last-first
+            if (total < PXG_MAX_UNSPLIT) {
+                out_iv[(r * PXG_MAX_UNSPLIT + total) * 2] = cand[(u * UN_WCAND + q) * 2];
+                out_iv[(r * PXG_MAX_UNSPLIT + total) * 2 + 1] = cand[(u * UN_WCAND + q) * 2 + 1];
+            }
+            total++;
+        }
+    }
+    out_cnt[r] = overflow ? -1 : total;
+}
+
+static UnsplitParams unsplit_params(const pxg_ctx* ctx, int stride)
+{
     const pxg_config& c = ctx->cfg;
     UnsplitParams P;
     P.window_size = c.unsplit_window_size; P.window_step = c.unsplit_window_step;
@@ -348,16 +419,61 @@ int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, const pxg_calib* cal, const
     P.seg_adapter_state = c.segmentation_model.adapter_state;
     P.stride = stride;
     P.pool_stride = c.stride;
-    const size_t blocks = (size_t)(n + UN_READS - 1) / UN_READS;
-    unsigned* bp = (unsigned*)scratch;
-    unsigned char* path = (unsigned char*)scratch + blocks * (UN_TMAX / 8) * 64 * sizeof(unsigned);
-    hipLaunchKernelGGL(k_unsplit_scan, dim3((unsigned)blocks), dim3(64), 0, ctx->stream, n, ctx->hmm[1], P,
-                       cal, status, segs, first_sample, ev_off, scaled, bp, path, out_iv, out_cnt);
+    return P;
+}
+
+int pxg_launch_unsplit_plan(pxg_ctx* ctx, int64_t n, const pxg_calib* cal, const int32_t* status,
+                            const int32_t* segs, const int64_t* first_sample, const int64_t* ev_off,
+                            int stride, int32_t* n_win)
+{
+    if (n <= 0) return PXG_OK;
+    hipLaunchKernelGGL(k_unsplit_plan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
+                       unsplit_params(ctx, stride), cal, status, segs, first_sample, ev_off, n_win);
     return PXG_OK;
 }
 
-size_t pxg_unsplit_scratch_bytes(int64_t n)
+int pxg_unsplit_waves(const pxg_ctx* ctx, int64_t n_units)
 {
-    const size_t blocks = (size_t)(n + UN_READS - 1) / UN_READS;
-    return blocks * ((UN_TMAX / 8) * 64 * sizeof(unsigned) + (size_t)UN_TMAX * 8);
+    const int64_t need = (n_units + UN_READS - 1) / UN_READS;
+    const int64_t cap = (int64_t)ctx->n_cu * 16;
+    return (int)(need < cap ? (need > 0 ? need : 1) : cap);
+}
+
+size_t pxg_unsplit_scratch_bytes(const pxg_ctx* ctx, int64_t n_units)
+{
+    return (size_t)pxg_unsplit_waves(ctx, n_units) * UN_TMAX * UN_READS * sizeof(unsigned);
+}
+
+size_t pxg_unsplit_cand_bytes(int64_t n_units)
+{
+    return (size_t)(n_units > 0 ? n_units : 1) * (UN_WCAND * 2 * sizeof(int64_t) + sizeof(int32_t));
+}
+
+int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t n_units, const pxg_calib* cal,
+                            const int32_t* status, const int32_t* segs, const int64_t* first_sample,
+                            const int64_t* ev_off, const int64_t* unit_off, const int32_t* n_win,
+                            const float* scaled, int stride, void* scratch, void* candbuf,
+                            int64_t* out_iv, int32_t* out_cnt)
+{
+    if (n <= 0) return PXG_OK;
+    const UnsplitParams P = unsplit_params(ctx, stride);
+    const int waves = pxg_unsplit_waves(ctx, n_units);
+    unsigned* bp = (unsigned*)scratch;
+    int64_t* cand = (int64_t*)candbuf;
+    int32_t* cand_cnt = (int32_t*)((char*)candbuf + (size_t)(n_units > 0 ? n_units : 1) * UN_WCAND * 2 * sizeof(int64_t));
+    if (n_units > 0) {
+#define SCAN(NIN)                                                                                      \
+    hipLaunchKernelGGL(k_unsplit_scan<NIN>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, n,        \
+                       n_units, ctx->hmm[1], P, cal, status, segs, first_sample, ev_off, unit_off,     \
+                       scaled, bp, cand, cand_cnt)
+        const int nin = ctx->hmm[1].max_in;
+        if (nin <= 2) SCAN(2);
+        else if (nin <= 3) SCAN(3);
+        else if (nin <= 5) SCAN(5);
+        else SCAN(8);
+#undef SCAN
+    }
+    hipLaunchKernelGGL(k_unsplit_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
+                       unit_off, n_win, cand, cand_cnt, out_iv, out_cnt);
+    return PXG_OK;
 }

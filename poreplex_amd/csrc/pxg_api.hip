@@ -247,6 +247,7 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     release(ctx->results); release(ctx->polya_ev); release(ctx->polya_out); release(ctx->spikes);
     release(ctx->ev_first); release(ctx->ev_off); release(ctx->ev_mean); release(ctx->ev_scaled);
     release(ctx->unsplit_scr); release(ctx->unsplit_iv); release(ctx->unsplit_cnt);
+    release(ctx->unsplit_cand); release(ctx->unit_off); release(ctx->n_win);
     free_lstm(ctx->scaler1); free_lstm(ctx->scaler2); free_lstm(ctx->demux_fwd);
     free_lstm(ctx->demux_bwd); free_lstm(ctx->demux_top);
     if (ctx->scaler_dense.kernel) (void)hipFree(ctx->scaler_dense.kernel);
@@ -759,7 +760,7 @@ extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
     int rc;
     if ((rc = pxg_reserve(ctx, ctx->ev_first, (size_t)n)) || (rc = pxg_reserve(ctx, ctx->ev_off, (size_t)n + 1)) ||
         (rc = pxg_reserve(ctx, ctx->ev_mean, ne)) || (rc = pxg_reserve(ctx, ctx->ev_scaled, ne)) ||
-        (rc = pxg_reserve(ctx, ctx->unsplit_scr, pxg_unsplit_scratch_bytes(n))) ||
+        (rc = pxg_reserve(ctx, ctx->unit_off, (size_t)n + 1)) || (rc = pxg_reserve(ctx, ctx->n_win, (size_t)n)) ||
         (rc = pxg_reserve(ctx, ctx->unsplit_iv, (size_t)n * PXG_MAX_UNSPLIT * 2)) ||
         (rc = pxg_reserve(ctx, ctx->unsplit_cnt, (size_t)n)))
         return rc;
@@ -767,21 +768,39 @@ extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
     int64_t* d_eoff = ctx->ev_off.p;
     float* d_mean = ctx->ev_mean.p;
     float* d_scaled = ctx->ev_scaled.p;
-    char* d_scr = ctx->unsplit_scr.p;
     int64_t* d_iv = ctx->unsplit_iv.p;
     int32_t* d_cnt = ctx->unsplit_cnt.p;
     PXG_HIP(ctx, hipMemcpyAsync(d_first, first_sample, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     PXG_HIP(ctx, hipMemcpyAsync(d_eoff, eoff.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));     // eoff is a stack-lifetime host vector
     PXG_HIP(ctx, hipMemsetAsync(d_iv, 0, (size_t)n * PXG_MAX_UNSPLIT * 2 * sizeof(int64_t), ctx->stream));
     pxg_timer_begin(ctx, PXG_T_EVENT_MEANS);
     rc = pxg_launch_guppy_event_means(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p,
-                                          d_first, d_eoff, block_stride, d_mean, d_scaled);
+                                      d_first, d_eoff, block_stride, d_mean, d_scaled);
     if (rc) return rc;
     pxg_timer_end(ctx, PXG_T_EVENT_MEANS);
+    // plan: windows per read (device) -> unit offsets (host prefix sum) while K7a runs
+    if ((rc = pxg_launch_unsplit_plan(ctx, n, ctx->calib.p, ctx->status.p, ctx->segs.p, d_first, d_eoff,
+                                      block_stride, ctx->n_win.p)))
+        return rc;
+    std::vector<int32_t> nwin((size_t)n);
+    HOOK_GET(nwin.data(), ctx->n_win.p, n);
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int64_t> uoff((size_t)n + 1, 0);
+    for (int64_t i = 0; i < n; i++) {
+        if (nwin[i] < 0)
+            return fail(ctx, PXG_E_UNSUPPORTED, "pxg_batch_unsplit_scan: a window exceeds 4096 event blocks");
+        uoff[i + 1] = uoff[i] + nwin[i];
+    }
+    const int64_t n_units = uoff[n];
+    if ((rc = pxg_reserve(ctx, ctx->unsplit_scr, pxg_unsplit_scratch_bytes(ctx, n_units))) ||
+        (rc = pxg_reserve(ctx, ctx->unsplit_cand, pxg_unsplit_cand_bytes(n_units))))
+        return rc;
+    PXG_HIP(ctx, hipMemcpyAsync(ctx->unit_off.p, uoff.data(), ((size_t)n + 1) * sizeof(int64_t),
+                                hipMemcpyHostToDevice, ctx->stream));
     pxg_timer_begin(ctx, PXG_T_UNSPLIT);
-    rc = pxg_launch_unsplit_scan(ctx, n, ctx->calib.p, ctx->status.p, ctx->segs.p, d_first, d_eoff,
-                                 d_scaled, block_stride, d_scr, d_iv, d_cnt);
+    rc = pxg_launch_unsplit_scan(ctx, n, n_units, ctx->calib.p, ctx->status.p, ctx->segs.p, d_first, d_eoff,
+                                 ctx->unit_off.p, ctx->n_win.p, d_scaled, block_stride, ctx->unsplit_scr.p,
+                                 ctx->unsplit_cand.p, d_iv, d_cnt);
     if (rc) return rc;
     pxg_timer_end(ctx, PXG_T_UNSPLIT);
     HOOK_GET(out_intervals, d_iv, (size_t)n * PXG_MAX_UNSPLIT * 2);
@@ -789,6 +808,6 @@ extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
     PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int64_t i = 0; i < n; i++)
         if (out_count[i] < 0)
-            return fail(ctx, PXG_E_UNSUPPORTED, "pxg_batch_unsplit_scan: a window exceeds 4096 event blocks");
+            return fail(ctx, PXG_E_UNSUPPORTED, "pxg_batch_unsplit_scan: more than 8 candidate adapters in one window");
     HOOK_END
 }

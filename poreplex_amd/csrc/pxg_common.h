@@ -204,6 +204,9 @@ struct pxg_ctx {
     DevBuf<int64_t> ev_first, ev_off;   // K7: per-read first sample / event offsets
     DevBuf<float> ev_mean, ev_scaled;   // K7: Guppy block means
     DevBuf<char> unsplit_scr;           // K7: back-pointer + path scratch
+    DevBuf<char> unsplit_cand;          // K7: per-window candidates
+    DevBuf<int64_t> unit_off;           // K7: first (read, window) unit of each read
+    DevBuf<int32_t> n_win;              // K7: windows per read
     DevBuf<int64_t> unsplit_iv;         // n x PXG_MAX_UNSPLIT x 2
     DevBuf<int32_t> unsplit_cnt;
 
@@ -286,11 +289,16 @@ int pxg_launch_detect_events(pxg_ctx* ctx, int64_t n, const float* sig, const in
 int pxg_launch_guppy_event_means(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
                                  const pxg_calib* cal, const float* ss, const int64_t* first,
                                  const int64_t* ev_off, int stride, float* mean, float* scaled);
-size_t pxg_unsplit_scratch_bytes(int64_t n);
-int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, const pxg_calib* cal, const int32_t* status,
+int pxg_launch_unsplit_plan(pxg_ctx* ctx, int64_t n, const pxg_calib* cal, const int32_t* status,
                             const int32_t* segs, const int64_t* first_sample, const int64_t* ev_off,
-                            const float* scaled, int stride, void* scratch, int64_t* out_iv,
-                            int32_t* out_cnt);
+                            int stride, int32_t* n_win);
+size_t pxg_unsplit_scratch_bytes(const pxg_ctx* ctx, int64_t n_units);
+size_t pxg_unsplit_cand_bytes(int64_t n_units);
+int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t n_units, const pxg_calib* cal,
+                            const int32_t* status, const int32_t* segs, const int64_t* first_sample,
+                            const int64_t* ev_off, const int64_t* unit_off, const int32_t* n_win,
+                            const float* scaled, int stride, void* scratch, void* candbuf,
+                            int64_t* out_iv, int32_t* out_cnt);
 
 void pxg_timer_begin(pxg_ctx* ctx, int t);
 void pxg_timer_end(pxg_ctx* ctx, int t);
