@@ -273,10 +273,6 @@ int pxg_batch_download(pxg_ctx* ctx, pxg_read_result* out);
 /* n_reads x PXG_MAX_SPIKES spike rows of the last run (poly(A) stage only) */
 int pxg_batch_download_spikes(pxg_ctx* ctx, pxg_polya_spike* out);
 int pxg_batch_times(pxg_ctx* ctx, pxg_stage_times* out);
-/* Fill the resident batch on the device from a seed (bench configs that are
- * too large to stage through the host). */
-int pxg_batch_synthesize(pxg_ctx* ctx, int64_t n_reads, int64_t samples_per_read,
-                         uint64_t seed);
 
 /* ---- per-stage hooks (parity tests call these through the same ABI) ------ */
 /* a1: Fast5Reader.get_raw_data (fast5_file.py:122-131) */

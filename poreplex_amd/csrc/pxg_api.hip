@@ -468,11 +468,6 @@ extern "C" int pxg_batch_times(pxg_ctx* ctx, pxg_stage_times* out)
     return PXG_OK;
 }
 
-extern "C" int pxg_batch_synthesize(pxg_ctx* ctx, int64_t, int64_t, uint64_t)
-{
-    return fail(ctx, PXG_E_UNSUPPORTED, "pxg_batch_synthesize: device-side generator not built yet");
-}
-
 extern "C" int pxg_process_batch(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
                                  const int64_t* raw_offsets, const pxg_calib* calib,
                                  const float* scale_shift_or_null, uint32_t stage_mask,

@@ -333,7 +333,6 @@ _SIGNATURES = {
     'pxg_batch_download': (C.c_int, [C.c_void_p, C.c_void_p]),
     'pxg_batch_download_spikes': (C.c_int, [C.c_void_p, C.c_void_p]),
     'pxg_batch_times': (C.c_int, [C.c_void_p, C.POINTER(PxgStageTimes)]),
-    'pxg_batch_synthesize': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64]),
     'pxg_raw_to_pa': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pxg_head_pool': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]),
@@ -460,11 +459,6 @@ class NativeContext:
             self.handle, n, _ptr(arena), _ptr(offsets), _ptr(calib), _ptr(scale_shift)),
             'pxg_batch_upload')
         self.n_resident = n
-
-    def synthesize(self, n_reads, samples_per_read, seed):
-        self._check(self.lib.pxg_batch_synthesize(self.handle, n_reads, samples_per_read,
-                                                  seed), 'pxg_batch_synthesize')
-        self.n_resident = n_reads
 
     def run(self, stage_mask=STAGE_ALL_DEMUX):
         self._check(self.lib.pxg_batch_run(self.handle, stage_mask), 'pxg_batch_run')
