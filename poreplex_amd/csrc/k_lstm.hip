@@ -48,18 +48,76 @@ __device__ __forceinline__ int hpos(int u)
     return (u & 3) * (H / 4) + (u >> 2);
 }
 
-// acc = (i, f, g, o) pre-activations of one (read, unit); returns h, updates c
-__device__ __forceinline__ float cell_update(const float4* tab, f32x4 acc, float& c)
+// acc = pre-activations of one (read, unit), ALREADY in table units: the gate
+// columns of every LSTM matrix/bias are scaled at upload (pxg_api.hip
+// upload_lstm) by 16 (i, f, o: sigmoid table step 1/16) and 32 (g: tanh =
+// 2*sigmoid(2x)-1).  A power-of-two scale commutes with every rounding of the
+// fma chain, so acc == 16z resp. 32z bit for bit and the lookups lose their
+// multiply.  The cell state is carried as C = 32c for the same reason:
+// fl(f*C) + fl(i*G) with G = fma(64, s, -32) = 32*tanh is exactly 32*c'.
+// Returns h = fl(o * tanh(c')), identical to the unscaled formulation.
+__device__ __forceinline__ float cell_update(const float4* tab, f32x4 acc, float& C)
 {
-    const float ig = pxg_sigmoid(tab, acc[0]);
-    const float fg = pxg_sigmoid(tab, acc[1]);
-    const float gg = pxg_tanh(tab, acc[2]);
-    const float og = pxg_sigmoid(tab, acc[3]);
-    const float fc = fg * c;
-    const float in = ig * gg;
+    const float ig = pxg_sig_lookup_u(tab, acc[0]);
+    const float fg = pxg_sig_lookup_u(tab, acc[1]);
+    const float G = __builtin_fmaf(64.0f, pxg_sig_lookup_u(tab, acc[2]), -32.0f);
+    const float og = pxg_sig_lookup_u(tab, acc[3]);
+    const float fc = fg * C;
+    const float in = ig * G;
     const float cn = fc + in;
-    c = cn;
-    return og * pxg_tanh(tab, cn);
+    C = cn;
+    const float th = __builtin_fmaf(2.0f, pxg_sig_lookup_u(tab, cn), -1.0f);
+    return og * th;
+}
+
+// The same update for the NT cells a lane owns in one layer, written in stages so
+// that the NT*4 table rows are requested back to back (one exposed LDS latency per
+// layer and tile instead of one per activation).
+template <int NT>
+__device__ __forceinline__ void cells_update(const float4* tab, const f32x4 (&acc)[NT], float (&C)[NT],
+                                             float (&h)[NT])
+{
+    float s[NT][4];
+    float4 c[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float u = __builtin_amdgcn_fmed3f(acc[nt][r], -512.0f, 511.99997f);
+            const float fl = __builtin_floorf(u);
+            s[nt][r] = u - fl;
+            c[nt][r] = tab[(int)fl + PXG_SIG_HALF];
+        }
+    float s2[NT], og[NT];
+    float4 c2[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        float g[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            float p = __builtin_fmaf(c[nt][r].w, s[nt][r], c[nt][r].z);
+            p = __builtin_fmaf(p, s[nt][r], c[nt][r].y);
+            g[r] = __builtin_fmaf(p, s[nt][r], c[nt][r].x);
+        }
+        const float G = __builtin_fmaf(64.0f, g[2], -32.0f);
+        const float fc = g[1] * C[nt];
+        const float in = g[0] * G;
+        const float cn = fc + in;
+        C[nt] = cn;
+        og[nt] = g[3];
+        const float u = __builtin_amdgcn_fmed3f(cn, -512.0f, 511.99997f);
+        const float fl = __builtin_floorf(u);
+        s2[nt] = u - fl;
+        c2[nt] = tab[(int)fl + PXG_SIG_HALF];
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        float p = __builtin_fmaf(c2[nt].w, s2[nt], c2[nt].z);
+        p = __builtin_fmaf(p, s2[nt], c2[nt].y);
+        const float st = __builtin_fmaf(p, s2[nt], c2[nt].x);
+        const float th = __builtin_fmaf(2.0f, st, -1.0f);
+        h[nt] = og[nt] * th;
+    }
 }
 
 // A fragments (weights) of one gate tile: rows [row0, row0+4*KB) of a Keras
@@ -229,14 +287,16 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
                 float* o1 = h1 + ((wrb * MTW + m) * 16 + rd_l) * HS;
                 float* o2 = h2 + ((wrb * MTW + m) * 16 + rd_l) * HS;
                 if (t < T) {
+                    float hn[NT];
+                    cells_update<NT>(tab, acc1, c1[m], hn);
 #pragma unroll
-                    for (int nt = 0; nt < NT; nt++)
-                        o1[hpos<H>(slice * 12 + nt * 4 + ul)] = cell_update(tab, acc1[nt], c1[m][nt]);
+                    for (int nt = 0; nt < NT; nt++) o1[hpos<H>(slice * 12 + nt * 4 + ul)] = hn[nt];
                 }
                 if (t >= 1) {
+                    float hn[NT];
+                    cells_update<NT>(tab, acc2, c2[m], hn);
 #pragma unroll
-                    for (int nt = 0; nt < NT; nt++)
-                        o2[hpos<H>(slice * 12 + nt * 4 + ul)] = cell_update(tab, acc2[nt], c2[m][nt]);
+                    for (int nt = 0; nt < NT; nt++) o2[hpos<H>(slice * 12 + nt * 4 + ul)] = hn[nt];
                 }
             }
         }
@@ -367,11 +427,14 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
                     }
                 }
                 const int ob = ((wrb * MTW + m) * 16 + rd_l) * HS;
+                float hn1[NT], hn2[NT];
+                cells_update<NT>(tab, acc1, cf[m], hn1);
+                cells_update<NT>(tab, acc2, cb[m], hn2);
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
                     const int hp = ob + hpos<H>(slice * 12 + nt * 4 + ul);
-                    hf[hp] = cell_update(tab, acc1[nt], cf[m][nt]);
-                    hb[hp] = cell_update(tab, acc2[nt], cb[m][nt]);
+                    hf[hp] = hn1[nt];
+                    hb[hp] = hn2[nt];
                 }
             }
         }
@@ -492,9 +555,18 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
                         for (int nt = 0; nt < NT; nt++) acc[nt] = mfma4(wR[nt][kb], a[kb], acc[nt]);
                 }
                 float* o3 = h3 + ((wrb * MTW + m) * 16 + rd_l) * HS;
+                float hn[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; nt++)
-                    o3[hpos<H>(slice * 16 + nt * 4 + ul)] = cell_update(tab, acc[nt], c3[m][nt]);
+                for (int half = 0; half < 2; half++) {      // 2 x 2 cells: 160 weight VGPRs leave no
+                    f32x4 a2[2] = { acc[2 * half], acc[2 * half + 1] };   // room for 16 rows in flight
+                    float cc[2] = { c3[m][2 * half], c3[m][2 * half + 1] };
+                    float hh[2];
+                    cells_update<2>(tab, a2, cc, hh);
+                    c3[m][2 * half] = cc[0]; c3[m][2 * half + 1] = cc[1];
+                    hn[2 * half] = hh[0]; hn[2 * half + 1] = hh[1];
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) o3[hpos<H>(slice * 16 + nt * 4 + ul)] = hn[nt];
             }
         }
 #pragma unroll

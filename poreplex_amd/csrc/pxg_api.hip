@@ -127,15 +127,30 @@ static int upload(pxg_ctx* ctx, T** dst, const T* src, size_t n)
     return PXG_OK;
 }
 
+// LSTM weights go to the device with their gate columns pre-scaled by the
+// activation-table step (Keras column order i, f, g, o: x16, x16, x32, x16);
+// exact (powers of two), see k_lstm.hip cell_update.
 static int upload_lstm(pxg_ctx* ctx, const pxg_lstm_layer& h, PxgLstmDev& d)
 {
     d.input_dim = h.input_dim;
     d.units = h.units;
     if (h.input_dim < 1 || h.units < 1) return fail(ctx, PXG_E_INVALID, "bad LSTM dims");
+    if (!h.kernel || !h.recurrent || !h.bias) return fail(ctx, PXG_E_INVALID, "missing weight array");
+    const size_t H = (size_t)h.units;
+    auto scaled = [&](const float* src, size_t rows) {
+        std::vector<float> v(rows * 4 * H);
+        for (size_t r = 0; r < rows; r++)
+            for (size_t c = 0; c < 4 * H; c++)
+                v[r * 4 * H + c] = src[r * 4 * H + c] * ((c / H) == 2 ? 32.0f : 16.0f);
+        return v;
+    };
     int rc;
-    if ((rc = upload(ctx, &d.kernel, h.kernel, (size_t)h.input_dim * 4 * h.units))) return rc;
-    if ((rc = upload(ctx, &d.recurrent, h.recurrent, (size_t)h.units * 4 * h.units))) return rc;
-    return upload(ctx, &d.bias, h.bias, (size_t)4 * h.units);
+    const std::vector<float> k = scaled(h.kernel, (size_t)h.input_dim);
+    const std::vector<float> u = scaled(h.recurrent, H);
+    const std::vector<float> b = scaled(h.bias, 1);
+    if ((rc = upload(ctx, &d.kernel, k.data(), k.size()))) return rc;
+    if ((rc = upload(ctx, &d.recurrent, u.data(), u.size()))) return rc;
+    return upload(ctx, &d.bias, b.data(), b.size());
 }
 
 static int upload_dense(pxg_ctx* ctx, const pxg_dense_layer& h, PxgDenseDev& d)

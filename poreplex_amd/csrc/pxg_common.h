@@ -42,6 +42,20 @@ __device__ __forceinline__ float pxg_sig_lookup(const float4* tab, float z, floa
     return __builtin_fmaf(p, s, c.x);
 }
 
+// Same lookup for an argument that already carries the table scale (u = 16 z for
+// a sigmoid, u = 32 x for tanh's inner sigmoid): the LSTM kernels fold the power
+// of two into the gate weights at upload (exact), see k_lstm.hip cell_update.
+__device__ __forceinline__ float pxg_sig_lookup_u(const float4* tab, float u)
+{
+    u = __builtin_amdgcn_fmed3f(u, -512.0f, 511.99997f);
+    const float fl = __builtin_floorf(u);
+    const float s = u - fl;
+    const float4 c = tab[(int)fl + PXG_SIG_HALF];
+    float p = __builtin_fmaf(c.w, s, c.z);
+    p = __builtin_fmaf(p, s, c.y);
+    return __builtin_fmaf(p, s, c.x);
+}
+
 __device__ __forceinline__ float pxg_sigmoid(const float4* tab, float x)
 {
     return pxg_sig_lookup(tab, x, 16.0f, -32.0f, 31.999998f);
