@@ -2,7 +2,10 @@
 // (a1, a5, a7, a8: signal_loader.py:233-264; pomegranate viterbi called at
 // signal_analyzer.py:352; run summary signal_analyzer.py:354-362).
 //
-// Layout: one wave = 8 reads x 8 state-lanes.  Per 64-step chunk
+// Layout: one block = 8 reads = 3 waves.  Wave 0 is 8 reads x 8 state-lanes and
+// runs the recurrence; waves 1-2 produce the emissions one 16-step chunk ahead
+// into a double-buffered LDS tile (measured: pooling 1.0 ms + densities 1.1 ms
+// were serialised with a 1.7 ms recurrence).  Per chunk
 //   (1) emission phase, all 64 lanes: lane (read, sub) pools 15 int16 samples
 //       (NumPy pairwise order), applies fl(fl(scale*x)+shift), evaluates the
 //       float64 log-densities of every state and parks them in LDS;
@@ -19,7 +22,8 @@
 #include "pxg_common.h"
 
 #define VIT_READS 8
-#define VIT_CHUNK 32
+#define VIT_CHUNK 16
+#define VIT_THREADS 192   // wave 0: recurrence; waves 1-2: emissions of the next chunk
 
 __device__ __forceinline__ double hmm_emission(const PxgHmmDev& H, int s, double x)
 {
@@ -94,43 +98,84 @@ __device__ __forceinline__ double dpp_shr_f64(double v, int k)
 // SPANS: bit k set = some edge goes from state s-k to state s (k >= 1);
 // NW: packed entry words in use = ceil(n_states / 2)
 template <bool RAW, unsigned SPANS, int NW>
-__global__ __launch_bounds__(64) void k_viterbi_ltr(
+__global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
     int64_t n_reads, PxgHmmDev H, const int16_t* __restrict__ raw, const float* __restrict__ sig,
     const int64_t* __restrict__ off, const pxg_calib* __restrict__ cal,
     const float* __restrict__ ss, int stride, int scan_pooled, int32_t* __restrict__ status,
     int32_t* __restrict__ segs, double* __restrict__ logp_out)
 {
-    __shared__ double em[VIT_READS * EM_STRIDE];
-    const int lane = threadIdx.x;
+    __shared__ double em[2][VIT_READS * EM_STRIDE];   // double buffer: producers run one chunk ahead
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
     const int rr = lane >> 3, s = lane & 7;
     const int64_t r = blockIdx.x * (int64_t)VIT_READS + rr;
     const int S = H.n_states;
     const bool valid_read = r < n_reads && (status == nullptr || status[r] == PXG_ST_OKAY);
 
     int T = 0;
-    int64_t base = 0;
-    double k = 0.0, offset = 0.0;
-    float scale = 1.0f, shift = 0.0f;
     if (valid_read) {
-        base = off[r];
         const int64_t len = off[r + 1] - off[r];
         const int64_t P = RAW ? len / stride : len;
         T = (int)(P < scan_pooled ? P : scan_pooled);
-        if (RAW) {
-            const pxg_calib c = cal[r];
-            k = c.range / c.digitisation;
-            offset = c.offset;
-            scale = ss[2 * r];
-            shift = ss[2 * r + 1];
-        }
     }
-    // longest read of this wave
+    // longest read of this block (every wave computes the same value)
     int Tmax = T;
     for (int d = 32; d >= 1; d >>= 1) {
         const int o = __shfl_xor(Tmax, d);
         Tmax = o > Tmax ? o : Tmax;
     }
+    const int n_chunks = (Tmax + VIT_CHUNK - 1) / VIT_CHUNK;
 
+    if (wv > 0) {
+        // ================= emission producers (waves 1 and 2) =====================
+        // lane -> (read, step) of a chunk: 2 waves x 64 lanes = 8 reads x 16 steps;
+        // consecutive lanes pool consecutive 15-sample blocks (coalesced)
+        const int item = (wv - 1) * 64 + lane;
+        const int prr = item / VIT_CHUNK, ptt = item % VIT_CHUNK;
+        const int64_t pr = blockIdx.x * (int64_t)VIT_READS + prr;
+        const bool pvalid = pr < n_reads && (status == nullptr || status[pr] == PXG_ST_OKAY);
+        int pT = 0;
+        int64_t base = 0;
+        double k = 0.0, offset = 0.0;
+        float scale = 1.0f, shift = 0.0f;
+        if (pvalid) {
+            base = off[pr];
+            const int64_t len = off[pr + 1] - off[pr];
+            const int64_t P = RAW ? len / stride : len;
+            pT = (int)(P < scan_pooled ? P : scan_pooled);
+            if (RAW) {
+                const pxg_calib c = cal[pr];
+                k = c.range / c.digitisation;
+                offset = c.offset;
+                scale = ss[2 * pr];
+                shift = ss[2 * pr + 1];
+            }
+        }
+        for (int c = 0; c <= n_chunks; c++) {
+            if (c < n_chunks) {
+                const int t = c * VIT_CHUNK + ptt;
+                if (t < pT) {
+                    float x;
+                    if (RAW) {
+                        float m = pxg_block_mean(raw + base + (int64_t)t * stride, stride, k, offset);
+                        float y = scale * m;
+                        x = y + shift;
+                    } else {
+                        x = sig[base + t];
+                    }
+                    const double xd = (double)x;
+                    double* dst = &em[c & 1][prr * EM_STRIDE + ptt * PXG_MAX_STATES];
+#pragma unroll
+                    for (int q = 0; q < PXG_MAX_STATES; q++)
+                        if (q < S) dst[q] = hmm_emission(H, q, xd);
+                }
+            }
+            __syncthreads();        // chunk c is published; chunk c-1 has been consumed
+        }
+        return;
+    }
+
+    // ===================== recurrence (wave 0) ====================================
     // per-lane edge table by SPAN: the source of span k is the lane k below.
     // lpk[k] = log P(state s-k -> s) (-inf if no such edge); prk[k] = position of
     // that source in pomegranate's name-sorted in-edge order (first maximum wins)
@@ -166,36 +211,16 @@ __global__ __launch_bounds__(64) void k_viterbi_ltr(
     double v = -__builtin_inf();
     unsigned ent[4] = { 0u, 0u, 0u, 0u };   // 16-bit entry step + 1 per state
 
+    __syncthreads();                // chunk 0 is in em[0]
     for (int c0 = 0; c0 < Tmax; c0 += VIT_CHUNK) {
-        // ---- emission phase ------------------------------------------------
-        __syncthreads();
-#pragma unroll 1
-        for (int p = 0; p < VIT_CHUNK / 8; p++) {
-            const int tt = p * 8 + s;          // here `s` is the sub-lane
-            const int t = c0 + tt;
-            if (t < T) {
-                float x;
-                if (RAW) {
-                    float m = pxg_block_mean(raw + base + (int64_t)t * stride, stride, k, offset);
-                    float y = scale * m;
-                    x = y + shift;
-                } else {
-                    x = sig[base + t];
-                }
-                const double xd = (double)x;
-#pragma unroll
-                for (int q = 0; q < PXG_MAX_STATES; q++)
-                    if (q < S) em[rr * EM_STRIDE + tt * PXG_MAX_STATES + q] = hmm_emission(H, q, xd);
-            }
-        }
-        __syncthreads();
+        const double* emc = em[(c0 / VIT_CHUNK) & 1];
         // ---- recurrence phase ---------------------------------------------
         const int tend = (Tmax - c0) < VIT_CHUNK ? (Tmax - c0) : VIT_CHUNK;
 #pragma unroll 1
         for (int tt = 0; tt < tend; tt++) {
             const int t = c0 + tt;
             const bool act = (t < T) && (s < S);
-            const double e = act ? em[rr * EM_STRIDE + tt * PXG_MAX_STATES + s] : 0.0;
+            const double e = act ? emc[rr * EM_STRIDE + tt * PXG_MAX_STATES + s] : 0.0;
             // v and the entry vectors of the lanes below, for the spans in use
             double vs[PXG_MAX_STATES];
             unsigned es[PXG_MAX_STATES][NW];
@@ -247,6 +272,7 @@ __global__ __launch_bounds__(64) void k_viterbi_ltr(
                     ent[w] = pxg_sel_u32(mmove, ent[w], (ne[w] & keep[w]) | (stamp & put[w]));
             }
         }
+        __syncthreads();            // this chunk is consumed; the next one is published
     }
 
     // ---- termination: first maximum of the last column in name-sorted order -
@@ -314,11 +340,11 @@ int pxg_launch_segment_raw(pxg_ctx* ctx, int64_t n, const int16_t* raw, const in
     const dim3 grid((unsigned)((n + VIT_READS - 1) / VIT_READS));
     const PxgHmmDev& H = ctx->hmm[0];
     if ((H.shift_mask & ~7u) == 0 && H.n_states <= 6)      // spans {1,2}: the shipped model
-        hipLaunchKernelGGL((k_viterbi_ltr<true, 0x6u, 3>), grid, dim3(64), 0, ctx->stream, n, H, raw,
+        hipLaunchKernelGGL((k_viterbi_ltr<true, 0x6u, 3>), grid, dim3(VIT_THREADS), 0, ctx->stream, n, H, raw,
                            (const float*)nullptr, off, cal, ss, ctx->cfg.stride, scan,
                            (int32_t*)status, segs, (double*)nullptr);
     else
-        hipLaunchKernelGGL((k_viterbi_ltr<true, 0xFEu, 4>), grid, dim3(64), 0, ctx->stream, n, H, raw,
+        hipLaunchKernelGGL((k_viterbi_ltr<true, 0xFEu, 4>), grid, dim3(VIT_THREADS), 0, ctx->stream, n, H, raw,
                            (const float*)nullptr, off, cal, ss, ctx->cfg.stride, scan,
                            (int32_t*)status, segs, (double*)nullptr);
     return PXG_OK;
@@ -333,11 +359,11 @@ int pxg_launch_viterbi_f32(pxg_ctx* ctx, int which, int64_t n, const float* sig,
     const dim3 grid((unsigned)((n + VIT_READS - 1) / VIT_READS));
     const PxgHmmDev& H = ctx->hmm[which];
     if ((H.shift_mask & ~7u) == 0 && H.n_states <= 6)
-        hipLaunchKernelGGL((k_viterbi_ltr<false, 0x6u, 3>), grid, dim3(64), 0, ctx->stream, n, H,
+        hipLaunchKernelGGL((k_viterbi_ltr<false, 0x6u, 3>), grid, dim3(VIT_THREADS), 0, ctx->stream, n, H,
                            (const int16_t*)nullptr, sig, off, (const pxg_calib*)nullptr,
                            (const float*)nullptr, 1, 65534, (int32_t*)nullptr, segs, logp);
     else
-        hipLaunchKernelGGL((k_viterbi_ltr<false, 0xFEu, 4>), grid, dim3(64), 0, ctx->stream, n, H,
+        hipLaunchKernelGGL((k_viterbi_ltr<false, 0xFEu, 4>), grid, dim3(VIT_THREADS), 0, ctx->stream, n, H,
                            (const int16_t*)nullptr, sig, off, (const pxg_calib*)nullptr,
                            (const float*)nullptr, 1, 65534, (int32_t*)nullptr, segs, logp);
     return PXG_OK;
