@@ -2,26 +2,30 @@
 // hook (a15).  Reference: poreplex/polya.py:50-187, src/csupport.c:70-124 ->
 // src/contrib/scrappie/event_detection.c:36-324.
 //
-// One LANE per read, PXG_PA_LANES reads per wave (the control flow is data
-// dependent, so narrow waves lose less to divergence and more of them hide the
-// serial latency): the peak detector is a sequential
-// two-detector state machine and the retry / recalibration logic is data
-// dependent, so reads are the parallel axis.  The event detector STREAMS: it
-// never materialises the filtered window, prefix sums or t-statistics --
-//   * 7 scaled samples slide through registers (median pre-filter, zero padded),
-//   * the float64 prefix sums live in a 64-deep LDS ring per lane (the two
-//     t-statistic windows need indices i-20 .. i+20 only); they are extended
+// 16 lanes per read, PXG_PA_LANES = 4 reads per wave.  Measured on the way here
+// (profiles/r01): with one lane per read the batch ran on 157 waves
+// (15 % of the SIMDs) and the per-sample cost -- six f64 divisions and two f64
+// square roots in the two t-statistics -- sat on a serial path; the data-dependent
+// FSM / retry / recalibration code diverges almost completely between reads, so
+// its cost grows with the reads per wave (16 reads/wave: 13.2 ms, 8: 9.1, 4: 7.4,
+// 2: 8.5, 1: 8.5-9.0).  So: the independent work (median pre-filter, t-statistics,
+// event-row and filtered-sample fetches) runs 16 lanes wide per read, everything
+// order-dependent (float64 prefix sums, peak FSM, interval search, NumPy pairwise
+// reductions, retry loop) is group-uniform: all 16 lanes of a read execute it with
+// identical values, lane 0 stores.
+//   * the float64 prefix sums live in a 128-deep LDS ring per read and are extended
 //     strictly sequentially, so they are bit-identical to scrappie's loop,
 //   * each detector remembers the prefix sums at its candidate peak, so an event
-//     is finished the moment its right boundary is emitted.
-// Events go to a wave-interleaved scratch arena ([event][lane], coalesced).
+//     is finished the moment its right boundary is emitted,
+//   * open-end retries (polya.py:81-85) resume from a snapshot of the detector
+//     taken at the last chunk that cannot see the window end.
+// Events go to a wave-interleaved scratch arena ([event][read slot]).
 // Everything downstream (interval DP, NumPy pairwise float32 reductions, the
 // open-end retry loop, recalibration, stdv QC) follows oracle/pxo_polya.c line
 // by line and is bit-exact with it; the oracle is pinned by the real polya.py.
 #include <float.h>
 #include "pxg_common.h"
 
-#define PA_RING 64
 
 struct PolyaParams {
     int stride, refinement_expansion, openend_expansion, median_pre_filter, max_ext;
@@ -97,14 +101,38 @@ __device__ __forceinline__ float filtered_at(const WindowSrc& S, int64_t j, int 
                    S.scaled(j + 2), S.scaled(j + 3));
 }
 
+// Per-read LDS workspace of the cooperative event detector (16 lanes per read)
+#ifndef PA_WAVES_PER_EU
+#define PA_WAVES_PER_EU 3        // 4 reads per wave: 10 000 reads = 2500 waves must be co-resident
+#endif
+#define PA_GL (64 / PXG_PA_LANES) // lanes per read
+#define PA_EVC 16                // event rows in the LDS chunk cache
+#define PA_PRE 128               // prefix-sum ring (needs i-31 .. i+31+16 around a 16-sample chunk)
+struct GroupLds {
+    double2 pre[PA_PRE];         // pre[k & 127] = (sum, sum of squares) of filtered samples [0, k)
+    float fbuf[PA_GL];           // filtered samples of the chunk being accumulated
+    float tb[2][PA_GL];          // t-statistics of the chunk being scanned
+    Ev evc[PA_EVC];              // consecutive event rows (chunk cache of the event passes)
+};
+
+// Resume point of the detector for open-end retries (polya.py:81-85: same window
+// start, longer window): the group-uniform registers at the start of the last
+// chunk whose inputs cannot see the window end; the prefix ring goes to HBM.
+struct GroupSnap {
+    int64_t ib, n, i0, filled;   // n: window length it was taken for (-1: none)
+    Detector det[2];
+    double cs, cq, prev_cs, prev_cq;
+    unsigned long long prev_pos;
+    int ne;
+};
+
 // t-statistic at i for window w from the prefix ring (event_detection.c:91-114)
-__device__ __forceinline__ float tstat_at(const double2* ring, int lane, int64_t i, int64_t w,
-                                          int64_t n)
+__device__ __forceinline__ float tstat_at(const double2* pre, int64_t i, int64_t w, int64_t n)
 {
     if (n < 2 * w || w < 2 || i < w || i > n - w) return 0.0f;
-    const double2 c0 = ring[((i - w) & (PA_RING - 1)) * PXG_PA_LANES + lane];
-    const double2 c1 = ring[(i & (PA_RING - 1)) * PXG_PA_LANES + lane];
-    const double2 c2 = ring[((i + w) & (PA_RING - 1)) * PXG_PA_LANES + lane];
+    const double2 c0 = pre[(i - w) & (PA_PRE - 1)];
+    const double2 c1 = pre[i & (PA_PRE - 1)];
+    const double2 c2 = pre[(i + w) & (PA_PRE - 1)];
     const float wf = (float)w;
     double s1 = c1.x, q1 = c1.y;
     if (i > w) {
@@ -139,116 +167,152 @@ __device__ __forceinline__ Ev make_event(unsigned long long b, unsigned long lon
     return ev;
 }
 
-// Resumable streaming state of detect_events for one lane.
-struct Stream {
-    Detector det[2];
-    double cs, cq;
-    int64_t filled;            // prefix indices [0, filled] are in the ring
-    int64_t i;                 // next sample the peak detector will visit
-    float x0, x1, x2, x3, x4, x5, x6;   // scaled samples filled-3 .. filled+3
-    int ne;
-    unsigned long long prev_pos;
-    double prev_cs, prev_cq;
-};
-
-__device__ __forceinline__ void stream_init(Stream& st, const WindowSrc& S, const PolyaParams& P,
-                                            double2* ring, int lane)
-{
-    st.det[0] = { P.thr1, (unsigned)P.w1, 0ull, -1, FLT_MAX, 0, 0.0, 0.0 };
-    st.det[1] = { P.thr2, (unsigned)P.w2, 0ull, -1, FLT_MAX, 0, 0.0, 0.0 };
-    st.cs = 0.0; st.cq = 0.0; st.filled = 0; st.i = 0;
-    st.x0 = st.x1 = st.x2 = 0.0f;
-    st.x3 = S.scaled(0); st.x4 = S.scaled(1); st.x5 = S.scaled(2); st.x6 = S.scaled(3);
-    st.ne = 0; st.prev_pos = 0; st.prev_cs = 0.0; st.prev_cq = 0.0;
-    ring[0 * PXG_PA_LANES + lane] = make_double2(0.0, 0.0);
-}
-
-// Streaming detect_events over the window S (event_detection.c:273-324);
-// returns the event count (>= 1); events beyond `cap` are counted, not stored.
-// When `snap` is given, the state at step n - PA_SAFE (everything before it is
-// independent of where the window ends: the median filter looks 3 samples
-// ahead, the t-statistics 20) is saved so that an open-end retry with a longer
-// window resumes there instead of starting over.
-#define PA_SAFE 28
-__device__ int detect_events_stream(Stream& st, const WindowSrc& S, const PolyaParams& P,
-                                    double2* ring, int lane, Ev* ev /* [cap][PXG_PA_LANES] */, int cap,
-                                    Stream* snap, double2* snap_ring /* [PA_RING][PXG_PA_LANES] */,
-                                    int64_t* snap_n)
+// detect_events over the window S (event_detection.c:273-324), one read per 16
+// lanes.  Per 16-sample chunk: (A) the lanes filter 16 samples in parallel, (B)
+// the float64 prefix sums are extended strictly in order (every lane of the
+// group runs the same 16 adds, so they stay bit-identical to scrappie's loop),
+// (C) the lanes evaluate the two t-statistics of 16 samples in parallel -- six
+// f64 divisions and two f64 square roots per sample, the bulk of the work --
+// (D) the two-detector peak FSM walks the 16 results.  Everything outside (A)
+// and (C) is group-uniform: all 16 lanes hold the same state.  Returns the event
+// count (>= 1); events beyond `cap` are counted, not stored.
+__device__ int detect_events_group(const WindowSrc& S, const PolyaParams& P, GroupLds* L, int gl, int grp,
+                                   Ev* ev /* [cap][PXG_PA_LANES] */, int cap,
+                                   GroupSnap* snap /* in: resume point or n < 0; out: new one */,
+                                   double2* snap_ring /* [PA_PRE], this read's */)
 {
     const int64_t n = S.W;
     const int mpf = P.median_pre_filter;
     const int64_t look = P.w1 > P.w2 ? P.w1 : P.w2;    // prefix look-ahead (<= 31)
-    const int64_t snap_at = n - PA_SAFE;
-    for (int64_t i = st.i; i < n; i++) {
-        if (snap && i == snap_at && i > 0) {
-            st.i = i;
-            *snap = st;
-            *snap_n = n;
-            for (int q = 0; q < PA_RING; q++) snap_ring[q * PXG_PA_LANES + lane] = ring[q * PXG_PA_LANES + lane];
+    Detector det[2];
+    det[0] = { P.thr1, (unsigned)P.w1, 0ull, -1, FLT_MAX, 0, 0.0, 0.0 };
+    det[1] = { P.thr2, (unsigned)P.w2, 0ull, -1, FLT_MAX, 0, 0.0, 0.0 };
+    double cs = 0.0, cq = 0.0;
+    int64_t filled = 0;
+    int ne = 0;
+    unsigned long long prev_pos = 0;
+    double prev_cs = 0.0, prev_cq = 0.0;
+    int64_t i_begin = 0;
+    if (snap && snap->n > 0 && snap->ib == S.ib && n > snap->n) {
+        // resume: everything before chunk snap->i0 is identical for the longer window
+        det[0] = snap->det[0]; det[1] = snap->det[1];
+        cs = snap->cs; cq = snap->cq; filled = snap->filled; ne = snap->ne;
+        prev_pos = snap->prev_pos; prev_cs = snap->prev_cs; prev_cq = snap->prev_cq;
+        i_begin = snap->i0;
+        for (int q = gl; q < PA_PRE; q += PA_GL) L->pre[q] = snap_ring[q];
+    } else if (gl == 0) {
+        L->pre[0] = make_double2(0.0, 0.0);
+    }
+    if (snap) snap->n = -1;
+    // last chunk start whose t-statistics (look-ahead <= 31), prefix sums (up to 15 more)
+    // and median filter (3 more) all stay inside this window
+    const int64_t snap_i0 = ((n - 51) / PA_GL) * PA_GL;
+    __builtin_amdgcn_wave_barrier();
+
+    for (int64_t i0 = i_begin; i0 < n; i0 += PA_GL) {
+        if (snap && i0 == snap_i0 && i0 > i_begin) {
+            snap->ib = S.ib; snap->n = n; snap->i0 = i0; snap->filled = filled;
+            snap->det[0] = det[0]; snap->det[1] = det[1];
+            snap->cs = cs; snap->cq = cq; snap->ne = ne;
+            snap->prev_pos = prev_pos; snap->prev_cs = prev_cs; snap->prev_cq = prev_cq;
+            for (int q = gl; q < PA_PRE; q += PA_GL) snap_ring[q] = L->pre[q];
         }
-        // extend the prefix sums to index min(i + look, n), strictly in order
-        const int64_t need = (i + look) < n ? (i + look) : n;
-        while (st.filled < need) {
-            const float f = mpf <= 1 ? st.x3 : median7(st.x0, st.x1, st.x2, st.x3, st.x4, st.x5, st.x6);
-            st.x0 = st.x1; st.x1 = st.x2; st.x2 = st.x3; st.x3 = st.x4; st.x4 = st.x5; st.x5 = st.x6;
-            st.x6 = S.scaled(st.filled + 4);
-            const float sq = f * f;
-            st.cs = st.cs + (double)f;
-            st.cq = st.cq + (double)sq;
-            st.filled++;
-            ring[(st.filled & (PA_RING - 1)) * PXG_PA_LANES + lane] = make_double2(st.cs, st.cq);
-        }
-        const double2 here = ring[(i & (PA_RING - 1)) * PXG_PA_LANES + lane];
+        // ---- (A)+(B): prefix sums up to index min(i0 + 15 + look, n) -----------------
+        const int64_t last = i0 + PA_GL - 1 + look;
+        const int64_t need = last < n ? last : n;
+        while (filled < need) {
+            const int64_t j = filled + gl;
+            float f = 0.0f;
+            if (j < n) {
+                f = mpf <= 1 ? S.scaled(j)
+                             : median7(S.scaled(j - 3), S.scaled(j - 2), S.scaled(j - 1), S.scaled(j),
+                                       S.scaled(j + 1), S.scaled(j + 2), S.scaled(j + 3));
+            }
+            L->fbuf[gl] = f;
+            __builtin_amdgcn_wave_barrier();
+            const int64_t m = (n - filled) < PA_GL ? (n - filled) : PA_GL;
 #pragma unroll
-        for (int d = 0; d < 2; d++) {
-            Detector& D = st.det[d];
-            if (D.masked_to >= (unsigned long long)i) continue;
-            const float cur = tstat_at(ring, lane, i, D.window, n);
-            if (D.peak_pos == -1) {
-                if (cur < D.peak_val) {
-                    D.peak_val = cur;
-                } else if (cur - D.peak_val > P.peak_height) {
-                    D.peak_val = cur;
-                    D.peak_pos = (int)i;
-                    D.pk_cs = here.x;
-                    D.pk_cq = here.y;
+            for (int q = 0; q < PA_GL; q++) {
+                if (q < m) {
+                    const float fq = L->fbuf[q];
+                    const float sq = fq * fq;
+                    cs = cs + (double)fq;
+                    cq = cq + (double)sq;
+                    if (gl == 0) L->pre[(filled + 1 + q) & (PA_PRE - 1)] = make_double2(cs, cq);
                 }
-            } else {
-                if (cur > D.peak_val) {
-                    D.peak_val = cur;
-                    D.peak_pos = (int)i;
-                    D.pk_cs = here.x;
-                    D.pk_cq = here.y;
-                }
-                if (d == 0 && D.peak_val > D.threshold) {
-                    st.det[1].masked_to = (unsigned long long)D.peak_pos + D.window;
-                    st.det[1].peak_pos = -1;
-                    st.det[1].peak_val = FLT_MAX;
-                    st.det[1].valid = 0;
-                }
-                if (D.peak_val - cur > P.peak_height && D.peak_val > D.threshold) D.valid = 1;
-                if (D.valid && ((unsigned long long)i - (unsigned long long)D.peak_pos) > D.window / 2) {
-                    const unsigned long long p = (unsigned long long)D.peak_pos;
-                    if (st.ne < cap)
-                        ev[(size_t)st.ne * PXG_PA_LANES + lane] = make_event(st.prev_pos, p, st.prev_cs, st.prev_cq, D.pk_cs, D.pk_cq);
-                    st.ne++;
-                    st.prev_pos = p;
-                    st.prev_cs = D.pk_cs;
-                    st.prev_cq = D.pk_cq;
-                    D.peak_pos = -1;
-                    D.peak_val = cur;
-                    D.valid = 0;
+            }
+            filled += m;
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- (C): the two t-statistics of sample i0 + gl ---------------------------------
+        {
+            const int64_t i = i0 + gl;
+            float t1 = 0.0f, t2 = 0.0f;
+            if (i < n) {
+                t1 = tstat_at(L->pre, i, det[0].window, n);
+                t2 = tstat_at(L->pre, i, det[1].window, n);
+            }
+            L->tb[0][gl] = t1;
+            L->tb[1][gl] = t2;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- (D): peak FSM over the chunk (group-uniform) ----------------------------------
+        const int jn = (n - i0) < PA_GL ? (int)(n - i0) : PA_GL;
+#pragma unroll 1
+        for (int jj = 0; jj < jn; jj++) {
+            const int64_t i = i0 + jj;
+            const double2 here = L->pre[i & (PA_PRE - 1)];
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                Detector& D = det[d];
+                if (D.masked_to >= (unsigned long long)i) continue;
+                const float cur = L->tb[d][jj];
+                if (D.peak_pos == -1) {
+                    if (cur < D.peak_val) {
+                        D.peak_val = cur;
+                    } else if (cur - D.peak_val > P.peak_height) {
+                        D.peak_val = cur;
+                        D.peak_pos = (int)i;
+                        D.pk_cs = here.x;
+                        D.pk_cq = here.y;
+                    }
+                } else {
+                    if (cur > D.peak_val) {
+                        D.peak_val = cur;
+                        D.peak_pos = (int)i;
+                        D.pk_cs = here.x;
+                        D.pk_cq = here.y;
+                    }
+                    if (d == 0 && D.peak_val > D.threshold) {
+                        det[1].masked_to = (unsigned long long)D.peak_pos + D.window;
+                        det[1].peak_pos = -1;
+                        det[1].peak_val = FLT_MAX;
+                        det[1].valid = 0;
+                    }
+                    if (D.peak_val - cur > P.peak_height && D.peak_val > D.threshold) D.valid = 1;
+                    if (D.valid && ((unsigned long long)i - (unsigned long long)D.peak_pos) > D.window / 2) {
+                        const unsigned long long p = (unsigned long long)D.peak_pos;
+                        if (ne < cap && gl == 0)
+                            ev[(size_t)ne * PXG_PA_LANES + grp] = make_event(prev_pos, p, prev_cs, prev_cq, D.pk_cs, D.pk_cq);
+                        ne++;
+                        prev_pos = p;
+                        prev_cs = D.pk_cs;
+                        prev_cq = D.pk_cq;
+                        D.peak_pos = -1;
+                        D.peak_val = cur;
+                        D.valid = 0;
+                    }
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
-    st.i = n;
     // last event [prev, n); with no peak at all scrappie emits the single
     // zero-length event [0, peaks[0] = 0)  (event_detection.c:261-268)
-    int ne = st.ne;
-    if (ne < cap)
-        ev[(size_t)ne * PXG_PA_LANES + lane] = ne > 0 ? make_event(st.prev_pos, (unsigned long long)n, st.prev_cs, st.prev_cq, st.cs, st.cq)
-                                            : make_event(0, 0, 0.0, 0.0, 0.0, 0.0);
+    if (ne < cap && gl == 0)
+        ev[(size_t)ne * PXG_PA_LANES + grp] = ne > 0 ? make_event(prev_pos, (unsigned long long)n, prev_cs, prev_cq, cs, cq)
+                                                    : make_event(0, 0, 0.0, 0.0, 0.0, 0.0);
+    __threadfence_block();        // the group's event rows before any lane of it reads them
     return ne + 1;
 }
 
@@ -328,24 +392,24 @@ __device__ __forceinline__ int nth_matching(const Pred& pred, int lo, int hi, in
     return c.q;
 }
 
-// filtered sample j through a sliding 7-sample register window: one pA
-// conversion per step when j advances by one (the QC reductions do)
-struct FiltCursor {
-    int64_t j;
-    float x0, x1, x2, x3, x4, x5, x6;
+// filtered sample j for the group-uniform reductions: the 16 lanes of a read
+// filter one aligned 16-sample chunk in parallel into LDS, the (sequential,
+// NumPy-ordered) reduction then reads it back; np_sum_f32 visits indices in
+// increasing order, so every chunk is built once.
+struct FiltCache {
+    int64_t c0;                  // first sample of the chunk held in L->fbuf, -1: none
 };
-__device__ __forceinline__ float filtered_seq(const WindowSrc& S, int mpf, int64_t j, FiltCursor& c)
+__device__ __forceinline__ float filtered_seq(const WindowSrc& S, int mpf, int64_t j, FiltCache& c,
+                                              GroupLds* L, int gl)
 {
-    if (mpf <= 1) return S.scaled(j);
-    if (j == c.j + 1) {
-        c.x0 = c.x1; c.x1 = c.x2; c.x2 = c.x3; c.x3 = c.x4; c.x4 = c.x5; c.x5 = c.x6;
-        c.x6 = S.scaled(j + 3);
-    } else if (j != c.j) {
-        c.x0 = S.scaled(j - 3); c.x1 = S.scaled(j - 2); c.x2 = S.scaled(j - 1); c.x3 = S.scaled(j);
-        c.x4 = S.scaled(j + 1); c.x5 = S.scaled(j + 2); c.x6 = S.scaled(j + 3);
+    const int64_t cb = j & ~(int64_t)(PA_GL - 1);
+    if (cb != c.c0) {                      // group-uniform
+        __builtin_amdgcn_wave_barrier();
+        L->fbuf[gl] = filtered_at(S, cb + gl, mpf);
+        __builtin_amdgcn_wave_barrier();
+        c.c0 = cb;
     }
-    c.j = j;
-    return median7(c.x0, c.x1, c.x2, c.x3, c.x4, c.x5, c.x6);
+    return L->fbuf[j & (PA_GL - 1)];
 }
 
 // ---------------------------------------------------------------------------
@@ -359,8 +423,8 @@ struct PolyaOut {
 
 __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t n_full, double k,
                                double offset, float scale, float shift, int rough_begin,
-                               int rough_end, int has_end0, double2* ring, int lane, Ev* ev,
-                               double2* snap_ring, PolyaOut& out, pxg_polya_spike* spikes)
+                               int rough_end, int has_end0, GroupLds* L, int gl, int lane /* read slot of the wave */,
+                               Ev* ev, double2* snap_ring, PolyaOut& out, pxg_polya_spike* spikes)
 {
     out.called = 0; out.n_spikes = 0; out.dwell = 0; out.begin = 0; out.end = 0;
     const int stride = P.stride;
@@ -376,13 +440,25 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
     S.raw = raw; S.sig = nullptr; S.k = k; S.offset = offset; S.scale = scale; S.shift = shift;
     S.ib = 0; S.W = 0;
     int ne = 0;
-    Stream st, snap;
-    int64_t snap_n = -1;           // window length the snapshot was taken for (-1: none)
+    GroupSnap snap;
+    snap.n = -1;
     int64_t ib = 0, ie = 0, adapter_end = 0;
     float flo = 0.0f, fhi = 0.0f;          // float32-rounded poly(A) mean range in force
     const int cap = P.ev_cap;
 
-    auto ev_at = [&](int q) -> Ev { return ev[(size_t)q * PXG_PA_LANES + lane]; };
+    // event rows through a 16-row LDS chunk (one coalesced fetch by the 16 lanes
+    // instead of a dependent global load per event and pass)
+    int evc0 = -1;
+    auto ev_at = [&](int q) -> Ev {
+        const int cb = q & ~(PA_EVC - 1);
+        if (cb != evc0) {                       // group-uniform
+            __builtin_amdgcn_wave_barrier();
+            for (int k = gl; k < PA_EVC; k += PA_GL) L->evc[k] = ev[(size_t)(cb + k) * PXG_PA_LANES + lane];
+            __builtin_amdgcn_wave_barrier();
+            evc0 = cb;
+        }
+        return L->evc[q & (PA_EVC - 1)];
+    };
     auto is_polya = [&](int q) -> bool { const float m = ev_at(q).mean; return m >= flo && m <= fhi; };
     auto ev_end = [&](int q) -> int64_t {
         const Ev e = ev_at(q);
@@ -399,16 +475,8 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
             adapter_end = (int64_t)rb * stride - ib;
             if (ie - ib <= 0) { state = DONE; break; }
             S.ib = ib; S.W = ie - ib;
-            if (snap_n > 0 && S.W > snap_n) {
-                // open-end retry: same window start, longer window -> resume the
-                // detector where the shorter window stopped being final
-                st = snap;
-                for (int q = 0; q < PA_RING; q++) ring[q * PXG_PA_LANES + lane] = snap_ring[q * PXG_PA_LANES + lane];
-            } else {
-                stream_init(st, S, P, ring, lane);
-            }
-            snap_n = -1;
-            ne = detect_events_stream(st, S, P, ring, lane, ev, cap, &snap, snap_ring, &snap_n);
+            ne = detect_events_group(S, P, L, gl, lane, ev, cap, &snap, snap_ring);
+            evc0 = -1;
             if (ne > cap) { state = DONE; break; }         // scratch overflow: not called
             if (has_range) { flo = (float)rlo; fhi = (float)rhi; }
             else { flo = (float)(P.mean_loc - half); fhi = (float)(P.mean_loc + half); }
@@ -503,21 +571,21 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
             for (int q = pi; q <= pj; q++)
                 if (ev_at(q).length > ev_at(lk).length) lk = q;
             const Ev le = ev_at(lk);
-            const int64_t L = (int64_t)le.length;
-            const int64_t b = (int64_t)((double)le.start + (double)L * P.stdv_lo);
-            const int64_t e = (int64_t)((double)le.start + (double)L * P.stdv_hi);
+            const int64_t Llen = (int64_t)le.length;
+            const int64_t b = (int64_t)((double)le.start + (double)Llen * P.stdv_lo);
+            const int64_t e = (int64_t)((double)le.start + (double)Llen * P.stdv_hi);
             bool qc_ok = false;
             if (e - b > 2) {
                 const int64_t bb = b < 0 ? 0 : b, ee = e > S.W ? S.W : e;
                 if (ee > bb) {
                     const int64_t cnt = ee - bb;
                     const int mpf = P.median_pre_filter;
-                    FiltCursor fc;
-                    fc.j = -100;
-                    auto fv = [&](int64_t q) -> float { return filtered_seq(S, mpf, bb + q, fc); };
+                    FiltCache fc;
+                    fc.c0 = -1;
+                    auto fv = [&](int64_t q) -> float { return filtered_seq(S, mpf, bb + q, fc, L, gl); };
                     const float mean = np_sum_f32(fv, cnt) / (float)cnt;
-                    fc.j = -100;
-                    auto dv = [&](int64_t q) -> float { const float x = filtered_seq(S, mpf, bb + q, fc) - mean; return x * x; };
+                    fc.c0 = -1;
+                    auto dv = [&](int64_t q) -> float { const float x = filtered_seq(S, mpf, bb + q, fc, L, gl) - mean; return x * x; };
                     const float ss = np_sum_f32(dv, cnt);
                     const float sd = sqrtf(ss / (float)cnt);
                     qc_ok = (double)sd < P.stdv_max;
@@ -540,11 +608,16 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
                 int ns = 0;
                 for (int q = pi; q <= pj; q++) {
                     if (!is_polya(q)) {
-                        if (ns < PXG_MAX_SPIKES && spikes) {
-                            spikes[ns].v[0] = ev_at(q).length;
-                            spikes[ns].v[1] = q - 1 >= pi ? ev_at(q - 1).mean : __builtin_nanf("");
-                            spikes[ns].v[2] = ev_at(q).mean;
-                            spikes[ns].v[3] = q + 1 <= pj ? ev_at(q + 1).mean : __builtin_nanf("");
+                        if (ns < PXG_MAX_SPIKES) {
+                            // the event fetches are group-uniform (all 16 lanes), the store is lane 0's
+                            const float s0 = ev_at(q).length;
+                            const float s1 = q - 1 >= pi ? ev_at(q - 1).mean : __builtin_nanf("");
+                            const float s2 = ev_at(q).mean;
+                            const float s3 = q + 1 <= pj ? ev_at(q + 1).mean : __builtin_nanf("");
+                            if (spikes) {
+                                spikes[ns].v[0] = s0; spikes[ns].v[1] = s1;
+                                spikes[ns].v[2] = s2; spikes[ns].v[3] = s3;
+                            }
                         }
                         ns++;
                     }
@@ -600,7 +673,7 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
 }
 
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_polya(int64_t n_reads, PolyaParams P,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PA_WAVES_PER_EU, 8))) void k_polya(int64_t n_reads, PolyaParams P,
                                               const int16_t* __restrict__ raw,
                                               const int64_t* __restrict__ off,
                                               const pxg_calib* __restrict__ cal,
@@ -611,13 +684,14 @@ __global__ __launch_bounds__(64) void k_polya(int64_t n_reads, PolyaParams P,
                                               int32_t* __restrict__ pout /* n x 8 */,
                                               pxg_polya_spike* __restrict__ spikes)
 {
-    __shared__ double2 ring[PA_RING * PXG_PA_LANES];
-    const int lane = threadIdx.x;
-    const int64_t r = blockIdx.x * (int64_t)PXG_PA_LANES + lane;
-    if (lane >= PXG_PA_LANES || r >= n_reads) return;
+    __shared__ GroupLds lds[PXG_PA_LANES];
+    const int grp = threadIdx.x / PA_GL, gl = threadIdx.x % PA_GL;     // read slot, lane inside it
+    const int64_t r = blockIdx.x * (int64_t)PXG_PA_LANES + grp;
+    if (r >= n_reads) return;
     int32_t* po = pout + r * 8;
-    for (int q = 0; q < 8; q++) po[q] = 0;
-    pxg_polya_spike* sp = spikes + r * PXG_MAX_SPIKES;
+    if (gl == 0)
+        for (int q = 0; q < 8; q++) po[q] = 0;
+    pxg_polya_spike* sp = gl == 0 ? spikes + r * PXG_MAX_SPIKES : nullptr;
     if (status[r] != PXG_ST_OKAY) return;
     const int32_t* first = segs + r * 2 * PXG_N_SEGMENTS;
     const int32_t* last = first + PXG_N_SEGMENTS;
@@ -631,9 +705,10 @@ __global__ __launch_bounds__(64) void k_polya(int64_t n_reads, PolyaParams P,
     const pxg_calib c = cal[r];
     PolyaOut out;
     Ev* ev = evbuf + (size_t)blockIdx.x * P.ev_cap * PXG_PA_LANES;
-    double2* snap_ring = snapbuf + (size_t)blockIdx.x * PA_RING * PXG_PA_LANES;
     polya_one_read(P, raw + off[r], off[r + 1] - off[r], c.range / c.digitisation, c.offset,
-                   ss[2 * r], ss[2 * r + 1], rb, re, has_end, ring, lane, ev, snap_ring, out, sp);
+                   ss[2 * r], ss[2 * r + 1], rb, re, has_end, &lds[grp], gl, grp, ev,
+                   snapbuf + ((size_t)blockIdx.x * PXG_PA_LANES + grp) * PA_PRE, out, sp);
+    if (gl != 0) return;
     po[0] = out.called;
     po[1] = out.n_spikes;
     po[2] = out.dwell;
@@ -650,18 +725,17 @@ __global__ __launch_bounds__(64) void k_detect_events(int64_t n_windows, PolyaPa
                                                       Ev* __restrict__ evbuf,
                                                       int64_t* __restrict__ n_events)
 {
-    __shared__ double2 ring[PA_RING * PXG_PA_LANES];
-    const int lane = threadIdx.x;
-    const int64_t r = blockIdx.x * (int64_t)PXG_PA_LANES + lane;
-    if (lane >= PXG_PA_LANES || r >= n_windows) return;
+    __shared__ GroupLds lds[PXG_PA_LANES];
+    const int grp = threadIdx.x / PA_GL, gl = threadIdx.x % PA_GL;
+    const int64_t r = blockIdx.x * (int64_t)PXG_PA_LANES + grp;
+    if (r >= n_windows) return;
     WindowSrc S;
     S.raw = nullptr; S.sig = sig + off[r]; S.ib = 0; S.W = off[r + 1] - off[r];
     S.k = 0; S.offset = 0; S.scale = 1; S.shift = 0;
-    if (S.W <= 0) { n_events[r] = 0; return; }
+    if (S.W <= 0) { if (gl == 0) n_events[r] = 0; return; }
     Ev* ev = evbuf + (size_t)blockIdx.x * P.ev_cap * PXG_PA_LANES;
-    Stream st;
-    stream_init(st, S, P, ring, lane);
-    n_events[r] = detect_events_stream(st, S, P, ring, lane, ev, P.ev_cap, nullptr, nullptr, nullptr);
+    const int ne = detect_events_group(S, P, &lds[grp], gl, grp, ev, P.ev_cap, nullptr, nullptr);
+    if (gl == 0) n_events[r] = ne;
 }
 
 static PolyaParams make_params(const pxg_config& c, int ev_cap, int mpf)
@@ -710,7 +784,7 @@ int pxg_launch_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t*
     if (rc) return rc;
     const int64_t blocks = (n + PXG_PA_LANES - 1) / PXG_PA_LANES;
     const size_t ev_bytes = (size_t)blocks * PA_EV_CAP * PXG_PA_LANES * sizeof(Ev);
-    const size_t snap_bytes = (size_t)blocks * PA_RING * PXG_PA_LANES * sizeof(double2);
+    const size_t snap_bytes = (size_t)blocks * PXG_PA_LANES * PA_PRE * sizeof(double2);
     if ((rc = pxg_reserve(ctx, ctx->polya_ev, ev_bytes + snap_bytes))) return rc;
     const PolyaParams P = make_params(ctx->cfg, PA_EV_CAP, ctx->cfg.polya_median_pre_filter);
     hipLaunchKernelGGL(k_polya, dim3((unsigned)blocks), dim3(64), 0, ctx->stream, n, P, raw, off, cal,

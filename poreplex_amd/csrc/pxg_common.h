@@ -296,7 +296,7 @@ int pxg_launch_detect_events(pxg_ctx* ctx, int64_t n, const float* sig, const in
                              int64_t cap, void* evbuf, int64_t* n_events);
 
 #ifndef PXG_PA_LANES
-#define PXG_PA_LANES 16   // reads per wave in k_polya / k_detect_events
+#define PXG_PA_LANES 4    // reads per wave in k_polya / k_detect_events (16 lanes each)
 #endif
 
 // K7: Guppy event means + pseudo-fusion window scan (k_unsplit.hip)
