@@ -55,12 +55,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     dist = None
-    if world > 1:
+    # PXG_BENCH_FORCE_DIST=1 takes the multi-rank path (torch + RCCL initialised before the
+    # HIP library, collectives issued) with a single rank: the way the N>1 path is validated
+    # on a 1-GPU box
+    force_dist = os.environ.get('PXG_BENCH_FORCE_DIST') == '1'
+    if world > 1 or force_dist:
         import torch
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=torch.device('cuda', local_rank))
     if args.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world), file=sys.stderr)
 
@@ -98,21 +105,27 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    from poreplex_amd.distributed import gather_labels
+    from poreplex_amd.distributed import gather_labels, gather_labels_start
+    shard_sizes = [args.reads] * world          # static sharding: every rank owns args.reads reads
     for _ in range(args.warmup):
         step()
         res = ctx.download()
-        gather_labels(res, dist)
+        gather_labels(res, dist, sizes=shard_sizes, force=force_dist)
     barrier()
     stage_acc = {k: 0.0 for k in N.TIMER_NAMES}
     t0 = time.perf_counter()
+    pending = None
     for _ in range(args.steps):
         step()
+        if pending is not None:          # last step's labels arrive while this step runs
+            labels = pending()
         res = ctx.download()             # D2H of the result records is part of a step
-        labels = gather_labels(res, dist)   # RCCL all-gather of label records (N>1)
+        # RCCL all-gather of the label records (N>1), asynchronous on RCCL's stream
+        pending = gather_labels_start(res, dist, sizes=shard_sizes, force=force_dist)
         times, _ = ctx.stage_times()
         for k in stage_acc:
             stage_acc[k] += times[k]
+    labels = pending()
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:

@@ -65,28 +65,47 @@ def _device_for(dist):
         if dist.get_backend() == 'nccl' else torch.device('cpu')
 
 
-def gather_labels(results, dist=None, first_index=0):
-    """All-gather the label records of every rank (ragged shards are padded to
-    the largest shard).  dist=None or world 1: local records only."""
+def gather_labels_start(results, dist=None, first_index=0, sizes=None, force=False):
+    """Launch the all-gather of the label records of every rank (ragged shards
+    are padded to the largest shard) and return ``finish() -> records``.  The
+    collective runs asynchronously on RCCL's stream, so a caller can start the
+    next batch on the GPU and collect the labels afterwards.  dist=None or world
+    1: local records only (unless `force`, which tests use to drive the
+    collective on a single GPU).  `sizes`: the per-rank shard sizes when the
+    caller already knows them (static sharding) -- saves the size exchange and
+    its host synchronisation."""
     rec = label_records(results, first_index)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return rec
+    if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
+        return lambda: rec
     import torch
     world = dist.get_world_size()
     dev = _device_for(dist)
-    n_local = torch.tensor([len(rec)], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, n_local)
-    sizes = [int(s.item()) for s in sizes]
+    if sizes is None:
+        n_local = torch.tensor([len(rec)], dtype=torch.int64, device=dev)
+        gathered = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(gathered, n_local)
+        sizes = [int(s.item()) for s in gathered]
+    elif len(sizes) != world or sizes[dist.get_rank()] != len(rec):
+        raise ValueError('sizes must list every rank\'s shard size')
     nmax = max(sizes)
     buf = np.zeros(nmax, dtype=LABEL_DTYPE)
     buf[:len(rec)] = rec
     mine = torch.from_numpy(buf.view(np.uint8).reshape(nmax, LABEL_DTYPE.itemsize)).to(dev)
     out = torch.empty((world * nmax, LABEL_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(out, mine)
-    allrec = out.cpu().numpy().reshape(world, nmax * LABEL_DTYPE.itemsize)
-    parts = [np.frombuffer(allrec[r].tobytes(), dtype=LABEL_DTYPE)[:sizes[r]] for r in range(world)]
-    return np.concatenate(parts)
+    work = dist.all_gather_into_tensor(out, mine, async_op=True)
+
+    def finish():
+        work.wait()
+        allrec = out.cpu().numpy().reshape(world, nmax * LABEL_DTYPE.itemsize)
+        parts = [np.frombuffer(allrec[r].tobytes(), dtype=LABEL_DTYPE)[:sizes[r]]
+                 for r in range(world)]
+        return np.concatenate(parts)
+    return finish
+
+
+def gather_labels(results, dist=None, first_index=0, sizes=None, force=False):
+    """Blocking form of gather_labels_start."""
+    return gather_labels_start(results, dist, first_index, sizes, force)()
 
 
 def reduce_counts(records, dist=None):

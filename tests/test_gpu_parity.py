@@ -369,3 +369,17 @@ def test_unsplit_scan_synthetic_vs_oracle(ctx, oracle, config):
         assert iv[i, :min(c, N.PXG_MAX_UNSPLIT)].tolist() == want.tolist(), i
         n_cand += c
     assert n_cand >= 8
+
+
+def test_label_all_gather_over_rccl_single_rank():
+    """The N>1 bookkeeping collectives (RCCL all-gather of label records, all-reduce
+    of the count table) driven on this one GPU: world 1, device tensors, nccl --
+    in a fresh process that brings torch/RCCL up BEFORE libpxg.so, the order
+    bench.py uses for N>1 (both then share one HIP runtime)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29617', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    out = subprocess.run([sys.executable, os.path.join(root, 'tests', 'rccl_single_rank.py')],
+                         env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'RCCL-SINGLE-RANK-OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
