@@ -160,13 +160,13 @@ def main():
                     'peak': PEAK_HBM / 1e9, 'unit': 'GB/s', 'frac': nbytes / dur / PEAK_HBM,
                     'traffic': None, 'algorithmic_bytes_per_read': nbytes / args.reads}
     # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes
-    # (profiles/r01/e_hbm_traffic.json, collected with tools/prof.sh on this exact
+    # (profiles/r01/f_final_hbm_traffic.json, collected with tools/prof.sh on this exact
     # default workload); None for any other workload size
     if args.reads == 10000 and args.samples == 60000 and args.seed == 924:
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01', 'e_hbm_traffic.json')) as fh:
+            with open(os.path.join(ROOT, 'profiles', 'r01', 'f_final_hbm_traffic.json')) as fh:
                 roofline['traffic'] = json.load(fh)['kernels'][roofline['kernel']]['hbm_bytes']
-            roofline['traffic_source'] = 'profiles/r01/e_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)'
+            roofline['traffic_source'] = 'profiles/r01/f_final_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)'
         except (OSError, KeyError):
             pass
     # secondary figures for DESIGN.md (not part of the contract)
