@@ -383,3 +383,41 @@ def test_label_all_gather_over_rccl_single_rank():
     out = subprocess.run([sys.executable, os.path.join(root, 'tests', 'rccl_single_rank.py')],
                          env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and 'RCCL-SINGLE-RANK-OK' in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_custom_left_to_right_hmm_generic_kernel(config, bundle):
+    """A 7-state model with skip edges of span 3 and 4, a 3-component mixture and two
+    start states: takes the generic K3 template (not the shipped-model fast path);
+    whole batches and the pooled-signal hook against an oracle built from the same
+    config."""
+    import copy
+    from oracle.pxo import Oracle
+    cfg = copy.deepcopy(config)
+    m = cfg['segmentation_model']
+    names = [st['name'] for st in m]
+    m.insert(3, {'name': 'stall', 'emission': [[90.0, 6.0, 0.5], [120.0, 9.0, 0.3], [60.0, 4.0, 0.2]],
+                 'transition': [['stall', 0.9], ['adapter', 0.1]]})
+    m[0]['start_prob'], m[1]['start_prob'] = 0.7, 0.3
+    m[0]['transition'] = [['pre-leader', 0.9], ['leader-low', 0.05], ['stall', 0.03], ['adapter', 0.02]]
+    m[2]['transition'] = [['leader-high', 0.98], ['stall', 0.01], ['adapter', 0.01]]
+    assert [st['name'] for st in m] == names[:3] + ['stall'] + names[3:]
+    orc = Oracle(cfg)
+    c = N.NativeContext(cfg, device_id=0)
+    try:
+        want = orc.process_batch(bundle['arena'], bundle['offsets'], bundle['calib'])
+        got = c.process_batch(bundle['arena'], bundle['offsets'], bundle['calib'])
+        assert_records_equal(got, want)
+        assert (got['status'] == 0).sum() >= 10
+        sb = synth_batch(64, seed=515, samples_per_read=12000, jitter=0.4)
+        want = orc.process_batch(sb['arena'], sb['offsets'], sb['calib'])
+        got = c.process_batch(sb['arena'], sb['offsets'], sb['calib'])
+        assert_records_equal(got, want)
+        rng = np.random.default_rng(8)
+        sigs = [rng.choice([71.5, 102, 112, 90, 80, 109, 95], n).astype(np.float32) +
+                rng.normal(0, 3, n).astype(np.float32) for n in (1, 7, 40, 333, 2000)]
+        first, last, paths, logp = c.viterbi(sigs, want_path=True)
+        for k, sg in enumerate(sigs):
+            olp, opath = orc.viterbi(sg)
+            assert np.array_equal(paths[k], opath), k
+    finally:
+        c.close()
