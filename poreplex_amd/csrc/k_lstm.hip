@@ -316,6 +316,198 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
 }
 
 // ===========================================================================
+// K2q: the same scaler network, TIME-SLICED.  With 512 < tiles < 1024 the static
+// split leaves 3 or 4 tiles on some CUs and 2 on the others (10 000 reads: 625 tiles
+// on 256 CUs -> 81 % busy; measured 13.3 ms static, 10.8 ms time-sliced).  Here every workgroup (2 per CU, all resident) pulls
+// (step block, tile) tasks from a queue; a tile's LSTM state travels through HBM
+// between blocks (12.8 KB), so the tiles advance round-robin on the 2 x #CU slots and
+// the launch ends when the WORK runs out, not when the fullest CU does.  Tasks are
+// ordered block-major, so the predecessor of a task was taken n_tiles tasks earlier;
+// its completion is still checked through a per-tile counter (release/acquire at
+// agent scope: the L2s of the 8 XCDs are not coherent with each other).  The step
+// body is k_scaler_lstm<1>'s, results are bit-identical.
+// ===========================================================================
+#define QBS 256                 // steps per task (multiple of XCH)
+#define QSTATE (2 * 16 * HSTRIDE(48) + 2 * LSTM_THREADS * 3)    // floats per saved tile state
+
+__global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q(
+    int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int T,
+    const float* __restrict__ head, const float* __restrict__ sigtab,
+    const float* __restrict__ W1, const float* __restrict__ U1, const float* __restrict__ b1,
+    const float* __restrict__ W2, const float* __restrict__ U2, const float* __restrict__ b2,
+    const float* __restrict__ Wd, const float* __restrict__ bd, float* __restrict__ pred,
+    int* __restrict__ queue /* [0] next task */, int* __restrict__ errflag, int* __restrict__ done /* per tile */,
+    float* __restrict__ state /* [block][tile][QSTATE] */)
+{
+    constexpr int H = 48, NT = 3, KB = 12, HS = HSTRIDE(H);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lim = count ? min(*count, n_rows) : n_rows;
+    const int n_tiles = (lim + 15) >> 4;
+    const int n_blocks = (T + 1 + QBS - 1) / QBS;
+    const int n_tasks = n_tiles * n_blocks;
+
+    float4* tab = reinterpret_cast<float4*>(smem);     // [1024] sigmoid spline
+    float* h1 = smem + 4 * PXG_SIG_NSEG;               // [2][16][HS]
+    float* h2 = h1 + 2 * 16 * HS;                      // [2][16][HS]
+    float* xb = h2 + 2 * 16 * HS;                      // [16][XS]
+    int* ridx = reinterpret_cast<int*>(xb + 16 * XS);  // [16]
+    int* s_task = ridx + 16;
+
+    const int tid = threadIdx.x, lane = tid & 63, slice = tid >> 6;
+    const int rd_l = lane & 15, ul = lane >> 4;
+
+    load_sigtab(tab, sigtab, tid);
+    float wA[NT][KB], wB[NT][2 * KB], bias1[NT][4], bias2[NT][4], wx[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int unit0 = slice * 12 + nt * 4;
+        load_wfrag<H, KB>(wA[nt], U1, 0, unit0, lane);
+        float tmp[KB];
+        load_wfrag<H, KB>(tmp, W2, 0, unit0, lane);
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++) wB[nt][kb] = tmp[kb];
+        load_wfrag<H, KB>(tmp, U2, 0, unit0, lane);
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++) wB[nt][KB + kb] = tmp[kb];
+        load_gate4<H>(bias1[nt], b1, unit0, lane);
+        load_gate4<H>(bias2[nt], b2, unit0, lane);
+        load_gate4<H>(wx[nt], W1, unit0, lane);
+    }
+
+    for (;;) {
+        __syncthreads();                       // everybody is done with the previous task's LDS
+        if (tid == 0) *s_task = atomicAdd(&queue[0], 1);
+        __syncthreads();
+        const int q = *s_task;
+        if (q >= n_tasks) break;
+        const int blk = q / n_tiles, tile = q % n_tiles;
+        const int t0 = blk * QBS;
+        const int t1 = min(t0 + QBS, T + 1);
+        const int row_base = tile * 16;
+        if (tid < 16) {
+            const int row = row_base + tid;
+            ridx[tid] = row < lim ? (idx ? idx[row] : row) : -1;
+        }
+        float c1[NT], c2[NT];
+        float* st_in = state + ((size_t)(blk - 1) * n_tiles + tile) * QSTATE;
+        if (blk == 0) {
+            for (int i = tid; i < 4 * 16 * HS; i += LSTM_THREADS) h1[i] = 0.0f;    // h1 and h2, both buffers
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) c1[nt] = c2[nt] = 0.0f;
+        } else {
+            if (tid == 0) {                    // predecessor block of this tile published?
+                int spins = 0;
+                while (__hip_atomic_load(&done[tile], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < blk) {
+                    __builtin_amdgcn_s_sleep(32);
+                    if (++spins > (1 << 24)) { atomicExch(errflag, 1); break; }
+                }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            const int rb = t0 & 1;
+            for (int i = tid; i < 16 * HS; i += LSTM_THREADS) {
+                h1[rb * 16 * HS + i] = st_in[i];
+                h2[rb * 16 * HS + i] = st_in[16 * HS + i];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                c1[nt] = st_in[2 * 16 * HS + nt * LSTM_THREADS + tid];
+                c2[nt] = st_in[2 * 16 * HS + (NT + nt) * LSTM_THREADS + tid];
+            }
+        }
+        __syncthreads();
+
+        for (int t = t0; t < t1; t++) {
+            if ((t % XCH) == 0 && t < T) {        // refill the x tile (rows x XCH steps)
+                __syncthreads();
+                for (int i = tid; i < 16 * (XCH / 4); i += LSTM_THREADS) {
+                    const int row = i / (XCH / 4), c4 = i % (XCH / 4);
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int rd = ridx[row];
+                    if (rd >= 0 && t + c4 * 4 < T)
+                        v = *reinterpret_cast<const float4*>(head + (size_t)rd * T + t + c4 * 4);
+                    *reinterpret_cast<float4*>(xb + row * XS + c4 * 4) = v;
+                }
+                __syncthreads();
+            }
+            const int rdb = t & 1, wrb = (t + 1) & 1;
+            float a1[KB], a2[KB];
+            load_afrag<H>(a1, h1 + rdb * 16 * HS, lane);
+            load_afrag<H>(a2, h2 + rdb * 16 * HS, lane);
+            f32x4 acc1[NT], acc2[NT];
+            const float x = xb[rd_l * XS + (t % XCH)];
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float xw = x * wx[nt][r];
+                    acc1[nt][r] = xw + bias1[nt][r];
+                    acc2[nt][r] = bias2[nt][r];
+                }
+            }
+#pragma unroll
+            for (int kb = 0; kb < KB; kb++) {
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    acc1[nt] = mfma4(wA[nt][kb], a1[kb], acc1[nt]);
+                    acc2[nt] = mfma4(wB[nt][kb], a1[kb], acc2[nt]);
+                }
+            }
+#pragma unroll
+            for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+                    acc2[nt] = mfma4(wB[nt][KB + kb], a2[kb], acc2[nt]);
+            float* o1 = h1 + (wrb * 16 + rd_l) * HS;
+            float* o2 = h2 + (wrb * 16 + rd_l) * HS;
+            if (t < T) {
+                float hn[NT];
+                cells_update<NT>(tab, acc1, c1, hn);
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) o1[hpos<H>(slice * 12 + nt * 4 + ul)] = hn[nt];
+            }
+            if (t >= 1) {
+                float hn[NT];
+                cells_update<NT>(tab, acc2, c2, hn);
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) o2[hpos<H>(slice * 12 + nt * 4 + ul)] = hn[nt];
+            }
+            __syncthreads();
+        }
+
+        if (t1 == T + 1) {
+            // ---- Dense(2): chain over k = 0..47 from the bias ----------------------
+            const int fin = (T + 1) & 1;
+            for (int i = tid; i < 16 * 2; i += LSTM_THREADS) {
+                const int row = i >> 1, j = i & 1;
+                const int rd = ridx[row];
+                if (rd < 0) continue;
+                const float* hr = h2 + (fin * 16 + row) * HS;
+                float acc = bd[j];
+                for (int k = 0; k < H; k++) acc = __builtin_fmaf(hr[hpos<H>(k)], Wd[k * 2 + j], acc);
+                pred[(size_t)rd * 2 + j] = acc;
+            }
+        } else {
+            // ---- hand the tile over: state of iteration t1 -> HBM, then publish -------
+            float* st_out = state + ((size_t)blk * n_tiles + tile) * QSTATE;
+            const int rb = t1 & 1;
+            for (int i = tid; i < 16 * HS; i += LSTM_THREADS) {
+                st_out[i] = h1[rb * 16 * HS + i];
+                st_out[16 * HS + i] = h2[rb * 16 * HS + i];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) {
+                st_out[2 * 16 * HS + nt * LSTM_THREADS + tid] = c1[nt];
+                st_out[2 * 16 * HS + (NT + nt) * LSTM_THREADS + tid] = c2[nt];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(&done[tile], blk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ===========================================================================
 // K5a: demux bidirectional layer.  The two "cells" are the forward net at step
 // t and the backward net at step T-1-t.  Every step's hidden rows are streamed
 // to HBM (k-major layout) for K5b.
@@ -656,6 +848,18 @@ static const size_t kTabBytes = sizeof(float) * 4 * PXG_SIG_NSEG;
     default: { CALL(4); } break;     \
     }
 
+// error flag of the time-sliced kernels: allocated and cleared once, read back by
+// pxg_batch_sync / pxg_batch_download
+static int pxg_timeslice_prepare(pxg_ctx* ctx)
+{
+    if (!ctx->lstm_err.p) {
+        int rc = pxg_reserve(ctx, ctx->lstm_err, 1);
+        if (rc) return rc;
+        PXG_HIP(ctx, hipMemsetAsync(ctx->lstm_err.p, 0, sizeof(int), ctx->stream));
+    }
+    return PXG_OK;
+}
+
 int pxg_launch_scaler_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
                            const int32_t* count, const float* head, float* pred)
 {
@@ -663,8 +867,29 @@ int pxg_launch_scaler_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
     const int T = ctx->cfg.scaler_length / ctx->cfg.stride;
     const LstmGrid g = pick_grid(ctx, n_rows);
     const PxgLstmDev &l1 = ctx->scaler1, &l2 = ctx->scaler2;
+    const int64_t tiles = (n_rows + 15) / 16, slots = 2 * (int64_t)ctx->n_cu;
+    if (tiles > slots && tiles < 2 * slots && !getenv("PXG_NO_TIMESLICE")) {
+        // between 1 and 2 tiles per resident workgroup: time-slice (see k_scaler_lstm_q)
+        const int n_blocks = (T + 1 + QBS - 1) / QBS;
+        int rc;
+        if ((rc = pxg_timeslice_prepare(ctx)) || (rc = pxg_reserve(ctx, ctx->lstm_q, (size_t)(2 + tiles))) ||
+            (rc = pxg_reserve(ctx, ctx->lstm_state, (size_t)n_blocks * tiles * QSTATE)))
+            return rc;
+        PXG_HIP(ctx, hipMemsetAsync(ctx->lstm_q.p, 0, (size_t)(2 + tiles) * sizeof(int), ctx->stream));
+        const size_t lds = kTabBytes + sizeof(float) * (4 * 16 * HSTRIDE(48) + 16 * XS) + sizeof(int) * 32;
+        PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_scaler_lstm_q,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_scaler_lstm_q, dim3((unsigned)slots), dim3(LSTM_THREADS), lds, ctx->stream,
+                           (int)n_rows, idx, count, T, head, ctx->d_sigtab, l1.kernel, l1.recurrent,
+                           l1.bias, l2.kernel, l2.recurrent, l2.bias, ctx->scaler_dense.kernel,
+                           ctx->scaler_dense.bias, pred, ctx->lstm_q.p, ctx->lstm_err.p, ctx->lstm_q.p + 2,
+                           ctx->lstm_state.p);
+        ctx->timeslice_used = true;
+        PXG_HIP(ctx, hipGetLastError());
+        return PXG_OK;
+    }
 #define CALL(M)                                                                                  \
-    const size_t lds = kTabBytes + sizeof(float) * (4 * M * 16 * HSTRIDE(48) + 16 * M * XS) +             \
+    const size_t lds = kTabBytes + sizeof(float) * (4 * M * 16 * HSTRIDE(48) + 16 * M * XS) +    \
                        sizeof(int) * 16 * M;                                                     \
     PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_scaler_lstm<M>,                              \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));     \

@@ -259,6 +259,7 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     release(ctx->head); release(ctx->pred); release(ctx->ss); release(ctx->status);
     release(ctx->segs); release(ctx->idx_scaler); release(ctx->idx_demux);
     release(ctx->counters); release(ctx->win); release(ctx->bidir); release(ctx->probs);
+    release(ctx->lstm_q); release(ctx->lstm_state); release(ctx->lstm_err);
     release(ctx->results); release(ctx->polya_ev); release(ctx->polya_out); release(ctx->spikes);
     release(ctx->ev_first); release(ctx->ev_off); release(ctx->ev_mean); release(ctx->ev_scaled);
     release(ctx->unsplit_scr); release(ctx->unsplit_iv); release(ctx->unsplit_cnt);
@@ -439,11 +440,27 @@ extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
     return PXG_OK;
 }
 
+// the time-sliced LSTM kernels raise a device flag instead of spinning forever when a
+// hand-over never arrives (cannot happen with all workgroups resident; belt and braces)
+static int check_timeslice_flag(pxg_ctx* ctx)
+{
+    if (!ctx->lstm_err.p || !ctx->timeslice_used) return PXG_OK;
+    int flag = 0;
+    PXG_HIP(ctx, hipMemcpyAsync(&flag, ctx->lstm_err.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->timeslice_used = false;
+    if (flag) {
+        (void)hipMemsetAsync(ctx->lstm_err.p, 0, sizeof(int), ctx->stream);
+        return fail(ctx, PXG_E_HIP, "time-sliced LSTM kernel: tile hand-over timed out");
+    }
+    return PXG_OK;
+}
+
 extern "C" int pxg_batch_sync(pxg_ctx* ctx)
 {
     if (!ctx) return PXG_E_INVALID;
     PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return PXG_OK;
+    return check_timeslice_flag(ctx);
 }
 
 extern "C" int pxg_batch_download(pxg_ctx* ctx, pxg_read_result* out)
@@ -453,7 +470,7 @@ extern "C" int pxg_batch_download(pxg_ctx* ctx, pxg_read_result* out)
     PXG_HIP(ctx, hipMemcpyAsync(out, ctx->results.p, (size_t)ctx->n_reads * sizeof(pxg_read_result),
                                 hipMemcpyDeviceToHost, ctx->stream));
     PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return PXG_OK;
+    return check_timeslice_flag(ctx);
 }
 
 extern "C" int pxg_batch_download_spikes(pxg_ctx* ctx, pxg_polya_spike* out)

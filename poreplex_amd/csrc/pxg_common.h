@@ -210,6 +210,10 @@ struct pxg_ctx {
     DevBuf<float> win;           // n x trim
     DevBuf<float> bidir;         // n x trim x (Hf+Hb), permuted layout
     DevBuf<float> probs;         // n x PXG_MAX_CLASSES
+    DevBuf<int> lstm_q;          // time-sliced LSTM: [0] task counter, [2+] per-tile progress
+    DevBuf<int> lstm_err;        // time-sliced LSTM: sticky error flag
+    DevBuf<float> lstm_state;    // time-sliced LSTM: tile states in flight between step blocks
+    bool timeslice_used = false;
     DevBuf<pxg_read_result> results;
     DevBuf<char> polya_ev;       // event scratch, [wave][event][lane]
     DevBuf<int32_t> polya_out;   // n x 8: called, n_spikes, dwell, begin lo/hi, end lo/hi

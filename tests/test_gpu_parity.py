@@ -83,6 +83,27 @@ def test_scaler_lstm_bit_exact(ctx, oracle, stages, n):
     assert np.array_equal(got, want), np.abs(got - want).max()
 
 
+@pytest.mark.parametrize('n', [8200, 9999, 13000])
+def test_scaler_lstm_time_sliced_equals_static(ctx, oracle, stages, n):
+    """Between 1 and 2 read tiles per resident workgroup K2 runs time-sliced (tile
+    states handed over through HBM between 256-step blocks, k_scaler_lstm_q): same
+    bits as the static kernel and as the oracle."""
+    heads = stages['scaler_in']
+    rng = np.random.default_rng(n)
+    rows = np.stack([heads[i % len(heads)] for i in range(n)])
+    rows = rows + rng.normal(0, 1.5, (n, 1)).astype(np.float32)     # every read differs
+    got = ctx.scaler_lstm(rows)
+    os.environ['PXG_NO_TIMESLICE'] = '1'
+    try:
+        static = ctx.scaler_lstm(rows)
+    finally:
+        del os.environ['PXG_NO_TIMESLICE']
+    assert np.array_equal(got, static)
+    pick = rng.choice(n, 24, replace=False)
+    want = np.stack([oracle.scaler_forward(rows[i]) for i in pick])
+    assert np.array_equal(got[pick], want)
+
+
 def test_scaler_transform_vs_reference_golden(ctx, unit):
     ss, status = ctx.scaler_transform(unit['xfrm_pred'])
     ok = status == 0
