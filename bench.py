@@ -149,7 +149,9 @@ def main():
     if args.workload in ('demux', 'polya', 'chimera'):
         dur = stage_ms['scaler_lstm'] * 1e-3
         flops = n_scaled * FLOP_SCALER
-        roofline = {'kernel': 'k_scaler_lstm', 'bound': 'mfma',
+        tiles, slots = (n_scaled + 15) // 16, 2 * info['compute_units']
+        roofline = {'kernel': 'k_scaler_lstm_q' if slots < (args.reads + 15) // 16 < 2 * slots
+                    else 'k_scaler_lstm', 'bound': 'mfma',
                     'achieved': flops / dur / 1e12, 'peak': PEAK_FP32_MFMA / 1e12,
                     'unit': 'TFLOP/s', 'frac': flops / dur / PEAK_FP32_MFMA, 'traffic': None,
                     'algorithmic_flop_per_read': FLOP_SCALER}
@@ -160,13 +162,13 @@ def main():
                     'peak': PEAK_HBM / 1e9, 'unit': 'GB/s', 'frac': nbytes / dur / PEAK_HBM,
                     'traffic': None, 'algorithmic_bytes_per_read': nbytes / args.reads}
     # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes
-    # (profiles/r01/f_final_hbm_traffic.json, collected with tools/prof.sh on this exact
+    # (profiles/r01/g_timesliced_hbm_traffic.json, collected with tools/prof.sh on this exact
     # default workload); None for any other workload size
     if args.reads == 10000 and args.samples == 60000 and args.seed == 924:
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01', 'f_final_hbm_traffic.json')) as fh:
+            with open(os.path.join(ROOT, 'profiles', 'r01', 'g_timesliced_hbm_traffic.json')) as fh:
                 roofline['traffic'] = json.load(fh)['kernels'][roofline['kernel']]['hbm_bytes']
-            roofline['traffic_source'] = 'profiles/r01/f_final_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)'
+            roofline['traffic_source'] = 'profiles/r01/g_timesliced_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)'
         except (OSError, KeyError):
             pass
     # secondary figures for DESIGN.md (not part of the contract)
