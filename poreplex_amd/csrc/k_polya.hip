@@ -62,6 +62,21 @@ struct WindowSrc {
     int64_t W;                 // window length
     double k, offset;
     float scale, shift;
+    // two-phase form of scaled(): fetch() only issues the load (so a caller can keep it in
+    // flight across other work), finish() converts; finish(fetch(j), j) == scaled(j)
+    __device__ __forceinline__ float fetch(int64_t j) const
+    {
+        if (j < 0 || j >= W) return 0.0f;
+        return sig ? sig[j] : (float)raw[ib + j];          // int16 -> float is exact
+    }
+    __device__ __forceinline__ float finish(float v, int64_t j) const
+    {
+        if (j < 0 || j >= W) return 0.0f;
+        if (sig) return v;
+        const float pa = (float)(k * ((double)v + offset));
+        const float y = scale * pa;
+        return y + shift;
+    }
     __device__ __forceinline__ float scaled(int64_t j) const
     {
         if (j < 0 || j >= W) return 0.0f;
@@ -107,12 +122,16 @@ __device__ __forceinline__ float filtered_at(const WindowSrc& S, int64_t j, int 
 #endif
 #define PA_GL (64 / PXG_PA_LANES) // lanes per read
 #define PA_EVC 16                // event rows in the LDS chunk cache
+#define PA_XS 64                 // scaled-sample ring (needs filled-3 .. filled+2*PA_GL+3)
 #define PA_PRE 128               // prefix-sum ring (needs i-31 .. i+31+16 around a 16-sample chunk)
 struct GroupLds {
     double2 pre[PA_PRE];         // pre[k & 127] = (sum, sum of squares) of filtered samples [0, k)
     float fbuf[PA_GL];           // filtered samples of the chunk being accumulated
     float tb[2][PA_GL];          // t-statistics of the chunk being scanned
     Ev evc[PA_EVC];              // consecutive event rows (chunk cache of the event passes)
+    float xs[PA_XS];             // scaled samples ring: xs[k & 63] = sample k of the window
+    double2 bsum[2 * PA_GL + 1]; // event boundaries found in the chunk being scanned: prefix sums ...
+    unsigned bpos[2 * PA_GL + 1];// ... and positions; [0] = the last boundary before the chunk
 };
 
 // Resume point of the detector for open-end retries (polya.py:81-85: same window
@@ -204,6 +223,10 @@ __device__ int detect_events_group(const WindowSrc& S, const PolyaParams& P, Gro
         L->pre[0] = make_double2(0.0, 0.0);
     }
     if (snap) snap->n = -1;
+    // sample ring: restart it 3 samples before the first prefix still to be extended (0 outside
+    // the window, like scipy's medfilt padding); slots of negative indices read as zero
+    int64_t xfilled = filled - 3;
+    float xraw = S.fetch(xfilled + gl);
     // last chunk start whose t-statistics (look-ahead <= 31), prefix sums (up to 15 more)
     // and median filter (3 more) all stay inside this window
     const int64_t snap_i0 = ((n - 51) / PA_GL) * PA_GL;
@@ -221,12 +244,23 @@ __device__ int detect_events_group(const WindowSrc& S, const PolyaParams& P, Gro
         const int64_t last = i0 + PA_GL - 1 + look;
         const int64_t need = last < n ? last : n;
         while (filled < need) {
+            // scaled samples up to filled + PA_GL + 3 into the ring; every lane converts ONE
+            // sample per step and its successor's load is already in flight
+            while (xfilled < filled + PA_GL + 3) {
+                L->xs[(xfilled + gl) & (PA_XS - 1)] = S.finish(xraw, xfilled + gl);
+                xfilled += PA_GL;
+                xraw = S.fetch(xfilled + gl);
+            }
+            __builtin_amdgcn_wave_barrier();
             const int64_t j = filled + gl;
             float f = 0.0f;
             if (j < n) {
-                f = mpf <= 1 ? S.scaled(j)
-                             : median7(S.scaled(j - 3), S.scaled(j - 2), S.scaled(j - 1), S.scaled(j),
-                                       S.scaled(j + 1), S.scaled(j + 2), S.scaled(j + 3));
+                const float* X = L->xs;
+                f = mpf <= 1 ? X[j & (PA_XS - 1)]
+                             : median7(X[(j - 3) & (PA_XS - 1)], X[(j - 2) & (PA_XS - 1)],
+                                       X[(j - 1) & (PA_XS - 1)], X[j & (PA_XS - 1)],
+                                       X[(j + 1) & (PA_XS - 1)], X[(j + 2) & (PA_XS - 1)],
+                                       X[(j + 3) & (PA_XS - 1)]);
             }
             L->fbuf[gl] = f;
             __builtin_amdgcn_wave_barrier();
@@ -257,16 +291,33 @@ __device__ int detect_events_group(const WindowSrc& S, const PolyaParams& P, Gro
         }
         __builtin_amdgcn_wave_barrier();
         // ---- (D): peak FSM over the chunk (group-uniform) ----------------------------------
+        // A boundary only costs an LDS append here; the event rows (two float divisions and
+        // a square root each) are materialised afterwards, one lane per event.
         const int jn = (n - i0) < PA_GL ? (int)(n - i0) : PA_GL;
+        const int ne0 = ne;
+        int nb = 0;
+        if (gl == 0) {
+            L->bsum[0] = make_double2(prev_cs, prev_cq);
+            L->bpos[0] = (unsigned)prev_pos;
+        }
+        // next sample's operands are requested one iteration ahead (LDS latency off the chain)
+        double2 here_n = L->pre[i0 & (PA_PRE - 1)];
+        float tn0 = L->tb[0][0], tn1 = L->tb[1][0];
 #pragma unroll 1
         for (int jj = 0; jj < jn; jj++) {
             const int64_t i = i0 + jj;
-            const double2 here = L->pre[i & (PA_PRE - 1)];
+            const double2 here = here_n;
+            const float tcur[2] = { tn0, tn1 };
+            if (jj + 1 < jn) {
+                here_n = L->pre[(i + 1) & (PA_PRE - 1)];
+                tn0 = L->tb[0][jj + 1];
+                tn1 = L->tb[1][jj + 1];
+            }
 #pragma unroll
             for (int d = 0; d < 2; d++) {
                 Detector& D = det[d];
                 if (D.masked_to >= (unsigned long long)i) continue;
-                const float cur = L->tb[d][jj];
+                const float cur = tcur[d];
                 if (D.peak_pos == -1) {
                     if (cur < D.peak_val) {
                         D.peak_val = cur;
@@ -291,11 +342,14 @@ __device__ int detect_events_group(const WindowSrc& S, const PolyaParams& P, Gro
                     }
                     if (D.peak_val - cur > P.peak_height && D.peak_val > D.threshold) D.valid = 1;
                     if (D.valid && ((unsigned long long)i - (unsigned long long)D.peak_pos) > D.window / 2) {
-                        const unsigned long long p = (unsigned long long)D.peak_pos;
-                        if (ne < cap && gl == 0)
-                            ev[(size_t)ne * PXG_PA_LANES + grp] = make_event(prev_pos, p, prev_cs, prev_cq, D.pk_cs, D.pk_cq);
+                        // a boundary: (position, prefix sums) appended to the chunk's list
+                        nb++;
+                        if (gl == 0) {
+                            L->bsum[nb] = make_double2(D.pk_cs, D.pk_cq);
+                            L->bpos[nb] = (unsigned)D.peak_pos;
+                        }
                         ne++;
-                        prev_pos = p;
+                        prev_pos = (unsigned long long)D.peak_pos;
                         prev_cs = D.pk_cs;
                         prev_cq = D.pk_cq;
                         D.peak_pos = -1;
@@ -303,6 +357,14 @@ __device__ int detect_events_group(const WindowSrc& S, const PolyaParams& P, Gro
                         D.valid = 0;
                     }
                 }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int k = gl; k < nb; k += PA_GL) {           // event k of the chunk = [boundary k, k + 1)
+            if (ne0 + k < cap) {
+                const double2 b0 = L->bsum[k], b1 = L->bsum[k + 1];
+                ev[(size_t)(ne0 + k) * PXG_PA_LANES + grp] =
+                    make_event(L->bpos[k], L->bpos[k + 1], b0.x, b0.y, b1.x, b1.y);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -804,3 +866,4 @@ int pxg_launch_detect_events(pxg_ctx* ctx, int64_t n, const float* sig, const in
                        sig, off, (Ev*)evbuf, n_events);
     return PXG_OK;
 }
+
