@@ -183,6 +183,26 @@ def main():
         'labels_gathered': int(len(labels)),
     }
 
+    # ---- PCIe-inclusive rate with the double-buffered loader path (not `value`): every step
+    # uploads a full batch from pinned host memory on the copy stream while the previous one
+    # computes (pxg_batch_stage / pxg_batch_swap)
+    try:
+        ctx.pin(batch['arena'])
+        n_over = min(args.steps, 5)
+        ctx.sync()
+        o0 = time.perf_counter()
+        for _ in range(n_over):
+            step()
+            ctx.stage(batch['arena'], batch['offsets'], batch['calib'], inject)
+            ctx.download()
+            ctx.swap()
+        ctx.sync()
+        extra['pcie_overlapped_reads_per_s'] = args.reads * n_over / (time.perf_counter() - o0)
+        ctx.unpin(batch['arena'])
+    except N.PxgError as exc:
+        extra['pcie_overlapped_reads_per_s'] = None
+        extra['pcie_overlapped_error'] = str(exc)
+
     # ---- CPU baseline + concordance: the oracle, rank 0, bounded sample -------
     cpu = None
     concordance = None

@@ -267,6 +267,19 @@ int pxg_process_batch(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
 int pxg_batch_upload(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
                      const int64_t* raw_offsets, const pxg_calib* calib,
                      const float* scale_shift_or_null);
+/* Double-buffered input for a loader (phase 1 of SignalAnalyzer.process,
+ * signal_analyzer.py:82-100, overlapped with the numeric phases of the previous
+ * batch): pxg_batch_stage copies the NEXT batch into the spare input slot on a
+ * dedicated copy stream while the resident batch computes; pxg_batch_swap waits
+ * for those copies and makes the staged batch the resident one (download the
+ * previous batch's results first).  The host arrays must stay valid until
+ * pxg_batch_swap returns; pin them (pxg_host_register) for true DMA transfers. */
+int pxg_batch_stage(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
+                    const int64_t* raw_offsets, const pxg_calib* calib,
+                    const float* scale_shift_or_null);
+int pxg_batch_swap(pxg_ctx* ctx);
+int pxg_host_register(pxg_ctx* ctx, void* ptr, size_t bytes);
+int pxg_host_unregister(pxg_ctx* ctx, void* ptr);
 int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask);
 int pxg_batch_sync(pxg_ctx* ctx);
 int pxg_batch_download(pxg_ctx* ctx, pxg_read_result* out);

@@ -194,7 +194,11 @@ extern "C" int pxg_create(const pxg_config* cfg, pxg_ctx** out)
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) { rc = fail(ctx, PXG_E_HIP, "props"); break; }
         ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_staged, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_run_done[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_run_done[1], hipEventDisableTiming) != hipSuccess) {
             rc = fail(ctx, PXG_E_HIP, "hipStreamCreate"); break;
         }
         for (int t = 0; t < PXG_N_TIMERS; t++) {
@@ -260,6 +264,7 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     release(ctx->segs); release(ctx->idx_scaler); release(ctx->idx_demux);
     release(ctx->counters); release(ctx->win); release(ctx->bidir); release(ctx->probs);
     release(ctx->lstm_q); release(ctx->lstm_state); release(ctx->lstm_err);
+    release(ctx->spare.raw); release(ctx->spare.offsets); release(ctx->spare.calib); release(ctx->spare.inject);
     release(ctx->results); release(ctx->polya_ev); release(ctx->polya_out); release(ctx->spikes);
     release(ctx->ev_first); release(ctx->ev_off); release(ctx->ev_mean); release(ctx->ev_scaled);
     release(ctx->unsplit_scr); release(ctx->unsplit_iv); release(ctx->unsplit_cnt);
@@ -278,6 +283,10 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
             (void)hipEventDestroy(ctx->ev_stop[t]);
         }
         (void)hipStreamDestroy(ctx->stream);
+        if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+        if (ctx->ev_staged) (void)hipEventDestroy(ctx->ev_staged);
+        for (int q = 0; q < 2; q++)
+            if (ctx->ev_run_done[q]) (void)hipEventDestroy(ctx->ev_run_done[q]);
     }
     delete ctx;
 }
@@ -361,6 +370,99 @@ extern "C" int pxg_batch_upload(pxg_ctx* ctx, int64_t n_reads, const int16_t* ra
     return PXG_OK;
 }
 
+static int check_batch_args(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
+                            const int64_t* raw_offsets, const pxg_calib* calib, const char* who)
+{
+    if (n_reads < 0 || (n_reads > 0 && (!raw_offsets || !calib)))
+        return fail(ctx, PXG_E_INVALID, std::string(who) + ": bad arguments");
+    for (int64_t i = 0; i < n_reads; i++)
+        if (raw_offsets[i + 1] < raw_offsets[i])
+            return fail(ctx, PXG_E_INVALID, "raw_offsets must be non-decreasing");
+    if (n_reads > 0 && raw_offsets[0] != 0) return fail(ctx, PXG_E_INVALID, "raw_offsets[0] must be 0");
+    if (n_reads > 0 && raw_offsets[n_reads] > 0 && !raw_arena)
+        return fail(ctx, PXG_E_INVALID, "raw_arena is null");
+    if (n_reads > (1LL << 30)) return fail(ctx, PXG_E_INVALID, "too many reads");
+    return PXG_OK;
+}
+
+extern "C" int pxg_batch_stage(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
+                               const int64_t* raw_offsets, const pxg_calib* calib,
+                               const float* scale_shift_or_null)
+{
+    if (!ctx) return PXG_E_INVALID;
+    int rc = check_batch_args(ctx, n_reads, raw_arena, raw_offsets, calib, "pxg_batch_stage");
+    if (rc) return rc;
+    if (n_reads == 0) return fail(ctx, PXG_E_INVALID, "pxg_batch_stage: empty batch");
+    PXG_HIP(ctx, hipSetDevice(ctx->device));
+    auto& sp = ctx->spare;
+    sp.staged = false;
+    const int64_t n_samples = raw_offsets[n_reads];
+    if ((rc = pxg_reserve(ctx, sp.raw, (size_t)n_samples + 64)) ||
+        (rc = pxg_reserve(ctx, sp.offsets, (size_t)n_reads + 1)) ||
+        (rc = pxg_reserve(ctx, sp.calib, (size_t)n_reads)) ||
+        (rc = pxg_reserve(ctx, sp.inject, (size_t)n_reads * 2)))
+        return rc;
+    // the spare buffers were the resident ones before the last swap: the copy may start once the
+    // last run that read them is done (not the run that is in flight on the resident ones)
+    if (ctx->run_recorded[ctx->cur ^ 1])
+        PXG_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_run_done[ctx->cur ^ 1], 0));
+    hipStream_t cs = ctx->copy_stream;
+    if (n_samples)
+        PXG_HIP(ctx, hipMemcpyAsync(sp.raw.p, raw_arena, (size_t)n_samples * sizeof(int16_t),
+                                    hipMemcpyHostToDevice, cs));
+    PXG_HIP(ctx, hipMemcpyAsync(sp.offsets.p, raw_offsets, (size_t)(n_reads + 1) * sizeof(int64_t),
+                                hipMemcpyHostToDevice, cs));
+    PXG_HIP(ctx, hipMemcpyAsync(sp.calib.p, calib, (size_t)n_reads * sizeof(pxg_calib),
+                                hipMemcpyHostToDevice, cs));
+    sp.have_inject = scale_shift_or_null != nullptr;
+    if (sp.have_inject)
+        PXG_HIP(ctx, hipMemcpyAsync(sp.inject.p, scale_shift_or_null, (size_t)n_reads * 2 * sizeof(float),
+                                    hipMemcpyHostToDevice, cs));
+    PXG_HIP(ctx, hipEventRecord(ctx->ev_staged, cs));
+    sp.n_reads = n_reads;
+    sp.n_samples = n_samples;
+    sp.staged = true;
+    return PXG_OK;
+}
+
+extern "C" int pxg_batch_swap(pxg_ctx* ctx)
+{
+    if (!ctx) return PXG_E_INVALID;
+    auto& sp = ctx->spare;
+    if (!sp.staged) return fail(ctx, PXG_E_STATE, "pxg_batch_swap: nothing staged");
+    PXG_HIP(ctx, hipSetDevice(ctx->device));
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->copy_stream));      // host arrays are free again
+    PXG_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_staged, 0));
+    std::swap(ctx->raw, sp.raw);
+    std::swap(ctx->offsets, sp.offsets);
+    std::swap(ctx->calib, sp.calib);
+    std::swap(ctx->inject, sp.inject);
+    ctx->cur ^= 1;
+    ctx->have_inject = sp.have_inject;
+    ctx->n_reads = 0;
+    int rc = reserve_batch(ctx, sp.n_reads, sp.n_samples);     // per-batch intermediates
+    if (rc) return rc;
+    ctx->n_reads = sp.n_reads;
+    ctx->n_samples = sp.n_samples;
+    sp.staged = false;
+    return PXG_OK;
+}
+
+extern "C" int pxg_host_register(pxg_ctx* ctx, void* ptr, size_t bytes)
+{
+    if (!ctx || !ptr || !bytes) return PXG_E_INVALID;
+    PXG_HIP(ctx, hipSetDevice(ctx->device));
+    PXG_HIP(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return PXG_OK;
+}
+
+extern "C" int pxg_host_unregister(pxg_ctx* ctx, void* ptr)
+{
+    if (!ctx || !ptr) return PXG_E_INVALID;
+    PXG_HIP(ctx, hipHostUnregister(ptr));
+    return PXG_OK;
+}
+
 extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
 {
     if (!ctx) return PXG_E_INVALID;
@@ -436,6 +538,8 @@ extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
     if ((rc = pxg_launch_finalize(ctx, n, stage_mask))) return rc;
     pxg_timer_end(ctx, PXG_T_FINALIZE);
     pxg_timer_end(ctx, PXG_T_TOTAL);
+    PXG_HIP(ctx, hipEventRecord(ctx->ev_run_done[ctx->cur], ctx->stream));
+    ctx->run_recorded[ctx->cur] = true;
     PXG_HIP(ctx, hipGetLastError());
     return PXG_OK;
 }

@@ -199,6 +199,20 @@ struct pxg_ctx {
     DevBuf<int64_t> offsets;
     DevBuf<pxg_calib> calib;
     DevBuf<float> inject;        // n x 2
+    // spare input slot (pxg_batch_stage / pxg_batch_swap) and its copy stream
+    struct {
+        DevBuf<int16_t> raw;
+        DevBuf<int64_t> offsets;
+        DevBuf<pxg_calib> calib;
+        DevBuf<float> inject;
+        int64_t n_reads = 0, n_samples = 0;
+        bool have_inject = false, staged = false;
+    } spare;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_staged = nullptr;
+    hipEvent_t ev_run_done[2] = { nullptr, nullptr };   // last run on the resident / the spare inputs
+    bool run_recorded[2] = { false, false };
+    int cur = 0;                 // which of the two belongs to the resident inputs
     DevBuf<float> head;          // n x head_width
     DevBuf<float> pred;          // n x 2
     DevBuf<float> ss;            // n x 2

@@ -328,6 +328,11 @@ _SIGNATURES = {
                                     C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     'pxg_batch_upload': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
+    'pxg_batch_stage': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]),
+    'pxg_batch_swap': (C.c_int, [C.c_void_p]),
+    'pxg_host_register': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    'pxg_host_unregister': (C.c_int, [C.c_void_p, C.c_void_p]),
     'pxg_batch_run': (C.c_int, [C.c_void_p, C.c_uint32]),
     'pxg_batch_sync': (C.c_int, [C.c_void_p]),
     'pxg_batch_download': (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -459,6 +464,30 @@ class NativeContext:
             self.handle, n, _ptr(arena), _ptr(offsets), _ptr(calib), _ptr(scale_shift)),
             'pxg_batch_upload')
         self.n_resident = n
+
+    def stage(self, arena, offsets, calib, scale_shift=None):
+        """Copy the NEXT batch into the spare input slot on the copy stream while the
+        resident batch computes; the arrays are kept alive until swap()."""
+        arena, offsets, calib, scale_shift, n = self._prep(arena, offsets, calib, scale_shift)
+        self._staged = (arena, offsets, calib, scale_shift, n)
+        self._check(self.lib.pxg_batch_stage(
+            self.handle, n, _ptr(arena), _ptr(offsets), _ptr(calib), _ptr(scale_shift)),
+            'pxg_batch_stage')
+
+    def swap(self):
+        """Make the staged batch the resident one (waits for its copies)."""
+        self._check(self.lib.pxg_batch_swap(self.handle), 'pxg_batch_swap')
+        self.n_resident = self._staged[4]
+        self._staged = None
+
+    def pin(self, array):
+        """Page-lock a NumPy array so stage() copies are DMA transfers; returns it."""
+        self._check(self.lib.pxg_host_register(self.handle, _ptr(array), array.nbytes),
+                    'pxg_host_register')
+        return array
+
+    def unpin(self, array):
+        self._check(self.lib.pxg_host_unregister(self.handle, _ptr(array)), 'pxg_host_unregister')
 
     def run(self, stage_mask=STAGE_ALL_DEMUX):
         self._check(self.lib.pxg_batch_run(self.handle, stage_mask), 'pxg_batch_run')

@@ -442,3 +442,27 @@ def test_custom_left_to_right_hmm_generic_kernel(config, bundle):
             assert np.array_equal(paths[k], opath), k
     finally:
         c.close()
+
+
+def test_staged_double_buffered_batches(ctx, oracle):
+    """pxg_batch_stage / pxg_batch_swap: batch i+1 is copied on the copy stream while
+    batch i computes; every batch gets the records of a plain upload -> run."""
+    batches = [synth_batch(n, seed=600 + n, samples_per_read=9000, jitter=0.3)
+               for n in (96, 33, 150, 1, 64)]
+    want = [oracle.process_batch(b['arena'], b['offsets'], b['calib']) for b in batches]
+    pinned = ctx.pin(batches[2]['arena'])           # one of them page-locked
+    try:
+        ctx.upload(batches[0]['arena'], batches[0]['offsets'], batches[0]['calib'])
+        for i in range(len(batches)):
+            ctx.run(N.STAGE_ALL_DEMUX)
+            if i + 1 < len(batches):
+                nb = batches[i + 1]
+                ctx.stage(nb['arena'], nb['offsets'], nb['calib'])
+            got = ctx.download()
+            assert_records_equal(got, want[i], ctxmsg='batch %d' % i)
+            if i + 1 < len(batches):
+                ctx.swap()
+    finally:
+        ctx.unpin(pinned)
+    with pytest.raises(N.PxgError):
+        ctx.swap()                                  # nothing staged
