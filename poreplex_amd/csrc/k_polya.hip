@@ -130,8 +130,17 @@ struct GroupLds {
     float tb[2][PA_GL];          // t-statistics of the chunk being scanned
     Ev evc[PA_EVC];              // consecutive event rows (chunk cache of the event passes)
     float xs[PA_XS];             // scaled samples ring: xs[k & 63] = sample k of the window
-    double2 bsum[2 * PA_GL + 1]; // event boundaries found in the chunk being scanned: prefix sums ...
-    unsigned bpos[2 * PA_GL + 1];// ... and positions; [0] = the last boundary before the chunk
+    union {                      // never live at the same time (4 KB per read keeps 10 waves per CU)
+        struct {                 // detector: event boundaries found in the chunk being scanned
+            double2 bsum[2 * PA_GL + 1];     // prefix sums ...
+            unsigned bpos[2 * PA_GL + 1];    // ... and positions; [0] = the last one before the chunk
+        };
+        struct {                 // reductions: one leaf block of a NumPy pairwise sum + its
+            float vb[128];       // recursion stack (depth <= log2(n / 64))
+            int sk_base[24], sk_n[24], sk_st[24];
+            float sk_acc[24];
+        };
+    };
 };
 
 // Resume point of the detector for open-end retries (polya.py:81-85: same window
@@ -381,57 +390,76 @@ __device__ int detect_events_group(const WindowSrc& S, const PolyaParams& P, Gro
 // ---------------------------------------------------------------------------
 // NumPy float32 add.reduce (pairwise) over a virtual array v(i), i in [0, n)
 // ---------------------------------------------------------------------------
-template <typename F>
-__device__ float np_block_sum(const F& v, int64_t base, int64_t n)   // n <= 128
+// The virtual array is consumed strictly in index order, one leaf block (<= 128
+// elements) at a time: the block is first staged into LDS by ONE loop around v() --
+// a single inlined copy of the caller's lambda instead of 18, which kept this kernel
+// above the instruction cache -- and then summed by plain code; the recursion stack
+// of the pairwise split lives in LDS as well (it used to be private memory: 3.2 of
+// the 6.6 ms of the whole poly(A) stage).  All of it is group-uniform.
+__device__ float np_block_sum_lds(const float* vb, int n)   // n <= 128
 {
     if (n < 8) {
         float res = 0.0f;
-        for (int64_t i = 0; i < n; i++) res += v(base + i);
+        for (int i = 0; i < n; i++) res += vb[i];
         return res;
     }
-    float r0 = v(base), r1 = v(base + 1), r2 = v(base + 2), r3 = v(base + 3), r4 = v(base + 4),
-          r5 = v(base + 5), r6 = v(base + 6), r7 = v(base + 7);
-    int64_t i;
+    float r0 = vb[0], r1 = vb[1], r2 = vb[2], r3 = vb[3], r4 = vb[4], r5 = vb[5], r6 = vb[6], r7 = vb[7];
+    int i;
     for (i = 8; i < n - (n % 8); i += 8) {
-        r0 += v(base + i); r1 += v(base + i + 1); r2 += v(base + i + 2); r3 += v(base + i + 3);
-        r4 += v(base + i + 4); r5 += v(base + i + 5); r6 += v(base + i + 6); r7 += v(base + i + 7);
+        r0 += vb[i]; r1 += vb[i + 1]; r2 += vb[i + 2]; r3 += vb[i + 3];
+        r4 += vb[i + 4]; r5 += vb[i + 5]; r6 += vb[i + 6]; r7 += vb[i + 7];
     }
     float res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-    for (; i < n; i++) res += v(base + i);
+    for (; i < n; i++) res += vb[i];
     return res;
 }
 
 template <typename F>
-__device__ float np_sum_f32(const F& v, int64_t n)
+__device__ __forceinline__ float np_leaf(const F& v, int64_t base, int n, GroupLds* L, int gl)
 {
-    if (n <= 128) return np_block_sum(v, 0, n);
-    // explicit stack for the recursive halving (n2 = n/2 rounded down to 8)
-    int64_t sb[40], sn[40];
-    float acc[40];
-    int st[40];       // 0: descend left, 1: left done, 2: both done
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (int i = 0; i < n; i++) {
+        const float x = v(base + i);
+        if (gl == 0) L->vb[i] = x;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return np_block_sum_lds(L->vb, n);
+}
+
+template <typename F>
+__device__ float np_sum_f32(const F& v, int64_t n, GroupLds* L, int gl)
+{
+    if (n <= 128) return np_leaf(v, 0, (int)n, L, gl);
+    // explicit stack for the recursive halving (n2 = n/2 rounded down to 8), in LDS
     int top = 0;
-    sb[0] = 0; sn[0] = n; st[0] = 0;
+    if (gl == 0) { L->sk_base[0] = 0; L->sk_n[0] = (int)n; L->sk_st[0] = 0; }
     float ret = 0.0f;
     while (top >= 0) {
-        const int64_t nn = sn[top];
+        __builtin_amdgcn_wave_barrier();
+        const int nn = L->sk_n[top], bb = L->sk_base[top], st = L->sk_st[top];
         if (nn <= 128) {
-            ret = np_block_sum(v, sb[top], nn);
+            ret = np_leaf(v, bb, nn, L, gl);
             top--;
             continue;
         }
-        int64_t n2 = nn / 2;
+        int n2 = nn / 2;
         n2 -= n2 % 8;
-        if (st[top] == 0) {
-            st[top] = 1;
-            sb[top + 1] = sb[top]; sn[top + 1] = n2; st[top + 1] = 0;
+        if (st == 0) {
+            if (gl == 0) {
+                L->sk_st[top] = 1;
+                L->sk_base[top + 1] = bb; L->sk_n[top + 1] = n2; L->sk_st[top + 1] = 0;
+            }
             top++;
-        } else if (st[top] == 1) {
-            acc[top] = ret;
-            st[top] = 2;
-            sb[top + 1] = sb[top] + n2; sn[top + 1] = nn - n2; st[top + 1] = 0;
+        } else if (st == 1) {
+            if (gl == 0) {
+                L->sk_acc[top] = ret;
+                L->sk_st[top] = 2;
+                L->sk_base[top + 1] = bb + n2; L->sk_n[top + 1] = nn - n2; L->sk_st[top + 1] = 0;
+            }
             top++;
         } else {
-            ret = acc[top] + ret;
+            ret = L->sk_acc[top] + ret;
             top--;
         }
     }
@@ -622,8 +650,8 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
                 const int m = pj - pi + 1;
                 auto ml = [&](int64_t q) -> float { const Ev e = ev_at(pi + (int)q); return e.mean * e.length; };
                 auto ln = [&](int64_t q) -> float { return ev_at(pi + (int)q).length; };
-                const float num = np_sum_f32(ml, m);
-                const float den = np_sum_f32(ln, m);
+                const float num = np_sum_f32(ml, m, L, gl);
+                const float den = np_sum_f32(ln, m, L, gl);
                 const float level = num / den;
                 shifted = fabs((double)level - P.mean_loc) > P.trigger * P.mean_scale;
             }
@@ -645,10 +673,10 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
                     FiltCache fc;
                     fc.c0 = -1;
                     auto fv = [&](int64_t q) -> float { return filtered_seq(S, mpf, bb + q, fc, L, gl); };
-                    const float mean = np_sum_f32(fv, cnt) / (float)cnt;
+                    const float mean = np_sum_f32(fv, cnt, L, gl) / (float)cnt;
                     fc.c0 = -1;
                     auto dv = [&](int64_t q) -> float { const float x = filtered_seq(S, mpf, bb + q, fc, L, gl) - mean; return x * x; };
-                    const float ss = np_sum_f32(dv, cnt);
+                    const float ss = np_sum_f32(dv, cnt, L, gl);
                     const float sd = sqrtf(ss / (float)cnt);
                     qc_ok = (double)sd < P.stdv_max;
                 }
@@ -666,7 +694,7 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
                 auto pl = [&](int64_t idx) -> float {
                     return ev_at(nth_matching(is_polya, pi, pj, (int)idx, pc)).length;
                 };
-                const float dwell = np_sum_f32(pl, np_);
+                const float dwell = np_sum_f32(pl, np_, L, gl);
                 int ns = 0;
                 for (int q = pi; q <= pj; q++) {
                     if (!is_polya(q)) {
@@ -707,12 +735,12 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
                 const Ev e = ev_at(nth_matching(anchor, 0, ne - 1, (int)idx, ac));
                 return e.mean * e.length;
             };
-            const float asum = np_sum_f32(aml, m);
+            const float asum = np_sum_f32(aml, m, L, gl);
             ac = { -1, -1 };
             auto aln = [&](int64_t idx) -> float {
                 return ev_at(nth_matching(anchor, 0, ne - 1, (int)idx, ac)).length;
             };
-            const float pm = asum / np_sum_f32(aln, m);
+            const float pm = asum / np_sum_f32(aln, m, L, gl);
             rlo = (double)pm - half;
             rhi = (double)pm + half;
             flo = (float)rlo;
@@ -723,7 +751,7 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
             auto pl = [&](int64_t idx) -> float {
                 return ev_at(nth_matching(is_polya, 0, ne - 1, (int)idx, pc)).length;
             };
-            const float tot = np_sum_f32(pl, np_);
+            const float tot = np_sum_f32(pl, np_, L, gl);
             if ((double)tot >= (double)P.recal_min_length) {
                 has_range = 1;
                 state = CALL;

@@ -287,11 +287,7 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
                     const double xd = (double)x[k0 + t];
 #pragma unroll
                     for (int q = 0; q < PXG_MAX_STATES; q++)
-#ifdef UN_EXP_NOEMIT
-                        if (q < S) em[rr * UN_EM_STRIDE + tt * PXG_MAX_STATES + q] = xd * 0.01 * q;
-#else
                         if (q < S) em[rr * UN_EM_STRIDE + tt * PXG_MAX_STATES + q] = un_emission(H, q, xd);
-#endif
                 }
             }
             __syncthreads();
@@ -352,7 +348,6 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
             }
         };
         __syncthreads();     // this wave's table stores (lanes s == 0) before the group's loads
-#ifndef UN_EXP_NOTRACE
         for (int tb = ((Tmax - 1) >> 3) << 3; tb >= 0; tb -= 8) {
             unsigned m[8];
 #pragma unroll
@@ -374,7 +369,6 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
                 if (t > 0 && src != 7) cur = src;
             }
         }
-#endif
         if (phase == 1) finalize(a_first);
         else if (phase == 2) finalize(lead);
         if (s == 0 && more) cand_cnt[u] = count;
