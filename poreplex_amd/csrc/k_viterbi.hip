@@ -21,9 +21,10 @@
 // current step.  The run-length summary falls out without a traceback.
 #include "pxg_common.h"
 
-#define VIT_READS 8
+#define VIT_CHAINS 1            // independent 8-read sets per recurrence wave (2 measured slower: 2.6 vs 1.9 ms, the wave is issue-bound)
+#define VIT_READS (8 * VIT_CHAINS)
 #define VIT_CHUNK 16
-#define VIT_THREADS 192   // wave 0: recurrence; waves 1-2: emissions of the next chunk
+#define VIT_THREADS (64 * (1 + 2 * VIT_CHAINS))   // wave 0: recurrence; the others: emissions of the next chunk
 
 __device__ __forceinline__ double hmm_emission(const PxgHmmDev& H, int s, double x)
 {
@@ -108,18 +109,27 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int rr = lane >> 3, s = lane & 7;
-    const int64_t r = blockIdx.x * (int64_t)VIT_READS + rr;
     const int S = H.n_states;
-    const bool valid_read = r < n_reads && (status == nullptr || status[r] == PXG_ST_OKAY);
 
-    int T = 0;
-    if (valid_read) {
-        const int64_t len = off[r + 1] - off[r];
-        const int64_t P = RAW ? len / stride : len;
-        T = (int)(P < scan_pooled ? P : scan_pooled);
+    // the recurrence wave carries VIT_CHAINS independent sets of 8 reads (chain c = reads
+    // [8c, 8c + 8) of the block); two interleaved chains were measured slower than one
+    int64_t r[VIT_CHAINS];
+    bool valid_read[VIT_CHAINS];
+    int T[VIT_CHAINS];
+    int Tmax = 0;
+#pragma unroll
+    for (int c = 0; c < VIT_CHAINS; c++) {
+        r[c] = blockIdx.x * (int64_t)VIT_READS + c * 8 + rr;
+        valid_read[c] = r[c] < n_reads && (status == nullptr || status[r[c]] == PXG_ST_OKAY);
+        T[c] = 0;
+        if (valid_read[c]) {
+            const int64_t len = off[r[c] + 1] - off[r[c]];
+            const int64_t P = RAW ? len / stride : len;
+            T[c] = (int)(P < scan_pooled ? P : scan_pooled);
+        }
+        Tmax = T[c] > Tmax ? T[c] : Tmax;
     }
     // longest read of this block (every wave computes the same value)
-    int Tmax = T;
     for (int d = 32; d >= 1; d >>= 1) {
         const int o = __shfl_xor(Tmax, d);
         Tmax = o > Tmax ? o : Tmax;
@@ -127,8 +137,8 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
     const int n_chunks = (Tmax + VIT_CHUNK - 1) / VIT_CHUNK;
 
     if (wv > 0) {
-        // ================= emission producers (waves 1 and 2) =====================
-        // lane -> (read, step) of a chunk: 2 waves x 64 lanes = 8 reads x 16 steps;
+        // ================= emission producers (waves 1 .. 2*VIT_CHAINS) ===============
+        // lane -> (read, step) of a chunk: 64 lanes = 4 reads x 16 steps;
         // consecutive lanes pool consecutive 15-sample blocks (coalesced)
         const int item = (wv - 1) * 64 + lane;
         const int prr = item / VIT_CHUNK, ptt = item % VIT_CHUNK;
@@ -208,8 +218,14 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
     }
     const unsigned stamp_sh = (unsigned)(s & 1) * 16u;
 
-    double v = -__builtin_inf();
-    unsigned ent[4] = { 0u, 0u, 0u, 0u };   // 16-bit entry step + 1 per state
+    double v[VIT_CHAINS];
+    unsigned ent[VIT_CHAINS][4];            // 16-bit entry step + 1 per state
+#pragma unroll
+    for (int c = 0; c < VIT_CHAINS; c++) {
+        v[c] = -__builtin_inf();
+#pragma unroll
+        for (int w = 0; w < 4; w++) ent[c][w] = 0u;
+    }
 
     __syncthreads();                // chunk 0 is in em[0]
     for (int c0 = 0; c0 < Tmax; c0 += VIT_CHUNK) {
@@ -219,97 +235,104 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
 #pragma unroll 1
         for (int tt = 0; tt < tend; tt++) {
             const int t = c0 + tt;
-            const bool act = (t < T) && (s < S);
-            const double e = act ? emc[rr * EM_STRIDE + tt * PXG_MAX_STATES + s] : 0.0;
-            // v and the entry vectors of the lanes below, for the spans in use
-            double vs[PXG_MAX_STATES];
-            unsigned es[PXG_MAX_STATES][NW];
 #pragma unroll
-            for (int k = 1; k < PXG_MAX_STATES; k++) {
-                if ((SPANS >> k) & 1u) {
-                    vs[k] = dpp_shr_f64(v, k);
-#pragma unroll
-                    for (int w = 0; w < NW; w++) es[k][w] = dpp_shr_u32(ent[w], k);
-                }
-            }
-            if (t == 0) {                       // wave-uniform
-                if (act) {
-                    v = lstart + e;
-#pragma unroll
-                    for (int w = 0; w < NW; w++) ent[w] = (ent[w] & keep[w]) | ((1u << stamp_sh) & put[w]);
-                }
-            } else {
-                double best = v + lpk[0];       // span 0 = self loop (or -inf)
-                int bd = 0, bpr = prk[0];
+            for (int c = 0; c < VIT_CHAINS; c++) {
+                const bool act = (t < T[c]) && (s < S);
+                const double e = act ? emc[(c * 8 + rr) * EM_STRIDE + tt * PXG_MAX_STATES + s] : 0.0;
+                // v and the entry vectors of the lanes below, for the spans in use
+                double vs[PXG_MAX_STATES];
+                unsigned es[PXG_MAX_STATES][NW];
 #pragma unroll
                 for (int k = 1; k < PXG_MAX_STATES; k++) {
                     if ((SPANS >> k) & 1u) {
-                        const double cand = vs[k] + lpk[k];
-                        const unsigned long long take =
-                            __ballot((cand > best) || (cand == best && prk[k] < bpr));
-                        best = pxg_sel_f64(take, best, cand);
-                        bd = (int)pxg_sel_u32(take, (unsigned)bd, (unsigned)k);
-                        bpr = (int)pxg_sel_u32(take, (unsigned)bpr, (unsigned)prk[k]);
+                        vs[k] = dpp_shr_f64(v[c], k);
+#pragma unroll
+                        for (int w = 0; w < NW; w++) es[k][w] = dpp_shr_u32(ent[c][w], k);
                     }
                 }
-                const unsigned long long mact = __ballot(act);
-                v = pxg_sel_f64(mact, v, best + e);
-                unsigned ne[NW];
+                if (t == 0) {                       // wave-uniform
+                    if (act) {
+                        v[c] = lstart + e;
 #pragma unroll
-                for (int w = 0; w < NW; w++) ne[w] = ent[w];
-#pragma unroll
-                for (int k = 1; k < PXG_MAX_STATES; k++) {
-                    if ((SPANS >> k) & 1u) {
-                        const unsigned long long mk = __ballot(bd == k);
-#pragma unroll
-                        for (int w = 0; w < NW; w++) ne[w] = pxg_sel_u32(mk, ne[w], es[k][w]);
+                        for (int w = 0; w < NW; w++)
+                            ent[c][w] = (ent[c][w] & keep[w]) | ((1u << stamp_sh) & put[w]);
                     }
-                }
-                const unsigned long long mmove = __ballot(act && bd != 0);
-                const unsigned stamp = (unsigned)(t + 1) << stamp_sh;
+                } else {
+                    double best = v[c] + lpk[0];    // span 0 = self loop (or -inf)
+                    int bd = 0, bpr = prk[0];
 #pragma unroll
-                for (int w = 0; w < NW; w++)
-                    ent[w] = pxg_sel_u32(mmove, ent[w], (ne[w] & keep[w]) | (stamp & put[w]));
+                    for (int k = 1; k < PXG_MAX_STATES; k++) {
+                        if ((SPANS >> k) & 1u) {
+                            const double cand = vs[k] + lpk[k];
+                            const unsigned long long take =
+                                __ballot((cand > best) || (cand == best && prk[k] < bpr));
+                            best = pxg_sel_f64(take, best, cand);
+                            bd = (int)pxg_sel_u32(take, (unsigned)bd, (unsigned)k);
+                            bpr = (int)pxg_sel_u32(take, (unsigned)bpr, (unsigned)prk[k]);
+                        }
+                    }
+                    const unsigned long long mact = __ballot(act);
+                    v[c] = pxg_sel_f64(mact, v[c], best + e);
+                    unsigned ne[NW];
+#pragma unroll
+                    for (int w = 0; w < NW; w++) ne[w] = ent[c][w];
+#pragma unroll
+                    for (int k = 1; k < PXG_MAX_STATES; k++) {
+                        if ((SPANS >> k) & 1u) {
+                            const unsigned long long mk = __ballot(bd == k);
+#pragma unroll
+                            for (int w = 0; w < NW; w++) ne[w] = pxg_sel_u32(mk, ne[w], es[k][w]);
+                        }
+                    }
+                    const unsigned long long mmove = __ballot(act && bd != 0);
+                    const unsigned stamp = (unsigned)(t + 1) << stamp_sh;
+#pragma unroll
+                    for (int w = 0; w < NW; w++)
+                        ent[c][w] = pxg_sel_u32(mmove, ent[c][w], (ne[w] & keep[w]) | (stamp & put[w]));
+                }
             }
         }
         __syncthreads();            // this chunk is consumed; the next one is published
     }
 
-    // ---- termination: first maximum of the last column in name-sorted order -
-    double bestv = -__builtin_inf();
-    int end_lane = rr * 8 + H.order[0];
-    for (int q = 0; q < S; q++) {
-        const int ln = rr * 8 + H.order[q];
-        const double vk = shfl_f64(v, ln);
-        if (q == 0 || vk > bestv) {
-            bestv = vk;
-            end_lane = ln;
-        }
-    }
-    unsigned fe[4] = { 0u, 0u, 0u, 0u };
 #pragma unroll
-    for (int w = 0; w < NW; w++) fe[w] = (unsigned)__shfl((int)ent[w], end_lane);
-
-    if (s == 0 && r < n_reads) {
-        int32_t* first = segs + r * 2 * PXG_N_SEGMENTS;
-        int32_t* last = first + PXG_N_SEGMENTS;
-        for (int q = 0; q < PXG_N_SEGMENTS; q++) first[q] = last[q] = -1;
-        if (valid_read && T > 0) {
-            int prev = -1;
-#pragma unroll
-            for (int q = 0; q < PXG_MAX_STATES; q++) {
-                const int en = (int)((fe[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu);
-                if (q >= S || en == 0) continue;
-                first[q] = en - 1;
-                if (prev >= 0) last[prev] = en - 2;
-                prev = q;
+    for (int c = 0; c < VIT_CHAINS; c++) {
+        // ---- termination: first maximum of the last column in name-sorted order -
+        double bestv = -__builtin_inf();
+        int end_lane = rr * 8 + H.order[0];
+        for (int q = 0; q < S; q++) {
+            const int ln = rr * 8 + H.order[q];
+            const double vk = shfl_f64(v[c], ln);
+            if (q == 0 || vk > bestv) {
+                bestv = vk;
+                end_lane = ln;
             }
-            if (prev >= 0) last[prev] = T - 1;
-            if (logp_out) logp_out[r] = bestv;
-            if (status != nullptr && H.adapter_state >= 0 && first[H.adapter_state] < 0)
-                status[r] = PXG_ST_ADAPTER_NOT_DETECTED;
-        } else if (logp_out) {
-            logp_out[r] = -__builtin_inf();
+        }
+        unsigned fe[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+        for (int w = 0; w < NW; w++) fe[w] = (unsigned)__shfl((int)ent[c][w], end_lane);
+
+        if (s == 0 && r[c] < n_reads) {
+            int32_t* first = segs + r[c] * 2 * PXG_N_SEGMENTS;
+            int32_t* last = first + PXG_N_SEGMENTS;
+            for (int q = 0; q < PXG_N_SEGMENTS; q++) first[q] = last[q] = -1;
+            if (valid_read[c] && T[c] > 0) {
+                int prev = -1;
+#pragma unroll
+                for (int q = 0; q < PXG_MAX_STATES; q++) {
+                    const int en = (int)((fe[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu);
+                    if (q >= S || en == 0) continue;
+                    first[q] = en - 1;
+                    if (prev >= 0) last[prev] = en - 2;
+                    prev = q;
+                }
+                if (prev >= 0) last[prev] = T[c] - 1;
+                if (logp_out) logp_out[r[c]] = bestv;
+                if (status != nullptr && H.adapter_state >= 0 && first[H.adapter_state] < 0)
+                    status[r[c]] = PXG_ST_ADAPTER_NOT_DETECTED;
+            } else if (logp_out) {
+                logp_out[r[c]] = -__builtin_inf();
+            }
         }
     }
 }
