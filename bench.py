@@ -180,6 +180,11 @@ def main():
         'upload_s': round(t_upload, 4),
         'pcie_inclusive_reads_per_s': args.reads / (elapsed / args.steps + t_upload),
         'reads_ok': n_ok, 'reads_barcoded_window': n_pushed,
+        # calls against the barcode the generator planted (synth.py; -1 = no barcode signal)
+        'barcode_called': int((res['bc_called'] == 1).sum()),
+        'barcode_called_correct': int(((res['bc_called'] == 1) &
+                                       (res['bc_label'] == batch['barcode'])).sum()),
+        'barcode_planted': int((batch['barcode'] >= 0).sum()),
         'labels_gathered': int(len(labels)),
     }
 

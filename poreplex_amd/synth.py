@@ -33,7 +33,9 @@ PROTOTYPE_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'prese
 
 
 def load_prototypes():
-    """5 x 300 float32 z-score windows (row 0 = decoy, unused) or None."""
+    """5 x 300 float32 z-score windows (row 0 = decoy class, unused) or None.  Made by
+    tools/make_prototypes.py: windows the shipped demux net classifies with p > 0.995
+    (checked with the oracle), so synthetic reads carry callable barcodes."""
     if os.path.isfile(PROTOTYPE_FILE):
         return np.load(PROTOTYPE_FILE).astype(np.float32)
     return None
