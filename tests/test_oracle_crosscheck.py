@@ -112,6 +112,23 @@ def test_lstm_layer_vs_torch(oracle):
     assert np.array_equal(seq[-1], last)
 
 
+def test_whole_networks_vs_torch_modules(oracle, stages):
+    """poreplex_amd.torch_models (independent fp32 statement of the two Keras nets,
+    incl. the Bidirectional merge and the left zero padding) vs the oracle."""
+    torch = pytest.importorskip('torch')
+    from poreplex_amd.torch_models import DemuxNet, ScalerNet
+    with torch.no_grad():
+        wins = np.ascontiguousarray(stages['demux_in'][:6], dtype=np.float32)
+        want = np.exp(DemuxNet()(torch.from_numpy(wins)).numpy())
+        got = np.stack([oracle.demux_forward(w) for w in wins])
+        assert np.abs(got - want).max() < 1e-4            # north_star softmax tolerance
+        assert np.array_equal(got.argmax(1), want.argmax(1))
+        heads = np.ascontiguousarray(stages['scaler_in'][:4], dtype=np.float32)
+        want = ScalerNet()(torch.from_numpy(heads)).numpy()
+        got = np.stack([oracle.scaler_forward(h) for h in heads])
+        assert np.abs(got - want).max() < 2e-4
+
+
 def test_viterbi_vs_brute_force(oracle):
     """Exhaustive path enumeration for tiny T, both HMMs."""
     rng = np.random.default_rng(11)

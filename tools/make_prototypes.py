@@ -21,40 +21,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle.pxo import Oracle  # noqa: E402
 from poreplex_amd.config import default_config, load_model_arrays  # noqa: E402
+from poreplex_amd.torch_models import DemuxNet  # noqa: E402
 
 OUT = os.path.join(ROOT, 'poreplex_amd', 'presets', 'MIN106-RNA001',
                    'synthetic-barcode-prototypes.npy')
-
-
-def keras_lstm(kernel, recurrent, bias):
-    """torch.nn.LSTM carrying a Keras LSTM's weights (same i,f,g,o gate order)."""
-    m = torch.nn.LSTM(kernel.shape[0], recurrent.shape[0], batch_first=True)
-    with torch.no_grad():
-        m.weight_ih_l0.copy_(torch.from_numpy(kernel.T.copy()))
-        m.weight_hh_l0.copy_(torch.from_numpy(recurrent.T.copy()))
-        m.bias_ih_l0.copy_(torch.from_numpy(bias.copy()))
-        m.bias_hh_l0.zero_()
-    for p in m.parameters():
-        p.requires_grad_(False)
-    return m
-
-
-class DemuxNet(torch.nn.Module):
-    def __init__(self, w):
-        super().__init__()
-        self.fwd = keras_lstm(w['fwd_kernel'], w['fwd_recurrent'], w['fwd_bias'])
-        self.bwd = keras_lstm(w['bwd_kernel'], w['bwd_recurrent'], w['bwd_bias'])
-        self.top = keras_lstm(w['top_kernel'], w['top_recurrent'], w['top_bias'])
-        self.dk = torch.from_numpy(w['dense_kernel'].copy())
-        self.db = torch.from_numpy(w['dense_bias'].copy())
-
-    def forward(self, x):                       # x: [B, T]
-        x = x.unsqueeze(-1)
-        hf, _ = self.fwd(x)
-        hb, _ = self.bwd(torch.flip(x, dims=[1]))
-        h = torch.cat([hf, torch.flip(hb, dims=[1])], dim=-1)
-        _, (hn, _) = self.top(h)
-        return torch.log_softmax(hn[0] @ self.dk + self.db, dim=-1)
 
 
 def standardise(x):
@@ -68,7 +38,7 @@ def main():
     torch.manual_seed(922)
     cfg = default_config()
     w = load_model_arrays(cfg['demultiplexing']['demux_model'])
-    net = DemuxNet(w)
+    net = DemuxNet(cfg['demultiplexing']['demux_model'])
     orc = Oracle(cfg)
     T = int(cfg['demultiplexing']['signal_trim_length'])
     n_cls = w['dense_kernel'].shape[1]
