@@ -316,9 +316,10 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
 }
 
 // ===========================================================================
-// K2q: the same scaler network, TIME-SLICED.  With 512 < tiles < 1024 the static
-// split leaves 3 or 4 tiles on some CUs and 2 on the others (10 000 reads: 625 tiles
-// on 256 CUs -> 81 % busy; measured 13.3 ms static, 10.8 ms time-sliced).  Here every workgroup (2 per CU, all resident) pulls
+// K2q: the same scaler network, TIME-SLICED, used whenever there are more tiles than
+// resident workgroups.  The static split leaves whole tiles of imbalance (10 000 reads:
+// 625 tiles on 256 CUs -> 3 on some CUs, 2 on the others, 81 % busy; measured 13.3 ms
+// static, 10.7 ms time-sliced).  Here every workgroup (2 per CU, all resident) pulls
 // (step block, tile) tasks from a queue; a tile's LSTM state travels through HBM
 // between blocks (12.8 KB), so the tiles advance round-robin on the 2 x #CU slots and
 // the launch ends when the WORK runs out, not when the fullest CU does.  Tasks are
@@ -809,13 +810,16 @@ struct LstmGrid { int blocks, mtw; };
 
 static LstmGrid pick_grid(pxg_ctx* ctx, int64_t n_rows, int maxt = LSTM_MAXT)
 {
+    // 2 workgroups per CU are resident.  More tiles than that: launch a whole number of
+    // "rounds" of resident groups and spread the tiles evenly over them (my_tiles gives the
+    // first groups one tile more), instead of filling groups to maxt and leaving a last,
+    // nearly empty round: 6250 tiles (100 000 reads) = 2048 groups of 3-4 tiles, not 1563 of 4.
     const int64_t tiles = (n_rows + 15) / 16;
-    int64_t blocks = std::min<int64_t>(tiles, 2 * (int64_t)ctx->n_cu);   // 2 groups per CU
-    int64_t mtw = (tiles + blocks - 1) / blocks;
-    if (mtw > maxt) {                 // more than one round of groups
-        mtw = maxt;
-        blocks = (tiles + mtw - 1) / mtw;
-    }
+    const int64_t slots = 2 * (int64_t)ctx->n_cu;
+    if (tiles <= slots) return { (int)tiles, 1 };
+    const int64_t rounds = (tiles + slots * maxt - 1) / (slots * maxt);
+    const int64_t blocks = rounds * slots;
+    const int64_t mtw = (tiles + blocks - 1) / blocks;
     return { (int)blocks, (int)mtw };
 }
 
@@ -868,8 +872,9 @@ int pxg_launch_scaler_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
     const LstmGrid g = pick_grid(ctx, n_rows);
     const PxgLstmDev &l1 = ctx->scaler1, &l2 = ctx->scaler2;
     const int64_t tiles = (n_rows + 15) / 16, slots = 2 * (int64_t)ctx->n_cu;
-    if (tiles > slots && tiles < 2 * slots && !getenv("PXG_NO_TIMESLICE")) {
-        // between 1 and 2 tiles per resident workgroup: time-slice (see k_scaler_lstm_q)
+    if (tiles > slots && !getenv("PXG_NO_TIMESLICE")) {
+        // more tiles than resident workgroups: time-slice (see k_scaler_lstm_q); measured against
+        // the static split: 10 000 reads 13.3 -> 10.7 ms, 50 000 reads 75 -> 51, 100 000 reads 131 -> 101
         const int n_blocks = (T + 1 + QBS - 1) / QBS;
         int rc;
         if ((rc = pxg_timeslice_prepare(ctx)) || (rc = pxg_reserve(ctx, ctx->lstm_q, (size_t)(2 + tiles))) ||
