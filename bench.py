@@ -41,7 +41,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--reads', type=int, default=10000, help='reads per GPU per step')
     ap.add_argument('--samples', type=int, default=60000, help='nominal samples per read')
-    ap.add_argument('--workload', choices=['demux', 'segment', 'polya', 'chimera'], default='demux')
+    ap.add_argument('--workload', choices=['demux', 'segment', 'polya', 'chimera', 'full'], default='demux')
     ap.add_argument('--cpu-sample', type=int, default=1024,
                     help='reads timed on the host for cpu_baseline (0 = skip)')
     ap.add_argument('--check', type=int, default=64, help='reads compared with the oracle')
@@ -84,6 +84,8 @@ def main():
         mask, inject = N.STAGE_ALL_DEMUX | N.STAGE_POLYA, None
     elif args.workload == 'chimera':
         mask, inject = N.STAGE_ALL_DEMUX, None
+    elif args.workload == 'full':            # configs[3]: + poly(A) + pseudo-fusion scan
+        mask, inject = N.STAGE_ALL_DEMUX | N.STAGE_POLYA, None
     else:
         mask, inject = N.STAGE_SEGMENT, batch['scale_shift']
     # --filter-chimera: Guppy block frame of every read (first sample 0, stride 15)
@@ -92,7 +94,7 @@ def main():
 
     def step():
         ctx.run(mask)
-        if args.workload == 'chimera':
+        if args.workload in ('chimera', 'full'):
             ctx.unsplit_scan(ev_first, ev_blocks)
     t_up0 = time.perf_counter()
     ctx.upload(batch['arena'], batch['offsets'], batch['calib'], inject)
@@ -146,7 +148,7 @@ def main():
     n_pushed = int(res['bc_pushed'].sum())
 
     # ---- roofline of the dominant kernel ------------------------------------
-    if args.workload in ('demux', 'polya', 'chimera'):
+    if args.workload in ('demux', 'polya', 'chimera', 'full'):
         dur = stage_ms['scaler_lstm'] * 1e-3
         flops = n_scaled * FLOP_SCALER
         tiles, slots = (n_scaled + 15) // 16, 2 * info['compute_units']
@@ -220,7 +222,7 @@ def main():
         c0 = time.perf_counter()
         want = orc.process_batch(batch['arena'][:o[-1]], o, batch['calib'][:ns], inj, mask)
         cand_mismatch = None
-        if args.workload == 'chimera':
+        if args.workload in ('chimera', 'full'):
             iv, cnt = ctx.unsplit_scan(ev_first, ev_blocks)
             cand_mismatch = 0
             for i in range(ns):
@@ -255,16 +257,18 @@ def main():
     line = {
         'metric': {'demux': 'reads/s (segment+barcode)', 'polya': 'reads/s (segment+barcode+polyA)',
                    'chimera': 'reads/s (segment+barcode+chimera filter)',
+                   'full': 'reads/s (segment+barcode+polyA+chimera filter)',
                    'segment': 'reads/s (normalise+segment)'}[args.workload],
         'value': value, 'unit': 'reads/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32 (LSTM MFMA) / f64 (Viterbi) / i16 in', 'data': 'synthetic',
         'config': {'workload': 'BASELINE configs[{}]: {} reads/GPU x ~{} int16 samples, stages {}'.format(
-                       {'demux': 2, 'polya': 3, 'chimera': 3, 'segment': 1}[args.workload], args.reads, args.samples,
+                       {'demux': 2, 'polya': 3, 'chimera': 3, 'full': 3, 'segment': 1}[args.workload], args.reads, args.samples,
                        {'demux': 'a1-a13 (scaler LSTM + Viterbi + barcode LSTMs)',
                         'polya': 'a1-a17 (+ poly(A) events/DP)',
                         'chimera': 'a1-a13 + a18/a19 (Guppy block means + window scan)',
+                        'full': 'a1-a19 (+ poly(A) + Guppy block means + window scan)',
                         'segment': 'a1,a5,a7,a8 (injected scaling)'}[args.workload]),
                    'reads_per_gpu': args.reads, 'samples_per_read': args.samples,
                    'parallelism': 'reads sharded x{}'.format(world), 'device': info['name'],
