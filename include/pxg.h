@@ -11,7 +11,8 @@
  * GPU.  Each entry point cites the reference code it replaces.
  *
  * Conventions (mirroring src/csupport.c:92-121): caller owns every host
- * buffer; nothing is retained after return; functions return 0 or a negative
+ * buffer; nothing is retained after return (one exception: the arrays handed
+ * to pxg_batch_stage are read until pxg_batch_swap returns); functions return 0 or a negative
  * pxg_error and never throw; per-read domain failures are DATA (the `status`
  * field), not errors.  A context is bound to one GPU and one host thread.
  * Plain pointers and sizes only -- no torch / HIP types in any signature.

@@ -341,8 +341,8 @@ static int check_supported(pxg_ctx* ctx, int which)
 {
     const PxgHmmDev& H = ctx->hmm[which];
     if (!H.left_to_right) {
-        ctx->err = "Viterbi kernel: HMM is not left-to-right (back-edges need the "
-                   "back-pointer kernel, not built yet)";
+        ctx->err = "Viterbi kernel: HMM is not left-to-right (models with back-edges run through "
+                   "the back-pointer scan of pxg_batch_unsplit_scan)";
         return PXG_E_UNSUPPORTED;
     }
     if (ctx->cfg.segmentation_scan_limit / ctx->cfg.stride >= 65535) {
