@@ -564,19 +564,40 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir(
         for (int nt = 0; nt < NT; nt++) cf[m][nt] = cb[m][nt] = 0.0f;
     __syncthreads();
 
+    // streaming of the hidden rows to HBM: the (row, direction, float4) a thread moves every
+    // step is fixed, so the index arithmetic is done once (it was ~20 % of this kernel's VALU work)
+    constexpr int NST = (MTW * 16 * 2 * (H / 4) + LSTM_THREADS - 1) / LSTM_THREADS;
+    int st_src[NST];              // LDS float offset inside one (buffer, direction) plane, -1: idle
+    int st_dir[NST];
+    float* st_dst[NST];           // bidir + (rd * T) * 2H + dir * H + c4 * 4
+#pragma unroll
+    for (int p = 0; p < NST; p++) {
+        const int i = tid + p * LSTM_THREADS;
+        st_src[p] = -1; st_dir[p] = 0; st_dst[p] = bidir;
+        if (i < 16 * ntile * 2 * (H / 4)) {
+            const int c4 = i % (H / 4);
+            const int dir = (i / (H / 4)) & 1;
+            const int row = i / (2 * (H / 4));
+            const int rd = ridx[row];
+            if (rd >= 0) {
+                st_src[p] = ((row >> 4) * 16 + (row & 15)) * HS + c4 * 4;
+                st_dir[p] = dir;
+                st_dst[p] = bidir + ((size_t)rd * T) * (2 * H) + dir * H + c4 * 4;
+            }
+        }
+    }
+
     for (int t = 0; t <= T; t++) {
         const int rdb = t & 1, wrb = (t + 1) & 1;
         if (t >= 1) {    // stream the rows written in the previous step to HBM
             const int tf = t - 1, tb = T - t;
-            for (int i = tid; i < 16 * ntile * 2 * (H / 4); i += LSTM_THREADS) {
-                const int c4 = i % (H / 4);
-                const int dir = (i / (H / 4)) & 1;
-                const int row = i / (2 * (H / 4));
-                const int rd = ridx[row];
-                if (rd < 0) continue;
-                const float* src = (dir ? hb : hf) + ((rdb * MTW + (row >> 4)) * 16 + (row & 15)) * HS + c4 * 4;
-                float* dst = bidir + ((size_t)rd * T + (dir ? tb : tf)) * (2 * H) + dir * H + c4 * 4;
-                *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+#pragma unroll
+            for (int p = 0; p < NST; p++) {
+                if (st_src[p] >= 0) {
+                    const float* src = (st_dir[p] ? hb : hf) + rdb * MTW * 16 * HS + st_src[p];
+                    float* dst = st_dst[p] + (size_t)(st_dir[p] ? tb : tf) * (2 * H);
+                    *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+                }
             }
         }
         if (t == T) break;
@@ -695,24 +716,35 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
     }
     __syncthreads();
 
+    // per-thread constants of the input prefetch (fixed (row, float4) per thread: no index
+    // arithmetic inside the step loop)
+    constexpr int NPF = (MTW * 16 * (2 * HI / 4) + LSTM_THREADS - 1) / LSTM_THREADS;
+    const float* pf_src[NPF];     // bidir + (rd * T) * 2HI + c4 * 4, nullptr: idle / padding row
+    int pf_dst[NPF];              // LDS float offset inside one input buffer, -1: idle
+#pragma unroll
+    for (int p = 0; p < NPF; p++) {
+        const int i = tid + p * LSTM_THREADS;
+        pf_src[p] = nullptr;
+        pf_dst[p] = -1;
+        if (i < n_f4) {
+            const int row = i / (2 * HI / 4), c4 = i % (2 * HI / 4);
+            const int rd = ridx[row];
+            pf_dst[p] = row * IS + c4 * 4;
+            if (rd >= 0) pf_src[p] = bidir + ((size_t)rd * T) * (2 * HI) + c4 * 4;
+        }
+    }
+
     for (int t = 0; t < T; t++) {
         const int rdb = t & 1, wrb = (t + 1) & 1;
         // next step's input rows: issue the global loads now, park them in
         // registers while the MFMAs run, write them to the other LDS buffer
         // just before the barrier
-        constexpr int NPF = (MTW * 16 * (2 * HI / 4) + LSTM_THREADS - 1) / LSTM_THREADS;
         float4 pf[NPF];
 #pragma unroll
         for (int p = 0; p < NPF; p++) {
-            const int i = tid + p * LSTM_THREADS;
             pf[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < n_f4 && t + 1 < T) {
-                const int row = i / (2 * HI / 4), c4 = i % (2 * HI / 4);
-                const int rd = ridx[row];
-                if (rd >= 0)
-                    pf[p] = *reinterpret_cast<const float4*>(
-                        bidir + ((size_t)rd * T + t + 1) * (2 * HI) + c4 * 4);
-            }
+            if (pf_src[p] != nullptr && t + 1 < T)
+                pf[p] = *reinterpret_cast<const float4*>(pf_src[p] + (size_t)(t + 1) * (2 * HI));
         }
 #pragma unroll
         for (int m = 0; m < MTW; m++) {
@@ -763,13 +795,9 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
             }
         }
 #pragma unroll
-        for (int p = 0; p < NPF; p++) {
-            const int i = tid + p * LSTM_THREADS;
-            if (i < n_f4) {
-                const int row = i / (2 * HI / 4), c4 = i % (2 * HI / 4);
-                *reinterpret_cast<float4*>(inb + (wrb * MTW * 16 + row) * IS + c4 * 4) = pf[p];
-            }
-        }
+        for (int p = 0; p < NPF; p++)
+            if (pf_dst[p] >= 0)
+                *reinterpret_cast<float4*>(inb + wrb * MTW * 16 * IS + pf_dst[p]) = pf[p];
         __syncthreads();
     }
     // ---- Dense(n_classes) + softmax ----------------------------------------
