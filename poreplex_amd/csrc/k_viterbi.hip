@@ -73,18 +73,21 @@ __device__ __forceinline__ void ent_stamp(unsigned (&e)[4], int q, unsigned val1
 
 #define EM_STRIDE (VIT_CHUNK * PXG_MAX_STATES + 8)   // +8 doubles: spread reads over banks
 
-// value of the lane `k` below inside a 16-lane row (DPP row_shr:k)
+// value of the lane `k` below inside a 16-lane row (DPP row_shr:k).  bound_ctrl: a lane
+// whose source falls outside the row reads 0 -- such a lane has no edge of that span
+// (lpk = -inf), so the value is never used, and the instruction needs no copy of an
+// "old" operand (that copy was 10 of the ~66 instructions of a recurrence step).
 template <typename T>
 __device__ __forceinline__ int dpp_shr_i32(int v, T k)
 {
     switch (k) {
-    case 1: return __builtin_amdgcn_update_dpp(v, v, 0x111, 0xF, 0xF, false);
-    case 2: return __builtin_amdgcn_update_dpp(v, v, 0x112, 0xF, 0xF, false);
-    case 3: return __builtin_amdgcn_update_dpp(v, v, 0x113, 0xF, 0xF, false);
-    case 4: return __builtin_amdgcn_update_dpp(v, v, 0x114, 0xF, 0xF, false);
-    case 5: return __builtin_amdgcn_update_dpp(v, v, 0x115, 0xF, 0xF, false);
-    case 6: return __builtin_amdgcn_update_dpp(v, v, 0x116, 0xF, 0xF, false);
-    default: return __builtin_amdgcn_update_dpp(v, v, 0x117, 0xF, 0xF, false);
+    case 1: return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true);
+    case 2: return __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true);
+    case 3: return __builtin_amdgcn_update_dpp(0, v, 0x113, 0xF, 0xF, true);
+    case 4: return __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true);
+    case 5: return __builtin_amdgcn_update_dpp(0, v, 0x115, 0xF, 0xF, true);
+    case 6: return __builtin_amdgcn_update_dpp(0, v, 0x116, 0xF, 0xF, true);
+    default: return __builtin_amdgcn_update_dpp(0, v, 0x117, 0xF, 0xF, true);
     }
 }
 __device__ __forceinline__ unsigned dpp_shr_u32(unsigned v, int k) { return (unsigned)dpp_shr_i32((int)v, k); }
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
                         v[c] = lstart + e;
 #pragma unroll
                         for (int w = 0; w < NW; w++)
-                            ent[c][w] = (ent[c][w] & keep[w]) | ((1u << stamp_sh) & put[w]);
+                            ent[c][w] = pxg_bfi(put[w], 1u << stamp_sh, ent[c][w]);
                     }
                 } else {
                     double best = v[c] + lpk[0];    // span 0 = self loop (or -inf)
@@ -264,8 +267,10 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
                     for (int k = 1; k < PXG_MAX_STATES; k++) {
                         if ((SPANS >> k) & 1u) {
                             const double cand = vs[k] + lpk[k];
+                            // three plain compares into SGPR masks (the short-circuit form
+                            // compiled into nested exec-mask branches)
                             const unsigned long long take =
-                                __ballot((cand > best) || (cand == best && prk[k] < bpr));
+                                __ballot(cand > best) | (__ballot(cand == best) & __ballot(prk[k] < bpr));
                             best = pxg_sel_f64(take, best, cand);
                             bd = (int)pxg_sel_u32(take, (unsigned)bd, (unsigned)k);
                             bpr = (int)pxg_sel_u32(take, (unsigned)bpr, (unsigned)prk[k]);
@@ -288,7 +293,7 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
                     const unsigned stamp = (unsigned)(t + 1) << stamp_sh;
 #pragma unroll
                     for (int w = 0; w < NW; w++)
-                        ent[c][w] = pxg_sel_u32(mmove, ent[c][w], (ne[w] & keep[w]) | (stamp & put[w]));
+                        ent[c][w] = pxg_sel_u32(mmove, ent[c][w], pxg_bfi(put[w], stamp, ne[w]));
                 }
             }
         }

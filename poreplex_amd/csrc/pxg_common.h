@@ -107,6 +107,15 @@ __device__ __forceinline__ double pxg_sel_f64(unsigned long long take, double if
     return __hiloint2double((int)hi, (int)lo);
 }
 
+// (mask & a) | (~mask & b) in one instruction
+__device__ __forceinline__ unsigned pxg_bfi(unsigned mask, unsigned a, unsigned b)
+{
+    unsigned d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "v"(b));
+    return d;
+}
+
+
 // DAQ counts -> pA (fast5_file.py:130-131): float64 product, one cast.
 __device__ __forceinline__ float pxg_raw2pa(int16_t raw, double k, double offset)
 {
