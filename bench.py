@@ -54,6 +54,12 @@ def parse():
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON: libraries print there too (RCCL writes a
+    # version banner to stdout when the first communicator comes up), so fd 1 is pointed at
+    # stderr for the whole run and the JSON goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -280,7 +286,7 @@ def main():
                    'arch': info['arch'], 'compute_units': info['compute_units']},
         'roofline': roofline, 'cpu_baseline': cpu, 'concordance': concordance, 'extra': extra,
     }
-    print(json.dumps(line))
+    os.write(json_fd, (json.dumps(line) + '\n').encode())
     if dist is not None:
         dist.destroy_process_group()
 
