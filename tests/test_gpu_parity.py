@@ -466,3 +466,51 @@ def test_staged_double_buffered_batches(ctx, oracle):
         ctx.unpin(pinned)
     with pytest.raises(N.PxgError):
         ctx.swap()                                  # nothing staged
+
+
+def test_structured_reads_around_every_length_threshold(ctx, oracle):
+    """Real-looking reads cut at / around every length rule of the path: the scaler gate
+    (9 000), the head window (30 000), the segmentation scan limit (100 000 samples =
+    6 666 pooled), reads that end inside the adapter or the poly(A) tail, adapters shorter
+    than minimum_dna_length (260 pooled) and longer than maximum_dna_length (3 000), all
+    stages incl. poly(A), and the chimera scan on top."""
+    sb = synth_batch(24, seed=8642, samples_per_read=130000, jitter=0.02)
+    o, tr = sb['offsets'], sb['truth']
+    reads, calib = [], []
+    cuts = [8999, 9000, 9014, 29999, 30000, 30001, 99999, 100000, 100001, 100014, 100015, 129990]
+    for i, c in enumerate(cuts):
+        reads.append(sb['arena'][o[i]:o[i] + c])
+        calib.append(sb['calib'][i])
+    for i in range(12, 18):          # cut inside the adapter / the poly(A) tail / right after it
+        a_beg, a_end, p_end = int(tr[i, 3, 0]), int(tr[i, 3, 1]), int(tr[i, 4, 1])
+        for c in (a_beg + 260 * 15 - 15, a_beg + 260 * 15 + 15, a_end - 30, a_end + 7, p_end - 45, p_end + 15):
+            reads.append(sb['arena'][o[i]:o[i] + max(c, 9100)])
+            calib.append(sb['calib'][i])
+    # a very long adapter (> 3 000 pooled): splice an adapter piece in several times
+    i = 20
+    a_beg, a_end = int(tr[i, 3, 0]), int(tr[i, 3, 1])
+    piece = sb['arena'][o[i] + a_beg:o[i] + a_end]
+    reads.append(np.concatenate([sb['arena'][o[i]:o[i] + a_beg]] + [piece] * 8 +
+                                [sb['arena'][o[i] + a_end:o[i + 1]]]))
+    calib.append(sb['calib'][i])
+    arena, off = N.pack_reads(reads)
+    calib = np.array(calib, dtype=N.CALIB_DTYPE)
+    mask = N.STAGE_ALL_DEMUX | N.STAGE_POLYA
+    want, wsp = oracle.process_batch(arena, off, calib, None, mask, want_spikes=True)
+    ctx.upload(arena, off, calib)
+    ctx.run(mask)
+    got = ctx.download()
+    assert_records_equal(got, want, ctxmsg='thresholds')
+    assert np.array_equal(ctx.download_spikes(), wsp, equal_nan=True)
+    assert len(set(got['status'].tolist())) >= 2 and (got['bc_pushed'] == 0).any() and (got['bc_pushed'] == 1).any()
+    first = np.zeros(len(reads), np.int64)
+    nb = np.diff(off) // 15
+    iv, cnt = ctx.unsplit_scan(first, nb)
+    a = 3
+    for r in range(len(reads)):
+        if got[r]['status'] != 0 or got[r]['seg_first'][a] < 0:
+            assert cnt[r] == 0
+            continue
+        _, sc = oracle.guppy_event_means(reads[r], calib[r], 0, int(nb[r]), got[r]['scale'], got[r]['shift'])
+        wiv, wc = oracle.unsplit_scan(sc, 0, (int(got[r]['seg_last'][a]) + 1) * 15, 3012.0)
+        assert cnt[r] == wc and iv[r, :min(wc, N.PXG_MAX_UNSPLIT)].tolist() == wiv.tolist(), r
