@@ -1,19 +1,27 @@
 #!/usr/bin/env python
 """bench.py -- reads/s of the raw-signal hot path (segment + barcode) on MI355X.
 
-Contract (driver): python bench.py --gpus N --steps K --warmup W; for N>1 it
-is launched by torch.distributed.run, one rank per GPU.  A "step" is one pass
-of the hot path (head pool -> scaler LSTM -> pool+scale+Viterbi -> barcode
-window -> demux LSTMs -> result records) over one resident batch of synthetic
-reads; inputs are in HBM before the timed region.  Rank 0 prints ONE JSON line.
+Contract (driver): python bench.py --gpus N --steps K --warmup W.  With N > 1 and no
+WORLD_SIZE in the environment this script re-launches itself under torch.distributed.run
+(one rank per GPU over RCCL); launched by torch.distributed.run it reads RANK / LOCAL_RANK /
+WORLD_SIZE.  A "step" is one pass of the hot path (head pool -> scaler LSTM -> pool + scale +
+Viterbi -> barcode window -> demux LSTMs -> result records, + D2H of the records, + the RCCL
+label all-gather for N > 1) over one resident batch of synthetic reads; inputs are in HBM
+before the timed region.  Rank 0 prints ONE JSON line on stdout.
 
-Workload = BASELINE.json configs[2] (the config the metric "reads/s
-(segment+barcode)" is quoted on): a 10 000-read batch of ~60 000-sample reads
-per GPU, all stages a1-a13.  `--workload segment` runs configs[1] instead.
+Workload = BASELINE.json configs[2] (the config the metric "reads/s (segment+barcode)" is
+quoted on): a 10 000-read batch of ~60 000-sample reads per GPU, all stages a1-a13.
+  --workload segment|polya|chimera|full   configs[1] / configs[3] stage sets
+  --scaling strong --total-reads 1000000  configs[4]: ONE seeded run sharded over the ranks
+  --base-reads K                          K distinct synthetic reads, tiled on the device into
+                                          the resident batch (automatic for big batches:
+                                          configs[3] is 12 GB and configs[4] 15 GB of int16
+                                          per GPU, never materialised on the host)
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -24,6 +32,8 @@ sys.path.insert(0, ROOT)
 
 from poreplex_amd import native as N  # noqa: E402
 from poreplex_amd.config import default_config  # noqa: E402
+from poreplex_amd.distributed import (gather_labels, gather_labels_start,  # noqa: E402
+                                      shard_range)
 from poreplex_amd.synth import synth_batch  # noqa: E402
 
 # algorithmic work per read (SURVEY.md 8d / DESIGN.md "Roofline accounting")
@@ -32,28 +42,139 @@ FLOP_BIDIR = 2.0 * 300 * 2 * (48 * 192) + 300 * 2 * 192 * 2
 FLOP_TOP = 2.0 * 300 * (160 * 256) + 2 * 64 * 5
 PEAK_FP32_MFMA = 157.3e12      # MI355X_MICROARCH.md: dense fp32 MFMA peak, FLOP/s
 PEAK_HBM = 8.0e12              # B/s
+# the only throughput the reference publishes (Poreplex 0.1, whole
+# pipeline incl. FAST5 I/O, 2x Xeon E5-2687W v3 = 20 cores): 1 339 070 reads in 1 h 37 min
+PUBLISHED_READS_PER_S = 1339070 / (97 * 60.0)
+TRAFFIC_FILE = os.path.join('profiles', 'r02', 'hbm_traffic.json')
+
+STAGES = {
+    'demux': (2, 'a1-a13 (scaler LSTM + Viterbi + barcode LSTMs)', 'reads/s (segment+barcode)'),
+    'segment': (1, 'a1,a5,a7,a8 (injected scaling)', 'reads/s (normalise+segment)'),
+    'polya': (3, 'a1-a17 (+ poly(A) events/DP)', 'reads/s (segment+barcode+polyA)'),
+    'chimera': (3, 'a1-a13 + a18/a19 (Guppy block means + window scan)',
+                'reads/s (segment+barcode+chimera filter)'),
+    'full': (3, 'a1-a19 (+ poly(A) + Guppy block means + window scan)',
+             'reads/s (segment+barcode+polyA+chimera filter)'),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--reads', type=int, default=10000, help='reads per GPU per step')
+    ap.add_argument('--reads', type=int, default=10000, help='reads per GPU per step (weak scaling)')
     ap.add_argument('--samples', type=int, default=60000, help='nominal samples per read')
-    ap.add_argument('--workload', choices=['demux', 'segment', 'polya', 'chimera', 'full'], default='demux')
+    ap.add_argument('--workload', choices=sorted(STAGES), default='demux')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak')
+    ap.add_argument('--total-reads', type=int, default=1000000,
+                    help='--scaling strong: reads of the whole run, sharded over the ranks')
+    ap.add_argument('--base-reads', type=int, default=-1,
+                    help='distinct reads generated on the host and tiled on the device '
+                         '(0 = every read distinct; -1 = 0 up to 16384 reads per GPU, else 2048)')
     ap.add_argument('--cpu-sample', type=int, default=1024,
-                    help='reads timed on the host for cpu_baseline (0 = skip)')
-    ap.add_argument('--check', type=int, default=64, help='reads compared with the oracle')
+                    help='reads timed on ONE host core for cpu_baseline (0 = skip)')
+    ap.add_argument('--cpu-all-cores-sample', type=int, default=4096,
+                    help='reads timed over all physical cores, one process each (0 = skip)')
     ap.add_argument('--seed', type=int, default=924)
     ap.add_argument('--no-overlap-test', action='store_true',
                     help='skip the extra PCIe-overlapped steps (profiling runs: keeps the kernel '
                          'statistics to the timed steps)')
-    return ap.parse_args()
+    ap.add_argument('--context-factory', default=None,
+                    help='TEST SEAM (module:attr): CPU rendezvous tests of the multi-rank driver '
+                         'inject a stand-in context; the line then says data=TEST-STANDIN, value=null')
+    return ap.parse_args(argv)
+
+
+def respawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: become N ranks under
+    torch.distributed.run (the reference's process-level data parallelism,
+    pipeline.py:96,204-205, one worker process per device)."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node={}'.format(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
+def host_description():
+    model = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False) or os.cpu_count()
+    except ImportError:
+        physical = os.cpu_count()
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
+    return model, int(physical), int(usable)
+
+
+# ---- CPU baseline over all cores: one process per physical core, read shards ----------
+_POOL = {}
+
+
+def _cpu_worker_init(config, base, mask, use_inject):
+    from oracle.pxo import Oracle
+    _POOL.update(oracle=Oracle(config), base=base, mask=mask, use_inject=use_inject)
+
+
+def _cpu_worker_run(read_ids):
+    b = _POOL['base']
+    o = b['offsets']
+    parts = [b['arena'][o[i]:o[i + 1]] for i in read_ids]
+    arena, off = N.pack_reads(parts)
+    inj = b['scale_shift'][read_ids] if _POOL['use_inject'] else None
+    t0 = time.perf_counter()
+    _POOL['oracle'].process_batch(arena, off, b['calib'][read_ids], inj, _POOL['mask'])
+    return time.perf_counter() - t0
+
+
+def cpu_all_cores(config, base, mask, use_inject, n_sample):
+    """The reference's own deployment shape on the CPU: ProcessPoolExecutor(config['parallel'])
+    (pipeline.py:96), every worker process running whole reads.  Must run BEFORE the HIP
+    runtime is initialised in this process (fork)."""
+    import multiprocessing as mp
+    model, physical, usable = host_description()
+    workers = max(1, min(physical, usable))
+    n_base = len(base['offsets']) - 1
+    n = max(n_sample, 96 * workers)                        # ~0.7 s of work per core at least
+    ids = np.arange(n) % n_base
+    shards = [ids[w::workers] for w in range(workers)]
+    ctx = mp.get_context('fork')
+    with ctx.Pool(workers, initializer=_cpu_worker_init,
+                  initargs=(config, base, mask, use_inject)) as pool:
+        pool.map(_cpu_worker_run, [s[:2] for s in shards])     # warm: library loaded, pages touched
+        t0 = time.perf_counter()
+        busy = pool.map(_cpu_worker_run, shards)
+        wall = time.perf_counter() - t0
+    return {'value': n / wall, 'unit': 'reads/s', 'cores': workers, 'reads': int(n),
+            'wall_s': round(wall, 3), 'per_core': n / wall / workers,
+            'slowest_worker_s': round(max(busy), 3)}
+
+
+def make_context(args, config, local_rank):
+    if args.context_factory:
+        import importlib
+        mod, attr = args.context_factory.split(':')
+        return getattr(importlib.import_module(mod), attr)(config, device_id=local_rank)
+    return N.NativeContext(config, device_id=local_rank)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        respawn_ranks(args)
     # stdout carries exactly ONE line, the JSON: libraries print there too (RCCL writes a
     # version banner to stdout when the first communicator comes up), so fd 1 is pointed at
     # stderr for the whole run and the JSON goes to the saved descriptor
@@ -63,6 +184,46 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus != world:
+        raise SystemExit('bench.py: --gpus {} but WORLD_SIZE {} (launch with --nproc-per-node {} '
+                         'or without a launcher)'.format(args.gpus, world, args.gpus))
+    standin = args.context_factory is not None
+    config = default_config()
+    wl_cfg, wl_stages, wl_metric = STAGES[args.workload]
+    mask = {'demux': N.STAGE_ALL_DEMUX, 'chimera': N.STAGE_ALL_DEMUX,
+            'polya': N.STAGE_ALL_DEMUX | N.STAGE_POLYA, 'full': N.STAGE_ALL_DEMUX | N.STAGE_POLYA,
+            'segment': N.STAGE_SEGMENT}[args.workload]
+    use_inject = args.workload == 'segment'
+    scan = args.workload in ('chimera', 'full')
+
+    # ---- this rank's shard of ONE global run (reads are independent units: contiguous
+    # blocks by rank; read_index is global) --------------------------------------
+    if args.scaling == 'strong':
+        total = args.total_reads
+        lo, hi = shard_range(total, rank, world)
+    else:
+        total = args.reads * world
+        lo, hi = rank * args.reads, (rank + 1) * args.reads
+    n_local = hi - lo
+    shard_sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0]
+                   if args.scaling == 'strong' else args.reads for r in range(world)]
+    n_base = args.base_reads if args.base_reads >= 0 else (0 if max(shard_sizes) <= 16384 else 2048)
+    t_gen = time.perf_counter()
+    if n_base:      # K distinct reads (same on every rank), global read i = base read i % K
+        base = synth_batch(n_base, seed=args.seed, samples_per_read=args.samples)
+        which = (lo + np.arange(n_local)) % n_base
+    else:           # every read distinct: rank r draws its own block of the run
+        base = synth_batch(n_local, seed=args.seed + 1000 * rank, samples_per_read=args.samples)
+        which = np.arange(n_local)
+    t_gen = time.perf_counter() - t_gen
+    lens = np.diff(base['offsets'])[which]
+    inject = base['scale_shift'] if use_inject else None
+
+    # ---- CPU baseline over all cores: before anything touches the HIP runtime (fork) --------
+    cpu_all = None
+    if rank == 0 and world == 1 and args.cpu_all_cores_sample > 0 and not standin:
+        cpu_all = cpu_all_cores(config, base, mask, use_inject, args.cpu_all_cores_sample)
+
     dist = None
     # PXG_BENCH_FORCE_DIST=1 takes the multi-rank path (torch + RCCL initialised before the
     # HIP library, collectives issued) with a single rank: the way the N>1 path is validated
@@ -72,56 +233,46 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29531')
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local_rank))
-    if args.gpus != world and rank == 0 and world > 1:
-        print('warning: --gpus {} but WORLD_SIZE {}'.format(args.gpus, world), file=sys.stderr)
+        if standin:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', rank=rank, world_size=world,
+                                    device_id=torch.device('cuda', local_rank))
 
-    config = default_config()
-    ctx = N.NativeContext(config, device_id=local_rank)
+    ctx = make_context(args, config, local_rank)
     info = ctx.device_info()
 
-    # every rank draws its own shard of the synthetic run (reads are independent
-    # units: contiguous blocks by rank)
-    batch = synth_batch(args.reads, seed=args.seed + 1000 * rank, samples_per_read=args.samples)
-    if args.workload == 'demux':
-        mask, inject = N.STAGE_ALL_DEMUX, None
-    elif args.workload == 'polya':
-        mask, inject = N.STAGE_ALL_DEMUX | N.STAGE_POLYA, None
-    elif args.workload == 'chimera':
-        mask, inject = N.STAGE_ALL_DEMUX, None
-    elif args.workload == 'full':            # configs[3]: + poly(A) + pseudo-fusion scan
-        mask, inject = N.STAGE_ALL_DEMUX | N.STAGE_POLYA, None
-    else:
-        mask, inject = N.STAGE_SEGMENT, batch['scale_shift']
     # --filter-chimera: Guppy block frame of every read (first sample 0, stride 15)
-    ev_first = np.zeros(args.reads, dtype=np.int64)
-    ev_blocks = np.diff(batch['offsets']) // 15
+    ev_first = np.zeros(n_local, dtype=np.int64)
+    ev_blocks = lens // 15
 
     def step():
         ctx.run(mask)
-        if args.workload in ('chimera', 'full'):
+        if scan:
             ctx.unsplit_scan(ev_first, ev_blocks)
     t_up0 = time.perf_counter()
-    ctx.upload(batch['arena'], batch['offsets'], batch['calib'], inject)
+    if n_base:
+        ctx.upload_tiled(n_local, base['arena'], base['offsets'], base['calib'], inject,
+                         phase=lo % n_base)
+    else:
+        ctx.upload(base['arena'], base['offsets'], base['calib'], inject)
     t_upload = time.perf_counter() - t_up0
 
     def barrier():
         ctx.sync()
         if dist is not None:
-            import torch
             dist.barrier()
-            torch.cuda.synchronize()
+            if not standin:
+                import torch
+                torch.cuda.synchronize()
 
-    from poreplex_amd.distributed import gather_labels, gather_labels_start
-    shard_sizes = [args.reads] * world          # static sharding: every rank owns args.reads reads
     for _ in range(args.warmup):
         step()
         res = ctx.download()
-        gather_labels(res, dist, sizes=shard_sizes, force=force_dist)
+        gather_labels(res, dist, first_index=lo, sizes=shard_sizes, force=force_dist)
     barrier()
     stage_acc = {k: 0.0 for k in N.TIMER_NAMES}
     t0 = time.perf_counter()
@@ -132,20 +283,22 @@ def main():
             labels = pending()
         res = ctx.download()             # D2H of the result records is part of a step
         # RCCL all-gather of the label records (N>1), asynchronous on RCCL's stream
-        pending = gather_labels_start(res, dist, sizes=shard_sizes, force=force_dist)
+        pending = gather_labels_start(res, dist, first_index=lo, sizes=shard_sizes, force=force_dist)
         times, _ = ctx.stage_times()
         for k in stage_acc:
             stage_acc[k] += times[k]
     labels = pending()
     barrier()
     elapsed = time.perf_counter() - t0
+    n_ranks = 1
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    total_reads = args.reads * world * args.steps
-    value = total_reads / elapsed
+        t = torch.tensor([elapsed, 1.0], dtype=torch.float64,
+                         device='cpu' if standin else 'cuda')
+        dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)     # ranks that took part, counted by RCCL
+        elapsed, n_ranks = float(t[0].item()), int(round(t[1].item()))
+    value = total * args.steps / elapsed
 
     if rank != 0:
         if dist is not None:
@@ -155,101 +308,131 @@ def main():
     n_ok = int((res['status'] == 0).sum())
     n_scaled = int((res['status'] != N.STATUS_CODE['scaler_signal_too_short']).sum())
     n_pushed = int(res['bc_pushed'].sum())
+    truth_barcode = base['barcode'][which]
 
     # ---- roofline of the dominant kernel ------------------------------------
-    if args.workload in ('demux', 'polya', 'chimera', 'full'):
+    if args.workload != 'segment':
         dur = stage_ms['scaler_lstm'] * 1e-3
         flops = n_scaled * FLOP_SCALER
-        tiles, slots = (n_scaled + 15) // 16, 2 * info['compute_units']
-        roofline = {'kernel': 'k_scaler_lstm_q' if slots < (args.reads + 15) // 16 < 2 * slots
-                    else 'k_scaler_lstm', 'bound': 'mfma',
-                    'achieved': flops / dur / 1e12, 'peak': PEAK_FP32_MFMA / 1e12,
-                    'unit': 'TFLOP/s', 'frac': flops / dur / PEAK_FP32_MFMA, 'traffic': None,
-                    'algorithmic_flop_per_read': FLOP_SCALER}
+        # k_lstm.hip pxg_launch_scaler_lstm: time-sliced kernel whenever the batch has more
+        # 16-read tiles than the 2 x #CU resident workgroups
+        kernel = 'k_scaler_lstm_q' if (n_local + 15) // 16 > 2 * info['compute_units'] else 'k_scaler_lstm'
+        roofline = {'kernel': kernel, 'bound': 'mfma',
+                    'achieved': flops / dur / 1e12 if dur else None, 'peak': PEAK_FP32_MFMA / 1e12,
+                    'unit': 'TFLOP/s', 'frac': flops / dur / PEAK_FP32_MFMA if dur else None,
+                    'traffic': None, 'algorithmic_flop_per_read': FLOP_SCALER,
+                    'kernel_ms': stage_ms['scaler_lstm']}
     else:
         dur = stage_ms['segment'] * 1e-3
-        nbytes = float(np.minimum(np.diff(batch['offsets']), 100000).sum() * 2 + args.reads * 88)
-        roofline = {'kernel': 'k_viterbi_ltr', 'bound': 'hbm', 'achieved': nbytes / dur / 1e9,
-                    'peak': PEAK_HBM / 1e9, 'unit': 'GB/s', 'frac': nbytes / dur / PEAK_HBM,
-                    'traffic': None, 'algorithmic_bytes_per_read': nbytes / args.reads}
-    # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes
-    # (profiles/r01/i_final_hbm_traffic.json, collected with tools/prof.sh on this exact
-    # default workload); None for any other workload size
-    if args.reads == 10000 and args.samples == 60000 and args.seed == 924:
+        nbytes = float(np.minimum(lens, 100000).sum() * 2 + n_local * 88)
+        roofline = {'kernel': 'k_viterbi_ltr', 'bound': 'hbm',
+                    'achieved': nbytes / dur / 1e9 if dur else None,
+                    'peak': PEAK_HBM / 1e9, 'unit': 'GB/s', 'frac': nbytes / dur / PEAK_HBM if dur else None,
+                    'traffic': None, 'algorithmic_bytes_per_read': nbytes / n_local,
+                    'kernel_ms': stage_ms['segment']}
+    # HBM bytes per launch of that kernel: NOT measured by this run (PMC counters need
+    # rocprofv3); a static figure from the committed PMC passes of this exact default workload
+    if n_local == 10000 and args.samples == 60000 and args.seed == 924 and not n_base:
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r01', 'i_final_hbm_traffic.json')) as fh:
+            with open(os.path.join(ROOT, TRAFFIC_FILE)) as fh:
                 roofline['traffic'] = json.load(fh)['kernels'][roofline['kernel']]['hbm_bytes']
-            roofline['traffic_source'] = 'profiles/r01/i_final_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE)'
+            roofline['traffic_source'] = ('static: {} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
+                                          'this workload, tools/prof.sh), not re-measured here'
+                                          .format(TRAFFIC_FILE))
         except (OSError, KeyError):
             pass
     # secondary figures for DESIGN.md (not part of the contract)
-    alg_bytes = float(np.minimum(np.diff(batch['offsets']), 100000).sum() * 2 + args.reads * 88)
+    alg_bytes = float(np.minimum(lens, 100000).sum() * 2 + n_local * 88)
     extra = {
         'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
-        'hbm_frac_whole_path': value / world * (alg_bytes / args.reads) / PEAK_HBM,
+        'host_ms_per_step': round(elapsed / args.steps * 1e3 - stage_ms['total']
+                                  - stage_ms['event_means'] - stage_ms['unsplit'], 4),
+        'hbm_frac_whole_path': value / world * (alg_bytes / n_local) / PEAK_HBM,
         'fp32_frac_whole_path': value / world * (FLOP_SCALER + FLOP_BIDIR + FLOP_TOP) / PEAK_FP32_MFMA,
-        'upload_s': round(t_upload, 4),
-        'pcie_inclusive_reads_per_s': args.reads / (elapsed / args.steps + t_upload),
+        'upload_s': round(t_upload, 4), 'synth_s': round(t_gen, 2),
         'reads_ok': n_ok, 'reads_barcoded_window': n_pushed,
         # calls against the barcode the generator planted (synth.py; -1 = no barcode signal)
         'barcode_called': int((res['bc_called'] == 1).sum()),
-        'barcode_called_correct': int(((res['bc_called'] == 1) &
-                                       (res['bc_label'] == batch['barcode'])).sum()),
-        'barcode_planted': int((batch['barcode'] >= 0).sum()),
+        'barcode_called_correct': int(((res['bc_called'] == 1) & (res['bc_label'] == truth_barcode)).sum()),
+        'barcode_planted': int((truth_barcode >= 0).sum()),
         'labels_gathered': int(len(labels)),
+        'labels_read_index_unique': bool(len(np.unique(labels['read_index'])) == len(labels)),
+        'ranks_counted_by_collective': n_ranks,
     }
 
-    # ---- PCIe-inclusive rate with the double-buffered loader path (not `value`): every step
-    # uploads a full batch from pinned host memory on the copy stream while the previous one
-    # computes (pxg_batch_stage / pxg_batch_swap)
-    try:
-        if args.no_overlap_test:
-            raise N.PxgError('skipped (--no-overlap-test)')
-        ctx.pin(batch['arena'])
-        n_over = min(args.steps, 5)
-        ctx.sync()
-        o0 = time.perf_counter()
-        for _ in range(n_over):
-            step()
-            ctx.stage(batch['arena'], batch['offsets'], batch['calib'], inject)
-            ctx.download()
-            ctx.swap()
-        ctx.sync()
-        extra['pcie_overlapped_reads_per_s'] = args.reads * n_over / (time.perf_counter() - o0)
-        ctx.unpin(batch['arena'])
-    except N.PxgError as exc:
-        extra['pcie_overlapped_reads_per_s'] = None
-        extra['pcie_overlapped_error'] = str(exc)
+    # ---- PCIe-inclusive rates (never `value`): (i) upload and compute alternating,
+    # (ii) the double-buffered loader path: every step uploads a full batch from pinned host
+    # memory on the copy stream while the previous one computes (pxg_batch_stage / swap)
+    if not n_base and not standin:
+        extra['pcie_inclusive_reads_per_s'] = n_local / (elapsed / args.steps + t_upload)
+        nbytes_in = base['arena'].nbytes
+        try:
+            if args.no_overlap_test:
+                raise N.PxgError('skipped (--no-overlap-test)')
+            ctx.pin(base['arena'])
+            n_over = min(args.steps, 5)
+            ctx.sync()
+            o0 = time.perf_counter()
+            for _ in range(n_over):
+                step()
+                ctx.stage(base['arena'], base['offsets'], base['calib'], inject)
+                ctx.download()
+                ctx.swap()
+            ctx.sync()
+            o_s = (time.perf_counter() - o0) / n_over
+            extra['pcie_overlapped_reads_per_s'] = n_local / o_s
+            # the ceiling this link sets for a batch of that size: H2D alone, pinned memory
+            h0 = time.perf_counter()
+            for _ in range(2):
+                ctx.stage(base['arena'], base['offsets'], base['calib'], inject)
+                ctx.swap()                      # waits for the staged copies
+            h_s = (time.perf_counter() - h0) / 2
+            extra['h2d_GBps'] = nbytes_in / h_s / 1e9
+            extra['pcie_bound_reads_per_s'] = n_local / h_s
+            extra['pcie_overlap_efficiency'] = (n_local / o_s) / min(n_local / h_s, value / world)
+            ctx.unpin(base['arena'])
+        except N.PxgError as exc:
+            extra['pcie_overlapped_reads_per_s'] = None
+            extra['pcie_overlapped_error'] = str(exc)
 
     # ---- CPU baseline + concordance: the oracle, rank 0, bounded sample -------
     cpu = None
     concordance = None
-    if args.cpu_sample > 0:
+    if args.cpu_sample > 0 and not standin:
         from oracle.pxo import Oracle
         orc = Oracle(config)
-        ns = min(args.cpu_sample, args.reads)
-        o = batch['offsets'][:ns + 1]
-        inj = None if inject is None else inject[:ns]
+        ns = min(args.cpu_sample, n_local)
+        parts = [base['arena'][base['offsets'][b]:base['offsets'][b + 1]] for b in which[:ns]]
+        s_arena, s_off = N.pack_reads(parts)
+        s_cal = base['calib'][which[:ns]]
+        inj = None if inject is None else inject[which[:ns]]
         c0 = time.perf_counter()
-        want = orc.process_batch(batch['arena'][:o[-1]], o, batch['calib'][:ns], inj, mask)
+        want = orc.process_batch(s_arena, s_off, s_cal, inj, mask)
         cand_mismatch = None
-        if args.workload in ('chimera', 'full'):
-            iv, cnt = ctx.unsplit_scan(ev_first, ev_blocks)
+        if scan:
+            iv, cnt, start = ctx.unsplit_scan(ev_first, ev_blocks)
             cand_mismatch = 0
             for i in range(ns):
                 w = want[i]
                 if w['status'] != 0 or w['seg_first'][3] < 0 or ev_blocks[i] <= 0:
                     cand_mismatch += int(cnt[i] != 0)
                     continue
-                _, sc = orc.guppy_event_means(batch['arena'][o[i]:o[i + 1]], batch['calib'][i], 0,
-                                              int(ev_blocks[i]), w['scale'], w['shift'])
+                _, sc = orc.guppy_event_means(parts[i], s_cal[i], 0, int(ev_blocks[i]), w['scale'], w['shift'])
                 wiv, wc = orc.unsplit_scan(sc, 0, (int(w['seg_last'][3]) + 1) * 15,
-                                           float(batch['calib'][i]['sampling_rate']))
-                cand_mismatch += int(wc != cnt[i] or wiv.tolist() != iv[i, :min(wc, iv.shape[1])].tolist())
+                                           float(s_cal[i]['sampling_rate']))
+                cand_mismatch += int(wc != cnt[i] or wiv.tolist() != iv[start[i]:start[i + 1]].tolist())
         cpu_s = time.perf_counter() - c0
+        model, physical, usable = host_description()
         cpu = {'value': ns / cpu_s, 'unit': 'reads/s', 'cores': 1, 'kind': 'port',
                'sample': 'first {} reads of the same batch, same stages, oracle/libpxo.so '
-                         '(C restatement, gcc -O2 AVX2), single thread, {:.1f} s'.format(ns, cpu_s)}
+                         '(C restatement, gcc -O2 AVX2), single thread, {:.1f} s'.format(ns, cpu_s),
+               'host_cpu': model, 'physical_cores': physical, 'usable_cores': usable,
+               'speedup_vs_one_core': value / world / (ns / cpu_s)}
+        if cpu_all is not None:
+            cpu['all_cores'] = dict(cpu_all, sample='{} reads over {} worker processes (one per physical '
+                                    'core, read shards; ProcessPoolExecutor shape of pipeline.py:96), '
+                                    '{} s wall'.format(cpu_all['reads'], cpu_all['cores'], cpu_all['wall_s']))
+            cpu['speedup_vs_all_cores'] = value / world / cpu_all['value']
         got = res[:ns]
         same = [f for f in got.dtype.names if np.array_equal(got[f], want[f], equal_nan=True)]
         concordance = {
@@ -266,24 +449,25 @@ def main():
             concordance['unsplit_candidate_mismatch'] = cand_mismatch
 
     line = {
-        'metric': {'demux': 'reads/s (segment+barcode)', 'polya': 'reads/s (segment+barcode+polyA)',
-                   'chimera': 'reads/s (segment+barcode+chimera filter)',
-                   'full': 'reads/s (segment+barcode+polyA+chimera filter)',
-                   'segment': 'reads/s (normalise+segment)'}[args.workload],
-        'value': value, 'unit': 'reads/s', 'n_gpus': world, 'steps': args.steps,
+        'metric': wl_metric,
+        'value': None if standin else value, 'unit': 'reads/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32 (LSTM MFMA) / f64 (Viterbi) / i16 in', 'data': 'synthetic',
-        'config': {'workload': 'BASELINE configs[{}]: {} reads/GPU x ~{} int16 samples, stages {}'.format(
-                       {'demux': 2, 'polya': 3, 'chimera': 3, 'full': 3, 'segment': 1}[args.workload], args.reads, args.samples,
-                       {'demux': 'a1-a13 (scaler LSTM + Viterbi + barcode LSTMs)',
-                        'polya': 'a1-a17 (+ poly(A) events/DP)',
-                        'chimera': 'a1-a13 + a18/a19 (Guppy block means + window scan)',
-                        'full': 'a1-a19 (+ poly(A) + Guppy block means + window scan)',
-                        'segment': 'a1,a5,a7,a8 (injected scaling)'}[args.workload]),
-                   'reads_per_gpu': args.reads, 'samples_per_read': args.samples,
-                   'parallelism': 'reads sharded x{}'.format(world), 'device': info['name'],
-                   'arch': info['arch'], 'compute_units': info['compute_units']},
+        'higher_is_better': True, 'scaling': args.scaling,
+        'vs_baseline': None if standin else value / PUBLISHED_READS_PER_S,
+        'vs_baseline_basis': 'BASELINE.md section 1: ~230 reads/s, the only published throughput '
+                             '(Poreplex 0.1, whole pipeline incl. FAST5 I/O, 20 Xeon cores): an '
+                             'order-of-magnitude anchor, not a hot-path number; see cpu_baseline',
+        'dtype': 'f32 (LSTM MFMA) / f64 (Viterbi) / i16 in',
+        'data': 'TEST-STANDIN (no GPU work timed)' if standin else 'synthetic',
+        'config': {'workload': 'BASELINE configs[{}]: {} x ~{} int16 samples, stages {}'.format(
+                       4 if args.scaling == 'strong' else wl_cfg,
+                       '{} reads sharded over {} GPU(s)'.format(total, world) if args.scaling == 'strong'
+                       else '{} reads/GPU'.format(args.reads), args.samples, wl_stages),
+                   'reads_per_gpu': shard_sizes, 'total_reads_per_step': total,
+                   'samples_per_read': args.samples,
+                   'distinct_reads': n_base or n_local, 'tiled_on_device': bool(n_base),
+                   'parallelism': 'reads sharded x{} (contiguous read_index blocks)'.format(world),
+                   'device': info['name'], 'arch': info['arch'], 'compute_units': info['compute_units']},
         'roofline': roofline, 'cpu_baseline': cpu, 'concordance': concordance, 'extra': extra,
     }
     os.write(json_fd, (json.dumps(line) + '\n').encode())

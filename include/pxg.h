@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PXG_ABI_VERSION 1
+#define PXG_ABI_VERSION 2
 
 #define PXG_MAX_STATES      8   /* HMM states per model (reference uses 6)        */
 #define PXG_MAX_MIXTURE     4   /* Gaussian components per state (reference <= 2) */
@@ -34,7 +34,11 @@ extern "C" {
 #define PXG_MAX_CLASSES     8   /* softmax width (reference: 1 decoy + 4 barcodes) */
 #define PXG_MAX_CALIBRATION 64  /* phred calibration table rows (reference: 29)    */
 #define PXG_MAX_SPIKES      64  /* poly(A) spike records kept per read             */
-#define PXG_MAX_UNSPLIT     64  /* in-read adapter candidates kept per read        */
+
+/* per-read error codes pxg_batch_unsplit_scan stores in out_count (data problems are
+ * per-read results, never call failures -- signal_analyzer.py:118-122) */
+#define PXG_UNSPLIT_E_WINDOW_CANDS (-2) /* one scan window produced more candidates than its slots */
+#define PXG_UNSPLIT_E_GEOMETRY     (-3) /* negative first_sample / n_blocks                  */
 
 /* ---- error codes (function return values) -------------------------------- */
 enum pxg_error {
@@ -278,6 +282,15 @@ int pxg_batch_upload(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
 int pxg_batch_stage(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
                     const int64_t* raw_offsets, const pxg_calib* calib,
                     const float* scale_shift_or_null);
+/* Large synthetic batches without staging them on the host (configs[3] is
+ * 12 GB of int16, configs[4] 15 GB per GPU): upload `base_n` distinct reads once and
+ * make the resident batch read j = base read (phase + j) % base_n, replicated on the
+ * device.  Every stage then runs on n_reads independent reads exactly as after
+ * pxg_batch_upload.  phase lets rank r of a sharded run own reads [lo, hi) of ONE
+ * global tiling (phase = lo % base_n). */
+int pxg_batch_upload_tiled(pxg_ctx* ctx, int64_t n_reads, int64_t base_n, int64_t phase,
+                           const int16_t* base_arena, const int64_t* base_offsets,
+                           const pxg_calib* base_calib, const float* base_scale_shift_or_null);
 int pxg_batch_swap(pxg_ctx* ctx);
 int pxg_host_register(pxg_ctx* ctx, void* ptr, size_t bytes);
 int pxg_host_unregister(pxg_ctx* ctx, void* ptr);
@@ -329,10 +342,24 @@ int pxg_guppy_event_means(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_aren
 /* a19 (numeric part): the window scan of detect_unsplit_read
  * (signal_analyzer.py:366-418) on the RESIDENT batch after a run with the
  * segment stage: per read first_sample_template and the number of Guppy
- * blocks; out_intervals n x PXG_MAX_UNSPLIT x 2 (leader start, adapter end + 1,
- * raw-sample coordinates), out_count n (may exceed PXG_MAX_UNSPLIT) */
+ * blocks.  Output is compact (CSR): out_count[r] >= 0 candidates of read r, or a
+ * negative PXG_UNSPLIT_E_* code for that read alone; the (leader start, adapter
+ * end + 1) pairs, raw-sample coordinates, of all reads back to back in read
+ * order in out_intervals (cap_intervals x 2); *out_total = pairs found (when it
+ * exceeds cap_intervals only the first cap_intervals were written: call again
+ * with a larger buffer).  Everything between the H2D of the two per-read arrays
+ * and the final D2H is enqueued without a host synchronisation. */
 int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample, const int64_t* n_blocks,
-                           int32_t block_stride, int64_t* out_intervals, int32_t* out_count);
+                           int32_t block_stride, int64_t cap_intervals, int64_t* out_intervals,
+                           int32_t* out_count, int64_t* out_total);
+/* a14-a17 as a standalone hook: PolyASignalAnalyzer.__call__ (polya.py:50-148) on
+ * reads whose scaling and segmentation the caller supplies (seg_first/seg_last:
+ * n x PXG_N_SEGMENTS, pooled right-inclusive, -1 absent, as pxg_viterbi returns
+ * them).  out: n records of which only the polya_* fields (and status = OKAY) are
+ * set; spikes_or_null n x PXG_MAX_SPIKES rows. */
+int pxg_polya(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena, const int64_t* raw_offsets,
+              const pxg_calib* calib, const float* scale_shift, const int32_t* seg_first,
+              const int32_t* seg_last, pxg_read_result* out, pxg_polya_spike* spikes_or_null);
 /* a15: csupport.detect_events (src/csupport.c:70-124) on a batch of windows */
 int pxg_detect_events(pxg_ctx* ctx, int64_t n_windows, const float* signal_arena,
                       const int64_t* signal_offsets, int64_t max_events_per_window,

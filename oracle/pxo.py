@@ -256,11 +256,12 @@ class Oracle:
 
     def unsplit_scan(self, scaled_mean, first_sample, payload_start, sampling_rate, stride=15):
         sm = np.ascontiguousarray(scaled_mean, dtype=np.float32)
-        iv = np.zeros((N.PXG_MAX_UNSPLIT, 2), dtype=np.int64)
+        cap = 4096                    # more in-read adapters than any read can hold
+        iv = np.zeros((cap, 2), dtype=np.int64)
         n = self.L.pxo_unsplit_scan(C.byref(self.cfg), _p(sm), len(sm), int(first_sample), stride,
-                                    int(payload_start), float(sampling_rate), _p(iv),
-                                    N.PXG_MAX_UNSPLIT)
-        return iv[:min(n, N.PXG_MAX_UNSPLIT)], n
+                                    int(payload_start), float(sampling_rate), _p(iv), cap)
+        assert n <= cap
+        return iv[:n], n
 
     # ---- whole path ------------------------------------------------------
     def process_batch(self, arena, offsets, calib, scale_shift=None,

@@ -15,17 +15,15 @@ class BarcodeDemultiplexer:
     PAD_FILLER = -1000.
 
     def __init__(self, config, qualitythreshold, ctx):
+        # NativeConfig already refused a quality filter beyond the calibration table
+        # (barcoding.py:41-45), with the reference's message
         self.config, self.ctx = config, ctx
         self.calibration_table = [float(v) for v in ctx.ncfg.calibration]
-        if len(self.calibration_table) - 1 < qualitythreshold:     # barcoding.py:41-44
-            raise ValueError('The current demultiplexer does not support calibrated score '
-                             'of {}. Consider lowering --barcoding-quality-filter value.'
-                             .format(qualitythreshold))
         self.score_threshold = self.calibration_table[qualitythreshold]
         self.signal_assoc_read = []
 
     def clear(self):
-        del self.signal_assoc_read[:]
+        self.signal_assoc_read = []
 
     def lookup_calibrated_phred_score(self, score):
         from bisect import bisect_right
@@ -42,17 +40,25 @@ class BarcodeDemultiplexer:
         n = min(len(sig), self.config['signal_trim_length'])
         return out[0][-n:]
 
+    def assign(self, table, rows, records):
+        """Barcode columns of many reads at once (what push + predict do per read,
+        barcoding.py:83-118): only reads whose adapter window passed the length gate
+        (decided on the GPU, record field bc_pushed) get a guess and a calibrated score."""
+        gate = records['bc_pushed'] != 0
+        rows, rec = rows[gate], records[gate]
+        called = rec['bc_called'] != 0
+        table.has_barcode[rows] = called
+        table.barcode[rows] = np.where(called, rec['bc_label'], -1)
+        table.barcode_guess[rows] = rec['bc_label']
+        table.barcode_phred[rows] = rec['bc_phred']
+
     def push(self, npread, signal=None):
-        """Queue a read whose adapter window passed the gate (decided on the
-        GPU: record field bc_pushed, barcoding.py:84-88)."""
+        """Single-read form of the reference surface: queue the read for predict()."""
         if npread.native is not None and npread.native['bc_pushed']:
             self.signal_assoc_read.append(npread)
 
     def predict(self):
         for npread in self.signal_assoc_read:
             rec = npread.native
-            bcid, score = int(rec['bc_label']), np.float32(rec['bc_score'])
-            effective = bcid if rec['bc_called'] else None
-            npread.set_barcode(effective, bcid, int(rec['bc_phred']))
-            npread.barcode_probs = np.array(rec['probs'][:self.ctx.cfg.demux_dense.out_dim])
-            npread.barcode_raw_score = score
+            self.assign(npread.table, np.array([npread.row]), np.array([rec], dtype=rec.dtype))
+        self.clear()

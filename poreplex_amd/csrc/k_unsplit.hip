@@ -7,17 +7,19 @@
 //        analysis with duration cut-offs -> candidate in-read adapters.
 //
 // The windows of a read are independent, so the parallel unit is the (read,
-// window) pair: a plan kernel counts each read's windows, the host prefix-sums
-// them, one 8-lane group scans one window, a gather kernel restores the
-// reference's append order.  The unsplit HMM is not left-to-right, so this
-// Viterbi keeps real back pointers (see k_unsplit_scan).
+// window) pair: a plan kernel counts each read's windows, a one-block scan turns
+// the counts into unit offsets (on the device: the host never waits inside the
+// call), one 8-lane group scans one window, two gather passes restore the
+// reference's append order and compact the candidates of all reads into one CSR
+// list.  The unsplit HMM is not left-to-right, so this Viterbi keeps real back
+// pointers (see k_unsplit_scan).
 #include "pxg_common.h"
 
 #define UN_READS 8
 #define UN_CHUNK 16
-#define UN_TMAX 4096                       // steps per window the scratch holds
 #define UN_EM_STRIDE (UN_CHUNK * PXG_MAX_STATES + 8)
-#define UN_WCAND 8                         // candidate adapters kept per window
+#define UN_WCAND 16                        // candidate adapters kept per window (the preset's
+                                           // duration cut-offs allow at most 14 in an 8 s window)
 
 // ---------------------------------------------------------------------------
 // a18: one thread per event block
@@ -203,14 +205,48 @@ __global__ void k_unsplit_plan(int64_t n_reads, UnsplitParams P, const pxg_calib
         for (int64_t left = g.payload_start; left < g.last_end; left += g.window_step) {
             int64_t k0, k1;
             if (!unsplit_window(g, P.stride, left, k0, k1)) break;               // :387-388
-            if (k1 - k0 + 1 > UN_TMAX) { cnt = -1; break; }
             cnt++;
         }
     }
     n_win[r] = cnt;
 }
 
-// scan: one 8-lane group per (read, window) unit; unit_off[r] = first unit of read r.
+// out[0] = 0, out[i + 1] = out[i] + max(in[i], 0): one block, each thread a contiguous
+// slice, wave + LDS scan of the slice totals.  n is a batch's read count (<= ~1e6), so a
+// single block is a few microseconds and needs no second kernel.
+__global__ __launch_bounds__(1024) void k_exclusive_scan(int64_t n, const int32_t* __restrict__ in,
+                                                         int64_t* __restrict__ out)
+{
+    __shared__ int64_t part[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
+    int64_t s = 0;
+    for (int64_t i = lo; i < hi; i++) s += in[i] > 0 ? in[i] : 0;
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {           // Hillis-Steele over the 1024 slice totals
+        const int64_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int64_t run = part[t] - s;
+    for (int64_t i = lo; i < hi; i++) {
+        out[i] = run;
+        run += in[i] > 0 ? in[i] : 0;
+    }
+    if (t == 1023) out[n] = part[1023];
+}
+
+int pxg_launch_exclusive_scan(pxg_ctx* ctx, int64_t n, const int32_t* in, int64_t* out)
+{
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, ctx->stream, n, in, out);
+    return PXG_OK;
+}
+
+// scan: one 8-lane group per (read, window) unit; unit_off[r] = first unit of read r,
+// unit_off[n_reads] = number of units (read on the device: the grid is persistent).
 // Back pointers: the 3-bit sources of a group's states are OR-combined over its 8
 // lanes (three DPP steps) into one 24-bit table word per step, so the traceback
 // of a group is a chain of bit-field extractions -- no cross-lane read on the
@@ -220,18 +256,19 @@ __global__ void k_unsplit_plan(int64_t n_reads, UnsplitParams P, const pxg_calib
 // candidates come out last-first and k_unsplit_gather reverses them.
 template <int NIN>
 __global__ __launch_bounds__(64) void k_unsplit_scan(
-    int64_t n_reads, int64_t n_units, PxgHmmDev H, UnsplitParams P, const pxg_calib* __restrict__ cal,
+    int64_t n_reads, int tmax, PxgHmmDev H, UnsplitParams P, const pxg_calib* __restrict__ cal,
     const int32_t* __restrict__ status, const int32_t* __restrict__ segs,
     const int64_t* __restrict__ first_sample, const int64_t* __restrict__ ev_off,
     const int64_t* __restrict__ unit_off, const float* __restrict__ scaled,
-    unsigned* __restrict__ bpbuf /* [wave][UN_TMAX][8 groups] */,
+    unsigned* __restrict__ bpbuf /* [wave][tmax][8 groups] */,
     int64_t* __restrict__ cand /* n_units x UN_WCAND x 2 */, int32_t* __restrict__ cand_cnt)
 {
     __shared__ double em[UN_READS * UN_EM_STRIDE];
     const int lane = threadIdx.x;
     const int rr = lane >> 3, s = lane & 7;
     const int S = H.n_states;
-    unsigned* bpm = bpbuf + (size_t)blockIdx.x * UN_TMAX * UN_READS;
+    unsigned* bpm = bpbuf + (size_t)blockIdx.x * tmax * UN_READS;
+    const int64_t n_units = unit_off[n_reads];
 
     // per-lane in-edge table (name-sorted slots); unused slots never win
     int src_lane[NIN];
@@ -252,6 +289,7 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
         const int64_t u = ubase + rr;
         int64_t r = 0;
         bool more = u < n_units;
+        const bool owned = more;
         if (more) {              // largest r with unit_off[r] <= u
             int64_t lo = 0, hi = n_reads;
             while (hi - lo > 1) {
@@ -267,7 +305,9 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
             const int64_t left = g.payload_start + (u - unit_off[r]) * g.window_step;
             more = g.valid && unsplit_window(g, P.stride, left, k0, k1);
         }
-        const int T = more ? (int)(k1 - k0 + 1) : 0;
+        int T = more ? (int)(k1 - k0 + 1) : 0;
+        bool too_long = T > tmax;        // cannot happen: tmax is sized from the largest window the
+        if (too_long) T = 0;             // config and the batch's sampling rates allow (host side)
         const float* x = scaled + (more ? ev_off[r] : 0);
         int Tmax = T;
         for (int d = 32; d >= 1; d >>= 1) {
@@ -371,32 +411,45 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
         }
         if (phase == 1) finalize(a_first);
         else if (phase == 2) finalize(lead);
-        if (s == 0 && more) cand_cnt[u] = count;
+        if (s == 0 && owned) cand_cnt[u] = too_long ? UN_WCAND + 1 : count;
     }
 }
 
-// gather: candidates of a read's windows, in window order (the order the reference appends them)
-__global__ void k_unsplit_gather(int64_t n_reads, const int64_t* __restrict__ unit_off,
-                                 const int32_t* __restrict__ n_win, const int64_t* __restrict__ cand,
-                                 const int32_t* __restrict__ cand_cnt, int64_t* __restrict__ out_iv,
-                                 int32_t* __restrict__ out_cnt)
+// gather, pass 1: candidates per read (or PXG_UNSPLIT_E_WINDOW_CANDS for that read alone)
+__global__ void k_unsplit_count(int64_t n_reads, const int64_t* __restrict__ unit_off,
+                                const int32_t* __restrict__ cand_cnt, int32_t* __restrict__ out_cnt)
 {
     const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     int total = 0;
-    bool overflow = n_win[r] < 0;
+    bool overflow = false;
     for (int64_t u = unit_off[r]; u < unit_off[r + 1]; u++) {
         const int c = cand_cnt[u];
         if (c > UN_WCAND) overflow = true;
-        for (int q = (c < UN_WCAND ? c : UN_WCAND) - 1; q >= 0; q--) {   // stored last-first
-            if (total < PXG_MAX_UNSPLIT) {
-                out_iv[(r * PXG_MAX_UNSPLIT + total) * 2] = cand[(u * UN_WCAND + q) * 2];
-                out_iv[(r * PXG_MAX_UNSPLIT + total) * 2 + 1] = cand[(u * UN_WCAND + q) * 2 + 1];
+        total += c < UN_WCAND ? c : UN_WCAND;
+    }
+    out_cnt[r] = overflow ? PXG_UNSPLIT_E_WINDOW_CANDS : total;
+}
+
+// gather, pass 2: the candidates of a read's windows in window order (the order the
+// reference appends them), all reads back to back; iv_off = exclusive scan of out_cnt
+__global__ void k_unsplit_gather(int64_t n_reads, const int64_t* __restrict__ unit_off,
+                                 const int64_t* __restrict__ cand, const int32_t* __restrict__ cand_cnt,
+                                 const int32_t* __restrict__ out_cnt, const int64_t* __restrict__ iv_off,
+                                 int64_t cap, int64_t* __restrict__ out_iv)
+{
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r >= n_reads || out_cnt[r] <= 0) return;
+    int64_t at = iv_off[r];
+    for (int64_t u = unit_off[r]; u < unit_off[r + 1]; u++) {
+        const int c = cand_cnt[u];
+        for (int q = (c < UN_WCAND ? c : UN_WCAND) - 1; q >= 0; q--, at++) {   // stored last-first
+            if (at < cap) {
+                out_iv[at * 2] = cand[(u * UN_WCAND + q) * 2];
+                out_iv[at * 2 + 1] = cand[(u * UN_WCAND + q) * 2 + 1];
             }
-            total++;
         }
     }
-    out_cnt[r] = overflow ? -1 : total;
 }
 
 static UnsplitParams unsplit_params(const pxg_ctx* ctx, int stride)
@@ -426,48 +479,60 @@ int pxg_launch_unsplit_plan(pxg_ctx* ctx, int64_t n, const pxg_calib* cal, const
     return PXG_OK;
 }
 
-int pxg_unsplit_waves(const pxg_ctx* ctx, int64_t n_units)
+// persistent grid: enough waves to fill the chip; the unit count is only known on the device
+int pxg_unsplit_waves(const pxg_ctx* ctx, int64_t units_bound)
 {
-    const int64_t need = (n_units + UN_READS - 1) / UN_READS;
+    const int64_t need = (units_bound + UN_READS - 1) / UN_READS;
     const int64_t cap = (int64_t)ctx->n_cu * 16;
     return (int)(need < cap ? (need > 0 ? need : 1) : cap);
 }
 
-size_t pxg_unsplit_scratch_bytes(const pxg_ctx* ctx, int64_t n_units)
+size_t pxg_unsplit_scratch_bytes(const pxg_ctx* ctx, int64_t units_bound, int tmax)
 {
-    return (size_t)pxg_unsplit_waves(ctx, n_units) * UN_TMAX * UN_READS * sizeof(unsigned);
+    return (size_t)pxg_unsplit_waves(ctx, units_bound) * (size_t)tmax * UN_READS * sizeof(unsigned);
 }
 
-size_t pxg_unsplit_cand_bytes(int64_t n_units)
+size_t pxg_unsplit_cand_bytes(int64_t units_bound)
 {
-    return (size_t)(n_units > 0 ? n_units : 1) * (UN_WCAND * 2 * sizeof(int64_t) + sizeof(int32_t));
+    return (size_t)(units_bound > 0 ? units_bound : 1) * (UN_WCAND * 2 * sizeof(int64_t) + sizeof(int32_t));
 }
 
-int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t n_units, const pxg_calib* cal,
+int64_t pxg_unsplit_cand_slots(void) { return UN_WCAND; }
+
+int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t units_bound, int tmax, const pxg_calib* cal,
                             const int32_t* status, const int32_t* segs, const int64_t* first_sample,
-                            const int64_t* ev_off, const int64_t* unit_off, const int32_t* n_win,
-                            const float* scaled, int stride, void* scratch, void* candbuf,
-                            int64_t* out_iv, int32_t* out_cnt)
+                            const int64_t* ev_off, const int64_t* unit_off, const float* scaled, int stride,
+                            void* scratch, void* candbuf, int32_t* out_cnt)
 {
     if (n <= 0) return PXG_OK;
     const UnsplitParams P = unsplit_params(ctx, stride);
-    const int waves = pxg_unsplit_waves(ctx, n_units);
+    const int waves = pxg_unsplit_waves(ctx, units_bound);
     unsigned* bp = (unsigned*)scratch;
     int64_t* cand = (int64_t*)candbuf;
-    int32_t* cand_cnt = (int32_t*)((char*)candbuf + (size_t)(n_units > 0 ? n_units : 1) * UN_WCAND * 2 * sizeof(int64_t));
-    if (n_units > 0) {
+    int32_t* cand_cnt = (int32_t*)((char*)candbuf + (size_t)(units_bound > 0 ? units_bound : 1) * UN_WCAND * 2 * sizeof(int64_t));
 #define SCAN(NIN)                                                                                      \
     hipLaunchKernelGGL(k_unsplit_scan<NIN>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, n,        \
-                       n_units, ctx->hmm[1], P, cal, status, segs, first_sample, ev_off, unit_off,     \
+                       tmax, ctx->hmm[1], P, cal, status, segs, first_sample, ev_off, unit_off,        \
                        scaled, bp, cand, cand_cnt)
-        const int nin = ctx->hmm[1].max_in;
-        if (nin <= 2) SCAN(2);
-        else if (nin <= 3) SCAN(3);
-        else if (nin <= 5) SCAN(5);
-        else SCAN(8);
+    const int nin = ctx->hmm[1].max_in;
+    if (nin <= 2) SCAN(2);
+    else if (nin <= 3) SCAN(3);
+    else if (nin <= 5) SCAN(5);
+    else SCAN(8);
 #undef SCAN
-    }
+    hipLaunchKernelGGL(k_unsplit_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
+                       unit_off, cand_cnt, out_cnt);
+    return PXG_OK;
+}
+
+int pxg_launch_unsplit_gather(pxg_ctx* ctx, int64_t n, int64_t units_bound, const int64_t* unit_off,
+                              const void* candbuf, const int32_t* out_cnt, const int64_t* iv_off,
+                              int64_t cap, int64_t* out_iv)
+{
+    if (n <= 0) return PXG_OK;
+    const int64_t* cand = (const int64_t*)candbuf;
+    const int32_t* cand_cnt = (const int32_t*)((const char*)candbuf + (size_t)(units_bound > 0 ? units_bound : 1) * UN_WCAND * 2 * sizeof(int64_t));
     hipLaunchKernelGGL(k_unsplit_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
-                       unit_off, n_win, cand, cand_cnt, out_iv, out_cnt);
+                       unit_off, cand, cand_cnt, out_cnt, iv_off, cap, out_iv);
     return PXG_OK;
 }

@@ -267,7 +267,7 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     release(ctx->spare.raw); release(ctx->spare.offsets); release(ctx->spare.calib); release(ctx->spare.inject);
     release(ctx->results); release(ctx->polya_ev); release(ctx->polya_out); release(ctx->spikes);
     release(ctx->ev_first); release(ctx->ev_off); release(ctx->ev_mean); release(ctx->ev_scaled);
-    release(ctx->unsplit_scr); release(ctx->unsplit_iv); release(ctx->unsplit_cnt);
+    release(ctx->unsplit_scr); release(ctx->unsplit_iv); release(ctx->unsplit_cnt); release(ctx->unsplit_ivoff);
     release(ctx->unsplit_cand); release(ctx->unit_off); release(ctx->n_win);
     free_lstm(ctx->scaler1); free_lstm(ctx->scaler2); free_lstm(ctx->demux_fwd);
     free_lstm(ctx->demux_bwd); free_lstm(ctx->demux_top);
@@ -334,6 +334,17 @@ static int reserve_batch(pxg_ctx* ctx, int64_t n, int64_t n_samples)
     return PXG_OK;
 }
 
+// sampling-rate range of a batch: sizes the window scratch of the chimera scan without a
+// device round trip (signal_analyzer.py:374-383: windows are int(seconds * rate) samples)
+static void rate_range(const pxg_calib* calib, int64_t n, double& lo, double& hi)
+{
+    lo = hi = n > 0 ? calib[0].sampling_rate : 0.0;
+    for (int64_t i = 1; i < n; i++) {
+        lo = std::min(lo, calib[i].sampling_rate);
+        hi = std::max(hi, calib[i].sampling_rate);
+    }
+}
+
 extern "C" int pxg_batch_upload(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
                                 const int64_t* raw_offsets, const pxg_calib* calib,
                                 const float* scale_shift_or_null)
@@ -367,6 +378,65 @@ extern "C" int pxg_batch_upload(pxg_ctx* ctx, int64_t n_reads, const int16_t* ra
     PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host buffers may be reused on return
     ctx->n_reads = n_reads;
     ctx->n_samples = n_samples;
+    rate_range(calib, n_reads, ctx->rate_min, ctx->rate_max);
+    return PXG_OK;
+}
+
+extern "C" int pxg_batch_upload_tiled(pxg_ctx* ctx, int64_t n_reads, int64_t base_n, int64_t phase,
+                                      const int16_t* base_arena, const int64_t* base_offsets,
+                                      const pxg_calib* base_calib, const float* base_ss)
+{
+    if (!ctx) return PXG_E_INVALID;
+    if (n_reads < 1 || base_n < 1 || phase < 0 || !base_offsets || !base_calib || !base_arena)
+        return fail(ctx, PXG_E_INVALID, "pxg_batch_upload_tiled: bad arguments");
+    for (int64_t i = 0; i < base_n; i++)
+        if (base_offsets[i + 1] < base_offsets[i])
+            return fail(ctx, PXG_E_INVALID, "raw_offsets must be non-decreasing");
+    if (base_offsets[0] != 0) return fail(ctx, PXG_E_INVALID, "raw_offsets[0] must be 0");
+    if (n_reads > (1LL << 30)) return fail(ctx, PXG_E_INVALID, "too many reads");
+    PXG_HIP(ctx, hipSetDevice(ctx->device));
+    ctx->n_reads = 0;
+    phase %= base_n;
+    const int64_t base_samples = base_offsets[base_n];
+    // per-read metadata of the tiled batch on the host (a few MB even for 1M reads)
+    std::vector<int64_t> off((size_t)n_reads + 1);
+    std::vector<pxg_calib> cal((size_t)n_reads);
+    std::vector<float> ss(base_ss ? (size_t)n_reads * 2 : 0);
+    off[0] = 0;
+    for (int64_t j = 0, b = phase; j < n_reads; j++, b = (b + 1 == base_n ? 0 : b + 1)) {
+        off[j + 1] = off[j] + (base_offsets[b + 1] - base_offsets[b]);
+        cal[j] = base_calib[b];
+        if (base_ss) { ss[2 * j] = base_ss[2 * b]; ss[2 * j + 1] = base_ss[2 * b + 1]; }
+    }
+    const int64_t n_samples = off[n_reads];
+    int rc = reserve_batch(ctx, n_reads, n_samples);
+    if (rc) return rc;
+    DevBuf<int16_t> base;                                   // the distinct reads, once over PCIe
+    if ((rc = pxg_reserve(ctx, base, (size_t)base_samples + 64))) return rc;
+    hipStream_t st = ctx->stream;
+    hipError_t e = hipMemcpyAsync(base.p, base_arena, (size_t)base_samples * sizeof(int16_t),
+                                  hipMemcpyHostToDevice, st);
+    // cyclic replication: [phase .. base_n) then whole copies of the base set
+    int64_t at = 0, src = base_offsets[phase];
+    while (e == hipSuccess && at < n_samples) {
+        const int64_t len = std::min(base_samples - src, n_samples - at);
+        if (len > 0)
+            e = hipMemcpyAsync(ctx->raw.p + at, base.p + src, (size_t)len * sizeof(int16_t),
+                               hipMemcpyDeviceToDevice, st);
+        at += len;
+        src = 0;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->offsets.p, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->calib.p, cal.data(), cal.size() * sizeof(pxg_calib), hipMemcpyHostToDevice, st);
+    ctx->have_inject = base_ss != nullptr;
+    if (e == hipSuccess && base_ss)
+        e = hipMemcpyAsync(ctx->inject.p, ss.data(), ss.size() * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(base.p);
+    if (e != hipSuccess) return fail(ctx, PXG_E_HIP, std::string("pxg_batch_upload_tiled: ") + hipGetErrorString(e));
+    ctx->n_reads = n_reads;
+    ctx->n_samples = n_samples;
+    rate_range(base_calib, base_n, ctx->rate_min, ctx->rate_max);
     return PXG_OK;
 }
 
@@ -421,6 +491,7 @@ extern "C" int pxg_batch_stage(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw
     PXG_HIP(ctx, hipEventRecord(ctx->ev_staged, cs));
     sp.n_reads = n_reads;
     sp.n_samples = n_samples;
+    rate_range(calib, n_reads, sp.rate_min, sp.rate_max);
     sp.staged = true;
     return PXG_OK;
 }
@@ -444,6 +515,8 @@ extern "C" int pxg_batch_swap(pxg_ctx* ctx)
     if (rc) return rc;
     ctx->n_reads = sp.n_reads;
     ctx->n_samples = sp.n_samples;
+    ctx->rate_min = sp.rate_min;
+    ctx->rate_max = sp.rate_max;
     sp.staged = false;
     return PXG_OK;
 }
@@ -873,72 +946,133 @@ extern "C" int pxg_guppy_event_means(pxg_ctx* ctx, int64_t n, const int16_t* raw
 
 extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
                                       const int64_t* n_blocks, int32_t block_stride,
-                                      int64_t* out_intervals, int32_t* out_count)
+                                      int64_t cap_intervals, int64_t* out_intervals,
+                                      int32_t* out_count, int64_t* out_total)
 {
     HOOK_BEGIN
     const int64_t n = ctx->n_reads;
+    if (out_total) *out_total = 0;
     if (n <= 0) return PXG_OK;
-    const pxg_hmm& U = ctx->cfg.unsplit_model;
+    if (!first_sample || !n_blocks || !out_count || !out_total || cap_intervals < 0 ||
+        (cap_intervals > 0 && !out_intervals))
+        return fail(ctx, PXG_E_INVALID, "pxg_batch_unsplit_scan: bad arguments");
+    if (block_stride < 1) return fail(ctx, PXG_E_INVALID, "pxg_batch_unsplit_scan: block_stride < 1");
+    const pxg_config& c = ctx->cfg;
+    const pxg_hmm& U = c.unsplit_model;
     if (U.n_states < 1 || U.adapter_state < 0 || U.leader_low_state < 0 || U.leader_high_state < 0)
         return fail(ctx, PXG_E_INVALID, "unsplit model lacks adapter / leader states");
-    std::vector<int64_t> eoff((size_t)n + 1, 0);
+    // window geometry bounds from the config and the batch's sampling-rate range: the largest
+    // window (steps of back pointers a wave must hold) and the most windows a read can have
+    const int64_t win_max = (int64_t)(c.unsplit_window_size * ctx->rate_max);
+    const int64_t step_min = (int64_t)(c.unsplit_window_step * ctx->rate_min);
+    if (step_min < 1 || win_max < 0 || win_max / block_stride + 2 > (1 << 22))
+        return fail(ctx, PXG_E_INVALID, "unsplit_read_detection window_size / window_step out of range");
+    const int tmax = (int)(win_max / block_stride + 2);
+    // per-read frames; a read with an impossible frame gets an empty one and its own error code
+    std::vector<int64_t> eoff((size_t)n + 1, 0), first((size_t)n);
+    std::vector<int64_t> bad;
+    int64_t units_bound = 0;
     for (int64_t i = 0; i < n; i++) {
-        if (first_sample[i] < 0 || n_blocks[i] < 0)
-            return fail(ctx, PXG_E_INVALID, "pxg_batch_unsplit_scan: negative first_sample / n_blocks");
-        eoff[i + 1] = eoff[i] + n_blocks[i];
+        const bool ok = first_sample[i] >= 0 && n_blocks[i] >= 0;
+        if (!ok) bad.push_back(i);
+        first[i] = ok ? first_sample[i] : 0;
+        const int64_t nb = ok ? n_blocks[i] : 0;
+        eoff[i + 1] = eoff[i] + nb;
+        units_bound += nb * block_stride / step_min + 2;
     }
     const size_t ne = (size_t)eoff[n];
     int rc;
     if ((rc = pxg_reserve(ctx, ctx->ev_first, (size_t)n)) || (rc = pxg_reserve(ctx, ctx->ev_off, (size_t)n + 1)) ||
         (rc = pxg_reserve(ctx, ctx->ev_mean, ne)) || (rc = pxg_reserve(ctx, ctx->ev_scaled, ne)) ||
         (rc = pxg_reserve(ctx, ctx->unit_off, (size_t)n + 1)) || (rc = pxg_reserve(ctx, ctx->n_win, (size_t)n)) ||
-        (rc = pxg_reserve(ctx, ctx->unsplit_iv, (size_t)n * PXG_MAX_UNSPLIT * 2)) ||
-        (rc = pxg_reserve(ctx, ctx->unsplit_cnt, (size_t)n)))
+        (rc = pxg_reserve(ctx, ctx->unsplit_ivoff, (size_t)n + 1)) ||
+        (rc = pxg_reserve(ctx, ctx->unsplit_iv, (size_t)std::max<int64_t>(cap_intervals, 1) * 2)) ||
+        (rc = pxg_reserve(ctx, ctx->unsplit_cnt, (size_t)n)) ||
+        (rc = pxg_reserve(ctx, ctx->unsplit_scr, pxg_unsplit_scratch_bytes(ctx, units_bound, tmax))) ||
+        (rc = pxg_reserve(ctx, ctx->unsplit_cand, pxg_unsplit_cand_bytes(units_bound))))
         return rc;
     int64_t* d_first = ctx->ev_first.p;
     int64_t* d_eoff = ctx->ev_off.p;
-    float* d_mean = ctx->ev_mean.p;
-    float* d_scaled = ctx->ev_scaled.p;
-    int64_t* d_iv = ctx->unsplit_iv.p;
-    int32_t* d_cnt = ctx->unsplit_cnt.p;
-    PXG_HIP(ctx, hipMemcpyAsync(d_first, first_sample, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    PXG_HIP(ctx, hipMemcpyAsync(d_first, first.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     PXG_HIP(ctx, hipMemcpyAsync(d_eoff, eoff.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-    PXG_HIP(ctx, hipMemsetAsync(d_iv, 0, (size_t)n * PXG_MAX_UNSPLIT * 2 * sizeof(int64_t), ctx->stream));
     pxg_timer_begin(ctx, PXG_T_EVENT_MEANS);
     rc = pxg_launch_guppy_event_means(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p,
-                                      d_first, d_eoff, block_stride, d_mean, d_scaled);
+                                      d_first, d_eoff, block_stride, ctx->ev_mean.p, ctx->ev_scaled.p);
     if (rc) return rc;
     pxg_timer_end(ctx, PXG_T_EVENT_MEANS);
-    // plan: windows per read (device) -> unit offsets (host prefix sum) while K7a runs
-    if ((rc = pxg_launch_unsplit_plan(ctx, n, ctx->calib.p, ctx->status.p, ctx->segs.p, d_first, d_eoff,
-                                      block_stride, ctx->n_win.p)))
-        return rc;
-    std::vector<int32_t> nwin((size_t)n);
-    HOOK_GET(nwin.data(), ctx->n_win.p, n);
-    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<int64_t> uoff((size_t)n + 1, 0);
-    for (int64_t i = 0; i < n; i++) {
-        if (nwin[i] < 0)
-            return fail(ctx, PXG_E_UNSUPPORTED, "pxg_batch_unsplit_scan: a window exceeds 4096 event blocks");
-        uoff[i + 1] = uoff[i] + nwin[i];
-    }
-    const int64_t n_units = uoff[n];
-    if ((rc = pxg_reserve(ctx, ctx->unsplit_scr, pxg_unsplit_scratch_bytes(ctx, n_units))) ||
-        (rc = pxg_reserve(ctx, ctx->unsplit_cand, pxg_unsplit_cand_bytes(n_units))))
-        return rc;
-    PXG_HIP(ctx, hipMemcpyAsync(ctx->unit_off.p, uoff.data(), ((size_t)n + 1) * sizeof(int64_t),
-                                hipMemcpyHostToDevice, ctx->stream));
     pxg_timer_begin(ctx, PXG_T_UNSPLIT);
-    rc = pxg_launch_unsplit_scan(ctx, n, n_units, ctx->calib.p, ctx->status.p, ctx->segs.p, d_first, d_eoff,
-                                 ctx->unit_off.p, ctx->n_win.p, d_scaled, block_stride, ctx->unsplit_scr.p,
-                                 ctx->unsplit_cand.p, d_iv, d_cnt);
-    if (rc) return rc;
+    // plan -> unit offsets -> scan -> per-read counts -> interval offsets -> compact gather,
+    // all on the stream: nothing here waits for the device
+    if ((rc = pxg_launch_unsplit_plan(ctx, n, ctx->calib.p, ctx->status.p, ctx->segs.p, d_first, d_eoff,
+                                      block_stride, ctx->n_win.p)) ||
+        (rc = pxg_launch_exclusive_scan(ctx, n, ctx->n_win.p, ctx->unit_off.p)) ||
+        (rc = pxg_launch_unsplit_scan(ctx, n, units_bound, tmax, ctx->calib.p, ctx->status.p, ctx->segs.p,
+                                      d_first, d_eoff, ctx->unit_off.p, ctx->ev_scaled.p, block_stride,
+                                      ctx->unsplit_scr.p, ctx->unsplit_cand.p, ctx->unsplit_cnt.p)) ||
+        (rc = pxg_launch_exclusive_scan(ctx, n, ctx->unsplit_cnt.p, ctx->unsplit_ivoff.p)) ||
+        (rc = pxg_launch_unsplit_gather(ctx, n, units_bound, ctx->unit_off.p, ctx->unsplit_cand.p,
+                                        ctx->unsplit_cnt.p, ctx->unsplit_ivoff.p, cap_intervals,
+                                        ctx->unsplit_iv.p)))
+        return rc;
     pxg_timer_end(ctx, PXG_T_UNSPLIT);
-    HOOK_GET(out_intervals, d_iv, (size_t)n * PXG_MAX_UNSPLIT * 2);
-    HOOK_GET(out_count, d_cnt, n);
+    HOOK_GET(out_count, ctx->unsplit_cnt.p, n);
+    HOOK_GET(out_total, ctx->unsplit_ivoff.p + n, 1);
     PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t got = std::min(*out_total, cap_intervals);
+    if (got > 0) HOOK_GET(out_intervals, ctx->unsplit_iv.p, (size_t)got * 2);
+    for (int64_t i : bad) out_count[i] = PXG_UNSPLIT_E_GEOMETRY;
+    HOOK_END
+}
+
+extern "C" int pxg_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
+                         const pxg_calib* calib, const float* scale_shift, const int32_t* seg_first,
+                         const int32_t* seg_last, pxg_read_result* out, pxg_polya_spike* spikes_or_null)
+{
+    HOOK_BEGIN
+    if (n <= 0) return PXG_OK;
+    if (!off || !calib || !scale_shift || !seg_first || !seg_last || !out || (off[n] > 0 && !raw))
+        return fail(ctx, PXG_E_INVALID, "pxg_polya: bad arguments");
+    std::vector<int32_t> segs((size_t)n * 2 * PXG_N_SEGMENTS);
     for (int64_t i = 0; i < n; i++)
-        if (out_count[i] < 0)
-            return fail(ctx, PXG_E_UNSUPPORTED, "pxg_batch_unsplit_scan: more than 8 candidate adapters in one window");
+        for (int q = 0; q < PXG_N_SEGMENTS; q++) {
+            segs[(size_t)i * 2 * PXG_N_SEGMENTS + q] = seg_first[i * PXG_N_SEGMENTS + q];
+            segs[(size_t)i * 2 * PXG_N_SEGMENTS + PXG_N_SEGMENTS + q] = seg_last[i * PXG_N_SEGMENTS + q];
+        }
+    int16_t* d_raw = S.put(raw, (size_t)off[n], ctx->stream);
+    int64_t* d_off = S.put(off, (size_t)n + 1, ctx->stream);
+    pxg_calib* d_cal = S.put(calib, (size_t)n, ctx->stream);
+    float* d_ss = S.put(scale_shift, (size_t)n * 2, ctx->stream);
+    int32_t* d_segs = S.put(segs.data(), segs.size(), ctx->stream);
+    int32_t* d_status = S.alloc<int32_t>((size_t)n);
+    int32_t* d_pout = S.alloc<int32_t>((size_t)n * 8);
+    pxg_polya_spike* d_spk = S.alloc<pxg_polya_spike>((size_t)n * PXG_MAX_SPIKES);
+    HOOK_CHECK(d_raw && d_off && d_cal && d_ss && d_segs && d_status && d_pout && d_spk);
+    PXG_HIP(ctx, hipMemsetAsync(d_status, 0, (size_t)n * sizeof(int32_t), ctx->stream));
+    PXG_HIP(ctx, hipMemsetAsync(d_spk, 0, (size_t)n * PXG_MAX_SPIKES * sizeof(pxg_polya_spike), ctx->stream));
+    int rc = pxg_launch_polya(ctx, n, d_raw, d_off, d_cal, d_ss, d_status, d_segs, d_pout, d_spk);
+    if (rc) return rc;
+    std::vector<int32_t> po((size_t)n * 8);
+    HOOK_GET(po.data(), d_pout, po.size());
+    if (spikes_or_null) HOOK_GET(spikes_or_null, d_spk, (size_t)n * PXG_MAX_SPIKES);
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memset(out, 0, (size_t)n * sizeof(pxg_read_result));
+    for (int64_t i = 0; i < n; i++) {
+        pxg_read_result& o = out[i];
+        const int32_t* q = &po[(size_t)i * 8];
+        o.status = PXG_ST_OKAY;
+        o.n_pooled = (int32_t)((off[i + 1] - off[i]) / ctx->cfg.stride);
+        for (int k = 0; k < PXG_N_SEGMENTS; k++) {
+            o.seg_first[k] = seg_first[i * PXG_N_SEGMENTS + k];
+            o.seg_last[k] = seg_last[i * PXG_N_SEGMENTS + k];
+        }
+        o.scale = scale_shift[2 * i];
+        o.shift = scale_shift[2 * i + 1];
+        o.bc_label = -1;
+        o.polya_called = (int8_t)q[0];
+        o.polya_n_spikes = (int8_t)q[1];
+        o.polya_dwell_samples = q[2];
+        o.polya_begin = (int64_t)(((uint64_t)(uint32_t)q[4] << 32) | (uint32_t)q[3]);
+        o.polya_end = (int64_t)(((uint64_t)(uint32_t)q[6] << 32) | (uint32_t)q[5]);
+    }
     HOOK_END
 }

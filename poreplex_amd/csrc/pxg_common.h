@@ -216,6 +216,7 @@ struct pxg_ctx {
         DevBuf<float> inject;
         int64_t n_reads = 0, n_samples = 0;
         bool have_inject = false, staged = false;
+        double rate_min = 0.0, rate_max = 0.0;
     } spare;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_staged = nullptr;
@@ -248,8 +249,10 @@ struct pxg_ctx {
     DevBuf<char> unsplit_cand;          // K7: per-window candidates
     DevBuf<int64_t> unit_off;           // K7: first (read, window) unit of each read
     DevBuf<int32_t> n_win;              // K7: windows per read
-    DevBuf<int64_t> unsplit_iv;         // n x PXG_MAX_UNSPLIT x 2
+    DevBuf<int64_t> unsplit_iv;         // compact candidate list (pairs), all reads back to back
+    DevBuf<int64_t> unsplit_ivoff;      // n + 1: first pair of each read
     DevBuf<int32_t> unsplit_cnt;
+    double rate_min = 0.0, rate_max = 0.0;   // sampling-rate range of the resident batch (host copy)
 
     hipEvent_t ev_start[PXG_N_TIMERS];
     hipEvent_t ev_stop[PXG_N_TIMERS];
@@ -333,13 +336,16 @@ int pxg_launch_guppy_event_means(pxg_ctx* ctx, int64_t n, const int16_t* raw, co
 int pxg_launch_unsplit_plan(pxg_ctx* ctx, int64_t n, const pxg_calib* cal, const int32_t* status,
                             const int32_t* segs, const int64_t* first_sample, const int64_t* ev_off,
                             int stride, int32_t* n_win);
-size_t pxg_unsplit_scratch_bytes(const pxg_ctx* ctx, int64_t n_units);
-size_t pxg_unsplit_cand_bytes(int64_t n_units);
-int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t n_units, const pxg_calib* cal,
+int pxg_launch_exclusive_scan(pxg_ctx* ctx, int64_t n, const int32_t* in, int64_t* out /* n + 1 */);
+size_t pxg_unsplit_scratch_bytes(const pxg_ctx* ctx, int64_t units_bound, int tmax);
+size_t pxg_unsplit_cand_bytes(int64_t units_bound);
+int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t units_bound, int tmax, const pxg_calib* cal,
                             const int32_t* status, const int32_t* segs, const int64_t* first_sample,
-                            const int64_t* ev_off, const int64_t* unit_off, const int32_t* n_win,
-                            const float* scaled, int stride, void* scratch, void* candbuf,
-                            int64_t* out_iv, int32_t* out_cnt);
+                            const int64_t* ev_off, const int64_t* unit_off, const float* scaled, int stride,
+                            void* scratch, void* candbuf, int32_t* out_cnt);
+int pxg_launch_unsplit_gather(pxg_ctx* ctx, int64_t n, int64_t units_bound, const int64_t* unit_off,
+                              const void* candbuf, const int32_t* out_cnt, const int64_t* iv_off,
+                              int64_t cap, int64_t* out_iv);
 
 void pxg_timer_begin(pxg_ctx* ctx, int t);
 void pxg_timer_end(pxg_ctx* ctx, int t);

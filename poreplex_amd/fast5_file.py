@@ -91,7 +91,8 @@ class BundleReader:
                 'mean_qscore': float(np.float32(bc['mean_qscore'])),
                 'num_events': int(bc['num_events']),
                 'first_sample_template': int(bc['first_sample_template']),
-                'move': bc.get('move')}
+                'table': bc.get('table', 'move' if bc.get('move') is not None else None),
+                'move': bc.get('move'), 'p_model_state': bc.get('p_model_state')}
 
 
 class Fast5Reader:
@@ -132,36 +133,50 @@ class Fast5Reader:
         self.run_id, self.sample_id = s(tr['run_id']), s(tr['sample_id'])
 
     def close(self):
-        if self.handle is not None:
-            self.handle.close()
-            self.handle = None
+        handle, self.handle = self.handle, None
+        if handle is not None:
+            handle.close()
 
     def get_raw_int16(self):
         return np.asarray(self.handle[self.read_node + '/Signal'][()], dtype=np.int16)
 
     def get_basecall(self, analysis_group='Basecall_1D'):
-        try:
-            analnode = self.handle[self.analyses_node]
-        except KeyError:
-            return None
-        groups = [n for n in analnode.keys() if n.startswith(analysis_group)]
+        analnode = self.handle.get(self.analyses_node)
+        groups = sorted(n for n in (analnode or ()) if n.startswith(analysis_group))
         if not groups:
             return None
-        analyses = analnode[max(groups)]
+        analyses = analnode[groups[-1]]            # highest-numbered group wins (:143)
         groupno = analyses.name.rsplit('_', 1)[-1]
         seg = analnode['Segmentation_{}/Summary/segmentation'.format(groupno)].attrs
         fq = analyses['BaseCalled_template/Fastq'][()]
         fq = (fq.decode() if isinstance(fq, bytes) else str(fq)).split('\n')
         sm = analyses['Summary/{}_template'.format(analysis_group.lower())].attrs
-        move = None
-        if 'BaseCalled_template/Move' in analyses:
-            move = analyses['BaseCalled_template/Move'][()].tolist()
+        # event mapping (fast5_file.py:166-181): `Events' (albacore, guppy < 2.3.7) wins over
+        # `Move' (guppy >= 2.3.7); Guppy tables only say which blocks moved, the block means
+        # are re-cut from the raw signal (on the GPU here)
+        table, move, pms = None, None, None
+        if 'BaseCalled_template/Events' in analyses:
+            ev = analyses['BaseCalled_template/Events'][()]
+            cols = ev.dtype.names or ()
+            if len(cols) <= 3 and 'move' in cols:
+                table = 'guppy_events'
+            elif len(cols) == 14:
+                table = 'albacore'
+            else:
+                table = 'unsupported'
+            if 'move' in cols:
+                move = ev['move'].tolist()
+            if 'p_model_state' in cols:
+                pms = ev['p_model_state'].astype(np.float64).tolist()
+        elif 'BaseCalled_template/Move' in analyses:
+            table, move = 'move', analyses['BaseCalled_template/Move'][()].tolist()
         return {'sequence': fq[1], 'qstring': fq[3],
                 'block_stride': int(sm.get('block_stride', 15)),
                 'sequence_length': int(sm['sequence_length']),
                 'mean_qscore': float(sm['mean_qscore']),
                 'num_events': int(seg['num_events_template']),
-                'first_sample_template': int(seg['first_sample_template']), 'move': move}
+                'first_sample_template': int(seg['first_sample_template']),
+                'table': table, 'move': move, 'p_model_state': pms}
 
 
 def get_read_ids(filename, basedir, bundle=None):

@@ -15,14 +15,15 @@ from . import config as _config
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'csrc', 'libpxg.so')
 
-PXG_ABI_VERSION = 1
+PXG_ABI_VERSION = 2
 PXG_MAX_STATES = 8
 PXG_MAX_MIXTURE = 4
 PXG_N_SEGMENTS = 8
 PXG_MAX_CLASSES = 8
 PXG_MAX_CALIBRATION = 64
 PXG_MAX_SPIKES = 64
-PXG_MAX_UNSPLIT = 64
+UNSPLIT_E_WINDOW_CANDS = -2
+UNSPLIT_E_GEOMETRY = -3
 
 STATUS_NAMES = (
     'okay', 'disappeared', 'irregular_fast5', 'scaler_signal_too_short',
@@ -330,6 +331,8 @@ _SIGNATURES = {
                                    C.c_void_p, C.c_void_p]),
     'pxg_batch_stage': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
+    'pxg_batch_upload_tiled': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     'pxg_batch_swap': (C.c_int, [C.c_void_p]),
     'pxg_host_register': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     'pxg_host_unregister': (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -354,8 +357,10 @@ _SIGNATURES = {
     'pxg_guppy_event_means': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                                         C.c_void_p]),
-    'pxg_batch_unsplit_scan': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
-                                         C.c_void_p, C.c_void_p]),
+    'pxg_batch_unsplit_scan': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                                         C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    'pxg_polya': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pxg_detect_events': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_int64, C.c_void_p, C.c_void_p]),
 }
@@ -464,6 +469,16 @@ class NativeContext:
             self.handle, n, _ptr(arena), _ptr(offsets), _ptr(calib), _ptr(scale_shift)),
             'pxg_batch_upload')
         self.n_resident = n
+
+    def upload_tiled(self, n_reads, arena, offsets, calib, scale_shift=None, phase=0):
+        """Resident batch of `n_reads` reads, read j = base read (phase + j) % len(base),
+        replicated on the device from ONE upload of the distinct base reads (configs[3]/[4]
+        shapes: 12-15 GB of int16 per GPU never exist on the host)."""
+        arena, offsets, calib, scale_shift, nb = self._prep(arena, offsets, calib, scale_shift)
+        self._check(self.lib.pxg_batch_upload_tiled(
+            self.handle, int(n_reads), nb, int(phase), _ptr(arena), _ptr(offsets), _ptr(calib),
+            _ptr(scale_shift)), 'pxg_batch_upload_tiled')
+        self.n_resident = int(n_reads)
 
     def stage(self, arena, offsets, calib, scale_shift=None):
         """Copy the NEXT batch into the spare input slot on the copy stream while the
@@ -615,18 +630,41 @@ class NativeContext:
         return mean, scaled, eoff
 
     def unsplit_scan(self, first_sample, n_blocks, block_stride=15):
-        """Window scan of detect_unsplit_read on the resident batch."""
+        """Window scan of detect_unsplit_read on the resident batch.  Returns (intervals
+        [total, 2] int64, count [n] int32, start [n+1] int64): the candidates of read r are
+        intervals[start[r]:start[r+1]]; count[r] < 0 is that read's own error code."""
         n = self.n_resident
         first = np.ascontiguousarray(first_sample, dtype=np.int64)
         nb = np.ascontiguousarray(n_blocks, dtype=np.int64)
         if len(first) != n or len(nb) != n:
             raise ValueError('one first_sample / n_blocks entry per resident read')
-        iv = np.zeros((n, PXG_MAX_UNSPLIT, 2), dtype=np.int64)
-        cnt = np.zeros(n, dtype=np.int32)
-        self._check(self.lib.pxg_batch_unsplit_scan(self.handle, _ptr(first), _ptr(nb),
-                                                    block_stride, _ptr(iv), _ptr(cnt)),
-                    'pxg_batch_unsplit_scan')
-        return iv, cnt
+        cnt = np.empty(n, dtype=np.int32)
+        total = C.c_int64(0)
+        cap = max(getattr(self, '_unsplit_cap', 0), n // 4 + 1024)
+        while True:
+            iv = np.empty((cap, 2), dtype=np.int64)
+            self._check(self.lib.pxg_batch_unsplit_scan(self.handle, _ptr(first), _ptr(nb),
+                                                        block_stride, cap, _ptr(iv), _ptr(cnt),
+                                                        C.byref(total)), 'pxg_batch_unsplit_scan')
+            if total.value <= cap:
+                break
+            cap = int(total.value) + 1024        # rare: more candidates than the guess, run again
+        self._unsplit_cap = cap
+        start = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.maximum(cnt, 0), out=start[1:])
+        return iv[:total.value], cnt, start
+
+    def polya(self, arena, offsets, calib, scale_shift, seg_first, seg_last, want_spikes=True):
+        """a14-a17 on caller-supplied scaling and segmentation (standalone hook)."""
+        arena, offsets, calib, scale_shift, n = self._prep(arena, offsets, calib, scale_shift)
+        sf = np.ascontiguousarray(seg_first, dtype=np.int32).reshape(n, PXG_N_SEGMENTS)
+        sl = np.ascontiguousarray(seg_last, dtype=np.int32).reshape(n, PXG_N_SEGMENTS)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        spikes = np.zeros((n, PXG_MAX_SPIKES, 4), dtype=np.float32) if want_spikes else None
+        self._check(self.lib.pxg_polya(self.handle, n, _ptr(arena), _ptr(offsets), _ptr(calib),
+                                       _ptr(scale_shift), _ptr(sf), _ptr(sl), _ptr(out),
+                                       _ptr(spikes)), 'pxg_polya')
+        return out, spikes
 
     def detect_events(self, signals, max_events=None):
         sigs = [np.ascontiguousarray(s, dtype=np.float32) for s in signals]

@@ -3,174 +3,200 @@
 Drop-in for poreplex/signal_analyzer.py: ``process_batch(batchid, reads,
 config)`` (picklable, :46-58), ``SignalAnalyzer(config, batchid)`` context
 manager with ``.process(reads)`` (:61-134) and ``SignalAnalysis`` (:214-466).
-Same signatures, result-dict schema, status/label vocabulary and result order;
-every numeric stage between int16 DAQ samples and the per-read record runs in
-HIP behind the C ABI (include/pxg.h).  There is no CPU fallback: a missing
-library or GPU surfaces as the ``(-1, msg, traceback)`` tuple the pipeline
-treats as fatal (pipeline.py:207-213).
+Same signatures, result-dict schema, status/label vocabulary and result order.
+
+How it differs inside: the reference walks reads one object at a time in
+Python; here every numeric stage between int16 DAQ samples and the per-read
+record runs in HIP behind the C ABI (include/pxg.h) in ONE pass per batch, and
+what is left on the host is written over the columns of the batch's
+``ReadTable`` (signal_loader.py) -- status / label rules are mask operations
+on the ``pxg_read_result`` array, only the steps that must open a read's
+basecall group run per read.  There is no CPU fallback: a missing library or
+GPU surfaces as the ``(-1, msg, traceback)`` tuple the pipeline treats as fatal
+(pipeline.py:207-213).
 """
 import os
 import sys
 import traceback
-from io import StringIO
+from contextlib import AbstractContextManager
 from weakref import proxy
 
 import numpy as np
 
 from . import native
-from .signal_loader import SignalAnalysisError
+from .signal_loader import NanoporeRead, SignalAnalysisError
 from .utils import union_intervals  # noqa: F401  (re-exported like the reference)
 from .worker_persistence import WorkerPersistenceStorage
 
 __all__ = ['SignalAnalyzer', 'SignalAnalysis', 'process_batch']
 
+# the two message layouts downstream log parsers know (signal_analyzer.py:56-58,141-146)
+BATCH_ERROR_FORMAT = '[{filename}:{lineno}] Unhandled exception {name}: {msg}'
+READ_ERROR_FORMAT = ('[{srcfilename}:{lineno}] ({f5filename}#{read_id}) Unhandled '
+                     'exception {name}: {msg}\n{exc}')
 
-# This function must be picklable.
+
+def _where_caught(excinfo):
+    """(source file name, line) of the frame that caught the exception, plus the
+    formatted traceback."""
+    tb = excinfo[2]
+    return (os.path.basename(tb.tb_frame.f_code.co_filename), tb.tb_lineno,
+            ''.join(traceback.format_exception(*excinfo)))
+
+
 def process_batch(batchid, reads, config):
+    """Worker entry point (top level, so it pickles into a ProcessPoolExecutor).  Returns
+    the result-dict list, or the fatal ``(-1, message, traceback)`` tuple."""
+    analyzer = None
     try:
-        with SignalAnalyzer(config, batchid) as analyzer:
-            return analyzer.process(reads)
+        analyzer = SignalAnalyzer(config, batchid)
+        return analyzer.process(reads)
     except Exception as exc:
-        exc_type, exc_obj, exc_tb = sys.exc_info()
-        filename = os.path.split(exc_tb.tb_frame.f_code.co_filename)[-1]
-        errorf = StringIO()
-        traceback.print_exc(file=errorf)
-        return (-1, '[{filename}:{lineno}] Unhandled exception {name}: {msg}'.format(
-            filename=filename, lineno=exc_tb.tb_lineno,
-            name=type(exc).__name__, msg=str(exc)), errorf.getvalue())
+        srcname, lineno, text = _where_caught(sys.exc_info())
+        return (-1, BATCH_ERROR_FORMAT.format(filename=srcname, lineno=lineno,
+                                              name=type(exc).__name__, msg=str(exc)), text)
+    finally:
+        if analyzer is not None:
+            analyzer.close()
 
 
-class SignalAnalyzer:
+class SignalAnalyzer(AbstractContextManager):
+    """Context manager; `with SignalAnalyzer(config, batchid) as analyzer` yields itself."""
 
     def __init__(self, config, batchid):
         WorkerPersistenceStorage(config).retrieve_objects(self)
         self.config = config
-        self.inputdir = config['inputdir']
-        self.outputdir = config['outputdir']
-        self.batchid = batchid
-        self.formatted_batchid = format(batchid, '08d')
+        self.inputdir, self.outputdir = config['inputdir'], config['outputdir']
+        self.batchid, self.formatted_batchid = batchid, format(batchid, '08d')
         if config.get('dump_adapter_signals') or config.get('dump_basecalls'):
             raise NotImplementedError('HDF5 dump outputs are outside the hot path')
-        mask = native.STAGE_SCALER | native.STAGE_SEGMENT
-        if config['barcoding']:
-            mask |= native.STAGE_BARCODE
-        if config['measure_polya']:
-            mask |= native.STAGE_POLYA
-        self.loader.stage_mask = mask
+        self.loader.stage_mask = (
+            native.STAGE_SCALER | native.STAGE_SEGMENT
+            | (native.STAGE_BARCODE if config['barcoding'] else 0)
+            | (native.STAGE_POLYA if config['measure_polya'] else 0))
         self.loader.scan_unsplit = bool(config.get('filter_unsplit_reads'))
 
+    # ---- batch driver --------------------------------------------------------
     def process(self, reads):
-        results, loaded = [], []
-        nextprocs = []
-        prepare_loading = self.loader.prepare_loading
+        """Result list of signal_analyzer.py:82-134: whatever was decided before the GPU
+        pass first (encounter order), then every read that entered it (input order)."""
+        loader = self.loader
+        table = loader.table
+        early, entered = [], []          # early: finished dicts, or table rows to report
         for f5file, read_id in reads:
-            if not self.loader.exists(f5file):
-                results.append({'filename': f5file, 'status': 'disappeared'})
+            if not loader.exists(f5file):
+                early.append({'filename': f5file, 'status': 'disappeared'})
                 continue
             try:
-                npread = prepare_loading(f5file, read_id)
-                if npread.is_stopped():
-                    results.append(npread.report())
-                else:
-                    nextprocs.append(SignalAnalysis(npread, self))
-                    loaded.append(npread)
+                row = loader.prepare_loading(f5file, read_id).row
             except Exception as exc:
-                results.append(self.pack_unhandled_exception(f5file, read_id, exc, sys.exc_info()))
+                early.append(self.pack_unhandled_exception(f5file, read_id, exc, sys.exc_info()))
+                continue
+            (early if table.stopped[row] else entered).append(row)
 
-        # scaling parameters -- and, in the same GPU pass, every other numeric stage
-        self.loader.fit_scalers()
+        loader.fit_scalers()             # scaling parameters AND every other numeric stage
+        self.judge(entered)
+        table.release(entered)
 
-        for siganal in nextprocs:
-            try:
-                if not siganal.is_stopped():
-                    siganal.process()
-            except Exception as exc:
-                error = self.pack_unhandled_exception(siganal.npread.filename,
-                                                      siganal.npread.read_id, exc, sys.exc_info())
-                siganal.set_error(error)
-            finally:
-                siganal.clear_cache()
+        early_rows = [r for r in early if not isinstance(r, dict)]
+        reports = iter(table.report(early_rows + entered))
+        return [r if isinstance(r, dict) else next(reports) for r in early] + list(reports)
 
-        if self.config['barcoding']:
-            self.demuxer.predict()
+    def judge(self, rows):
+        """Status / label rules of SignalAnalysis.process (:230-286) for many rows."""
+        t, cfg = self.loader.table, self.config
+        rows = t.live_rows(rows)
+        if not len(rows):
+            return
+        rec = t.records[t.gpu_row[rows]]
+        adapter = self.ctx.state_names.index('adapter')
+        found = rec['seg_first'][:, adapter] >= 0
+        t.halt(rows[~found], 'adapter_not_detected', 'fail')
+        rows, rec = rows[found], rec[found]
 
-        for npread in loaded:
-            results.append(npread.report())
-        return results
+        # barcodes are decided before anything base-space can fail, so reads that fail
+        # later keep theirs (:243-244 queues the window first)
+        if cfg['barcoding']:
+            self.demuxer.assign(t, rows, rec)
+        broken = np.zeros(len(rows), dtype=bool)
+        if cfg['measure_polya']:
+            for k in np.nonzero(rec['polya_called'])[0].tolist():
+                broken[k] = not self._guarded(rows[k], self.polyaanalyzer, NanoporeRead(t, rows[k]))
+        for k in np.nonzero(~broken)[0].tolist():
+            broken[k] = not self._guarded(rows[k], self.base_space_checks, rows[k], rec[k])
+        done = rows[~broken & ~t.stopped[rows]]
+        t.label[done] = 0                # 'pass'
+
+    def _guarded(self, row, fn, *args):
+        """Run one read's step; a domain failure halts the read with its label, anything
+        else becomes that read's 'unknown_error' (:118-122).  False if the read is out."""
+        t = self.loader.table
+        try:
+            fn(*args)
+            return not t.stopped[row]
+        except SignalAnalysisError as exc:
+            t.halt(row, exc.args[0], 'artifact' if exc.args[0] == 'unsplit_read' else 'fail')
+        except Exception as exc:
+            err = self.pack_unhandled_exception(t.filename[row], t.read_id[row], exc, sys.exc_info())
+            NanoporeRead(t, row).set_error(err['status'], err['error_message'])
+        return False
+
+    def base_space_checks(self, row, record):
+        """The part of :262-279 that needs the read's basecall group."""
+        cfg, t = self.config, self.loader.table
+        analysis = SignalAnalysis(NanoporeRead(t, row), self)
+        segments = analysis.segments_of(record)
+        stride = cfg['signal_processing']['rough_signal_stride']
+        events = analysis.load_events()
+        if cfg['trim_adapter']:
+            analysis.trim_adapter(events, segments, stride)
+        if cfg['filter_unsplit_reads'] and analysis.detect_unsplit_read(events, segments, stride):
+            raise SignalAnalysisError('unsplit_read')
+        seq = t.sequence[row]
+        if seq is not None and len(seq[0]) - seq[2] < cfg['minimum_sequence_length']:
+            raise SignalAnalysisError('sequence_too_short')
 
     def pack_unhandled_exception(self, f5filename, read_id, exc, excinfo):
-        exc_type, exc_obj, exc_tb = excinfo
-        srcfilename = os.path.split(exc_tb.tb_frame.f_code.co_filename)[-1]
-        errorf = StringIO()
-        traceback.print_exception(exc_type, exc_obj, exc_tb, file=errorf)
-        errmsg = ('[{srcfilename}:{lineno}] ({f5filename}#{read_id}) Unhandled '
-                  'exception {name}: {msg}\n{exc}'.format(
-                      srcfilename=srcfilename, lineno=exc_tb.tb_lineno, f5filename=f5filename,
-                      read_id=read_id, name=type(exc).__name__, msg=str(exc),
-                      exc=errorf.getvalue()))
+        srcname, lineno, text = _where_caught(excinfo)
         return {'filename': f5filename, 'read_id': read_id, 'status': 'unknown_error',
-                'error_message': errmsg}
+                'error_message': READ_ERROR_FORMAT.format(
+                    srcfilename=srcname, lineno=lineno, f5filename=f5filename, read_id=read_id,
+                    name=type(exc).__name__, msg=str(exc), exc=text)}
 
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
+    def __exit__(self, exc_type, exc_value, tb):
         self.close()
 
     def close(self):
-        pass
+        """Nothing to flush: the GPU context outlives the batch (worker_persistence)."""
 
 
 class SignalAnalysis:
+    """One read's view of the batch (the reference's per-read object)."""
 
     def __init__(self, npread, analyzer):
-        self.npread = npread
-        self.config = analyzer.config
-        self.analyzer = proxy(analyzer)
+        self.npread, self.config, self.analyzer = npread, analyzer.config, proxy(analyzer)
 
     def set_error(self, error):
+        """`error`: a pack_unhandled_exception dict."""
         self.npread.set_error(error['status'], error['error_message'])
 
     def is_stopped(self):
+        """True once a domain failure ended this read's processing."""
         return self.npread.is_stopped()
 
     def clear_cache(self):
+        """Drop the raw samples and close the read's file."""
         self.npread.close()
 
-    def segments_of(self, record):
-        """pxg_read_result -> {state name: (first, last)} (signal_analyzer.py:354-362)."""
-        names = self.analyzer.ctx.state_names
-        return {names[i]: (int(record['seg_first'][i]), int(record['seg_last'][i]))
-                for i in range(len(names)) if record['seg_first'][i] >= 0}
-
     def process(self):
-        """Stage order and status/label rules of signal_analyzer.py:230-286."""
-        stride = self.config['signal_processing']['rough_signal_stride']
-        rec = self.npread.native
-        try:
-            segments = self.segments_of(rec)
-            if 'adapter' not in segments:
-                raise SignalAnalysisError('adapter_not_detected')
-            if self.config['barcoding']:
-                self.push_barcode_signal(None, segments)
-            if self.config['measure_polya']:
-                self.analyzer.polyaanalyzer(self.npread)
-            events = self.load_events()
-            if self.config['trim_adapter']:
-                self.trim_adapter(events, segments, stride)
-            if self.config['filter_unsplit_reads']:
-                if self.detect_unsplit_read(events, segments, stride):
-                    raise SignalAnalysisError('unsplit_read')
-            if self.npread.sequence is not None:
-                readlength = len(self.npread.sequence[0]) - self.npread.sequence[2]
-                if readlength < self.config['minimum_sequence_length']:
-                    raise SignalAnalysisError('sequence_too_short')
-        except SignalAnalysisError as exc:
-            outname = 'artifact' if exc.args[0] in ('unsplit_read',) else 'fail'
-            self.npread.set_status(exc.args[0], stop=True)
-            self.npread.set_label(outname)
-        else:
-            self.npread.set_label('pass')
+        """Single-read entry: the batch rules applied to this row alone."""
+        self.analyzer.judge([self.npread.row])
+
+    def segments_of(self, record):
+        """pxg_read_result -> {state name: (first, last)} (:354-362)."""
+        names = self.analyzer.ctx.state_names
+        first, last = record['seg_first'].tolist(), record['seg_last'].tolist()
+        return {name: (first[i], last[i]) for i, name in enumerate(names) if first[i] >= 0}
 
     def load_events(self):
         if self.config['albacore_onthefly']:
@@ -184,72 +210,70 @@ class SignalAnalysis:
 
     def event_frame(self, bcall):
         """Base-space columns of the Guppy event table (fast5_file.py:183-208,
-        signal_analyzer.py:319-324).  The signal-space columns (mean,
-        scaled_mean) live on the GPU: SignalLoader.scan_unsplit_candidates."""
-        first, n_blocks, stride = self.npread.guppy_event_geometry()
+        signal_analyzer.py:319-324).  The signal-space columns (mean, scaled_mean) never
+        leave the GPU: SignalLoader.scan_unsplit_candidates."""
+        first, n_blocks, stride = self.npread.guppy_event_geometry(bcall=bcall)
         moves = np.asarray(bcall['move'], dtype=np.uint8)
-        pos = moves.cumsum() - 1
-        kmer_size = len(bcall['sequence']) - int(moves.sum()) + 1
-        qual = 1 - 10 ** -((np.frombuffer(bcall['qstring'].encode(), 'B') - 33) / 10)
-        if kmer_size == 5:          # Guppy old models
-            posshift = 2
-        elif kmer_size == 1:        # Guppy flip-flop models
-            posshift = 0
-        else:
-            raise Exception('Move table is encoded with an unknown kmer-size.')
-        start = np.arange(first, first + stride * n_blocks, stride)
-        return {'start': start, 'end': start + np.hstack((np.diff(start), [1])).astype(np.int64),
-                'move': moves, 'pos': np.cumsum(moves), 'p_model_state': qual[pos + posshift]}
+        if bcall.get('table') == 'guppy_events':         # Events table: the column is stored
+            if bcall.get('p_model_state') is None:
+                raise KeyError('p_model_state')
+            pms = np.asarray(bcall['p_model_state'], dtype=np.float64)
+        else:                                            # Move table: from the quality string
+            lead = {5: 2, 1: 0}.get(len(bcall['sequence']) - int(moves.sum()) + 1)
+            if lead is None:
+                raise Exception('Move table is encoded with an unknown kmer-size.')
+            phred = np.frombuffer(bcall['qstring'].encode(), 'B') - 33
+            pms = (1 - 10 ** -(phred / 10))[moves.cumsum() - 1 + lead]
+        start = first + stride * np.arange(n_blocks, dtype=np.int64)
+        end = np.append(start[1:], start[-1:] + 1) if n_blocks else start
+        return {'start': start, 'end': end, 'move': moves, 'pos': np.cumsum(moves),
+                'p_model_state': pms}
 
     def trim_adapter(self, events, segments, elspan):
-        # signal_analyzer.py:328-331: returns as soon as a sequence is present,
-        # which is always after load_events -> adapter trimming is a no-op in
-        # this revision of the reference (SURVEY section 0).
-        if self.npread.sequence is not None:
-            return
+        # signal_analyzer.py:328-331 returns as soon as a sequence is present, which is
+        # always the case after load_events: --trim-adapter is a no-op in this revision of
+        # the reference (SURVEY section 0) and stays one here.
+        return
 
     def detect_unsplit_read(self, events, segments, elspan):
-        """Decision rule of signal_analyzer.py:366-443 over the candidate
-        in-read adapters the GPU window scan found for this read."""
-        try:
-            payload_start = (segments['adapter'][1] + 1) * elspan
-        except (KeyError, IndexError):
+        """Decision rule of :420-443 over the in-read adapter candidates the GPU window
+        scan found for this read: count confidently called bases in the stretches between
+        the candidates and compare the later sub-reads with the first."""
+        t, row = self.npread.table, self.npread.row
+        if 'adapter' not in segments:
             return False            # must be an adapter-only read
-        if self.npread.native_unsplit_count > native.PXG_MAX_UNSPLIT:
-            raise Exception('more than {} in-read adapter candidates'.format(native.PXG_MAX_UNSPLIT))
-        excessive_adapters = self.npread.native_unsplit
-        if not excessive_adapters:
+        if t.unsplit_count[row] < 0:
+            raise Exception('chimera window scan failed for this read (code {})'.format(
+                int(t.unsplit_count[row])))
+        candidates = t.unsplit[row]
+        if not candidates:
             return False
-
-        config = self.config['unsplit_read_detection']
-        adapter_intervals = ([[0, payload_start]] + union_intervals(excessive_adapters)
-                             + [[np.inf, np.inf]])
-        basequality_cutoff = config['basecount_quality_limit']
+        limits = self.config['unsplit_read_detection']
+        payload_start = (segments['adapter'][1] + 1) * elspan
+        cuts = np.array([[0, payload_start]] + union_intervals(candidates) + [[np.inf, np.inf]])
+        # sub-read k = events whose start lies in [cuts[k, 1], cuts[k + 1, 0]], both inclusive
         start, pos, pms = events['start'], events['pos'], events['p_model_state']
-
-        def count_high_quality_reads(left, right):
-            # events[start.between(left, right)].groupby('pos')['p_model_state'].max() > cutoff
-            sel = (start >= left) & (start <= right)
-            if not sel.any():
-                return 0
-            p, q = pos[sel], pms[sel]
+        lo = np.searchsorted(start, cuts[:-1, 1], side='left')
+        hi = np.searchsorted(start, cuts[1:, 0], side='right')
+        # a base (one value of `pos`) counts when the best p_model_state among its events
+        # INSIDE the sub-read clears the limit (a cut may split a base's events)
+        hq = []
+        for a, b in zip(lo.tolist(), hi.tolist()):
+            if b <= a:
+                hq.append(0)
+                continue
+            p = pos[a:b]
             heads = np.nonzero(np.r_[True, p[1:] != p[:-1]])[0]
-            return int((np.maximum.reduceat(q, heads) > basequality_cutoff).sum())
-
-        subread_lengths = [count_high_quality_reads(left, right)
-                           for (_, left), (right, _) in zip(adapter_intervals[0:],
-                                                            adapter_intervals[1:])]
-        subread_hq_length_total = sum(subread_lengths[1:])
-        return bool(subread_hq_length_total > config['subread_basecount_limit'] or
-                    (subread_hq_length_total + 1) / (subread_lengths[0] + 1)
-                    > config['subread_baseratio_limit'])
+            hq.append(int((np.maximum.reduceat(pms[a:b], heads)
+                           > limits['basecount_quality_limit']).sum()))
+        later = sum(hq[1:])
+        return bool(later > limits['subread_basecount_limit'] or
+                    (later + 1) / (hq[0] + 1) > limits['subread_baseratio_limit'])
 
     def detect_segments(self, signal, elspan):
-        """Single-read debug path (signal_analyzer.py:346-364) through the GPU hook."""
+        """Single-read debug path (:346-364) through the GPU hook."""
         scan_limit = self.config['segmentation']['segmentation_scan_limit'] // elspan
-        if len(signal) > scan_limit:
-            signal = signal[:scan_limit]
-        first, last, _, _ = self.analyzer.ctx.viterbi([signal])
+        first, last, _, _ = self.analyzer.ctx.viterbi([signal[:scan_limit]])
         names = self.analyzer.ctx.state_names
         return {names[i]: (int(first[0][i]), int(last[0][i]))
                 for i in range(len(names)) if first[0][i] >= 0}

@@ -1,11 +1,18 @@
-"""Per-read record and batch loader (reference: poreplex/signal_loader.py).
+"""Batch read table and loader (reference module: poreplex/signal_loader.py).
 
-``NanoporeRead`` keeps the reference's attribute/report surface
-(signal_loader.py:112-198).  ``SignalLoader`` gathers the int16 DAQ samples of
-every read of a worker batch into ONE packed arena and runs all numeric stages
-in a single GPU call (``fit_scalers``), where the reference makes one Keras
-``predict`` per batch and then loops over reads in Python
-(signal_loader.py:89-109, signal_analyzer.py:107-123).
+The reference keeps one ``NanoporeRead`` object per read and walks them in
+Python between two Keras ``predict`` calls (signal_loader.py:77-109,112-198).
+A GPU worker batch is thousands of reads, so here a batch is ONE columnar
+``ReadTable`` (NumPy columns for everything numeric, the GPU's
+``pxg_read_result`` array attached as it comes back) and every rule that does
+not need a per-read file access is a column operation.  ``NanoporeRead`` is
+kept as the reference's operator surface -- same constructor-less attribute
+and method names, same ``report()`` dict (keys and order of
+signal_loader.py:165-198) -- but it is only a (table, row) handle.
+
+``SignalLoader.fit_scalers`` is the single GPU pass of the batch: scaler
+network + QC, pooling, segmentation, barcode classifier, optional poly(A) and
+the chimera window scan all run behind one upload.
 """
 import os
 
@@ -14,11 +21,272 @@ import numpy as np
 from . import native
 from .fast5_file import ReadBundle, open_read
 
-__all__ = ['SignalLoader', 'NanoporeRead', 'SignalAnalysisError']
+__all__ = ['SignalLoader', 'NanoporeRead', 'ReadTable', 'SignalAnalysisError']
+
+LABELS = ('pass', 'fail', 'artifact')
+_OKAY = native.STATUS_CODE['okay']
+_NO_LABEL = -1
 
 
 class SignalAnalysisError(Exception):
     pass
+
+
+def _grown(col, n):
+    """`col` with room for at least n rows (amortised doubling, zero filled)."""
+    if n <= len(col):
+        return col
+    out = np.zeros((max(n, 2 * len(col), 64),) + col.shape[1:], dtype=col.dtype)
+    out[:len(col)] = col
+    return out
+
+
+class ReadTable:
+    """Struct of arrays for the reads of one worker batch that opened."""
+
+    NUMERIC = (('status', np.int8), ('stopped', np.bool_), ('label', np.int8),
+               ('barcode', np.int8), ('barcode_guess', np.int8), ('barcode_phred', np.int16),
+               ('has_barcode', np.bool_), ('has_scaling', np.bool_), ('has_summary', np.bool_),
+               ('start_time', np.int64), ('duration', np.int64), ('sampling_rate', np.float64),
+               ('num_events', np.int64), ('sequence_length', np.int64),
+               ('mean_qscore', np.float64), ('n_raw', np.int64),
+               ('unsplit_count', np.int32))
+
+    def __init__(self):
+        self.n = 0
+        for name, dtype in self.NUMERIC:
+            setattr(self, name, np.zeros(0, dtype=dtype))
+        self.scale_shift = np.zeros((0, 2), dtype=np.float32)
+        self.calib = np.zeros(0, dtype=native.CALIB_DTYPE)
+        # per-row Python objects
+        self.filename, self.read_id, self.source = [], [], []
+        self.channel, self.run_id, self.sample_id = [], [], []
+        self.raw, self.sequence, self.error_message, self.polya = [], [], [], []
+        self.unsplit = []
+        # attached by the GPU pass
+        self.gpu_row = np.zeros(0, dtype=np.int64)      # row -> index in `records`, -1 if not run
+        self.records = None
+        self.spikes = None
+
+    def append(self, filename, read_id, source):
+        i = self.n
+        self.n = i + 1
+        for name, _ in self.NUMERIC:
+            setattr(self, name, _grown(getattr(self, name), self.n))
+        self.scale_shift = _grown(self.scale_shift, self.n)
+        self.calib = _grown(self.calib, self.n)
+        self.gpu_row = _grown(self.gpu_row, self.n)
+        self.status[i], self.label[i], self.gpu_row[i] = _OKAY, _NO_LABEL, -1
+        self.start_time[i], self.duration[i] = source.start_time, source.duration
+        self.sampling_rate[i] = source.sampling_rate
+        self.calib[i] = (source.range, source.digitization, source.offset, source.sampling_rate)
+        self.filename.append(filename)
+        self.read_id.append(read_id)
+        self.source.append(source)
+        self.channel.append(source.channel_number)
+        self.run_id.append(source.run_id)
+        self.sample_id.append(source.sample_id)
+        for col in (self.raw, self.sequence, self.error_message, self.polya, self.unsplit):
+            col.append(None)
+        return i
+
+    # -- column updates ------------------------------------------------------
+    def halt(self, rows, status, label=None):
+        """Domain failure of `rows`: status string, processing stops, optional label."""
+        self.status[rows] = native.STATUS_CODE[status]
+        self.stopped[rows] = True
+        if label is not None:
+            self.label[rows] = LABELS.index(label)
+
+    def live_rows(self, rows=None):
+        rows = np.arange(self.n) if rows is None else np.asarray(rows, dtype=np.int64)
+        return rows[~self.stopped[rows]]
+
+    def record_of(self, row):
+        g = self.gpu_row[row]
+        return None if g < 0 or self.records is None else self.records[g]
+
+    def release(self, rows):
+        for i in rows:
+            self.raw[i] = None
+            src = self.source[i]
+            if src is not None:
+                src.close()
+
+    # -- result dicts --------------------------------------------------------
+    def report(self, rows):
+        """Result dicts of `rows`, keys and key order of signal_loader.py:165-198."""
+        rows = [int(i) for i in rows]
+        idx = np.asarray(rows, dtype=np.int64)
+        status = [native.STATUS_NAMES[c] for c in self.status[idx].tolist()]
+        # Python's round (correctly rounded decimal), not np.round: part of the output contract
+        start = [round(a / b, 3) for a, b in zip(self.start_time[idx].tolist(),
+                                                 self.sampling_rate[idx].tolist())]
+        duration = self.duration[idx].tolist()
+        n_events = self.num_events[idx].tolist()
+        seq_len = self.sequence_length[idx].tolist()
+        # the reference's default for a read without a basecall summary is the int 0
+        qscore = [q if got else 0 for q, got in zip(self.mean_qscore[idx].tolist(),
+                                                    self.has_summary[idx].tolist())]
+        label = self.label[idx].tolist()
+        called = self.has_barcode[idx].tolist()
+        barcode = self.barcode[idx].tolist()
+        guess = self.barcode_guess[idx].tolist()
+        phred = self.barcode_phred[idx].tolist()
+        out = []
+        for k, i in enumerate(rows):
+            rep = {'filename': self.filename[i], 'read_id': self.read_id[i], 'status': status[k],
+                   'channel': self.channel[i], 'start_time': start[k], 'run_id': self.run_id[i],
+                   'sample_id': self.sample_id[i], 'duration': duration[k],
+                   'num_events': n_events[k], 'sequence_length': seq_len[k],
+                   'mean_qscore': qscore[k]}
+            if self.sequence[i] is not None:
+                rep['sequence'] = self.sequence[i]
+            if self.error_message[i]:
+                rep['error_message'] = self.error_message[i]
+            if label[k] != _NO_LABEL:
+                rep['label'] = LABELS[label[k]]
+            if called[k]:
+                rep['barcode'], rep['barcode_guess'] = barcode[k], guess[k]
+                rep['barcode_score'] = phred[k]
+            if self.polya[i] is not None:
+                rep['polya'] = self.polya[i]
+            out.append(rep)
+        return out
+
+
+class NanoporeRead:
+    """Row handle with the reference's NanoporeRead surface."""
+
+    __slots__ = ('table', 'row')
+
+    def __init__(self, table, row):
+        self.table, self.row = table, row
+
+    # identity / metadata
+    filename = property(lambda self: self.table.filename[self.row])
+    read_id = property(lambda self: self.table.read_id[self.row])
+    fast5 = property(lambda self: self.table.source[self.row])
+    sampling_rate = property(lambda self: float(self.table.sampling_rate[self.row]))
+    status = property(lambda self: native.STATUS_NAMES[self.table.status[self.row]])
+    stopped = property(lambda self: bool(self.table.stopped[self.row]))
+    error_message = property(lambda self: self.table.error_message[self.row])
+    sequence = property(lambda self: self.table.sequence[self.row])
+    polya = property(lambda self: self.table.polya[self.row])
+    num_events = property(lambda self: int(self.table.num_events[self.row]))
+    sequence_length = property(lambda self: int(self.table.sequence_length[self.row]))
+    mean_qscore = property(lambda self: float(self.table.mean_qscore[self.row])
+                           if self.table.has_summary[self.row] else 0)
+    native = property(lambda self: self.table.record_of(self.row))
+
+    @property
+    def label(self):
+        code = self.table.label[self.row]
+        return None if code == _NO_LABEL else LABELS[code]
+
+    @property
+    def scaling_params(self):
+        t = self.table
+        return t.scale_shift[self.row].copy() if t.has_scaling[self.row] else None
+
+    @property
+    def barcode(self):
+        t = self.table
+        return int(t.barcode[self.row]) if t.has_barcode[self.row] else None
+
+    @property
+    def native_spikes(self):
+        t, g = self.table, self.table.gpu_row[self.row]
+        return None if t.spikes is None or g < 0 else t.spikes[g]
+
+    # setters of the reference surface
+    def set_status(self, newstatus, stop=False):
+        t = self.table
+        t.status[self.row] = native.STATUS_CODE[newstatus]
+        t.stopped[self.row] |= bool(stop)
+
+    def set_error(self, status, error_message):
+        self.table.status[self.row] = native.STATUS_CODE[status]
+        self.table.error_message[self.row] = error_message
+
+    def set_scaling_params(self, params):
+        self.table.scale_shift[self.row] = params
+        self.table.has_scaling[self.row] = True
+
+    def set_label(self, newlabel):
+        self.table.label[self.row] = LABELS.index(newlabel)
+
+    def set_barcode(self, newbarcode, guess, quality):
+        t, i = self.table, self.row
+        t.has_barcode[i] = newbarcode is not None
+        t.barcode[i] = -1 if newbarcode is None else newbarcode
+        t.barcode_guess[i], t.barcode_phred[i] = guess, quality
+
+    def set_adapter_trimming_length(self, newlength):
+        seq = self.table.sequence[self.row]
+        if seq is None:
+            raise Exception('Sequence is not set.')
+        self.table.sequence[self.row] = (seq[0], seq[1], newlength)
+
+    def set_polya_tail(self, polya_info):
+        self.table.polya[self.row] = polya_info
+
+    def is_stopped(self):
+        return self.stopped
+
+    def close(self):
+        self.table.release([self.row])
+
+    def report(self):
+        return self.table.report([self.row])[0]
+
+    # basecall access (the FAST5 is read per read; nothing to batch)
+    def load_fast5_events(self):
+        """Basecall summary into the table (signal_loader.py:266-279).  The reference
+        builds the whole event table inside get_basecall, so a basecall group whose table
+        is missing, of an unknown kind or of the wrong size fails BEFORE any summary field
+        is stored (fast5_file.py:166-181,210-223): validate first, commit second.  The
+        table's signal columns are only materialised by the stage that consumes them."""
+        t, i = self.table, self.row
+        if t.source[i] is None:
+            raise Exception('Fast5 must be open for getting events.')
+        bcall = t.source[i].get_basecall()
+        if bcall is None:
+            raise SignalAnalysisError('not_basecalled')
+        kind = bcall.get('table', 'move' if bcall.get('move') is not None else None)
+        if kind is None:
+            raise Exception("Neither `Events' or `Move' table found in the basecall.")
+        if kind == 'unsupported':
+            raise Exception('Unsupported event table found.')
+        if kind != 'albacore':          # Guppy frames are re-cut from the raw signal
+            self.guppy_event_geometry(bcall=bcall)
+        t.sequence_length[i], t.mean_qscore[i] = bcall['sequence_length'], bcall['mean_qscore']
+        t.num_events[i], t.has_summary[i] = bcall['num_events'], True
+        t.sequence[i] = (bcall['sequence'], bcall['qstring'], 0)
+        return bcall
+
+    def guppy_event_geometry(self, n_raw=None, bcall=None):
+        """(first_sample, n_blocks, block_stride) of the Guppy event frame under the size
+        rule of convert_events_guppy (fast5_file.py:210-223): the raw slice, padded to
+        whole blocks, must hold exactly one block per move."""
+        t, i = self.table, self.row
+        if bcall is None:
+            bcall = t.source[i].get_basecall()
+        if bcall is None:
+            raise SignalAnalysisError('not_basecalled')
+        if bcall.get('move') is None:
+            raise Exception("Neither `Events' or `Move' table found in the basecall.")
+        if bcall.get('table') == 'albacore':
+            raise NotImplementedError(
+                'albacore 14-column Events tables carry their own event boundaries; the GPU '
+                'chimera filter handles Guppy block frames (Move / Guppy Events) only')
+        n_raw = int(t.n_raw[i]) if n_raw is None else int(n_raw)
+        first, stride = int(bcall['first_sample_template']), int(bcall['block_stride'])
+        n_blocks = len(bcall['move'])
+        covered = max(min(first + stride * n_blocks, n_raw) - first, 0)
+        if -(-covered // stride) != n_blocks:
+            raise Exception('Numbers of events and raw data strides does not match.')
+        return first, n_blocks, stride
 
 
 class SignalLoader:
@@ -33,12 +301,12 @@ class SignalLoader:
             'qc_scale': (float(c.scaler_qc_scale[0]), float(c.scaler_qc_scale[1])),
             'qc_shift': (float(c.scaler_qc_shift[0]), float(c.scaler_qc_shift[1])),
         }
-        self.batch_reads = []
         self.stage_mask = native.STAGE_ALL_DEMUX
         self.scan_unsplit = False      # --filter-chimera: also run the a19 window scan
+        self.table = ReadTable()
 
     def clear(self):
-        del self.batch_reads[:]
+        self.table = ReadTable()
 
     def exists(self, filename):
         if self.bundle is not None and self.bundle.has_file(filename):
@@ -46,194 +314,64 @@ class SignalLoader:
         return os.path.exists(os.path.join(self.fast5prefix, filename))
 
     def prepare_loading(self, filename, read_id):
-        npread = NanoporeRead(filename, self.fast5prefix, read_id, self.bundle)
-        # signal_loader.py:212-222: the length gate of load_padded_signal_head
-        npread.check_signal_head(self.scaler_cfg['length'], self.scaler_cfg['stride'],
-                                 self.scaler_cfg['min_length'])
-        if not npread.is_stopped():
-            self.batch_reads.append(npread)
-        return npread
+        """Open one read into the batch table.  An unreadable file raises: the reference
+        marks it 'irregular_fast5' (signal_loader.py:200-207) and then trips over the
+        missing reader, so its caller reports 'unknown_error' -- same outcome here."""
+        source = open_read(os.path.join(self.fast5prefix, filename), filename, read_id,
+                           self.bundle)
+        t = self.table
+        row = t.append(filename, read_id, source)
+        raw = np.ascontiguousarray(source.get_raw_int16(), dtype=np.int16)
+        t.n_raw[row] = len(raw)
+        cfg = self.scaler_cfg      # length gate of load_padded_signal_head (:212-222)
+        usable = min(cfg['length'], int(t.duration[row]), len(raw))
+        if usable - usable % cfg['stride'] < cfg['min_length']:
+            t.halt(row, 'scaler_signal_too_short')
+        else:
+            t.raw[row] = raw
+        return NanoporeRead(t, row)
 
     def fit_scalers(self):
-        """One GPU pass over every loaded read: scaler net + QC, pooling,
-        Viterbi segmentation, barcode window + classifier (+ poly(A))."""
-        if not self.batch_reads:
+        """The GPU pass over every read of the table that is still live."""
+        t = self.table
+        rows = t.live_rows()
+        rows = rows[[t.raw[i] is not None for i in rows]] if len(rows) else rows
+        if not len(rows):
             return
-        sigs = [r.raw for r in self.batch_reads]
-        arena, offsets = native.pack_reads(sigs)
-        calib = np.zeros(len(sigs), dtype=native.CALIB_DTYPE)
-        for i, r in enumerate(self.batch_reads):
-            calib[i] = (r.fast5.range, r.fast5.digitization, r.fast5.offset, r.fast5.sampling_rate)
-        self.ctx.upload(arena, offsets, calib)
+        arena, offsets = native.pack_reads([t.raw[i] for i in rows])
+        self.ctx.upload(arena, offsets, t.calib[rows])
         self.ctx.run(self.stage_mask)
-        records = self.ctx.download()
-        spikes = self.ctx.download_spikes() if self.stage_mask & native.STAGE_POLYA else None
-        qc_fail = native.STATUS_CODE['scaling_qc_fail']
-        for i, r in enumerate(self.batch_reads):
-            r.native = records[i]
-            r.native_spikes = None if spikes is None else spikes[i]
-            if records[i]['status'] == qc_fail:                 # signal_loader.py:108-109
-                r.set_status('scaling_qc_fail', stop=True)
-            else:
-                r.set_scaling_params(np.array([records[i]['scale'], records[i]['shift']],
-                                              dtype=np.float32))
+        t.records = rec = self.ctx.download()
+        t.spikes = self.ctx.download_spikes() if self.stage_mask & native.STAGE_POLYA else None
+        t.gpu_row[rows] = np.arange(len(rows))
+        qc_failed = rec['status'] == native.STATUS_CODE['scaling_qc_fail']   # :108-109
+        t.halt(rows[qc_failed], 'scaling_qc_fail')
+        good = rows[~qc_failed]
+        t.scale_shift[good, 0], t.scale_shift[good, 1] = rec['scale'][~qc_failed], rec['shift'][~qc_failed]
+        t.has_scaling[good] = True
         if self.scan_unsplit:
-            self.scan_unsplit_candidates(offsets)
-        for r in self.batch_reads:
-            r.raw = None
+            self.scan_unsplit_candidates(rows, offsets)
+        for i in rows:
+            t.raw[i] = None
 
-    def scan_unsplit_candidates(self, offsets):
-        """a18+a19 numeric part for the resident batch: Guppy block means of
-        every basecalled read and the windowed Viterbi scan, on the GPU
-        (signal_analyzer.py:366-418).  Reads whose event table cannot be built
-        are skipped here; SignalAnalysis.load_events raises for them."""
-        n = len(self.batch_reads)
-        first = np.zeros(n, dtype=np.int64)
-        blocks = np.zeros(n, dtype=np.int64)
-        strides = np.zeros(n, dtype=np.int64)
-        for i, r in enumerate(self.batch_reads):
+    def scan_unsplit_candidates(self, rows, offsets):
+        """a18 + a19 numeric part for the resident batch: Guppy block means of every
+        basecalled read and the windowed Viterbi scan (signal_analyzer.py:366-418), on the
+        GPU.  Reads whose event frame cannot be built are left out here; load_events raises
+        for them later, per read."""
+        t = self.table
+        n = len(rows)
+        frame = np.zeros((n, 3), dtype=np.int64)        # first sample, blocks, block stride
+        for k, i in enumerate(rows):
             try:
-                table = r.guppy_event_geometry(int(offsets[i + 1] - offsets[i]))
+                frame[k] = NanoporeRead(t, i).guppy_event_geometry(offsets[k + 1] - offsets[k])
             except Exception:
-                continue
-            first[i], blocks[i], strides[i] = table
-        for stride in sorted(set(strides[blocks > 0].tolist())):
-            sel = (strides == stride) & (blocks > 0)
-            iv, cnt = self.ctx.unsplit_scan(first, np.where(sel, blocks, 0), int(stride))
-            for i in np.nonzero(sel)[0]:
-                r = self.batch_reads[i]
-                r.native_unsplit_count = int(cnt[i])
-                r.native_unsplit = iv[i, :min(int(cnt[i]), iv.shape[1])].tolist()
-
-
-class NanoporeRead:
-
-    fast5 = error_message = None
-    sequence_length = mean_qscore = num_events = 0
-    sequence = scaling_params = label = barcode = polya = None
-    barcode_bestguess = barcode_quality = None
-    native = native_spikes = raw = None
-    native_unsplit = None
-    native_unsplit_count = 0
-
-    def __init__(self, filename, srcdir, read_id, bundle=None):
-        self.fullpath = os.path.join(srcdir, filename)
-        self.filename = filename
-        self.read_id = read_id
-        self.status = 'okay'
-        self.stopped = False
-        self.load(bundle)
-
-    def set_status(self, newstatus, stop=False):
-        self.status = newstatus
-        self.stopped = self.stopped or stop
-
-    def set_error(self, status, error_message):
-        self.status = status
-        self.error_message = error_message
-
-    def set_scaling_params(self, params):
-        self.scaling_params = params
-
-    def set_label(self, newlabel):
-        self.label = newlabel
-
-    def set_barcode(self, newbarcode, guess, quality):
-        self.barcode = newbarcode
-        self.barcode_bestguess = guess
-        self.barcode_quality = quality
-
-    def set_adapter_trimming_length(self, newlength):
-        if self.sequence is None:
-            raise Exception('Sequence is not set.')
-        self.sequence = self.sequence[:2] + (newlength,)
-
-    def set_polya_tail(self, polya_info):
-        self.polya = polya_info
-
-    def is_stopped(self):
-        return self.stopped
-
-    def close(self):
-        self.raw = None
-        if self.fast5 is not None:
-            self.fast5.close()
-
-    def report(self):
-        """Result dict, keys and order as signal_loader.py:165-198."""
-        rep = {'filename': self.filename, 'read_id': self.read_id, 'status': self.status}
-        if self.fast5 is not None:
-            rep.update({
-                'channel': self.fast5.channel_number,
-                'start_time': round(self.fast5.start_time / self.fast5.sampling_rate, 3),
-                'run_id': self.fast5.run_id,
-                'sample_id': self.fast5.sample_id,
-                'duration': self.fast5.duration,
-                'num_events': self.num_events,
-                'sequence_length': self.sequence_length,
-                'mean_qscore': self.mean_qscore,
-            })
-        if self.sequence is not None:
-            rep['sequence'] = self.sequence
-        if self.error_message:
-            rep['error_message'] = self.error_message
-        if self.label is not None:
-            rep['label'] = self.label
-        if self.barcode is not None:
-            rep['barcode'] = self.barcode
-            rep['barcode_guess'] = self.barcode_bestguess
-            rep['barcode_score'] = self.barcode_quality
-        if self.polya is not None:
-            rep['polya'] = self.polya
-        return rep
-
-    def load(self, bundle=None):
-        # The reference marks an unreadable file 'irregular_fast5' here
-        # (signal_loader.py:200-207) and then trips over fast5 == None in
-        # load_padded_signal_head, so the caller reports 'unknown_error'
-        # (SURVEY App. C / golden batch0): keep that observable behaviour by
-        # letting the exception reach SignalAnalyzer.process.
-        self.fast5 = open_read(self.fullpath, self.filename, self.read_id, bundle)
-        self.sampling_rate = self.fast5.sampling_rate
-
-    def check_signal_head(self, length_limit, stride, min_length):
-        self.raw = np.ascontiguousarray(self.fast5.get_raw_int16(), dtype=np.int16)
-        sigload_length = min(length_limit, self.fast5.duration, len(self.raw))
-        sigload_length -= sigload_length % stride
-        if sigload_length < min_length:
-            self.set_status('scaler_signal_too_short', stop=True)
-            self.raw = None
-
-    def load_fast5_events(self):
-        """Basecall summary of the FAST5 (signal_loader.py:266-279); the event
-        table itself is only materialised by the stages that consume it."""
-        if self.fast5 is None:
-            raise Exception('Fast5 must be open for getting events.')
-        bcall = self.fast5.get_basecall()
-        if bcall is None:
-            raise SignalAnalysisError('not_basecalled')
-        self.sequence_length = bcall['sequence_length']
-        self.mean_qscore = bcall['mean_qscore']
-        self.num_events = bcall['num_events']
-        self.sequence = bcall['sequence'], bcall['qstring'], 0
-        return bcall
-
-    def guppy_event_geometry(self, n_raw=None):
-        """(first_sample, n_blocks, block_stride) of the Move-table event
-        frame, with the size rule of convert_events_guppy (fast5_file.py:
-        210-223): the raw slice, NaN-padded to whole blocks, must hold exactly
-        one block per move."""
-        bcall = self.fast5.get_basecall()
-        if bcall is None:
-            raise SignalAnalysisError('not_basecalled')
-        if bcall.get('move') is None:
-            raise Exception("Neither `Events' or `Move' table found in the basecall.")
-        if n_raw is None:
-            n_raw = len(self.fast5.get_raw_int16())
-        first, stride = int(bcall['first_sample_template']), int(bcall['block_stride'])
-        n_blocks = len(bcall['move'])
-        length = max(min(first + stride * n_blocks, n_raw) - first, 0)
-        padded = length + (stride - length % stride if length % stride else 0)
-        if padded // stride != n_blocks:
-            raise Exception('Numbers of events and raw data strides does not match.')
-        return first, n_blocks, stride
+                pass
+        for stride in np.unique(frame[frame[:, 1] > 0, 2]).tolist():
+            sel = (frame[:, 2] == stride) & (frame[:, 1] > 0)
+            iv, cnt, start = self.ctx.unsplit_scan(frame[:, 0], np.where(sel, frame[:, 1], 0),
+                                                   int(stride))
+            picked = np.nonzero(sel)[0]
+            t.unsplit_count[rows[picked]] = cnt[picked]
+            for k in picked[cnt[picked] > 0].tolist():
+                t.unsplit[rows[k]] = iv[start[k]:start[k + 1]].tolist()

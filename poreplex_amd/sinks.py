@@ -68,10 +68,10 @@ class SequencingSummaryWriter:
                              'label']
 
     def __init__(self, config, output_dir, label_mapping, barcode_mapping):
-        self.file = open(os.path.join(output_dir, 'sequencing_summary.txt'), 'w')
         self.lock = Lock()
         self.label_mapping = label_mapping
         self.barcode_mapping = barcode_mapping if config['barcoding'] else None
+        self.file = open(os.path.join(output_dir, 'sequencing_summary.txt'), 'w')
         self.polya_enabled = bool(config['measure_polya'])
         self.fast5_layout = bool(config['fast5_output'])
         self.output_fields = list(self.SUMMARY_OUTPUT_FIELDS)
@@ -116,28 +116,28 @@ class FinalSummaryTracker:
     REPORTING_ORDER = ['pass', 'artifact', 'fail']
     FRIENDLY_LABELS = {'pass': 'Successfully processed', 'fail': 'Processing failed',
                        'artifact': 'Possible artifact'}
-    FRIENDLY_STATUS = {
-        'fail': {
-            'scaler_signal_too_short': 'Signal is too short',
-            'sequence_too_short': 'Sequence is too short',
-            'irregular_fast5': 'Invalid FAST5 format',
-            'basecall_table_incomplete': 'Basecall table does not match',
-            'adapter_not_detected': "3' Adapter could not be located",
-            'not_basecalled': 'No albacore basecall data found',
-            'scaling_qc_fail': 'Signal scaling QC failed',
-            'disappeared': 'File is moved to other location',
-            'unknown_error': 'File could not be opened due to unknown error',
-        },
-        'artifact': {'unsplit_read': 'Two or more molecules found within a read'},
-    }
+    # label / status / the wording of the end-of-run table (io.py:245-260; output text)
+    FRIENDLY_STATUS = {}
+    for _row in ("fail|scaler_signal_too_short|Signal is too short",
+                 "fail|sequence_too_short|Sequence is too short",
+                 "fail|irregular_fast5|Invalid FAST5 format",
+                 "fail|basecall_table_incomplete|Basecall table does not match",
+                 "fail|adapter_not_detected|3' Adapter could not be located",
+                 "fail|not_basecalled|No albacore basecall data found",
+                 "fail|scaling_qc_fail|Signal scaling QC failed",
+                 "fail|disappeared|File is moved to other location",
+                 "fail|unknown_error|File could not be opened due to unknown error",
+                 "artifact|unsplit_read|Two or more molecules found within a read"):
+        _label, _status, _text = _row.split('|')
+        FRIENDLY_STATUS.setdefault(_label, {})[_status] = _text
+    del _row, _label, _status, _text
     LABEL_FORMAT = '{:49s} '
     LABEL_BULLET = ' - '
     MINIMUM_COLUMN_WIDTH = 3
 
     def __init__(self, label_names, barcode_names):
-        self.label_names = label_names
-        self.barcode_names = barcode_names
-        self.counts = defaultdict(int)
+        self.label_names, self.barcode_names = label_names, barcode_names
+        self.counts = defaultdict(int)          # (label, barcode, status) -> reads
         self.label_reporting_order = self.REPORTING_ORDER
         self.barcode_reporting_order = sorted(n for n in barcode_names if n is not None) + [None]
 
@@ -200,10 +200,8 @@ class FASTQWriter:
     adapter_length trailing bases (io.py:63-74)."""
 
     def __init__(self, output_dir, output_layout):
-        self.output_dir = output_dir
-        self.output_layout = output_layout
-        self.lock = Lock()
-        self.streams = {}
+        self.output_dir, self.output_layout = output_dir, output_layout
+        self.lock, self.streams = Lock(), {}
         for key, name in output_layout.items():
             path = self.get_output_path(name)
             _ensure_parent(path)

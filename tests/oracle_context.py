@@ -1,0 +1,94 @@
+"""TEST DOUBLE of poreplex_amd.native.NativeContext, answering from oracle/libpxo.so.
+
+Test infrastructure only: it lets the CPU suite drive the HOST logic that sits on top of the
+GPU context (facade ordering / status rules, the session driver, bench.py's multi-rank
+plumbing over gloo) in a container without a GPU.  Nothing under poreplex_amd/ imports it;
+tests inject it (monkeypatch, or bench.py's --context-factory test seam, whose JSON line is
+then marked TEST-STANDIN and carries no value).
+"""
+import numpy as np
+
+from poreplex_amd import native as N
+
+
+class OracleBackedContext:
+    """Same methods the host code uses, answers computed by the oracle."""
+
+    def __init__(self, config, device_id=0):
+        from oracle.pxo import Oracle
+        self.oracle = Oracle(config)
+        self.ncfg = self.oracle.ncfg
+        self.cfg = self.oracle.cfg
+        self.state_names = self.oracle.state_names
+        self.n_resident = 0
+        self.staged = None
+
+    def device_info(self):
+        return {'name': 'oracle test double (CPU)', 'arch': 'none', 'compute_units': 0,
+                'wavefront_size': 0, 'total_mem': 0, 'lds_per_cu': 0, 'clock_khz': 0}
+
+    def upload(self, arena, offsets, calib, scale_shift=None):
+        self.batch = (np.asarray(arena), np.asarray(offsets), np.asarray(calib), scale_shift)
+        self.n_resident = len(offsets) - 1
+
+    def upload_tiled(self, n_reads, arena, offsets, calib, scale_shift=None, phase=0):
+        k = len(offsets) - 1
+        which = (phase + np.arange(n_reads)) % k
+        parts = [arena[offsets[b]:offsets[b + 1]] for b in which]
+        a, o = N.pack_reads(parts)
+        self.upload(a, o, np.asarray(calib)[which],
+                    None if scale_shift is None else np.asarray(scale_shift)[which])
+
+    def stage(self, arena, offsets, calib, scale_shift=None):
+        self.staged = (np.array(arena), np.array(offsets), np.array(calib), scale_shift)
+
+    def swap(self):
+        self.upload(*self.staged)
+        self.staged = None
+
+    def pin(self, array):
+        return array
+
+    def unpin(self, array):
+        pass
+
+    def run(self, mask=N.STAGE_ALL_DEMUX):
+        self.res, self.spk = self.oracle.process_batch(*self.batch, stage_mask=mask,
+                                                       want_spikes=True)
+
+    def sync(self):
+        pass
+
+    def download(self):
+        return self.res
+
+    def download_spikes(self):
+        return self.spk
+
+    def stage_times(self):
+        return {k: 0.0 for k in N.TIMER_NAMES}, {k: 0 for k in N.TIMER_NAMES}
+
+    def unsplit_scan(self, first_sample, n_blocks, block_stride=15):
+        arena, offsets, calib, _ = self.batch
+        n = len(offsets) - 1
+        found = []
+        cnt = np.zeros(n, dtype=np.int32)
+        a = int(self.cfg.segmentation_model.adapter_state)
+        for i in range(n):
+            r = self.res[i]
+            if n_blocks[i] <= 0 or r['status'] != 0 or r['seg_first'][a] < 0:
+                continue
+            _, scaled = self.oracle.guppy_event_means(
+                arena[offsets[i]:offsets[i + 1]], calib[i], first_sample[i], n_blocks[i],
+                r['scale'], r['shift'], block_stride)
+            got, c = self.oracle.unsplit_scan(scaled, first_sample[i],
+                                              (int(r['seg_last'][a]) + 1) * int(self.cfg.stride),
+                                              float(calib[i]['sampling_rate']), block_stride)
+            found.append(got)
+            cnt[i] = c
+        start = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        iv = np.concatenate(found) if found else np.zeros((0, 2), dtype=np.int64)
+        return iv.reshape(-1, 2), cnt, start
+
+    def close(self):
+        pass

@@ -93,3 +93,32 @@ def test_two_rank_gloo_gather_and_reduce(tmp_path):
         env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert (tmp_path / 'rank0.ok').exists() and (tmp_path / 'rank1.ok').exists()
+
+
+def test_bench_self_spawns_two_ranks_over_gloo():
+    """`python bench.py --gpus 2` with no launcher in the environment: the script re-launches
+    itself under torch.distributed.run, both ranks take part (counted by the collective),
+    the label records of the whole run arrive on rank 0 with a GLOBAL, duplicate-free
+    read_index, and stdout carries exactly one JSON line.  The GPU context is replaced by the
+    oracle test double through bench.py's test seam (the line is marked TEST-STANDIN)."""
+    import json
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['PYTHONPATH'] = os.path.join(ROOT, 'tests') + os.pathsep + env.get('PYTHONPATH', '')
+    for scaling, extra, total in (('weak', ['--reads', '12'], 24),
+                                  ('strong', ['--total-reads', '25', '--base-reads', '7'], 25)):
+        out = subprocess.run(
+            [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
+             '--warmup', '1', '--samples', '12000', '--cpu-sample', '0', '--cpu-all-cores-sample', '0',
+             '--scaling', scaling, '--context-factory', 'oracle_context:OracleBackedContext'] + extra,
+            env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stdout + out.stderr
+        lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, out.stdout
+        line = json.loads(lines[0])
+        assert line['n_gpus'] == 2 and line['scaling'] == scaling and line['value'] is None
+        assert line['data'].startswith('TEST-STANDIN')
+        assert line['extra']['ranks_counted_by_collective'] == 2
+        assert line['extra']['labels_gathered'] == total
+        assert line['extra']['labels_read_index_unique'] is True
+        assert sum(line['config']['reads_per_gpu']) == total

@@ -58,52 +58,7 @@ def compare_results(got, want, check_polya):
             assert g[k] == w[k], (g.get('read_id'), k, g[k], w[k])
 
 
-class OracleBackedContext:
-    """Test double of NativeContext for the CPU leg: same methods the facade
-    uses, answers computed by oracle/libpxo.so."""
-
-    def __init__(self, config, device_id=0):
-        from oracle.pxo import Oracle
-        self.oracle = Oracle(config)
-        self.ncfg = self.oracle.ncfg
-        self.cfg = self.oracle.cfg
-        self.state_names = self.oracle.state_names
-
-    def upload(self, arena, offsets, calib, scale_shift=None):
-        self.batch = (arena, offsets, calib, scale_shift)
-
-    def run(self, mask):
-        self.res, self.spk = self.oracle.process_batch(*self.batch, stage_mask=mask,
-                                                       want_spikes=True)
-
-    def download(self):
-        return self.res
-
-    def download_spikes(self):
-        return self.spk
-
-    def unsplit_scan(self, first_sample, n_blocks, block_stride=15):
-        arena, offsets, calib, _ = self.batch
-        n = len(offsets) - 1
-        iv = np.zeros((n, N.PXG_MAX_UNSPLIT, 2), dtype=np.int64)
-        cnt = np.zeros(n, dtype=np.int32)
-        a = int(self.cfg.segmentation_model.adapter_state)
-        for i in range(n):
-            r = self.res[i]
-            if n_blocks[i] <= 0 or r['status'] != 0 or r['seg_first'][a] < 0:
-                continue
-            _, scaled = self.oracle.guppy_event_means(
-                arena[offsets[i]:offsets[i + 1]], calib[i], first_sample[i], n_blocks[i],
-                r['scale'], r['shift'], block_stride)
-            got, c = self.oracle.unsplit_scan(scaled, first_sample[i],
-                                              (int(r['seg_last'][a]) + 1) * int(self.cfg.stride),
-                                              float(calib[i]['sampling_rate']), block_stride)
-            iv[i, :len(got)] = got
-            cnt[i] = c
-        return iv, cnt
-
-    def close(self):
-        pass
+from oracle_context import OracleBackedContext  # noqa: E402  (tests/oracle_context.py)
 
 
 @pytest.fixture()

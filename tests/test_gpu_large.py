@@ -34,5 +34,48 @@ def test_100k_read_batch_grid_limits_and_tiling(ctx, oracle):
         assert np.array_equal(first[f][:256], want[f], equal_nan=True), f
     # the chimera scan at the same size
     nb = lens // 15
-    iv, cnt = ctx.unsplit_scan(np.zeros(len(lens), np.int64), nb)
-    assert np.array_equal(cnt[:n0], cnt[-n0:]) and np.array_equal(iv[:n0], iv[-n0:])
+    iv, cnt, start = ctx.unsplit_scan(np.zeros(len(lens), np.int64), nb)
+    assert np.array_equal(cnt[:n0], cnt[-n0:]) and (cnt >= 0).all()
+    assert np.array_equal(iv[:start[n0]], iv[start[-1 - n0]:])
+
+
+def test_configs3_full_shape_100k_reads_60k_samples(ctx, oracle):
+    """BASELINE configs[3] at its stated shape: 100 000 reads x ~60 000 samples (12 GB of
+    int16) resident on one GPU, all stages + the chimera scan.  The batch is 2 048 distinct
+    reads tiled ON THE DEVICE (pxg_batch_upload_tiled), so (i) every copy of a read must give
+    byte-identical records and candidates, (ii) the first 256 reads are checked against the
+    oracle field by field."""
+    K, n = 2048, 100000
+    base = synth_batch(K, seed=925, samples_per_read=60000)
+    mask = N.STAGE_ALL_DEMUX | N.STAGE_POLYA
+    ctx.upload_tiled(n, base['arena'], base['offsets'], base['calib'])
+    ctx.run(mask)
+    res = ctx.download()
+    spk = ctx.download_spikes()
+    assert len(res) == n
+    for k in range(1, n // K):
+        assert res[k * K:(k + 1) * K].tobytes() == res[:K].tobytes(), k
+        assert spk[k * K:(k + 1) * K].tobytes() == spk[:K].tobytes(), k
+    tail = n - (n // K) * K
+    assert res[-tail:].tobytes() == res[:tail].tobytes()
+    assert (res['status'] == 0).mean() > 0.9 and res['polya_called'].mean() > 0.5
+    want, wsp = oracle.process_batch(base['arena'][:base['offsets'][256]], base['offsets'][:257],
+                                     base['calib'][:256], None, mask, want_spikes=True)
+    for f in res.dtype.names:
+        assert np.array_equal(res[f][:256], want[f], equal_nan=True), f
+    assert np.array_equal(spk[:256], wsp, equal_nan=True)
+    lens = np.diff(base['offsets'])[np.arange(n) % K]
+    nb = lens // 15
+    iv, cnt, start = ctx.unsplit_scan(np.zeros(n, np.int64), nb)
+    assert (cnt >= 0).all()
+    assert np.array_equal(cnt[:K], cnt[K:2 * K]) and np.array_equal(cnt[:tail], cnt[-tail:])
+    assert np.array_equal(iv[:start[K]], iv[start[K]:start[2 * K]])
+    a = 3
+    for r in range(64):
+        if res[r]['status'] != 0 or res[r]['seg_first'][a] < 0:
+            assert cnt[r] == 0
+            continue
+        raw = base['arena'][base['offsets'][r]:base['offsets'][r + 1]]
+        _, sc = oracle.guppy_event_means(raw, base['calib'][r], 0, int(nb[r]), res[r]['scale'], res[r]['shift'])
+        wiv, wc = oracle.unsplit_scan(sc, 0, (int(res[r]['seg_last'][a]) + 1) * 15, 3012.0)
+        assert cnt[r] == wc and iv[start[r]:start[r + 1]].tolist() == wiv.tolist(), r

@@ -348,12 +348,12 @@ def test_unsplit_scan_vs_reference_candidates(ctx):
     b, st, res, bc = _chimera()
     ctx.upload(b['arena'], b['offsets'], b['calib'])
     ctx.run(N.STAGE_SCALER | N.STAGE_SEGMENT)
-    iv, cnt = ctx.unsplit_scan([c['first_sample_template'] for c in bc],
-                               [len(c['move']) for c in bc])
+    iv, cnt, start = ctx.unsplit_scan([c['first_sample_template'] for c in bc],
+                                      [len(c['move']) for c in bc])
     for i, want in enumerate(res['candidates']):
         assert cnt[i] == len(want), (i, str(b['tag'][i]))
-        assert iv[i, :cnt[i]].tolist() == want, (i, str(b['tag'][i]))
-    assert (cnt > 0).sum() >= 6
+        assert iv[start[i]:start[i + 1]].tolist() == want, (i, str(b['tag'][i]))
+    assert (cnt > 0).sum() >= 6 and len(iv) == cnt.sum()
 
 
 def test_unsplit_scan_synthetic_vs_oracle(ctx, oracle, config):
@@ -375,7 +375,7 @@ def test_unsplit_scan_synthetic_vs_oracle(ctx, oracle, config):
     ctx.upload(arena, off, calib)
     ctx.run(N.STAGE_SCALER | N.STAGE_SEGMENT)
     recs = ctx.download()
-    iv, cnt = ctx.unsplit_scan(first, nb)
+    iv, cnt, start = ctx.unsplit_scan(first, nb)
     a = 3
     n_cand = 0
     for i, r in enumerate(reads):
@@ -387,9 +387,18 @@ def test_unsplit_scan_synthetic_vs_oracle(ctx, oracle, config):
         want, c = oracle.unsplit_scan(scaled, first[i], (int(recs[i]['seg_last'][a]) + 1) * 15,
                                       3012.0)
         assert cnt[i] == c, i
-        assert iv[i, :min(c, N.PXG_MAX_UNSPLIT)].tolist() == want.tolist(), i
+        assert iv[start[i]:start[i + 1]].tolist() == want.tolist(), i
         n_cand += c
     assert n_cand >= 8
+    # a read with an impossible event frame gets ITS OWN error code; the others are unchanged
+    bad_first = first.copy()
+    bad_first[7] = -5
+    iv2, cnt2, start2 = ctx.unsplit_scan(bad_first, nb)
+    assert cnt2[7] == N.UNSPLIT_E_GEOMETRY
+    keep = np.arange(len(reads)) != 7
+    assert np.array_equal(cnt2[keep], cnt[keep])
+    for i in np.nonzero(keep)[0]:
+        assert iv2[start2[i]:start2[i + 1]].tolist() == iv[start[i]:start[i + 1]].tolist(), i
 
 
 def test_label_all_gather_over_rccl_single_rank():
@@ -505,7 +514,7 @@ def test_structured_reads_around_every_length_threshold(ctx, oracle):
     assert len(set(got['status'].tolist())) >= 2 and (got['bc_pushed'] == 0).any() and (got['bc_pushed'] == 1).any()
     first = np.zeros(len(reads), np.int64)
     nb = np.diff(off) // 15
-    iv, cnt = ctx.unsplit_scan(first, nb)
+    iv, cnt, start = ctx.unsplit_scan(first, nb)
     a = 3
     for r in range(len(reads)):
         if got[r]['status'] != 0 or got[r]['seg_first'][a] < 0:
@@ -513,4 +522,48 @@ def test_structured_reads_around_every_length_threshold(ctx, oracle):
             continue
         _, sc = oracle.guppy_event_means(reads[r], calib[r], 0, int(nb[r]), got[r]['scale'], got[r]['shift'])
         wiv, wc = oracle.unsplit_scan(sc, 0, (int(got[r]['seg_last'][a]) + 1) * 15, 3012.0)
-        assert cnt[r] == wc and iv[r, :min(wc, N.PXG_MAX_UNSPLIT)].tolist() == wiv.tolist(), r
+        assert cnt[r] == wc and iv[start[r]:start[r + 1]].tolist() == wiv.tolist(), r
+
+
+def test_tiled_upload_equals_host_tiling(ctx):
+    """pxg_batch_upload_tiled: read j of the resident batch is base read (phase + j) % K,
+    replicated on the device -- records identical to uploading the same tiling from the host."""
+    from poreplex_amd.synth import synth_batch
+    base = synth_batch(37, seed=77, samples_per_read=14000, jitter=0.4, short_fraction=0.1)
+    K, n, phase = 37, 150, 11
+    order = (phase + np.arange(n)) % K
+    parts = [base['arena'][base['offsets'][b]:base['offsets'][b + 1]] for b in order]
+    arena, off = N.pack_reads(parts)
+    mask = N.STAGE_ALL_DEMUX | N.STAGE_POLYA
+    ctx.upload(arena, off, base['calib'][order])
+    ctx.run(mask)
+    want = ctx.download()
+    ctx.upload_tiled(n, base['arena'], base['offsets'], base['calib'], phase=phase)
+    ctx.run(mask)
+    got = ctx.download()
+    assert got.tobytes() == want.tobytes()
+    # injected scaling travels with the tiling too
+    ctx.upload_tiled(n, base['arena'], base['offsets'], base['calib'], base['scale_shift'], phase=phase)
+    ctx.run(N.STAGE_SEGMENT)
+    inj = ctx.download()
+    assert np.array_equal(inj['scale'], base['scale_shift'][order, 0])
+    assert np.array_equal(inj['n_pooled'], np.diff(off) // 15)
+
+
+def test_polya_hook_equals_stage(ctx):
+    """pxg_polya on caller-supplied scaling + segmentation == the poly(A) stage of a run."""
+    from poreplex_amd.synth import synth_batch
+    sb = synth_batch(64, seed=5150, samples_per_read=26000, jitter=0.3)
+    ctx.upload(sb['arena'], sb['offsets'], sb['calib'])
+    ctx.run(N.STAGE_ALL_DEMUX | N.STAGE_POLYA)
+    want = ctx.download()
+    wsp = ctx.download_spikes()
+    ok = want['status'] == 0
+    assert ok.sum() > 40 and want['polya_called'][ok].sum() > 10
+    idx = np.nonzero(ok)[0]
+    arena, off = N.pack_reads([sb['arena'][sb['offsets'][i]:sb['offsets'][i + 1]] for i in idx])
+    ss = np.stack([want['scale'][idx], want['shift'][idx]], axis=1)
+    got, gsp = ctx.polya(arena, off, sb['calib'][idx], ss, want['seg_first'][idx], want['seg_last'][idx])
+    for f in ('polya_called', 'polya_n_spikes', 'polya_dwell_samples', 'polya_begin', 'polya_end'):
+        assert np.array_equal(got[f], want[f][idx]), f
+    assert np.array_equal(gsp, wsp[idx], equal_nan=True)
