@@ -117,7 +117,22 @@ def host_description():
     except ImportError:
         physical = os.cpu_count()
     usable = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else os.cpu_count()
-    return model, int(physical), int(usable)
+    # a container may see every core of the host and still be capped by a cgroup CPU quota
+    quota = None
+    for path, parse_quota in (('/sys/fs/cgroup/cpu.max', lambda t: t.split()),
+                              ('/sys/fs/cgroup/cpu/cpu.cfs_quota_us', lambda t: [t.strip(), None])):
+        try:
+            with open(path) as fh:
+                q, period = parse_quota(fh.read())
+            if period is None:
+                with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as fh:
+                    period = fh.read().strip()
+            if q not in ('max', '-1'):
+                quota = float(q) / float(period)
+            break
+        except (OSError, ValueError):
+            continue
+    return model, int(physical), int(usable), quota
 
 
 # ---- CPU baseline over all cores: one process per physical core, read shards ----------
@@ -145,7 +160,7 @@ def cpu_all_cores(config, base, mask, use_inject, n_sample):
     (pipeline.py:96), every worker process running whole reads.  Must run BEFORE the HIP
     runtime is initialised in this process (fork)."""
     import multiprocessing as mp
-    model, physical, usable = host_description()
+    model, physical, usable, quota = host_description()
     workers = max(1, min(physical, usable))
     n_base = len(base['offsets']) - 1
     n = max(n_sample, 96 * workers)                        # ~0.7 s of work per core at least
@@ -160,7 +175,7 @@ def cpu_all_cores(config, base, mask, use_inject, n_sample):
         wall = time.perf_counter() - t0
     return {'value': n / wall, 'unit': 'reads/s', 'cores': workers, 'reads': int(n),
             'wall_s': round(wall, 3), 'per_core': n / wall / workers,
-            'slowest_worker_s': round(max(busy), 3)}
+            'slowest_worker_s': round(max(busy), 3), 'cgroup_cpu_quota': quota}
 
 
 def make_context(args, config, local_rank):
@@ -422,11 +437,15 @@ def main():
                                            float(s_cal[i]['sampling_rate']))
                 cand_mismatch += int(wc != cnt[i] or wiv.tolist() != iv[start[i]:start[i + 1]].tolist())
         cpu_s = time.perf_counter() - c0
-        model, physical, usable = host_description()
+        model, physical, usable, quota = host_description()
         cpu = {'value': ns / cpu_s, 'unit': 'reads/s', 'cores': 1, 'kind': 'port',
                'sample': 'first {} reads of the same batch, same stages, oracle/libpxo.so '
                          '(C restatement, gcc -O2 AVX2), single thread, {:.1f} s'.format(ns, cpu_s),
                'host_cpu': model, 'physical_cores': physical, 'usable_cores': usable,
+               'cgroup_cpu_quota': quota,
+               # what perfect scaling of the one-core rate over every physical core would give
+               'ideal_all_cores': ns / cpu_s * physical,
+               'speedup_vs_ideal_all_cores': value / world / (ns / cpu_s * physical),
                'speedup_vs_one_core': value / world / (ns / cpu_s)}
         if cpu_all is not None:
             cpu['all_cores'] = dict(cpu_all, sample='{} reads over {} worker processes (one per physical '

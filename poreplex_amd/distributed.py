@@ -36,10 +36,27 @@ def shard_by_samples(lengths, world, cap=100000, fixed_cost=30000):
     return [(bounds[r], max(bounds[r], bounds[r + 1])) for r in range(world)]
 
 
+def final_label_records(results, first_index=0):
+    """Label records from the FINAL result dicts of the facade (label, barcode, status as
+    NanoporeRead.report() emits them): what the sinks count.  A read that never got a label
+    counts as 'fail' with an undetermined barcode, like FinalSummaryTracker.feed_results
+    (io.py:274-277)."""
+    rec = np.zeros(len(results), dtype=LABEL_DTYPE)
+    rec['read_index'] = first_index + np.arange(len(results), dtype=np.int32)
+    rec['status'] = [N.STATUS_CODE[r['status']] for r in results]
+    rec['label'] = [LABEL_NAMES.index(r.get('label', 'fail')) for r in results]
+    rec['barcode'] = [-1 if r.get('barcode') is None else r['barcode'] for r in results]
+    rec['phred'] = [r.get('barcode_score', 0) for r in results]
+    rec['adapter_end'] = -1
+    return rec
+
+
 def label_records(results, first_index=0, adapter_state=3):
-    """Compact per-read label records from pxg_read_result rows.  `label`
-    here is the numeric-stage verdict (0 pass / 1 fail); the facade refines it
-    with base-space checks (signal_analyzer.py:275-286)."""
+    """Compact per-read label records from pxg_read_result rows: the NUMERIC-stage verdict
+    only (0 pass / 1 fail), for callers that never build result dicts (bench.py).  A run
+    that goes through the facade exchanges final_label_records instead: the base-space
+    rules (not_basecalled, sequence_too_short, unsplit_read, ...) change status and label
+    after the GPU pass (signal_analyzer.py:262-286)."""
     rec = np.zeros(len(results), dtype=LABEL_DTYPE)
     rec['read_index'] = first_index + np.arange(len(results), dtype=np.int32)
     rec['status'] = results['status']
@@ -65,7 +82,7 @@ def _device_for(dist):
         if dist.get_backend() == 'nccl' else torch.device('cpu')
 
 
-def gather_labels_start(results, dist=None, first_index=0, sizes=None, force=False):
+def gather_labels_start(results, dist=None, first_index=0, sizes=None, force=False, records=None):
     """Launch the all-gather of the label records of every rank (ragged shards
     are padded to the largest shard) and return ``finish() -> records``.  The
     collective runs asynchronously on RCCL's stream, so a caller can start the
@@ -74,7 +91,7 @@ def gather_labels_start(results, dist=None, first_index=0, sizes=None, force=Fal
     collective on a single GPU).  `sizes`: the per-rank shard sizes when the
     caller already knows them (static sharding) -- saves the size exchange and
     its host synchronisation."""
-    rec = label_records(results, first_index)
+    rec = label_records(results, first_index) if records is None else records
     if dist is None or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return lambda: rec
     import torch
@@ -103,9 +120,9 @@ def gather_labels_start(results, dist=None, first_index=0, sizes=None, force=Fal
     return finish
 
 
-def gather_labels(results, dist=None, first_index=0, sizes=None, force=False):
+def gather_labels(results, dist=None, first_index=0, sizes=None, force=False, records=None):
     """Blocking form of gather_labels_start."""
-    return gather_labels_start(results, dist, first_index, sizes, force)()
+    return gather_labels_start(results, dist, first_index, sizes, force, records)()
 
 
 def reduce_counts(records, dist=None):

@@ -1,0 +1,268 @@
+"""GPU-shaped session driver: inputs -> shards -> fat double-buffered batches -> sinks.
+
+The reference's ``ProcessingSession`` (pipeline.py:193-301) feeds 128-read batches to a
+``ProcessPoolExecutor`` of CPU workers through an asyncio loop and writes whatever comes
+back in completion order.  On GPUs the same job has a different shape:
+
+  * one process per GPU (``torch.distributed``; RCCL on GPUs, gloo in CPU tests); rank r owns
+    one contiguous, cost-balanced block of the run's reads (``distributed.shard_by_samples``)
+    -- no data-path collective;
+  * inside a rank the block is cut into a few FAT batches (thousands of reads: the LSTM
+    kernels want >= 512 read tiles in flight).  A loader thread opens the reads of batch k+1
+    and packs their int16 samples into a page-locked staging arena while batch k is on the
+    GPU; ``pxg_batch_stage`` copies the arena on the copy stream under the running kernels
+    and ``pxg_batch_swap`` makes it resident (include/pxg.h);
+  * the facade turns the records of each batch into the reference's result dicts
+    (signal_analyzer.py), which go to the sinks (sinks.py) in INPUT order, so the output
+    files do not depend on the number of GPUs or on the batch size;
+  * at the end the [label x barcode x status] count table is all-reduced and rank 0 prints
+    the run summary (io.py:236-332) and stitches the per-rank part files together.
+
+What it keeps from the reference: the (-1, message, traceback) fatality convention of
+``process_batch``, the per-read error logging, and the early stop when nothing is
+basecalled (pipeline.py:250-260).
+"""
+import logging
+import os
+import queue
+import shutil
+import threading
+import time
+
+import numpy as np
+
+from . import distributed as D
+from . import native
+from . import sinks
+from .signal_analyzer import SignalAnalyzer
+from .signal_loader import ReadTable
+
+__all__ = ['GpuSession', 'enumerate_reads']
+
+
+def enumerate_reads(config, bundle=None):
+    """Every (filename, read_id) of the run, in a deterministic order: the bundle's own
+    order, or a sorted recursive walk of inputdir (pipeline.py:303-337 without the inotify
+    branch) with fast5_file.get_read_ids per file."""
+    from .fast5_file import get_read_ids
+    if bundle is not None:
+        d = bundle.d
+        return [(str(f), str(r)) for f, r in zip(d['filename'], d['read_id'])], d.get('duration')
+    found = []
+    top = config['inputdir']
+    for dirpath, dirnames, filenames in os.walk(top):
+        dirnames[:] = sorted(n for n in dirnames if not n.startswith('.'))
+        for name in sorted(filenames):
+            if name.startswith('.') or not name.lower().endswith('.fast5'):
+                continue
+            found.extend(get_read_ids(os.path.relpath(os.path.join(dirpath, name), top), top))
+    return found, None
+
+
+class _Staging:
+    """One int16 staging arena.  The loader thread only allocates (reserve); page-locking
+    happens on the session's thread right before the copy (settle), because every call into
+    the GPU context belongs to one host thread (include/pxg.h)."""
+
+    def __init__(self, ctx):
+        self.ctx, self.buf, self.pinned, self.retired = ctx, np.empty(0, dtype=np.int16), False, []
+
+    def reserve(self, n_samples):
+        if n_samples > len(self.buf):
+            if self.pinned:
+                self.retired.append(self.buf)          # still registered: unpin in settle()
+            self.buf, self.pinned = np.empty(int(n_samples * 1.1) + 4096, dtype=np.int16), False
+        return self.buf
+
+    def settle(self):
+        for old in self.retired:
+            self.ctx.unpin(old)
+        self.retired = []
+        if not self.pinned and len(self.buf):
+            self.ctx.pin(self.buf)
+            self.pinned = True
+
+    def release(self):
+        self.settle()
+        if self.pinned:
+            self.ctx.unpin(self.buf)
+        self.buf, self.pinned = np.empty(0, dtype=np.int16), False
+
+
+class GpuSession:
+
+    def __init__(self, config, dist=None, batch_reads=8192, logger=None):
+        self.config, self.dist = config, dist
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.batch_reads = int(batch_reads)
+        self.logger = logger or logging.getLogger('poreplex')
+        self.analyzer = SignalAnalyzer(config, batchid=self.rank)
+        self.ctx, self.loader = self.analyzer.ctx, self.analyzer.loader
+        self.timing = {'load_s': 0.0, 'gpu_wait_s': 0.0, 'facade_s': 0.0, 'sink_s': 0.0}
+
+    # ---- loader thread: batch k+1 is opened and packed while batch k computes ---------
+    def _produce(self, batches, slots, out):
+        try:
+            for k, reads in enumerate(batches):
+                staging = slots.get()                 # a staging arena nobody is copying from
+                t0 = time.perf_counter()
+                batch = self.analyzer.prepare(reads, ReadTable())
+                need = sum(len(batch.table.raw[i]) for i in batch.entered)
+                rows, arena, offsets, calib = self.loader.pack(batch.table, staging.reserve(need))
+                self.timing['load_s'] += time.perf_counter() - t0
+                out.put((batch, staging, rows, arena, offsets, calib))
+            out.put(None)
+        except BaseException as exc:                   # surfaces in run() on the main thread
+            out.put(exc)
+
+    def run(self, reads=None, lengths=None):
+        """Process this rank's share of `reads` (default: everything enumerate_reads finds).
+        Returns the run summary dict on every rank; files are complete when it returns."""
+        cfg = self.config
+        if reads is None:
+            reads, lengths = enumerate_reads(cfg, self.loader.bundle)
+        if lengths is not None and len(lengths) == len(reads):
+            lo, hi = D.shard_by_samples(lengths, self.world)[self.rank]
+        else:
+            lo, hi = D.shard_range(len(reads), self.rank, self.world)
+        mine = reads[lo:hi]
+        batches = [mine[a:a + self.batch_reads] for a in range(0, len(mine), self.batch_reads)]
+
+        outdir = cfg['outputdir']
+        os.makedirs(outdir, exist_ok=True)
+        part = '.part{:04d}'.format(self.rank)
+        # output names as the CLI derives them (commandline.py:137-159) unless the caller did
+        labels, barcodes, layout = sinks.setup_output_name_mapping(cfg)
+        labels = cfg.get('label_names', labels)
+        barcodes = cfg.get('barcode_names', barcodes)
+        layout = cfg.get('output_layout', layout)
+        sink_cfg = dict(cfg, fast5_output=cfg.get('fast5_output', False))
+        summary = sinks.SequencingSummaryWriter(sink_cfg, outdir, labels, barcodes, suffix=part,
+                                                header=self.rank == 0)
+        fastq = sinks.FASTQWriter(outdir, layout, suffix=part) if cfg.get('fastq_output') else None
+
+        slots, ready = queue.Queue(), queue.Queue(maxsize=2)
+        stagings = [_Staging(self.ctx), _Staging(self.ctx)]
+        for s in stagings:
+            slots.put(s)
+        thread = threading.Thread(target=self._produce, args=(batches, slots, ready), daemon=True)
+        thread.start()
+
+        records, status_seen = [], {}
+        t_start = time.perf_counter()
+
+        def take():
+            item = ready.get()
+            if isinstance(item, BaseException):
+                raise item
+            return item
+
+        current = take()
+        if current is not None:
+            batch, staging, rows, arena, offsets, calib = current
+            if len(rows):
+                staging.settle()
+                self.ctx.stage(arena, offsets, calib)
+                self.ctx.swap()
+            slots.put(staging)
+        done = 0
+        while current is not None:
+            batch, staging, rows, arena, offsets, calib = current
+            t0 = time.perf_counter()
+            if len(rows):
+                self.ctx.run(self.loader.stage_mask)      # asynchronous: kernels are enqueued
+            nxt = take()                                  # next batch is (being) packed meanwhile
+            staged = False
+            if nxt is not None and len(nxt[2]):
+                nxt[1].settle()
+                self.ctx.stage(nxt[3], nxt[4], nxt[5])    # H2D on the copy stream, under the kernels
+                staged = True
+            self._attach(batch.table, rows, offsets)      # D2H of the records: waits for the run
+            self.timing['gpu_wait_s'] += time.perf_counter() - t0
+            if staged:
+                self.ctx.swap()
+            if nxt is not None:
+                slots.put(nxt[1])
+
+            t0 = time.perf_counter()
+            results = self.analyzer.finish(batch, input_order=True)
+            self.timing['facade_s'] += time.perf_counter() - t0
+            t0 = time.perf_counter()
+            for r in results:
+                status_seen[r['status']] = status_seen.get(r['status'], 0) + 1
+                if 'error_message' in r:
+                    self.logger.error(r['error_message'])
+            summary.write_results(results)
+            if fastq is not None:
+                fastq.write_sequences(results)
+            records.append(D.final_label_records(results, first_index=lo + done))
+            done += len(results)
+            self.timing['sink_s'] += time.perf_counter() - t0
+            self._check_early_stop(status_seen)
+            current = nxt
+        thread.join()
+        for s in stagings:
+            s.release()
+        summary.close()
+        if fastq is not None:
+            fastq.close()
+        wall = time.perf_counter() - t_start
+
+        local = np.concatenate(records) if records else np.zeros(0, dtype=D.LABEL_DTYPE)
+        counts = D.reduce_counts(local, self.dist)                    # all-reduce (RCCL / gloo)
+        gathered = D.gather_labels(None, self.dist, records=local)    # all-gather of the labels
+        if self.dist is not None:
+            self.dist.barrier()                                       # every part file is closed
+        out = {'reads': int(counts.sum()), 'reads_this_rank': int(len(local)), 'wall_s': wall,
+               'rank': self.rank, 'world': self.world, 'batches': len(batches),
+               'timing': dict(self.timing), 'labels': gathered, 'counts': counts}
+        if self.rank == 0:
+            self._stitch(outdir, 'sequencing_summary.txt')
+            if fastq is not None:
+                for name in set(layout.values()):
+                    self._stitch(outdir, os.path.join('fastq', name + '.fastq.gz'))
+            tracker = sinks.FinalSummaryTracker(labels, barcodes)
+            tracker.feed_counts(counts, label_order=D.LABEL_NAMES)
+            out['tracker'] = tracker
+        if self.dist is not None:
+            self.dist.barrier()
+        return out
+
+    def _attach(self, table, rows, offsets):
+        """Download + attach the records of the resident batch (loader.run_resident without
+        the launch: the kernels were enqueued before the next batch was staged)."""
+        if not len(rows):
+            return
+        rec = self.ctx.download()
+        table.records = rec
+        table.spikes = self.ctx.download_spikes() if self.loader.stage_mask & native.STAGE_POLYA else None
+        table.gpu_row[rows] = np.arange(len(rows))
+        qc_failed = rec['status'] == native.STATUS_CODE['scaling_qc_fail']
+        table.halt(rows[qc_failed], 'scaling_qc_fail')
+        good = rows[~qc_failed]
+        table.scale_shift[good, 0], table.scale_shift[good, 1] = rec['scale'][~qc_failed], rec['shift'][~qc_failed]
+        table.has_scaling[good] = True
+        if self.loader.scan_unsplit:
+            self.loader.scan_unsplit_candidates(table, rows, offsets)
+
+    def _check_early_stop(self, seen):
+        """pipeline.py:250-260: stop when reads keep arriving without basecalls."""
+        trigger = self.config.get('nobasecall_stop_trigger')
+        if trigger and seen.get('okay', 0) == 0 and seen.get('not_basecalled', 0) >= trigger:
+            raise RuntimeError(
+                'Early stopping: {} out of {} reads are not basecalled. Please check if the files '
+                "are correctly analyzed, or add `--basecall' to the command line.".format(
+                    seen['not_basecalled'], sum(seen.values())))
+
+    def _stitch(self, outdir, relname):
+        """Rank 0: concatenate the per-rank part files in rank order (contiguous shards ->
+        global input order).  gzip members concatenate into a valid gzip file."""
+        final = os.path.join(outdir, relname)
+        with open(final, 'wb') as dst:
+            for r in range(self.world):
+                part = '{}.part{:04d}'.format(final, r)
+                if os.path.exists(part):
+                    with open(part, 'rb') as src:
+                        shutil.copyfileobj(src, dst)
+                    os.unlink(part)

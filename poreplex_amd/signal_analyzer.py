@@ -60,6 +60,21 @@ def process_batch(batchid, reads, config):
             analyzer.close()
 
 
+class _Batch:
+    """One worker batch between prepare() and finish(): its table, the outcomes that were
+    settled before the GPU pass (finished dicts, or rows of reads that opened and stopped),
+    the rows that entered the pass, and everybody's position in the input list."""
+
+    def __init__(self, table):
+        self.table = table
+        self.early, self.early_at = [], []
+        self.entered, self.entered_at = [], []
+
+    def settle(self, position, outcome):
+        self.early.append(outcome)
+        self.early_at.append(position)
+
+
 class SignalAnalyzer(AbstractContextManager):
     """Context manager; `with SignalAnalyzer(config, batchid) as analyzer` yields itself."""
 
@@ -80,31 +95,48 @@ class SignalAnalyzer(AbstractContextManager):
     def process(self, reads):
         """Result list of signal_analyzer.py:82-134: whatever was decided before the GPU
         pass first (encounter order), then every read that entered it (input order)."""
+        batch = self.prepare(reads)
+        self.loader.fit_scalers(batch.table)     # scaling parameters AND every other numeric stage
+        return self.finish(batch)
+
+    def prepare(self, reads, table=None):
+        """Host-only first phase: open every read into a batch table.  The session driver
+        runs this for batch k+1 while batch k is on the GPU."""
         loader = self.loader
-        table = loader.table
-        early, entered = [], []          # early: finished dicts, or table rows to report
-        for f5file, read_id in reads:
+        table = loader.table if table is None else table
+        batch = _Batch(table)
+        for position, (f5file, read_id) in enumerate(reads):
             if not loader.exists(f5file):
-                early.append({'filename': f5file, 'status': 'disappeared'})
+                batch.settle(position, {'filename': f5file, 'status': 'disappeared'})
                 continue
             try:
-                row = loader.prepare_loading(f5file, read_id).row
+                row = loader.prepare_loading(f5file, read_id, table).row
             except Exception as exc:
-                early.append(self.pack_unhandled_exception(f5file, read_id, exc, sys.exc_info()))
+                batch.settle(position, self.pack_unhandled_exception(f5file, read_id, exc, sys.exc_info()))
                 continue
-            (early if table.stopped[row] else entered).append(row)
+            if table.stopped[row]:
+                batch.settle(position, row)
+            else:
+                batch.entered.append(row)
+                batch.entered_at.append(position)
+        return batch
 
-        loader.fit_scalers()             # scaling parameters AND every other numeric stage
-        self.judge(entered)
-        table.release(entered)
+    def finish(self, batch, input_order=False):
+        """Last phase: status / label rules over the GPU records, then the result dicts --
+        early outcomes first as the reference returns them, or in input order."""
+        self.judge(batch.entered, batch.table)
+        batch.table.release(batch.entered)
+        early_rows = [r for r in batch.early if not isinstance(r, dict)]
+        reports = iter(batch.table.report(early_rows + batch.entered))
+        results = [r if isinstance(r, dict) else next(reports) for r in batch.early] + list(reports)
+        if input_order:
+            at = np.argsort(np.array(batch.early_at + batch.entered_at, dtype=np.int64), kind='stable')
+            results = [results[i] for i in at]
+        return results
 
-        early_rows = [r for r in early if not isinstance(r, dict)]
-        reports = iter(table.report(early_rows + entered))
-        return [r if isinstance(r, dict) else next(reports) for r in early] + list(reports)
-
-    def judge(self, rows):
+    def judge(self, rows, table=None):
         """Status / label rules of SignalAnalysis.process (:230-286) for many rows."""
-        t, cfg = self.loader.table, self.config
+        t, cfg = (self.loader.table if table is None else table), self.config
         rows = t.live_rows(rows)
         if not len(rows):
             return
@@ -121,16 +153,15 @@ class SignalAnalyzer(AbstractContextManager):
         broken = np.zeros(len(rows), dtype=bool)
         if cfg['measure_polya']:
             for k in np.nonzero(rec['polya_called'])[0].tolist():
-                broken[k] = not self._guarded(rows[k], self.polyaanalyzer, NanoporeRead(t, rows[k]))
+                broken[k] = not self._guarded(t, rows[k], self.polyaanalyzer, NanoporeRead(t, rows[k]))
         for k in np.nonzero(~broken)[0].tolist():
-            broken[k] = not self._guarded(rows[k], self.base_space_checks, rows[k], rec[k])
+            broken[k] = not self._guarded(t, rows[k], self.base_space_checks, t, rows[k], rec[k])
         done = rows[~broken & ~t.stopped[rows]]
         t.label[done] = 0                # 'pass'
 
-    def _guarded(self, row, fn, *args):
+    def _guarded(self, t, row, fn, *args):
         """Run one read's step; a domain failure halts the read with its label, anything
         else becomes that read's 'unknown_error' (:118-122).  False if the read is out."""
-        t = self.loader.table
         try:
             fn(*args)
             return not t.stopped[row]
@@ -141,9 +172,9 @@ class SignalAnalyzer(AbstractContextManager):
             NanoporeRead(t, row).set_error(err['status'], err['error_message'])
         return False
 
-    def base_space_checks(self, row, record):
+    def base_space_checks(self, t, row, record):
         """The part of :262-279 that needs the read's basecall group."""
-        cfg, t = self.config, self.loader.table
+        cfg = self.config
         analysis = SignalAnalysis(NanoporeRead(t, row), self)
         segments = analysis.segments_of(record)
         stride = cfg['signal_processing']['rough_signal_stride']
@@ -190,7 +221,7 @@ class SignalAnalysis:
 
     def process(self):
         """Single-read entry: the batch rules applied to this row alone."""
-        self.analyzer.judge([self.npread.row])
+        self.analyzer.judge([self.npread.row], self.npread.table)
 
     def segments_of(self, record):
         """pxg_read_result -> {state name: (first, last)} (:354-362)."""

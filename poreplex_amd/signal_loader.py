@@ -290,6 +290,9 @@ class NanoporeRead:
 
 
 class SignalLoader:
+    """Opens reads into a ReadTable and runs the GPU pass over it.  `self.table` is the
+    batch the reference-style calls (prepare_loading / fit_scalers) work on; the session
+    driver keeps several tables in flight and passes them explicitly."""
 
     def __init__(self, config, fast5prefix, ctx, read_bundle=None):
         self.config, self.fast5prefix, self.ctx = config, fast5prefix, ctx
@@ -313,13 +316,13 @@ class SignalLoader:
             return True
         return os.path.exists(os.path.join(self.fast5prefix, filename))
 
-    def prepare_loading(self, filename, read_id):
+    def prepare_loading(self, filename, read_id, table=None):
         """Open one read into the batch table.  An unreadable file raises: the reference
         marks it 'irregular_fast5' (signal_loader.py:200-207) and then trips over the
         missing reader, so its caller reports 'unknown_error' -- same outcome here."""
         source = open_read(os.path.join(self.fast5prefix, filename), filename, read_id,
                            self.bundle)
-        t = self.table
+        t = self.table if table is None else table
         row = t.append(filename, read_id, source)
         raw = np.ascontiguousarray(source.get_raw_int16(), dtype=np.int16)
         t.n_raw[row] = len(raw)
@@ -331,15 +334,31 @@ class SignalLoader:
             t.raw[row] = raw
         return NanoporeRead(t, row)
 
-    def fit_scalers(self):
-        """The GPU pass over every read of the table that is still live."""
-        t = self.table
+    # ---- the GPU pass, in the three steps the session driver overlaps ------------------
+    def pack(self, table=None, arena=None):
+        """(rows, arena, offsets, calib) of the reads of `table` that go to the GPU.  With
+        `arena` (a page-locked staging buffer) the samples are packed in place."""
+        t = self.table if table is None else table
         rows = t.live_rows()
         rows = rows[[t.raw[i] is not None for i in rows]] if len(rows) else rows
+        lens = np.array([len(t.raw[i]) for i in rows], dtype=np.int64)
+        offsets = np.zeros(len(rows) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        if arena is None:
+            arena = np.empty(int(offsets[-1]), dtype=np.int16)
+        elif len(arena) < offsets[-1]:
+            raise ValueError('staging arena too small: {} < {}'.format(len(arena), offsets[-1]))
+        for k, i in enumerate(rows):
+            arena[offsets[k]:offsets[k + 1]] = t.raw[i]
+            t.raw[i] = None
+        return rows, arena[:offsets[-1]], offsets, np.ascontiguousarray(t.calib[rows])
+
+    def run_resident(self, table, rows, offsets):
+        """Launch every numeric stage on the batch that is resident on the GPU (uploaded or
+        swapped in by the caller) and attach the records to `table`."""
+        t = table
         if not len(rows):
             return
-        arena, offsets = native.pack_reads([t.raw[i] for i in rows])
-        self.ctx.upload(arena, offsets, t.calib[rows])
         self.ctx.run(self.stage_mask)
         t.records = rec = self.ctx.download()
         t.spikes = self.ctx.download_spikes() if self.stage_mask & native.STAGE_POLYA else None
@@ -350,16 +369,23 @@ class SignalLoader:
         t.scale_shift[good, 0], t.scale_shift[good, 1] = rec['scale'][~qc_failed], rec['shift'][~qc_failed]
         t.has_scaling[good] = True
         if self.scan_unsplit:
-            self.scan_unsplit_candidates(rows, offsets)
-        for i in rows:
-            t.raw[i] = None
+            self.scan_unsplit_candidates(t, rows, offsets)
 
-    def scan_unsplit_candidates(self, rows, offsets):
+    def fit_scalers(self, table=None):
+        """The GPU pass over every read of the table that is still live: scaler network +
+        QC and, behind the same upload, every other numeric stage."""
+        t = self.table if table is None else table
+        rows, arena, offsets, calib = self.pack(t)
+        if len(rows):
+            self.ctx.upload(arena, offsets, calib)
+            self.run_resident(t, rows, offsets)
+
+    def scan_unsplit_candidates(self, table, rows, offsets):
         """a18 + a19 numeric part for the resident batch: Guppy block means of every
         basecalled read and the windowed Viterbi scan (signal_analyzer.py:366-418), on the
         GPU.  Reads whose event frame cannot be built are left out here; load_events raises
         for them later, per read."""
-        t = self.table
+        t = table
         n = len(rows)
         frame = np.zeros((n, 3), dtype=np.int64)        # first sample, blocks, block stride
         for k, i in enumerate(rows):

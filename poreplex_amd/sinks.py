@@ -67,11 +67,13 @@ class SequencingSummaryWriter:
                              'num_events', 'sequence_length', 'mean_qscore', 'sample_id', 'status',
                              'label']
 
-    def __init__(self, config, output_dir, label_mapping, barcode_mapping):
+    def __init__(self, config, output_dir, label_mapping, barcode_mapping, suffix='', header=True):
+        """`suffix` / `header`: a multi-GPU session writes one part file per rank (only rank
+        0's carries the header) and stitches them together in rank order."""
         self.lock = Lock()
         self.label_mapping = label_mapping
         self.barcode_mapping = barcode_mapping if config['barcoding'] else None
-        self.file = open(os.path.join(output_dir, 'sequencing_summary.txt'), 'w')
+        self.file = open(os.path.join(output_dir, 'sequencing_summary.txt' + suffix), 'w')
         self.polya_enabled = bool(config['measure_polya'])
         self.fast5_layout = bool(config['fast5_output'])
         self.output_fields = list(self.SUMMARY_OUTPUT_FIELDS)
@@ -79,7 +81,8 @@ class SequencingSummaryWriter:
             self.output_fields += ['barcode', 'barcode_score']
         if self.polya_enabled:
             self.output_fields.append('polya_dwell')
-        self.file.write('\t'.join(self.output_fields) + '\n')
+        if header:
+            self.file.write('\t'.join(self.output_fields) + '\n')
 
     def close(self):
         self.file.close()
@@ -199,8 +202,8 @@ class FASTQWriter:
     """<output_dir>/fastq/<layout name>.fastq.gz per (label, barcode); sequences lose their
     adapter_length trailing bases (io.py:63-74)."""
 
-    def __init__(self, output_dir, output_layout):
-        self.output_dir, self.output_layout = output_dir, output_layout
+    def __init__(self, output_dir, output_layout, suffix=''):
+        self.output_dir, self.output_layout, self.suffix = output_dir, output_layout, suffix
         self.lock, self.streams = Lock(), {}
         for key, name in output_layout.items():
             path = self.get_output_path(name)
@@ -208,7 +211,7 @@ class FASTQWriter:
             self.streams[key] = gzip.open(path, 'wb')
 
     def get_output_path(self, name):
-        return os.path.join(self.output_dir, 'fastq', name + '.fastq.gz')
+        return os.path.join(self.output_dir, 'fastq', name + '.fastq.gz' + self.suffix)
 
     def close(self):
         for stream in self.streams.values():

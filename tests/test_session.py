@@ -1,0 +1,178 @@
+"""Session driver (poreplex_amd/session.py): files -> shards -> double-buffered fat batches
+-> facade -> sinks -> count all-reduce.  CPU legs drive the host logic with the oracle test
+double of the GPU context (tests/oracle_context.py); the -m gpu leg streams the same bundles
+through the real stage/swap path."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from poreplex_amd import native as N
+from poreplex_amd import sinks as SINK
+from poreplex_amd.config import default_config
+from poreplex_amd.worker_persistence import WorkerPersistenceStorage
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def session_config(outdir, bundle='chimera.pxr.npz', **kw):
+    with open(os.path.join(GOLDEN, bundle.replace('.pxr.npz', '.results.json'))) as fh:
+        flags = dict(json.load(fh)['config_flags'])
+    flags.update(kw)
+    return default_config(inputdir='/nonexistent-inputdir', outputdir=str(outdir),
+                          read_bundle=os.path.join(GOLDEN, bundle), fastq_output=True, **flags)
+
+
+def golden_reads(bundle):
+    """The read list the reference was given for this bundle (includes a file that vanished
+    and a corrupt one for batch0: they never enter the GPU pass but must be reported)."""
+    with open(os.path.join(GOLDEN, bundle.replace('.pxr.npz', '.results.json'))) as fh:
+        return [tuple(r) for r in json.load(fh)['reads']]
+
+
+def run_session(outdir, bundle, batch_reads, **kw):
+    from poreplex_amd.session import GpuSession
+    WorkerPersistenceStorage.reset()
+    try:
+        return GpuSession(session_config(outdir, bundle, **kw),
+                          batch_reads=batch_reads).run(golden_reads(bundle))
+    finally:
+        WorkerPersistenceStorage.reset()
+
+
+@pytest.fixture()
+def oracle_backed(monkeypatch):
+    from oracle_context import OracleBackedContext
+    WorkerPersistenceStorage.reset()
+    monkeypatch.setattr(N, 'NativeContext', OracleBackedContext)
+    yield
+    WorkerPersistenceStorage.reset()
+
+
+def reference_outputs(bundle):
+    """What one process_batch call over the whole bundle + the sinks write (input order)."""
+    from poreplex_amd.signal_analyzer import SignalAnalyzer
+    cfg = session_config('/tmp', bundle)
+    reads = golden_reads(bundle)
+    with SignalAnalyzer(cfg, 0) as an:
+        batch = an.prepare(reads)
+        an.loader.fit_scalers(batch.table)
+        return an.finish(batch, input_order=True)
+
+
+@pytest.mark.parametrize('bundle', ['batch0.pxr.npz', 'chimera.pxr.npz'])
+def test_session_outputs_do_not_depend_on_batch_size(oracle_backed, tmp_path, bundle):
+    whole = run_session(tmp_path / 'a', bundle, batch_reads=10000)
+    small = run_session(tmp_path / 'b', bundle, batch_reads=5)
+    assert whole['batches'] == 1 and small['batches'] >= 3
+    a = (tmp_path / 'a' / 'sequencing_summary.txt').read_bytes()
+    assert a == (tmp_path / 'b' / 'sequencing_summary.txt').read_bytes() and a.count(b'\n') > 5
+    assert np.array_equal(whole['counts'], small['counts'])
+    assert whole['labels'].tobytes() == small['labels'].tobytes()
+    # the same rows the facade + sinks give for one process_batch over everything
+    results = reference_outputs(bundle)
+    cfg = session_config(tmp_path / 'c', bundle)
+    os.makedirs(tmp_path / 'c')
+    labels, barcodes, layout = SINK.setup_output_name_mapping(cfg)
+    w = SINK.SequencingSummaryWriter(dict(cfg, fast5_output=False), str(tmp_path / 'c'), labels, barcodes)
+    w.write_results(results)
+    w.close()
+    assert a == (tmp_path / 'c' / 'sequencing_summary.txt').read_bytes()
+    # rank 0's tracker was fed by the reduced count table == feeding the final result dicts
+    direct = SINK.FinalSummaryTracker(labels, barcodes)
+    direct.feed_results(results)
+    assert dict(whole['tracker'].counts) == dict(direct.counts)
+    # FASTQ routing: every sequence once, in the file of its (label, barcode)
+    import gzip
+    n_seq = 0
+    for (label, bc), name in layout.items():
+        path = tmp_path / 'b' / 'fastq' / (name + '.fastq.gz')
+        ids = [ln[1:] for ln in gzip.open(path, 'rt').read().splitlines()[0::4]]
+        want = [r['read_id'] for r in results if r.get('sequence') is not None
+                and r.get('label') == label and r.get('barcode') == bc]
+        assert ids == want, (label, bc)
+        n_seq += len(ids)
+    assert n_seq == sum(1 for r in results if r.get('sequence') is not None)
+    assert not [f for f in os.listdir(tmp_path / 'b') if '.part' in f]
+
+
+def test_count_table_uses_final_labels(oracle_backed, tmp_path):
+    """The all-reduced table must carry the statuses the facade decides AFTER the GPU pass
+    (unsplit_read / artifact here), not the numeric-stage verdict."""
+    out = run_session(tmp_path, 'chimera.pxr.npz', batch_reads=4)
+    from poreplex_amd import distributed as D
+    counts = out['counts']
+    assert counts[D.LABEL_NAMES.index('artifact'), :, N.STATUS_CODE['unsplit_read']].sum() == 6
+    assert counts.sum() == len(out['labels']) == 11
+
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests'))
+    import torch.distributed as dist
+    from poreplex_amd import native as N
+    from oracle_context import OracleBackedContext
+    N.NativeContext = OracleBackedContext          # test double: no GPU in this container
+    import test_session as TS
+    from poreplex_amd.session import GpuSession
+    dist.init_process_group('gloo')
+    out = GpuSession(TS.session_config({out!r}, {bundle!r}), dist=dist,
+                     batch_reads=3).run(TS.golden_reads({bundle!r}))
+    assert out['reads'] == {n_reads} and out['world'] == 2 and 0 < out['reads_this_rank'] < {n_reads}
+    assert out['labels']['read_index'].tolist() == list(range({n_reads}))
+    dist.destroy_process_group()
+    open(os.path.join({out!r}, 'rank%d.ok' % out['rank']), 'w').write('ok')
+""")
+
+
+@pytest.mark.parametrize('bundle,n_reads', [('chimera.pxr.npz', 11)])
+def test_two_rank_session_writes_the_single_rank_files(oracle_backed, tmp_path, bundle, n_reads):
+    single = run_session(tmp_path / 'one', bundle, batch_reads=4)
+    assert single['reads'] == n_reads
+    two = tmp_path / 'two'
+    two.mkdir()
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER.format(root=ROOT, out=str(two), bundle=bundle, n_reads=n_reads))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
+        capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert (two / 'rank0.ok').exists() and (two / 'rank1.ok').exists()
+    assert (two / 'sequencing_summary.txt').read_bytes() == \
+        (tmp_path / 'one' / 'sequencing_summary.txt').read_bytes()
+    import gzip
+    for dirpath, _, files in os.walk(tmp_path / 'one' / 'fastq'):
+        for f in files:
+            rel = os.path.relpath(os.path.join(dirpath, f), tmp_path / 'one')
+            assert gzip.open(two / rel).read() == gzip.open(tmp_path / 'one' / rel).read(), rel
+    assert not [f for f in os.listdir(two) if '.part' in f]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('bundle', ['batch0.pxr.npz', 'chimera.pxr.npz'])
+def test_session_on_gpu_streams_batches_through_stage_swap(tmp_path, bundle):
+    """Real context: >= 3 double-buffered batches through pinned staging arenas; the files
+    equal those of the single upload/run path (process over the whole bundle)."""
+    small = run_session(tmp_path / 'b', bundle, batch_reads=4)
+    assert small['batches'] >= 3
+    WorkerPersistenceStorage.reset()
+    results = reference_outputs(bundle)
+    WorkerPersistenceStorage.reset()
+    cfg = session_config(tmp_path / 'c', bundle)
+    os.makedirs(tmp_path / 'c')
+    labels, barcodes, _ = SINK.setup_output_name_mapping(cfg)
+    w = SINK.SequencingSummaryWriter(dict(cfg, fast5_output=False), str(tmp_path / 'c'), labels, barcodes)
+    w.write_results(results)
+    w.close()
+    assert (tmp_path / 'b' / 'sequencing_summary.txt').read_bytes() == \
+        (tmp_path / 'c' / 'sequencing_summary.txt').read_bytes()
