@@ -80,6 +80,12 @@ def parse(argv=None):
     ap.add_argument('--no-overlap-test', action='store_true',
                     help='skip the extra PCIe-overlapped steps (profiling runs: keeps the kernel '
                          'statistics to the timed steps)')
+    ap.add_argument('--end-to-end', action='store_true',
+                    help='files -> labels: every rank writes its shard of the run as a .pxr.npz read '
+                         'bundle, then the session driver (poreplex_amd/session.py: loader thread, pinned '
+                         'double-buffered batches, facade, sequencing_summary.txt, RCCL all-gather / '
+                         'all-reduce) processes it; value = reads / wall of the whole session')
+    ap.add_argument('--batch-reads', type=int, default=10000, help='--end-to-end: reads per GPU batch')
     ap.add_argument('--context-factory', default=None,
                     help='TEST SEAM (module:attr): CPU rendezvous tests of the multi-rank driver '
                          'inject a stand-in context; the line then says data=TEST-STANDIN, value=null')
@@ -178,6 +184,94 @@ def cpu_all_cores(config, base, mask, use_inject, n_sample):
             'slowest_worker_s': round(max(busy), 3), 'cgroup_cpu_quota': quota}
 
 
+def end_to_end(args, config, rank, local_rank, world, dist, standin, base, which, lo, total,
+               mask, json_fd):
+    """configs[4] as a user gets it: read bundles on disk -> session driver -> labels."""
+    import shutil
+    import tempfile
+    from poreplex_amd.fast5_file import write_bundle
+    from poreplex_amd.session import GpuSession
+    from poreplex_amd.synth import synth_basecalls
+    from poreplex_amd.worker_persistence import WorkerPersistenceStorage
+    if standin:
+        import importlib
+        mod, attr = args.context_factory.split(':')
+        N.NativeContext = getattr(importlib.import_module(mod), attr)
+    work = tempfile.mkdtemp(prefix='pxg_e2e_r{}_'.format(rank))
+    try:
+        o = base['offsets']
+        parts = [base['arena'][o[b]:o[b + 1]] for b in which]
+        arena, off = N.pack_reads(parts)
+        shard = {'offsets': off}
+        names = ['shard{:02d}/read{:07d}.fast5'.format(rank, lo + j) for j in range(len(which))]
+        ids = ['{:08x}-0000-4000-8000-{:012x}'.format(args.seed, lo + j) for j in range(len(which))]
+        t0 = time.perf_counter()
+        path = os.path.join(work, 'shard.pxr.npz')
+        write_bundle(path, arena, off, base['calib'][which], names, ids,
+                     basecalls=synth_basecalls(shard, seed=args.seed + rank))
+        t_write = time.perf_counter() - t0
+        cfg = default_config(inputdir=work, outputdir=os.path.join(work, 'out'), read_bundle=path,
+                             barcoding=True, measure_polya=bool(mask & N.STAGE_POLYA),
+                             filter_unsplit_reads=args.workload in ('chimera', 'full'),
+                             device_id=local_rank)
+        del arena, parts
+        t0 = time.perf_counter()
+        session = GpuSession(cfg, dist=dist, batch_reads=args.batch_reads)    # context + bundle load
+        t_open = time.perf_counter() - t0
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        out = session.run(list(zip(names, ids)), presharded_at=lo)
+        wall = time.perf_counter() - t0
+        n_ranks = 1
+        if dist is not None:
+            import torch
+            t = torch.tensor([wall, 1.0], dtype=torch.float64, device='cpu' if standin else 'cuda')
+            dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
+            dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
+            wall, n_ranks = float(t[0].item()), int(round(t[1].item()))
+        if rank == 0:
+            info = session.ctx.device_info()
+            counts = out['counts']
+            from poreplex_amd.distributed import LABEL_NAMES
+            with open(os.path.join(cfg['outputdir'], 'sequencing_summary.txt')) as fh:
+                n_rows = sum(1 for _ in fh) - 1
+            line = {
+                'metric': 'reads/s (end-to-end demux: read bundles on disk -> barcode labels + '
+                          'sequencing_summary.txt)',
+                'value': None if standin else total / wall, 'unit': 'reads/s', 'n_gpus': world,
+                'steps': out['batches'], 'warmup': 0, 'ms_per_step': wall / max(out['batches'], 1) * 1e3,
+                'higher_is_better': True, 'scaling': args.scaling,
+                'vs_baseline': None if standin else total / wall / PUBLISHED_READS_PER_S,
+                'vs_baseline_basis': 'BASELINE.md section 1: ~230 reads/s, Poreplex 0.1 whole pipeline '
+                                     '(pre-basecalled FAST5 -> FASTQ), 20 Xeon cores -- the closest '
+                                     'published counterpart of this end-to-end figure',
+                'dtype': 'f32 (LSTM MFMA) / f64 (Viterbi) / i16 in',
+                'data': 'TEST-STANDIN (no GPU work timed)' if standin else 'synthetic',
+                'config': {'workload': 'BASELINE configs[4] shape: {} reads over {} GPU(s) x ~{} int16 samples, '
+                                       'files -> session driver -> sinks, stages {}'.format(
+                                           total, world, args.samples, STAGES[args.workload][1]),
+                           'reads_per_gpu': [out['reads_this_rank']], 'batch_reads': args.batch_reads,
+                           'samples_per_read': args.samples, 'device': info['name'], 'arch': info['arch']},
+                'roofline': None, 'cpu_baseline': None, 'concordance': None,
+                'extra': {'session_timing_rank0': {k: round(v, 4) for k, v in out['timing'].items()},
+                          'bundle_write_s': round(t_write, 3), 'context_and_bundle_open_s': round(t_open, 3),
+                          'reads_labelled_pass': int(counts[LABEL_NAMES.index('pass')].sum()),
+                          'reads_with_barcode': int(counts[:, 1:].sum()), 'summary_rows': n_rows,
+                          'labels_gathered': int(len(out['labels'])),
+                          'labels_read_index_unique': bool(len(np.unique(out['labels']['read_index'])) == len(out['labels'])),
+                          'ranks_counted_by_collective': n_ranks,
+                          'host_us_per_read_rank0': round((out['timing']['facade_s'] + out['timing']['sink_s'])
+                                                          / max(out['reads_this_rank'], 1) * 1e6, 2)},
+            }
+            os.write(json_fd, (json.dumps(line) + '\n').encode())
+        WorkerPersistenceStorage.reset()
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def make_context(args, config, local_rank):
     if args.context_factory:
         import importlib
@@ -257,6 +351,9 @@ def main():
             dist.init_process_group('nccl', rank=rank, world_size=world,
                                     device_id=torch.device('cuda', local_rank))
 
+    if args.end_to_end:
+        return end_to_end(args, config, rank, local_rank, world, dist, standin, base, which,
+                          lo, total, mask, json_fd)
     ctx = make_context(args, config, local_rank)
     info = ctx.device_info()
 

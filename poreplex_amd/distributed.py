@@ -51,6 +51,27 @@ def final_label_records(results, first_index=0):
     return rec
 
 
+def final_label_records_from_table(table, rows, positions, loose, first_index=0):
+    """final_label_records without the dicts: `rows` of a settled signal_loader.ReadTable
+    at input `positions`, plus the `loose` (position, dict) outcomes of reads that never
+    opened.  Record k describes input read first_index + k."""
+    n = len(rows) + len(loose)
+    rec = np.zeros(n, dtype=LABEL_DTYPE)
+    rec['read_index'] = first_index + np.arange(n, dtype=np.int32)
+    rec['adapter_end'] = -1
+    idx, at = np.asarray(rows, dtype=np.int64), np.asarray(positions, dtype=np.int64)
+    if len(idx):
+        label = table.label[idx]
+        rec['status'][at] = table.status[idx]
+        rec['label'][at] = np.where(label < 0, LABEL_NAMES.index('fail'), label)
+        rec['barcode'][at] = np.where(table.has_barcode[idx], table.barcode[idx], -1)
+        rec['phred'][at] = np.where(table.has_barcode[idx], table.barcode_phred[idx], 0)
+    for p, r in loose:
+        rec['status'][p], rec['label'][p], rec['barcode'][p] = N.STATUS_CODE[r['status']], \
+            LABEL_NAMES.index('fail'), -1
+    return rec
+
+
 def label_records(results, first_index=0, adapter_state=3):
     """Compact per-read label records from pxg_read_result rows: the NUMERIC-stage verdict
     only (0 pass / 1 fail), for callers that never build result dicts (bench.py).  A run

@@ -19,28 +19,101 @@ try:  # optional: only needed for real FAST5 input
 except ImportError:  # pragma: no cover
     h5py = None
 
-__all__ = ['get_read_ids', 'open_read', 'ReadBundle', 'Fast5Reader']
+__all__ = ['get_read_ids', 'open_read', 'ReadBundle', 'Fast5Reader', 'write_bundle']
+
+
+TABLE_KINDS = ('', 'move', 'guppy_events', 'albacore', 'unsupported')   # '' = no event table
+
+# columnar basecall summary of a bundle (version 2); ragged columns have offsets[n+1]
+BASECALL_COLUMNS = ('bc_present', 'bc_sequence_length', 'bc_mean_qscore', 'bc_num_events',
+                    'bc_first_sample', 'bc_block_stride', 'bc_table', 'bc_n_moves', 'bc_move_sum',
+                    'seq_offsets', 'seq_arena', 'qual_arena', 'move_offsets', 'move_arena')
+
+
+def basecall_columns(basecalls):
+    """list of get_basecall()-style dicts (or None) -> the columnar form stored in a bundle.
+    A per-event p_model_state column (Guppy `Events' tables) is kept as JSON text: rare."""
+    n = len(basecalls)
+    c = {'bc_present': np.zeros(n, dtype=bool), 'bc_sequence_length': np.zeros(n, dtype=np.int64),
+         'bc_mean_qscore': np.zeros(n, dtype=np.float64), 'bc_num_events': np.zeros(n, dtype=np.int64),
+         'bc_first_sample': np.zeros(n, dtype=np.int64), 'bc_block_stride': np.full(n, 15, dtype=np.int32),
+         'bc_table': np.zeros(n, dtype=np.int8), 'bc_n_moves': np.full(n, -1, dtype=np.int64),
+         'bc_move_sum': np.zeros(n, dtype=np.int64)}
+    seqs, quals, moves, pms = [], [], [], []
+    for i, bc in enumerate(basecalls):
+        if not bc:
+            seqs.append(b''); quals.append(b''); moves.append(np.zeros(0, np.uint8)); pms.append('')
+            continue
+        c['bc_present'][i] = True
+        c['bc_sequence_length'][i] = bc['sequence_length']
+        c['bc_mean_qscore'][i] = bc['mean_qscore']
+        c['bc_num_events'][i] = bc['num_events']
+        c['bc_first_sample'][i] = bc['first_sample_template']
+        c['bc_block_stride'][i] = bc.get('block_stride', 15)
+        move = bc.get('move')
+        kind = bc.get('table', 'move' if move is not None else '') or ''
+        c['bc_table'][i] = TABLE_KINDS.index(kind)
+        mv = np.zeros(0, np.uint8) if move is None else np.asarray(move, dtype=np.uint8)
+        if move is not None:
+            c['bc_n_moves'][i], c['bc_move_sum'][i] = len(mv), int(mv.sum())
+        seqs.append(bc['sequence'].encode('ascii'))
+        quals.append(bc['qstring'].encode('ascii'))
+        moves.append(mv)
+        pms.append(json.dumps(bc['p_model_state']) if bc.get('p_model_state') is not None else '')
+    for name, parts in (('seq', seqs), ('move', moves)):
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(p) for p in parts], out=off[1:])
+        c[name + '_offsets'] = off
+    c['seq_arena'] = np.frombuffer(b''.join(seqs), dtype=np.uint8).copy()
+    c['qual_arena'] = np.frombuffer(b''.join(quals), dtype=np.uint8).copy()
+    c['move_arena'] = np.concatenate(moves) if moves else np.zeros(0, np.uint8)
+    if any(pms):
+        c['bc_p_model_state'] = np.array(pms)
+    return c
+
+
+def write_bundle(path, arena, offsets, calib, filename, read_id, basecalls=None, **columns):
+    """Write a version-2 .pxr.npz read bundle (this build's array container for many reads:
+    int16 samples + per-read metadata + columnar basecall summaries).  Missing metadata
+    columns get neutral defaults."""
+    n = len(offsets) - 1
+    d = {'arena': np.ascontiguousarray(arena, dtype=np.int16),
+         'offsets': np.ascontiguousarray(offsets, dtype=np.int64), 'calib': calib,
+         'filename': np.asarray(filename), 'read_id': np.asarray(read_id),
+         'duration': np.diff(offsets), 'start_time': np.zeros(n, dtype=np.int64),
+         'channel_number': np.array(['0'] * n), 'run_id': np.array(['run'] * n),
+         'sample_id': np.array(['sample'] * n), 'broken_files': np.array([], dtype='<U1'),
+         'bundle_version': np.int64(2)}
+    d.update(columns)
+    d.update(basecall_columns(basecalls if basecalls is not None else [None] * n))
+    np.savez(path, **d)
 
 
 class ReadBundle:
-    """Random access to the reads of one .pxr.npz file by (filename, read_id)."""
+    """Random access to the reads of one .pxr.npz file by (filename, read_id), and columnar
+    access for the batch paths (signal_loader.ReadTable.extend_from_bundle)."""
 
     def __init__(self, path):
         with np.load(path, allow_pickle=False) as npz:
             self.d = {k: npz[k] for k in npz.files}
-        self.index = {(str(f), str(r)): i
-                      for i, (f, r) in enumerate(zip(self.d['filename'], self.d['read_id']))}
+        d = self.d
+        if 'bc_present' not in d:          # version 1: one JSON string per read -> columns
+            js = d['basecall'] if 'basecall' in d else [''] * len(d['read_id'])
+            d.update(basecall_columns([json.loads(str(j)) if str(j) else None for j in js]))
+        self.filenames = [str(f) for f in d['filename']]
+        self.read_ids = [str(r) for r in d['read_id']]
+        self.index = {key: i for i, key in enumerate(zip(self.filenames, self.read_ids))}
         self.by_file = {}
-        for (f, r), i in self.index.items():
+        for i, f in enumerate(self.filenames):
             self.by_file.setdefault(f, []).append(i)
         # files that exist but cannot be opened (the corrupt-FAST5 case)
-        self.broken = set(str(f) for f in self.d.get('broken_files', []))
+        self.broken = set(str(f) for f in d.get('broken_files', []))
 
     def has_file(self, filename):
         return filename in self.by_file or filename in self.broken
 
-    def read_ids(self, filename):
-        return [(filename, str(self.d['read_id'][i])) for i in self.by_file.get(filename, [])]
+    def read_ids_of(self, filename):
+        return [(filename, self.read_ids[i]) for i in self.by_file.get(filename, [])]
 
     def reader(self, filename, read_id):
         key = (filename, read_id)
@@ -49,9 +122,39 @@ class ReadBundle:
         if key not in self.index:
             if filename in self.by_file:     # fast5_file.py:104-107
                 raise ValueError('Unexpected read {} found in {}'.format(
-                    self.d['read_id'][self.by_file[filename][0]], filename))
+                    self.read_ids[self.by_file[filename][0]], filename))
             raise FileNotFoundError(filename)
         return BundleReader(self, self.index[key])
+
+    def sequence_text(self):
+        """(sequences, quality strings) of all reads as two bytes objects (made once)."""
+        if getattr(self, '_text', None) is None:
+            self._text = (self.d['seq_arena'].tobytes(), self.d['qual_arena'].tobytes())
+        return self._text
+
+    def sequence_of(self, i):
+        o = self.d['seq_offsets']
+        return (self.d['seq_arena'][o[i]:o[i + 1]].tobytes().decode('ascii'),
+                self.d['qual_arena'][o[i]:o[i + 1]].tobytes().decode('ascii'))
+
+    def basecall_of(self, i):
+        """get_basecall()-style dict of read i from the columns; None if not basecalled."""
+        d = self.d
+        if not d['bc_present'][i]:
+            return None
+        seq, qual = self.sequence_of(i)
+        kind = TABLE_KINDS[int(d['bc_table'][i])] or None
+        mo = d['move_offsets']
+        move = d['move_arena'][mo[i]:mo[i + 1]].tolist() if d['bc_n_moves'][i] >= 0 else None
+        pms = None
+        if 'bc_p_model_state' in d and str(d['bc_p_model_state'][i]):
+            pms = json.loads(str(d['bc_p_model_state'][i]))
+        return {'sequence': seq, 'qstring': qual, 'block_stride': int(d['bc_block_stride'][i]),
+                'sequence_length': int(d['bc_sequence_length'][i]),
+                'mean_qscore': float(np.float32(d['bc_mean_qscore'][i])),
+                'num_events': int(d['bc_num_events'][i]),
+                'first_sample_template': int(d['bc_first_sample'][i]),
+                'table': kind, 'move': move, 'p_model_state': pms}
 
 
 class BundleReader:
@@ -59,8 +162,8 @@ class BundleReader:
 
     def __init__(self, bundle, i):
         d = bundle.d
-        self.path, self.i, self.d = str(d['filename'][i]), i, d
-        self.read_id = str(d['read_id'][i])
+        self.bundle, self.i, self.d = bundle, i, d
+        self.path, self.read_id = bundle.filenames[i], bundle.read_ids[i]
         self.duration = int(d['duration'][i])
         self.start_time = int(d['start_time'][i])
         self.channel_number = str(d['channel_number'][i])
@@ -81,18 +184,7 @@ class BundleReader:
 
     def get_basecall(self):
         """Summary of Analyses/Basecall_1D_* (fast5_file.py:133-164); None if absent."""
-        js = str(self.d['basecall'][self.i]) if 'basecall' in self.d else ''
-        if not js:
-            return None
-        bc = json.loads(js)
-        return {'sequence': bc['sequence'], 'qstring': bc['qstring'],
-                'block_stride': int(bc.get('block_stride', 15)),
-                'sequence_length': int(bc['sequence_length']),
-                'mean_qscore': float(np.float32(bc['mean_qscore'])),
-                'num_events': int(bc['num_events']),
-                'first_sample_template': int(bc['first_sample_template']),
-                'table': bc.get('table', 'move' if bc.get('move') is not None else None),
-                'move': bc.get('move'), 'p_model_state': bc.get('p_model_state')}
+        return self.bundle.basecall_of(self.i)
 
 
 class Fast5Reader:
@@ -182,7 +274,7 @@ class Fast5Reader:
 def get_read_ids(filename, basedir, bundle=None):
     """(filename, read_id) pairs of one input file (fast5_file.py:37-58)."""
     if bundle is not None and bundle.has_file(filename):
-        return bundle.read_ids(filename)
+        return bundle.read_ids_of(filename)
     path = os.path.join(basedir, filename) if basedir is not None else filename
     if h5py is None:
         raise RuntimeError('h5py is not installed')

@@ -35,7 +35,7 @@ from . import distributed as D
 from . import native
 from . import sinks
 from .signal_analyzer import SignalAnalyzer
-from .signal_loader import ReadTable
+from .signal_loader import ReadTable, summary_columns
 
 __all__ = ['GpuSession', 'enumerate_reads']
 
@@ -109,24 +109,30 @@ class GpuSession:
                 t0 = time.perf_counter()
                 batch = self.analyzer.prepare(reads, ReadTable())
                 need = sum(len(batch.table.raw[i]) for i in batch.entered)
-                rows, arena, offsets, calib = self.loader.pack(batch.table, staging.reserve(need))
+                rows, arena, offsets, calib = self.loader.pack(batch.table, staging, need)
                 self.timing['load_s'] += time.perf_counter() - t0
                 out.put((batch, staging, rows, arena, offsets, calib))
             out.put(None)
         except BaseException as exc:                   # surfaces in run() on the main thread
             out.put(exc)
 
-    def run(self, reads=None, lengths=None):
+    def run(self, reads=None, lengths=None, presharded_at=None):
         """Process this rank's share of `reads` (default: everything enumerate_reads finds).
-        Returns the run summary dict on every rank; files are complete when it returns."""
+        `presharded_at`: `reads` is already this rank's block of the run and starts at that
+        global read index (each rank opened its own input shard).  Returns the run summary
+        dict on every rank; files are complete when it returns."""
         cfg = self.config
         if reads is None:
             reads, lengths = enumerate_reads(cfg, self.loader.bundle)
-        if lengths is not None and len(lengths) == len(reads):
-            lo, hi = D.shard_by_samples(lengths, self.world)[self.rank]
+        if presharded_at is not None:
+            lo, hi = int(presharded_at), int(presharded_at) + len(reads)
+            mine = reads
         else:
-            lo, hi = D.shard_range(len(reads), self.rank, self.world)
-        mine = reads[lo:hi]
+            if lengths is not None and len(lengths) == len(reads):
+                lo, hi = D.shard_by_samples(lengths, self.world)[self.rank]
+            else:
+                lo, hi = D.shard_range(len(reads), self.rank, self.world)
+            mine = reads[lo:hi]
         batches = [mine[a:a + self.batch_reads] for a in range(0, len(mine), self.batch_reads)]
 
         outdir = cfg['outputdir']
@@ -142,6 +148,9 @@ class GpuSession:
                                                 header=self.rank == 0)
         fastq = sinks.FASTQWriter(outdir, layout, suffix=part) if cfg.get('fastq_output') else None
 
+        bundle_arena = self.loader.bundle.d['arena'] if self.loader.bundle is not None else None
+        if bundle_arena is not None and len(bundle_arena):
+            self.ctx.pin(bundle_arena)      # batches of consecutive bundle reads are staged in place
         slots, ready = queue.Queue(), queue.Queue(maxsize=2)
         stagings = [_Staging(self.ctx), _Staging(self.ctx)]
         for s in stagings:
@@ -186,24 +195,38 @@ class GpuSession:
                 slots.put(nxt[1])
 
             t0 = time.perf_counter()
-            results = self.analyzer.finish(batch, input_order=True)
+            table = batch.table
+            self.analyzer.settle(batch)
+            rows, positions, loose = batch.in_input_order()
+            results = self.analyzer.finish(batch, input_order=True) if fastq is not None else None
             self.timing['facade_s'] += time.perf_counter() - t0
             t0 = time.perf_counter()
-            for r in results:
+            idx = np.asarray(rows, dtype=np.int64)
+            for code, n_seen in zip(*np.unique(table.status[idx], return_counts=True)):
+                name = native.STATUS_NAMES[code]
+                status_seen[name] = status_seen.get(name, 0) + int(n_seen)
+            for _, r in loose:
                 status_seen[r['status']] = status_seen.get(r['status'], 0) + 1
-                if 'error_message' in r:
-                    self.logger.error(r['error_message'])
-            summary.write_results(results)
+            for message in [table.error_message[i] for i in rows if table.error_message[i]] + \
+                    [r['error_message'] for _, r in loose if 'error_message' in r]:
+                self.logger.error(message)
+            # the sinks, from the columns: only labelled reads have a summary row (io.py:166-168)
+            labelled = [i for i in rows if table.label[i] >= 0]
+            summary.write_columns(summary_columns(table, labelled, bool(cfg['barcoding']),
+                                                  bool(cfg['measure_polya'])))
             if fastq is not None:
                 fastq.write_sequences(results)
-            records.append(D.final_label_records(results, first_index=lo + done))
-            done += len(results)
+            records.append(D.final_label_records_from_table(table, rows, positions, loose,
+                                                            first_index=lo + done))
+            done += len(rows) + len(loose)
             self.timing['sink_s'] += time.perf_counter() - t0
             self._check_early_stop(status_seen)
             current = nxt
         thread.join()
         for s in stagings:
             s.release()
+        if bundle_arena is not None and len(bundle_arena):
+            self.ctx.unpin(bundle_arena)
         summary.close()
         if fastq is not None:
             fastq.close()

@@ -69,6 +69,17 @@ class _Batch:
         self.table = table
         self.early, self.early_at = [], []
         self.entered, self.entered_at = [], []
+        self.judged = False
+
+    def in_input_order(self):
+        """(rows, positions, loose): table rows of the batch sorted by input position with
+        those positions, and the outcomes that never became rows (file vanished / could not
+        be opened) as (position, dict) pairs."""
+        placed = [(p, r) for p, r in zip(self.early_at, self.early) if not isinstance(r, dict)]
+        placed += list(zip(self.entered_at, self.entered))
+        placed.sort()
+        loose = [(p, r) for p, r in zip(self.early_at, self.early) if isinstance(r, dict)]
+        return [r for _, r in placed], [p for p, _ in placed], loose
 
     def settle(self, position, outcome):
         self.early.append(outcome)
@@ -105,7 +116,17 @@ class SignalAnalyzer(AbstractContextManager):
         loader = self.loader
         table = loader.table if table is None else table
         batch = _Batch(table)
+        reads = [tuple(r) for r in reads]
+        bulk = loader.prepare_many(reads, table)       # bundle reads: one column append
         for position, (f5file, read_id) in enumerate(reads):
+            if bulk[position] is not None:
+                row = bulk[position]
+                if table.stopped[row]:
+                    batch.settle(position, row)
+                else:
+                    batch.entered.append(row)
+                    batch.entered_at.append(position)
+                continue
             if not loader.exists(f5file):
                 batch.settle(position, {'filename': f5file, 'status': 'disappeared'})
                 continue
@@ -121,11 +142,19 @@ class SignalAnalyzer(AbstractContextManager):
                 batch.entered_at.append(position)
         return batch
 
+    def settle(self, batch):
+        """Last phase without the dicts: status / label rules over the GPU records; the
+        outcome of every read is then in the batch table's columns (batch.in_input_order())."""
+        if not batch.judged:
+            self.judge(batch.entered, batch.table)
+            batch.table.release(batch.entered)
+            batch.judged = True
+        return batch
+
     def finish(self, batch, input_order=False):
         """Last phase: status / label rules over the GPU records, then the result dicts --
         early outcomes first as the reference returns them, or in input order."""
-        self.judge(batch.entered, batch.table)
-        batch.table.release(batch.entered)
+        self.settle(batch)
         early_rows = [r for r in batch.early if not isinstance(r, dict)]
         reports = iter(batch.table.report(early_rows + batch.entered))
         results = [r if isinstance(r, dict) else next(reports) for r in batch.early] + list(reports)
@@ -154,10 +183,53 @@ class SignalAnalyzer(AbstractContextManager):
         if cfg['measure_polya']:
             for k in np.nonzero(rec['polya_called'])[0].tolist():
                 broken[k] = not self._guarded(t, rows[k], self.polyaanalyzer, NanoporeRead(t, rows[k]))
-        for k in np.nonzero(~broken)[0].tolist():
+        settled = self.bulk_base_space(t, rows, ~broken)
+        for k in np.nonzero(~broken & ~settled)[0].tolist():
             broken[k] = not self._guarded(t, rows[k], self.base_space_checks, t, rows[k], rec[k])
         done = rows[~broken & ~t.stopped[rows]]
         t.label[done] = 0                # 'pass'
+
+    def bulk_base_space(self, t, rows, todo):
+        """base_space_checks as column operations, for rows whose basecall summary sits in a
+        read bundle's columns (fast5_file.BASECALL_COLUMNS).  Returns the mask of rows it
+        settled (passed, or halted with a domain status); everything irregular -- a missing
+        or odd event table, a frame that does not fit the raw signal, reads the chimera scan
+        flagged -- is left to the per-read path, which raises exactly as before."""
+        cfg = self.config
+        settled = np.zeros(len(rows), dtype=bool)
+        if t.bundle is None or cfg['albacore_onthefly']:
+            return settled
+        bi = t.bundle_index[rows]
+        pick = np.nonzero(todo & (bi >= 0))[0]
+        if not len(pick):
+            return settled
+        d, r, b = t.bundle.d, rows[pick], bi[pick]
+        absent = ~d['bc_present'][b]
+        t.halt(r[absent], 'not_basecalled', 'fail')
+        settled[pick[absent]] = True
+        # regular = Guppy frame that fits the raw signal (convert_events_guppy's size rule)
+        first, stride, n_moves = d['bc_first_sample'][b], d['bc_block_stride'][b].astype(np.int64), d['bc_n_moves'][b]
+        covered = np.maximum(np.minimum(first + stride * n_moves, t.n_raw[r]) - first, 0)
+        kind = d['bc_table'][b]
+        regular = ~absent & ((kind == 1) | (kind == 2)) & (n_moves >= 0) & (stride > 0) & \
+            (-(-covered // np.maximum(stride, 1)) == n_moves) & t.has_scaling[r]
+        if cfg['filter_unsplit_reads']:
+            # the decision rule needs the event frame only for reads with candidates; the
+            # frame's own validity (k-mer size of a Move table) is checked for everyone
+            kmer = (d['seq_offsets'][b + 1] - d['seq_offsets'][b]) - d['bc_move_sum'][b] + 1
+            regular &= (t.unsplit_count[r] == 0) & ((kind == 2) | (kmer == 5) | (kmer == 1))
+        ok, okb = r[regular], b[regular]
+        t.sequence_length[ok], t.mean_qscore[ok] = d['bc_sequence_length'][okb], \
+            d['bc_mean_qscore'][okb].astype(np.float32)
+        t.num_events[ok], t.has_summary[ok] = d['bc_num_events'][okb], True
+        so = d['seq_offsets']
+        text_s, text_q = t.bundle.sequence_text()
+        for i, a, z in zip(ok.tolist(), so[okb].tolist(), so[okb + 1].tolist()):
+            t.sequence[i] = (text_s[a:z].decode('ascii'), text_q[a:z].decode('ascii'), 0)
+        short = (so[okb + 1] - so[okb]) < cfg['minimum_sequence_length']      # trimming is a no-op
+        t.halt(ok[short], 'sequence_too_short', 'fail')
+        settled[pick[regular]] = True
+        return settled
 
     def _guarded(self, t, row, fn, *args):
         """Run one read's step; a domain failure halts the read with its label, anything

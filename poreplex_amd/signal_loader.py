@@ -63,6 +63,8 @@ class ReadTable:
         self.channel, self.run_id, self.sample_id = [], [], []
         self.raw, self.sequence, self.error_message, self.polya = [], [], [], []
         self.unsplit = []
+        # rows that came out of a read bundle: the bundle and the read's index in it
+        self.bundle, self.bundle_index = None, np.zeros(0, dtype=np.int64)
         # attached by the GPU pass
         self.gpu_row = np.zeros(0, dtype=np.int64)      # row -> index in `records`, -1 if not run
         self.records = None
@@ -76,6 +78,10 @@ class ReadTable:
         self.scale_shift = _grown(self.scale_shift, self.n)
         self.calib = _grown(self.calib, self.n)
         self.gpu_row = _grown(self.gpu_row, self.n)
+        self.bundle_index = _grown(self.bundle_index, self.n)
+        self.bundle_index[i] = getattr(source, 'i', -1) if getattr(source, 'bundle', None) is not None else -1
+        if self.bundle_index[i] >= 0:
+            self.bundle = source.bundle
         self.status[i], self.label[i], self.gpu_row[i] = _OKAY, _NO_LABEL, -1
         self.start_time[i], self.duration[i] = source.start_time, source.duration
         self.sampling_rate[i] = source.sampling_rate
@@ -89,6 +95,43 @@ class ReadTable:
         for col in (self.raw, self.sequence, self.error_message, self.polya, self.unsplit):
             col.append(None)
         return i
+
+    def extend_from_bundle(self, bundle, idx):
+        """Append the bundle's reads `idx` (int array) in one go: every column is a slice of
+        the bundle's columns, the raw samples are views into its arena.  Returns the rows."""
+        idx = np.asarray(idx, dtype=np.int64)
+        k, d = len(idx), bundle.d
+        lo, hi = self.n, self.n + k
+        self.n = hi
+        for name, _ in self.NUMERIC:
+            setattr(self, name, _grown(getattr(self, name), hi))
+        for name in ('scale_shift', 'calib', 'gpu_row', 'bundle_index'):
+            setattr(self, name, _grown(getattr(self, name), hi))
+        rows = np.arange(lo, hi)
+        self.status[rows], self.label[rows], self.gpu_row[rows] = _OKAY, _NO_LABEL, -1
+        self.bundle, self.bundle_index[rows] = bundle, idx
+        self.start_time[rows], self.duration[rows] = d['start_time'][idx], d['duration'][idx]
+        self.calib[rows] = d['calib'][idx]
+        self.sampling_rate[rows] = d['calib']['sampling_rate'][idx]
+        o = d['offsets']
+        self.n_raw[rows] = o[idx + 1] - o[idx]
+        self.filename += [bundle.filenames[i] for i in idx.tolist()]
+        self.read_id += [bundle.read_ids[i] for i in idx.tolist()]
+        self.channel += d['channel_number'][idx].tolist()
+        self.run_id += d['run_id'][idx].tolist()
+        self.sample_id += d['sample_id'][idx].tolist()
+        arena = d['arena']
+        self.raw += [arena[a:b] for a, b in zip(o[idx].tolist(), o[idx + 1].tolist())]
+        for col in (self.source, self.sequence, self.error_message, self.polya, self.unsplit):
+            col.extend([None] * k)
+        return rows
+
+    def source_of(self, i):
+        """The read's file object; bundle rows get theirs on first use."""
+        if self.source[i] is None and self.bundle_index[i] >= 0:
+            from .fast5_file import BundleReader
+            self.source[i] = BundleReader(self.bundle, int(self.bundle_index[i]))
+        return self.source[i]
 
     # -- column updates ------------------------------------------------------
     def halt(self, rows, status, label=None):
@@ -155,6 +198,37 @@ class ReadTable:
         return out
 
 
+def summary_columns(table, rows, barcoding, polya):
+    """The values SequencingSummaryWriter prints for `rows`, as per-field lists of the SAME
+    Python objects report() would put into the dicts (so str() of them is identical), without
+    building the dicts.  Only labelled rows are written by the writer: the caller filters."""
+    idx = np.asarray(rows, dtype=np.int64)
+    rows = idx.tolist()
+    cols = {
+        'filename': [table.filename[i] for i in rows],
+        'read_id': [table.read_id[i] for i in rows],
+        'run_id': [table.run_id[i] for i in rows],
+        'channel': [table.channel[i] for i in rows],
+        'start_time': [round(a / b, 3) for a, b in zip(table.start_time[idx].tolist(),
+                                                       table.sampling_rate[idx].tolist())],
+        'duration': table.duration[idx].tolist(),
+        'num_events': table.num_events[idx].tolist(),
+        'sequence_length': table.sequence_length[idx].tolist(),
+        'mean_qscore': [q if got else 0 for q, got in zip(table.mean_qscore[idx].tolist(),
+                                                          table.has_summary[idx].tolist())],
+        'sample_id': [table.sample_id[i] for i in rows],
+        'status': [native.STATUS_NAMES[c] for c in table.status[idx].tolist()],
+        'label': [LABELS[c] for c in table.label[idx].tolist()],
+    }
+    if barcoding:
+        called = table.has_barcode[idx]
+        cols['barcode'] = [b if c else None for b, c in zip(table.barcode[idx].tolist(), called.tolist())]
+        cols['barcode_score'] = np.where(called, table.barcode_phred[idx], 0).tolist()
+    if polya:
+        cols['polya'] = [table.polya[i] for i in rows]
+    return cols
+
+
 class NanoporeRead:
     """Row handle with the reference's NanoporeRead surface."""
 
@@ -166,7 +240,7 @@ class NanoporeRead:
     # identity / metadata
     filename = property(lambda self: self.table.filename[self.row])
     read_id = property(lambda self: self.table.read_id[self.row])
-    fast5 = property(lambda self: self.table.source[self.row])
+    fast5 = property(lambda self: self.table.source_of(self.row))
     sampling_rate = property(lambda self: float(self.table.sampling_rate[self.row]))
     status = property(lambda self: native.STATUS_NAMES[self.table.status[self.row]])
     stopped = property(lambda self: bool(self.table.stopped[self.row]))
@@ -248,7 +322,7 @@ class NanoporeRead:
         is stored (fast5_file.py:166-181,210-223): validate first, commit second.  The
         table's signal columns are only materialised by the stage that consumes them."""
         t, i = self.table, self.row
-        if t.source[i] is None:
+        if t.source_of(i) is None:
             raise Exception('Fast5 must be open for getting events.')
         bcall = t.source[i].get_basecall()
         if bcall is None:
@@ -271,7 +345,7 @@ class NanoporeRead:
         whole blocks, must hold exactly one block per move."""
         t, i = self.table, self.row
         if bcall is None:
-            bcall = t.source[i].get_basecall()
+            bcall = t.source_of(i).get_basecall()
         if bcall is None:
             raise SignalAnalysisError('not_basecalled')
         if bcall.get('move') is None:
@@ -334,16 +408,49 @@ class SignalLoader:
             t.raw[row] = raw
         return NanoporeRead(t, row)
 
+    def prepare_many(self, reads, table):
+        """Bulk form of prepare_loading for reads that live in the read bundle: one column
+        append for all of them.  Returns one entry per input read: its row, or None when the
+        read needs the per-read path (not in the bundle, or its file is marked corrupt)."""
+        b = self.bundle
+        if b is None:
+            return [None] * len(reads)
+        index, broken = b.index, b.broken
+        where = [index.get(key, -1) if key[0] not in broken else -1 for key in reads]
+        idx = np.array([i for i in where if i >= 0], dtype=np.int64)
+        rows = table.extend_from_bundle(b, idx)
+        cfg = self.scaler_cfg      # length gate of load_padded_signal_head (:212-222)
+        usable = np.minimum(np.minimum(cfg['length'], table.duration[rows]), table.n_raw[rows])
+        short = rows[usable - usable % cfg['stride'] < cfg['min_length']]
+        table.halt(short, 'scaler_signal_too_short')
+        for i in short.tolist():
+            table.raw[i] = None
+        it = iter(rows.tolist())
+        return [next(it) if i >= 0 else None for i in where]
+
     # ---- the GPU pass, in the three steps the session driver overlaps ------------------
-    def pack(self, table=None, arena=None):
+    def pack(self, table=None, arena=None, need=None):
         """(rows, arena, offsets, calib) of the reads of `table` that go to the GPU.  With
-        `arena` (a page-locked staging buffer) the samples are packed in place."""
+        `arena` (a page-locked staging buffer, or an object whose reserve(n) returns one) the
+        samples are packed in place."""
         t = self.table if table is None else table
         rows = t.live_rows()
         rows = rows[[t.raw[i] is not None for i in rows]] if len(rows) else rows
         lens = np.array([len(t.raw[i]) for i in rows], dtype=np.int64)
         offsets = np.zeros(len(rows) + 1, dtype=np.int64)
         np.cumsum(lens, out=offsets[1:])
+        # a run of consecutive bundle reads is already packed: hand out the bundle's own
+        # arena (page-locked once by the session) instead of copying 120 KB per read
+        bi = t.bundle_index[rows] if len(rows) else np.zeros(0, dtype=np.int64)
+        if len(rows) and t.bundle is not None and bi[0] >= 0 and \
+                np.array_equal(bi, bi[0] + np.arange(len(rows))):
+            o = t.bundle.d['offsets']
+            for i in rows:
+                t.raw[i] = None
+            return rows, t.bundle.d['arena'][o[bi[0]]:o[bi[-1] + 1]], offsets, \
+                np.ascontiguousarray(t.calib[rows])
+        if hasattr(arena, 'reserve'):
+            arena = arena.reserve(int(offsets[-1]))
         if arena is None:
             arena = np.empty(int(offsets[-1]), dtype=np.int16)
         elif len(arena) < offsets[-1]:

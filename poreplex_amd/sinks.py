@@ -113,6 +113,31 @@ class SequencingSummaryWriter:
                 self.file.write('\t'.join(str(row[f]) for f in self.output_fields) + '\n')
 
 
+    def write_columns(self, cols):
+        """write_results for rows that only exist as columns (signal_loader.summary_columns):
+        same text, no per-read dicts.  Every row must carry a label."""
+        n = len(cols['read_id'])
+        label = [self.label_mapping[v] for v in cols['label']]
+        bcname = [self.barcode_mapping[b] for b in cols['barcode']] \
+            if self.barcode_mapping is not None else None
+        if not self.fast5_layout:
+            filename = cols['filename']
+        elif bcname is not None:
+            filename = [os.path.join('fast5', a, b, f) for a, b, f in zip(label, bcname, cols['filename'])]
+        else:
+            filename = [os.path.join('fast5', a, f) for a, f in zip(label, cols['filename'])]
+        out = dict(cols, label=label, filename=filename)
+        if bcname is not None:
+            out['barcode'] = bcname
+        if self.polya_enabled:
+            out['polya_dwell'] = [format(p['dwell_time'], '.4f') if p is not None else ''
+                                  for p in cols['polya']]
+        fields = [list(map(str, out[f])) for f in self.output_fields]
+        text = ''.join('\t'.join(row) + '\n' for row in zip(*fields)) if n else ''
+        with self.lock:
+            self.file.write(text)
+
+
 class FinalSummaryTracker:
     """Counts per (label, barcode, status) and the end-of-run table."""
 

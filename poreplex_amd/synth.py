@@ -167,3 +167,24 @@ def synth_batch(n_reads, seed=922, samples_per_read=60000, jitter=0.1, barcodes=
         'scale_shift': np.stack([scale, shift], axis=1).astype(np.float32),
         'barcode': barcodes, 'truth': truth,
     }
+
+
+def synth_basecalls(batch, seed=0, block_stride=15):
+    """Plausible Guppy basecall summaries for a synthetic batch (one per read): a sequence of
+    one base per ~12 blocks, a Move table with one block per 15 samples whose moves add up to
+    len(sequence) - 4 (5-mer frames), first_sample_template 0."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = []
+    for n_raw in np.diff(batch['offsets']).tolist():
+        n_blocks = n_raw // block_stride
+        n_bases = max(n_blocks // 12, 16)
+        move = np.zeros(n_blocks, dtype=np.uint8)
+        move[rng.choice(n_blocks, size=min(n_bases - 4, n_blocks), replace=False)] = 1
+        n_bases = int(move.sum()) + 4
+        seq = ''.join('ACGU'[i] for i in rng.integers(0, 4, n_bases))
+        qual = ''.join(chr(33 + q) for q in rng.integers(5, 25, n_bases))
+        out.append({'sequence': seq, 'qstring': qual, 'block_stride': block_stride,
+                    'sequence_length': n_bases, 'mean_qscore': float(np.float32(rng.uniform(7, 13))),
+                    'num_events': n_blocks, 'first_sample_template': 0, 'table': 'move',
+                    'move': move})
+    return out

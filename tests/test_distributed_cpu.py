@@ -122,3 +122,26 @@ def test_bench_self_spawns_two_ranks_over_gloo():
         assert line['extra']['labels_gathered'] == total
         assert line['extra']['labels_read_index_unique'] is True
         assert sum(line['config']['reads_per_gpu']) == total
+
+
+def test_bench_end_to_end_two_ranks_over_gloo():
+    """bench.py --end-to-end --gpus 2: each rank writes its shard as a read bundle, the session
+    driver runs it (loader thread, batches, facade, sinks, all-gather / all-reduce); rank 0
+    stitches one sequencing_summary.txt with a row per labelled read of BOTH shards."""
+    import json
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['PYTHONPATH'] = os.path.join(ROOT, 'tests') + os.pathsep + env.get('PYTHONPATH', '')
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--end-to-end', '--reads', '14',
+         '--batch-reads', '5', '--samples', '12000', '--cpu-sample', '0', '--cpu-all-cores-sample', '0',
+         '--context-factory', 'oracle_context:OracleBackedContext'],
+        env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    x = line['extra']
+    assert line['n_gpus'] == 2 and x['ranks_counted_by_collective'] == 2
+    assert x['labels_gathered'] == 28 and x['labels_read_index_unique'] is True
+    assert x['summary_rows'] == 28 and x['reads_labelled_pass'] >= 20
