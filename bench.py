@@ -198,6 +198,9 @@ def end_to_end(args, config, rank, local_rank, world, dist, standin, base, which
         mod, attr = args.context_factory.split(':')
         N.NativeContext = getattr(importlib.import_module(mod), attr)
     work = tempfile.mkdtemp(prefix='pxg_e2e_r{}_'.format(rank))
+    # the output directory is shared by the ranks (rank 0 stitches their part files)
+    outdir = os.path.join(tempfile.gettempdir(), 'pxg_e2e_out_{}_{}'.format(
+        os.environ.get('MASTER_PORT', 'solo'), os.getppid() if world > 1 else os.getpid()))
     try:
         o = base['offsets']
         parts = [base['arena'][o[b]:o[b + 1]] for b in which]
@@ -210,7 +213,7 @@ def end_to_end(args, config, rank, local_rank, world, dist, standin, base, which
         write_bundle(path, arena, off, base['calib'][which], names, ids,
                      basecalls=synth_basecalls(shard, seed=args.seed + rank))
         t_write = time.perf_counter() - t0
-        cfg = default_config(inputdir=work, outputdir=os.path.join(work, 'out'), read_bundle=path,
+        cfg = default_config(inputdir=work, outputdir=outdir, read_bundle=path,
                              barcoding=True, measure_polya=bool(mask & N.STAGE_POLYA),
                              filter_unsplit_reads=args.workload in ('chimera', 'full'),
                              device_id=local_rank)
@@ -268,6 +271,8 @@ def end_to_end(args, config, rank, local_rank, world, dist, standin, base, which
         WorkerPersistenceStorage.reset()
     finally:
         shutil.rmtree(work, ignore_errors=True)
+        if rank == 0:
+            shutil.rmtree(outdir, ignore_errors=True)
     if dist is not None:
         dist.destroy_process_group()
 
