@@ -167,7 +167,7 @@ def cpu_all_cores(config, base, mask, use_inject, n_sample):
     runtime is initialised in this process (fork)."""
     import multiprocessing as mp
     model, physical, usable, quota = host_description()
-    workers = max(1, min(physical, usable))
+    workers = max(1, min(physical, usable, int(quota) if quota else physical))
     n_base = len(base['offsets']) - 1
     n = max(n_sample, 96 * workers)                        # ~0.7 s of work per core at least
     ids = np.arange(n) % n_base

@@ -174,51 +174,53 @@ class GpuSession:
                 staging.settle()
                 self.ctx.stage(arena, offsets, calib)
                 self.ctx.swap()
+                self.ctx.run(self.loader.stage_mask)      # asynchronous: kernels are enqueued
             slots.put(staging)
         done = 0
         while current is not None:
             batch, staging, rows, arena, offsets, calib = current
+            # ---- GPU side: batch k computes; k+1 is copied under it, then launched ----------
             t0 = time.perf_counter()
-            if len(rows):
-                self.ctx.run(self.loader.stage_mask)      # asynchronous: kernels are enqueued
-            nxt = take()                                  # next batch is (being) packed meanwhile
+            nxt = take()                                  # packed by the loader thread meanwhile
             staged = False
             if nxt is not None and len(nxt[2]):
                 nxt[1].settle()
                 self.ctx.stage(nxt[3], nxt[4], nxt[5])    # H2D on the copy stream, under the kernels
                 staged = True
-            self._attach(batch.table, rows, offsets)      # D2H of the records: waits for the run
-            self.timing['gpu_wait_s'] += time.perf_counter() - t0
+            self._attach(batch.table, rows, offsets)      # D2H of the records: waits for run k
             if staged:
-                self.ctx.swap()
+                self.ctx.swap()                           # k+1 resident ...
+                self.ctx.run(self.loader.stage_mask)      # ... and computing while k is written out
             if nxt is not None:
                 slots.put(nxt[1])
+            self.timing['gpu_wait_s'] += time.perf_counter() - t0
 
+            # ---- host side of batch k, under the kernels of k+1 ------------------------------
             t0 = time.perf_counter()
             table = batch.table
             self.analyzer.settle(batch)
-            rows, positions, loose = batch.in_input_order()
+            rows_in, positions, loose = batch.in_input_order()
             results = self.analyzer.finish(batch, input_order=True) if fastq is not None else None
             self.timing['facade_s'] += time.perf_counter() - t0
             t0 = time.perf_counter()
-            idx = np.asarray(rows, dtype=np.int64)
+            idx = np.asarray(rows_in, dtype=np.int64)
             for code, n_seen in zip(*np.unique(table.status[idx], return_counts=True)):
                 name = native.STATUS_NAMES[code]
                 status_seen[name] = status_seen.get(name, 0) + int(n_seen)
             for _, r in loose:
                 status_seen[r['status']] = status_seen.get(r['status'], 0) + 1
-            for message in [table.error_message[i] for i in rows if table.error_message[i]] + \
+            for message in [table.error_message[i] for i in rows_in if table.error_message[i]] + \
                     [r['error_message'] for _, r in loose if 'error_message' in r]:
                 self.logger.error(message)
             # the sinks, from the columns: only labelled reads have a summary row (io.py:166-168)
-            labelled = [i for i in rows if table.label[i] >= 0]
+            labelled = idx[table.label[idx] >= 0]
             summary.write_columns(summary_columns(table, labelled, bool(cfg['barcoding']),
                                                   bool(cfg['measure_polya'])))
             if fastq is not None:
                 fastq.write_sequences(results)
-            records.append(D.final_label_records_from_table(table, rows, positions, loose,
+            records.append(D.final_label_records_from_table(table, rows_in, positions, loose,
                                                             first_index=lo + done))
-            done += len(rows) + len(loose)
+            done += len(rows_in) + len(loose)
             self.timing['sink_s'] += time.perf_counter() - t0
             self._check_early_stop(status_seen)
             current = nxt
