@@ -832,6 +832,464 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
 }
 
 // ===========================================================================
+// K5a-q / K5b-q: the demux kernels TIME-SLICED like K2q, used whenever the batch has more
+// 16-read tiles than resident workgroups.  With the static split a 10 000-read batch puts 2
+// tiles on 107 of the 512 workgroups and 1 on the rest, and every step of a 2-tile group
+// costs two tile-steps: the launch lasts 2 x 300 tile-steps for 619 x 300 / 512 = 363 of
+// work per slot (60 %).  Here the 2 x #CU resident workgroups pull (step block, tile) tasks
+// from a queue; the number of blocks per tile is chosen ON THE DEVICE from the actual tile
+// count (demux_blocks: the cut that minimises whole rounds x block length, 4 blocks for 619
+// tiles: 5 rounds x 75 steps = 375).  A tile's state (hidden rows + cell registers) travels
+// through HBM between its blocks, two alternating slots per tile; hand-over as in K2q
+// (per-tile progress counter, release / acquire at agent scope).  Weights stay in VGPRs
+// across tasks.  The step bodies are those of k_demux_bidir<1> / k_demux_top<1>:
+// bit-identical results.
+// ===========================================================================
+#define DQ_HANDOVER 3           // cost of one hand-over, in steps (cost model only)
+#define DQ_MAXBLK 12
+
+__device__ __forceinline__ int demux_blocks(int n_tiles, int slots, int T)
+{
+    int best = 1, best_cost = 0x7fffffff;
+    for (int nb = 1; nb <= DQ_MAXBLK; nb++) {
+        const int rounds = (nb * n_tiles + slots - 1) / slots;
+        const int cost = rounds * ((T + nb - 1) / nb + DQ_HANDOVER);
+        if (cost < best_cost) { best_cost = cost; best = nb; }
+    }
+    return best;
+}
+
+// wait until block `blk` of `tile` may start (its predecessor published), bounded spin
+__device__ __forceinline__ void dq_wait(const int* done, int tile, int blk, int* errflag, int tid)
+{
+    if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(&done[tile], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < blk) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins > (1 << 24)) { atomicExch(errflag, 1); break; }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+__device__ __forceinline__ void dq_publish(int* done, int tile, int blk, int tid)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&done[tile], blk + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define DQA_STATE (2 * 16 * HSTRIDE(48) + 2 * LSTM_THREADS * 3)     // hf, hb rows + cf, cb registers
+
+// MT = read tiles per task.  Only MT = 1 is launched: a task chain is one tile group, so
+// pairs halve the number of independent chains (619 tiles -> 310 groups for 512 slots) and
+// measured slower at every batch size tried (10 000 reads: 2.33 + 2.97 ms against 1.56 + 2.29;
+// 100 000 reads: 13.4 + 19.6 against 13.1 + 19.7).  An 8-wave variant of K5a (forward cell on
+// waves 0-3, backward on 4-7, 128 VGPRs, four waves per SIMD) measured the same 1.57 ms as
+// this one: the kernel is not latency-bound, see DESIGN.md section 3.1.
+template <int MT>
+__global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir_q(
+    int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int T,
+    const float* __restrict__ win, const float* __restrict__ sigtab,
+    const float* __restrict__ Wf, const float* __restrict__ Uf, const float* __restrict__ bf,
+    const float* __restrict__ Wb, const float* __restrict__ Ub, const float* __restrict__ bb,
+    float* __restrict__ bidir, int* __restrict__ queue, int* __restrict__ errflag,
+    int* __restrict__ done /* per tile group */, float* __restrict__ state /* [2][tile][DQA_STATE] */)
+{
+    constexpr int H = 48, NT = 3, KB = 12, HS = HSTRIDE(H);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lim = count ? min(*count, n_rows) : n_rows;
+    const int n_tiles = (lim + 15) >> 4;
+    const int n_groups = (n_tiles + MT - 1) / MT;
+    const int n_blocks = demux_blocks(n_groups, (int)gridDim.x, T);
+    const int QB = (T + n_blocks - 1) / n_blocks;
+    const int n_tasks = n_groups * n_blocks;
+
+    float4* tab = reinterpret_cast<float4*>(smem);
+    float* hf = smem + 4 * PXG_SIG_NSEG;               // [2][MT][16][HS]
+    float* hb = hf + 2 * MT * 16 * HS;
+    float* xf = hb + 2 * MT * 16 * HS;                 // [16*MT][XS]  x[c0 + c]
+    float* xr = xf + 16 * MT * XS;                     // [16*MT][XS]  x[T-1-(c0+c)]
+    int* ridx = reinterpret_cast<int*>(xr + 16 * MT * XS);  // [16*MT]
+    int* s_task = ridx + 16 * MT;
+
+    const int tid = threadIdx.x, lane = tid & 63, slice = tid >> 6;
+    const int rd_l = lane & 15, ul = lane >> 4;
+
+    load_sigtab(tab, sigtab, tid);
+    float wF[NT][KB], wBk[NT][KB], biasf[NT][4], biasb[NT][4], wxf[NT][4], wxb[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int unit0 = slice * 12 + nt * 4;
+        load_wfrag<H, KB>(wF[nt], Uf, 0, unit0, lane);
+        load_wfrag<H, KB>(wBk[nt], Ub, 0, unit0, lane);
+        load_gate4<H>(biasf[nt], bf, unit0, lane);
+        load_gate4<H>(biasb[nt], bb, unit0, lane);
+        load_gate4<H>(wxf[nt], Wf, unit0, lane);
+        load_gate4<H>(wxb[nt], Wb, unit0, lane);
+    }
+    constexpr int NST = (MT * 16 * 2 * (H / 4) + LSTM_THREADS - 1) / LSTM_THREADS;
+
+    for (;;) {
+        __syncthreads();                       // everybody is done with the previous task's LDS
+        if (tid == 0) *s_task = atomicAdd(&queue[0], 1);
+        __syncthreads();
+        const int q = *s_task;
+        if (q >= n_tasks) break;
+        const int blk = q / n_groups, grp = q % n_groups;
+        const int tile0 = grp * MT;
+        const int ntile = min(MT, n_tiles - tile0);
+        const int t0 = blk * QB;
+        const int t1 = min(t0 + QB, T);
+        for (int i = tid; i < 16 * MT; i += LSTM_THREADS) {
+            const int row = tile0 * 16 + i;
+            ridx[i] = (i < 16 * ntile && row < lim) ? (idx ? idx[row] : row) : -1;
+        }
+        float cf[MT][NT], cb[MT][NT];
+        if (blk == 0) {
+            for (int i = tid; i < 4 * MT * 16 * HS; i += LSTM_THREADS) hf[i] = 0.0f;     // hf and hb, both buffers
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) cf[m][nt] = cb[m][nt] = 0.0f;
+            __syncthreads();
+        } else {
+            dq_wait(done, grp, blk, errflag, tid);
+            const int rb = t0 & 1;
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const float* st_in = state + ((size_t)((blk - 1) & 1) * n_tiles + min(tile0 + m, n_tiles - 1)) * DQA_STATE;
+                for (int i = tid; i < 16 * HS; i += LSTM_THREADS) {
+                    hf[(rb * MT + m) * 16 * HS + i] = st_in[i];
+                    hb[(rb * MT + m) * 16 * HS + i] = st_in[16 * HS + i];
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) {
+                    cf[m][nt] = st_in[2 * 16 * HS + nt * LSTM_THREADS + tid];
+                    cb[m][nt] = st_in[2 * 16 * HS + (NT + nt) * LSTM_THREADS + tid];
+                }
+            }
+            __syncthreads();
+        }
+        // streaming of the hidden rows to HBM: fixed (row, direction, float4) per thread and task
+        int st_src[NST], st_dir[NST];
+        float* st_dst[NST];
+#pragma unroll
+        for (int p = 0; p < NST; p++) {
+            const int i = tid + p * LSTM_THREADS;
+            st_src[p] = -1; st_dir[p] = 0; st_dst[p] = bidir;
+            if (i < 16 * ntile * 2 * (H / 4)) {
+                const int c4 = i % (H / 4);
+                const int dir = (i / (H / 4)) & 1;
+                const int row = i / (2 * (H / 4));
+                const int rd = ridx[row];
+                if (rd >= 0) {
+                    st_src[p] = row * HS + c4 * 4;
+                    st_dir[p] = dir;
+                    st_dst[p] = bidir + ((size_t)rd * T) * (2 * H) + dir * H + c4 * 4;
+                }
+            }
+        }
+
+        for (int t = t0; t <= t1; t++) {
+            const int rdb = t & 1, wrb = (t + 1) & 1;
+            if (t > t0) {    // stream the rows written in the previous step to HBM
+                const int tf = t - 1, tb = T - t;
+#pragma unroll
+                for (int p = 0; p < NST; p++) {
+                    if (st_src[p] >= 0) {
+                        const float* src = (st_dir[p] ? hb : hf) + rdb * MT * 16 * HS + st_src[p];
+                        float* dst = st_dst[p] + (size_t)(st_dir[p] ? tb : tf) * (2 * H);
+                        *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+                    }
+                }
+            }
+            if (t == t1) break;
+            if (((t - t0) % XCH) == 0) {          // refill both x tiles
+                __syncthreads();
+                for (int i = tid; i < 16 * ntile * XCH; i += LSTM_THREADS) {
+                    const int row = i / XCH, c = i % XCH;
+                    const int rd = ridx[row];
+                    const int tt = t + c;
+                    const bool ok = rd >= 0 && tt < T;
+                    xf[row * XS + c] = ok ? win[(size_t)rd * T + tt] : 0.0f;
+                    xr[row * XS + c] = ok ? win[(size_t)rd * T + (T - 1 - tt)] : 0.0f;
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                if (m < ntile) {
+                    float a1[KB], a2[KB];
+                    load_afrag<H>(a1, hf + (rdb * MT + m) * 16 * HS, lane);
+                    load_afrag<H>(a2, hb + (rdb * MT + m) * 16 * HS, lane);
+                    f32x4 acc1[NT], acc2[NT];
+                    const float x1 = xf[(m * 16 + rd_l) * XS + ((t - t0) % XCH)];
+                    const float x2 = xr[(m * 16 + rd_l) * XS + ((t - t0) % XCH)];
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const float p1 = x1 * wxf[nt][r];
+                            acc1[nt][r] = p1 + biasf[nt][r];
+                            const float p2 = x2 * wxb[nt][r];
+                            acc2[nt][r] = p2 + biasb[nt][r];
+                        }
+                    }
+#pragma unroll
+                    for (int kb = 0; kb < KB; kb++) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; nt++) {
+                            acc1[nt] = mfma4(wF[nt][kb], a1[kb], acc1[nt]);
+                            acc2[nt] = mfma4(wBk[nt][kb], a2[kb], acc2[nt]);
+                        }
+                    }
+                    const int ob = ((wrb * MT + m) * 16 + rd_l) * HS;
+                    float hn1[NT], hn2[NT];
+                    cells_update<NT>(tab, acc1, cf[m], hn1);
+                    cells_update<NT>(tab, acc2, cb[m], hn2);
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {
+                        const int hp = ob + hpos<H>(slice * 12 + nt * 4 + ul);
+                        hf[hp] = hn1[nt];
+                        hb[hp] = hn2[nt];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+
+        if (t1 < T) {        // hand the tiles over: state of iteration t1 -> HBM, then publish
+            const int rb = t1 & 1;
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                if (m < ntile) {
+                    float* st_out = state + ((size_t)(blk & 1) * n_tiles + tile0 + m) * DQA_STATE;
+                    for (int i = tid; i < 16 * HS; i += LSTM_THREADS) {
+                        st_out[i] = hf[(rb * MT + m) * 16 * HS + i];
+                        st_out[16 * HS + i] = hb[(rb * MT + m) * 16 * HS + i];
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {
+                        st_out[2 * 16 * HS + nt * LSTM_THREADS + tid] = cf[m][nt];
+                        st_out[2 * 16 * HS + (NT + nt) * LSTM_THREADS + tid] = cb[m][nt];
+                    }
+                }
+            }
+            dq_publish(done, grp, blk, tid);
+        }
+    }
+}
+
+#define DQB_STATE (16 * HSTRIDE(64) + LSTM_THREADS * 4)              // h3 rows + c3 registers
+
+template <int MT>
+__global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top_q(
+    int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int T,
+    const float* __restrict__ bidir, const float* __restrict__ sigtab,
+    const float* __restrict__ W3, const float* __restrict__ U3, const float* __restrict__ b3,
+    const float* __restrict__ Wd, const float* __restrict__ bd, int n_classes,
+    float* __restrict__ probs, int* __restrict__ queue, int* __restrict__ errflag,
+    int* __restrict__ done, float* __restrict__ state /* [2][tile][DQB_STATE] */)
+{
+    constexpr int H = 64, HI = 48, NT = 4, KBI = 24, KBR = 16;
+    constexpr int HS = HSTRIDE(H), IS = HSTRIDE(2 * HI);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lim = count ? min(*count, n_rows) : n_rows;
+    const int n_tiles = (lim + 15) >> 4;
+    const int n_groups = (n_tiles + MT - 1) / MT;
+    const int n_blocks = demux_blocks(n_groups, (int)gridDim.x, T);
+    const int QB = (T + n_blocks - 1) / n_blocks;
+    const int n_tasks = n_groups * n_blocks;
+
+    float4* tab = reinterpret_cast<float4*>(smem);
+    float* h3 = smem + 4 * PXG_SIG_NSEG;               // [2][MT][16][HS]
+    float* inb = h3 + 2 * MT * 16 * HS;                // [2][MT*16][IS]
+    float* bl = inb + 2 * MT * 16 * IS;                // [H][4] bias, (i,f,g,o) per unit
+    int* ridx = reinterpret_cast<int*>(bl + 4 * H);    // [16*MT]
+    int* s_task = ridx + 16 * MT;
+
+    const int tid = threadIdx.x, lane = tid & 63, slice = tid >> 6;
+    const int rd_l = lane & 15, ul = lane >> 4;
+
+    load_sigtab(tab, sigtab, tid);
+    for (int i = tid; i < 4 * H; i += LSTM_THREADS) bl[i] = b3[(i & 3) * H + (i >> 2)];
+    float wI[NT][KBI], wR[NT][KBR];
+#pragma unroll
+    for (int nt = 0; nt < NT; nt++) {
+        const int unit0 = slice * 16 + nt * 4;
+        load_wfrag<H, KBI>(wI[nt], W3, 0, unit0, lane);
+        load_wfrag<H, KBR>(wR[nt], U3, 0, unit0, lane);
+    }
+    constexpr int NPF = (MT * 16 * (2 * HI / 4) + LSTM_THREADS - 1) / LSTM_THREADS;
+
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) *s_task = atomicAdd(&queue[0], 1);
+        __syncthreads();
+        const int q = *s_task;
+        if (q >= n_tasks) break;
+        const int blk = q / n_groups, grp = q % n_groups;
+        const int tile0 = grp * MT;
+        const int ntile = min(MT, n_tiles - tile0);
+        const int t0 = blk * QB;
+        const int t1 = min(t0 + QB, T);
+        for (int i = tid; i < 16 * MT; i += LSTM_THREADS) {
+            const int row = tile0 * 16 + i;
+            ridx[i] = (i < 16 * ntile && row < lim) ? (idx ? idx[row] : row) : -1;
+        }
+        float c3[MT][NT];
+        if (blk == 0) {
+            for (int i = tid; i < 2 * MT * 16 * HS; i += LSTM_THREADS) h3[i] = 0.0f;
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) c3[m][nt] = 0.0f;
+            __syncthreads();
+        } else {
+            dq_wait(done, grp, blk, errflag, tid);
+            const int rb = t0 & 1;
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const float* st_in = state + ((size_t)((blk - 1) & 1) * n_tiles + min(tile0 + m, n_tiles - 1)) * DQB_STATE;
+                for (int i = tid; i < 16 * HS; i += LSTM_THREADS) h3[(rb * MT + m) * 16 * HS + i] = st_in[i];
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++) c3[m][nt] = st_in[16 * HS + nt * LSTM_THREADS + tid];
+            }
+            __syncthreads();
+        }
+        // input rows of step t0 into the buffer step t0 reads; prefetch constants of the task
+        const int n_f4 = 16 * ntile * (2 * HI / 4);    // float4 per step of input rows
+        const float* pf_src[NPF];
+        int pf_dst[NPF];
+#pragma unroll
+        for (int p = 0; p < NPF; p++) {
+            const int i = tid + p * LSTM_THREADS;
+            pf_src[p] = nullptr;
+            pf_dst[p] = -1;
+            if (i < n_f4) {
+                const int row = i / (2 * HI / 4), c4 = i % (2 * HI / 4);
+                const int rd = ridx[row];
+                pf_dst[p] = row * IS + c4 * 4;
+                if (rd >= 0) pf_src[p] = bidir + ((size_t)rd * T) * (2 * HI) + c4 * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rd >= 0) v = *reinterpret_cast<const float4*>(pf_src[p] + (size_t)t0 * (2 * HI));
+                *reinterpret_cast<float4*>(inb + (t0 & 1) * MT * 16 * IS + pf_dst[p]) = v;
+            }
+        }
+        __syncthreads();
+
+        for (int t = t0; t < t1; t++) {
+            const int rdb = t & 1, wrb = (t + 1) & 1;
+            float4 pf[NPF];
+#pragma unroll
+            for (int p = 0; p < NPF; p++) {
+                pf[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pf_src[p] != nullptr && t + 1 < t1)
+                    pf[p] = *reinterpret_cast<const float4*>(pf_src[p] + (size_t)(t + 1) * (2 * HI));
+            }
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                if (m < ntile) {
+                    f32x4 acc[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) {
+                        const float4 bv = *reinterpret_cast<const float4*>(bl + (slice * 16 + nt * 4 + ul) * 4);
+                        acc[nt][0] = bv.x; acc[nt][1] = bv.y; acc[nt][2] = bv.z; acc[nt][3] = bv.w;
+                    }
+                    const float* p = inb + (rdb * MT * 16 + m * 16) * IS + rd_l * IS + (lane >> 4) * (HI / 4);
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        float a[HI / 4];
+#pragma unroll
+                        for (int v4 = 0; v4 < HI / 16; v4++) {
+                            const float4 v = *reinterpret_cast<const float4*>(p + half * HI + 4 * v4);
+                            a[4 * v4] = v.x; a[4 * v4 + 1] = v.y; a[4 * v4 + 2] = v.z; a[4 * v4 + 3] = v.w;
+                        }
+#pragma unroll
+                        for (int kb = 0; kb < HI / 4; kb++)
+#pragma unroll
+                            for (int nt = 0; nt < NT; nt++)
+                                acc[nt] = mfma4(wI[nt][half * (HI / 4) + kb], a[kb], acc[nt]);
+                    }
+                    {
+                        float a[KBR];
+                        load_afrag<H>(a, h3 + (rdb * MT + m) * 16 * HS, lane);
+#pragma unroll
+                        for (int kb = 0; kb < KBR; kb++)
+#pragma unroll
+                            for (int nt = 0; nt < NT; nt++) acc[nt] = mfma4(wR[nt][kb], a[kb], acc[nt]);
+                    }
+                    float* o3 = h3 + ((wrb * MT + m) * 16 + rd_l) * HS;
+                    float hn[NT];
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        f32x4 a2[2] = { acc[2 * half], acc[2 * half + 1] };
+                        float cc[2] = { c3[m][2 * half], c3[m][2 * half + 1] };
+                        float hh[2];
+                        cells_update<2>(tab, a2, cc, hh);
+                        c3[m][2 * half] = cc[0]; c3[m][2 * half + 1] = cc[1];
+                        hn[2 * half] = hh[0]; hn[2 * half + 1] = hh[1];
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) o3[hpos<H>(slice * 16 + nt * 4 + ul)] = hn[nt];
+                }
+            }
+#pragma unroll
+            for (int p2 = 0; p2 < NPF; p2++)
+                if (pf_dst[p2] >= 0)
+                    *reinterpret_cast<float4*>(inb + wrb * MT * 16 * IS + pf_dst[p2]) = pf[p2];
+            __syncthreads();
+        }
+
+        if (t1 == T) {
+            // ---- Dense(n_classes) + softmax ------------------------------------
+            const int fin = T & 1;
+            for (int row = tid; row < 16 * ntile; row += LSTM_THREADS) {
+                const int rd = ridx[row];
+                if (rd < 0) continue;
+                const float* hr = h3 + ((fin * MT + (row >> 4)) * 16 + (row & 15)) * HS;
+                float z[PXG_MAX_CLASSES], e[PXG_MAX_CLASSES];
+#pragma unroll
+                for (int j = 0; j < PXG_MAX_CLASSES; j++) {
+                    z[j] = -__builtin_inff();
+                    if (j < n_classes) {
+                        float acc = bd[j];
+                        for (int k = 0; k < H; k++) acc = __builtin_fmaf(hr[hpos<H>(k)], Wd[k * n_classes + j], acc);
+                        z[j] = acc;
+                    }
+                }
+                float mx = z[0];
+#pragma unroll
+                for (int j = 1; j < PXG_MAX_CLASSES; j++) mx = (j < n_classes && z[j] > mx) ? z[j] : mx;
+                float sden = 0.0f;
+#pragma unroll
+                for (int j = 0; j < PXG_MAX_CLASSES; j++) {
+                    e[j] = j < n_classes ? pxg_expf(z[j] - mx) : 0.0f;
+                    if (j < n_classes) sden = (j == 0) ? e[0] : sden + e[j];
+                }
+#pragma unroll
+                for (int j = 0; j < PXG_MAX_CLASSES; j++)
+                    probs[(size_t)rd * PXG_MAX_CLASSES + j] = j < n_classes ? e[j] / sden : 0.0f;
+            }
+        } else {
+            const int rb = t1 & 1;
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                if (m < ntile) {
+                    float* st_out = state + ((size_t)(blk & 1) * n_tiles + tile0 + m) * DQB_STATE;
+                    for (int i = tid; i < 16 * HS; i += LSTM_THREADS) st_out[i] = h3[(rb * MT + m) * 16 * HS + i];
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++) st_out[16 * HS + nt * LSTM_THREADS + tid] = c3[m][nt];
+                }
+            }
+            dq_publish(done, grp, blk, tid);
+        }
+    }
+}
+
+// ===========================================================================
 // launchers
 // ===========================================================================
 struct LstmGrid { int blocks, mtw; };
@@ -943,6 +1401,54 @@ int pxg_launch_demux_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
     if (n_rows <= 0) return PXG_OK;
     const int T = ctx->cfg.signal_trim_length;
     const LstmGrid g = pick_grid(ctx, n_rows);
+    const int64_t tiles = (n_rows + 15) / 16, slots = 2 * (int64_t)ctx->n_cu;
+    if (tiles > slots && !getenv("PXG_NO_TIMESLICE") && !getenv("PXG_NO_DEMUX_TIMESLICE")) {
+        // more tiles than resident workgroups: time-sliced kernels (k_demux_bidir_q / k_demux_top_q)
+        const size_t state_floats = (size_t)2 * tiles * (DQA_STATE > DQB_STATE ? DQA_STATE : DQB_STATE);
+        int rc;
+        if ((rc = pxg_timeslice_prepare(ctx)) || (rc = pxg_reserve(ctx, ctx->demux_q, (size_t)2 * (2 + tiles))) ||
+            (rc = pxg_reserve(ctx, ctx->demux_state, state_floats)))
+            return rc;
+        PXG_HIP(ctx, hipMemsetAsync(ctx->demux_q.p, 0, (size_t)2 * (2 + tiles) * sizeof(int), ctx->stream));
+        int* qa = ctx->demux_q.p;
+        int* qb = ctx->demux_q.p + 2 + tiles;
+        const PxgLstmDev &f = ctx->demux_fwd, &b = ctx->demux_bwd, &t3 = ctx->demux_top;
+#define CALL_A(MT)                                                                                         \
+    {                                                                                                      \
+        const size_t lds = kTabBytes + sizeof(float) * (4 * MT * 16 * HSTRIDE(48) + 2 * 16 * MT * XS) +    \
+                           sizeof(int) * (16 * MT + 16);                                                   \
+        PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_demux_bidir_q<MT>,                                 \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+        hipLaunchKernelGGL(k_demux_bidir_q<MT>, dim3((unsigned)slots), dim3(LSTM_THREADS), lds,            \
+                           ctx->stream, (int)n_rows, idx, count, T, win, ctx->d_sigtab, f.kernel,          \
+                           f.recurrent, f.bias, b.kernel, b.recurrent, b.bias, bidir, qa, ctx->lstm_err.p, \
+                           qa + 2, ctx->demux_state.p);                                                    \
+    }
+#define CALL_B(MT)                                                                                         \
+    {                                                                                                      \
+        const size_t lds = kTabBytes + sizeof(float) * (2 * MT * 16 * HSTRIDE(64) +                        \
+                                                        2 * MT * 16 * HSTRIDE(96) + 256) +                 \
+                           sizeof(int) * (16 * MT + 16);                                                   \
+        PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_demux_top_q<MT>,                                   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+        hipLaunchKernelGGL(k_demux_top_q<MT>, dim3((unsigned)slots), dim3(LSTM_THREADS), lds, ctx->stream, \
+                           (int)n_rows, idx, count, T, bidir, ctx->d_sigtab, t3.kernel, t3.recurrent,      \
+                           t3.bias, ctx->demux_dense.kernel, ctx->demux_dense.bias,                        \
+                           ctx->demux_dense.out_dim, probs, qb, ctx->lstm_err.p, qb + 2,                   \
+                           ctx->demux_state.p);                                                            \
+    }
+        pxg_timer_begin(ctx, timer_a);
+        CALL_A(1)
+        pxg_timer_end(ctx, timer_a);
+        pxg_timer_begin(ctx, timer_b);
+        CALL_B(1)
+        pxg_timer_end(ctx, timer_b);
+#undef CALL_A
+#undef CALL_B
+        ctx->timeslice_used = true;
+        PXG_HIP(ctx, hipGetLastError());
+        return PXG_OK;
+    }
     {
         const PxgLstmDev &f = ctx->demux_fwd, &b = ctx->demux_bwd;
         pxg_timer_begin(ctx, timer_a);

@@ -264,6 +264,7 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     release(ctx->segs); release(ctx->idx_scaler); release(ctx->idx_demux);
     release(ctx->counters); release(ctx->win); release(ctx->bidir); release(ctx->probs);
     release(ctx->lstm_q); release(ctx->lstm_state); release(ctx->lstm_err);
+    release(ctx->demux_q); release(ctx->demux_state);
     release(ctx->spare.raw); release(ctx->spare.offsets); release(ctx->spare.calib); release(ctx->spare.inject);
     release(ctx->results); release(ctx->polya_ev); release(ctx->polya_out); release(ctx->spikes);
     release(ctx->ev_first); release(ctx->ev_off); release(ctx->ev_mean); release(ctx->ev_scaled);

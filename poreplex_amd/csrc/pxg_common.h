@@ -237,6 +237,8 @@ struct pxg_ctx {
     DevBuf<int> lstm_q;          // time-sliced LSTM: [0] task counter, [2+] per-tile progress
     DevBuf<int> lstm_err;        // time-sliced LSTM: sticky error flag
     DevBuf<float> lstm_state;    // time-sliced LSTM: tile states in flight between step blocks
+    DevBuf<int> demux_q;         // time-sliced demux kernels: two queues (bidir, top)
+    DevBuf<float> demux_state;   // time-sliced demux kernels: two alternating state slots per tile
     bool timeslice_used = false;
     DevBuf<pxg_read_result> results;
     DevBuf<char> polya_ev;       // event scratch, [wave][event][lane]

@@ -164,6 +164,29 @@ def test_demux_lstm_bit_exact(ctx, oracle, stages, n):
     assert np.array_equal(got.argmax(1), want.argmax(1))
 
 
+@pytest.mark.parametrize('n', [8200, 9898, 13000, 20001])
+def test_demux_lstm_time_sliced_equals_static(ctx, oracle, stages, n):
+    """With more read tiles than resident workgroups K5a / K5b run time-sliced
+    (k_demux_bidir_q / k_demux_top_q: tile states handed over through HBM between step
+    blocks whose number is chosen on the device): same bits as the static kernels and as
+    the oracle."""
+    wins = stages['demux_in']
+    rng = np.random.default_rng(n)
+    rows = np.stack([wins[i % len(wins)] for i in range(n)])
+    rows = rows + rng.normal(0, 0.05, (n, 1)).astype(np.float32)     # every window differs
+    rows[::7] = np.roll(rows[::7], 5, axis=1)
+    got = ctx.demux_lstm(rows)
+    os.environ['PXG_NO_DEMUX_TIMESLICE'] = '1'
+    try:
+        static = ctx.demux_lstm(rows)
+    finally:
+        del os.environ['PXG_NO_DEMUX_TIMESLICE']
+    assert np.array_equal(got, static)
+    pick = rng.choice(n, 24, replace=False)
+    want = np.stack([oracle.demux_forward(rows[i]) for i in pick])
+    assert np.array_equal(got[pick], want)
+
+
 # ---- a14-a17: events + poly(A) ----------------------------------------------------
 def test_detect_events_vs_reference_extension(ctx, oracle, unit):
     # src/csupport.c:70-124 outputs captured from the real CPython extension
