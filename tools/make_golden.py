@@ -57,6 +57,16 @@ def _attr_get_bytes(self, name):
 h5py.AttributeManager.__getitem__ = _attr_get_bytes
 
 OUT = os.path.join(REPO, 'tests', 'golden')
+# `make_golden.py --only batch0` rewrites just the fixtures whose name starts with that prefix.
+# Every fixture is an (inputs, outputs-of-the-real-reference) pair that carries its own inputs,
+# so sets made by different revisions of the synthetic generator can coexist: unit / polya /
+# chimera date from before the generator planted barcode prototypes, batch0 was redone after
+# (32 reads, six of them at the bench's ~60 000-sample shape).
+ONLY = sys.argv[sys.argv.index('--only') + 1] if '--only' in sys.argv else ''
+if ONLY:
+    _scratch = os.path.join(__import__('tempfile').mkdtemp(prefix='pxg_golden_'), 'all')
+    os.makedirs(_scratch)
+    _FINAL, OUT = OUT, _scratch
 os.makedirs(OUT, exist_ok=True)
 TMP = tempfile.mkdtemp(prefix='pxgold')
 
@@ -324,6 +334,10 @@ def build_read_set(rng):
         raw = np.clip(base['raw'].astype(np.float64) * mul + add_, -32768, 32767).astype(np.int16)
         reads.append({'tag': 'misscaled%d' % k, 'raw': raw, 'cal': base['cal'], 'ss': base['ss'],
                       'barcode': base['barcode'], 'basecall': None, 'seq_len': None})
+    # configs[0] is "32 reads": six more reads at the bench's own shape (~60 000 samples)
+    b = synth_batch(6, seed=9230, samples_per_read=61000, jitter=0.05)
+    for i in range(6):
+        add(b, i, 'bench60k_%d' % i, basecall='auto' if i != 4 else None)
     return reads
 
 
@@ -348,16 +362,18 @@ def main():
     os.makedirs(inputdir)
     reads = build_read_set(rng)
     items = []
-    for i, r in enumerate(reads):
+    rng_extra = np.random.default_rng(9230)     # reads added later draw from their own stream, so
+    for i, r in enumerate(reads):               # every other fixture stays bit-identical
         rid = '%08x-0000-4000-8000-%012x' % (0x9220 + i, i)
         fn = 'r%03d.fast5' % i
-        meta = {'read_number': 100 + i, 'start_time': int(rng.integers(10**5, 10**8)),
-                'channel_number': int(rng.integers(1, 513)), 'run_id': 'run' + 'ab' * 19,
+        g = rng_extra if r['tag'].startswith('bench60k') else rng
+        meta = {'read_number': 100 + i, 'start_time': int(g.integers(10**5, 10**8)),
+                'channel_number': int(g.integers(1, 513)), 'run_id': 'run' + 'ab' * 19,
                 'sample_id': 'synthetic'}
         bc = None
         if r['basecall'] == 'auto' and len(r['raw']) > 12000:
-            first = int(rng.integers(0, 40))
-            bc = make_basecall(rng, len(r['raw']), first, r['seq_len'])
+            first = int(g.integers(0, 40))
+            bc = make_basecall(g, len(r['raw']), first, r['seq_len'])
         write_fast5(os.path.join(inputdir, fn), rid, r['raw'], r['cal'], meta, bc)
         items.append({**r, 'filename': fn, 'read_id': rid, 'meta': meta, 'basecall': bc})
     # a corrupt file and a vanished file
@@ -746,3 +762,9 @@ def main():
 
 if __name__ == '__main__':
     main()
+    if ONLY:
+        import shutil
+        for name in sorted(os.listdir(OUT)):
+            if name.startswith(ONLY):
+                shutil.copy(os.path.join(OUT, name), os.path.join(_FINAL, name))
+                print('kept', name)
