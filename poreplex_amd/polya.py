@@ -4,6 +4,8 @@ Event detection (a15), the interval DP (a16) and the retry/recalibration logic
 (a14, a17) are GPU stages; this class converts the per-read record into the
 dict the reference stores with ``npread.set_polya_tail`` (polya.py:116-121).
 """
+import numpy as np
+
 __all__ = ['PolyASignalAnalyzer']
 
 
@@ -15,6 +17,27 @@ class PolyASignalAnalyzer:
         centre, spread = config['polya_mean_dist']
         halfwidth = spread * config['polya_mean_z_cutoff']
         self.polya_mean_cutoff = (centre - halfwidth, centre + halfwidth)
+
+    def assign(self, table, rows, records):
+        """set_polya_tail for many reads at once: the dicts of polya.py:116-121 from the GPU
+        records.  Returns the rows whose tail cannot be reported faithfully (more spike events
+        than the GPU keeps): the caller runs those through __call__, which raises per read."""
+        called = np.nonzero(records['polya_called'])[0]
+        n_spikes = records['polya_n_spikes'][called].astype(np.int64)
+        cap = table.spikes.shape[1] if table.spikes is not None else 0
+        begin, end = records['polya_begin'][called].tolist(), records['polya_end'][called].tolist()
+        dwell = (records['polya_dwell_samples'][called] / table.sampling_rate[rows[called]]).tolist()
+        odd = []
+        for k, i, ns, b, e, dw in zip(called.tolist(), rows[called].tolist(), n_spikes.tolist(),
+                                      begin, end, dwell):
+            if ns > cap and table.spikes is not None:
+                odd.append(k)
+                continue
+            spikes = []
+            if ns and table.spikes is not None:
+                spikes = [tuple(r) for r in table.spikes[table.gpu_row[i], :ns].astype(float).tolist()]
+            table.polya[i] = {'begin': b, 'end': e, 'dwell_time': dw, 'spikes': spikes}
+        return odd
 
     def __call__(self, npread, rough_range=None, stride=None):
         rec = npread.native

@@ -181,7 +181,7 @@ class SignalAnalyzer(AbstractContextManager):
             self.demuxer.assign(t, rows, rec)
         broken = np.zeros(len(rows), dtype=bool)
         if cfg['measure_polya']:
-            for k in np.nonzero(rec['polya_called'])[0].tolist():
+            for k in self.polyaanalyzer.assign(t, rows, rec):      # bulk; the odd ones per read
                 broken[k] = not self._guarded(t, rows[k], self.polyaanalyzer, NanoporeRead(t, rows[k]))
         settled = self.bulk_base_space(t, rows, ~broken)
         for k in np.nonzero(~broken & ~settled)[0].tolist():

@@ -495,9 +495,21 @@ class SignalLoader:
         t = table
         n = len(rows)
         frame = np.zeros((n, 3), dtype=np.int64)        # first sample, blocks, block stride
-        for k, i in enumerate(rows):
+        n_raw = np.diff(offsets)
+        per_read = np.ones(n, dtype=bool)
+        if t.bundle is not None:                        # bundle rows: the frame from the columns
+            d, bi = t.bundle.d, t.bundle_index[rows]
+            b = np.where(bi >= 0, bi, 0)
+            first, stride, moves = d['bc_first_sample'][b], d['bc_block_stride'][b].astype(np.int64), d['bc_n_moves'][b]
+            covered = np.maximum(np.minimum(first + stride * moves, n_raw) - first, 0)
+            kind = d['bc_table'][b]
+            fits = (bi >= 0) & d['bc_present'][b] & ((kind == 1) | (kind == 2)) & (moves >= 0) & \
+                (stride > 0) & (-(-covered // np.maximum(stride, 1)) == moves)
+            frame[fits] = np.stack([first, moves, stride], axis=1)[fits]
+            per_read = bi < 0                           # everything else in a bundle has no usable frame
+        for k in np.nonzero(per_read)[0].tolist():
             try:
-                frame[k] = NanoporeRead(t, i).guppy_event_geometry(offsets[k + 1] - offsets[k])
+                frame[k] = NanoporeRead(t, rows[k]).guppy_event_geometry(n_raw[k])
             except Exception:
                 pass
         for stride in np.unique(frame[frame[:, 1] > 0, 2]).tolist():
