@@ -39,12 +39,15 @@ __device__ __forceinline__ double hmm_emission(const PxgHmmDev& H, int s, double
         for (int k = 1; k < H.n_mix[s]; k++) {
             const double d = x - H.mu[s][k];
             const double l = (H.lssp[s][k] - (d * d) * H.tss[s][k]) + H.logw[s][k];
+            // pair_lse(a, b) without lane-divergent branches: the items of a wave disagree on
+            // a > b, and the if / else form ran exp + log TWICE per item (both sides under exec
+            // masks).  m + log(exp(lo - m) + 1) is the same expression on either side; the
+            // infinities are selects (one -inf: exp(-inf) = 0, log(1) = 0, m + 0 = m exactly).
             const double a = lp, b = l;
-            if (a == __builtin_inf() || b == __builtin_inf()) lp = __builtin_inf();
-            else if (a == -__builtin_inf()) lp = b;
-            else if (b == -__builtin_inf()) lp = a;
-            else if (a > b) lp = a + log(exp(b - a) + 1.0);
-            else lp = b + log(exp(a - b) + 1.0);
+            const bool agb = a > b;
+            const double m = agb ? a : b, lo = agb ? b : a;
+            const double r = m + log(exp(lo - m) + 1.0);
+            lp = (m == -__builtin_inf()) ? m : ((m == __builtin_inf()) ? m : r);
         }
     }
     return lp;
