@@ -108,7 +108,7 @@ class GpuSession:
                 staging = slots.get()                 # a staging arena nobody is copying from
                 t0 = time.perf_counter()
                 batch = self.analyzer.prepare(reads, ReadTable())
-                need = sum(len(batch.table.raw[i]) for i in batch.entered)
+                need = int(batch.table.n_raw[np.asarray(batch.entered, dtype=np.int64)].sum()) if batch.entered else 0
                 rows, arena, offsets, calib = self.loader.pack(batch.table, staging, need)
                 self.timing['load_s'] += time.perf_counter() - t0
                 out.put((batch, staging, rows, arena, offsets, calib))
@@ -167,32 +167,39 @@ class GpuSession:
                 raise item
             return item
 
+        def stage(item):
+            """Start the H2D copy of a packed batch into the spare input slot (copy stream)."""
+            if item is not None and len(item[2]):
+                item[1].settle()
+                self.ctx.stage(item[3], item[4], item[5])
+                return True
+            return False
+
+        # pipeline: [k computes] [k+1 is copied under it] [k-1 is judged and written on the host].
+        # The copy of k+1 is enqueued the moment the spare slot is free -- right after k became
+        # resident -- so it runs under BOTH the kernels of k and the host work of k-1.
         current = take()
+        nxt, nxt_staged = None, False
         if current is not None:
-            batch, staging, rows, arena, offsets, calib = current
-            if len(rows):
-                staging.settle()
-                self.ctx.stage(arena, offsets, calib)
+            if stage(current):
                 self.ctx.swap()
                 self.ctx.run(self.loader.stage_mask)      # asynchronous: kernels are enqueued
-            slots.put(staging)
+            slots.put(current[1])
+            nxt = take()
+            nxt_staged = stage(nxt)
         done = 0
         while current is not None:
             batch, staging, rows, arena, offsets, calib = current
-            # ---- GPU side: batch k computes; k+1 is copied under it, then launched ----------
             t0 = time.perf_counter()
-            nxt = take()                                  # packed by the loader thread meanwhile
-            staged = False
-            if nxt is not None and len(nxt[2]):
-                nxt[1].settle()
-                self.ctx.stage(nxt[3], nxt[4], nxt[5])    # H2D on the copy stream, under the kernels
-                staged = True
             self._attach(batch.table, rows, offsets)      # D2H of the records: waits for run k
-            if staged:
-                self.ctx.swap()                           # k+1 resident ...
-                self.ctx.run(self.loader.stage_mask)      # ... and computing while k is written out
+            after = None
             if nxt is not None:
+                if nxt_staged:
+                    self.ctx.swap()                       # k+1 resident (waits for its copy) ...
+                    self.ctx.run(self.loader.stage_mask)  # ... and computing while k is written out
                 slots.put(nxt[1])
+                after = take()                            # k+2, packed by the loader thread meanwhile
+                after_staged = stage(after)               # its copy starts now, under run k+1
             self.timing['gpu_wait_s'] += time.perf_counter() - t0
 
             # ---- host side of batch k, under the kernels of k+1 ------------------------------
@@ -224,6 +231,8 @@ class GpuSession:
             self.timing['sink_s'] += time.perf_counter() - t0
             self._check_early_stop(status_seen)
             current = nxt
+            if nxt is not None:
+                nxt, nxt_staged = after, (after_staged if after is not None else False)
         thread.join()
         for s in stagings:
             s.release()

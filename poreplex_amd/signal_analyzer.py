@@ -85,6 +85,15 @@ class _Batch:
         self.early.append(outcome)
         self.early_at.append(position)
 
+    def sort_by_position(self):
+        """Both lists in input order (the bulk and the per-read admissions were appended apart)."""
+        for name in ('early', 'entered'):
+            at = getattr(self, name + '_at')
+            if any(a > b for a, b in zip(at, at[1:])):
+                order = sorted(range(len(at)), key=at.__getitem__)
+                setattr(self, name, [getattr(self, name)[k] for k in order])
+                setattr(self, name + '_at', [at[k] for k in order])
+
 
 class SignalAnalyzer(AbstractContextManager):
     """Context manager; `with SignalAnalyzer(config, batchid) as analyzer` yields itself."""
@@ -117,16 +126,11 @@ class SignalAnalyzer(AbstractContextManager):
         table = loader.table if table is None else table
         batch = _Batch(table)
         reads = [tuple(r) for r in reads]
-        bulk = loader.prepare_many(reads, table)       # bundle reads: one column append
-        for position, (f5file, read_id) in enumerate(reads):
-            if bulk[position] is not None:
-                row = bulk[position]
-                if table.stopped[row]:
-                    batch.settle(position, row)
-                else:
-                    batch.entered.append(row)
-                    batch.entered_at.append(position)
-                continue
+        where = loader.prepare_many(reads, table)      # bundle reads: one column append
+        bulk = np.nonzero(where >= 0)[0]
+        stopped = table.stopped[where[bulk]]
+        for position in np.nonzero(where < 0)[0].tolist():     # everything else, read by read
+            f5file, read_id = reads[position]
             if not loader.exists(f5file):
                 batch.settle(position, {'filename': f5file, 'status': 'disappeared'})
                 continue
@@ -140,6 +144,11 @@ class SignalAnalyzer(AbstractContextManager):
             else:
                 batch.entered.append(row)
                 batch.entered_at.append(position)
+        batch.early += where[bulk[stopped]].tolist()
+        batch.early_at += bulk[stopped].tolist()
+        batch.entered += where[bulk[~stopped]].tolist()
+        batch.entered_at += bulk[~stopped].tolist()
+        batch.sort_by_position()
         return batch
 
     def settle(self, batch):
@@ -223,9 +232,7 @@ class SignalAnalyzer(AbstractContextManager):
             d['bc_mean_qscore'][okb].astype(np.float32)
         t.num_events[ok], t.has_summary[ok] = d['bc_num_events'][okb], True
         so = d['seq_offsets']
-        text_s, text_q = t.bundle.sequence_text()
-        for i, a, z in zip(ok.tolist(), so[okb].tolist(), so[okb + 1].tolist()):
-            t.sequence[i] = (text_s[a:z].decode('ascii'), text_q[a:z].decode('ascii'), 0)
+        t.seq_lazy[ok] = True             # the (sequence, qstring, 0) tuples are made on demand
         short = (so[okb + 1] - so[okb]) < cfg['minimum_sequence_length']      # trimming is a no-op
         t.halt(ok[short], 'sequence_too_short', 'fail')
         settled[pick[regular]] = True
@@ -255,7 +262,7 @@ class SignalAnalyzer(AbstractContextManager):
             analysis.trim_adapter(events, segments, stride)
         if cfg['filter_unsplit_reads'] and analysis.detect_unsplit_read(events, segments, stride):
             raise SignalAnalysisError('unsplit_read')
-        seq = t.sequence[row]
+        seq = t.sequence_of(row)
         if seq is not None and len(seq[0]) - seq[2] < cfg['minimum_sequence_length']:
             raise SignalAnalysisError('sequence_too_short')
 

@@ -15,6 +15,7 @@ network + QC, pooling, segmentation, barcode classifier, optional poly(A) and
 the chimera window scan all run behind one upload.
 """
 import os
+from operator import itemgetter
 
 import numpy as np
 
@@ -49,7 +50,8 @@ class ReadTable:
                ('has_barcode', np.bool_), ('has_scaling', np.bool_), ('has_summary', np.bool_),
                ('start_time', np.int64), ('duration', np.int64), ('sampling_rate', np.float64),
                ('num_events', np.int64), ('sequence_length', np.int64),
-               ('mean_qscore', np.float64), ('n_raw', np.int64),
+               ('mean_qscore', np.float64), ('n_raw', np.int64), ('pending', np.bool_),
+               ('seq_lazy', np.bool_),
                ('unsplit_count', np.int32))
 
     def __init__(self):
@@ -120,11 +122,25 @@ class ReadTable:
         self.channel += d['channel_number'][idx].tolist()
         self.run_id += d['run_id'][idx].tolist()
         self.sample_id += d['sample_id'][idx].tolist()
-        arena = d['arena']
-        self.raw += [arena[a:b] for a, b in zip(o[idx].tolist(), o[idx + 1].tolist())]
-        for col in (self.source, self.sequence, self.error_message, self.polya, self.unsplit):
+        self.pending[rows] = True            # samples wait in the bundle arena (raw stays None)
+        for col in (self.raw, self.source, self.sequence, self.error_message, self.polya, self.unsplit):
             col.extend([None] * k)
         return rows
+
+    def samples_of(self, i):
+        """int16 samples of a read that has not been packed yet."""
+        if self.raw[i] is not None:
+            return self.raw[i]
+        o, b = self.bundle.d['offsets'], int(self.bundle_index[i])
+        return self.bundle.d['arena'][o[b]:o[b + 1]]
+
+    def sequence_of(self, i):
+        """(sequence, quality string, adapter trim length) or None; bundle rows settled by the
+        bulk rules keep theirs in the bundle until somebody asks (FASTQ output, result dicts)."""
+        if self.sequence[i] is None and self.seq_lazy[i]:
+            seq, qual = self.bundle.sequence_of(int(self.bundle_index[i]))
+            self.sequence[i] = (seq, qual, 0)
+        return self.sequence[i]
 
     def source_of(self, i):
         """The read's file object; bundle rows get theirs on first use."""
@@ -150,6 +166,7 @@ class ReadTable:
         return None if g < 0 or self.records is None else self.records[g]
 
     def release(self, rows):
+        self.pending[np.asarray(rows, dtype=np.int64)] = False
         for i in rows:
             self.raw[i] = None
             src = self.source[i]
@@ -183,7 +200,7 @@ class ReadTable:
                    'sample_id': self.sample_id[i], 'duration': duration[k],
                    'num_events': n_events[k], 'sequence_length': seq_len[k],
                    'mean_qscore': qscore[k]}
-            if self.sequence[i] is not None:
+            if self.sequence_of(i) is not None:
                 rep['sequence'] = self.sequence[i]
             if self.error_message[i]:
                 rep['error_message'] = self.error_message[i]
@@ -204,11 +221,15 @@ def summary_columns(table, rows, barcoding, polya):
     building the dicts.  Only labelled rows are written by the writer: the caller filters."""
     idx = np.asarray(rows, dtype=np.int64)
     rows = idx.tolist()
+
+    def pick(column):                      # column[i] for i in rows, at C speed
+        if not rows:
+            return []
+        got = itemgetter(*rows)(column)
+        return list(got) if len(rows) > 1 else [got]
     cols = {
-        'filename': [table.filename[i] for i in rows],
-        'read_id': [table.read_id[i] for i in rows],
-        'run_id': [table.run_id[i] for i in rows],
-        'channel': [table.channel[i] for i in rows],
+        'filename': pick(table.filename), 'read_id': pick(table.read_id),
+        'run_id': pick(table.run_id), 'channel': pick(table.channel),
         'start_time': [round(a / b, 3) for a, b in zip(table.start_time[idx].tolist(),
                                                        table.sampling_rate[idx].tolist())],
         'duration': table.duration[idx].tolist(),
@@ -216,7 +237,7 @@ def summary_columns(table, rows, barcoding, polya):
         'sequence_length': table.sequence_length[idx].tolist(),
         'mean_qscore': [q if got else 0 for q, got in zip(table.mean_qscore[idx].tolist(),
                                                           table.has_summary[idx].tolist())],
-        'sample_id': [table.sample_id[i] for i in rows],
+        'sample_id': pick(table.sample_id),
         'status': [native.STATUS_NAMES[c] for c in table.status[idx].tolist()],
         'label': [LABELS[c] for c in table.label[idx].tolist()],
     }
@@ -225,7 +246,7 @@ def summary_columns(table, rows, barcoding, polya):
         cols['barcode'] = [b if c else None for b, c in zip(table.barcode[idx].tolist(), called.tolist())]
         cols['barcode_score'] = np.where(called, table.barcode_phred[idx], 0).tolist()
     if polya:
-        cols['polya'] = [table.polya[i] for i in rows]
+        cols['polya'] = pick(table.polya)
     return cols
 
 
@@ -245,7 +266,7 @@ class NanoporeRead:
     status = property(lambda self: native.STATUS_NAMES[self.table.status[self.row]])
     stopped = property(lambda self: bool(self.table.stopped[self.row]))
     error_message = property(lambda self: self.table.error_message[self.row])
-    sequence = property(lambda self: self.table.sequence[self.row])
+    sequence = property(lambda self: self.table.sequence_of(self.row))
     polya = property(lambda self: self.table.polya[self.row])
     num_events = property(lambda self: int(self.table.num_events[self.row]))
     sequence_length = property(lambda self: int(self.table.sequence_length[self.row]))
@@ -297,7 +318,7 @@ class NanoporeRead:
         t.barcode_guess[i], t.barcode_phred[i] = guess, quality
 
     def set_adapter_trimming_length(self, newlength):
-        seq = self.table.sequence[self.row]
+        seq = self.table.sequence_of(self.row)
         if seq is None:
             raise Exception('Sequence is not set.')
         self.table.sequence[self.row] = (seq[0], seq[1], newlength)
@@ -405,28 +426,31 @@ class SignalLoader:
         if usable - usable % cfg['stride'] < cfg['min_length']:
             t.halt(row, 'scaler_signal_too_short')
         else:
-            t.raw[row] = raw
+            t.raw[row], t.pending[row] = raw, True
         return NanoporeRead(t, row)
 
     def prepare_many(self, reads, table):
         """Bulk form of prepare_loading for reads that live in the read bundle: one column
-        append for all of them.  Returns one entry per input read: its row, or None when the
-        read needs the per-read path (not in the bundle, or its file is marked corrupt)."""
+        append for all of them.  Returns an int array with one entry per input read: its row,
+        or -1 when the read needs the per-read path (not in the bundle, or its file is marked
+        corrupt)."""
         b = self.bundle
+        where = np.full(len(reads), -1, dtype=np.int64)
         if b is None:
-            return [None] * len(reads)
+            return where
         index, broken = b.index, b.broken
-        where = [index.get(key, -1) if key[0] not in broken else -1 for key in reads]
-        idx = np.array([i for i in where if i >= 0], dtype=np.int64)
-        rows = table.extend_from_bundle(b, idx)
+        where[:] = [index.get(key, -1) for key in reads]
+        if broken:
+            where[[key[0] in broken for key in reads]] = -1
+        found = where >= 0
+        rows = table.extend_from_bundle(b, where[found])
         cfg = self.scaler_cfg      # length gate of load_padded_signal_head (:212-222)
         usable = np.minimum(np.minimum(cfg['length'], table.duration[rows]), table.n_raw[rows])
         short = rows[usable - usable % cfg['stride'] < cfg['min_length']]
         table.halt(short, 'scaler_signal_too_short')
-        for i in short.tolist():
-            table.raw[i] = None
-        it = iter(rows.tolist())
-        return [next(it) if i >= 0 else None for i in where]
+        table.pending[short] = False
+        where[found] = rows
+        return where
 
     # ---- the GPU pass, in the three steps the session driver overlaps ------------------
     def pack(self, table=None, arena=None, need=None):
@@ -435,18 +459,16 @@ class SignalLoader:
         samples are packed in place."""
         t = self.table if table is None else table
         rows = t.live_rows()
-        rows = rows[[t.raw[i] is not None for i in rows]] if len(rows) else rows
-        lens = np.array([len(t.raw[i]) for i in rows], dtype=np.int64)
+        rows = rows[t.pending[rows]]
         offsets = np.zeros(len(rows) + 1, dtype=np.int64)
-        np.cumsum(lens, out=offsets[1:])
+        np.cumsum(t.n_raw[rows], out=offsets[1:])
         # a run of consecutive bundle reads is already packed: hand out the bundle's own
         # arena (page-locked once by the session) instead of copying 120 KB per read
         bi = t.bundle_index[rows] if len(rows) else np.zeros(0, dtype=np.int64)
         if len(rows) and t.bundle is not None and bi[0] >= 0 and \
                 np.array_equal(bi, bi[0] + np.arange(len(rows))):
             o = t.bundle.d['offsets']
-            for i in rows:
-                t.raw[i] = None
+            t.pending[rows] = False
             return rows, t.bundle.d['arena'][o[bi[0]]:o[bi[-1] + 1]], offsets, \
                 np.ascontiguousarray(t.calib[rows])
         if hasattr(arena, 'reserve'):
@@ -455,9 +477,10 @@ class SignalLoader:
             arena = np.empty(int(offsets[-1]), dtype=np.int16)
         elif len(arena) < offsets[-1]:
             raise ValueError('staging arena too small: {} < {}'.format(len(arena), offsets[-1]))
-        for k, i in enumerate(rows):
-            arena[offsets[k]:offsets[k + 1]] = t.raw[i]
+        for k, i in enumerate(rows.tolist()):
+            arena[offsets[k]:offsets[k + 1]] = t.samples_of(i)
             t.raw[i] = None
+        t.pending[rows] = False
         return rows, arena[:offsets[-1]], offsets, np.ascontiguousarray(t.calib[rows])
 
     def run_resident(self, table, rows, offsets):

@@ -132,7 +132,8 @@ class SequencingSummaryWriter:
         if self.polya_enabled:
             out['polya_dwell'] = [format(p['dwell_time'], '.4f') if p is not None else ''
                                   for p in cols['polya']]
-        fields = [list(map(str, out[f])) for f in self.output_fields]
+        fields = [col if (n and type(col[0]) is str and f not in ('barcode_score',)) else list(map(str, col))
+                  for f, col in ((f, out[f]) for f in self.output_fields)]
         text = ''.join('\t'.join(row) + '\n' for row in zip(*fields)) if n else ''
         with self.lock:
             self.file.write(text)
