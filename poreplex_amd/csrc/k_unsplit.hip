@@ -115,7 +115,7 @@ struct UnsplitParams {
     int pool_stride;       // rough_signal_stride (payload start units)
 };
 
-__device__ __forceinline__ double un_emission(const PxgHmmDev& H, int s, double x)
+__device__ __forceinline__ double un_emission(const PxgHmmDev& H, const double* lsetab, int s, double x)
 {
     double lp;
     {
@@ -134,7 +134,7 @@ __device__ __forceinline__ double un_emission(const PxgHmmDev& H, int s, double 
             const double a = lp, b = l;
             const bool agb = a > b;
             const double m = agb ? a : b, lo = agb ? b : a;
-            const double r = m + log(exp(lo - m) + 1.0);
+            const double r = m + pxg_log1pexp(lsetab, lo - m);
             lp = (m == -__builtin_inf()) ? m : ((m == __builtin_inf()) ? m : r);
         }
     }
@@ -264,9 +264,13 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
     const int64_t* __restrict__ first_sample, const int64_t* __restrict__ ev_off,
     const int64_t* __restrict__ unit_off, const float* __restrict__ scaled,
     unsigned* __restrict__ bpbuf /* [wave][tmax][8 groups] */,
-    int64_t* __restrict__ cand /* n_units x UN_WCAND x 2 */, int32_t* __restrict__ cand_cnt)
+    int64_t* __restrict__ cand /* n_units x UN_WCAND x 2 */, int32_t* __restrict__ cand_cnt,
+    const double* __restrict__ lsetab_g)
 {
     __shared__ double em[UN_READS * UN_EM_STRIDE];
+    __shared__ double lsetab[PXG_LSE_TAB_DOUBLES];
+    for (int i = threadIdx.x; i < PXG_LSE_TAB_DOUBLES; i += blockDim.x) lsetab[i] = lsetab_g[i];
+    __syncthreads();
     const int lane = threadIdx.x;
     const int rr = lane >> 3, s = lane & 7;
     const int S = H.n_states;
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
                     const double xd = (double)x[k0 + t];
 #pragma unroll
                     for (int q = 0; q < PXG_MAX_STATES; q++)
-                        if (q < S) em[rr * UN_EM_STRIDE + tt * PXG_MAX_STATES + q] = un_emission(H, q, xd);
+                        if (q < S) em[rr * UN_EM_STRIDE + tt * PXG_MAX_STATES + q] = un_emission(H, lsetab, q, xd);
                 }
             }
             __syncthreads();
@@ -516,7 +520,7 @@ int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t units_bound, int tm
 #define SCAN(NIN)                                                                                      \
     hipLaunchKernelGGL(k_unsplit_scan<NIN>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, n,        \
                        tmax, ctx->hmm[1], P, cal, status, segs, first_sample, ev_off, unit_off,        \
-                       scaled, bp, cand, cand_cnt)
+                       scaled, bp, cand, cand_cnt, ctx->d_lsetab)
     const int nin = ctx->hmm[1].max_in;
     if (nin <= 2) SCAN(2);
     else if (nin <= 3) SCAN(3);

@@ -26,7 +26,7 @@
 #define VIT_CHUNK 16
 #define VIT_THREADS (64 * (1 + 2 * VIT_CHAINS))   // wave 0: recurrence; the others: emissions of the next chunk
 
-__device__ __forceinline__ double hmm_emission(const PxgHmmDev& H, int s, double x)
+__device__ __forceinline__ double hmm_emission(const PxgHmmDev& H, const double* lsetab, int s, double x)
 {
     // pomegranate Normal: lssp - (x-mu)^2 * tss ; mixture: pair_lse fold
     double lp;
@@ -46,7 +46,7 @@ __device__ __forceinline__ double hmm_emission(const PxgHmmDev& H, int s, double
             const double a = lp, b = l;
             const bool agb = a > b;
             const double m = agb ? a : b, lo = agb ? b : a;
-            const double r = m + log(exp(lo - m) + 1.0);
+            const double r = m + pxg_log1pexp(lsetab, lo - m);
             lp = (m == -__builtin_inf()) ? m : ((m == __builtin_inf()) ? m : r);
         }
     }
@@ -109,9 +109,12 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
     int64_t n_reads, PxgHmmDev H, const int16_t* __restrict__ raw, const float* __restrict__ sig,
     const int64_t* __restrict__ off, const pxg_calib* __restrict__ cal,
     const float* __restrict__ ss, int stride, int scan_pooled, int32_t* __restrict__ status,
-    int32_t* __restrict__ segs, double* __restrict__ logp_out)
+    int32_t* __restrict__ segs, double* __restrict__ logp_out, const double* __restrict__ lsetab_g)
 {
     __shared__ double em[2][VIT_READS * EM_STRIDE];   // double buffer: producers run one chunk ahead
+    __shared__ double lsetab[PXG_LSE_TAB_DOUBLES];
+    for (int i = threadIdx.x; i < PXG_LSE_TAB_DOUBLES; i += blockDim.x) lsetab[i] = lsetab_g[i];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int rr = lane >> 3, s = lane & 7;
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
                     double* dst = &em[c & 1][prr * EM_STRIDE + ptt * PXG_MAX_STATES];
 #pragma unroll
                     for (int q = 0; q < PXG_MAX_STATES; q++)
-                        if (q < S) dst[q] = hmm_emission(H, q, xd);
+                        if (q < S) dst[q] = hmm_emission(H, lsetab, q, xd);
                 }
             }
             __syncthreads();        // chunk c is published; chunk c-1 has been consumed
@@ -373,11 +376,11 @@ int pxg_launch_segment_raw(pxg_ctx* ctx, int64_t n, const int16_t* raw, const in
     if ((H.shift_mask & ~7u) == 0 && H.n_states <= 6)      // spans {1,2}: the shipped model
         hipLaunchKernelGGL((k_viterbi_ltr<true, 0x6u, 3>), grid, dim3(VIT_THREADS), 0, ctx->stream, n, H, raw,
                            (const float*)nullptr, off, cal, ss, ctx->cfg.stride, scan,
-                           (int32_t*)status, segs, (double*)nullptr);
+                           (int32_t*)status, segs, (double*)nullptr, ctx->d_lsetab);
     else
         hipLaunchKernelGGL((k_viterbi_ltr<true, 0xFEu, 4>), grid, dim3(VIT_THREADS), 0, ctx->stream, n, H, raw,
                            (const float*)nullptr, off, cal, ss, ctx->cfg.stride, scan,
-                           (int32_t*)status, segs, (double*)nullptr);
+                           (int32_t*)status, segs, (double*)nullptr, ctx->d_lsetab);
     return PXG_OK;
 }
 
@@ -392,10 +395,10 @@ int pxg_launch_viterbi_f32(pxg_ctx* ctx, int which, int64_t n, const float* sig,
     if ((H.shift_mask & ~7u) == 0 && H.n_states <= 6)
         hipLaunchKernelGGL((k_viterbi_ltr<false, 0x6u, 3>), grid, dim3(VIT_THREADS), 0, ctx->stream, n, H,
                            (const int16_t*)nullptr, sig, off, (const pxg_calib*)nullptr,
-                           (const float*)nullptr, 1, 65534, (int32_t*)nullptr, segs, logp);
+                           (const float*)nullptr, 1, 65534, (int32_t*)nullptr, segs, logp, ctx->d_lsetab);
     else
         hipLaunchKernelGGL((k_viterbi_ltr<false, 0xFEu, 4>), grid, dim3(VIT_THREADS), 0, ctx->stream, n, H,
                            (const int16_t*)nullptr, sig, off, (const pxg_calib*)nullptr,
-                           (const float*)nullptr, 1, 65534, (int32_t*)nullptr, segs, logp);
+                           (const float*)nullptr, 1, 65534, (int32_t*)nullptr, segs, logp, ctx->d_lsetab);
     return PXG_OK;
 }

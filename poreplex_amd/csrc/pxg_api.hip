@@ -220,6 +220,16 @@ extern "C" int pxg_create(const pxg_config* cfg, pxg_ctx** out)
             build_sigmoid_table(tab);
             if ((rc = upload(ctx, &ctx->d_sigtab, tab.data(), tab.size()))) break;
         }
+        {   // tables of pxg_log1pexp (pxg_common.h), from the host's libm
+            std::vector<double> lt(PXG_LSE_TAB_DOUBLES);
+            for (int j = 0; j < 64; j++) lt[j] = exp2((double)j / 64.0);
+            for (int j = 0; j <= 128; j++) {
+                const double c = 1.0 + (double)j / 128.0;
+                lt[64 + j] = log(c);
+                lt[64 + 129 + j] = 1.0 / c;
+            }
+            if ((rc = upload(ctx, &ctx->d_lsetab, lt.data(), lt.size()))) break;
+        }
         if ((rc = pxg_lstm_upload(ctx))) break;
     } while (0);
     // host pointers in the copied config are not retained
@@ -278,6 +288,7 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     if (ctx->demux_dense.bias) (void)hipFree(ctx->demux_dense.bias);
     if (ctx->d_calibration) (void)hipFree(ctx->d_calibration);
     if (ctx->d_sigtab) (void)hipFree(ctx->d_sigtab);
+    if (ctx->d_lsetab) (void)hipFree(ctx->d_lsetab);
     if (ctx->stream) {
         for (int t = 0; t < PXG_N_TIMERS; t++) {
             (void)hipEventDestroy(ctx->ev_start[t]);

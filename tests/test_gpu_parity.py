@@ -476,6 +476,35 @@ def test_custom_left_to_right_hmm_generic_kernel(config, bundle):
         c.close()
 
 
+def test_mixture_emission_log_sum_exp_vs_libm(config):
+    """The table-driven log(exp(d) + 1) of the kernels (pxg_common.h pxg_log1pexp) against the
+    oracle's libm formula: a ONE-state HMM whose emission is a mixture makes the Viterbi
+    log-probability of a 1-step sequence exactly log(1) + emission(x).  Sweeps the whole range
+    of component gaps (identical components ... one component 40 log-units below the other),
+    two- and three-component mixtures."""
+    import copy
+    from oracle.pxo import Oracle
+    xs = np.concatenate([np.linspace(20, 180, 4001), np.random.default_rng(3).uniform(40, 140, 4000)]
+                        ).astype(np.float32)
+    for emission in ([[80.49, 7.41, 0.848], [65.30, 3.31, 0.152]],
+                     [[81.9, 7.76, 0.49], [109.73, 12.73, 0.51]],
+                     [[100.0, 2.0, 0.5], [100.0, 2.0, 0.5]],
+                     [[90.0, 6.0, 0.5], [120.0, 9.0, 0.3], [60.0, 4.0, 0.2]]):
+        cfg = copy.deepcopy(config)
+        cfg['segmentation_model'] = [{'name': 'adapter', 'emission': emission, 'start_prob': 1.0,
+                                      'transition': [['adapter', 1.0]]}]
+        orc = Oracle(cfg)
+        c = N.NativeContext(cfg, device_id=0)
+        try:
+            _, _, _, logp = c.viterbi([np.array([x], np.float32) for x in xs])
+        finally:
+            c.close()
+        want = np.array([orc.emission(0, float(x)) for x in xs])
+        err = np.abs(logp - want)
+        # one ulp of the rounded sum exp(d) + 1 (2.2e-16) plus one ulp of the result
+        assert err.max() <= 2.3e-16 + 2 * np.spacing(np.abs(want).max()), (emission, err.max())
+
+
 def test_staged_double_buffered_batches(ctx, oracle):
     """pxg_batch_stage / pxg_batch_swap: batch i+1 is copied on the copy stream while
     batch i computes; every batch gets the records of a plain upload -> run."""
