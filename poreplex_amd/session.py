@@ -191,7 +191,7 @@ class GpuSession:
         while current is not None:
             batch, staging, rows, arena, offsets, calib = current
             t0 = time.perf_counter()
-            self._attach(batch.table, rows, offsets)      # D2H of the records: waits for run k
+            self.loader.collect_resident(batch.table, rows, offsets)   # D2H of the records: waits for run k
             after = None
             if nxt is not None:
                 if nxt_staged:
@@ -262,23 +262,6 @@ class GpuSession:
         if self.dist is not None:
             self.dist.barrier()
         return out
-
-    def _attach(self, table, rows, offsets):
-        """Download + attach the records of the resident batch (loader.run_resident without
-        the launch: the kernels were enqueued before the next batch was staged)."""
-        if not len(rows):
-            return
-        rec = self.ctx.download()
-        table.records = rec
-        table.spikes = self.ctx.download_spikes() if self.loader.stage_mask & native.STAGE_POLYA else None
-        table.gpu_row[rows] = np.arange(len(rows))
-        qc_failed = rec['status'] == native.STATUS_CODE['scaling_qc_fail']
-        table.halt(rows[qc_failed], 'scaling_qc_fail')
-        good = rows[~qc_failed]
-        table.scale_shift[good, 0], table.scale_shift[good, 1] = rec['scale'][~qc_failed], rec['shift'][~qc_failed]
-        table.has_scaling[good] = True
-        if self.loader.scan_unsplit:
-            self.loader.scan_unsplit_candidates(table, rows, offsets)
 
     def _check_early_stop(self, seen):
         """pipeline.py:250-260: stop when reads keep arriving without basecalls."""

@@ -486,10 +486,17 @@ class SignalLoader:
     def run_resident(self, table, rows, offsets):
         """Launch every numeric stage on the batch that is resident on the GPU (uploaded or
         swapped in by the caller) and attach the records to `table`."""
+        if len(rows):
+            self.ctx.run(self.stage_mask)
+            self.collect_resident(table, rows, offsets)
+
+    def collect_resident(self, table, rows, offsets):
+        """Second half of run_resident: download the records of the run that was launched on
+        the resident batch (waits for it) and attach them to `table`; the chimera window scan
+        runs here because it needs the batch's samples still resident."""
         t = table
         if not len(rows):
             return
-        self.ctx.run(self.stage_mask)
         t.records = rec = self.ctx.download()
         t.spikes = self.ctx.download_spikes() if self.stage_mask & native.STAGE_POLYA else None
         t.gpu_row[rows] = np.arange(len(rows))

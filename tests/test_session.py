@@ -102,6 +102,34 @@ def test_session_outputs_do_not_depend_on_batch_size(oracle_backed, tmp_path, bu
     assert not [f for f in os.listdir(tmp_path / 'b') if '.part' in f]
 
 
+def test_session_edge_cases_empty_run_and_no_gpu_rows(oracle_backed, tmp_path):
+    """No reads at all; and a run in which NO read reaches the GPU (all too short, one file
+    gone): the driver must neither launch nor wait for anything, and still write its files."""
+    from poreplex_amd.fast5_file import write_bundle
+    from poreplex_amd.session import GpuSession
+    from poreplex_amd.synth import synth_batch
+    sb = synth_batch(9, seed=4, samples_per_read=4000, jitter=0.2)        # < 9000 samples: too short
+    names = ['s%02d.fast5' % i for i in range(9)]
+    ids = ['%08d-0000-4000-8000-000000000000' % i for i in range(9)]
+    path = str(tmp_path / 'short.pxr.npz')
+    write_bundle(path, sb['arena'], sb['offsets'], sb['calib'], names, ids)
+    cfg = default_config(inputdir='/nonexistent', outputdir=str(tmp_path / 'o1'), read_bundle=path)
+    WorkerPersistenceStorage.reset()
+    out = GpuSession(cfg, batch_reads=4).run([])
+    assert out['reads'] == 0 and out['batches'] == 0
+    assert (tmp_path / 'o1' / 'sequencing_summary.txt').read_text().count('\n') == 1      # header only
+    WorkerPersistenceStorage.reset()
+    cfg = default_config(inputdir='/nonexistent', outputdir=str(tmp_path / 'o2'), read_bundle=path)
+    out = GpuSession(cfg, batch_reads=4).run(list(zip(names, ids)) + [('gone.fast5', 'x')])
+    assert out['reads'] == 10 and out['batches'] == 3
+    from poreplex_amd import distributed as D
+    fail = D.LABEL_NAMES.index('fail')
+    assert out['counts'][fail, 0, N.STATUS_CODE['scaler_signal_too_short']] == 9
+    assert out['counts'][fail, 0, N.STATUS_CODE['disappeared']] == 1
+    assert (tmp_path / 'o2' / 'sequencing_summary.txt').read_text().count('\n') == 1      # no labelled read
+    WorkerPersistenceStorage.reset()
+
+
 def test_count_table_uses_final_labels(oracle_backed, tmp_path):
     """The all-reduced table must carry the statuses the facade decides AFTER the GPU pass
     (unsplit_read / artifact here), not the numeric-stage verdict."""
