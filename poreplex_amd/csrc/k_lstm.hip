@@ -279,19 +279,19 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
                         acc2[nt] = mfma4(wB[nt][kb], a1[kb], acc2[nt]);
                     }
                 }
-#pragma unroll
-                for (int kb = 0; kb < KB; kb++)
-#pragma unroll
-                    for (int nt = 0; nt < NT; nt++)
-                        acc2[nt] = mfma4(wB[nt][KB + kb], a2[kb], acc2[nt]);
                 float* o1 = h1 + ((wrb * MTW + m) * 16 + rd_l) * HS;
                 float* o2 = h2 + ((wrb * MTW + m) * 16 + rd_l) * HS;
-                if (t < T) {
+                if (t < T) {          // layer-1 activations under the last third of the MFMAs (see K2q)
                     float hn[NT];
                     cells_update<NT>(tab, acc1, c1[m], hn);
 #pragma unroll
                     for (int nt = 0; nt < NT; nt++) o1[hpos<H>(slice * 12 + nt * 4 + ul)] = hn[nt];
                 }
+#pragma unroll
+                for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+                    for (int nt = 0; nt < NT; nt++)
+                        acc2[nt] = mfma4(wB[nt][KB + kb], a2[kb], acc2[nt]);
                 if (t >= 1) {
                     float hn[NT];
                     cells_update<NT>(tab, acc2, c2[m], hn);
@@ -454,11 +454,10 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q(
                     acc2[nt] = mfma4(wB[nt][kb], a1[kb], acc2[nt]);
                 }
             }
-#pragma unroll
-            for (int kb = 0; kb < KB; kb++)
-#pragma unroll
-                for (int nt = 0; nt < NT; nt++)
-                    acc2[nt] = mfma4(wB[nt][KB + kb], a2[kb], acc2[nt]);
+            // layer 1 is complete here: its activations (LDS table rows) are requested before the
+            // last third of the matrix work, so their round trips run under those 36 MFMAs
+            // (measured: 10.49 -> 10.30 ms; the same split of K5b's four gate tiles into two halves
+            // leaves only two independent accumulator chains per phase and is SLOWER, 2.28 -> 2.41)
             float* o1 = h1 + (wrb * 16 + rd_l) * HS;
             float* o2 = h2 + (wrb * 16 + rd_l) * HS;
             if (t < T) {
@@ -467,6 +466,11 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q(
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) o1[hpos<H>(slice * 12 + nt * 4 + ul)] = hn[nt];
             }
+#pragma unroll
+            for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+                for (int nt = 0; nt < NT; nt++)
+                    acc2[nt] = mfma4(wB[nt][KB + kb], a2[kb], acc2[nt]);
             if (t >= 1) {
                 float hn[NT];
                 cells_update<NT>(tab, acc2, c2, hn);
