@@ -386,24 +386,35 @@ def main():
                 import torch
                 torch.cuda.synchronize()
 
+    # the result records land in ONE page-locked host buffer, reused by every step
+    res_buf = np.zeros(n_local, dtype=N.RESULT_DTYPE)
+    if not standin:
+        ctx.pin(res_buf)
     for _ in range(args.warmup):
         step()
-        res = ctx.download()
+        res = ctx.download(res_buf)
         gather_labels(res, dist, first_index=lo, sizes=shard_sizes, force=force_dist)
     barrier()
     stage_acc = {k: 0.0 for k in N.TIMER_NAMES}
     t0 = time.perf_counter()
-    pending = None
+    pending, prev = None, None
     for _ in range(args.steps):
-        step()
-        if pending is not None:          # last step's labels arrive while this step runs
-            labels = pending()
-        res = ctx.download()             # D2H of the result records is part of a step
-        # RCCL all-gather of the label records (N>1), asynchronous on RCCL's stream
-        pending = gather_labels_start(res, dist, first_index=lo, sizes=shard_sizes, force=force_dist)
+        step()                           # enqueue this step's kernels
+        if prev is not None:
+            # the label records of the PREVIOUS step are built, and their RCCL all-gather (N>1)
+            # launched, on the host while this step's kernels run; the gather before that one is
+            # collected first (asynchronous on RCCL's stream, one step of slack)
+            if pending is not None:
+                labels = pending()
+            pending = gather_labels_start(prev, dist, first_index=lo, sizes=shard_sizes, force=force_dist)
+        res = ctx.download(res_buf)      # D2H of the result records is part of a step
+        prev = res
         times, _ = ctx.stage_times()
         for k in stage_acc:
             stage_acc[k] += times[k]
+    if pending is not None:
+        labels = pending()
+    pending = gather_labels_start(prev, dist, first_index=lo, sizes=shard_sizes, force=force_dist)
     labels = pending()
     barrier()
     elapsed = time.perf_counter() - t0

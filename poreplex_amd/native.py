@@ -510,10 +510,16 @@ class NativeContext:
     def sync(self):
         self._check(self.lib.pxg_batch_sync(self.handle), 'pxg_batch_sync')
 
-    def download(self):
-        out = np.zeros(self.n_resident, dtype=RESULT_DTYPE)
+    def download(self, out=None):
+        """Result records of the last run.  `out`: a caller-owned RESULT_DTYPE array of at
+        least n_resident rows to receive them (page-lock it with pin() and reuse it across
+        batches: the D2H copy is then a direct DMA transfer, not a staged one)."""
+        if out is None:
+            out = np.zeros(self.n_resident, dtype=RESULT_DTYPE)
+        elif out.dtype != RESULT_DTYPE or len(out) < self.n_resident or not out.flags.c_contiguous:
+            raise ValueError('out must be a contiguous RESULT_DTYPE array of >= n_resident rows')
         self._check(self.lib.pxg_batch_download(self.handle, _ptr(out)), 'pxg_batch_download')
-        return out
+        return out[:self.n_resident]
 
     def download_spikes(self):
         out = np.zeros((self.n_resident, PXG_MAX_SPIKES, 4), dtype=np.float32)
