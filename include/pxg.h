@@ -296,6 +296,10 @@ int pxg_host_register(pxg_ctx* ctx, void* ptr, size_t bytes);
 int pxg_host_unregister(pxg_ctx* ctx, void* ptr);
 int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask);
 int pxg_batch_sync(pxg_ctx* ctx);
+/* sync / download also finish the poly(A) stage: a read whose inspection window needed more
+ * event rows than the first pass hands out (open-ended extension over a long featureless
+ * signal) is re-run with what it asked for before any record leaves the device, so a
+ * record never depends on the size of a scratch buffer. */
 int pxg_batch_download(pxg_ctx* ctx, pxg_read_result* out);
 /* n_reads x PXG_MAX_SPIKES spike rows of the last run (poly(A) stage only) */
 int pxg_batch_download_spikes(pxg_ctx* ctx, pxg_polya_spike* out);

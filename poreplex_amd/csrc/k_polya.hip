@@ -24,6 +24,7 @@
 // open-end retry loop, recalibration, stdv QC) follows oracle/pxo_polya.c line
 // by line and is bit-exact with it; the oracle is pinned by the real polya.py.
 #include <float.h>
+#include <algorithm>
 #include "pxg_common.h"
 
 
@@ -509,6 +510,7 @@ __device__ __forceinline__ float filtered_seq(const WindowSrc& S, int mpf, int64
 struct PolyaOut {
     int called, n_spikes, dwell;
     int64_t begin, end;
+    int overflow;          // events the window needed when the scratch rows ran out (0 = fitted)
 };
 
 __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t n_full, double k,
@@ -516,7 +518,7 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
                                int rough_end, int has_end0, GroupLds* L, int gl, int lane /* read slot of the wave */,
                                Ev* ev, double2* snap_ring, PolyaOut& out, pxg_polya_spike* spikes)
 {
-    out.called = 0; out.n_spikes = 0; out.dwell = 0; out.begin = 0; out.end = 0;
+    out.called = 0; out.n_spikes = 0; out.dwell = 0; out.begin = 0; out.end = 0; out.overflow = 0;
     const int stride = P.stride;
     const int min_unit = P.openend_expansion / stride;
     const double half = P.mean_scale * P.z_cutoff;
@@ -567,7 +569,8 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
             S.ib = ib; S.W = ie - ib;
             ne = detect_events_group(S, P, L, gl, lane, ev, cap, &snap, snap_ring);
             evc0 = -1;
-            if (ne > cap) { state = DONE; break; }         // scratch overflow: not called
+            if (ne > cap) { out.overflow = ne; state = DONE; break; }   // scratch rows ran out: the read is queued for the
+                                                                        // retry pass with more rows (pxg_polya_settle)
             if (has_range) { flo = (float)rlo; fhi = (float)rhi; }
             else { flo = (float)(P.mean_loc - half); fhi = (float)(P.mean_loc + half); }
             state = has_end ? CALL : RECAL;
@@ -772,12 +775,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PA_WAVES_PER
                                               const int32_t* __restrict__ segs, Ev* __restrict__ evbuf,
                                               double2* __restrict__ snapbuf,
                                               int32_t* __restrict__ pout /* n x 8 */,
-                                              pxg_polya_spike* __restrict__ spikes)
+                                              pxg_polya_spike* __restrict__ spikes,
+                                              const int32_t* __restrict__ subset /* read ids of a retry pass, or null */,
+                                              int32_t* __restrict__ over /* [0] count, [1] max events, [2..] read ids */)
 {
     __shared__ GroupLds lds[PXG_PA_LANES];
     const int grp = threadIdx.x / PA_GL, gl = threadIdx.x % PA_GL;     // read slot, lane inside it
-    const int64_t r = blockIdx.x * (int64_t)PXG_PA_LANES + grp;
-    if (r >= n_reads) return;
+    const int64_t slot = blockIdx.x * (int64_t)PXG_PA_LANES + grp;
+    if (slot >= n_reads) return;
+    const int64_t r = subset ? subset[slot] : slot;
     int32_t* po = pout + r * 8;
     if (gl == 0)
         for (int q = 0; q < 8; q++) po[q] = 0;
@@ -799,6 +805,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PA_WAVES_PER
                    ss[2 * r], ss[2 * r + 1], rb, re, has_end, &lds[grp], gl, grp, ev,
                    snapbuf + ((size_t)blockIdx.x * PXG_PA_LANES + grp) * PA_PRE, out, sp);
     if (gl != 0) return;
+    if (out.overflow) {
+        over[2 + atomicAdd(over, 1)] = (int32_t)r;
+        atomicMax(over + 1, out.overflow);
+    }
     po[0] = out.called;
     po[1] = out.n_spikes;
     po[2] = out.dwell;
@@ -863,7 +873,28 @@ int pxg_polya_supported(pxg_ctx* ctx)
     return PXG_OK;
 }
 
-#define PA_EV_CAP 4096
+#define PA_EV_CAP 4096            // event rows per read of the first pass
+#define PA_RETRY_BYTES (1ll << 31) // event scratch of one retry launch
+
+static void launch_polya(pxg_ctx* ctx, int64_t n, int cap, const int32_t* subset, const int16_t* raw,
+                         const int64_t* off, const pxg_calib* cal, const float* ss, const int32_t* status,
+                         const int32_t* segs, int32_t* pout, pxg_polya_spike* spikes)
+{
+    const int64_t blocks = (n + PXG_PA_LANES - 1) / PXG_PA_LANES;
+    const size_t ev_bytes = (size_t)blocks * cap * PXG_PA_LANES * sizeof(Ev);
+    const PolyaParams P = make_params(ctx->cfg, cap, ctx->cfg.polya_median_pre_filter);
+    hipLaunchKernelGGL(k_polya, dim3((unsigned)blocks), dim3(64), 0, ctx->stream, n, P, raw, off, cal,
+                       ss, status, segs, (Ev*)ctx->polya_ev.p, (double2*)(ctx->polya_ev.p + ev_bytes),
+                       pout, spikes, subset, ctx->polya_over.p);
+}
+
+static int reserve_polya(pxg_ctx* ctx, int64_t n, int cap)
+{
+    const int64_t blocks = (n + PXG_PA_LANES - 1) / PXG_PA_LANES;
+    const size_t ev_bytes = (size_t)blocks * cap * PXG_PA_LANES * sizeof(Ev);
+    const size_t snap_bytes = (size_t)blocks * PXG_PA_LANES * PA_PRE * sizeof(double2);
+    return pxg_reserve(ctx, ctx->polya_ev, ev_bytes + snap_bytes);
+}
 
 int pxg_launch_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
                      const pxg_calib* cal, const float* ss, const int32_t* status,
@@ -872,15 +903,51 @@ int pxg_launch_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t*
     if (n <= 0) return PXG_OK;
     int rc = pxg_polya_supported(ctx);
     if (rc) return rc;
-    const int64_t blocks = (n + PXG_PA_LANES - 1) / PXG_PA_LANES;
-    const size_t ev_bytes = (size_t)blocks * PA_EV_CAP * PXG_PA_LANES * sizeof(Ev);
-    const size_t snap_bytes = (size_t)blocks * PXG_PA_LANES * PA_PRE * sizeof(double2);
-    if ((rc = pxg_reserve(ctx, ctx->polya_ev, ev_bytes + snap_bytes))) return rc;
-    const PolyaParams P = make_params(ctx->cfg, PA_EV_CAP, ctx->cfg.polya_median_pre_filter);
-    hipLaunchKernelGGL(k_polya, dim3((unsigned)blocks), dim3(64), 0, ctx->stream, n, P, raw, off, cal,
-                       ss, status, segs, (Ev*)ctx->polya_ev.p, (double2*)(ctx->polya_ev.p + ev_bytes),
-                       pout, spikes);
+    if ((rc = reserve_polya(ctx, n, PA_EV_CAP))) return rc;
+    if ((rc = pxg_reserve(ctx, ctx->polya_over, (size_t)n + 2))) return rc;
+    PXG_HIP(ctx, hipMemsetAsync(ctx->polya_over.p, 0, 2 * sizeof(int32_t), ctx->stream));
+    launch_polya(ctx, n, PA_EV_CAP, nullptr, raw, off, cal, ss, status, segs, pout, spikes);
     return PXG_OK;
+}
+
+// The first pass gives every read PA_EV_CAP event rows.  A window that needs more (tens of
+// thousands of samples of open-ended extension over a featureless signal) is listed by the
+// kernel and re-run here, alone, with as many rows as it asked for (doubled, so that a
+// further extension still fits; the loop ends at the latest when the rows cover a window of
+// the whole arena).  Synchronises the stream; *retried = reads that went through a retry.
+int pxg_polya_settle(pxg_ctx* ctx, int64_t n, int64_t n_samples, const int16_t* raw, const int64_t* off,
+                     const pxg_calib* cal, const float* ss, const int32_t* status, const int32_t* segs,
+                     int32_t* pout, pxg_polya_spike* spikes, int64_t* retried)
+{
+    if (retried) *retried = 0;
+    if (n <= 0) return PXG_OK;
+    int cap = PA_EV_CAP;
+    for (;;) {
+        int32_t head[2] = { 0, 0 };
+        PXG_HIP(ctx, hipMemcpyAsync(head, ctx->polya_over.p, sizeof(head), hipMemcpyDeviceToHost, ctx->stream));
+        PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const int64_t m = head[0];
+        if (m <= 0) return PXG_OK;
+        if ((int64_t)cap > n_samples) {
+            ctx->err = "poly(A): event scratch overflow with rows for the whole arena";
+            return PXG_E_HIP;
+        }
+        if (retried) *retried += m;
+        cap = (int)std::min<int64_t>(std::max<int64_t>(2 * (int64_t)head[1], 2 * (int64_t)cap), n_samples + 1);
+        // the listed reads move to a list of their own: the kernel appends the next round's to polya_over
+        int rc = pxg_reserve(ctx, ctx->polya_retry, (size_t)m);
+        if (rc) return rc;
+        PXG_HIP(ctx, hipMemcpyAsync(ctx->polya_retry.p, ctx->polya_over.p + 2, (size_t)m * sizeof(int32_t),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+        PXG_HIP(ctx, hipMemsetAsync(ctx->polya_over.p, 0, 2 * sizeof(int32_t), ctx->stream));
+        const int64_t per_launch = std::max<int64_t>(
+            PXG_PA_LANES, PA_RETRY_BYTES / ((int64_t)cap * (int64_t)sizeof(Ev)) / PXG_PA_LANES * PXG_PA_LANES);
+        if ((rc = reserve_polya(ctx, std::min(per_launch, m), cap))) return rc;
+        for (int64_t at = 0; at < m; at += per_launch) {
+            const int64_t k = std::min(per_launch, m - at);
+            launch_polya(ctx, k, cap, ctx->polya_retry.p + at, raw, off, cal, ss, status, segs, pout, spikes);
+        }
+    }
 }
 
 int pxg_launch_detect_events(pxg_ctx* ctx, int64_t n, const float* sig, const int64_t* off,

@@ -276,7 +276,7 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     release(ctx->lstm_q); release(ctx->lstm_state); release(ctx->lstm_err);
     release(ctx->demux_q); release(ctx->demux_state);
     release(ctx->spare.raw); release(ctx->spare.offsets); release(ctx->spare.calib); release(ctx->spare.inject);
-    release(ctx->results); release(ctx->polya_ev); release(ctx->polya_out); release(ctx->spikes);
+    release(ctx->results); release(ctx->polya_ev); release(ctx->polya_over); release(ctx->polya_retry); release(ctx->polya_out); release(ctx->spikes);
     release(ctx->ev_first); release(ctx->ev_off); release(ctx->ev_mean); release(ctx->ev_scaled);
     release(ctx->unsplit_scr); release(ctx->unsplit_iv); release(ctx->unsplit_cnt); release(ctx->unsplit_ivoff);
     release(ctx->unsplit_cand); release(ctx->unit_off); release(ctx->n_win);
@@ -366,6 +366,7 @@ extern "C" int pxg_batch_upload(pxg_ctx* ctx, int64_t n_reads, const int16_t* ra
         return fail(ctx, PXG_E_INVALID, "pxg_batch_upload: bad arguments");
     PXG_HIP(ctx, hipSetDevice(ctx->device));
     ctx->n_reads = 0;
+    ctx->polya_unsettled = false;     // results not downloaded by now are given up
     if (n_reads == 0) return PXG_OK;
     for (int64_t i = 0; i < n_reads; i++)
         if (raw_offsets[i + 1] < raw_offsets[i])
@@ -408,6 +409,7 @@ extern "C" int pxg_batch_upload_tiled(pxg_ctx* ctx, int64_t n_reads, int64_t bas
     if (n_reads > (1LL << 30)) return fail(ctx, PXG_E_INVALID, "too many reads");
     PXG_HIP(ctx, hipSetDevice(ctx->device));
     ctx->n_reads = 0;
+    ctx->polya_unsettled = false;     // results not downloaded by now are given up
     phase %= base_n;
     const int64_t base_samples = base_offsets[base_n];
     // per-read metadata of the tiled batch on the host (a few MB even for 1M reads)
@@ -523,6 +525,7 @@ extern "C" int pxg_batch_swap(pxg_ctx* ctx)
     ctx->cur ^= 1;
     ctx->have_inject = sp.have_inject;
     ctx->n_reads = 0;
+    ctx->polya_unsettled = false;     // results not downloaded by now are given up
     int rc = reserve_batch(ctx, sp.n_reads, sp.n_samples);     // per-batch intermediates
     if (rc) return rc;
     ctx->n_reads = sp.n_reads;
@@ -619,6 +622,8 @@ extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
         pxg_timer_end(ctx, PXG_T_POLYA);
         ctx->polya_ran = true;
     }
+    ctx->polya_unsettled = ctx->polya_ran;
+    ctx->last_stage_mask = stage_mask;
     pxg_timer_begin(ctx, PXG_T_FINALIZE);
     if ((rc = pxg_launch_finalize(ctx, n, stage_mask))) return rc;
     pxg_timer_end(ctx, PXG_T_FINALIZE);
@@ -645,9 +650,25 @@ static int check_timeslice_flag(pxg_ctx* ctx)
     return PXG_OK;
 }
 
+// K6's first pass lists the reads whose inspection window needed more event rows than it
+// hands out; they are re-run with what they asked for and the records rebuilt, before any
+// result leaves the device.  No read listed (every batch but the odd one): one 8-byte copy.
+static int settle_polya(pxg_ctx* ctx)
+{
+    if (!ctx->polya_unsettled) return PXG_OK;
+    ctx->polya_unsettled = false;
+    int64_t retried = 0;
+    int rc = pxg_polya_settle(ctx, ctx->n_reads, ctx->n_samples, ctx->raw.p, ctx->offsets.p, ctx->calib.p,
+                              ctx->ss.p, ctx->status.p, ctx->segs.p, ctx->polya_out.p, ctx->spikes.p, &retried);
+    if (rc || !retried) return rc;
+    return pxg_launch_finalize(ctx, ctx->n_reads, ctx->last_stage_mask);
+}
+
 extern "C" int pxg_batch_sync(pxg_ctx* ctx)
 {
     if (!ctx) return PXG_E_INVALID;
+    int rc = settle_polya(ctx);
+    if (rc) return rc;
     PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return check_timeslice_flag(ctx);
 }
@@ -656,6 +677,8 @@ extern "C" int pxg_batch_download(pxg_ctx* ctx, pxg_read_result* out)
 {
     if (!ctx || (!out && ctx->n_reads)) return PXG_E_INVALID;
     if (ctx->n_reads <= 0) return PXG_OK;
+    int rc = settle_polya(ctx);
+    if (rc) return rc;
     PXG_HIP(ctx, hipMemcpyAsync(out, ctx->results.p, (size_t)ctx->n_reads * sizeof(pxg_read_result),
                                 hipMemcpyDeviceToHost, ctx->stream));
     PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -667,6 +690,8 @@ extern "C" int pxg_batch_download_spikes(pxg_ctx* ctx, pxg_polya_spike* out)
     if (!ctx || (!out && ctx->n_reads)) return PXG_E_INVALID;
     if (ctx->n_reads <= 0) return PXG_OK;
     if (!ctx->polya_ran) return fail(ctx, PXG_E_STATE, "the last run had no poly(A) stage");
+    int rc = settle_polya(ctx);
+    if (rc) return rc;
     PXG_HIP(ctx, hipMemcpyAsync(out, ctx->spikes.p, (size_t)ctx->n_reads * PXG_MAX_SPIKES * sizeof(pxg_polya_spike),
                                 hipMemcpyDeviceToHost, ctx->stream));
     PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1063,6 +1088,8 @@ extern "C" int pxg_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int6
     PXG_HIP(ctx, hipMemsetAsync(d_spk, 0, (size_t)n * PXG_MAX_SPIKES * sizeof(pxg_polya_spike), ctx->stream));
     int rc = pxg_launch_polya(ctx, n, d_raw, d_off, d_cal, d_ss, d_status, d_segs, d_pout, d_spk);
     if (rc) return rc;
+    if ((rc = pxg_polya_settle(ctx, n, off[n], d_raw, d_off, d_cal, d_ss, d_status, d_segs, d_pout, d_spk, nullptr)))
+        return rc;
     std::vector<int32_t> po((size_t)n * 8);
     HOOK_GET(po.data(), d_pout, po.size());
     if (spikes_or_null) HOOK_GET(spikes_or_null, d_spk, (size_t)n * PXG_MAX_SPIKES);

@@ -286,6 +286,10 @@ struct pxg_ctx {
     bool timeslice_used = false;
     DevBuf<pxg_read_result> results;
     DevBuf<char> polya_ev;       // event scratch, [wave][event][lane]
+    DevBuf<int32_t> polya_over;  // [0] reads whose window outgrew the scratch, [1] most events asked for, [2..] their ids
+    DevBuf<int32_t> polya_retry; // the ids a retry launch works through
+    bool polya_unsettled = false;   // K6 ran and its overflow list has not been looked at yet
+    uint32_t last_stage_mask = 0;
     DevBuf<int32_t> polya_out;   // n x 8: called, n_spikes, dwell, begin lo/hi, end lo/hi
     DevBuf<pxg_polya_spike> spikes;   // n x PXG_MAX_SPIKES
     bool polya_ran = false;
@@ -368,6 +372,9 @@ int pxg_polya_supported(pxg_ctx* ctx);
 int pxg_launch_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
                      const pxg_calib* cal, const float* ss, const int32_t* status,
                      const int32_t* segs, int32_t* pout, pxg_polya_spike* spikes);
+int pxg_polya_settle(pxg_ctx* ctx, int64_t n, int64_t n_samples, const int16_t* raw, const int64_t* off,
+                     const pxg_calib* cal, const float* ss, const int32_t* status, const int32_t* segs,
+                     int32_t* pout, pxg_polya_spike* spikes, int64_t* retried);
 int pxg_launch_detect_events(pxg_ctx* ctx, int64_t n, const float* sig, const int64_t* off,
                              int64_t cap, void* evbuf, int64_t* n_events);
 

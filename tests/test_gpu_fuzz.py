@@ -1,0 +1,84 @@
+"""Seeded fuzz of the whole path against the oracle (-m gpu): ragged batches that mix
+degenerate lengths (0, 1, 14, 15 samples ... just over every threshold ... 250 000 samples),
+structured squiggles, flat lines, full-scale noise and saturated int16 runs, with odd DAQ
+calibrations (non-integer offsets, other sampling rates).  Every field of every record, the
+poly(A) spike rows and the chimera candidates must equal the oracle's."""
+import os
+
+import numpy as np
+import pytest
+
+from poreplex_amd import native as N
+from poreplex_amd.synth import synth_batch
+
+pytestmark = pytest.mark.gpu
+
+LENGTHS = [0, 1, 14, 15, 16, 100, 3899, 3900, 4500, 8985, 8999, 9000, 9014, 9015, 12000, 29999, 30000,
+           30001, 45000, 99990, 100000, 100001, 100015, 130000, 250000]
+
+
+def make_batch(rng, n):
+    pool = synth_batch(24, seed=int(rng.integers(1 << 30)), samples_per_read=int(rng.choice([12000, 40000, 110000])),
+                       jitter=0.3, scale_sigma=0.12, shift_sigma=8.0)
+    parts, cal = [], []
+    for _ in range(n):
+        L = int(rng.choice(LENGTHS)) if rng.random() < 0.6 else int(rng.integers(0, 60000))
+        kind = rng.integers(0, 6)
+        if kind <= 2:                                   # structured squiggle, cut or tiled to L
+            i = int(rng.integers(0, 24))
+            src = pool['arena'][pool['offsets'][i]:pool['offsets'][i + 1]]
+            raw = np.resize(src, L) if L else src[:0]
+            c = pool['calib'][i].copy()
+        else:
+            c = np.zeros(1, dtype=N.CALIB_DTYPE)[0]
+            c['range'], c['digitisation'] = rng.uniform(900, 1500), rng.choice([8192.0, 4096.0, 2048.0])
+            c['offset'], c['sampling_rate'] = rng.uniform(-40, 40), rng.choice([3012.0, 4000.0, 5000.0])
+            if kind == 3:                               # flat line with a little noise
+                raw = (rng.integers(300, 900) + rng.normal(0, 3, L)).astype(np.int16)
+            elif kind == 4:                             # full-scale noise
+                raw = rng.integers(-32768, 32768, L).astype(np.int16)
+            else:                                       # saturated runs
+                raw = np.repeat(rng.choice([-32768, 32767, 0, 500], max(L // 50, 1)), 50)[:L].astype(np.int16)
+                raw = np.resize(raw, L)
+        if rng.random() < 0.3:
+            c['offset'] = float(c['offset']) + 0.37      # a non-integer DAQ offset
+        parts.append(np.ascontiguousarray(raw, dtype=np.int16))
+        cal.append(c)
+    arena, off = N.pack_reads(parts)
+    return arena, off, np.array(cal, dtype=N.CALIB_DTYPE), parts
+
+
+def test_fuzz_whole_path_vs_oracle(ctx, oracle):
+    rng = np.random.default_rng(int(os.environ.get('PXG_FUZZ_SEED', 20260928)))
+    mask = N.STAGE_ALL_DEMUX | N.STAGE_POLYA
+    seen = np.zeros(len(N.STATUS_NAMES), dtype=np.int64)
+    for trial in range(int(os.environ.get('PXG_FUZZ_TRIALS', 40))):
+        n = int(rng.choice([1, 3, 17, 64, 130]))
+        arena, off, cal, parts = make_batch(rng, n)
+        inject = None
+        if rng.random() < 0.25:        # caller-supplied scaling (the scaler stage is skipped)
+            inject = np.stack([rng.normal(1.0, 0.15, n), rng.normal(0.0, 10.0, n)], axis=1).astype(np.float32)
+        want, wsp = oracle.process_batch(arena, off, cal, inject, mask, want_spikes=True)
+        ctx.upload(arena, off, cal, inject)
+        ctx.run(mask)
+        got = ctx.download()
+        for f in got.dtype.names:
+            assert np.array_equal(got[f], want[f], equal_nan=True), (trial, f, np.nonzero(got[f] != want[f])[0][:5])
+        assert np.array_equal(ctx.download_spikes(), wsp, equal_nan=True), trial
+        seen += np.bincount(got['status'], minlength=len(seen))
+        # the chimera scan with Guppy frames of random phase / truncated tables
+        first = rng.integers(0, 50, n)
+        nb = np.maximum((np.diff(off) - first) // 15 - rng.integers(0, 3, n) * 200, 0)
+        iv, cnt, start = ctx.unsplit_scan(first, nb)
+        a = 3
+        for r in range(n):
+            if nb[r] <= 0 or got[r]['status'] != 0 or got[r]['seg_first'][a] < 0:
+                assert cnt[r] == 0, (trial, r)
+                continue
+            _, sc = oracle.guppy_event_means(parts[r], cal[r], int(first[r]), int(nb[r]), got[r]['scale'], got[r]['shift'])
+            wiv, wc = oracle.unsplit_scan(sc, int(first[r]), (int(got[r]['seg_last'][a]) + 1) * 15,
+                                          float(cal[r]['sampling_rate']))
+            assert cnt[r] == wc and iv[start[r]:start[r + 1]].tolist() == wiv.tolist(), (trial, r)
+    # the fuzz reached the failure statuses as well as the happy path
+    assert seen[N.STATUS_CODE['okay']] > 20 and seen[N.STATUS_CODE['scaler_signal_too_short']] > 20
+    assert seen[N.STATUS_CODE['scaling_qc_fail']] + seen[N.STATUS_CODE['adapter_not_detected']] > 5

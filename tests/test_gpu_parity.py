@@ -619,3 +619,39 @@ def test_polya_hook_equals_stage(ctx):
     for f in ('polya_called', 'polya_n_spikes', 'polya_dwell_samples', 'polya_begin', 'polya_end'):
         assert np.array_equal(got[f], want[f][idx]), f
     assert np.array_equal(gsp, wsp[idx], equal_nan=True)
+
+
+def test_polya_window_larger_than_first_pass_scratch(ctx, oracle):
+    """A featureless read whose segmentation calls 100 000 samples of poly(A): the open-ended
+    extension grows the inspection window to the whole read and event detection returns more
+    events than the first pass of K6 has rows for.  The read goes through the retry pass
+    (pxg_polya_settle) and equals the oracle -- in a batch next to ordinary reads, and through
+    the pxg_polya hook."""
+    rng = np.random.default_rng(77)
+    flat = (775 + rng.normal(0, 3, 130000)).astype(np.int16)
+    sb = synth_batch(6, seed=5, samples_per_read=30000)
+    parts = [sb['arena'][sb['offsets'][i]:sb['offsets'][i + 1]] for i in range(6)]
+    parts.insert(2, flat); parts.append(flat[:120000].copy())
+    cal = np.concatenate([sb['calib'][:2], sb['calib'][:1], sb['calib'][2:], sb['calib'][:1]])
+    arena, off = N.pack_reads(parts)
+    mask = N.STAGE_ALL_DEMUX | N.STAGE_POLYA
+    want, wsp = oracle.process_batch(arena, off, cal, None, mask, want_spikes=True)
+    assert want['polya_called'][2] == 1 and want['polya_end'][2] - want['polya_begin'][2] > 100000
+    ctx.upload(arena, off, cal)
+    ctx.run(mask)
+    got = ctx.download()
+    for f in got.dtype.names:
+        assert np.array_equal(got[f], want[f], equal_nan=True), f
+    assert np.array_equal(ctx.download_spikes(), wsp, equal_nan=True)
+    # spikes first, records second: either download settles the stage
+    ctx.run(mask)
+    assert np.array_equal(ctx.download_spikes(), wsp, equal_nan=True)
+    assert np.array_equal(ctx.download()['polya_end'], want['polya_end'])
+    ok = np.nonzero(want['status'] == 0)[0]
+    ss = np.stack([want['scale'], want['shift']], axis=1).astype(np.float32)
+    sub_arena, sub_off = N.pack_reads([parts[i] for i in ok])
+    res, spikes = ctx.polya(sub_arena, sub_off, cal[ok], ss[ok], want['seg_first'][ok], want['seg_last'][ok],
+                            want_spikes=True)
+    for f in ('polya_called', 'polya_n_spikes', 'polya_dwell_samples', 'polya_begin', 'polya_end'):
+        assert np.array_equal(res[f], want[f][ok]), f
+    assert np.array_equal(spikes, wsp[ok], equal_nan=True)
