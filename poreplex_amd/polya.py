@@ -19,24 +19,24 @@ class PolyASignalAnalyzer:
         self.polya_mean_cutoff = (centre - halfwidth, centre + halfwidth)
 
     def assign(self, table, rows, records):
-        """set_polya_tail for many reads at once: the dicts of polya.py:116-121 from the GPU
-        records.  Returns the rows whose tail cannot be reported faithfully (more spike events
-        than the GPU keeps): the caller runs those through __call__, which raises per read."""
+        """set_polya_tail for many reads at once, as columns: begin / end / dwell time / spike
+        count of every called tail go into the table, and the dict of polya.py:116-121 is built
+        from them (and the spike rows) when somebody asks for it (ReadTable.polya_of).  Returns
+        the positions whose tail cannot be reported faithfully (more spike events than the GPU
+        keeps): the caller runs those through __call__, which raises per read."""
         called = np.nonzero(records['polya_called'])[0]
         n_spikes = records['polya_n_spikes'][called].astype(np.int64)
-        cap = table.spikes.shape[1] if table.spikes is not None else 0
-        begin, end = records['polya_begin'][called].tolist(), records['polya_end'][called].tolist()
-        dwell = (records['polya_dwell_samples'][called] / table.sampling_rate[rows[called]]).tolist()
-        odd = []
-        for k, i, ns, b, e, dw in zip(called.tolist(), rows[called].tolist(), n_spikes.tolist(),
-                                      begin, end, dwell):
-            if ns > cap and table.spikes is not None:
-                odd.append(k)
-                continue
-            spikes = []
-            if ns and table.spikes is not None:
-                spikes = [tuple(r) for r in table.spikes[table.gpu_row[i], :ns].astype(float).tolist()]
-            table.polya[i] = {'begin': b, 'end': e, 'dwell_time': dw, 'spikes': spikes}
+        if table.spikes is not None:
+            fits = n_spikes <= table.spikes.shape[1]
+            odd, called, n_spikes = called[~fits].tolist(), called[fits], n_spikes[fits]
+        else:
+            odd = []
+        at = rows[called]
+        table.polya_begin[at] = records['polya_begin'][called]
+        table.polya_end[at] = records['polya_end'][called]
+        table.polya_dwell_time[at] = records['polya_dwell_samples'][called] / table.sampling_rate[at]
+        table.polya_spike_count[at] = n_spikes
+        table.polya_lazy[at] = True
         return odd
 
     def __call__(self, npread, rough_range=None, stride=None):

@@ -52,7 +52,10 @@ class ReadTable:
                ('num_events', np.int64), ('sequence_length', np.int64),
                ('mean_qscore', np.float64), ('n_raw', np.int64), ('pending', np.bool_),
                ('seq_lazy', np.bool_),
-               ('unsplit_count', np.int32))
+               ('unsplit_count', np.int32),
+               # poly(A) tail as the GPU record has it; the dict of polya.py:116-121 is built on demand
+               ('polya_lazy', np.bool_), ('polya_begin', np.int64), ('polya_end', np.int64),
+               ('polya_dwell_time', np.float64), ('polya_spike_count', np.int16))
 
     def __init__(self):
         self.n = 0
@@ -126,6 +129,18 @@ class ReadTable:
         for col in (self.raw, self.source, self.sequence, self.error_message, self.polya, self.unsplit):
             col.extend([None] * k)
         return rows
+
+    def polya_of(self, i):
+        """set_polya_tail's dict for row i (None if no tail was called)."""
+        if self.polya[i] is None and self.polya_lazy[i]:
+            ns = int(self.polya_spike_count[i])
+            spikes = []
+            if ns and self.spikes is not None:
+                spikes = [tuple(r) for r in self.spikes[self.gpu_row[i], :ns].astype(float).tolist()]
+            self.polya[i] = {'begin': int(self.polya_begin[i]), 'end': int(self.polya_end[i]),
+                             'dwell_time': float(self.polya_dwell_time[i]), 'spikes': spikes}
+            self.polya_lazy[i] = False
+        return self.polya[i]
 
     def samples_of(self, i):
         """int16 samples of a read that has not been packed yet."""
@@ -209,7 +224,7 @@ class ReadTable:
             if called[k]:
                 rep['barcode'], rep['barcode_guess'] = barcode[k], guess[k]
                 rep['barcode_score'] = phred[k]
-            if self.polya[i] is not None:
+            if self.polya_of(i) is not None:
                 rep['polya'] = self.polya[i]
             out.append(rep)
         return out
@@ -245,8 +260,11 @@ def summary_columns(table, rows, barcoding, polya):
         called = table.has_barcode[idx]
         cols['barcode'] = [b if c else None for b, c in zip(table.barcode[idx].tolist(), called.tolist())]
         cols['barcode_score'] = np.where(called, table.barcode_phred[idx], 0).tolist()
-    if polya:
-        cols['polya'] = pick(table.polya)
+    if polya:        # dwell time in seconds, None where no tail was called
+        lazy = table.polya_lazy[idx].tolist()
+        cols['polya_dwell_time'] = [d if z else (p['dwell_time'] if p is not None else None)
+                                    for d, z, p in zip(table.polya_dwell_time[idx].tolist(), lazy,
+                                                       pick(table.polya))]
     return cols
 
 
@@ -267,7 +285,7 @@ class NanoporeRead:
     stopped = property(lambda self: bool(self.table.stopped[self.row]))
     error_message = property(lambda self: self.table.error_message[self.row])
     sequence = property(lambda self: self.table.sequence_of(self.row))
-    polya = property(lambda self: self.table.polya[self.row])
+    polya = property(lambda self: self.table.polya_of(self.row))
     num_events = property(lambda self: int(self.table.num_events[self.row]))
     sequence_length = property(lambda self: int(self.table.sequence_length[self.row]))
     mean_qscore = property(lambda self: float(self.table.mean_qscore[self.row])
@@ -325,6 +343,7 @@ class NanoporeRead:
 
     def set_polya_tail(self, polya_info):
         self.table.polya[self.row] = polya_info
+        self.table.polya_lazy[self.row] = False
 
     def is_stopped(self):
         return self.stopped

@@ -130,8 +130,7 @@ class SequencingSummaryWriter:
         if bcname is not None:
             out['barcode'] = bcname
         if self.polya_enabled:
-            out['polya_dwell'] = [format(p['dwell_time'], '.4f') if p is not None else ''
-                                  for p in cols['polya']]
+            out['polya_dwell'] = [format(d, '.4f') if d is not None else '' for d in cols['polya_dwell_time']]
         fields = [col if (n and type(col[0]) is str and f not in ('barcode_score',)) else list(map(str, col))
                   for f, col in ((f, out[f]) for f in self.output_fields)]
         text = ''.join('\t'.join(row) + '\n' for row in zip(*fields)) if n else ''
