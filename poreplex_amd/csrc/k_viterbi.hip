@@ -14,11 +14,16 @@
 //       (no LDS round trip; the model is left-to-right so a source is always
 //       0..7 lanes down), max-plus with strict '>' in pomegranate's name-sorted
 //       source order.
-// No back-pointer table: the segmentation model is left-to-right (every edge
-// i->j has j >= i), so a path is fully described by the step at which it
-// entered each state.  Each lane carries those entry steps packed 16 bit per
-// state; taking an in-edge copies the source lane's vector and stamps the
-// current step.  The run-length summary falls out without a traceback.
+// Back-pointers: the segmentation model is left-to-right (every edge i->j has j >= i), so a
+// step's decision is the SPAN of the in-edge it took (0 = self loop).  Each recurrence lane
+// shifts that span into a register, FB bits per step, and stores the register once per
+// 16-step chunk (one coalesced 256-byte row per wave).  k_viterbi_trace then walks the
+// fields of the winning state backwards, a wave per read, 64 chunks per load: the entry
+// step of every state on the path IS the run-length summary.  (Round 1 carried the entry
+// steps through the recurrence instead -- 6 DPP moves, 9 selects and 3 bit-field inserts
+// of its ~66 instructions per step.)
+#include <algorithm>
+#include <type_traits>
 #include "pxg_common.h"
 
 #define VIT_CHAINS 1            // independent 8-read sets per recurrence wave (2 measured slower: 2.6 vs 1.9 ms, the wave is issue-bound)
@@ -61,17 +66,26 @@ __device__ __forceinline__ double shfl_f64(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
-// stamp a 16-bit field (state q) of the packed entry vector without dynamic
-// register indexing
-__device__ __forceinline__ void ent_stamp(unsigned (&e)[4], int q, unsigned val16)
+// Workgroup barrier that publishes LDS only.  __syncthreads() also drains the vector-memory
+// counter (its fence covers global memory), which would wait for the producers' prefetch of
+// the NEXT chunk's samples at every chunk; nothing in this kernel passes global data
+// between waves.
+__device__ __forceinline__ void lds_barrier()
 {
-    const unsigned sh = (unsigned)(q & 1) * 16u;
-    const int w = q >> 1;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// pxg_block_mean for 15 samples already in registers (same NumPy pairwise order)
+__device__ __forceinline__ float block_mean15(const int16_t (&x)[15], double k, double offset)
+{
+    float r[8];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const unsigned nv = (e[i] & ~(0xFFFFu << sh)) | (val16 << sh);
-        e[i] = (i == w) ? nv : e[i];
-    }
+    for (int j = 0; j < 8; j++) r[j] = pxg_raw2pa(x[j], k, offset);
+    float s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+    for (int i = 8; i < 15; i++) s += pxg_raw2pa(x[i], k, offset);
+    s = 0.0f + s;
+    return s / 15.0f;
 }
 
 #define EM_STRIDE (VIT_CHUNK * PXG_MAX_STATES + 8)   // +8 doubles: spread reads over banks
@@ -102,15 +116,23 @@ __device__ __forceinline__ double dpp_shr_f64(double v, int k)
 
 // RAW=true : signal is pooled on the fly from int16 DAQ samples
 // RAW=false: signal is an already pooled+scaled float arena (test hook)
-// SPANS: bit k set = some edge goes from state s-k to state s (k >= 1);
-// NW: packed entry words in use = ceil(n_states / 2)
-template <bool RAW, unsigned SPANS, int NW>
+// SPANS: bit k set = some edge goes from state s-k to state s (k >= 1)
+// BT: register of back-pointer fields of one chunk -- uint32_t = 2 bits per step (spans <= 3),
+//     uint64_t = 4 bits per step (spans <= 7)
+template <typename BT> struct BpFields { static constexpr int bits = (int)sizeof(BT) * 8 / VIT_CHUNK; };
+
+// POOL: 15 = the pooling stride is 15 (samples are prefetched into registers a chunk ahead),
+//       0 = any stride / float input
+template <bool RAW, int POOL, unsigned SPANS, typename BT>
 __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
     int64_t n_reads, PxgHmmDev H, const int16_t* __restrict__ raw, const float* __restrict__ sig,
     const int64_t* __restrict__ off, const pxg_calib* __restrict__ cal,
-    const float* __restrict__ ss, int stride, int scan_pooled, int32_t* __restrict__ status,
-    int32_t* __restrict__ segs, double* __restrict__ logp_out, const double* __restrict__ lsetab_g)
+    const float* __restrict__ ss, int stride, int scan_pooled, const int32_t* __restrict__ status,
+    BT* __restrict__ bp /* [block][chunk][64 lanes] */, int bp_chunks,
+    int32_t* __restrict__ end_state, double* __restrict__ logp_out, const double* __restrict__ lsetab_g)
 {
+    constexpr int FB = BpFields<BT>::bits;
+    static_assert((SPANS >> (1 << FB)) == 0, "span does not fit the back-pointer field");
     __shared__ double em[2][VIT_READS * EM_STRIDE];   // double buffer: producers run one chunk ahead
     __shared__ double lsetab[PXG_LSE_TAB_DOUBLES];
     for (int i = threadIdx.x; i < PXG_LSE_TAB_DOUBLES; i += blockDim.x) lsetab[i] = lsetab_g[i];
@@ -120,29 +142,21 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
     const int rr = lane >> 3, s = lane & 7;
     const int S = H.n_states;
 
-    // the recurrence wave carries VIT_CHAINS independent sets of 8 reads (chain c = reads
-    // [8c, 8c + 8) of the block); two interleaved chains were measured slower than one
-    int64_t r[VIT_CHAINS];
-    bool valid_read[VIT_CHAINS];
-    int T[VIT_CHAINS];
-    int Tmax = 0;
-#pragma unroll
-    for (int c = 0; c < VIT_CHAINS; c++) {
-        r[c] = blockIdx.x * (int64_t)VIT_READS + c * 8 + rr;
-        valid_read[c] = r[c] < n_reads && (status == nullptr || status[r[c]] == PXG_ST_OKAY);
-        T[c] = 0;
-        if (valid_read[c]) {
-            const int64_t len = off[r[c] + 1] - off[r[c]];
-            const int64_t P = RAW ? len / stride : len;
-            T[c] = (int)(P < scan_pooled ? P : scan_pooled);
-        }
-        Tmax = T[c] > Tmax ? T[c] : Tmax;
+    const int64_t r = blockIdx.x * (int64_t)VIT_READS + rr;
+    const bool valid_read = r < n_reads && (status == nullptr || status[r] == PXG_ST_OKAY);
+    int T = 0;
+    if (valid_read) {
+        const int64_t len = off[r + 1] - off[r];
+        const int64_t P = RAW ? len / stride : len;
+        T = (int)(P < scan_pooled ? P : scan_pooled);
     }
+    int Tmax = T;
     // longest read of this block (every wave computes the same value)
     for (int d = 32; d >= 1; d >>= 1) {
         const int o = __shfl_xor(Tmax, d);
         Tmax = o > Tmax ? o : Tmax;
     }
+    Tmax = __builtin_amdgcn_readfirstlane(Tmax);
     const int n_chunks = (Tmax + VIT_CHUNK - 1) / VIT_CHUNK;
 
     if (wv > 0) {
@@ -170,26 +184,65 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
                 shift = ss[2 * pr + 1];
             }
         }
-        for (int c = 0; c <= n_chunks; c++) {
-            if (c < n_chunks) {
+        auto publish = [&](int c, float x) {
+            const double xd = (double)x;
+            double* dst = &em[c & 1][prr * EM_STRIDE + ptt * PXG_MAX_STATES];
+#pragma unroll
+            for (int q = 0; q < PXG_MAX_STATES; q++)
+                if (q < S) dst[q] = hmm_emission(H, lsetab, q, xd);
+        };
+        if (RAW && POOL == 15) {
+            // the 15 samples of chunk c+1 are requested before chunk c is worked on: one
+            // memory round trip per chunk was ~all of this wave's time (measured: producers
+            // alone 1.06 ms of a 1.07 ms kernel, their instructions ~0.3 ms)
+            int16_t nx[15];
+#pragma unroll
+            for (int j = 0; j < 15; j++) nx[j] = 0;
+            auto fetch = [&](int c) {
                 const int t = c * VIT_CHUNK + ptt;
                 if (t < pT) {
-                    float x;
-                    if (RAW) {
-                        float m = pxg_block_mean(raw + base + (int64_t)t * stride, stride, k, offset);
-                        float y = scale * m;
-                        x = y + shift;
-                    } else {
-                        x = sig[base + t];
-                    }
-                    const double xd = (double)x;
-                    double* dst = &em[c & 1][prr * EM_STRIDE + ptt * PXG_MAX_STATES];
+                    const int16_t* src = raw + base + (int64_t)t * 15;
 #pragma unroll
-                    for (int q = 0; q < PXG_MAX_STATES; q++)
-                        if (q < S) dst[q] = hmm_emission(H, lsetab, q, xd);
+                    for (int j = 0; j < 15; j++) nx[j] = src[j];
                 }
+            };
+            if (n_chunks > 0) fetch(0);
+            for (int c = 0; c <= n_chunks; c++) {
+                if (c < n_chunks) {
+                    int16_t cur[15];
+#pragma unroll
+                    for (int j = 0; j < 15; j++) cur[j] = nx[j];
+                    if (c + 1 < n_chunks) fetch(c + 1);
+                    if (c * VIT_CHUNK + ptt < pT) {
+                        const float m = block_mean15(cur, k, offset);
+                        const float y = scale * m;
+                        publish(c, y + shift);
+                    }
+                }
+                lds_barrier();      // chunk c is published; chunk c-1 has been consumed
             }
-            __syncthreads();        // chunk c is published; chunk c-1 has been consumed
+        } else if (!RAW) {
+            float nx = 0.0f;
+            if (n_chunks > 0 && ptt < pT) nx = sig[base + ptt];
+            for (int c = 0; c <= n_chunks; c++) {
+                if (c < n_chunks) {
+                    const float cur = nx;
+                    const int tn = (c + 1) * VIT_CHUNK + ptt;
+                    if (c + 1 < n_chunks && tn < pT) nx = sig[base + tn];
+                    if (c * VIT_CHUNK + ptt < pT) publish(c, cur);
+                }
+                lds_barrier();
+            }
+        } else {
+            for (int c = 0; c <= n_chunks; c++) {
+                const int t = c * VIT_CHUNK + ptt;
+                if (c < n_chunks && t < pT) {
+                    const float m = pxg_block_mean(raw + base + (int64_t)t * stride, stride, k, offset);
+                    const float y = scale * m;
+                    publish(c, y + shift);
+                }
+                lds_barrier();
+            }
         }
         return;
     }
@@ -216,135 +269,187 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
             prk[k] = hit ? d : prk[k];
         }
     }
+    // ties: candidate k replaces the running best (reached over span j) iff prk[k] < prk[j].
+    // Those comparisons are lane constants: before[k][j] = lanes where span k outranks span j,
+    // and which span holds the best is a partition of the wave kept in scalar masks, so the
+    // tie rule costs no vector instruction inside the loop.
+    unsigned long long before[PXG_MAX_STATES][PXG_MAX_STATES];
+#pragma unroll
+    for (int k = 1; k < PXG_MAX_STATES; k++)
+#pragma unroll
+        for (int j = 0; j < k; j++)
+            before[k][j] = (((SPANS >> k) & 1u) && (j == 0 || ((SPANS >> j) & 1u))) ? __ballot(prk[k] < prk[j]) : 0ull;
     const double lstart = (s < S) ? H.log_start[s] : -__builtin_inf();
-    // lane-constant masks to stamp the 16-bit entry field of state s
-    unsigned keep[4], put[4];
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        const unsigned field = 0xFFFFu << ((unsigned)(s & 1) * 16u);
-        put[w] = (w == (s >> 1)) ? field : 0u;
-        keep[w] = ~put[w];
-    }
-    const unsigned stamp_sh = (unsigned)(s & 1) * 16u;
+    const unsigned long long state_lanes = __ballot(s < S);
 
-    double v[VIT_CHAINS];
-    unsigned ent[VIT_CHAINS][4];            // 16-bit entry step + 1 per state
-#pragma unroll
-    for (int c = 0; c < VIT_CHAINS; c++) {
-        v[c] = -__builtin_inf();
-#pragma unroll
-        for (int w = 0; w < 4; w++) ent[c][w] = 0u;
-    }
+    double v = -__builtin_inf();    // runs on past T-1 (on stale emissions, never read back) ...
+    double vfin = v;                // ... the column of step T-1 is kept here
+    BT* bpw = bp + (size_t)blockIdx.x * bp_chunks * 64 + lane;
+    // lanes of unused states read the emission of the last state: finite, and never used
+    const int es = s < S ? s : S - 1;
 
-    __syncthreads();                // chunk 0 is in em[0]
-    for (int c0 = 0; c0 < Tmax; c0 += VIT_CHUNK) {
-        const double* emc = em[(c0 / VIT_CHUNK) & 1];
-        // ---- recurrence phase ---------------------------------------------
-        const int tend = (Tmax - c0) < VIT_CHUNK ? (Tmax - c0) : VIT_CHUNK;
+    // One step.  EXACT = false is the speculative form: a candidate replaces the best iff it
+    // is strictly greater, which is the whole rule unless two candidates of a live lane are
+    // EQUAL (then pomegranate's in-edge order decides).  Its dependent chain is
+    // add -> cmp -> select per span, all vector; the exact form adds two scalar mask
+    // operations per span in the middle of that chain.  `ties` collects the live lanes that
+    // saw an equality; a chunk that saw one is run again with EXACT = true (the first chunk,
+    // while states are still unreachable at -inf, and practically never after it).
+    auto step = [&](auto exact, int t, double e, unsigned long long& ties, BT& fields) {
+        constexpr bool EXACT = decltype(exact)::value;
+        const unsigned long long live = __ballot(t < T) & state_lanes;
+        double cand[PXG_MAX_STATES];
+#pragma unroll
+        for (int k = 1; k < PXG_MAX_STATES; k++)
+            if ((SPANS >> k) & 1u) cand[k] = dpp_shr_f64(v, k) + lpk[k];
+        double best = v + lpk[0];    // span 0 = self loop (or -inf)
+        unsigned bd = 0u;
+        if (EXACT) {
+            unsigned long long holds[PXG_MAX_STATES];      // holds[j]: lanes whose best came over span j
+            holds[0] = ~0ull;
+#pragma unroll
+            for (int k = 1; k < PXG_MAX_STATES; k++) {
+                holds[k] = 0ull;
+                if ((SPANS >> k) & 1u) {
+                    unsigned long long outranks = 0ull;
+#pragma unroll
+                    for (int j = 0; j < k; j++) outranks |= holds[j] & before[k][j];
+                    const unsigned long long take =
+                        __ballot(cand[k] > best) | (__ballot(cand[k] == best) & outranks);
+                    best = pxg_sel_f64(take, best, cand[k]);
+                    bd = pxg_sel_u32(take, bd, (unsigned)k);
+#pragma unroll
+                    for (int j = 0; j < k; j++) holds[j] &= ~take;
+                    holds[k] = take;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 1; k < PXG_MAX_STATES; k++) {
+                if ((SPANS >> k) & 1u) {
+                    ties |= __ballot(cand[k] == best) & live;
+                    const bool take = cand[k] > best;
+                    best = take ? cand[k] : best;
+                    bd = take ? (unsigned)k : bd;
+                }
+            }
+        }
+        v = best + e;
+        vfin = pxg_sel_f64(__ballot(t == T - 1), vfin, v);
+        fields = (fields << FB) | (BT)bd;          // steps at or after T leave fields nobody reads
+    };
+    auto run_chunk = [&](auto exact, const double* emc, int c0, int tend, unsigned long long& ties) {
+        BT fields = 0;
+        int tt = 0;
+        if (c0 == 0) {              // t = 0: out of the silent start state, no back-pointer
+            v = (0 < T && s < S) ? lstart + emc[0] : v;
+            vfin = pxg_sel_f64(__ballot(T == 1), vfin, v);
+            tt = 1;
+        }
 #pragma unroll 1
-        for (int tt = 0; tt < tend; tt++) {
-            const int t = c0 + tt;
-#pragma unroll
-            for (int c = 0; c < VIT_CHAINS; c++) {
-                const bool act = (t < T[c]) && (s < S);
-                const double e = act ? emc[(c * 8 + rr) * EM_STRIDE + tt * PXG_MAX_STATES + s] : 0.0;
-                // v and the entry vectors of the lanes below, for the spans in use
-                double vs[PXG_MAX_STATES];
-                unsigned es[PXG_MAX_STATES][NW];
-#pragma unroll
-                for (int k = 1; k < PXG_MAX_STATES; k++) {
-                    if ((SPANS >> k) & 1u) {
-                        vs[k] = dpp_shr_f64(v[c], k);
-#pragma unroll
-                        for (int w = 0; w < NW; w++) es[k][w] = dpp_shr_u32(ent[c][w], k);
-                    }
-                }
-                if (t == 0) {                       // wave-uniform
-                    if (act) {
-                        v[c] = lstart + e;
-#pragma unroll
-                        for (int w = 0; w < NW; w++)
-                            ent[c][w] = pxg_bfi(put[w], 1u << stamp_sh, ent[c][w]);
-                    }
-                } else {
-                    double best = v[c] + lpk[0];    // span 0 = self loop (or -inf)
-                    int bd = 0, bpr = prk[0];
-#pragma unroll
-                    for (int k = 1; k < PXG_MAX_STATES; k++) {
-                        if ((SPANS >> k) & 1u) {
-                            const double cand = vs[k] + lpk[k];
-                            // three plain compares into SGPR masks (the short-circuit form
-                            // compiled into nested exec-mask branches)
-                            const unsigned long long take =
-                                __ballot(cand > best) | (__ballot(cand == best) & __ballot(prk[k] < bpr));
-                            best = pxg_sel_f64(take, best, cand);
-                            bd = (int)pxg_sel_u32(take, (unsigned)bd, (unsigned)k);
-                            bpr = (int)pxg_sel_u32(take, (unsigned)bpr, (unsigned)prk[k]);
-                        }
-                    }
-                    const unsigned long long mact = __ballot(act);
-                    v[c] = pxg_sel_f64(mact, v[c], best + e);
-                    unsigned ne[NW];
-#pragma unroll
-                    for (int w = 0; w < NW; w++) ne[w] = ent[c][w];
-#pragma unroll
-                    for (int k = 1; k < PXG_MAX_STATES; k++) {
-                        if ((SPANS >> k) & 1u) {
-                            const unsigned long long mk = __ballot(bd == k);
-#pragma unroll
-                            for (int w = 0; w < NW; w++) ne[w] = pxg_sel_u32(mk, ne[w], es[k][w]);
-                        }
-                    }
-                    const unsigned long long mmove = __ballot(act && bd != 0);
-                    const unsigned stamp = (unsigned)(t + 1) << stamp_sh;
-#pragma unroll
-                    for (int w = 0; w < NW; w++)
-                        ent[c][w] = pxg_sel_u32(mmove, ent[c][w], pxg_bfi(put[w], stamp, ne[w]));
-                }
-            }
+        for (; tt < tend; tt++) step(exact, c0 + tt, emc[tt * PXG_MAX_STATES], ties, fields);
+        return (BT)(fields << ((VIT_CHUNK - tend) * FB));      // a short last chunk: step tt still sits at field 15 - tt
+    };
+
+    lds_barrier();                  // chunk 0 is in em[0]
+    for (int c0 = 0; c0 < Tmax; c0 += VIT_CHUNK) {
+        const double* emc = em[(c0 / VIT_CHUNK) & 1] + rr * EM_STRIDE + es;
+        const int tend = (Tmax - c0) < VIT_CHUNK ? (Tmax - c0) : VIT_CHUNK;
+        const double v0 = v, vfin0 = vfin;
+        unsigned long long ties = 0ull, unused = 0ull;
+        BT fields = run_chunk(std::false_type(), emc, c0, tend, ties);
+        if (ties != 0ull) {
+            v = v0;
+            vfin = vfin0;
+            fields = run_chunk(std::true_type(), emc, c0, tend, unused);
         }
-        __syncthreads();            // this chunk is consumed; the next one is published
+        bpw[(size_t)(c0 / VIT_CHUNK) * 64] = fields;
+        lds_barrier();              // this chunk is consumed; the next one is published
     }
+    v = vfin;
 
+    // ---- termination: first maximum of the last column in name-sorted order ------------
+    double bestv = -__builtin_inf();
+    int end_s = H.order[0];
+    for (int q = 0; q < S; q++) {
+        const double vk = shfl_f64(v, rr * 8 + H.order[q]);
+        if (q == 0 || vk > bestv) {
+            bestv = vk;
+            end_s = H.order[q];
+        }
+    }
+    if (s == 0 && r < n_reads) {
+        const bool ran = valid_read && T > 0;
+        end_state[r] = ran ? end_s : -1;
+        if (logp_out) logp_out[r] = ran ? bestv : -__builtin_inf();
+    }
+}
+
+// One wave per read: walk the back-pointer fields from the winning state at T-1 down to the
+// start.  For the state the path is in, 64 lanes fetch its fields of 64 consecutive chunks
+// (newest first), the newest non-zero field at or before the current step is the step the
+// state was entered and the span it was entered over.
+template <typename BT>
+__global__ __launch_bounds__(64) void k_viterbi_trace(
+    int64_t n_reads, PxgHmmDev H, bool raw_lengths, const int64_t* __restrict__ off, int stride,
+    int scan_pooled, const BT* __restrict__ bp, int bp_chunks, const int32_t* __restrict__ end_state,
+    int32_t* __restrict__ status, int32_t* __restrict__ segs)
+{
+    constexpr int FB = BpFields<BT>::bits;
+    const int64_t r = blockIdx.x;
+    const int lane = threadIdx.x;
+    int32_t* first = segs + r * 2 * PXG_N_SEGMENTS;
+    int32_t* last = first + PXG_N_SEGMENTS;
+    int cur = end_state[r];
+    if (cur < 0) {                                // not run, or no samples
+        if (lane < 2 * PXG_N_SEGMENTS) first[lane] = -1;
+        return;
+    }
+    const int64_t len = off[r + 1] - off[r];
+    const int64_t P = raw_lengths ? len / stride : len;
+    const int T = (int)(P < scan_pooled ? P : scan_pooled);
+    const BT* mine = bp + ((size_t)(r / VIT_READS) * bp_chunks) * 64 + (r % VIT_READS) * 8;
+    int f[PXG_MAX_STATES], l[PXG_MAX_STATES];
 #pragma unroll
-    for (int c = 0; c < VIT_CHAINS; c++) {
-        // ---- termination: first maximum of the last column in name-sorted order -
-        double bestv = -__builtin_inf();
-        int end_lane = rr * 8 + H.order[0];
-        for (int q = 0; q < S; q++) {
-            const int ln = rr * 8 + H.order[q];
-            const double vk = shfl_f64(v[c], ln);
-            if (q == 0 || vk > bestv) {
-                bestv = vk;
-                end_lane = ln;
+    for (int q = 0; q < PXG_MAX_STATES; q++) f[q] = l[q] = -1;
+    auto put = [&](int (&a)[PXG_MAX_STATES], int q, int val) {
+#pragma unroll
+        for (int i = 0; i < PXG_MAX_STATES; i++) a[i] = (i == q) ? val : a[i];
+    };
+    put(l, cur, T - 1);
+    int t = T - 1;
+    for (int hops = 0; hops < PXG_MAX_STATES; hops++) {
+        int entered = 0, span = 0;                // entered stays 0: the path started in `cur`
+        bool found = false;
+        for (int cb = t / VIT_CHUNK; cb >= 0 && !found; cb -= 64) {
+            const int c = cb - lane;
+            BT w = c >= 0 ? mine[(size_t)c * 64 + cur] : (BT)0;
+            if (c == t / VIT_CHUNK)               // drop the steps after t
+                w &= ~(BT)0 << ((VIT_CHUNK - 1 - t % VIT_CHUNK) * FB);
+            const unsigned long long nz = __ballot(w != 0);
+            if (nz) {
+                const int src = __builtin_ctzll(nz);          // lowest lane = newest chunk
+                const int low = (sizeof(BT) == 8 ? __builtin_ctzll((unsigned long long)w | (w == 0))
+                                                 : __builtin_ctz((unsigned)w | (w == 0))) / FB;
+                const int my_t = c * VIT_CHUNK + (VIT_CHUNK - 1 - low);
+                const int my_span = (int)((w >> (low * FB)) & (BT)((1 << FB) - 1));
+                entered = __shfl(my_t, src);
+                span = __shfl(my_span, src);
+                found = true;
             }
         }
-        unsigned fe[4] = { 0u, 0u, 0u, 0u };
+        put(f, cur, entered);
+        if (!found) break;
+        cur -= span;
+        put(l, cur, entered - 1);
+        t = entered - 1;
+    }
+    if (lane == 0) {
 #pragma unroll
-        for (int w = 0; w < NW; w++) fe[w] = (unsigned)__shfl((int)ent[c][w], end_lane);
-
-        if (s == 0 && r[c] < n_reads) {
-            int32_t* first = segs + r[c] * 2 * PXG_N_SEGMENTS;
-            int32_t* last = first + PXG_N_SEGMENTS;
-            for (int q = 0; q < PXG_N_SEGMENTS; q++) first[q] = last[q] = -1;
-            if (valid_read[c] && T[c] > 0) {
-                int prev = -1;
-#pragma unroll
-                for (int q = 0; q < PXG_MAX_STATES; q++) {
-                    const int en = (int)((fe[q >> 1] >> ((q & 1) * 16)) & 0xFFFFu);
-                    if (q >= S || en == 0) continue;
-                    first[q] = en - 1;
-                    if (prev >= 0) last[prev] = en - 2;
-                    prev = q;
-                }
-                if (prev >= 0) last[prev] = T[c] - 1;
-                if (logp_out) logp_out[r[c]] = bestv;
-                if (status != nullptr && H.adapter_state >= 0 && first[H.adapter_state] < 0)
-                    status[r[c]] = PXG_ST_ADAPTER_NOT_DETECTED;
-            } else if (logp_out) {
-                logp_out[r[c]] = -__builtin_inf();
-            }
-        }
+        for (int q = 0; q < PXG_MAX_STATES; q++)
+            if (q < PXG_N_SEGMENTS) { first[q] = f[q]; last[q] = l[q]; }
+        if (status != nullptr && H.adapter_state >= 0 && f[H.adapter_state] < 0)
+            status[r] = PXG_ST_ADAPTER_NOT_DETECTED;
     }
 }
 
@@ -356,9 +461,45 @@ static int check_supported(pxg_ctx* ctx, int which)
                    "the back-pointer scan of pxg_batch_unsplit_scan)";
         return PXG_E_UNSUPPORTED;
     }
-    if (ctx->cfg.segmentation_scan_limit / ctx->cfg.stride >= 65535) {
-        ctx->err = "segmentation_scan_limit/stride must be < 65535";
-        return PXG_E_UNSUPPORTED;
+    return PXG_OK;
+}
+
+// spans {1,2,3} fit 2-bit fields (the shipped model uses {1,2}); anything wider takes 4 bits
+template <bool RAW>
+static int launch_viterbi(pxg_ctx* ctx, const PxgHmmDev& H, int64_t n, const int16_t* raw, const float* sig,
+                          const int64_t* off, const pxg_calib* cal, const float* ss, int stride, int scan,
+                          int max_steps, int32_t* status, int32_t* segs, double* logp)
+{
+    const int64_t blocks = (n + VIT_READS - 1) / VIT_READS;
+    const int bp_chunks = std::max(1, (std::min(scan, max_steps) + VIT_CHUNK - 1) / VIT_CHUNK);
+    const bool narrow = (H.shift_mask & ~7u) == 0 && H.n_states <= 6;
+    int rc = pxg_reserve(ctx, ctx->vit_bp, (size_t)blocks * bp_chunks * 64 * (narrow ? 4 : 8));
+    if (rc || (rc = pxg_reserve(ctx, ctx->vit_end, (size_t)n))) return rc;
+    constexpr int GEN = 0;
+    if (narrow) {
+        uint32_t* bp = (uint32_t*)ctx->vit_bp.p;
+        if (RAW && stride == 15)
+            hipLaunchKernelGGL((k_viterbi_ltr<RAW, RAW ? 15 : GEN, 0x6u, uint32_t>), dim3((unsigned)blocks),
+                               dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, status,
+                               bp, bp_chunks, ctx->vit_end.p, logp, ctx->d_lsetab);
+        else
+            hipLaunchKernelGGL((k_viterbi_ltr<RAW, GEN, 0x6u, uint32_t>), dim3((unsigned)blocks),
+                               dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, status,
+                               bp, bp_chunks, ctx->vit_end.p, logp, ctx->d_lsetab);
+        hipLaunchKernelGGL((k_viterbi_trace<uint32_t>), dim3((unsigned)n), dim3(64), 0, ctx->stream, n, H, RAW,
+                           off, stride, scan, bp, bp_chunks, ctx->vit_end.p, status, segs);
+    } else {
+        uint64_t* bp = (uint64_t*)ctx->vit_bp.p;
+        if (RAW && stride == 15)
+            hipLaunchKernelGGL((k_viterbi_ltr<RAW, RAW ? 15 : GEN, 0xFEu, uint64_t>), dim3((unsigned)blocks),
+                               dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, status,
+                               bp, bp_chunks, ctx->vit_end.p, logp, ctx->d_lsetab);
+        else
+            hipLaunchKernelGGL((k_viterbi_ltr<RAW, GEN, 0xFEu, uint64_t>), dim3((unsigned)blocks),
+                               dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, status,
+                               bp, bp_chunks, ctx->vit_end.p, logp, ctx->d_lsetab);
+        hipLaunchKernelGGL((k_viterbi_trace<uint64_t>), dim3((unsigned)n), dim3(64), 0, ctx->stream, n, H, RAW,
+                           off, stride, scan, bp, bp_chunks, ctx->vit_end.p, status, segs);
     }
     return PXG_OK;
 }
@@ -371,34 +512,16 @@ int pxg_launch_segment_raw(pxg_ctx* ctx, int64_t n, const int16_t* raw, const in
     int rc = check_supported(ctx, 0);
     if (rc) return rc;
     const int scan = ctx->cfg.segmentation_scan_limit / ctx->cfg.stride;
-    const dim3 grid((unsigned)((n + VIT_READS - 1) / VIT_READS));
-    const PxgHmmDev& H = ctx->hmm[0];
-    if ((H.shift_mask & ~7u) == 0 && H.n_states <= 6)      // spans {1,2}: the shipped model
-        hipLaunchKernelGGL((k_viterbi_ltr<true, 0x6u, 3>), grid, dim3(VIT_THREADS), 0, ctx->stream, n, H, raw,
-                           (const float*)nullptr, off, cal, ss, ctx->cfg.stride, scan,
-                           (int32_t*)status, segs, (double*)nullptr, ctx->d_lsetab);
-    else
-        hipLaunchKernelGGL((k_viterbi_ltr<true, 0xFEu, 4>), grid, dim3(VIT_THREADS), 0, ctx->stream, n, H, raw,
-                           (const float*)nullptr, off, cal, ss, ctx->cfg.stride, scan,
-                           (int32_t*)status, segs, (double*)nullptr, ctx->d_lsetab);
-    return PXG_OK;
+    return launch_viterbi<true>(ctx, ctx->hmm[0], n, raw, nullptr, off, cal, ss, ctx->cfg.stride, scan, scan,
+                                (int32_t*)status, segs, nullptr);
 }
 
 int pxg_launch_viterbi_f32(pxg_ctx* ctx, int which, int64_t n, const float* sig,
-                           const int64_t* off, int32_t* segs, double* logp)
+                           const int64_t* off, int max_steps, int32_t* segs, double* logp)
 {
     if (n <= 0) return PXG_OK;
     int rc = check_supported(ctx, which);
     if (rc) return rc;
-    const dim3 grid((unsigned)((n + VIT_READS - 1) / VIT_READS));
-    const PxgHmmDev& H = ctx->hmm[which];
-    if ((H.shift_mask & ~7u) == 0 && H.n_states <= 6)
-        hipLaunchKernelGGL((k_viterbi_ltr<false, 0x6u, 3>), grid, dim3(VIT_THREADS), 0, ctx->stream, n, H,
-                           (const int16_t*)nullptr, sig, off, (const pxg_calib*)nullptr,
-                           (const float*)nullptr, 1, 65534, (int32_t*)nullptr, segs, logp, ctx->d_lsetab);
-    else
-        hipLaunchKernelGGL((k_viterbi_ltr<false, 0xFEu, 4>), grid, dim3(VIT_THREADS), 0, ctx->stream, n, H,
-                           (const int16_t*)nullptr, sig, off, (const pxg_calib*)nullptr,
-                           (const float*)nullptr, 1, 65534, (int32_t*)nullptr, segs, logp, ctx->d_lsetab);
-    return PXG_OK;
+    return launch_viterbi<false>(ctx, ctx->hmm[which], n, nullptr, sig, off, nullptr, nullptr, 1, 1 << 30,
+                                 max_steps, nullptr, segs, logp);
 }

@@ -276,7 +276,7 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     release(ctx->lstm_q); release(ctx->lstm_state); release(ctx->lstm_err);
     release(ctx->demux_q); release(ctx->demux_state);
     release(ctx->spare.raw); release(ctx->spare.offsets); release(ctx->spare.calib); release(ctx->spare.inject);
-    release(ctx->results); release(ctx->polya_ev); release(ctx->polya_over); release(ctx->polya_retry); release(ctx->polya_out); release(ctx->spikes);
+    release(ctx->results); release(ctx->vit_bp); release(ctx->vit_end); release(ctx->polya_ev); release(ctx->polya_over); release(ctx->polya_retry); release(ctx->polya_out); release(ctx->spikes);
     release(ctx->ev_first); release(ctx->ev_off); release(ctx->ev_mean); release(ctx->ev_scaled);
     release(ctx->unsplit_scr); release(ctx->unsplit_iv); release(ctx->unsplit_cnt); release(ctx->unsplit_ivoff);
     release(ctx->unsplit_cand); release(ctx->unit_off); release(ctx->n_win);
@@ -851,15 +851,15 @@ extern "C" int pxg_viterbi(pxg_ctx* ctx, int which_model, int64_t n, const float
     HOOK_BEGIN
     if (n <= 0) return PXG_OK;
     if (which_model < 0 || which_model > 1) return fail(ctx, PXG_E_INVALID, "which_model");
-    for (int64_t i = 0; i < n; i++)
-        if (off[i + 1] - off[i] >= 65535)
-            return fail(ctx, PXG_E_UNSUPPORTED, "pxg_viterbi: sequences must be < 65535 steps");
+    int64_t longest = 0;
+    for (int64_t i = 0; i < n; i++) longest = std::max(longest, off[i + 1] - off[i]);
+    if (longest >= (1 << 30)) return fail(ctx, PXG_E_UNSUPPORTED, "pxg_viterbi: sequences must be < 2^30 steps");
     float* d_sig = S.put(signal_arena, (size_t)off[n], ctx->stream);
     int64_t* d_off = S.put(off, (size_t)n + 1, ctx->stream);
     int32_t* d_segs = S.alloc<int32_t>((size_t)n * 2 * PXG_N_SEGMENTS);
     double* d_logp = S.alloc<double>((size_t)n);
     HOOK_CHECK(d_sig && d_off && d_segs && d_logp);
-    int rc = pxg_launch_viterbi_f32(ctx, which_model, n, d_sig, d_off, d_segs, d_logp);
+    int rc = pxg_launch_viterbi_f32(ctx, which_model, n, d_sig, d_off, (int)longest, d_segs, d_logp);
     if (rc) return rc;
     std::vector<int32_t> segs((size_t)n * 2 * PXG_N_SEGMENTS);
     HOOK_GET(segs.data(), d_segs, segs.size());

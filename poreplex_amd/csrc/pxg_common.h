@@ -272,6 +272,8 @@ struct pxg_ctx {
     DevBuf<float> ss;            // n x 2
     DevBuf<int32_t> status;      // n
     DevBuf<int32_t> segs;        // n x 2 x PXG_N_SEGMENTS
+    DevBuf<char> vit_bp;         // K3 back-pointer fields, [block][chunk][64 lanes]
+    DevBuf<int32_t> vit_end;     // K3 winning state per read (-1: not run)
     DevBuf<int32_t> idx_scaler;  // compacted read indices
     DevBuf<int32_t> idx_demux;
     DevBuf<int32_t> counters;    // [0] scaler count, [1] demux count
@@ -352,7 +354,7 @@ int pxg_launch_segment_raw(pxg_ctx* ctx, int64_t n, const int16_t* raw, const in
                            int32_t* segs);
 // Viterbi on already pooled float signals (test hook)
 int pxg_launch_viterbi_f32(pxg_ctx* ctx, int which, int64_t n, const float* sig,
-                           const int64_t* off, int32_t* segs, double* logp);
+                           const int64_t* off, int max_steps, int32_t* segs, double* logp);
 int pxg_launch_barcode_window_raw(pxg_ctx* ctx, int64_t n, const int16_t* raw,
                                   const int64_t* off, const pxg_calib* cal, const float* ss,
                                   const int32_t* status, const int32_t* segs, float* win,
