@@ -75,19 +75,6 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// pxg_block_mean for 15 samples already in registers (same NumPy pairwise order)
-__device__ __forceinline__ float block_mean15(const int16_t (&x)[15], double k, double offset)
-{
-    float r[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) r[j] = pxg_raw2pa(x[j], k, offset);
-    float s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-#pragma unroll
-    for (int i = 8; i < 15; i++) s += pxg_raw2pa(x[i], k, offset);
-    s = 0.0f + s;
-    return s / 15.0f;
-}
-
 #define EM_STRIDE (VIT_CHUNK * PXG_MAX_STATES + 8)   // +8 doubles: spread reads over banks
 
 // value of the lane `k` below inside a 16-lane row (DPP row_shr:k).  bound_ctrl: a lane
@@ -214,7 +201,7 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
                     for (int j = 0; j < 15; j++) cur[j] = nx[j];
                     if (c + 1 < n_chunks) fetch(c + 1);
                     if (c * VIT_CHUNK + ptt < pT) {
-                        const float m = block_mean15(cur, k, offset);
+                        const float m = pxg_block_mean15(cur, k, offset);
                         const float y = scale * m;
                         publish(c, y + shift);
                     }

@@ -168,10 +168,29 @@ __device__ __forceinline__ float pxg_raw2pa(int16_t raw, double k, double offset
 // NumPy float32 pairwise add.reduce of exactly `stride` pA values starting at
 // raw[0] (n < 8: sequential; 8..128: eight partial sums + tail), then the
 // float32 true-divide of numpy's mean (signal_loader.py:224-225).
+// the shipped stride, samples already in registers
+__device__ __forceinline__ float pxg_block_mean15(const int16_t (&x)[15], double k, double offset)
+{
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) r[j] = pxg_raw2pa(x[j], k, offset);
+    float s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+    for (int i = 8; i < 15; i++) s += pxg_raw2pa(x[i], k, offset);
+    s = 0.0f + s;
+    return s / 15.0f;
+}
+
 __device__ __forceinline__ float pxg_block_mean(const int16_t* __restrict__ raw, int stride,
                                                 double k, double offset)
 {
     float s;
+    if (stride == 15) {          // all 15 loads in flight at once, no loop-carried address
+        int16_t x[15];
+#pragma unroll
+        for (int j = 0; j < 15; j++) x[j] = raw[j];
+        return pxg_block_mean15(x, k, offset);
+    }
     if (stride < 8) {
         s = 0.0f;
         for (int i = 0; i < stride; i++) s += pxg_raw2pa(raw[i], k, offset);
