@@ -101,7 +101,10 @@ __device__ __forceinline__ double dpp_shr_f64(double v, int k)
     return __hiloint2double(hi, lo);
 }
 
-// RAW=true : signal is pooled on the fly from int16 DAQ samples
+// RAW=true : signal is pooled on the fly from int16 DAQ samples; `sig`, if not null, is K1's
+//            left-padded head tensor [n][head_width] -- the block means of the first
+//            min(n_raw, head_limit) samples, by the same function -- and is read instead of
+//            pooling those samples a second time
 // RAW=false: signal is an already pooled+scaled float arena (test hook)
 // SPANS: bit k set = some edge goes from state s-k to state s (k >= 1)
 // BT: register of back-pointer fields of one chunk -- uint32_t = 2 bits per step (spans <= 3),
@@ -114,8 +117,8 @@ template <bool RAW, int POOL, unsigned SPANS, typename BT>
 __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
     int64_t n_reads, PxgHmmDev H, const int16_t* __restrict__ raw, const float* __restrict__ sig,
     const int64_t* __restrict__ off, const pxg_calib* __restrict__ cal,
-    const float* __restrict__ ss, int stride, int scan_pooled, const int32_t* __restrict__ status,
-    BT* __restrict__ bp /* [block][chunk][64 lanes] */, int bp_chunks,
+    const float* __restrict__ ss, int stride, int scan_pooled, int head_width, int head_limit,
+    const int32_t* __restrict__ status, BT* __restrict__ bp /* [block][chunk][64 lanes] */, int bp_chunks,
     int32_t* __restrict__ end_state, double* __restrict__ logp_out, const double* __restrict__ lsetab_g)
 {
     constexpr int FB = BpFields<BT>::bits;
@@ -183,11 +186,21 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
             // memory round trip per chunk was ~all of this wave's time (measured: producers
             // alone 1.06 ms of a 1.07 ms kernel, their instructions ~0.3 ms)
             int16_t nx[15];
+            float nxh = 0.0f;
 #pragma unroll
             for (int j = 0; j < 15; j++) nx[j] = 0;
+            int pNM = 0;                   // steps whose block mean K1 left in the head tensor
+            const float* hrow = sig;
+            if (pvalid && sig != nullptr) {
+                const int64_t len = off[pr + 1] - off[pr];
+                pNM = (int)((len < head_limit ? len : head_limit) / 15);
+                hrow = sig + pr * (int64_t)head_width + (head_width - pNM);
+            }
             auto fetch = [&](int c) {
                 const int t = c * VIT_CHUNK + ptt;
-                if (t < pT) {
+                if (t < pNM) {
+                    nxh = hrow[t];
+                } else if (t < pT) {
                     const int16_t* src = raw + base + (int64_t)t * 15;
 #pragma unroll
                     for (int j = 0; j < 15; j++) nx[j] = src[j];
@@ -197,11 +210,15 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
             for (int c = 0; c <= n_chunks; c++) {
                 if (c < n_chunks) {
                     int16_t cur[15];
+                    const float curh = nxh;
 #pragma unroll
                     for (int j = 0; j < 15; j++) cur[j] = nx[j];
                     if (c + 1 < n_chunks) fetch(c + 1);
-                    if (c * VIT_CHUNK + ptt < pT) {
-                        const float m = pxg_block_mean15(cur, k, offset);
+                    const int t = c * VIT_CHUNK + ptt;
+                    if (t < pT) {
+                        float m;
+                        if (t < pNM) m = curh;
+                        else m = pxg_block_mean15(cur, k, offset);
                         const float y = scale * m;
                         publish(c, y + shift);
                     }
@@ -457,6 +474,7 @@ static int launch_viterbi(pxg_ctx* ctx, const PxgHmmDev& H, int64_t n, const int
                           const int64_t* off, const pxg_calib* cal, const float* ss, int stride, int scan,
                           int max_steps, int32_t* status, int32_t* segs, double* logp)
 {
+    const int head_width = ctx->cfg.scaler_length / ctx->cfg.stride, head_limit = ctx->cfg.scaler_length;
     const int64_t blocks = (n + VIT_READS - 1) / VIT_READS;
     const int bp_chunks = std::max(1, (std::min(scan, max_steps) + VIT_CHUNK - 1) / VIT_CHUNK);
     const bool narrow = (H.shift_mask & ~7u) == 0 && H.n_states <= 6;
@@ -467,11 +485,11 @@ static int launch_viterbi(pxg_ctx* ctx, const PxgHmmDev& H, int64_t n, const int
         uint32_t* bp = (uint32_t*)ctx->vit_bp.p;
         if (RAW && stride == 15)
             hipLaunchKernelGGL((k_viterbi_ltr<RAW, RAW ? 15 : GEN, 0x6u, uint32_t>), dim3((unsigned)blocks),
-                               dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, status,
+                               dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, head_width, head_limit, status,
                                bp, bp_chunks, ctx->vit_end.p, logp, ctx->d_lsetab);
         else
             hipLaunchKernelGGL((k_viterbi_ltr<RAW, GEN, 0x6u, uint32_t>), dim3((unsigned)blocks),
-                               dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, status,
+                               dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, head_width, head_limit, status,
                                bp, bp_chunks, ctx->vit_end.p, logp, ctx->d_lsetab);
         hipLaunchKernelGGL((k_viterbi_trace<uint32_t>), dim3((unsigned)n), dim3(64), 0, ctx->stream, n, H, RAW,
                            off, stride, scan, bp, bp_chunks, ctx->vit_end.p, status, segs);
@@ -479,11 +497,11 @@ static int launch_viterbi(pxg_ctx* ctx, const PxgHmmDev& H, int64_t n, const int
         uint64_t* bp = (uint64_t*)ctx->vit_bp.p;
         if (RAW && stride == 15)
             hipLaunchKernelGGL((k_viterbi_ltr<RAW, RAW ? 15 : GEN, 0xFEu, uint64_t>), dim3((unsigned)blocks),
-                               dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, status,
+                               dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, head_width, head_limit, status,
                                bp, bp_chunks, ctx->vit_end.p, logp, ctx->d_lsetab);
         else
             hipLaunchKernelGGL((k_viterbi_ltr<RAW, GEN, 0xFEu, uint64_t>), dim3((unsigned)blocks),
-                               dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, status,
+                               dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, head_width, head_limit, status,
                                bp, bp_chunks, ctx->vit_end.p, logp, ctx->d_lsetab);
         hipLaunchKernelGGL((k_viterbi_trace<uint64_t>), dim3((unsigned)n), dim3(64), 0, ctx->stream, n, H, RAW,
                            off, stride, scan, bp, bp_chunks, ctx->vit_end.p, status, segs);
@@ -492,14 +510,14 @@ static int launch_viterbi(pxg_ctx* ctx, const PxgHmmDev& H, int64_t n, const int
 }
 
 int pxg_launch_segment_raw(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
-                           const pxg_calib* cal, const float* ss, const int32_t* status,
-                           int32_t* segs)
+                           const pxg_calib* cal, const float* ss, const float* head_or_null,
+                           const int32_t* status, int32_t* segs)
 {
     if (n <= 0) return PXG_OK;
     int rc = check_supported(ctx, 0);
     if (rc) return rc;
     const int scan = ctx->cfg.segmentation_scan_limit / ctx->cfg.stride;
-    return launch_viterbi<true>(ctx, ctx->hmm[0], n, raw, nullptr, off, cal, ss, ctx->cfg.stride, scan, scan,
+    return launch_viterbi<true>(ctx, ctx->hmm[0], n, raw, head_or_null, off, cal, ss, ctx->cfg.stride, scan, scan,
                                 (int32_t*)status, segs, nullptr);
 }
 

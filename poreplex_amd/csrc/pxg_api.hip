@@ -597,8 +597,10 @@ extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
     }
     if (stage_mask & PXG_STAGE_SEGMENT) {
         pxg_timer_begin(ctx, PXG_T_SEGMENT);
+        // with the scaler stage in the same run K1's block means of the head are still in HBM
+        const float* head = (stage_mask & PXG_STAGE_SCALER) ? ctx->head.p : nullptr;
         if ((rc = pxg_launch_segment_raw(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p,
-                                         ctx->status.p, ctx->segs.p))) return rc;
+                                         head, ctx->status.p, ctx->segs.p))) return rc;
         pxg_timer_end(ctx, PXG_T_SEGMENT);
     }
     if (stage_mask & PXG_STAGE_BARCODE) {

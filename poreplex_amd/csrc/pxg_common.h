@@ -369,8 +369,8 @@ int pxg_launch_scaler_transform(pxg_ctx* ctx, int64_t n, const float* pred, floa
                                 int32_t* status, const int32_t* idx, const int32_t* count);
 // segmentation of raw reads (pool + scale + Viterbi + run summary)
 int pxg_launch_segment_raw(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
-                           const pxg_calib* cal, const float* ss, const int32_t* status,
-                           int32_t* segs);
+                           const pxg_calib* cal, const float* ss, const float* head_or_null,
+                           const int32_t* status, int32_t* segs);
 // Viterbi on already pooled float signals (test hook)
 int pxg_launch_viterbi_f32(pxg_ctx* ctx, int which, int64_t n, const float* sig,
                            const int64_t* off, int max_steps, int32_t* segs, double* logp);
