@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
     const int64_t* __restrict__ unit_off, const float* __restrict__ scaled,
     unsigned* __restrict__ bpbuf /* [wave][tmax][8 groups] */,
     int64_t* __restrict__ cand /* n_units x UN_WCAND x 2 */, int32_t* __restrict__ cand_cnt,
-    const double* __restrict__ lsetab_g)
+    const double* __restrict__ lsetab_g, unsigned long long* __restrict__ queue)
 {
     __shared__ double em[UN_READS * UN_EM_STRIDE];
     __shared__ double lsetab[PXG_LSE_TAB_DOUBLES];
@@ -290,8 +290,14 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
     }
     const double lstart = (s < S) ? H.log_start[s] : -__builtin_inf();
 
-    for (int64_t ubase = (int64_t)blockIdx.x * UN_READS; ubase < n_units;
-         ubase += (int64_t)gridDim.x * UN_READS) {
+    // units are handed out 8 at a time from one counter: windows differ in length (the last
+    // window of a read is short), and a static stride left the waves with 1 or 2 rounds each
+    for (;;) {
+        unsigned long long claimed = 0ull;
+        if (lane == 0) claimed = atomicAdd(queue, (unsigned long long)UN_READS);
+        const int64_t ubase = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(claimed >> 32)) << 32)
+                                        | (unsigned)__builtin_amdgcn_readfirstlane((int)claimed));
+        if (ubase >= n_units) break;
         // ---- which (read, window) is this 8-lane group's unit --------------------
         const int64_t u = ubase + rr;
         int64_t r = 0;
@@ -323,21 +329,37 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
         }
 
         // ---- forward pass ---------------------------------------------------
+        // (one wave per block: LDS operations of a wave complete in order, so the phases need a
+        //  compiler fence, not __syncthreads() -- whose vmcnt(0) would wait for the block means
+        //  of the NEXT chunk, requested a chunk ahead)
         double v = -__builtin_inf();
+        float xn[UN_CHUNK / 8];
+#pragma unroll
+        for (int p = 0; p < UN_CHUNK / 8; p++) {
+            const int t = p * 8 + s;
+            xn[p] = t < T ? x[k0 + t] : 0.0f;
+        }
         for (int c0 = 0; c0 < Tmax; c0 += UN_CHUNK) {
-            __syncthreads();
-#pragma unroll 1
+            float xc[UN_CHUNK / 8];
+#pragma unroll
+            for (int p = 0; p < UN_CHUNK / 8; p++) {
+                xc[p] = xn[p];
+                const int t = c0 + UN_CHUNK + p * 8 + s;
+                xn[p] = t < T ? x[k0 + t] : 0.0f;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
             for (int p = 0; p < UN_CHUNK / 8; p++) {
                 const int tt = p * 8 + s;
                 const int t = c0 + tt;
                 if (t < T) {
-                    const double xd = (double)x[k0 + t];
+                    const double xd = (double)xc[p];
 #pragma unroll
                     for (int q = 0; q < PXG_MAX_STATES; q++)
                         if (q < S) em[rr * UN_EM_STRIDE + tt * PXG_MAX_STATES + q] = un_emission(H, lsetab, q, xd);
                 }
             }
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             const int tend = (Tmax - c0) < UN_CHUNK ? (Tmax - c0) : UN_CHUNK;
 #pragma unroll 1
             for (int tt = 0; tt < tend; tt++) {
@@ -395,12 +417,24 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
             }
         };
         __syncthreads();     // this wave's table stores (lanes s == 0) before the group's loads
-        for (int tb = ((Tmax - 1) >> 3) << 3; tb >= 0; tb -= 8) {
-            unsigned m[8];
+        // 16 table words per round, the next round's already requested: the words do not depend
+        // on the path, only the bit-field chain through them does
+        constexpr int TBW = 16;
+        unsigned mn[TBW];
+        auto fetch = [&](int tb) {
 #pragma unroll
-            for (int q = 0; q < 8; q++) m[q] = (tb + q < Tmax) ? bpm[(size_t)(tb + q) * UN_READS + rr] : 0u;
+            for (int q = 0; q < TBW; q++)
+                mn[q] = (tb >= 0 && tb + q < Tmax) ? bpm[(size_t)(tb + q) * UN_READS + rr] : 0u;
+        };
+        const int tb_first = ((Tmax - 1) / TBW) * TBW;
+        fetch(Tmax > 0 ? tb_first : -1);
+        for (int tb = tb_first; tb >= 0 && Tmax > 0; tb -= TBW) {
+            unsigned m[TBW];
 #pragma unroll
-            for (int q = 7; q >= 0; q--) {
+            for (int q = 0; q < TBW; q++) m[q] = mn[q];
+            fetch(tb - TBW);
+#pragma unroll
+            for (int q = TBW - 1; q >= 0; q--) {
                 const int t = tb + q;
                 if (t >= T) continue;                // also skips t >= Tmax
                 const bool isA = cur == P.adapter_state;
@@ -514,13 +548,16 @@ int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t units_bound, int tm
     if (n <= 0) return PXG_OK;
     const UnsplitParams P = unsplit_params(ctx, stride);
     const int waves = pxg_unsplit_waves(ctx, units_bound);
+    int rcq = pxg_reserve(ctx, ctx->unsplit_q, 1);
+    if (rcq) return rcq;
+    (void)hipMemsetAsync(ctx->unsplit_q.p, 0, sizeof(unsigned long long), ctx->stream);
     unsigned* bp = (unsigned*)scratch;
     int64_t* cand = (int64_t*)candbuf;
     int32_t* cand_cnt = (int32_t*)((char*)candbuf + (size_t)(units_bound > 0 ? units_bound : 1) * UN_WCAND * 2 * sizeof(int64_t));
 #define SCAN(NIN)                                                                                      \
     hipLaunchKernelGGL(k_unsplit_scan<NIN>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, n,        \
                        tmax, ctx->hmm[1], P, cal, status, segs, first_sample, ev_off, unit_off,        \
-                       scaled, bp, cand, cand_cnt, ctx->d_lsetab)
+                       scaled, bp, cand, cand_cnt, ctx->d_lsetab, ctx->unsplit_q.p)
     const int nin = ctx->hmm[1].max_in;
     if (nin <= 2) SCAN(2);
     else if (nin <= 3) SCAN(3);
