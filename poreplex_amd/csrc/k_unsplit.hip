@@ -58,10 +58,19 @@ __global__ void k_guppy_event_means(int64_t n_reads, const int16_t* __restrict__
         // pA of the stride + 4 samples this block's medians touch, zero outside [0, len)
         float w[20];
         const int64_t q0 = e * stride;
+        if (stride == 15 && q0 >= 2 && q0 + 17 < len) {      // interior block: 19 loads in flight at once
+            int16_t x[19];
 #pragma unroll
-        for (int j = 0; j < 20; j++) {
-            const int64_t p = q0 + j - 2;
-            w[j] = (j < stride + 4 && p >= 0 && p < len) ? pxg_raw2pa(base[p], k, c.offset) : 0.0f;
+            for (int j = 0; j < 19; j++) x[j] = base[q0 + j - 2];
+#pragma unroll
+            for (int j = 0; j < 19; j++) w[j] = pxg_raw2pa(x[j], k, c.offset);
+            w[19] = 0.0f;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 20; j++) {
+                const int64_t p = q0 + j - 2;
+                w[j] = (j < stride + 4 && p >= 0 && p < len) ? pxg_raw2pa(base[p], k, c.offset) : 0.0f;
+            }
         }
 #pragma unroll
         for (int j = 0; j < 16; j++) {
@@ -99,7 +108,7 @@ int pxg_launch_guppy_event_means(pxg_ctx* ctx, int64_t n, const int16_t* raw, co
         ctx->err = "block_stride must be 1..16";
         return PXG_E_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(k_guppy_event_means, dim3((unsigned)n, 8), dim3(256), 0, ctx->stream, n, raw, off,
+    hipLaunchKernelGGL(k_guppy_event_means, dim3((unsigned)n, 16), dim3(256), 0, ctx->stream, n, raw, off,
                        cal, ss, first, ev_off, stride, mean, scaled);
     return PXG_OK;
 }
