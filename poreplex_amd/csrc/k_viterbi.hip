@@ -17,8 +17,8 @@
 // Back-pointers: the segmentation model is left-to-right (every edge i->j has j >= i), so a
 // step's decision is the SPAN of the in-edge it took (0 = self loop).  Each recurrence lane
 // shifts that span into a register, FB bits per step, and stores the register once per
-// 16-step chunk (one coalesced 256-byte row per wave).  k_viterbi_trace then walks the
-// fields of the winning state backwards, a wave per read, 64 chunks per load: the entry
+// 16-step chunk (one coalesced 256-byte row per wave).  The block's three waves then walk the
+// fields of the winning states backwards, a wave per read, 64 chunks per load: the entry
 // step of every state on the path IS the run-length summary.  (Round 1 carried the entry
 // steps through the recurrence instead -- 6 DPP moves, 9 selects and 3 bit-field inserts
 // of its ~66 instructions per step.)
@@ -101,16 +101,76 @@ __device__ __forceinline__ double dpp_shr_f64(double v, int k)
     return __hiloint2double(hi, lo);
 }
 
+// BT: register of back-pointer fields of one chunk -- uint32_t = 2 bits per step (spans <= 3),
+//     uint64_t = 4 bits per step (spans <= 7)
+template <typename BT> struct BpFields { static constexpr int bits = (int)sizeof(BT) * 8 / VIT_CHUNK; };
+
+// A whole wave walks one read's back-pointer fields from the winning state at T-1 down to the
+// start.  For the state the path is in, 64 lanes fetch its fields of 64 consecutive chunks
+// (newest first); the newest non-zero field at or before the current step is the step the
+// state was entered at and the span it was entered over.
+template <typename BT>
+__device__ __forceinline__ void viterbi_trace(const PxgHmmDev& H, const BT* __restrict__ mine /* this read's lane 0 */,
+                                              int T, int cur, int lane, int32_t* __restrict__ first,
+                                              int32_t* __restrict__ status_of_read)
+{
+    constexpr int FB = BpFields<BT>::bits;
+    int32_t* last = first + PXG_N_SEGMENTS;
+    if (cur < 0) {                                // not run, or no samples
+        if (lane < 2 * PXG_N_SEGMENTS) first[lane] = -1;
+        return;
+    }
+    int f[PXG_MAX_STATES], l[PXG_MAX_STATES];
+#pragma unroll
+    for (int q = 0; q < PXG_MAX_STATES; q++) f[q] = l[q] = -1;
+    auto put = [&](int (&a)[PXG_MAX_STATES], int q, int val) {
+#pragma unroll
+        for (int i = 0; i < PXG_MAX_STATES; i++) a[i] = (i == q) ? val : a[i];
+    };
+    put(l, cur, T - 1);
+    int t = T - 1;
+    for (int hops = 0; hops < PXG_MAX_STATES; hops++) {
+        int entered = 0, span = 0;                // entered stays 0: the path started in `cur`
+        bool found = false;
+        for (int cb = t / VIT_CHUNK; cb >= 0 && !found; cb -= 64) {
+            const int c = cb - lane;
+            BT w = c >= 0 ? mine[(size_t)c * 64 + cur] : (BT)0;
+            if (c == t / VIT_CHUNK)               // drop the steps after t
+                w &= ~(BT)0 << ((VIT_CHUNK - 1 - t % VIT_CHUNK) * FB);
+            const unsigned long long nz = __ballot(w != 0);
+            if (nz) {
+                const int src = __builtin_ctzll(nz);          // lowest lane = newest chunk
+                const int low = (sizeof(BT) == 8 ? __builtin_ctzll((unsigned long long)w | (w == 0))
+                                                 : __builtin_ctz((unsigned)w | (w == 0))) / FB;
+                const int my_t = c * VIT_CHUNK + (VIT_CHUNK - 1 - low);
+                const int my_span = (int)((w >> (low * FB)) & (BT)((1 << FB) - 1));
+                entered = __shfl(my_t, src);
+                span = __shfl(my_span, src);
+                found = true;
+            }
+        }
+        put(f, cur, entered);
+        if (!found) break;
+        cur -= span;
+        put(l, cur, entered - 1);
+        t = entered - 1;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < PXG_MAX_STATES; q++)
+            if (q < PXG_N_SEGMENTS) { first[q] = f[q]; last[q] = l[q]; }
+        if (status_of_read != nullptr && H.adapter_state >= 0 && f[H.adapter_state] < 0)
+            *status_of_read = PXG_ST_ADAPTER_NOT_DETECTED;
+    }
+}
+
 // RAW=true : signal is pooled on the fly from int16 DAQ samples; `sig`, if not null, is K1's
 //            left-padded head tensor [n][head_width] -- the block means of the first
 //            min(n_raw, head_limit) samples, by the same function -- and is read instead of
 //            pooling those samples a second time
 // RAW=false: signal is an already pooled+scaled float arena (test hook)
 // SPANS: bit k set = some edge goes from state s-k to state s (k >= 1)
-// BT: register of back-pointer fields of one chunk -- uint32_t = 2 bits per step (spans <= 3),
-//     uint64_t = 4 bits per step (spans <= 7)
-template <typename BT> struct BpFields { static constexpr int bits = (int)sizeof(BT) * 8 / VIT_CHUNK; };
-
+// BT: see BpFields
 // POOL: 15 = the pooling stride is 15 (samples are prefetched into registers a chunk ahead),
 //       0 = any stride / float input
 template <bool RAW, int POOL, unsigned SPANS, typename BT>
@@ -118,13 +178,14 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
     int64_t n_reads, PxgHmmDev H, const int16_t* __restrict__ raw, const float* __restrict__ sig,
     const int64_t* __restrict__ off, const pxg_calib* __restrict__ cal,
     const float* __restrict__ ss, int stride, int scan_pooled, int head_width, int head_limit,
-    const int32_t* __restrict__ status, BT* __restrict__ bp /* [block][chunk][64 lanes] */, int bp_chunks,
-    int32_t* __restrict__ end_state, double* __restrict__ logp_out, const double* __restrict__ lsetab_g)
+    int32_t* __restrict__ status, BT* __restrict__ bp /* [block][chunk][64 lanes] */, int bp_chunks,
+    int32_t* __restrict__ segs, double* __restrict__ logp_out, const double* __restrict__ lsetab_g)
 {
     constexpr int FB = BpFields<BT>::bits;
     static_assert((SPANS >> (1 << FB)) == 0, "span does not fit the back-pointer field");
     __shared__ double em[2][VIT_READS * EM_STRIDE];   // double buffer: producers run one chunk ahead
     __shared__ double lsetab[PXG_LSE_TAB_DOUBLES];
+    __shared__ int end_of[VIT_READS], steps_of[VIT_READS];     // winning state (-1: not run) and T per read
     for (int i = threadIdx.x; i < PXG_LSE_TAB_DOUBLES; i += blockDim.x) lsetab[i] = lsetab_g[i];
     __syncthreads();
     const int lane = threadIdx.x & 63;
@@ -248,9 +309,7 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
                 lds_barrier();
             }
         }
-        return;
-    }
-
+    } else {
     // ===================== recurrence (wave 0) ====================================
     // per-lane edge table by SPAN: the source of span k is the lane k below.
     // lpk[k] = log P(state s-k -> s) (-inf if no such edge); prk[k] = position of
@@ -382,78 +441,23 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
             end_s = H.order[q];
         }
     }
-    if (s == 0 && r < n_reads) {
+    if (s == 0) {
         const bool ran = valid_read && T > 0;
-        end_state[r] = ran ? end_s : -1;
-        if (logp_out) logp_out[r] = ran ? bestv : -__builtin_inf();
+        end_of[rr] = ran ? end_s : -1;
+        steps_of[rr] = T;
+        if (logp_out && r < n_reads) logp_out[r] = ran ? bestv : -__builtin_inf();
     }
-}
+    }
 
-// One wave per read: walk the back-pointer fields from the winning state at T-1 down to the
-// start.  For the state the path is in, 64 lanes fetch its fields of 64 consecutive chunks
-// (newest first), the newest non-zero field at or before the current step is the step the
-// state was entered and the span it was entered over.
-template <typename BT>
-__global__ __launch_bounds__(64) void k_viterbi_trace(
-    int64_t n_reads, PxgHmmDev H, bool raw_lengths, const int64_t* __restrict__ off, int stride,
-    int scan_pooled, const BT* __restrict__ bp, int bp_chunks, const int32_t* __restrict__ end_state,
-    int32_t* __restrict__ status, int32_t* __restrict__ segs)
-{
-    constexpr int FB = BpFields<BT>::bits;
-    const int64_t r = blockIdx.x;
-    const int lane = threadIdx.x;
-    int32_t* first = segs + r * 2 * PXG_N_SEGMENTS;
-    int32_t* last = first + PXG_N_SEGMENTS;
-    int cur = end_state[r];
-    if (cur < 0) {                                // not run, or no samples
-        if (lane < 2 * PXG_N_SEGMENTS) first[lane] = -1;
-        return;
-    }
-    const int64_t len = off[r + 1] - off[r];
-    const int64_t P = raw_lengths ? len / stride : len;
-    const int T = (int)(P < scan_pooled ? P : scan_pooled);
-    const BT* mine = bp + ((size_t)(r / VIT_READS) * bp_chunks) * 64 + (r % VIT_READS) * 8;
-    int f[PXG_MAX_STATES], l[PXG_MAX_STATES];
-#pragma unroll
-    for (int q = 0; q < PXG_MAX_STATES; q++) f[q] = l[q] = -1;
-    auto put = [&](int (&a)[PXG_MAX_STATES], int q, int val) {
-#pragma unroll
-        for (int i = 0; i < PXG_MAX_STATES; i++) a[i] = (i == q) ? val : a[i];
-    };
-    put(l, cur, T - 1);
-    int t = T - 1;
-    for (int hops = 0; hops < PXG_MAX_STATES; hops++) {
-        int entered = 0, span = 0;                // entered stays 0: the path started in `cur`
-        bool found = false;
-        for (int cb = t / VIT_CHUNK; cb >= 0 && !found; cb -= 64) {
-            const int c = cb - lane;
-            BT w = c >= 0 ? mine[(size_t)c * 64 + cur] : (BT)0;
-            if (c == t / VIT_CHUNK)               // drop the steps after t
-                w &= ~(BT)0 << ((VIT_CHUNK - 1 - t % VIT_CHUNK) * FB);
-            const unsigned long long nz = __ballot(w != 0);
-            if (nz) {
-                const int src = __builtin_ctzll(nz);          // lowest lane = newest chunk
-                const int low = (sizeof(BT) == 8 ? __builtin_ctzll((unsigned long long)w | (w == 0))
-                                                 : __builtin_ctz((unsigned)w | (w == 0))) / FB;
-                const int my_t = c * VIT_CHUNK + (VIT_CHUNK - 1 - low);
-                const int my_span = (int)((w >> (low * FB)) & (BT)((1 << FB) - 1));
-                entered = __shfl(my_t, src);
-                span = __shfl(my_span, src);
-                found = true;
-            }
-        }
-        put(f, cur, entered);
-        if (!found) break;
-        cur -= span;
-        put(l, cur, entered - 1);
-        t = entered - 1;
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int q = 0; q < PXG_MAX_STATES; q++)
-            if (q < PXG_N_SEGMENTS) { first[q] = f[q]; last[q] = l[q]; }
-        if (status != nullptr && H.adapter_state >= 0 && f[H.adapter_state] < 0)
-            status[r] = PXG_ST_ADAPTER_NOT_DETECTED;
+    // ---- traceback: the three waves share the block's eight reads ---------------------------
+    // (the fields were stored by wave 0 of this block and are read here for the first time in
+    //  this kernel: __syncthreads() has waited for the stores, no line of them is in the L1)
+    __syncthreads();
+    for (int q = wv; q < VIT_READS; q += VIT_THREADS / 64) {
+        const int64_t rq = blockIdx.x * (int64_t)VIT_READS + q;
+        if (rq >= n_reads) break;
+        viterbi_trace<BT>(H, bp + (size_t)blockIdx.x * bp_chunks * 64 + q * 8, steps_of[q], end_of[q], lane,
+                          segs + rq * 2 * PXG_N_SEGMENTS, status ? status + rq : nullptr);
     }
 }
 
@@ -479,32 +483,28 @@ static int launch_viterbi(pxg_ctx* ctx, const PxgHmmDev& H, int64_t n, const int
     const int bp_chunks = std::max(1, (std::min(scan, max_steps) + VIT_CHUNK - 1) / VIT_CHUNK);
     const bool narrow = (H.shift_mask & ~7u) == 0 && H.n_states <= 6;
     int rc = pxg_reserve(ctx, ctx->vit_bp, (size_t)blocks * bp_chunks * 64 * (narrow ? 4 : 8));
-    if (rc || (rc = pxg_reserve(ctx, ctx->vit_end, (size_t)n))) return rc;
+    if (rc) return rc;
     constexpr int GEN = 0;
     if (narrow) {
         uint32_t* bp = (uint32_t*)ctx->vit_bp.p;
         if (RAW && stride == 15)
             hipLaunchKernelGGL((k_viterbi_ltr<RAW, RAW ? 15 : GEN, 0x6u, uint32_t>), dim3((unsigned)blocks),
                                dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, head_width, head_limit, status,
-                               bp, bp_chunks, ctx->vit_end.p, logp, ctx->d_lsetab);
+                               bp, bp_chunks, segs, logp, ctx->d_lsetab);
         else
             hipLaunchKernelGGL((k_viterbi_ltr<RAW, GEN, 0x6u, uint32_t>), dim3((unsigned)blocks),
                                dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, head_width, head_limit, status,
-                               bp, bp_chunks, ctx->vit_end.p, logp, ctx->d_lsetab);
-        hipLaunchKernelGGL((k_viterbi_trace<uint32_t>), dim3((unsigned)n), dim3(64), 0, ctx->stream, n, H, RAW,
-                           off, stride, scan, bp, bp_chunks, ctx->vit_end.p, status, segs);
+                               bp, bp_chunks, segs, logp, ctx->d_lsetab);
     } else {
         uint64_t* bp = (uint64_t*)ctx->vit_bp.p;
         if (RAW && stride == 15)
             hipLaunchKernelGGL((k_viterbi_ltr<RAW, RAW ? 15 : GEN, 0xFEu, uint64_t>), dim3((unsigned)blocks),
                                dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, head_width, head_limit, status,
-                               bp, bp_chunks, ctx->vit_end.p, logp, ctx->d_lsetab);
+                               bp, bp_chunks, segs, logp, ctx->d_lsetab);
         else
             hipLaunchKernelGGL((k_viterbi_ltr<RAW, GEN, 0xFEu, uint64_t>), dim3((unsigned)blocks),
                                dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, head_width, head_limit, status,
-                               bp, bp_chunks, ctx->vit_end.p, logp, ctx->d_lsetab);
-        hipLaunchKernelGGL((k_viterbi_trace<uint64_t>), dim3((unsigned)n), dim3(64), 0, ctx->stream, n, H, RAW,
-                           off, stride, scan, bp, bp_chunks, ctx->vit_end.p, status, segs);
+                               bp, bp_chunks, segs, logp, ctx->d_lsetab);
     }
     return PXG_OK;
 }

@@ -293,7 +293,6 @@ struct pxg_ctx {
     DevBuf<int32_t> segs;        // n x 2 x PXG_N_SEGMENTS
     DevBuf<unsigned long long> unsplit_q;   // K7b unit queue
     DevBuf<char> vit_bp;         // K3 back-pointer fields, [block][chunk][64 lanes]
-    DevBuf<int32_t> vit_end;     // K3 winning state per read (-1: not run)
     DevBuf<int32_t> idx_scaler;  // compacted read indices
     DevBuf<int32_t> idx_demux;
     DevBuf<int32_t> counters;    // [0] scaler count, [1] demux count

@@ -1,0 +1,29 @@
+#!/bin/bash
+# Every bench line + profile the round's profiles/ directory quotes, in one gpurun call.
+# usage (on the GPU box): tools/measure_round.sh <tag>     -> gpurun_out/final_<tag>/
+set -u
+TAG=${1:-final}
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+OUT=gpurun_out/final_$TAG
+mkdir -p $OUT
+B="python bench.py --cpu-sample 0 --cpu-all-cores-sample 0"
+python bench.py --steps 20 --warmup 5 > $OUT/bench_demux.json 2> $OUT/bench_demux.err          # the driver's form
+for w in segment polya chimera full; do
+  $B --workload $w --steps 10 --warmup 3 > $OUT/bench_$w.json 2> $OUT/bench_$w.err
+done
+$B --reads 100000 --steps 5 --warmup 2 > $OUT/bench_demux_100k_reads_60k_samples.json 2> $OUT/b100k.err
+$B --workload full --reads 100000 --steps 5 --warmup 2 > $OUT/bench_full_100k_reads_60k_samples.json 2>> $OUT/b100k.err
+$B --scaling strong --total-reads 125000 --steps 3 --warmup 1 > $OUT/bench_strong_125k_shard.json 2>> $OUT/b100k.err
+$B --end-to-end --reads 120000 --batch-reads 10000 > $OUT/bench_end_to_end_demux.json 2> $OUT/e2e.err
+$B --end-to-end --workload full --reads 120000 --batch-reads 10000 > $OUT/bench_end_to_end_full.json 2>> $OUT/e2e.err
+bash tools/prof.sh ${TAG}_demux > /dev/null 2>&1
+bash tools/prof.sh ${TAG}_full --workload full > /dev/null 2>&1
+for f in $OUT/bench_*.json; do python - "$f" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    print(sys.argv[1].split('/')[-1], round(d['value']), round(d['ms_per_step'], 3), (d.get('roofline') or {}).get('frac'))
+except Exception as e:
+    print(sys.argv[1], 'unreadable', e)
+PY
+done
