@@ -82,3 +82,74 @@ def test_fuzz_whole_path_vs_oracle(ctx, oracle):
     # the fuzz reached the failure statuses as well as the happy path
     assert seen[N.STATUS_CODE['okay']] > 20 and seen[N.STATUS_CODE['scaler_signal_too_short']] > 20
     assert seen[N.STATUS_CODE['scaling_qc_fail']] + seen[N.STATUS_CODE['adapter_not_detected']] > 5
+
+
+def random_left_to_right_model(rng):
+    """2..8 states in chain order, random spans / mixtures / start states, names shuffled (the
+    in-edge order of a tie is the name order), and CLONED states -- same emission, same in- and
+    out-edges -- so that exact ties between candidates happen long after the first steps."""
+    S = int(rng.integers(2, 9))
+    pool = ['adapter', 'polya-tail', 'zeta', 'alpha', 'mid', 'beta', 'omega', 'kappa']
+    names = [str(x) for x in rng.permutation(pool)[:S]]
+    max_span = int(rng.choice([1, 2, 3, 5, 7]))
+    mus = rng.uniform(60, 130, S)
+    states = []
+    for i, name in enumerate(names):
+        n_mix = int(rng.choice([1, 1, 2, 3]))
+        em = [[float(mus[i] + rng.normal(0, 6)), float(rng.uniform(2, 9)), float(rng.uniform(0.2, 1.0))]
+              for _ in range(n_mix)]
+        if n_mix == 1:
+            em = [em[0][:2]]
+        targets = [i] + [j for j in range(i + 1, min(S, i + max_span + 1)) if rng.random() < 0.7]
+        if i + 1 < S and i + 1 not in targets:
+            targets.append(i + 1)
+        if rng.random() < 0.4:           # equal probabilities: candidates tie as often as they can
+            p = np.full(len(targets), 1.0 / len(targets))
+        else:
+            p = rng.dirichlet(np.ones(len(targets)) * 2)
+        st = {'name': name, 'emission': em, 'transition': [[names[j], float(q)] for j, q in zip(targets, p)]}
+        states.append(st)
+    n_start = int(rng.integers(1, min(S, 3) + 1))
+    sp = rng.dirichlet(np.ones(n_start)) if rng.random() < 0.6 else np.full(n_start, 1.0 / n_start)
+    for i in range(n_start):
+        states[i]['start_prob'] = float(sp[i])
+    if S >= 4 and rng.random() < 0.7:    # state 2 becomes a clone of state 1 (both fed by state 0, both feed state 3)
+        states[2]['emission'] = [list(e) for e in states[1]['emission']]
+        states[0]['transition'] = [[names[0], 0.5], [names[1], 0.25], [names[2], 0.25]]
+        states[1]['transition'] = [[names[1], 0.75], [names[3], 0.25]]
+        states[2]['transition'] = [[names[2], 0.75], [names[3], 0.25]]
+        if n_start > 1:
+            for st in states[1:]:
+                st.pop('start_prob', None)
+            states[0]['start_prob'] = 1.0
+    return states, mus
+
+
+def test_fuzz_random_left_to_right_hmms_vs_oracle(config):
+    """K3's generic template (2- and 4-bit back-pointer fields, tie replay) on random models,
+    through the pooled-signal hook: paths identical to the oracle's, log-probabilities to 1e-9.
+    (Negative control, run by hand: with the exact replay of tied chunks compiled out the first
+    model already fails, so the ties are there; 900 models over three seeds pass.)"""
+    import copy
+    from oracle.pxo import Oracle
+    rng = np.random.default_rng(int(os.environ.get('PXG_FUZZ_SEED', 7)))
+    for trial in range(int(os.environ.get('PXG_FUZZ_MODELS', 16))):
+        cfg = copy.deepcopy(config)
+        cfg['segmentation_model'], mus = random_left_to_right_model(rng)
+        orc = Oracle(cfg)
+        c = N.NativeContext(cfg, device_id=0)
+        try:
+            sigs = []
+            for n in (1, 2, 15, 16, 17, 33, 400, int(rng.integers(500, 3000)), 7000):
+                k = max(1, n // int(rng.integers(20, 200)))         # piece-wise levels drawn from the states' means
+                levels = np.repeat(rng.choice(mus, k + 1), n // k + 1)[:n]
+                sigs.append((levels + rng.normal(0, 3, n)).astype(np.float32))
+            first, last, paths, logp = c.viterbi(sigs, want_path=True)
+            for k, sg in enumerate(sigs):
+                olp, opath = orc.viterbi(sg)
+                assert np.array_equal(paths[k], opath), (trial, k, cfg['segmentation_model'])
+                assert abs(logp[k] - olp) <= 1e-9 * max(1.0, abs(olp)), (trial, k)
+                ofirst, olast = orc.segments(opath)
+                assert np.array_equal(first[k], ofirst) and np.array_equal(last[k], olast), (trial, k)
+        finally:
+            c.close()
