@@ -512,10 +512,16 @@ static float median_f32(const float* v, int n, float* tmp)
 {
     memcpy(tmp, v, sizeof(float) * n);
     qsort(tmp, n, sizeof(float), cmp_f32);
-    if (n & 1)
-        return tmp[n / 2];
-    float s = tmp[n / 2 - 1] + tmp[n / 2];
-    return s / 2.0f;
+    /* a zero median is +0: which of several +-0 samples a partition (NumPy's introselect, qsort
+     * here, the GPU's radix select) leaves in the middle is not defined by any of them */
+    float m;
+    if (n & 1) {
+        m = tmp[n / 2];
+    } else {
+        const float s = tmp[n / 2 - 1] + tmp[n / 2];
+        m = s / 2.0f;
+    }
+    return m == 0.0f ? 0.0f : m;
 }
 
 void pxo_normalize_signal(const float* sig, int n, float* out)

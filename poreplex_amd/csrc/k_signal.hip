@@ -246,6 +246,8 @@ __device__ __forceinline__ void window_normalize(float* xs, float* ys, float* se
     {
         float s = sel[0] + sel[1];
         med = (n & 1) ? sel[1] : s / 2.0f;
+        med = (med == 0.0f) ? 0.0f : med;      // a zero median is +0 (which of several +-0 samples a
+                                               // partition leaves in the middle is not defined)
     }
     __syncthreads();
     for (int i = lane; i < n; i += PXG_WAVE) ys[i] = __builtin_fabsf(xs[i] - med);

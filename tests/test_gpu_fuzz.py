@@ -153,3 +153,74 @@ def test_fuzz_random_left_to_right_hmms_vs_oracle(config):
                 assert np.array_equal(first[k], ofirst) and np.array_equal(last[k], olast), (trial, k)
         finally:
             c.close()
+
+
+def test_fuzz_stage_hooks_vs_oracle(ctx, oracle):
+    """The per-stage hooks on adversarial inputs: barcode windows full of duplicated values, signed
+    zeros and constant runs (the medians are radix selects over order-preserving keys), windows of
+    every length around the 260 / 300 / 3000 gates; event detection on constant, stepped, spiky
+    and tiny windows; DAQ -> pA / pooling on full-scale int16 with odd calibrations."""
+    rng = np.random.default_rng(int(os.environ.get('PXG_FUZZ_SEED', 3)))
+    # ---- a9-a11 ------------------------------------------------------------------
+    sigs = []
+    for n in [0, 1, 259, 260, 261, 299, 300, 301, 2999, 3000, 3001] + rng.integers(200, 3400, 60).tolist():
+        kind = rng.integers(0, 5)
+        if kind == 0:
+            x = rng.normal(90, 12, n)
+        elif kind == 1:
+            x = rng.choice([80.0, 80.0, 95.5, 101.25], n)                   # heavy ties
+        elif kind == 2:
+            x = np.full(n, 77.0)                                            # MAD = 0 -> the 0.01 floor
+        elif kind == 3:
+            x = rng.choice([0.0, -0.0, 1e-30, -1e-30, 3.5], n)              # signed zeros, denormal-ish
+        else:
+            x = np.round(rng.normal(90, 4, n))                              # integers: many equal pairs
+        sigs.append(x.astype(np.float32))
+    out, pushed = ctx.barcode_window(sigs)
+    for k, sg in enumerate(sigs):
+        want, wp = oracle.barcode_window(sg)
+        assert bool(pushed[k]) == bool(wp), (k, len(sg))
+        if wp:
+            assert np.array_equal(out[k].view(np.uint32), want.view(np.uint32)), (k, len(sg))
+    # ---- a15 -----------------------------------------------------------------------
+    wins = []
+    for n in [1, 2, 3, 6, 7, 13, 14, 19, 20, 21, 39, 40, 41, 63, 64, 65] + rng.integers(30, 6000, 50).tolist():
+        kind = rng.integers(0, 5)
+        if kind == 0:
+            x = np.full(n, 100.0)
+        elif kind == 1:
+            x = np.repeat(rng.normal(95, 15, n // 3 + 1), 3)[:n]            # steps shorter than both windows
+        elif kind == 2:
+            x = rng.normal(95, 1, n); x[rng.integers(0, n, max(n // 50, 1))] += 400   # spikes
+        elif kind == 3:
+            x = np.repeat(rng.normal(95, 15, n // 40 + 1), 40)[:n] + rng.normal(0, 0.05, n)
+        else:
+            x = rng.normal(0, 1e-3, n)                                       # variance at the FLT_MIN clamp
+        wins.append(x.astype(np.float32))
+    evs, cnt = ctx.detect_events(wins, max_events=2500)
+    for k, w in enumerate(wins):
+        want = oracle.detect_events(w)
+        assert cnt[k] == len(want), (k, len(w))
+        for f in ('start', 'length', 'mean', 'stdv'):
+            assert np.array_equal(evs[k][f], want[f], equal_nan=True), (k, f, len(w))
+    # ---- a1, a2, a5 ----------------------------------------------------------------
+    parts, cal = [], np.zeros(24, dtype=N.CALIB_DTYPE)
+    for i in range(24):
+        n = int(rng.choice([0, 14, 15, 8999, 9000, 30000, 30014, 31000, 47000]))
+        parts.append(rng.integers(-32768, 32768, n).astype(np.int16))
+        cal[i] = (rng.uniform(100, 3000), rng.choice([2048.0, 8192.0, 65536.0]), rng.uniform(-500, 500),
+                  rng.choice([3012.0, 4000.0]))
+    arena, off = N.pack_reads(parts)
+    head, status = ctx.head_pool(arena, off, cal)
+    ss = np.stack([rng.normal(1, 0.2, 24), rng.normal(0, 20, 24)], axis=1).astype(np.float32)
+    pooled, poff = ctx.pool_scale(arena, off, cal, ss)
+    for i, raw in enumerate(parts):
+        wh, wst = oracle.head_pool(raw, cal[i])
+        assert status[i] == wst, i
+        if wst == 0:
+            assert np.array_equal(head[i].view(np.uint32), wh.view(np.uint32)), i
+        assert np.array_equal(pooled[poff[i]:poff[i + 1]].view(np.uint32),
+                              oracle.pool_scale(raw, cal[i], ss[i, 0], ss[i, 1]).view(np.uint32)), i
+        if len(raw):
+            assert np.array_equal(ctx.raw_to_pa(raw, cal[i]).view(np.uint32),
+                                  oracle.raw_to_pa(raw, cal[i]).view(np.uint32)), i
