@@ -224,3 +224,42 @@ def test_fuzz_stage_hooks_vs_oracle(ctx, oracle):
         if len(raw):
             assert np.array_equal(ctx.raw_to_pa(raw, cal[i]).view(np.uint32),
                                   oracle.raw_to_pa(raw, cal[i]).view(np.uint32)), i
+
+
+def test_fuzz_lstm_hooks_on_extreme_inputs(ctx, oracle):
+    """The two networks on inputs that drive the spline tables to and past their ends (the sigmoid
+    table covers [-32, 32), tanh's half of that): huge and tiny values, exact zeros, constant rows,
+    alternating signs, the -1000 padding everywhere.  Bit-identical to the oracle."""
+    rng = np.random.default_rng(int(os.environ.get('PXG_FUZZ_SEED', 21)))
+    width = oracle.cfg.scaler_length // oracle.cfg.stride
+
+    def rows(n, T):
+        out = np.zeros((n, T), dtype=np.float32)
+        for i in range(n):
+            kind = i % 8
+            if kind == 0:
+                out[i] = rng.normal(90, 15, T)
+            elif kind == 1:
+                out[i] = rng.choice([-1e6, 1e6, 0.0, 3e4, -3e4], T)
+            elif kind == 2:
+                out[i] = 0.0
+            elif kind == 3:
+                out[i] = np.where(np.arange(T) % 2 == 0, 500.0, -500.0)
+            elif kind == 4:
+                out[i] = rng.normal(0, 1e-20, T)
+            elif kind == 5:
+                out[i] = -1000.0
+            elif kind == 6:
+                out[i, T // 2:] = rng.normal(100, 200, T - T // 2)      # left-padded like a short head
+            else:
+                out[i] = np.linspace(-40, 40, T)
+        return out
+    heads = rows(19, width)
+    got = ctx.scaler_lstm(heads)
+    want = np.stack([oracle.scaler_forward(h) for h in heads])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+    wins = rows(35, oracle.cfg.signal_trim_length)
+    got = ctx.demux_lstm(wins)
+    want = np.stack([oracle.demux_forward(w) for w in wins])
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+    assert np.isfinite(got).all()
