@@ -369,6 +369,35 @@ int pxg_detect_events(pxg_ctx* ctx, int64_t n_windows, const float* signal_arena
                       const int64_t* signal_offsets, int64_t max_events_per_window,
                       pxg_event* events, int64_t* n_events);
 
+/* ---- result sinks ------------------------------------------------------
+ * The rows of sequencing_summary.txt (io.py:120-184, SequencingSummaryWriter.write_results)
+ * as text, from columns -- byte for byte what the reference's print of str(int), repr(float),
+ * round(start_time / sampling_rate, 3) and format(dwell, '.4f') produces.  Host only, exported by
+ * libpxgtext.so (no HIP runtime behind it, loads anywhere).  The
+ * five string fields come straight from NumPy '<U' arrays (UCS-4, fixed width, NUL padded):
+ * text[0..4] = filename, read_id, run_id, channel, sample_id, row string_row[k] of each.
+ * Every other array has n elements.  barcode_names == NULL: barcoding off (no barcode /
+ * score fields); else barcode_names[0] is the "no call" name and [b + 1] barcode b's, and
+ * barcode[k] = -1 for no call.  polya_dwell == NULL: no poly(A) field.
+ * Returns the number of bytes written to `out` (no terminator), PXG_E_NOMEM if `cap` is too
+ * small, PXG_E_UNSUPPORTED for non-ASCII text or a start time beyond 1e12 s (the caller then
+ * formats in Python), PXG_E_INVALID for an index outside a name table. */
+typedef struct { const uint32_t* data; int64_t width; } pxg_text_column;
+typedef struct {
+    int64_t n;
+    const int64_t* string_row;
+    pxg_text_column text[5];
+    const int64_t* start_time;  const double* sampling_rate;  const int64_t* duration;
+    const uint8_t* has_summary; const int64_t* num_events;    const int64_t* sequence_length;
+    const double* mean_qscore;
+    const int32_t* status;      const char* const* status_names;  int32_t n_status;
+    const int32_t* label;       const char* const* label_names;   int32_t n_labels;
+    const int32_t* barcode;     const int32_t* barcode_score;
+    const char* const* barcode_names;  int32_t n_barcode_names;
+    const uint8_t* has_polya;   const double* polya_dwell;
+} pxg_summary_columns;
+int64_t pxg_summary_rows(const pxg_summary_columns* cols, char* out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'csrc', 'libpxg.so')
 
 PXG_ABI_VERSION = 2
+PXG_E_NOMEM, PXG_E_UNSUPPORTED = -4, -6
 PXG_MAX_STATES = 8
 PXG_MAX_MIXTURE = 4
 PXG_N_SEGMENTS = 8
@@ -133,6 +134,22 @@ class PxgReadResult(C.Structure):
 class PxgEvent(C.Structure):
     _fields_ = [('start', C.c_uint64), ('length', C.c_float), ('mean', C.c_float),
                 ('stdv', C.c_float), ('pos', C.c_int32), ('state', C.c_int32)]
+
+
+class PxgTextColumn(C.Structure):          # one NumPy '<U' array: UCS-4, fixed width
+    _fields_ = [('data', C.c_void_p), ('width', C.c_int64)]
+
+
+class PxgSummaryColumns(C.Structure):       # pxg_summary_columns
+    _fields_ = [('n', C.c_int64), ('string_row', C.c_void_p), ('text', PxgTextColumn * 5),
+                ('start_time', C.c_void_p), ('sampling_rate', C.c_void_p), ('duration', C.c_void_p),
+                ('has_summary', C.c_void_p), ('num_events', C.c_void_p), ('sequence_length', C.c_void_p),
+                ('mean_qscore', C.c_void_p),
+                ('status', C.c_void_p), ('status_names', C.POINTER(C.c_char_p)), ('n_status', C.c_int32),
+                ('label', C.c_void_p), ('label_names', C.POINTER(C.c_char_p)), ('n_labels', C.c_int32),
+                ('barcode', C.c_void_p), ('barcode_score', C.c_void_p),
+                ('barcode_names', C.POINTER(C.c_char_p)), ('n_barcode_names', C.c_int32),
+                ('has_polya', C.c_void_p), ('polya_dwell', C.c_void_p)]
 
 
 class PxgStageTimes(C.Structure):
@@ -319,6 +336,12 @@ class NativeConfig:
 # --------------------------------------------------------------------------
 _lib = None
 
+TEXT_LIB_PATH = os.path.join(HERE, 'csrc', 'libpxgtext.so')
+_TEXT_SIGNATURES = {      # libpxgtext.so: host-only text of the result sinks
+    'pxg_summary_rows': (C.c_int64, [C.POINTER(PxgSummaryColumns), C.c_char_p, C.c_int64]),
+}
+_text_lib = None
+
 _SIGNATURES = {
     'pxg_create': (C.c_int, [C.POINTER(PxgConfig), C.POINTER(C.c_void_p)]),
     'pxg_destroy': (None, [C.c_void_p]),
@@ -365,6 +388,7 @@ _SIGNATURES = {
                                     C.c_int64, C.c_void_p, C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+TEXT_SYMBOLS = tuple(_TEXT_SIGNATURES)
 
 
 def load_library(path=None):
@@ -389,8 +413,90 @@ def load_library(path=None):
     return lib
 
 
+def load_text_library(path=None):
+    """Load libpxgtext.so (built next to libpxg.so by the same Makefile); loud when absent."""
+    global _text_lib
+    if _text_lib is not None and path is None:
+        return _text_lib
+    path = path or TEXT_LIB_PATH
+    if not os.path.isfile(path):
+        raise PxgError('{} is missing: run `python -c "import __graft_entry__ as g; g.build()"`'.format(path))
+    lib = C.CDLL(path)
+    for name, (restype, argtypes) in _TEXT_SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _text_lib = lib
+    return lib
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _names(strings):
+    arr = (C.c_char_p * len(strings))(*[s.encode('ascii') for s in strings])
+    return arr
+
+
+def summary_rows(text_columns, string_row, start_time, sampling_rate, duration, has_summary,
+                 num_events, sequence_length, mean_qscore, status, status_names, label, label_names,
+                 barcode=None, barcode_score=None, barcode_names=None, has_polya=None, polya_dwell=None,
+                 scratch=None):
+    """pxg_summary_rows: the sequencing_summary.txt rows of n reads as one bytes object, or
+    None when the library declines (non-ASCII text: the caller formats in Python).
+    text_columns = the five NumPy '<U' arrays filename, read_id, run_id, channel, sample_id;
+    string_row[k] = the element of those arrays row k prints.  `scratch`: a one-element list
+    that keeps the output buffer between calls (a fresh 3 MB buffer per batch is page faults)."""
+    lib = load_text_library()
+    n = len(string_row)
+    keep = []                                     # keeps the converted arrays alive over the call
+
+    def col(a, dtype):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        keep.append(a)
+        return a.ctypes.data_as(C.c_void_p)
+    c = PxgSummaryColumns()
+    c.n = n
+    c.string_row = col(string_row, np.int64)
+    width = 0
+    for f, arr in enumerate(text_columns):
+        if arr.dtype.kind != 'U' or arr.dtype.byteorder not in ('<', '='):
+            return None
+        arr = np.ascontiguousarray(arr)
+        keep.append(arr)
+        c.text[f].data = arr.ctypes.data_as(C.c_void_p)
+        c.text[f].width = arr.dtype.itemsize // 4
+        width += arr.dtype.itemsize // 4
+    c.start_time, c.sampling_rate = col(start_time, np.int64), col(sampling_rate, np.float64)
+    c.duration, c.has_summary = col(duration, np.int64), col(has_summary, np.uint8)
+    c.num_events, c.sequence_length = col(num_events, np.int64), col(sequence_length, np.int64)
+    c.mean_qscore = col(mean_qscore, np.float64)
+    sn, ln = _names(status_names), _names(label_names)
+    c.status, c.status_names, c.n_status = col(status, np.int32), sn, len(status_names)
+    c.label, c.label_names, c.n_labels = col(label, np.int32), ln, len(label_names)
+    extra = max(len(x) for x in status_names) + max(len(x) for x in label_names)
+    if barcode_names is not None:
+        bn = _names(barcode_names)
+        c.barcode, c.barcode_score = col(barcode, np.int32), col(barcode_score, np.int32)
+        c.barcode_names, c.n_barcode_names = bn, len(barcode_names)
+        extra += max(len(x) for x in barcode_names) + 12
+    if polya_dwell is not None:
+        c.has_polya, c.polya_dwell = col(has_polya, np.uint8), col(polya_dwell, np.float64)
+        extra += 32
+    cap = n * (width + extra + 140) + 64          # 4 integers + 2 floats of <= 25 characters, separators
+    if scratch is not None and scratch and len(scratch[0]) >= cap:
+        buf = scratch[0]
+    else:
+        buf = C.create_string_buffer(cap + cap // 4)
+        if scratch is not None:
+            scratch[:] = [buf]
+    got = lib.pxg_summary_rows(C.byref(c), buf, len(buf))
+    if got == PXG_E_UNSUPPORTED:
+        return None
+    if got < 0:
+        raise PxgError('pxg_summary_rows failed ({})'.format(got))
+    return C.string_at(buf, got)
 
 
 def pack_reads(signals):

@@ -221,8 +221,9 @@ class GpuSession:
                 self.logger.error(message)
             # the sinks, from the columns: only labelled reads have a summary row (io.py:166-168)
             labelled = idx[table.label[idx] >= 0]
-            summary.write_columns(summary_columns(table, labelled, bool(cfg['barcoding']),
-                                                  bool(cfg['measure_polya'])))
+            if not summary.write_table_rows(table, labelled):
+                summary.write_columns(summary_columns(table, labelled, bool(cfg['barcoding']),
+                                                      bool(cfg['measure_polya'])))
             if fastq is not None:
                 fastq.write_sequences(results)
             records.append(D.final_label_records_from_table(table, rows_in, positions, loose,

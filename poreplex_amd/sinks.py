@@ -18,6 +18,8 @@ BAM writers stay out of scope (file plumbing, no signal path).
 import gzip
 import logging
 import os
+
+import numpy as np
 from collections import defaultdict
 from threading import Lock
 
@@ -83,6 +85,7 @@ class SequencingSummaryWriter:
             self.output_fields.append('polya_dwell')
         if header:
             self.file.write('\t'.join(self.output_fields) + '\n')
+        self._row_scratch = []
 
     def close(self):
         self.file.close()
@@ -112,6 +115,46 @@ class SequencingSummaryWriter:
                                           if 'polya' in entry else '')
                 self.file.write('\t'.join(str(row[f]) for f in self.output_fields) + '\n')
 
+
+    def write_table_rows(self, table, rows):
+        """The rows of `rows` (all labelled, all from table.bundle) through the library's
+        formatter (pxg_summary_rows): same bytes as write_columns(summary_columns(...)), without
+        a Python object per field.  False if it does not apply (the caller then takes the
+        Python path): fast5 output layout, reads that are not in a bundle, non-ASCII names."""
+        from . import native
+        bundle = table.bundle
+        idx = np.asarray(rows, dtype=np.int64)
+        if self.fast5_layout or bundle is None or not len(idx) or (table.bundle_index[idx] < 0).any():
+            return False
+        d = bundle.d
+        labels = [self.label_mapping.get(name, '') for name in ('pass', 'fail', 'artifact')]
+        bc = {}
+        if self.barcode_mapping is not None:
+            called = table.has_barcode[idx]
+            n_bc = max([k for k in self.barcode_mapping if k is not None], default=-1) + 1
+            bc = dict(barcode=np.where(called, table.barcode[idx], -1),
+                      barcode_score=np.where(called, table.barcode_phred[idx], 0),
+                      barcode_names=[self.barcode_mapping[None]] + [self.barcode_mapping[k] for k in range(n_bc)])
+        pa = {}
+        if self.polya_enabled:
+            lazy = table.polya_lazy[idx]
+            dwell = table.polya_dwell_time[idx].copy()
+            has = lazy.copy()
+            for k in np.nonzero(~lazy)[0].tolist():          # tails set through set_polya_tail (dicts)
+                p = table.polya[int(idx[k])]
+                if p is not None:
+                    has[k], dwell[k] = True, p['dwell_time']
+            pa = dict(has_polya=has, polya_dwell=dwell)
+        text = native.summary_rows(
+            [d['filename'], d['read_id'], d['run_id'], d['channel_number'], d['sample_id']],
+            table.bundle_index[idx], table.start_time[idx], table.sampling_rate[idx], table.duration[idx],
+            table.has_summary[idx], table.num_events[idx], table.sequence_length[idx], table.mean_qscore[idx],
+            table.status[idx], native.STATUS_NAMES, table.label[idx], labels, scratch=self._row_scratch, **bc, **pa)
+        if text is None:
+            return False
+        with self.lock:
+            self.file.write(text.decode('ascii'))
+        return True
 
     def write_columns(self, cols):
         """write_results for rows that only exist as columns (signal_loader.summary_columns):

@@ -13,19 +13,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def declared_symbols():
     text = open(os.path.join(ROOT, 'include', 'pxg.h')).read()
-    return sorted(set(re.findall(r'^\s*(?:int|void|const char\*)\s+(pxg_\w+)\s*\(', text, re.M)))
+    return sorted(set(re.findall(r'^\s*(?:int|int64_t|void|const char\*)\s+(pxg_\w+)\s*\(', text, re.M)))
 
 
 def test_header_and_binding_agree():
-    assert declared_symbols() == sorted(N.EXPORTED_SYMBOLS)
+    assert declared_symbols() == sorted(N.EXPORTED_SYMBOLS + N.TEXT_SYMBOLS)
 
 
 def test_library_exports_every_declared_symbol():
     if not os.path.isfile(N.LIB_PATH):
         pytest.skip('libpxg.so not built (run __graft_entry__.build())')
     lib = ctypes.CDLL(N.LIB_PATH)
+    text = ctypes.CDLL(N.TEXT_LIB_PATH)          # the host-only sink text lives in its own library
     for name in declared_symbols():
-        getattr(lib, name)
+        getattr(text if name in N.TEXT_SYMBOLS else lib, name)
     lib.pxg_abi_version.restype = ctypes.c_int
     assert lib.pxg_abi_version() == N.PXG_ABI_VERSION
 
@@ -33,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header_sizes():
     # sizes the C compiler gives the ABI structs (computed from the header by gcc)
     import subprocess, tempfile
-    src = '#include <stdio.h>\n#include "pxg.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu", sizeof(pxg_config), sizeof(pxg_read_result), sizeof(pxg_hmm), sizeof(pxg_event), sizeof(pxg_calib), sizeof(pxg_stage_times));return 0;}'
+    src = '#include <stdio.h>\n#include "pxg.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu", sizeof(pxg_config), sizeof(pxg_read_result), sizeof(pxg_hmm), sizeof(pxg_event), sizeof(pxg_calib), sizeof(pxg_stage_times), sizeof(pxg_summary_columns));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, 'sz.c')
         open(c, 'w').write(src)
@@ -41,7 +42,8 @@ def test_struct_layouts_match_the_header_sizes():
         subprocess.check_call(['gcc', '-I' + os.path.join(ROOT, 'include'), c, '-o', exe])
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
     want = [ctypes.sizeof(N.PxgConfig), ctypes.sizeof(N.PxgReadResult), ctypes.sizeof(N.PxgHmm),
-            ctypes.sizeof(N.PxgEvent), ctypes.sizeof(N.PxgCalib), ctypes.sizeof(N.PxgStageTimes)]
+            ctypes.sizeof(N.PxgEvent), ctypes.sizeof(N.PxgCalib), ctypes.sizeof(N.PxgStageTimes),
+            ctypes.sizeof(N.PxgSummaryColumns)]
     assert sizes == want
 
 

@@ -134,3 +134,86 @@ def test_process_batch_into_the_sinks_end_to_end(sinks, tmp_path, monkeypatch):
         assert sum(trk.counts.values()) == len(got)
     finally:
         WorkerPersistenceStorage.reset()
+
+
+def _random_table(tmp_path, n, seed, unicode_name=False):
+    """A ReadTable over a small bundle with every column the summary prints randomised."""
+    from poreplex_amd import native as N
+    from poreplex_amd.fast5_file import write_bundle, ReadBundle
+    from poreplex_amd.signal_loader import ReadTable
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(20, 60, n)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    arena = rng.integers(0, 1000, int(off[-1])).astype(np.int16)
+    cal = np.zeros(n, dtype=N.CALIB_DTYPE)
+    cal['range'], cal['digitisation'], cal['offset'] = 1400.0, 8192.0, 10.0
+    cal['sampling_rate'] = rng.choice([3012.0, 4000.0, 3012.5], n)
+    names = ['dir{}/r{:05d}.fast5'.format(i % 3, i) for i in range(n)]
+    if unicode_name:
+        names[n // 2] = 'dir0/résumé.fast5'
+    ids = ['{:08x}-{:04x}'.format(int(rng.integers(1 << 31)), i) for i in range(n)]
+    path = str(tmp_path / 'rand{}.pxr.npz'.format(seed))
+    write_bundle(path, arena, off, cal, names, ids)
+    b = ReadBundle(path)
+    b.d['start_time'] = rng.choice([0, 1, 1506, 3012, 123456789, 10 ** 12], n).astype(np.int64) * rng.integers(1, 9, n)
+    b.d['duration'] = rng.integers(0, 10 ** 7, n).astype(np.int64)
+    b.d['channel_number'] = np.array([str(int(c)) for c in rng.integers(1, 513, n)])
+    b.d['run_id'] = np.array([('run' + 'x' * int(c)) for c in rng.integers(0, 30, n)])
+    b.d['sample_id'] = np.array([('s' * int(c)) for c in rng.integers(0, 5, n)])
+    t = ReadTable()
+    rows = t.extend_from_bundle(b, np.arange(n))
+    t.label[rows] = rng.integers(0, 3, n)
+    t.status[rows] = rng.integers(0, len(N.STATUS_NAMES), n)
+    t.has_barcode[rows] = rng.random(n) < 0.6
+    t.barcode[rows] = rng.integers(0, 4, n)
+    t.barcode_phred[rows] = rng.integers(0, 30, n)
+    t.has_summary[rows] = rng.random(n) < 0.8
+    t.num_events[rows] = rng.integers(0, 10 ** 6, n)
+    t.sequence_length[rows] = rng.integers(0, 10 ** 5, n)
+    q = np.concatenate([rng.uniform(0, 40, n - 12).astype(np.float32).astype(np.float64),
+                        [0.0, 1.0, 10.0, 100.0, 1e-5, 1.5e-4, 1e16, 1.25e17, 123456.0, 0.1, 1e15, 9.87]])
+    t.mean_qscore[rows] = rng.permutation(q)
+    t.polya_lazy[rows] = rng.random(n) < 0.5
+    t.polya_dwell_time[rows] = np.where(rng.random(n) < 0.2, rng.integers(0, 3, n) * 0.00005, rng.uniform(0, 3, n))
+    for i in rng.choice(n, 5, replace=False).tolist():       # a tail that came through set_polya_tail
+        t.polya_lazy[i] = False
+        t.polya[i] = {'begin': 1, 'end': 2, 'dwell_time': 0.12345, 'spikes': []}
+    return t, rows
+
+
+@pytest.mark.parametrize('barcoding,polya', [(True, True), (True, False), (False, True), (False, False)])
+def test_native_summary_rows_equal_the_python_writer(tmp_path, barcoding, polya):
+    """pxg_summary_rows (C, libpxg.so; no GPU involved) prints the bytes the Python writer
+    prints: str(int), repr(float) in both layouts, round(x, 3), '%.4f', every name table."""
+    import io
+    from poreplex_amd.config import default_config
+    from poreplex_amd.signal_loader import summary_columns
+    cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path), barcoding=barcoding,
+                         measure_polya=polya, filter_unsplit_reads=True)
+    labels, barcodes, _ = SINK.setup_output_name_mapping(cfg)
+    for seed in range(4):
+        t, rows = _random_table(tmp_path, 300, seed)
+        w = SINK.SequencingSummaryWriter(dict(cfg, fast5_output=False), str(tmp_path), labels, barcodes)
+        w.file.close()
+        w.file = io.StringIO()
+        assert w.write_table_rows(t, rows)
+        native_text = w.file.getvalue()
+        w.file = io.StringIO()
+        w.write_columns(summary_columns(t, rows, barcoding, polya))
+        assert native_text == w.file.getvalue()
+        assert native_text.count('\n') == len(rows)
+
+
+def test_native_summary_rows_decline_what_they_cannot_print(tmp_path):
+    import io
+    from poreplex_amd.config import default_config
+    cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path), barcoding=True, filter_unsplit_reads=True)
+    labels, barcodes, _ = SINK.setup_output_name_mapping(cfg)
+    t, rows = _random_table(tmp_path, 40, 9, unicode_name=True)
+    w = SINK.SequencingSummaryWriter(dict(cfg, fast5_output=False), str(tmp_path), labels, barcodes)
+    w.file.close()
+    w.file = io.StringIO()
+    assert w.write_table_rows(t, rows) is False and w.file.getvalue() == ''      # non-ASCII file name
+    w2 = SINK.SequencingSummaryWriter(dict(cfg, fast5_output=True), str(tmp_path), labels, barcodes)
+    assert w2.write_table_rows(t, rows[:3]) is False                               # fast5 layout
+    w2.close()
