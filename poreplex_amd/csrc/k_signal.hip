@@ -28,6 +28,32 @@ int pxg_launch_raw_to_pa(pxg_ctx* ctx, int64_t n, const int16_t* raw, const pxg_
 }
 
 // ---------------------------------------------------------------------------
+// start of a run: per-read state back to "nothing decided" in ONE launch (it was five
+// hipMemsetAsync fills, ~4.4 us each plus the gaps between them)
+// ---------------------------------------------------------------------------
+__global__ void k_reset_batch(int64_t n_reads, int32_t* __restrict__ counters, int32_t* __restrict__ status,
+                              float* __restrict__ pred, float* __restrict__ ss, int32_t* __restrict__ segs)
+{
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r < 8) counters[r] = 0;
+    if (r >= n_reads) return;
+    status[r] = 0;
+    reinterpret_cast<float2*>(pred)[r] = make_float2(0.0f, 0.0f);
+    reinterpret_cast<float2*>(ss)[r] = make_float2(0.0f, 0.0f);
+    int4* sg = reinterpret_cast<int4*>(segs + r * 2 * PXG_N_SEGMENTS);
+#pragma unroll
+    for (int q = 0; q < 2 * PXG_N_SEGMENTS / 4; q++) sg[q] = make_int4(-1, -1, -1, -1);
+}
+
+int pxg_launch_reset_batch(pxg_ctx* ctx, int64_t n)
+{
+    const int64_t threads = n > 8 ? n : 8;
+    hipLaunchKernelGGL(k_reset_batch, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, n,
+                       ctx->counters.p, ctx->status.p, ctx->pred.p, ctx->ss.p, ctx->segs.p);
+    return PXG_OK;
+}
+
+// ---------------------------------------------------------------------------
 // K1: one thread per output element of the left-padded head (width = 2000).
 // ---------------------------------------------------------------------------
 __global__ void k_head_pool(int64_t n_reads, const int16_t* __restrict__ raw,

@@ -567,11 +567,7 @@ extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
     memset(ctx->launches, 0, sizeof(ctx->launches));
     int rc;
     pxg_timer_begin(ctx, PXG_T_TOTAL);
-    PXG_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 8 * sizeof(int32_t), ctx->stream));
-    PXG_HIP(ctx, hipMemsetAsync(ctx->status.p, 0, (size_t)n * sizeof(int32_t), ctx->stream));
-    PXG_HIP(ctx, hipMemsetAsync(ctx->pred.p, 0, (size_t)n * 2 * sizeof(float), ctx->stream));
-    PXG_HIP(ctx, hipMemsetAsync(ctx->ss.p, 0, (size_t)n * 2 * sizeof(float), ctx->stream));
-    PXG_HIP(ctx, hipMemsetAsync(ctx->segs.p, 0xFF, (size_t)n * 2 * PXG_N_SEGMENTS * sizeof(int32_t), ctx->stream));
+    if ((rc = pxg_launch_reset_batch(ctx, n))) return rc;
 
     if (stage_mask & PXG_STAGE_SCALER) {
         pxg_timer_begin(ctx, PXG_T_HEAD_POOL);

@@ -387,6 +387,7 @@ int pxg_launch_scaler_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
 int pxg_launch_demux_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
                           const int32_t* count, const float* win, float* bidir, float* probs,
                           int timer_a, int timer_b);
+int pxg_launch_reset_batch(pxg_ctx* ctx, int64_t n);
 int pxg_launch_finalize(pxg_ctx* ctx, int64_t n, uint32_t stage_mask);
 int pxg_lstm_upload(pxg_ctx* ctx);   // shape checks
 int pxg_polya_supported(pxg_ctx* ctx);
