@@ -26,10 +26,9 @@
 #include <type_traits>
 #include "pxg_common.h"
 
-#define VIT_CHAINS 1            // independent 8-read sets per recurrence wave (2 measured slower: 2.6 vs 1.9 ms, the wave is issue-bound)
-#define VIT_READS (8 * VIT_CHAINS)
+#define VIT_READS 8             // reads per block = 8-lane groups of the recurrence wave
 #define VIT_CHUNK 16
-#define VIT_THREADS (64 * (1 + 2 * VIT_CHAINS))   // wave 0: recurrence; the others: emissions of the next chunk
+#define VIT_THREADS 192         // wave 0: recurrence; waves 1-2: emissions of the next chunk
 
 __device__ __forceinline__ double hmm_emission(const PxgHmmDev& H, const double* lsetab, int s, double x)
 {
@@ -211,7 +210,7 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
     const int n_chunks = (Tmax + VIT_CHUNK - 1) / VIT_CHUNK;
 
     if (wv > 0) {
-        // ================= emission producers (waves 1 .. 2*VIT_CHAINS) ===============
+        // ================= emission producers (waves 1 and 2) ==========================
         // lane -> (read, step) of a chunk: 64 lanes = 4 reads x 16 steps;
         // consecutive lanes pool consecutive 15-sample blocks (coalesced)
         const int item = (wv - 1) * 64 + lane;
