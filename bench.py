@@ -495,8 +495,9 @@ def main():
         extra['pcie_inclusive_reads_per_s'] = n_local / (elapsed / args.steps + t_upload)
         nbytes_in = base['arena'].nbytes
         try:
-            if args.no_overlap_test:
-                raise N.PxgError('skipped (--no-overlap-test)')
+            if args.no_overlap_test or world > 1:     # a one-GPU figure: the other ranks have left by now
+                raise N.PxgError('skipped (--no-overlap-test)' if args.no_overlap_test else
+                                 'skipped: PCIe figures are measured at N = 1')
             ctx.pin(base['arena'])
             n_over = min(args.steps, 5)
             ctx.sync()
@@ -529,7 +530,8 @@ def main():
     if args.cpu_sample > 0 and not standin:
         from oracle.pxo import Oracle
         orc = Oracle(config)
-        ns = min(args.cpu_sample, n_local)
+        # N > 1: no cpu_baseline (it is an N = 1 figure), only the concordance check on a small sample
+        ns = min(args.cpu_sample if world == 1 else min(args.cpu_sample, 128), n_local)
         parts = [base['arena'][base['offsets'][b]:base['offsets'][b + 1]] for b in which[:ns]]
         s_arena, s_off = N.pack_reads(parts)
         s_cal = base['calib'][which[:ns]]
@@ -579,6 +581,8 @@ def main():
         }
         if cand_mismatch is not None:
             concordance['unsplit_candidate_mismatch'] = cand_mismatch
+        if world > 1:
+            cpu = None
 
     line = {
         'metric': wl_metric,
