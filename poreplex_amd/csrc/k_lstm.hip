@@ -328,8 +328,28 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm(
 // agent scope: the L2s of the 8 XCDs are not coherent with each other).  The step
 // body is k_scaler_lstm<1>'s, results are bit-identical.
 // ===========================================================================
-#define QBS 256                 // steps per task (multiple of XCH)
 #define QSTATE (2 * 16 * HSTRIDE(48) + 2 * LSTM_THREADS * 3)    // floats per saved tile state
+#define SQ_MAXBLK 32            // most step blocks per tile
+#define SQ_HANDOVER 3           // cost of one hand-over, in steps (cost model only)
+
+// Steps per task, chosen on the device from the actual tile count: the launch takes
+// ceil(tiles x blocks / slots) rounds of tasks, so the cut is the block count that minimises
+// rounds x block length.  (Round 1 used a fixed 256 steps: 625 tiles x 8 blocks on 512 slots
+// = 9.77 rounds = 9 x 256 + 209 = 2 513 step times for 2 442 of work; 9 blocks of 224 steps
+// fill 10.99 rounds: 2 449.)  Lengths are multiples of 4 so that the float4 loads of the x
+// tile stay aligned.
+__device__ __forceinline__ int scaler_block_steps(int n_tiles, int slots, int T1)
+{
+    int best = T1, best_cost = 0x7fffffff;
+    for (int nb = 1; nb <= SQ_MAXBLK; nb++) {
+        const int qb = (((T1 + nb - 1) / nb) + 3) & ~3;
+        const int blocks = (T1 + qb - 1) / qb;
+        const int rounds = (blocks * n_tiles + slots - 1) / slots;
+        const int cost = rounds * (qb + SQ_HANDOVER);
+        if (cost < best_cost) { best_cost = cost; best = qb; }
+    }
+    return best;
+}
 
 __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q(
     int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int T,
@@ -344,6 +364,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lim = count ? min(*count, n_rows) : n_rows;
     const int n_tiles = (lim + 15) >> 4;
+    const int QBS = scaler_block_steps(n_tiles, (int)gridDim.x, T + 1);
     const int n_blocks = (T + 1 + QBS - 1) / QBS;
     const int n_tasks = n_tiles * n_blocks;
 
@@ -390,7 +411,9 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q(
             ridx[tid] = row < lim ? (idx ? idx[row] : row) : -1;
         }
         float c1[NT], c2[NT];
-        float* st_in = state + ((size_t)(blk - 1) * n_tiles + tile) * QSTATE;
+        // two alternating state slots per tile: block b + 2 overwrites block b's only after block
+        // b + 1 -- which read it -- has published
+        float* st_in = state + ((size_t)((blk - 1) & 1) * n_tiles + tile) * QSTATE;
         if (blk == 0) {
             for (int i = tid; i < 4 * 16 * HS; i += LSTM_THREADS) h1[i] = 0.0f;    // h1 and h2, both buffers
 #pragma unroll
@@ -419,7 +442,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q(
         __syncthreads();
 
         for (int t = t0; t < t1; t++) {
-            if ((t % XCH) == 0 && t < T) {        // refill the x tile (rows x XCH steps)
+            if (((t - t0) % XCH) == 0 && t < T) {        // refill the x tile (rows x XCH steps)
                 __syncthreads();
                 for (int i = tid; i < 16 * (XCH / 4); i += LSTM_THREADS) {
                     const int row = i / (XCH / 4), c4 = i % (XCH / 4);
@@ -436,7 +459,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q(
             load_afrag<H>(a1, h1 + rdb * 16 * HS, lane);
             load_afrag<H>(a2, h2 + rdb * 16 * HS, lane);
             f32x4 acc1[NT], acc2[NT];
-            const float x = xb[rd_l * XS + (t % XCH)];
+            const float x = xb[rd_l * XS + ((t - t0) % XCH)];
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
 #pragma unroll
@@ -494,7 +517,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q(
             }
         } else {
             // ---- hand the tile over: state of iteration t1 -> HBM, then publish -------
-            float* st_out = state + ((size_t)blk * n_tiles + tile) * QSTATE;
+            float* st_out = state + ((size_t)(blk & 1) * n_tiles + tile) * QSTATE;
             const int rb = t1 & 1;
             for (int i = tid; i < 16 * HS; i += LSTM_THREADS) {
                 st_out[i] = h1[rb * 16 * HS + i];
@@ -1365,10 +1388,9 @@ int pxg_launch_scaler_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
     if (tiles > slots && !getenv("PXG_NO_TIMESLICE")) {
         // more tiles than resident workgroups: time-slice (see k_scaler_lstm_q); measured against
         // the static split: 10 000 reads 13.3 -> 10.7 ms, 50 000 reads 75 -> 51, 100 000 reads 131 -> 101
-        const int n_blocks = (T + 1 + QBS - 1) / QBS;
         int rc;
         if ((rc = pxg_timeslice_prepare(ctx)) || (rc = pxg_reserve(ctx, ctx->lstm_q, (size_t)(2 + tiles))) ||
-            (rc = pxg_reserve(ctx, ctx->lstm_state, (size_t)n_blocks * tiles * QSTATE)))
+            (rc = pxg_reserve(ctx, ctx->lstm_state, (size_t)2 * tiles * QSTATE)))
             return rc;
         PXG_HIP(ctx, hipMemsetAsync(ctx->lstm_q.p, 0, (size_t)(2 + tiles) * sizeof(int), ctx->stream));
         const size_t lds = kTabBytes + sizeof(float) * (4 * 16 * HSTRIDE(48) + 16 * XS) + sizeof(int) * 32;
