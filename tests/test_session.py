@@ -204,3 +204,26 @@ def test_session_on_gpu_streams_batches_through_stage_swap(tmp_path, bundle):
     w.close()
     assert (tmp_path / 'b' / 'sequencing_summary.txt').read_bytes() == \
         (tmp_path / 'c' / 'sequencing_summary.txt').read_bytes()
+
+
+def test_session_degenerate_inputs(oracle_backed, tmp_path):
+    """No reads at all, one read per batch, and a run whose reads all fail before the GPU pass
+    (files that are not in the bundle): the driver still writes complete, consistent outputs."""
+    from poreplex_amd.session import GpuSession
+    cfg = session_config(tmp_path / 'none', 'chimera.pxr.npz')
+    out = GpuSession(cfg, batch_reads=4).run([])
+    assert out['reads'] == 0 and out['batches'] == 0 and len(out['labels']) == 0
+    assert (tmp_path / 'none' / 'sequencing_summary.txt').read_text().count('\n') == 1      # header only
+    WorkerPersistenceStorage.reset()
+    reads = golden_reads('chimera.pxr.npz')
+    one = run_session(tmp_path / 'one', 'chimera.pxr.npz', batch_reads=1)
+    many = run_session(tmp_path / 'many', 'chimera.pxr.npz', batch_reads=64)
+    assert one['batches'] == len(reads) and many['batches'] == 1
+    assert (tmp_path / 'one' / 'sequencing_summary.txt').read_bytes() == \
+        (tmp_path / 'many' / 'sequencing_summary.txt').read_bytes()
+    assert one['labels'].tobytes() == many['labels'].tobytes()
+    WorkerPersistenceStorage.reset()
+    ghosts = [('no/such/file_%d.fast5' % i, 'ghost-%d' % i) for i in range(7)]
+    out = GpuSession(session_config(tmp_path / 'ghosts', 'chimera.pxr.npz'), batch_reads=3).run(ghosts)
+    assert out['reads'] == 7 and len(out['labels']) == 7
+    assert int(out['counts'].sum()) == 7
