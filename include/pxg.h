@@ -373,7 +373,7 @@ int pxg_detect_events(pxg_ctx* ctx, int64_t n_windows, const float* signal_arena
  * The rows of sequencing_summary.txt (io.py:120-184, SequencingSummaryWriter.write_results)
  * as text, from columns -- byte for byte what the reference's print of str(int), repr(float),
  * round(start_time / sampling_rate, 3) and format(dwell, '.4f') produces.  Host only, exported by
- * libpxgtext.so (no HIP runtime behind it, loads anywhere).  The
+ * libpxghost.so (no HIP runtime behind it, loads anywhere).  The
  * five string fields come straight from NumPy '<U' arrays (UCS-4, fixed width, NUL padded):
  * text[0..4] = filename, read_id, run_id, channel, sample_id, row string_row[k] of each.
  * Every other array has n elements.  barcode_names == NULL: barcoding off (no barcode /
@@ -397,6 +397,36 @@ typedef struct {
     const uint8_t* has_polya;   const double* polya_dwell;
 } pxg_summary_columns;
 int64_t pxg_summary_rows(const pxg_summary_columns* cols, char* out, int64_t cap);
+
+/* ---- compressed samples across PCIe --------------------------------------
+ * A read bundle may carry its samples as zig-zag deltas of one or two bytes (the variable-
+ * byte stage of ONT's VBZ) in independent chunks of PXG_Z_CHUNK samples that never span
+ * reads: 128 control bytes (bit i: sample i took two bytes) + the data bytes of samples
+ * 1 .. len-1; sample 0 is in the chunk record.  pxg_batch_stage_z copies the bytes and the
+ * chunk records of a batch to the device and decodes them there into the spare input slot
+ * (a workgroup per chunk), so the link carries ~1.1 bytes per sample instead of 2; the
+ * resident batch is the same int16 arena either way.  data_off / dst of the records may be
+ * relative to any base: the call takes the bases of the slice it is given.
+ * pxg_z_encode / pxg_z_decode / pxg_z_count_chunks: host only (libpxghost.so). */
+#define PXG_Z_CHUNK 1024
+#define PXG_Z_CTRL_BYTES (PXG_Z_CHUNK / 8)
+typedef struct {
+    int64_t data_off;      /* byte offset of the chunk (its control bytes) in the encoded stream */
+    int64_t dst;           /* sample index of the chunk's first sample in the decoded arena */
+    int16_t first;         /* sample 0 */
+    int16_t len;           /* samples in the chunk, 1 .. PXG_Z_CHUNK */
+    int32_t reserved;
+} pxg_z_chunk;
+int64_t pxg_z_count_chunks(int64_t n_reads, const int64_t* offsets);
+/* -> bytes written (worst case PXG_Z_CTRL_BYTES * chunks + 2 * samples), PXG_E_NOMEM if cap is short */
+int64_t pxg_z_encode(int64_t n_reads, const int16_t* arena, const int64_t* offsets, uint8_t* out,
+                     int64_t cap, pxg_z_chunk* chunks);
+int pxg_z_decode(int64_t n_chunks, const uint8_t* z, const pxg_z_chunk* chunks, int64_t data_base,
+                 int64_t dst_base, int16_t* out);
+int pxg_batch_stage_z(pxg_ctx* ctx, int64_t n_reads, const uint8_t* z, int64_t z_bytes,
+                      const pxg_z_chunk* chunks, int64_t n_chunks, int64_t data_base, int64_t dst_base,
+                      const int64_t* raw_offsets, const pxg_calib* calib,
+                      const float* scale_shift_or_null);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,83 @@ int pxg_launch_reset_batch(pxg_ctx* ctx, int64_t n)
 }
 
 // ---------------------------------------------------------------------------
+// K0: samples that crossed PCIe as zig-zag delta bytes (pxg_batch_stage_z, include/pxg.h) back to
+// int16.  One workgroup per 1 024-sample chunk, four samples per thread: the byte offset of a
+// sample is a prefix sum of (1 + control bit), its value a prefix sum of the deltas -- both as
+// a per-thread serial part + one wave scan + one cross-wave step.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int block_exclusive_scan_256(int v, int* wave_totals, int& total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_totals[wv] = inc;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) base += (w < wv) ? wave_totals[w] : 0;
+    total = wave_totals[0] + wave_totals[1] + wave_totals[2] + wave_totals[3];
+    __syncthreads();                       // wave_totals may be reused
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_z_decode(int64_t n_chunks, const uint8_t* __restrict__ z,
+                                                  const pxg_z_chunk* __restrict__ chunks, int64_t data_base,
+                                                  int64_t dst_base, int16_t* __restrict__ out)
+{
+    __shared__ int wave_totals[4];
+    const int64_t g = blockIdx.x;
+    if (g >= n_chunks) return;
+    const pxg_z_chunk c = chunks[g];
+    const uint8_t* ctrl = z + (c.data_off - data_base);
+    const uint8_t* data = ctrl + PXG_Z_CTRL_BYTES;
+    const int t = threadIdx.x, i0 = 4 * t;                 // samples i0 .. i0 + 3 of the chunk
+    const unsigned bits = (ctrl[t >> 1] >> ((t & 1) * 4)) & 0xFu;
+    int size[4], mine = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int i = i0 + q;
+        size[q] = (i >= 1 && i < c.len) ? 1 + (int)((bits >> q) & 1u) : 0;     // sample 0 is in the record
+        mine += size[q];
+    }
+    int total;
+    int at = block_exclusive_scan_256(mine, wave_totals, total);
+    int delta[4], sum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        unsigned zz = 0;
+        if (size[q] >= 1) zz = data[at];
+        if (size[q] == 2) zz |= (unsigned)data[at + 1] << 8;
+        at += size[q];
+        delta[q] = (int)((zz >> 1) ^ (0u - (zz & 1u)));      // zig-zag; only the low 16 bits matter
+        sum += delta[q];
+        delta[q] = sum;                                       // inclusive, inside the thread
+    }
+    const int before = block_exclusive_scan_256(sum, wave_totals, total);
+    int16_t* dst = out + (c.dst - dst_base);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (i0 + q < c.len) dst[i0 + q] = (int16_t)(uint16_t)((int)c.first + before + delta[q]);
+}
+
+int pxg_launch_z_decode(pxg_ctx* ctx, hipStream_t stream, int64_t n_chunks, const uint8_t* z,
+                        const pxg_z_chunk* chunks, int64_t data_base, int64_t dst_base, int16_t* out)
+{
+    if (n_chunks <= 0) return PXG_OK;
+    if (n_chunks > 0x7fffffffLL) {
+        ctx->err = "pxg_batch_stage_z: too many chunks";
+        return PXG_E_INVALID;
+    }
+    hipLaunchKernelGGL(k_z_decode, dim3((unsigned)n_chunks), dim3(256), 0, stream, n_chunks, z, chunks, data_base,
+                       dst_base, out);
+    return PXG_OK;
+}
+
+// ---------------------------------------------------------------------------
 // K1: one thread per output element of the left-padded head (width = 2000).
 // ---------------------------------------------------------------------------
 __global__ void k_head_pool(int64_t n_reads, const int16_t* __restrict__ raw,

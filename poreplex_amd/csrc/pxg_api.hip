@@ -276,7 +276,7 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     release(ctx->lstm_q); release(ctx->lstm_state); release(ctx->lstm_err);
     release(ctx->demux_q); release(ctx->demux_state);
     release(ctx->spare.raw); release(ctx->spare.offsets); release(ctx->spare.calib); release(ctx->spare.inject);
-    release(ctx->results); release(ctx->unsplit_q); release(ctx->vit_bp); release(ctx->polya_ev); release(ctx->polya_over); release(ctx->polya_retry); release(ctx->polya_out); release(ctx->spikes);
+    release(ctx->results); release(ctx->spare.z); release(ctx->spare.zchunks); release(ctx->unsplit_q); release(ctx->vit_bp); release(ctx->polya_ev); release(ctx->polya_over); release(ctx->polya_retry); release(ctx->polya_out); release(ctx->spikes);
     release(ctx->ev_first); release(ctx->ev_off); release(ctx->ev_mean); release(ctx->ev_scaled);
     release(ctx->unsplit_scr); release(ctx->unsplit_iv); release(ctx->unsplit_cnt); release(ctx->unsplit_ivoff);
     release(ctx->unsplit_cand); release(ctx->unit_off); release(ctx->n_win);
@@ -502,6 +502,55 @@ extern "C" int pxg_batch_stage(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw
     if (sp.have_inject)
         PXG_HIP(ctx, hipMemcpyAsync(sp.inject.p, scale_shift_or_null, (size_t)n_reads * 2 * sizeof(float),
                                     hipMemcpyHostToDevice, cs));
+    PXG_HIP(ctx, hipEventRecord(ctx->ev_staged, cs));
+    sp.n_reads = n_reads;
+    sp.n_samples = n_samples;
+    rate_range(calib, n_reads, sp.rate_min, sp.rate_max);
+    sp.staged = true;
+    return PXG_OK;
+}
+
+// pxg_batch_stage with the samples as encoded bytes (include/pxg.h): the bytes and the chunk
+// records cross the link, a decode kernel on the copy stream fills the spare slot's int16 arena.
+extern "C" int pxg_batch_stage_z(pxg_ctx* ctx, int64_t n_reads, const uint8_t* z, int64_t z_bytes,
+                                 const pxg_z_chunk* chunks, int64_t n_chunks, int64_t data_base,
+                                 int64_t dst_base, const int64_t* raw_offsets, const pxg_calib* calib,
+                                 const float* scale_shift_or_null)
+{
+    if (!ctx) return PXG_E_INVALID;
+    int rc = check_batch_args(ctx, n_reads, (const int16_t*)z, raw_offsets, calib, "pxg_batch_stage_z");
+    if (rc) return rc;
+    if (n_reads == 0) return fail(ctx, PXG_E_INVALID, "pxg_batch_stage_z: empty batch");
+    if (z_bytes < 0 || n_chunks < 0 || (n_chunks && !chunks)) return fail(ctx, PXG_E_INVALID, "pxg_batch_stage_z: bad arguments");
+    PXG_HIP(ctx, hipSetDevice(ctx->device));
+    auto& sp = ctx->spare;
+    sp.staged = false;
+    const int64_t n_samples = raw_offsets[n_reads];
+    if ((rc = pxg_reserve(ctx, sp.raw, (size_t)n_samples + 64)) ||
+        (rc = pxg_reserve(ctx, sp.offsets, (size_t)n_reads + 1)) ||
+        (rc = pxg_reserve(ctx, sp.calib, (size_t)n_reads)) ||
+        (rc = pxg_reserve(ctx, sp.inject, (size_t)n_reads * 2)) ||
+        (rc = pxg_reserve(ctx, sp.z, (size_t)z_bytes + 16)) ||
+        (rc = pxg_reserve(ctx, sp.zchunks, (size_t)n_chunks + 1)))
+        return rc;
+    if (ctx->run_recorded[ctx->cur ^ 1])
+        PXG_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_run_done[ctx->cur ^ 1], 0));
+    hipStream_t cs = ctx->copy_stream;
+    if (z_bytes) PXG_HIP(ctx, hipMemcpyAsync(sp.z.p, z, (size_t)z_bytes, hipMemcpyHostToDevice, cs));
+    if (n_chunks)
+        PXG_HIP(ctx, hipMemcpyAsync(sp.zchunks.p, chunks, (size_t)n_chunks * sizeof(pxg_z_chunk),
+                                    hipMemcpyHostToDevice, cs));
+    PXG_HIP(ctx, hipMemcpyAsync(sp.offsets.p, raw_offsets, (size_t)(n_reads + 1) * sizeof(int64_t),
+                                hipMemcpyHostToDevice, cs));
+    PXG_HIP(ctx, hipMemcpyAsync(sp.calib.p, calib, (size_t)n_reads * sizeof(pxg_calib),
+                                hipMemcpyHostToDevice, cs));
+    sp.have_inject = scale_shift_or_null != nullptr;
+    if (sp.have_inject)
+        PXG_HIP(ctx, hipMemcpyAsync(sp.inject.p, scale_shift_or_null, (size_t)n_reads * 2 * sizeof(float),
+                                    hipMemcpyHostToDevice, cs));
+    if ((rc = pxg_launch_z_decode(ctx, cs, n_chunks, sp.z.p, sp.zchunks.p, data_base, dst_base, sp.raw.p)))
+        return rc;
+    PXG_HIP(ctx, hipGetLastError());
     PXG_HIP(ctx, hipEventRecord(ctx->ev_staged, cs));
     sp.n_reads = n_reads;
     sp.n_samples = n_samples;

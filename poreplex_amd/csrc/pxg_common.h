@@ -280,6 +280,8 @@ struct pxg_ctx {
         int64_t n_reads = 0, n_samples = 0;
         bool have_inject = false, staged = false;
         double rate_min = 0.0, rate_max = 0.0;
+        DevBuf<uint8_t> z;           // encoded samples of a pxg_batch_stage_z batch ...
+        DevBuf<pxg_z_chunk> zchunks; // ... and their chunk records, decoded into `raw` on the copy stream
     } spare;
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_staged = nullptr;
@@ -388,6 +390,8 @@ int pxg_launch_demux_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
                           const int32_t* count, const float* win, float* bidir, float* probs,
                           int timer_a, int timer_b);
 int pxg_launch_reset_batch(pxg_ctx* ctx, int64_t n);
+int pxg_launch_z_decode(pxg_ctx* ctx, hipStream_t stream, int64_t n_chunks, const uint8_t* z, const pxg_z_chunk* chunks,
+                        int64_t data_base, int64_t dst_base, int16_t* out);
 int pxg_launch_finalize(pxg_ctx* ctx, int64_t n, uint32_t stage_mask);
 int pxg_lstm_upload(pxg_ctx* ctx);   // shape checks
 int pxg_polya_supported(pxg_ctx* ctx);

@@ -1,4 +1,4 @@
-// pxg_text.cpp -- libpxgtext.so, host only: the rows of sequencing_summary.txt (io.py:120-184,
+// pxg_text.cpp -- libpxghost.so, host only: the rows of sequencing_summary.txt (io.py:120-184,
 // SequencingSummaryWriter) formatted from columns.  After the kernels went from ~70 to ~15 ms
 // per 10 000-read batch the session's main thread was the slowest stage of the end-to-end
 // pipeline, and a third of it was Python building this text field by field (1.05 us per

@@ -72,18 +72,28 @@ def basecall_columns(basecalls):
     return c
 
 
-def write_bundle(path, arena, offsets, calib, filename, read_id, basecalls=None, **columns):
-    """Write a version-2 .pxr.npz read bundle (this build's array container for many reads:
-    int16 samples + per-read metadata + columnar basecall summaries).  Missing metadata
-    columns get neutral defaults."""
+def write_bundle(path, arena, offsets, calib, filename, read_id, basecalls=None, compress=False, **columns):
+    """Write a .pxr.npz read bundle (this build's array container for many reads: int16
+    samples + per-read metadata + columnar basecall summaries).  Missing metadata columns get
+    neutral defaults.  compress=True stores the samples as zig-zag delta bytes in independent
+    1 024-sample chunks (include/pxg.h, pxg_z_*: ~1.2 bytes per sample) instead of the int16
+    arena; the session then sends those bytes across PCIe and the GPU decodes them."""
     n = len(offsets) - 1
-    d = {'arena': np.ascontiguousarray(arena, dtype=np.int16),
-         'offsets': np.ascontiguousarray(offsets, dtype=np.int64), 'calib': calib,
+    arena = np.ascontiguousarray(arena, dtype=np.int16)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    if compress:
+        from . import native
+        z, chunks, chunk_base = native.z_encode(arena, offsets)
+        samples = {'arena_z': z, 'z_chunks': chunks, 'z_chunk_base': chunk_base}
+    else:
+        samples = {'arena': arena}
+    d = {'offsets': offsets, 'calib': calib,
          'filename': np.asarray(filename), 'read_id': np.asarray(read_id),
          'duration': np.diff(offsets), 'start_time': np.zeros(n, dtype=np.int64),
          'channel_number': np.array(['0'] * n), 'run_id': np.array(['run'] * n),
          'sample_id': np.array(['sample'] * n), 'broken_files': np.array([], dtype='<U1'),
-         'bundle_version': np.int64(2)}
+         'bundle_version': np.int64(3 if compress else 2)}
+    d.update(samples)
     d.update(columns)
     d.update(basecall_columns(basecalls if basecalls is not None else [None] * n))
     np.savez(path, **d)
@@ -108,6 +118,28 @@ class ReadBundle:
             self.by_file.setdefault(f, []).append(i)
         # files that exist but cannot be opened (the corrupt-FAST5 case)
         self.broken = set(str(f) for f in d.get('broken_files', []))
+
+    compressed = property(lambda self: 'arena_z' in self.d)
+
+    def samples_run(self, i0, i1):
+        """The samples of the consecutive reads [i0, i1): an int16 view of the arena, or -- in a
+        compressed bundle -- the encoded bytes and chunk records of exactly those reads
+        (native.EncodedSamples, views as well: chunks never span reads)."""
+        d = self.d
+        o = d['offsets']
+        if not self.compressed:
+            return d['arena'][o[i0]:o[i1]]
+        from . import native
+        base, ch = d['z_chunk_base'], d['z_chunks']
+        c0, c1 = int(base[i0]), int(base[i1])
+        b0 = int(ch['data_off'][c0]) if c0 < len(ch) else len(d['arena_z'])
+        b1 = int(ch['data_off'][c1]) if c1 < len(ch) else len(d['arena_z'])
+        return native.EncodedSamples(d['arena_z'][b0:b1], ch[c0:c1], b0, int(o[i0]), int(o[i1] - o[i0]))
+
+    def samples(self, i):
+        """int16 samples of read i (decoded on the host if the bundle is compressed)."""
+        run = self.samples_run(i, i + 1)
+        return run if isinstance(run, np.ndarray) else run.decode()
 
     def has_file(self, filename):
         return filename in self.by_file or filename in self.broken
@@ -179,8 +211,7 @@ class BundleReader:
         pass
 
     def get_raw_int16(self):
-        o = self.d['offsets']
-        return self.d['arena'][o[self.i]:o[self.i + 1]]
+        return self.bundle.samples(self.i)
 
     def get_basecall(self):
         """Summary of Analyses/Basecall_1D_* (fast5_file.py:133-164); None if absent."""

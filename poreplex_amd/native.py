@@ -336,9 +336,12 @@ class NativeConfig:
 # --------------------------------------------------------------------------
 _lib = None
 
-TEXT_LIB_PATH = os.path.join(HERE, 'csrc', 'libpxgtext.so')
-_TEXT_SIGNATURES = {      # libpxgtext.so: host-only text of the result sinks
+TEXT_LIB_PATH = os.path.join(HERE, 'csrc', 'libpxghost.so')
+_TEXT_SIGNATURES = {      # libpxghost.so: host-only helpers (sink text, sample codec)
     'pxg_summary_rows': (C.c_int64, [C.POINTER(PxgSummaryColumns), C.c_char_p, C.c_int64]),
+    'pxg_z_count_chunks': (C.c_int64, [C.c_int64, C.c_void_p]),
+    'pxg_z_encode': (C.c_int64, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'pxg_z_decode': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
 }
 _text_lib = None
 
@@ -354,6 +357,8 @@ _SIGNATURES = {
                                    C.c_void_p, C.c_void_p]),
     'pxg_batch_stage': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
+    'pxg_batch_stage_z': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                    C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pxg_batch_upload_tiled': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     'pxg_batch_swap': (C.c_int, [C.c_void_p]),
@@ -414,7 +419,7 @@ def load_library(path=None):
 
 
 def load_text_library(path=None):
-    """Load libpxgtext.so (built next to libpxg.so by the same Makefile); loud when absent."""
+    """Load libpxghost.so (built next to libpxg.so by the same Makefile); loud when absent."""
     global _text_lib
     if _text_lib is not None and path is None:
         return _text_lib
@@ -432,6 +437,59 @@ def load_text_library(path=None):
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+# ---- compressed samples (include/pxg.h, pxg_zcodec.cpp) ---------------------------------------
+Z_CHUNK = 1024
+Z_CHUNK_DTYPE = np.dtype([('data_off', np.int64), ('dst', np.int64), ('first', np.int16),
+                          ('len', np.int16), ('reserved', np.int32)])
+
+
+def z_encode(arena, offsets):
+    """int16 samples of many reads -> (bytes uint8[], chunk records, chunk_base int64[n + 1]):
+    chunk_base[r] = index of read r's first chunk.  Host side, offline (bundle writing)."""
+    lib = load_text_library()
+    arena = np.ascontiguousarray(arena, dtype=np.int16)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = len(offsets) - 1
+    per_read = (np.diff(offsets) + Z_CHUNK - 1) // Z_CHUNK
+    chunk_base = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(per_read, out=chunk_base[1:])
+    n_chunks = int(chunk_base[-1])
+    chunks = np.zeros(n_chunks, dtype=Z_CHUNK_DTYPE)
+    out = np.empty(n_chunks * (Z_CHUNK // 8) + 2 * len(arena) + 16, dtype=np.uint8)
+    got = lib.pxg_z_encode(n, _ptr(arena), _ptr(offsets), _ptr(out), len(out), _ptr(chunks))
+    if got < 0:
+        raise PxgError('pxg_z_encode failed ({})'.format(got))
+    return out[:got].copy(), chunks, chunk_base
+
+
+def z_decode(z, chunks, n_samples, data_base=0, dst_base=0):
+    """Reference decoder (host): the int16 samples the chunk records describe."""
+    lib = load_text_library()
+    z = np.ascontiguousarray(z, dtype=np.uint8)
+    chunks = np.ascontiguousarray(chunks, dtype=Z_CHUNK_DTYPE)
+    out = np.zeros(int(n_samples), dtype=np.int16)
+    rc = lib.pxg_z_decode(len(chunks), _ptr(z), _ptr(chunks), int(data_base), int(dst_base), _ptr(out))
+    if rc:
+        raise PxgError('pxg_z_decode failed ({})'.format(rc))
+    return out
+
+
+class EncodedSamples:
+    """The samples of a run of consecutive reads as the encoded bytes + chunk records of a
+    bundle (views, nothing copied): what ReadBundle hands to the loader instead of an int16
+    arena, and NativeContext.stage_z sends across the link."""
+
+    def __init__(self, z, chunks, data_base, dst_base, n_samples):
+        self.z, self.chunks = z, chunks
+        self.data_base, self.dst_base, self.n_samples = int(data_base), int(dst_base), int(n_samples)
+
+    def __len__(self):
+        return self.n_samples
+
+    def decode(self):
+        return z_decode(self.z, self.chunks, self.n_samples, self.data_base, self.dst_base)
 
 
 def _names(strings):
@@ -594,6 +652,23 @@ class NativeContext:
         self._check(self.lib.pxg_batch_stage(
             self.handle, n, _ptr(arena), _ptr(offsets), _ptr(calib), _ptr(scale_shift)),
             'pxg_batch_stage')
+
+    def stage_z(self, enc, offsets, calib, scale_shift=None):
+        """stage() for samples that arrive encoded (EncodedSamples): the bytes cross the link
+        and are decoded on the device into the spare input slot."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        calib = np.ascontiguousarray(calib, dtype=CALIB_DTYPE)
+        n = len(offsets) - 1
+        if scale_shift is not None:
+            scale_shift = np.ascontiguousarray(scale_shift, dtype=np.float32).reshape(n, 2)
+        z = np.ascontiguousarray(enc.z, dtype=np.uint8)
+        chunks = np.ascontiguousarray(enc.chunks, dtype=Z_CHUNK_DTYPE)
+        if int(offsets[-1]) != enc.n_samples:
+            raise ValueError('offsets describe {} samples, the encoded slice {}'.format(int(offsets[-1]), enc.n_samples))
+        self._staged = ((z, chunks), offsets, calib, scale_shift, n)
+        self._check(self.lib.pxg_batch_stage_z(
+            self.handle, n, _ptr(z), len(z), _ptr(chunks), len(chunks), enc.data_base, enc.dst_base,
+            _ptr(offsets), _ptr(calib), _ptr(scale_shift)), 'pxg_batch_stage_z')
 
     def swap(self):
         """Make the staged batch the resident one (waits for its copies)."""

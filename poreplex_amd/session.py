@@ -148,9 +148,11 @@ class GpuSession:
                                                 header=self.rank == 0)
         fastq = sinks.FASTQWriter(outdir, layout, suffix=part) if cfg.get('fastq_output') else None
 
-        bundle_arena = self.loader.bundle.d['arena'] if self.loader.bundle is not None else None
+        bundle_arena = None
+        if self.loader.bundle is not None:       # batches of consecutive bundle reads are staged in place
+            bundle_arena = self.loader.bundle.d['arena_z' if self.loader.bundle.compressed else 'arena']
         if bundle_arena is not None and len(bundle_arena):
-            self.ctx.pin(bundle_arena)      # batches of consecutive bundle reads are staged in place
+            self.ctx.pin(bundle_arena)
         slots, ready = queue.Queue(), queue.Queue(maxsize=2)
         stagings = [_Staging(self.ctx), _Staging(self.ctx)]
         for s in stagings:
@@ -171,7 +173,10 @@ class GpuSession:
             """Start the H2D copy of a packed batch into the spare input slot (copy stream)."""
             if item is not None and len(item[2]):
                 item[1].settle()
-                self.ctx.stage(item[3], item[4], item[5])
+                if isinstance(item[3], native.EncodedSamples):     # compressed bundle: bytes + chunk records
+                    self.ctx.stage_z(item[3], item[4], item[5])
+                else:
+                    self.ctx.stage(item[3], item[4], item[5])
                 return True
             return False
 

@@ -146,8 +146,7 @@ class ReadTable:
         """int16 samples of a read that has not been packed yet."""
         if self.raw[i] is not None:
             return self.raw[i]
-        o, b = self.bundle.d['offsets'], int(self.bundle_index[i])
-        return self.bundle.d['arena'][o[b]:o[b + 1]]
+        return self.bundle.samples(int(self.bundle_index[i]))
 
     def sequence_of(self, i):
         """(sequence, quality string, adapter trim length) or None; bundle rows settled by the
@@ -486,9 +485,9 @@ class SignalLoader:
         bi = t.bundle_index[rows] if len(rows) else np.zeros(0, dtype=np.int64)
         if len(rows) and t.bundle is not None and bi[0] >= 0 and \
                 np.array_equal(bi, bi[0] + np.arange(len(rows))):
-            o = t.bundle.d['offsets']
             t.pending[rows] = False
-            return rows, t.bundle.d['arena'][o[bi[0]]:o[bi[-1] + 1]], offsets, \
+            # (an int16 view, or the encoded bytes of a compressed bundle: native.EncodedSamples)
+            return rows, t.bundle.samples_run(int(bi[0]), int(bi[-1]) + 1), offsets, \
                 np.ascontiguousarray(t.calib[rows])
         if hasattr(arena, 'reserve'):
             arena = arena.reserve(int(offsets[-1]))
@@ -533,6 +532,8 @@ class SignalLoader:
         t = self.table if table is None else table
         rows, arena, offsets, calib = self.pack(t)
         if len(rows):
+            if isinstance(arena, native.EncodedSamples):      # one-shot path: decode on the host
+                arena = arena.decode()
             self.ctx.upload(arena, offsets, calib)
             self.run_resident(t, rows, offsets)
 

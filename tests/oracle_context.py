@@ -42,6 +42,9 @@ class OracleBackedContext:
     def stage(self, arena, offsets, calib, scale_shift=None):
         self.staged = (np.array(arena), np.array(offsets), np.array(calib), scale_shift)
 
+    def stage_z(self, enc, offsets, calib, scale_shift=None):
+        self.stage(enc.decode(), offsets, calib, scale_shift)       # the host reference decoder
+
     def swap(self):
         self.upload(*self.staged)
         self.staged = None

@@ -1,0 +1,137 @@
+"""Compressed samples (include/pxg.h, pxg_z_*): the host codec round-trips every int16 pattern,
+a compressed read bundle is the same bundle, and the GPU decoder (-m gpu) fills the same arena
+the host decoder does."""
+import os
+
+import numpy as np
+import pytest
+
+from poreplex_amd import native as N
+from poreplex_amd.fast5_file import ReadBundle
+from poreplex_amd.synth import synth_batch
+from poreplex_amd.worker_persistence import WorkerPersistenceStorage
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def adversarial_reads(rng):
+    parts = []
+    for n in (0, 1, 2, 7, 1023, 1024, 1025, 2047, 2048, 2049, 5000, 0, 3):
+        kind = len(parts) % 5
+        if kind == 0:
+            x = rng.integers(-32768, 32768, n)                         # every delta needs two bytes
+        elif kind == 1:
+            x = np.full(n, -32768)                                      # zero deltas, extreme first
+        elif kind == 2:
+            x = np.where(np.arange(n) % 2 == 0, 32767, -32768)          # deltas that wrap around
+        elif kind == 3:
+            x = 500 + np.cumsum(rng.integers(-127, 128, n))             # one byte each, both signs: zz <= 255 edge
+        else:
+            x = 500 + np.cumsum(rng.choice([-128, 127, 128, -129, 0], n))   # straddles the 1 / 2 byte boundary
+        parts.append(np.asarray(x).astype(np.int16))
+    return parts
+
+
+def test_codec_round_trip_and_chunk_layout():
+    rng = np.random.default_rng(4)
+    parts = adversarial_reads(rng)
+    arena, off = N.pack_reads(parts)
+    z, chunks, base = N.z_encode(arena, off)
+    assert np.array_equal(N.z_decode(z, chunks, len(arena)), arena)
+    # chunks never span reads; chunk_base indexes them by read
+    per_read = (np.diff(off) + N.Z_CHUNK - 1) // N.Z_CHUNK
+    assert np.array_equal(np.diff(base), per_read) and len(chunks) == per_read.sum()
+    for r in range(len(parts)):
+        c = chunks[base[r]:base[r + 1]]
+        assert c['len'].sum() == len(parts[r])
+        if len(c):
+            assert c['dst'][0] == off[r] and np.array_equal(c['first'], arena[c['dst']])
+    # one byte per sample where the deltas are small, two where they are not
+    assert len(z) <= len(chunks) * (N.Z_CHUNK // 8) + 2 * len(arena)
+    sb = synth_batch(8, seed=3, samples_per_read=30000)
+    z2, ch2, _ = N.z_encode(sb['arena'], sb['offsets'])
+    assert np.array_equal(N.z_decode(z2, ch2, len(sb['arena'])), sb['arena'])
+    assert len(z2) < 1.3 * len(sb['arena'])              # ~1.17 bytes per sample on bench-like signal
+
+
+def compressed_copy(src, dst):
+    """The same bundle with its arena replaced by the encoded form."""
+    with np.load(src, allow_pickle=False) as npz:
+        d = {k: npz[k] for k in npz.files}
+    z, chunks, base = N.z_encode(d.pop('arena'), d['offsets'])
+    d.update(arena_z=z, z_chunks=chunks, z_chunk_base=base, bundle_version=np.int64(3))
+    np.savez(dst, **d)
+    return dst
+
+
+@pytest.mark.parametrize('bundle', ['batch0.pxr.npz', 'chimera.pxr.npz'])
+def test_compressed_bundle_is_the_same_bundle(tmp_path, bundle):
+    plain = ReadBundle(os.path.join(GOLDEN, bundle))
+    comp = ReadBundle(compressed_copy(os.path.join(GOLDEN, bundle), str(tmp_path / bundle)))
+    assert comp.compressed and not plain.compressed
+    n = len(plain.read_ids)
+    for i in range(n):
+        assert np.array_equal(comp.samples(i), plain.samples(i))
+    run = comp.samples_run(2, min(7, n))
+    assert isinstance(run, N.EncodedSamples)
+    assert np.array_equal(run.decode(), plain.samples_run(2, min(7, n)))
+    assert len(comp.samples_run(3, 3)) == 0
+
+
+@pytest.mark.parametrize('bundle', ['batch0.pxr.npz', 'chimera.pxr.npz'])
+def test_session_from_a_compressed_bundle_writes_the_same_files(tmp_path, monkeypatch, bundle):
+    """Session driver over the compressed bundle (oracle test double decodes with the host
+    reference decoder where the GPU context decodes on the device): byte-identical outputs."""
+    from oracle_context import OracleBackedContext
+    from test_session import session_config, golden_reads
+    from poreplex_amd.session import GpuSession
+    monkeypatch.setattr(N, 'NativeContext', OracleBackedContext)
+    outs = {}
+    for tag, path in (('plain', os.path.join(GOLDEN, bundle)),
+                      ('z', compressed_copy(os.path.join(GOLDEN, bundle), str(tmp_path / bundle)))):
+        WorkerPersistenceStorage.reset()
+        cfg = session_config(tmp_path / tag, bundle)
+        cfg['read_bundle'] = path
+        outs[tag] = GpuSession(cfg, batch_reads=6).run(golden_reads(bundle))
+        WorkerPersistenceStorage.reset()
+    assert (tmp_path / 'plain' / 'sequencing_summary.txt').read_bytes() == \
+        (tmp_path / 'z' / 'sequencing_summary.txt').read_bytes()
+    assert outs['plain']['labels'].tobytes() == outs['z']['labels'].tobytes()
+    assert np.array_equal(outs['plain']['counts'], outs['z']['counts'])
+
+
+@pytest.mark.gpu
+def test_device_decoder_fills_the_arena_the_host_decoder_does(ctx, oracle):
+    """pxg_batch_stage_z: bytes + chunk records cross the link, k_z_decode rebuilds the int16
+    arena; every stage then gives the records of the uncompressed upload -- for adversarial
+    sample patterns and for a slice of a larger encoded stream (non-zero bases)."""
+    rng = np.random.default_rng(5)
+    sb = synth_batch(40, seed=11, samples_per_read=30000, jitter=0.4)
+    o = sb['offsets']
+    parts = [sb['arena'][o[i]:o[i + 1]] for i in range(40)] + adversarial_reads(rng)
+    arena, off = N.pack_reads(parts)
+    cal = np.concatenate([sb['calib'], np.repeat(sb['calib'][:1], len(parts) - 40)])
+    z, chunks, base = N.z_encode(arena, off)
+    mask = N.STAGE_ALL_DEMUX | N.STAGE_POLYA
+    ctx.upload(arena, off, cal)
+    ctx.run(mask)
+    want = ctx.download().copy()
+    ctx.stage_z(N.EncodedSamples(z, chunks, 0, 0, len(arena)), off, cal)
+    ctx.swap()
+    ctx.run(mask)
+    got = ctx.download()
+    for f in got.dtype.names:
+        assert np.array_equal(got[f], want[f], equal_nan=True), f
+    assert np.array_equal(got['status'], oracle.process_batch(arena, off, cal, None, mask)['status'])
+    # reads 5 .. 25 as a slice of the stream
+    i0, i1 = 5, 25
+    c0, c1 = base[i0], base[i1]
+    enc = N.EncodedSamples(z[chunks['data_off'][c0]:chunks['data_off'][c1]], chunks[c0:c1],
+                           chunks['data_off'][c0], off[i0], off[i1] - off[i0])
+    ctx.stage_z(enc, off[i0:i1 + 1] - off[i0], cal[i0:i1])
+    ctx.swap()
+    ctx.run(mask)
+    got = ctx.download()
+    for f in got.dtype.names:
+        assert np.array_equal(got[f], want[f][i0:i1], equal_nan=True), f
