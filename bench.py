@@ -86,6 +86,8 @@ def parse(argv=None):
                          'double-buffered batches, facade, sequencing_summary.txt, RCCL all-gather / '
                          'all-reduce) processes it; value = reads / wall of the whole session')
     ap.add_argument('--batch-reads', type=int, default=10000, help='--end-to-end: reads per GPU batch')
+    ap.add_argument('--compressed-bundle', action='store_true',
+                    help='--end-to-end: the bundle carries encoded samples (pxg_z_*), decoded on the GPU')
     ap.add_argument('--context-factory', default=None,
                     help='TEST SEAM (module:attr): CPU rendezvous tests of the multi-rank driver '
                          'inject a stand-in context; the line then says data=TEST-STANDIN, value=null')
@@ -211,7 +213,7 @@ def end_to_end(args, config, rank, local_rank, world, dist, standin, base, which
         t0 = time.perf_counter()
         path = os.path.join(work, 'shard.pxr.npz')
         write_bundle(path, arena, off, base['calib'][which], names, ids,
-                     basecalls=synth_basecalls(shard, seed=args.seed + rank))
+                     basecalls=synth_basecalls(shard, seed=args.seed + rank), compress=args.compressed_bundle)
         t_write = time.perf_counter() - t0
         cfg = default_config(inputdir=work, outputdir=outdir, read_bundle=path,
                              barcoding=True, measure_polya=bool(mask & N.STAGE_POLYA),
@@ -258,7 +260,7 @@ def end_to_end(args, config, rank, local_rank, world, dist, standin, base, which
                            'samples_per_read': args.samples, 'device': info['name'], 'arch': info['arch']},
                 'roofline': None, 'cpu_baseline': None, 'concordance': None,
                 'extra': {'session_timing_rank0': {k: round(v, 4) for k, v in out['timing'].items()},
-                          'bundle_write_s': round(t_write, 3), 'context_and_bundle_open_s': round(t_open, 3),
+                          'bundle_write_s': round(t_write, 3), 'compressed_bundle': bool(args.compressed_bundle), 'context_and_bundle_open_s': round(t_open, 3),
                           'reads_labelled_pass': int(counts[LABEL_NAMES.index('pass')].sum()),
                           'reads_with_barcode': int(counts[:, 1:].sum()), 'summary_rows': n_rows,
                           'labels_gathered': int(len(out['labels'])),
@@ -520,6 +522,25 @@ def main():
             extra['pcie_bound_reads_per_s'] = n_local / h_s
             extra['pcie_overlap_efficiency'] = (n_local / o_s) / min(n_local / h_s, value / world)
             ctx.unpin(base['arena'])
+            # (iii) the same loop with the samples crossing the link ENCODED (zig-zag delta bytes in
+            # 1 024-sample chunks, pxg_batch_stage_z) and decoded on the device into the spare slot
+            z, chunks, _ = N.z_encode(base['arena'], base['offsets'])        # offline step, not timed
+            enc = N.EncodedSamples(z, chunks, 0, 0, len(base['arena']))
+            ctx.pin(z)
+            ctx.pin(chunks)
+            ctx.sync()
+            z0 = time.perf_counter()
+            for _ in range(n_over):
+                step()
+                ctx.stage_z(enc, base['offsets'], base['calib'], inject)
+                ctx.download()
+                ctx.swap()
+            ctx.sync()
+            z_s = (time.perf_counter() - z0) / n_over
+            extra['pcie_overlapped_encoded_reads_per_s'] = n_local / z_s
+            extra['encoded_bytes_per_sample'] = (z.nbytes + chunks.nbytes) / max(len(base['arena']), 1)
+            ctx.unpin(z)
+            ctx.unpin(chunks)
         except N.PxgError as exc:
             extra['pcie_overlapped_reads_per_s'] = None
             extra['pcie_overlapped_error'] = str(exc)

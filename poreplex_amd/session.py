@@ -99,7 +99,8 @@ class GpuSession:
         self.logger = logger or logging.getLogger('poreplex')
         self.analyzer = SignalAnalyzer(config, batchid=self.rank)
         self.ctx, self.loader = self.analyzer.ctx, self.analyzer.loader
-        self.timing = {'load_s': 0.0, 'gpu_wait_s': 0.0, 'facade_s': 0.0, 'sink_s': 0.0}
+        self.timing = {'load_s': 0.0, 'gpu_wait_s': 0.0, 'facade_s': 0.0, 'sink_s': 0.0,
+                       'collect_s': 0.0, 'swap_run_s': 0.0, 'take_s': 0.0, 'stage_s': 0.0}
 
     # ---- loader thread: batch k+1 is opened and packed while batch k computes ---------
     def _produce(self, batches, slots, out):
@@ -148,11 +149,13 @@ class GpuSession:
                                                 header=self.rank == 0)
         fastq = sinks.FASTQWriter(outdir, layout, suffix=part) if cfg.get('fastq_output') else None
 
-        bundle_arena = None
+        pinned = []
         if self.loader.bundle is not None:       # batches of consecutive bundle reads are staged in place
-            bundle_arena = self.loader.bundle.d['arena_z' if self.loader.bundle.compressed else 'arena']
-        if bundle_arena is not None and len(bundle_arena):
-            self.ctx.pin(bundle_arena)
+            d = self.loader.bundle.d
+            pinned = [d['arena_z'], d['z_chunks']] if self.loader.bundle.compressed else [d['arena']]
+            pinned = [a for a in pinned if a.nbytes]
+        for a in pinned:
+            self.ctx.pin(a)
         slots, ready = queue.Queue(), queue.Queue(maxsize=2)
         stagings = [_Staging(self.ctx), _Staging(self.ctx)]
         for s in stagings:
@@ -197,14 +200,21 @@ class GpuSession:
             batch, staging, rows, arena, offsets, calib = current
             t0 = time.perf_counter()
             self.loader.collect_resident(batch.table, rows, offsets)   # D2H of the records: waits for run k
+            t1 = time.perf_counter()
+            self.timing['collect_s'] += t1 - t0
             after = None
             if nxt is not None:
                 if nxt_staged:
                     self.ctx.swap()                       # k+1 resident (waits for its copy) ...
                     self.ctx.run(self.loader.stage_mask)  # ... and computing while k is written out
+                t2 = time.perf_counter()
+                self.timing['swap_run_s'] += t2 - t1
                 slots.put(nxt[1])
                 after = take()                            # k+2, packed by the loader thread meanwhile
+                t3 = time.perf_counter()
+                self.timing['take_s'] += t3 - t2
                 after_staged = stage(after)               # its copy starts now, under run k+1
+                self.timing['stage_s'] += time.perf_counter() - t3
             self.timing['gpu_wait_s'] += time.perf_counter() - t0
 
             # ---- host side of batch k, under the kernels of k+1 ------------------------------
@@ -242,8 +252,8 @@ class GpuSession:
         thread.join()
         for s in stagings:
             s.release()
-        if bundle_arena is not None and len(bundle_arena):
-            self.ctx.unpin(bundle_arena)
+        for a in pinned:
+            self.ctx.unpin(a)
         summary.close()
         if fastq is not None:
             fastq.close()

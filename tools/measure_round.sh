@@ -16,6 +16,8 @@ $B --workload full --reads 100000 --steps 5 --warmup 2 > $OUT/bench_full_100k_re
 $B --scaling strong --total-reads 125000 --steps 3 --warmup 1 > $OUT/bench_strong_125k_shard.json 2>> $OUT/b100k.err
 $B --end-to-end --reads 120000 --batch-reads 10000 > $OUT/bench_end_to_end_demux.json 2> $OUT/e2e.err
 $B --end-to-end --workload full --reads 120000 --batch-reads 10000 > $OUT/bench_end_to_end_full.json 2>> $OUT/e2e.err
+$B --end-to-end --compressed-bundle --reads 120000 --batch-reads 10000 > $OUT/bench_end_to_end_demux_compressed.json 2>> $OUT/e2e.err
+$B --end-to-end --compressed-bundle --workload full --reads 120000 --batch-reads 10000 > $OUT/bench_end_to_end_full_compressed.json 2>> $OUT/e2e.err
 bash tools/prof.sh ${TAG}_demux > /dev/null 2>&1
 bash tools/prof.sh ${TAG}_full --workload full > /dev/null 2>&1
 for f in $OUT/bench_*.json; do python - "$f" <<'PY'
