@@ -55,66 +55,85 @@ int pxg_launch_reset_batch(pxg_ctx* ctx, int64_t n)
 
 // ---------------------------------------------------------------------------
 // K0: samples that crossed PCIe as zig-zag delta bytes (pxg_batch_stage_z, include/pxg.h) back to
-// int16.  One workgroup per 1 024-sample chunk, four samples per thread: the byte offset of a
-// sample is a prefix sum of (1 + control bit), its value a prefix sum of the deltas -- both as
-// a per-thread serial part + one wave scan + one cross-wave step.
+// int16.  One WAVE per 1 024-sample chunk, sixteen samples per lane, four chunks per workgroup and
+// no workgroup barrier: the byte offset of a lane's samples is a wave prefix sum of (1 + control
+// bit), their values a wave prefix sum of the deltas, each as a serial part inside the lane + one
+// shuffle scan.  The chunk's bytes are staged through LDS with coalesced dword loads.  (First
+// version: a workgroup per chunk, four samples per thread, two block scans -- ten barriers per
+// chunk and 1.24 ms for a 10 000-read batch; this one 0.55 ms = 3.5 TB/s of reads + writes.)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int block_exclusive_scan_256(int v, int* wave_totals, int& total)
+#define ZD_STAGE_DW ((PXG_Z_CTRL_BYTES + 2 * PXG_Z_CHUNK) / 4 + 2)
+
+__device__ __forceinline__ int wave_exclusive_scan(int v, int lane, int& total)
 {
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int inc = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const int o = __shfl_up(inc, d);
         if (lane >= d) inc += o;
     }
-    if (lane == 63) wave_totals[wv] = inc;
-    __syncthreads();
-    int base = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) base += (w < wv) ? wave_totals[w] : 0;
-    total = wave_totals[0] + wave_totals[1] + wave_totals[2] + wave_totals[3];
-    __syncthreads();                       // wave_totals may be reused
-    return base + inc - v;
+    total = __shfl(inc, 63);
+    return inc - v;
 }
 
 __global__ __launch_bounds__(256) void k_z_decode(int64_t n_chunks, const uint8_t* __restrict__ z,
                                                   const pxg_z_chunk* __restrict__ chunks, int64_t data_base,
                                                   int64_t dst_base, int16_t* __restrict__ out)
 {
-    __shared__ int wave_totals[4];
-    const int64_t g = blockIdx.x;
-    if (g >= n_chunks) return;
+    __shared__ unsigned stage_all[4][ZD_STAGE_DW];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t g = blockIdx.x * 4ll + wv;
+    if (g >= n_chunks) return;                              // whole waves leave; nothing below is block-wide
     const pxg_z_chunk c = chunks[g];
-    const uint8_t* ctrl = z + (c.data_off - data_base);
+    unsigned* stage = stage_all[wv];
+    const uint8_t* src = z + (c.data_off - data_base);
+    const int mis = (int)((uintptr_t)src & 3);
+    const unsigned* src4 = reinterpret_cast<const unsigned*>(src - mis);
+    // at most 128 + 2 (len - 1) bytes; the last dword may reach into the next chunk (or the 16
+    // spare bytes behind the stream)
+    const int n_dw = (mis + PXG_Z_CTRL_BYTES + 2 * (c.len - 1) + 3) >> 2;
+    for (int k = lane; k < n_dw; k += 64) stage[k] = src4[k];
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t* ctrl = reinterpret_cast<const uint8_t*>(stage) + mis;
     const uint8_t* data = ctrl + PXG_Z_CTRL_BYTES;
-    const int t = threadIdx.x, i0 = 4 * t;                 // samples i0 .. i0 + 3 of the chunk
-    const unsigned bits = (ctrl[t >> 1] >> ((t & 1) * 4)) & 0xFu;
-    int size[4], mine = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int i = i0 + q;
-        size[q] = (i >= 1 && i < c.len) ? 1 + (int)((bits >> q) & 1u) : 0;     // sample 0 is in the record
-        mine += size[q];
-    }
+    const int i0 = 16 * lane;                               // samples i0 .. i0 + 15 of the chunk
+    const int n_valid = c.len - i0 < 0 ? 0 : (c.len - i0 > 16 ? 16 : c.len - i0);
+    unsigned bits = (unsigned)ctrl[2 * lane] | ((unsigned)ctrl[2 * lane + 1] << 8);
+    bits &= (1u << n_valid) - 1u;                           // (sample 0's bit is never set)
+    const int mine = n_valid + __builtin_popcount(bits) - ((lane == 0 && n_valid > 0) ? 1 : 0);
     int total;
-    int at = block_exclusive_scan_256(mine, wave_totals, total);
-    int delta[4], sum = 0;
+    int at = wave_exclusive_scan(mine, lane, total);
+    int d[16], sum = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < 16; q++) {
+        const bool has = q < n_valid && (i0 + q) >= 1;      // sample 0 is in the record
+        const bool two = (bits >> q) & 1u;
         unsigned zz = 0;
-        if (size[q] >= 1) zz = data[at];
-        if (size[q] == 2) zz |= (unsigned)data[at + 1] << 8;
-        at += size[q];
-        delta[q] = (int)((zz >> 1) ^ (0u - (zz & 1u)));      // zig-zag; only the low 16 bits matter
-        sum += delta[q];
-        delta[q] = sum;                                       // inclusive, inside the thread
+        if (has) zz = data[at];
+        if (has && two) zz |= (unsigned)data[at + 1] << 8;
+        at += has ? (two ? 2 : 1) : 0;
+        sum += (int)((zz >> 1) ^ (0u - (zz & 1u)));         // zig-zag; only the low 16 bits matter
+        d[q] = sum;                                          // inclusive, inside the lane
     }
-    const int before = block_exclusive_scan_256(sum, wave_totals, total);
-    int16_t* dst = out + (c.dst - dst_base);
+    const int before = wave_exclusive_scan(sum, lane, total) + (int)c.first;
+    int16_t* dst = out + (c.dst - dst_base) + i0;
+    if (n_valid == 16 && (((uintptr_t)dst) & 3) == 0) {     // eight dword stores
+        unsigned* d4 = reinterpret_cast<unsigned*>(dst);
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-        if (i0 + q < c.len) dst[i0 + q] = (int16_t)(uint16_t)((int)c.first + before + delta[q]);
+        for (int q = 0; q < 8; q++)
+            d4[q] = ((unsigned)(before + d[2 * q]) & 0xFFFFu) | ((unsigned)(before + d[2 * q + 1]) << 16);
+    } else if (n_valid == 16) {                             // 2-byte aligned: short, seven dwords, short
+        dst[0] = (int16_t)(uint16_t)(before + d[0]);
+        unsigned* d4 = reinterpret_cast<unsigned*>(dst + 1);
+#pragma unroll
+        for (int q = 0; q < 7; q++)
+            d4[q] = ((unsigned)(before + d[2 * q + 1]) & 0xFFFFu) | ((unsigned)(before + d[2 * q + 2]) << 16);
+        dst[15] = (int16_t)(uint16_t)(before + d[15]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            if (q < n_valid) dst[q] = (int16_t)(uint16_t)(before + d[q]);
+    }
 }
 
 int pxg_launch_z_decode(pxg_ctx* ctx, hipStream_t stream, int64_t n_chunks, const uint8_t* z,
@@ -125,7 +144,7 @@ int pxg_launch_z_decode(pxg_ctx* ctx, hipStream_t stream, int64_t n_chunks, cons
         ctx->err = "pxg_batch_stage_z: too many chunks";
         return PXG_E_INVALID;
     }
-    hipLaunchKernelGGL(k_z_decode, dim3((unsigned)n_chunks), dim3(256), 0, stream, n_chunks, z, chunks, data_base,
+    hipLaunchKernelGGL(k_z_decode, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, stream, n_chunks, z, chunks, data_base,
                        dst_base, out);
     return PXG_OK;
 }
