@@ -423,6 +423,9 @@ int64_t pxg_z_encode(int64_t n_reads, const int16_t* arena, const int64_t* offse
                      int64_t cap, pxg_z_chunk* chunks);
 int pxg_z_decode(int64_t n_chunks, const uint8_t* z, const pxg_z_chunk* chunks, int64_t data_base,
                  int64_t dst_base, int16_t* out);
+/* the resident batch's int16 samples back on the host (n_samples of the last upload / swap):
+ * what pxg_batch_stage_z decoded, for a caller that wants the samples themselves (and the tests) */
+int pxg_batch_download_samples(pxg_ctx* ctx, int16_t* out);
 int pxg_batch_stage_z(pxg_ctx* ctx, int64_t n_reads, const uint8_t* z, int64_t z_bytes,
                       const pxg_z_chunk* chunks, int64_t n_chunks, int64_t data_base, int64_t dst_base,
                       const int64_t* raw_offsets, const pxg_calib* calib,

@@ -732,6 +732,17 @@ extern "C" int pxg_batch_download(pxg_ctx* ctx, pxg_read_result* out)
     return check_timeslice_flag(ctx);
 }
 
+extern "C" int pxg_batch_download_samples(pxg_ctx* ctx, int16_t* out)
+{
+    if (!ctx || (!out && ctx->n_samples)) return PXG_E_INVALID;
+    if (ctx->n_reads <= 0) return fail(ctx, PXG_E_STATE, "pxg_batch_download_samples: no resident batch");
+    if (ctx->n_samples <= 0) return PXG_OK;
+    PXG_HIP(ctx, hipMemcpyAsync(out, ctx->raw.p, (size_t)ctx->n_samples * sizeof(int16_t), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PXG_OK;
+}
+
 extern "C" int pxg_batch_download_spikes(pxg_ctx* ctx, pxg_polya_spike* out)
 {
     if (!ctx || (!out && ctx->n_reads)) return PXG_E_INVALID;

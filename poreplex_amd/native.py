@@ -357,6 +357,7 @@ _SIGNATURES = {
                                    C.c_void_p, C.c_void_p]),
     'pxg_batch_stage': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
+    'pxg_batch_download_samples': (C.c_int, [C.c_void_p, C.c_void_p]),
     'pxg_batch_stage_z': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                     C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pxg_batch_upload_tiled': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p,
@@ -652,6 +653,12 @@ class NativeContext:
         self._check(self.lib.pxg_batch_stage(
             self.handle, n, _ptr(arena), _ptr(offsets), _ptr(calib), _ptr(scale_shift)),
             'pxg_batch_stage')
+
+    def download_samples(self, n_samples):
+        """The resident batch's int16 samples (what stage_z decoded on the device)."""
+        out = np.empty(int(n_samples), dtype=np.int16)
+        self._check(self.lib.pxg_batch_download_samples(self.handle, _ptr(out)), 'pxg_batch_download_samples')
+        return out
 
     def stage_z(self, enc, offsets, calib, scale_shift=None):
         """stage() for samples that arrive encoded (EncodedSamples): the bytes cross the link

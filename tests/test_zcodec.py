@@ -135,3 +135,46 @@ def test_device_decoder_fills_the_arena_the_host_decoder_does(ctx, oracle):
     got = ctx.download()
     for f in got.dtype.names:
         assert np.array_equal(got[f], want[f][i0:i1], equal_nan=True), f
+
+
+@pytest.mark.gpu
+def test_fuzz_device_decoder_sample_for_sample(ctx):
+    """Random ragged batches of every sample pattern: the arena k_z_decode leaves in HBM equals
+    the original, sample for sample (also through a slice with non-zero bases)."""
+    rng = np.random.default_rng(int(os.environ.get('PXG_FUZZ_SEED', 31)))
+    for trial in range(int(os.environ.get('PXG_FUZZ_TRIALS', 12))):
+        parts = []
+        for _ in range(int(rng.integers(1, 40))):
+            n = int(rng.choice([0, 1, 2, 15, 16, 17, 1023, 1024, 1025, 4095, 4096, 4097])) if rng.random() < 0.5 \
+                else int(rng.integers(0, 70000))
+            kind = rng.integers(0, 5)
+            if kind == 0:
+                x = rng.integers(-32768, 32768, n)
+            elif kind == 1:
+                x = 500 + np.cumsum(rng.integers(-130, 131, n))
+            elif kind == 2:
+                x = np.full(n, int(rng.integers(-32768, 32768)))
+            elif kind == 3:
+                x = np.where(rng.random(n) < 0.01, 32767, -32768)
+            else:
+                x = 600 + 80 * np.sin(np.arange(n) / 7.0) + rng.normal(0, 12, n)
+            parts.append(np.asarray(x).astype(np.int16))
+        if sum(len(p) for p in parts) == 0:
+            parts.append(np.arange(5, dtype=np.int16))
+        arena, off = N.pack_reads(parts)
+        cal = np.zeros(len(parts), dtype=N.CALIB_DTYPE)
+        cal['range'], cal['digitisation'], cal['sampling_rate'] = 1400.0, 8192.0, 3012.0
+        z, chunks, base = N.z_encode(arena, off)
+        ctx.stage_z(N.EncodedSamples(z, chunks, 0, 0, len(arena)), off, cal)
+        ctx.swap()
+        assert np.array_equal(ctx.download_samples(len(arena)), arena), trial
+        i0 = int(rng.integers(0, len(parts)))
+        i1 = int(rng.integers(i0 + 1, len(parts) + 1))
+        if off[i1] - off[i0] > 0:
+            c0, c1 = int(base[i0]), int(base[i1])
+            b0 = int(chunks['data_off'][c0])
+            b1 = int(chunks['data_off'][c1]) if c1 < len(chunks) else len(z)
+            enc = N.EncodedSamples(z[b0:b1], chunks[c0:c1], b0, int(off[i0]), int(off[i1] - off[i0]))
+            ctx.stage_z(enc, off[i0:i1 + 1] - off[i0], cal[i0:i1])
+            ctx.swap()
+            assert np.array_equal(ctx.download_samples(len(enc)), arena[off[i0]:off[i1]]), (trial, i0, i1)
