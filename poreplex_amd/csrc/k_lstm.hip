@@ -865,23 +865,33 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top(
 // costs two tile-steps: the launch lasts 2 x 300 tile-steps for 619 x 300 / 512 = 363 of
 // work per slot (60 %).  Here the 2 x #CU resident workgroups pull (step block, tile) tasks
 // from a queue; the number of blocks per tile is chosen ON THE DEVICE from the actual tile
-// count (demux_blocks: the cut that minimises whole rounds x block length, 4 blocks for 619
-// tiles: 5 rounds x 75 steps = 375).  A tile's state (hidden rows + cell registers) travels
+// count (demux_blocks below).  A tile's state (hidden rows + cell registers) travels
 // through HBM between its blocks, two alternating slots per tile; hand-over as in K2q
 // (per-tile progress counter, release / acquire at agent scope).  Weights stay in VGPRs
 // across tasks.  The step bodies are those of k_demux_bidir<1> / k_demux_top<1>:
 // bit-identical results.
 // ===========================================================================
-#define DQ_HANDOVER 3           // cost of one hand-over, in steps (cost model only)
+#define DQ_HANDOVER 24          // cost of one hand-over, in steps (cost model only)
 #define DQ_MAXBLK 12
 
+// Step blocks per tile.  Measured (PXG_DEMUX_BLOCKS sweep, 5 000 - 100 000 reads, profiles/r02):
+// every extra block per tile costs 25 - 40 us of hand-over per slot (state through HBM, L2
+// write-back / invalidate at agent scope with the XCD's L2 full of the streamed rows), and a last
+// round of tasks that fills at most half of the slots runs about twice as fast (one workgroup per
+// CU issues alone).  So: one block per tile unless cutting removes a nearly empty round --
+// 10 000 reads = 619 tiles on 512 slots: 2 blocks (2.4 rounds of 150 steps: K5a 1.56 -> 1.33 ms,
+// K5b 2.28 -> 2.12; the first model, whole rounds and 3 steps per hand-over, chose 4);
+// 20 000 - 100 000 reads: 1 block.
 __device__ __forceinline__ int demux_blocks(int n_tiles, int slots, int T)
 {
-    int best = 1, best_cost = 0x7fffffff;
+    int best = 1;
+    float best_cost = 3.0e38f;
     for (int nb = 1; nb <= DQ_MAXBLK; nb++) {
-        const int rounds = (nb * n_tiles + slots - 1) / slots;
-        const int cost = rounds * ((T + nb - 1) / nb + DQ_HANDOVER);
-        if (cost < best_cost) { best_cost = cost; best = nb; }
+        const int tasks = nb * n_tiles;
+        const int full = tasks / slots, rem = tasks - full * slots;
+        const float rounds = (float)full + (rem == 0 ? 0.0f : (2 * rem <= slots ? 0.5f : 1.0f));
+        const float cost = rounds * (float)((T + nb - 1) / nb) + (float)((nb - 1) * DQ_HANDOVER);
+        if (cost < 0.96f * best_cost) { best_cost = cost; best = nb; }      // more blocks must pay clearly
     }
     return best;
 }
@@ -929,7 +939,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir_q(
     const int lim = count ? min(*count, n_rows) : n_rows;
     const int n_tiles = (lim + 15) >> 4;
     const int n_groups = (n_tiles + MT - 1) / MT;
-    const int n_blocks = demux_blocks(n_groups, (int)gridDim.x, T);
+    const int n_blocks = queue[1] > 0 ? min(queue[1], T) : demux_blocks(n_groups, (int)gridDim.x, T);
     const int QB = (T + n_blocks - 1) / n_blocks;
     const int n_tasks = n_groups * n_blocks;
 
@@ -1126,7 +1136,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top_q(
     const int lim = count ? min(*count, n_rows) : n_rows;
     const int n_tiles = (lim + 15) >> 4;
     const int n_groups = (n_tiles + MT - 1) / MT;
-    const int n_blocks = demux_blocks(n_groups, (int)gridDim.x, T);
+    const int n_blocks = queue[1] > 0 ? min(queue[1], T) : demux_blocks(n_groups, (int)gridDim.x, T);
     const int QB = (T + n_blocks - 1) / n_blocks;
     const int n_tasks = n_groups * n_blocks;
 
@@ -1438,6 +1448,14 @@ int pxg_launch_demux_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
         PXG_HIP(ctx, hipMemsetAsync(ctx->demux_q.p, 0, (size_t)2 * (2 + tiles) * sizeof(int), ctx->stream));
         int* qa = ctx->demux_q.p;
         int* qb = ctx->demux_q.p + 2 + tiles;
+        if (const char* forced = getenv("PXG_DEMUX_BLOCKS")) {      // tuning knob: step blocks per tile
+            static int nb_a, nb_b;                                   // "a,b" or one number for both kernels
+            nb_a = nb_b = atoi(forced);
+            for (const char* c = forced; *c; c++)
+                if (*c == ',') nb_b = atoi(c + 1);
+            PXG_HIP(ctx, hipMemcpyAsync(qa + 1, &nb_a, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+            PXG_HIP(ctx, hipMemcpyAsync(qb + 1, &nb_b, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        }
         const PxgLstmDev &f = ctx->demux_fwd, &b = ctx->demux_bwd, &t3 = ctx->demux_top;
 #define CALL_A(MT)                                                                                         \
     {                                                                                                      \
