@@ -1038,7 +1038,10 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir_q(
                     if (st_src[p] >= 0) {
                         const float* src = (st_dir[p] ? hb : hf) + rdb * MT * 16 * HS + st_src[p];
                         float* dst = st_dst[p] + (size_t)(st_dir[p] ? tb : tf) * (2 * H);
-                        *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src);
+                        {   // streamed once, read by the next kernel: keep the rows out of the L2's dirty set
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+                            __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+                        }
                     }
                 }
             }
