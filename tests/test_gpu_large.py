@@ -79,3 +79,28 @@ def test_configs3_full_shape_100k_reads_60k_samples(ctx, oracle):
         _, sc = oracle.guppy_event_means(raw, base['calib'][r], 0, int(nb[r]), res[r]['scale'], res[r]['shift'])
         wiv, wc = oracle.unsplit_scan(sc, 0, (int(res[r]['seg_last'][a]) + 1) * 15, 3012.0)
         assert cnt[r] == wc and iv[start[r]:start[r + 1]].tolist() == wiv.tolist(), r
+
+
+def test_polya_retry_pass_in_several_launches(ctx, oracle):
+    """20 000 copies of a featureless 130 000-sample read (5 GB of int16, tiled on the device) next
+    to 24 ordinary reads: every copy outgrows the first-pass event scratch of K6, so the retry
+    pass has more reads than one launch's scratch budget covers and runs in several launches.
+    Every copy must give the oracle's record of that read."""
+    rng = np.random.default_rng(77)
+    flat = (775 + rng.normal(0, 3, 130000)).astype(np.int16)
+    sb = synth_batch(24, seed=5, samples_per_read=30000)
+    o = sb['offsets']
+    parts = [flat] + [sb['arena'][o[i]:o[i + 1]] for i in range(24)]
+    arena, off = N.pack_reads(parts)
+    cal = np.concatenate([sb['calib'][:1], sb['calib']])
+    mask = N.STAGE_ALL_DEMUX | N.STAGE_POLYA
+    want = oracle.process_batch(arena, off, cal, None, mask)
+    assert want['polya_called'][0] == 1 and want['polya_end'][0] - want['polya_begin'][0] > 100000
+    n = 25 * 20000                       # read j = base read j % 25
+    ctx.upload_tiled(n, arena, off, cal)
+    ctx.run(mask)
+    res = ctx.download()
+    for f in res.dtype.names:
+        got = res[f].reshape((20000, 25) + res[f].shape[1:])
+        assert np.array_equal(got[0], want[f], equal_nan=True), f
+        assert (got == got[0]).all() or f == 'probs' and np.array_equal(got, np.broadcast_to(got[0], got.shape), equal_nan=True), f
