@@ -2,8 +2,13 @@ import json
 import os
 import sys
 
-import numpy as np
-import pytest
+# torch-CPU legs (training, DDP over gloo) share the box with forked 2-rank helpers and BLAS:
+# without a cap every pool spins up one thread per core and the suite can stall for minutes
+for _var in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+    os.environ.setdefault(_var, '2')
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

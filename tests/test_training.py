@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 torch = pytest.importorskip('torch')
+torch.set_num_threads(2)          # see conftest.py: no thread pool per core next to the 2-rank helpers
 
 from poreplex_amd import training as TR  # noqa: E402
 from poreplex_amd.config import default_config  # noqa: E402
