@@ -88,6 +88,16 @@ def parse(argv=None):
     ap.add_argument('--batch-reads', type=int, default=10000, help='--end-to-end: reads per GPU batch')
     ap.add_argument('--compressed-bundle', action='store_true',
                     help='--end-to-end: the bundle carries encoded samples (pxg_z_*), decoded on the GPU')
+    ap.add_argument('--api', choices=['resident', 'process_batch'], default='resident',
+                    help="process_batch: value = reads/s through the reference's worker entry point "
+                         '(poreplex_amd.signal_analyzer.process_batch(batchid, reads, config) -> list of result '
+                         'dicts, pipeline.py:204-205), --in-flight calls kept in flight on one GPU context; the '
+                         'default line carries the same figure in extra.process_batch_reads_per_s')
+    ap.add_argument('--in-flight', type=int, default=3,
+                    help='process_batch leg: worker calls in flight (threads of this process; the '
+                         "reference's `parallel`, pipeline.py:96)")
+    ap.add_argument('--api-calls', type=int, default=8, help='process_batch leg: timed calls')
+    ap.add_argument('--no-api-leg', action='store_true', help='skip the process_batch leg of the default line')
     ap.add_argument('--context-factory', default=None,
                     help='TEST SEAM (module:attr): CPU rendezvous tests of the multi-rank driver '
                          'inject a stand-in context; the line then says data=TEST-STANDIN, value=null')
@@ -277,6 +287,87 @@ def end_to_end(args, config, rank, local_rank, world, dist, standin, base, which
             shutil.rmtree(outdir, ignore_errors=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def process_batch_leg(args, base, which, lo, mask, local_rank, compressed, resident_records=None):
+    """The drop-in API north_star names, as the reference's pipeline submits it
+    (pipeline.py:193-229: `parallel` process_batch(batchid, reads, config) calls in flight, each
+    returning the list of result dicts): the reads sit in a read bundle on disk, every call
+    copies its samples to the GPU again (page-locked bundle arena -> spare input slot on the
+    copy stream), runs every stage and builds the dicts.  Nothing stays resident between calls.
+    Returns rates for one call at a time and for `--in-flight` calls overlapping on one context."""
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from poreplex_amd.fast5_file import write_bundle
+    from poreplex_amd.signal_analyzer import process_batch
+    from poreplex_amd.synth import synth_basecalls
+    from poreplex_amd.worker_persistence import WorkerPersistenceStorage
+    work = tempfile.mkdtemp(prefix='pxg_api_')
+    try:
+        o = base['offsets']
+        if len(which) == len(o) - 1 and np.array_equal(which, np.arange(len(which))):
+            arena, off = base['arena'], o
+        else:
+            arena, off = N.pack_reads([base['arena'][o[b]:o[b + 1]] for b in which])
+        n = len(which)
+        names = ['api/read{:07d}.fast5'.format(lo + j) for j in range(n)]
+        ids = ['{:08x}-0000-4000-8000-{:012x}'.format(args.seed, lo + j) for j in range(n)]
+        path = os.path.join(work, 'api.pxr.npz')
+        t0 = time.perf_counter()
+        write_bundle(path, arena, off, base['calib'][which], names, ids,
+                     basecalls=synth_basecalls({'offsets': off}, seed=args.seed), compress=compressed)
+        t_write = time.perf_counter() - t0
+        cfg = default_config(inputdir=work, outputdir=work, read_bundle=path, barcoding=bool(mask & N.STAGE_BARCODE),
+                             measure_polya=bool(mask & N.STAGE_POLYA),
+                             filter_unsplit_reads=args.workload in ('chimera', 'full'), device_id=local_rank)
+        reads = list(zip(names, ids))
+        WorkerPersistenceStorage.reset()
+        t0 = time.perf_counter()
+        first = process_batch(0, reads, cfg)          # context, bundle load, page-locking: once per worker
+        t_first = time.perf_counter() - t0
+        if isinstance(first, tuple):
+            raise N.PxgError('process_batch failed: {}'.format(first[1]))
+        t0 = time.perf_counter()
+        for k in range(2):
+            process_batch(1 + k, reads, cfg)
+        serial = 2 * n / (time.perf_counter() - t0)
+        calls = max(args.api_calls, 1)
+        with ThreadPoolExecutor(max(args.in_flight, 1)) as pool:
+            t0 = time.perf_counter()
+            outs = list(pool.map(lambda k: process_batch(10 + k, reads, cfg), range(calls)))
+            wall = time.perf_counter() - t0
+        bad = [r for r in outs if isinstance(r, tuple)]
+        if bad:
+            raise N.PxgError('process_batch failed: {}'.format(bad[0][1]))
+        last = outs[-1]
+        out = {'reads_per_s': calls * n / wall, 'one_call_at_a_time_reads_per_s': serial,
+               'calls': calls, 'in_flight': args.in_flight, 'reads_per_call': n, 'ms_per_call': wall / calls * 1e3,
+               'first_call_s': round(t_first, 3), 'bundle_write_s': round(t_write, 3),
+               'compressed_bundle': bool(compressed), 'dicts_returned': len(last),
+               'dict_builder': 'csrc/_pxgpy' if N.load_pyhost() is not None else 'python loop',
+               'results_identical_across_calls': bool(all(o_ == first for o_ in outs))}
+        if resident_records is not None and len(resident_records) == n:
+            # the dicts against the records of the resident loop (same reads, same stages)
+            st = [N.STATUS_NAMES[c] for c in resident_records['status'].tolist()]
+            called = resident_records['bc_called'].tolist()
+            label = resident_records['bc_label'].tolist()
+            by_id = {r.get('read_id'): r for r in last}
+            diff = 0
+            for j, rid in enumerate(ids):
+                r = by_id[rid]
+                # a status the GPU pass decided must be the dict's; a GPU 'okay' may still fail later
+                # rules (adapter / basecall / length), but never with a GPU-side status
+                if st[j] != 'okay':
+                    diff += int(r['status'] != st[j])
+                else:
+                    diff += int(r['status'] in ('scaler_signal_too_short', 'scaling_qc_fail'))
+                diff += int(r.get('barcode') != (label[j] if called[j] else None))
+            out['barcode_or_status_mismatch_vs_resident_records'] = diff
+        WorkerPersistenceStorage.reset()
+        return out
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
 
 
 def make_context(args, config, local_rank):
@@ -605,6 +696,21 @@ def main():
         if world > 1:
             cpu = None
 
+    # ---- the reference-shaped API (never `value` of the default line): process_batch calls ----
+    api = None
+    if not standin and world == 1 and not n_base and not use_inject and \
+            (args.api == 'process_batch' or not args.no_api_leg):
+        try:
+            api = {'raw': process_batch_leg(args, base, which, lo, mask, local_rank, False, res)}
+            api['encoded'] = process_batch_leg(args, base, which, lo, mask, local_rank, True, res)
+            extra['process_batch_reads_per_s'] = api['raw']['reads_per_s']
+            extra['process_batch_encoded_bundle_reads_per_s'] = api['encoded']['reads_per_s']
+            extra['process_batch'] = api
+        except Exception as exc:                       # reported, never hidden
+            extra['process_batch_reads_per_s'] = None
+            extra['process_batch_error'] = '{}: {}'.format(type(exc).__name__, exc)
+            api = None
+
     line = {
         'metric': wl_metric,
         'value': None if standin else value, 'unit': 'reads/s', 'n_gpus': world, 'steps': args.steps,
@@ -627,6 +733,18 @@ def main():
                    'device': info['name'], 'arch': info['arch'], 'compute_units': info['compute_units']},
         'roofline': roofline, 'cpu_baseline': cpu, 'concordance': concordance, 'extra': extra,
     }
+    if args.api == 'process_batch' and api is not None:
+        best = api['encoded'] if api['encoded']['reads_per_s'] > api['raw']['reads_per_s'] else api['raw']
+        line.update({
+            'metric': wl_metric + ' through process_batch(batchid, reads, config) -> result dicts',
+            'value': api['raw']['reads_per_s'], 'steps': api['raw']['calls'], 'warmup': 3,
+            'ms_per_step': api['raw']['ms_per_call'],
+            'vs_baseline': api['raw']['reads_per_s'] / PUBLISHED_READS_PER_S,
+            'roofline': None})
+        line['config']['workload'] += ('; API leg: {} calls of {} reads from an int16 read bundle, {} in flight '
+                                       '(best of raw / encoded bundle: {:.0f} reads/s)'.format(
+                                           api['raw']['calls'], api['raw']['reads_per_call'],
+                                           api['raw']['in_flight'], best['reads_per_s']))
     os.write(json_fd, (json.dumps(line) + '\n').encode())
     if dist is not None:
         dist.destroy_process_group()

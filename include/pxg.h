@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PXG_ABI_VERSION 2
+#define PXG_ABI_VERSION 3
 
 #define PXG_MAX_STATES      8   /* HMM states per model (reference uses 6)        */
 #define PXG_MAX_MIXTURE     4   /* Gaussian components per state (reference <= 2) */
@@ -423,6 +423,12 @@ int64_t pxg_z_encode(int64_t n_reads, const int16_t* arena, const int64_t* offse
                      int64_t cap, pxg_z_chunk* chunks);
 int pxg_z_decode(int64_t n_chunks, const uint8_t* z, const pxg_z_chunk* chunks, int64_t data_base,
                  int64_t dst_base, int16_t* out);
+/* Chunk records come from files: PXG_OK iff the records tile [dst_base, dst_base + n_samples) in
+ * order with 1 .. PXG_Z_CHUNK samples each and every chunk lies inside the z_bytes of the stream
+ * (PXG_E_INVALID otherwise).  pxg_batch_stage_z runs the same check and refuses the batch; call
+ * this before pxg_z_decode on anything read from disk (host only, libpxghost.so). */
+int pxg_z_validate(int64_t n_chunks, const pxg_z_chunk* chunks, int64_t data_base, int64_t z_bytes,
+                   int64_t dst_base, int64_t n_samples);
 /* the resident batch's int16 samples back on the host (n_samples of the last upload / swap):
  * what pxg_batch_stage_z decoded, for a caller that wants the samples themselves (and the tests) */
 int pxg_batch_download_samples(pxg_ctx* ctx, int16_t* out);

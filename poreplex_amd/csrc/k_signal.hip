@@ -76,7 +76,7 @@ __device__ __forceinline__ int wave_exclusive_scan(int v, int lane, int& total)
     return inc - v;
 }
 
-__global__ __launch_bounds__(256) void k_z_decode(int64_t n_chunks, const uint8_t* __restrict__ z,
+__global__ __launch_bounds__(256) void k_z_decode(int64_t n_chunks, const uint8_t* __restrict__ z, int64_t z_bytes,
                                                   const pxg_z_chunk* __restrict__ chunks, int64_t data_base,
                                                   int64_t dst_base, int16_t* __restrict__ out)
 {
@@ -91,8 +91,13 @@ __global__ __launch_bounds__(256) void k_z_decode(int64_t n_chunks, const uint8_
     const unsigned* src4 = reinterpret_cast<const unsigned*>(src - mis);
     // at most 128 + 2 (len - 1) bytes; the last dword may reach into the next chunk (or the 16
     // spare bytes behind the stream)
-    const int n_dw = (mis + PXG_Z_CTRL_BYTES + 2 * (c.len - 1) + 3) >> 2;
-    for (int k = lane; k < n_dw; k += 64) stage[k] = src4[k];
+    int n_dw = (mis + PXG_Z_CTRL_BYTES + 2 * (c.len - 1) + 3) >> 2;
+    // ... but never past the stream's buffer (z_bytes + 16 allocated): a chunk near the end that
+    // needs fewer bytes than its worst case must not read beyond it (the words not staged are
+    // never addressed by a well-formed chunk; pxg_z_check vouches for the rest)
+    const int64_t room = (z_bytes + 12 - ((c.data_off - data_base) - mis)) >> 2;
+    if ((int64_t)n_dw > room) n_dw = room < 0 ? 0 : (int)room;
+    for (int k = lane; k < n_dw; k += 64) stage[k] = src4[k];   // (LDS words not staged are only read for malformed chunks)
     __builtin_amdgcn_wave_barrier();
     const uint8_t* ctrl = reinterpret_cast<const uint8_t*>(stage) + mis;
     const uint8_t* data = ctrl + PXG_Z_CTRL_BYTES;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256) void k_z_decode(int64_t n_chunks, const uint8_
     }
 }
 
-int pxg_launch_z_decode(pxg_ctx* ctx, hipStream_t stream, int64_t n_chunks, const uint8_t* z,
+int pxg_launch_z_decode(pxg_ctx* ctx, hipStream_t stream, int64_t n_chunks, const uint8_t* z, int64_t z_bytes,
                         const pxg_z_chunk* chunks, int64_t data_base, int64_t dst_base, int16_t* out)
 {
     if (n_chunks <= 0) return PXG_OK;
@@ -144,7 +149,7 @@ int pxg_launch_z_decode(pxg_ctx* ctx, hipStream_t stream, int64_t n_chunks, cons
         ctx->err = "pxg_batch_stage_z: too many chunks";
         return PXG_E_INVALID;
     }
-    hipLaunchKernelGGL(k_z_decode, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, stream, n_chunks, z, chunks, data_base,
+    hipLaunchKernelGGL(k_z_decode, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, stream, n_chunks, z, z_bytes, chunks, data_base,
                        dst_base, out);
     return PXG_OK;
 }

@@ -4,6 +4,7 @@
 #include <string.h>
 #include <algorithm>
 #include "pxg_common.h"
+#include "pxg_zcheck.h"
 
 static std::string g_last_error;
 
@@ -526,6 +527,11 @@ extern "C" int pxg_batch_stage_z(pxg_ctx* ctx, int64_t n_reads, const uint8_t* z
     auto& sp = ctx->spare;
     sp.staged = false;
     const int64_t n_samples = raw_offsets[n_reads];
+    // the records come from a file: they must tile the arena and stay inside the byte stream
+    // before a kernel is allowed to follow them
+    if (pxg_z_check(n_chunks, chunks, data_base, z_bytes, dst_base, n_samples) != PXG_OK)
+        return fail(ctx, PXG_E_INVALID, "pxg_batch_stage_z: the chunk records do not describe this byte "
+                                        "stream / sample arena (truncated or corrupt bundle)");
     if ((rc = pxg_reserve(ctx, sp.raw, (size_t)n_samples + 64)) ||
         (rc = pxg_reserve(ctx, sp.offsets, (size_t)n_reads + 1)) ||
         (rc = pxg_reserve(ctx, sp.calib, (size_t)n_reads)) ||
@@ -548,7 +554,7 @@ extern "C" int pxg_batch_stage_z(pxg_ctx* ctx, int64_t n_reads, const uint8_t* z
     if (sp.have_inject)
         PXG_HIP(ctx, hipMemcpyAsync(sp.inject.p, scale_shift_or_null, (size_t)n_reads * 2 * sizeof(float),
                                     hipMemcpyHostToDevice, cs));
-    if ((rc = pxg_launch_z_decode(ctx, cs, n_chunks, sp.z.p, sp.zchunks.p, data_base, dst_base, sp.raw.p)))
+    if ((rc = pxg_launch_z_decode(ctx, cs, n_chunks, sp.z.p, z_bytes, sp.zchunks.p, data_base, dst_base, sp.raw.p)))
         return rc;
     PXG_HIP(ctx, hipGetLastError());
     PXG_HIP(ctx, hipEventRecord(ctx->ev_staged, cs));

@@ -390,7 +390,7 @@ int pxg_launch_demux_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
                           const int32_t* count, const float* win, float* bidir, float* probs,
                           int timer_a, int timer_b);
 int pxg_launch_reset_batch(pxg_ctx* ctx, int64_t n);
-int pxg_launch_z_decode(pxg_ctx* ctx, hipStream_t stream, int64_t n_chunks, const uint8_t* z, const pxg_z_chunk* chunks,
+int pxg_launch_z_decode(pxg_ctx* ctx, hipStream_t stream, int64_t n_chunks, const uint8_t* z, int64_t z_bytes, const pxg_z_chunk* chunks,
                         int64_t data_base, int64_t dst_base, int16_t* out);
 int pxg_launch_finalize(pxg_ctx* ctx, int64_t n, uint32_t stage_mask);
 int pxg_lstm_upload(pxg_ctx* ctx);   // shape checks

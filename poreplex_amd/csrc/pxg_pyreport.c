@@ -1,0 +1,285 @@
+/*
+ * pxg_pyreport.c -- result dicts of a worker batch, built from the batch table's columns.
+ *
+ * The reference hands `process_batch`'s caller one dict per read (NanoporeRead.report,
+ * poreplex/signal_loader.py:165-198: keys in that order, optional keys only when set).  A GPU
+ * worker batch is ten thousand reads, and building those dicts in Python (ReadTable.report)
+ * was the largest host cost of the reference-shaped call (3.4 us per read; the whole GPU pass is
+ * 1.5 us per read).  This CPython extension builds the SAME objects -- same keys, same key
+ * order, same value types (str / int / float, `round(start / rate, 3)` correctly rounded the way
+ * float.__round__ is, the int 0 for a missing mean_qscore, the (sequence, qstring, trim) tuple,
+ * the poly(A) dict of polya.py:116-121) -- straight from the NumPy columns.  Host only; the
+ * product works without it (ReadTable.report falls back to the Python loop, e.g. under another
+ * interpreter version), tests/test_facade.py compares the two on randomised tables.
+ *
+ *   _pxgpy.report(columns: dict, rows: int64 buffer) -> list of dict
+ */
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#include <stdint.h>
+#include <string.h>
+
+typedef struct {
+    Py_buffer view;
+    int held;
+} Buf;
+
+static int get_buf(PyObject* cols, const char* name, Buf* b, Py_ssize_t itemsize, int optional)
+{
+    b->held = 0;
+    memset(&b->view, 0, sizeof(b->view));
+    PyObject* o = PyDict_GetItemString(cols, name);          /* borrowed */
+    if (!o || o == Py_None) {
+        if (optional) return 0;
+        PyErr_Format(PyExc_KeyError, "report: column '%s' is missing", name);
+        return -1;
+    }
+    if (PyObject_GetBuffer(o, &b->view, PyBUF_C_CONTIGUOUS) < 0) return -1;
+    b->held = 1;
+    if (b->view.itemsize != itemsize) {
+        PyErr_Format(PyExc_TypeError, "report: column '%s' has item size %zd, expected %zd", name,
+                     b->view.itemsize, itemsize);
+        return -1;
+    }
+    return 0;
+}
+
+static PyObject* get_list(PyObject* cols, const char* name, int optional)
+{
+    PyObject* o = PyDict_GetItemString(cols, name);
+    if (!o || o == Py_None) {
+        if (!optional) PyErr_Format(PyExc_KeyError, "report: column '%s' is missing", name);
+        return NULL;
+    }
+    if (!PyList_Check(o) && !PyTuple_Check(o)) {
+        PyErr_Format(PyExc_TypeError, "report: column '%s' must be a list or tuple", name);
+        return NULL;
+    }
+    return o;
+}
+
+/* round(x, 3) as float.__round__ does it: correctly rounded decimal, both ways */
+static PyObject* round3(double x)
+{
+    if (!(x == x) || x - x != 0.0) return PyFloat_FromDouble(x);       /* nan / inf unchanged */
+    char* s = PyOS_double_to_string(x, 'f', 3, 0, NULL);
+    if (!s) return NULL;
+    double r = PyOS_string_to_double(s, NULL, NULL);
+    PyMem_Free(s);
+    if (r == -1.0 && PyErr_Occurred()) return NULL;
+    return PyFloat_FromDouble(r);
+}
+
+#define SET(d, key, value)                                  \
+    do {                                                    \
+        PyObject* v_ = (value);                             \
+        if (!v_ || PyDict_SetItem(d, key, v_) < 0) {        \
+            Py_XDECREF(v_);                                 \
+            goto fail_row;                                  \
+        }                                                   \
+        Py_DECREF(v_);                                      \
+    } while (0)
+#define SET_BORROWED(d, key, value)                         \
+    do {                                                    \
+        if (PyDict_SetItem(d, key, (value)) < 0) goto fail_row; \
+    } while (0)
+
+enum { K_FILENAME, K_READ_ID, K_STATUS, K_CHANNEL, K_START_TIME, K_RUN_ID, K_SAMPLE_ID, K_DURATION,
+       K_NUM_EVENTS, K_SEQUENCE_LENGTH, K_MEAN_QSCORE, K_SEQUENCE, K_ERROR_MESSAGE, K_LABEL, K_BARCODE,
+       K_BARCODE_GUESS, K_BARCODE_SCORE, K_POLYA, K_BEGIN, K_END, K_DWELL_TIME, K_SPIKES, N_KEYS };
+static const char* const KEY_NAMES[N_KEYS] = {
+    "filename", "read_id", "status", "channel", "start_time", "run_id", "sample_id", "duration",
+    "num_events", "sequence_length", "mean_qscore", "sequence", "error_message", "label", "barcode",
+    "barcode_guess", "barcode_score", "polya", "begin", "end", "dwell_time", "spikes" };
+static PyObject* KEYS[N_KEYS];
+
+static PyObject* item(PyObject* seq, Py_ssize_t i)         /* borrowed; list or tuple */
+{
+    if (PyList_Check(seq)) {
+        if (i < 0 || i >= PyList_GET_SIZE(seq)) { PyErr_SetString(PyExc_IndexError, "report: row outside a column"); return NULL; }
+        return PyList_GET_ITEM(seq, i);
+    }
+    if (i < 0 || i >= PyTuple_GET_SIZE(seq)) { PyErr_SetString(PyExc_IndexError, "report: row outside a column"); return NULL; }
+    return PyTuple_GET_ITEM(seq, i);
+}
+
+static PyObject* report(PyObject* self, PyObject* args)
+{
+    PyObject *cols, *rows_obj;
+    if (!PyArg_ParseTuple(args, "O!O", &PyDict_Type, &cols, &rows_obj)) return NULL;
+    Buf rows, status, start_time, rate, duration, n_events, seq_len, qscore, has_summary, label, has_bc,
+        barcode, guess, phred, seq_lazy, bundle_index, seq_arena, qual_arena, seq_off, polya_lazy, pa_begin,
+        pa_end, pa_dwell, pa_nspk, spikes, gpu_row;
+    Buf* all[] = { &rows, &status, &start_time, &rate, &duration, &n_events, &seq_len, &qscore, &has_summary,
+                   &label, &has_bc, &barcode, &guess, &phred, &seq_lazy, &bundle_index, &seq_arena,
+                   &qual_arena, &seq_off, &polya_lazy, &pa_begin, &pa_end, &pa_dwell, &pa_nspk, &spikes,
+                   &gpu_row };
+    for (size_t k = 0; k < sizeof(all) / sizeof(all[0]); k++) all[k]->held = 0;
+    PyObject* out = NULL;
+    rows.held = 0;
+    if (PyObject_GetBuffer(rows_obj, &rows.view, PyBUF_C_CONTIGUOUS) < 0) return NULL;
+    rows.held = 1;
+    if (rows.view.itemsize != 8) { PyErr_SetString(PyExc_TypeError, "report: rows must be int64"); goto done; }
+    if (get_buf(cols, "status", &status, 1, 0) || get_buf(cols, "start_time", &start_time, 8, 0) ||
+        get_buf(cols, "sampling_rate", &rate, 8, 0) || get_buf(cols, "duration", &duration, 8, 0) ||
+        get_buf(cols, "num_events", &n_events, 8, 0) || get_buf(cols, "sequence_length", &seq_len, 8, 0) ||
+        get_buf(cols, "mean_qscore", &qscore, 8, 0) || get_buf(cols, "has_summary", &has_summary, 1, 0) ||
+        get_buf(cols, "label", &label, 1, 0) || get_buf(cols, "has_barcode", &has_bc, 1, 0) ||
+        get_buf(cols, "barcode", &barcode, 1, 0) || get_buf(cols, "barcode_guess", &guess, 1, 0) ||
+        get_buf(cols, "barcode_phred", &phred, 2, 0) || get_buf(cols, "seq_lazy", &seq_lazy, 1, 0) ||
+        get_buf(cols, "bundle_index", &bundle_index, 8, 0) || get_buf(cols, "seq_arena", &seq_arena, 1, 1) ||
+        get_buf(cols, "qual_arena", &qual_arena, 1, 1) || get_buf(cols, "seq_offsets", &seq_off, 8, 1) ||
+        get_buf(cols, "polya_lazy", &polya_lazy, 1, 0) || get_buf(cols, "polya_begin", &pa_begin, 8, 0) ||
+        get_buf(cols, "polya_end", &pa_end, 8, 0) || get_buf(cols, "polya_dwell_time", &pa_dwell, 8, 0) ||
+        get_buf(cols, "polya_spike_count", &pa_nspk, 2, 0) || get_buf(cols, "spikes", &spikes, 4, 1) ||
+        get_buf(cols, "gpu_row", &gpu_row, 8, 0))
+        goto done;
+    PyObject *filename = get_list(cols, "filename", 0), *read_id = get_list(cols, "read_id", 0),
+             *channel = get_list(cols, "channel", 0), *run_id = get_list(cols, "run_id", 0),
+             *sample_id = get_list(cols, "sample_id", 0), *sequence = get_list(cols, "sequence", 0),
+             *error_message = get_list(cols, "error_message", 0), *polya = get_list(cols, "polya", 0),
+             *status_names = get_list(cols, "status_names", 0), *label_names = get_list(cols, "label_names", 0);
+    if (!filename || !read_id || !channel || !run_id || !sample_id || !sequence || !error_message || !polya ||
+        !status_names || !label_names)
+        goto done;
+    {
+        const Py_ssize_t n_rows = rows.view.len / 8;
+        const Py_ssize_t n_table = status.view.len;             /* int8 column: one byte per row */
+        const int64_t* R = (const int64_t*)rows.view.buf;
+        const int8_t* st = (const int8_t*)status.view.buf;
+        const Py_ssize_t n_seq_off = seq_off.held ? seq_off.view.len / 8 : 0;
+        const Py_ssize_t spike_cap = spikes.held && spikes.view.ndim == 3 ? spikes.view.shape[1] : 0;
+        const Py_ssize_t spike_rows = spikes.held && spikes.view.ndim == 3 ? spikes.view.shape[0] : 0;
+        out = PyList_New(n_rows);
+        if (!out) goto done;
+        for (Py_ssize_t k = 0; k < n_rows; k++) {
+            const int64_t i = R[k];
+            PyObject* d = NULL;
+            if (i < 0 || i >= n_table) { PyErr_SetString(PyExc_IndexError, "report: row outside the table"); goto fail_row; }
+            d = PyDict_New();
+            if (!d) goto fail_row;
+            PyObject* o;
+            if (!(o = item(filename, i))) goto fail_row;
+            SET_BORROWED(d, KEYS[K_FILENAME], o);
+            if (!(o = item(read_id, i))) goto fail_row;
+            SET_BORROWED(d, KEYS[K_READ_ID], o);
+            if (!(o = item(status_names, st[i]))) goto fail_row;
+            SET_BORROWED(d, KEYS[K_STATUS], o);
+            if (!(o = item(channel, i))) goto fail_row;
+            SET_BORROWED(d, KEYS[K_CHANNEL], o);
+            {
+                const double b = ((const double*)rate.view.buf)[i];
+                if (b == 0.0) { PyErr_SetString(PyExc_ZeroDivisionError, "float division by zero"); goto fail_row; }
+                SET(d, KEYS[K_START_TIME], round3((double)((const int64_t*)start_time.view.buf)[i] / b));
+            }
+            if (!(o = item(run_id, i))) goto fail_row;
+            SET_BORROWED(d, KEYS[K_RUN_ID], o);
+            if (!(o = item(sample_id, i))) goto fail_row;
+            SET_BORROWED(d, KEYS[K_SAMPLE_ID], o);
+            SET(d, KEYS[K_DURATION], PyLong_FromLongLong(((const int64_t*)duration.view.buf)[i]));
+            SET(d, KEYS[K_NUM_EVENTS], PyLong_FromLongLong(((const int64_t*)n_events.view.buf)[i]));
+            SET(d, KEYS[K_SEQUENCE_LENGTH], PyLong_FromLongLong(((const int64_t*)seq_len.view.buf)[i]));
+            if (((const uint8_t*)has_summary.view.buf)[i])
+                SET(d, KEYS[K_MEAN_QSCORE], PyFloat_FromDouble(((const double*)qscore.view.buf)[i]));
+            else
+                SET(d, KEYS[K_MEAN_QSCORE], PyLong_FromLong(0));
+            /* sequence: the stored tuple, or (lazily) the bundle's text */
+            if (!(o = item(sequence, i))) goto fail_row;
+            if (o != Py_None) {
+                SET_BORROWED(d, KEYS[K_SEQUENCE], o);
+            } else if (((const uint8_t*)seq_lazy.view.buf)[i]) {
+                const int64_t b = ((const int64_t*)bundle_index.view.buf)[i];
+                if (!seq_arena.held || !qual_arena.held || b < 0 || b + 1 >= n_seq_off) {
+                    PyErr_SetString(PyExc_IndexError, "report: lazy sequence outside the bundle");
+                    goto fail_row;
+                }
+                const int64_t lo = ((const int64_t*)seq_off.view.buf)[b], hi = ((const int64_t*)seq_off.view.buf)[b + 1];
+                if (lo < 0 || hi < lo || hi > seq_arena.view.len || hi > qual_arena.view.len) {
+                    PyErr_SetString(PyExc_IndexError, "report: sequence offsets outside the arena");
+                    goto fail_row;
+                }
+                PyObject* s = PyUnicode_DecodeASCII((const char*)seq_arena.view.buf + lo, hi - lo, NULL);
+                PyObject* q = s ? PyUnicode_DecodeASCII((const char*)qual_arena.view.buf + lo, hi - lo, NULL) : NULL;
+                PyObject* z = q ? PyLong_FromLong(0) : NULL;
+                PyObject* t = z ? PyTuple_Pack(3, s, q, z) : NULL;
+                Py_XDECREF(s); Py_XDECREF(q); Py_XDECREF(z);
+                SET(d, KEYS[K_SEQUENCE], t);
+            }
+            if (!(o = item(error_message, i))) goto fail_row;
+            {
+                const int truth = PyObject_IsTrue(o);
+                if (truth < 0) goto fail_row;
+                if (truth) SET_BORROWED(d, KEYS[K_ERROR_MESSAGE], o);
+            }
+            {
+                const int8_t lb = ((const int8_t*)label.view.buf)[i];
+                if (lb != -1) {
+                    if (!(o = item(label_names, lb))) goto fail_row;
+                    SET_BORROWED(d, KEYS[K_LABEL], o);
+                }
+            }
+            if (((const uint8_t*)has_bc.view.buf)[i]) {
+                SET(d, KEYS[K_BARCODE], PyLong_FromLong(((const int8_t*)barcode.view.buf)[i]));
+                SET(d, KEYS[K_BARCODE_GUESS], PyLong_FromLong(((const int8_t*)guess.view.buf)[i]));
+                SET(d, KEYS[K_BARCODE_SCORE], PyLong_FromLong(((const int16_t*)phred.view.buf)[i]));
+            }
+            if (!(o = item(polya, i))) goto fail_row;
+            if (o != Py_None) {
+                SET_BORROWED(d, KEYS[K_POLYA], o);
+            } else if (((const uint8_t*)polya_lazy.view.buf)[i]) {
+                PyObject* p = PyDict_New();
+                if (!p) goto fail_row;
+                PyObject* v;
+                int bad = 0;
+                bad |= !(v = PyLong_FromLongLong(((const int64_t*)pa_begin.view.buf)[i])) || PyDict_SetItem(p, KEYS[K_BEGIN], v) < 0;
+                Py_XDECREF(v);
+                bad |= !(v = PyLong_FromLongLong(((const int64_t*)pa_end.view.buf)[i])) || PyDict_SetItem(p, KEYS[K_END], v) < 0;
+                Py_XDECREF(v);
+                bad |= !(v = PyFloat_FromDouble(((const double*)pa_dwell.view.buf)[i])) || PyDict_SetItem(p, KEYS[K_DWELL_TIME], v) < 0;
+                Py_XDECREF(v);
+                Py_ssize_t ns = ((const int16_t*)pa_nspk.view.buf)[i];
+                const int64_t g = ((const int64_t*)gpu_row.view.buf)[i];
+                if (!spikes.held || g < 0 || g >= spike_rows) ns = 0;
+                if (ns > spike_cap) ns = spike_cap;
+                PyObject* lst = PyList_New(ns > 0 ? ns : 0);
+                bad |= !lst;
+                for (Py_ssize_t s = 0; lst && s < ns; s++) {
+                    const float* row = (const float*)spikes.view.buf + ((size_t)g * spike_cap + s) * 4;
+                    PyObject* t = Py_BuildValue("(dddd)", (double)row[0], (double)row[1], (double)row[2], (double)row[3]);
+                    if (!t) { bad = 1; break; }
+                    PyList_SET_ITEM(lst, s, t);
+                }
+                if (lst) bad |= PyDict_SetItem(p, KEYS[K_SPIKES], lst) < 0;
+                Py_XDECREF(lst);
+                if (bad) { Py_DECREF(p); goto fail_row; }
+                SET(d, KEYS[K_POLYA], p);
+            }
+            PyList_SET_ITEM(out, k, d);
+            continue;
+        fail_row:
+            Py_XDECREF(d);
+            Py_CLEAR(out);
+            goto done;
+        }
+    }
+done:
+    for (size_t k = 0; k < sizeof(all) / sizeof(all[0]); k++)
+        if (all[k]->held) PyBuffer_Release(&all[k]->view);
+    return out;
+}
+
+static PyMethodDef METHODS[] = {
+    { "report", report, METH_VARARGS, "report(columns, rows) -> list of result dicts (signal_loader.py:165-198)" },
+    { NULL, NULL, 0, NULL }
+};
+
+static struct PyModuleDef MODULE = { PyModuleDef_HEAD_INIT, "_pxgpy", "host-side result-dict builder", -1, METHODS };
+
+PyMODINIT_FUNC PyInit__pxgpy(void)
+{
+    for (int k = 0; k < N_KEYS; k++) {
+        KEYS[k] = PyUnicode_InternFromString(KEY_NAMES[k]);
+        if (!KEYS[k]) return NULL;
+    }
+    return PyModule_Create(&MODULE);
+}

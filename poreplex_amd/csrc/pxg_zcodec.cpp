@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstring>
 #include "../../include/pxg.h"
+#include "pxg_zcheck.h"
 
 extern "C" int64_t pxg_z_count_chunks(int64_t n_reads, const int64_t* offsets)
 {
@@ -72,4 +73,10 @@ extern "C" int pxg_z_decode(int64_t n_chunks, const uint8_t* z, const pxg_z_chun
         }
     }
     return PXG_OK;
+}
+
+extern "C" int pxg_z_validate(int64_t n_chunks, const pxg_z_chunk* chunks, int64_t data_base, int64_t z_bytes,
+                              int64_t dst_base, int64_t n_samples)
+{
+    return pxg_z_check(n_chunks, chunks, data_base, z_bytes, dst_base, n_samples);
 }

@@ -112,10 +112,24 @@ class ReadBundle:
             d.update(basecall_columns([json.loads(str(j)) if str(j) else None for j in js]))
         self.filenames = [str(f) for f in d['filename']]
         self.read_ids = [str(r) for r in d['read_id']]
-        self.index = {key: i for i, key in enumerate(zip(self.filenames, self.read_ids))}
+        self.keys = list(zip(self.filenames, self.read_ids))
+        self.index = {key: i for i, key in enumerate(self.keys)}
         self.by_file = {}
         for i, f in enumerate(self.filenames):
             self.by_file.setdefault(f, []).append(i)
+        if 'arena_z' in d:       # encoded samples: the records must describe the bytes (once, here)
+            from . import native
+            o, base = d['offsets'], d['z_chunk_base']
+            if len(base) != len(o) or int(base[-1]) != len(d['z_chunks']) or \
+                    not np.array_equal(np.diff(base), (np.diff(o) + native.Z_CHUNK - 1) // native.Z_CHUNK):
+                raise native.PxgError('{}: chunk table does not match the read offsets'.format(path))
+            native.z_validate(d['arena_z'], d['z_chunks'], int(o[-1]))
+            # chunks never span reads: every read's first chunk starts at the read's first sample
+            if len(d['z_chunks']) and not np.array_equal(d['z_chunks']['dst'][base[:-1][np.diff(base) > 0]],
+                                                          o[:-1][np.diff(base) > 0]):
+                raise native.PxgError('{}: a chunk spans two reads'.format(path))
+        elif len(d['arena']) != int(d['offsets'][-1]) if len(d['offsets']) else False:
+            raise ValueError('{}: sample arena does not match the read offsets'.format(path))
         # files that exist but cannot be opened (the corrupt-FAST5 case)
         self.broken = set(str(f) for f in d.get('broken_files', []))
 

@@ -15,7 +15,7 @@ from . import config as _config
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'csrc', 'libpxg.so')
 
-PXG_ABI_VERSION = 2
+PXG_ABI_VERSION = 3
 PXG_E_NOMEM, PXG_E_UNSUPPORTED = -4, -6
 PXG_MAX_STATES = 8
 PXG_MAX_MIXTURE = 4
@@ -342,6 +342,7 @@ _TEXT_SIGNATURES = {      # libpxghost.so: host-only helpers (sink text, sample 
     'pxg_z_count_chunks': (C.c_int64, [C.c_int64, C.c_void_p]),
     'pxg_z_encode': (C.c_int64, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'pxg_z_decode': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    'pxg_z_validate': (C.c_int, [C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
 }
 _text_lib = None
 
@@ -436,6 +437,33 @@ def load_text_library(path=None):
     return lib
 
 
+_pyhost = False
+
+
+def load_pyhost():
+    """The CPython extension csrc/_pxgpy (result dicts from columns, pxg_pyreport.c) for THIS
+    interpreter, or None: it is a host-side accelerator with a Python fallback, not part of the
+    numeric path (PXG_NO_PYHOST=1 forces the fallback, for the equivalence tests)."""
+    global _pyhost
+    if _pyhost is False:
+        _pyhost = None
+        import importlib.machinery
+        import importlib.util
+        if not os.environ.get('PXG_NO_PYHOST'):
+            for suffix in importlib.machinery.EXTENSION_SUFFIXES:
+                path = os.path.join(HERE, 'csrc', '_pxgpy' + suffix)
+                if os.path.isfile(path):
+                    try:
+                        spec = importlib.util.spec_from_file_location('_pxgpy', path)
+                        mod = importlib.util.module_from_spec(spec)
+                        spec.loader.exec_module(mod)
+                        _pyhost = mod
+                    except ImportError:
+                        pass
+                    break
+    return _pyhost
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -465,11 +493,25 @@ def z_encode(arena, offsets):
     return out[:got].copy(), chunks, chunk_base
 
 
+def z_validate(z, chunks, n_samples, data_base=0, dst_base=0):
+    """Raise PxgError unless the chunk records tile [dst_base, dst_base + n_samples) and stay
+    inside the bytes of `z` (records and bytes come from files: a truncated bundle must not
+    become an out-of-bounds access in a decoder)."""
+    lib = load_text_library()
+    chunks = np.ascontiguousarray(chunks, dtype=Z_CHUNK_DTYPE)
+    rc = lib.pxg_z_validate(len(chunks), _ptr(chunks), int(data_base), int(len(z)), int(dst_base),
+                            int(n_samples))
+    if rc:
+        raise PxgError('encoded samples: the chunk records do not describe the byte stream '
+                       '(truncated or corrupt bundle)')
+
+
 def z_decode(z, chunks, n_samples, data_base=0, dst_base=0):
     """Reference decoder (host): the int16 samples the chunk records describe."""
     lib = load_text_library()
     z = np.ascontiguousarray(z, dtype=np.uint8)
     chunks = np.ascontiguousarray(chunks, dtype=Z_CHUNK_DTYPE)
+    z_validate(z, chunks, n_samples, data_base, dst_base)
     out = np.zeros(int(n_samples), dtype=np.int16)
     rc = lib.pxg_z_decode(len(chunks), _ptr(z), _ptr(chunks), int(data_base), int(dst_base), _ptr(out))
     if rc:

@@ -149,13 +149,7 @@ class GpuSession:
                                                 header=self.rank == 0)
         fastq = sinks.FASTQWriter(outdir, layout, suffix=part) if cfg.get('fastq_output') else None
 
-        pinned = []
-        if self.loader.bundle is not None:       # batches of consecutive bundle reads are staged in place
-            d = self.loader.bundle.d
-            pinned = [d['arena_z'], d['z_chunks']] if self.loader.bundle.compressed else [d['arena']]
-            pinned = [a for a in pinned if a.nbytes]
-        for a in pinned:
-            self.ctx.pin(a)
+        self.loader.pin_bundle()      # batches of consecutive bundle reads are staged in place
         slots, ready = queue.Queue(), queue.Queue(maxsize=2)
         stagings = [_Staging(self.ctx), _Staging(self.ctx)]
         for s in stagings:
@@ -252,8 +246,6 @@ class GpuSession:
         thread.join()
         for s in stagings:
             s.release()
-        for a in pinned:
-            self.ctx.unpin(a)
         summary.close()
         if fastq is not None:
             fastq.close()

@@ -24,7 +24,7 @@ from weakref import proxy
 import numpy as np
 
 from . import native
-from .signal_loader import NanoporeRead, SignalAnalysisError
+from .signal_loader import NanoporeRead, ReadTable, SignalAnalysisError
 from .utils import union_intervals  # noqa: F401  (re-exported like the reference)
 from .worker_persistence import WorkerPersistenceStorage
 
@@ -89,7 +89,7 @@ class _Batch:
         """Both lists in input order (the bulk and the per-read admissions were appended apart)."""
         for name in ('early', 'entered'):
             at = getattr(self, name + '_at')
-            if any(a > b for a, b in zip(at, at[1:])):
+            if len(at) > 1 and (np.diff(np.asarray(at, dtype=np.int64)) < 0).any():
                 order = sorted(range(len(at)), key=at.__getitem__)
                 setattr(self, name, [getattr(self, name)[k] for k in order])
                 setattr(self, name + '_at', [at[k] for k in order])
@@ -115,7 +115,7 @@ class SignalAnalyzer(AbstractContextManager):
     def process(self, reads):
         """Result list of signal_analyzer.py:82-134: whatever was decided before the GPU
         pass first (encounter order), then every read that entered it (input order)."""
-        batch = self.prepare(reads)
+        batch = self.prepare(reads, ReadTable())    # a table of its own: calls may overlap (threads)
         self.loader.fit_scalers(batch.table)     # scaling parameters AND every other numeric stage
         return self.finish(batch)
 

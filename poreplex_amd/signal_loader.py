@@ -15,6 +15,7 @@ network + QC, pooling, segmentation, barcode classifier, optional poly(A) and
 the chimera window scan all run behind one upload.
 """
 import os
+import threading
 from operator import itemgetter
 
 import numpy as np
@@ -74,9 +75,11 @@ class ReadTable:
         self.gpu_row = np.zeros(0, dtype=np.int64)      # row -> index in `records`, -1 if not run
         self.records = None
         self.spikes = None
+        self._opened = False          # some row holds its own samples / an open file
 
     def append(self, filename, read_id, source):
         i = self.n
+        self._opened = True
         self.n = i + 1
         for name, _ in self.NUMERIC:
             setattr(self, name, _grown(getattr(self, name), self.n))
@@ -120,8 +123,12 @@ class ReadTable:
         self.sampling_rate[rows] = d['calib']['sampling_rate'][idx]
         o = d['offsets']
         self.n_raw[rows] = o[idx + 1] - o[idx]
-        self.filename += [bundle.filenames[i] for i in idx.tolist()]
-        self.read_id += [bundle.read_ids[i] for i in idx.tolist()]
+        if k and idx[-1] - idx[0] == k - 1 and (k == 1 or (np.diff(idx) == 1).all()):
+            self.filename += bundle.filenames[int(idx[0]):int(idx[-1]) + 1]
+            self.read_id += bundle.read_ids[int(idx[0]):int(idx[-1]) + 1]
+        else:
+            self.filename += [bundle.filenames[i] for i in idx.tolist()]
+            self.read_id += [bundle.read_ids[i] for i in idx.tolist()]
         self.channel += d['channel_number'][idx].tolist()
         self.run_id += d['run_id'][idx].tolist()
         self.sample_id += d['sample_id'][idx].tolist()
@@ -181,6 +188,8 @@ class ReadTable:
 
     def release(self, rows):
         self.pending[np.asarray(rows, dtype=np.int64)] = False
+        if not self._opened:          # nothing but bundle rows: no samples held, no file open
+            return
         for i in rows:
             self.raw[i] = None
             src = self.source[i]
@@ -189,9 +198,14 @@ class ReadTable:
 
     # -- result dicts --------------------------------------------------------
     def report(self, rows):
-        """Result dicts of `rows`, keys and key order of signal_loader.py:165-198."""
-        rows = [int(i) for i in rows]
-        idx = np.asarray(rows, dtype=np.int64)
+        """Result dicts of `rows`, keys and key order of signal_loader.py:165-198.  Built by
+        the host extension (csrc/pxg_pyreport.c) straight from the columns when it is there;
+        the loop below is the same thing in Python."""
+        idx = np.ascontiguousarray(rows, dtype=np.int64)
+        fast = native.load_pyhost()
+        if fast is not None:
+            return fast.report(self._report_columns(), idx)
+        rows = idx.tolist()
         status = [native.STATUS_NAMES[c] for c in self.status[idx].tolist()]
         # Python's round (correctly rounded decimal), not np.round: part of the output contract
         start = [round(a / b, 3) for a, b in zip(self.start_time[idx].tolist(),
@@ -227,6 +241,29 @@ class ReadTable:
                 rep['polya'] = self.polya[i]
             out.append(rep)
         return out
+
+
+def _report_columns(self):
+    """The columns pxg_pyreport.c reads (contiguous NumPy arrays / the per-row lists)."""
+    c = {name: np.ascontiguousarray(getattr(self, name)) for name in (
+        'status', 'start_time', 'sampling_rate', 'duration', 'num_events', 'sequence_length',
+        'mean_qscore', 'has_summary', 'label', 'has_barcode', 'barcode', 'barcode_guess',
+        'barcode_phred', 'seq_lazy', 'bundle_index', 'polya_lazy', 'polya_begin', 'polya_end',
+        'polya_dwell_time', 'polya_spike_count', 'gpu_row')}
+    for name in ('filename', 'read_id', 'channel', 'run_id', 'sample_id', 'sequence',
+                 'error_message', 'polya'):
+        c[name] = getattr(self, name)
+    c['status_names'], c['label_names'] = native.STATUS_NAMES, LABELS
+    if self.bundle is not None:
+        d = self.bundle.d
+        c['seq_arena'], c['qual_arena'] = d['seq_arena'], d['qual_arena']
+        c['seq_offsets'] = np.ascontiguousarray(d['seq_offsets'], dtype=np.int64)
+    if self.spikes is not None:
+        c['spikes'] = np.ascontiguousarray(self.spikes, dtype=np.float32)
+    return c
+
+
+ReadTable._report_columns = _report_columns
 
 
 def summary_columns(table, rows, barcoding, polya):
@@ -420,6 +457,11 @@ class SignalLoader:
         self.stage_mask = native.STAGE_ALL_DEMUX
         self.scan_unsplit = False      # --filter-chimera: also run the a19 window scan
         self.table = ReadTable()
+        # several worker calls may be in flight on one context (threads: fit_scalers): one call
+        # owns the spare input slot from stage to swap, one owns the resident batch from swap
+        # to the download of its records
+        self._stage_lock, self._run_lock = threading.Lock(), threading.Lock()
+        self._pinned = []
 
     def clear(self):
         self.table = ReadTable()
@@ -454,10 +496,16 @@ class SignalLoader:
         corrupt)."""
         b = self.bundle
         where = np.full(len(reads), -1, dtype=np.int64)
-        if b is None:
+        if b is None or not len(reads):
             return where
         index, broken = b.index, b.broken
-        where[:] = [index.get(key, -1) for key in reads]
+        # the usual worker batch is a run of consecutive bundle reads: one list comparison
+        # instead of a dictionary lookup per read
+        first = index.get(reads[0], -1)
+        if first >= 0 and b.keys[first:first + len(reads)] == reads:
+            where[:] = np.arange(first, first + len(reads))
+        else:
+            where[:] = [index.get(key, -1) for key in reads]
         if broken:
             where[[key[0] in broken for key in reads]] = -1
         found = where >= 0
@@ -526,16 +574,55 @@ class SignalLoader:
         if self.scan_unsplit:
             self.scan_unsplit_candidates(t, rows, offsets)
 
+    def pin_bundle(self):
+        """Page-lock the bundle's sample arena (or its encoded bytes + chunk records) once, so
+        every batch of consecutive bundle reads goes to the GPU as a DMA transfer straight from
+        the bundle; stays pinned for the life of the worker (unpin_bundle)."""
+        if self.bundle is None or self._pinned:
+            return
+        d = self.bundle.d
+        arrays = [d['arena_z'], d['z_chunks']] if self.bundle.compressed else [d['arena']]
+        for a in arrays:
+            if a.nbytes:
+                self.ctx.pin(a)
+                self._pinned.append(a)
+
+    def unpin_bundle(self):
+        pinned, self._pinned = self._pinned, []
+        for a in pinned:
+            self.ctx.unpin(a)
+
     def fit_scalers(self, table=None):
         """The GPU pass over every read of the table that is still live: scaler network +
-        QC and, behind the same upload, every other numeric stage."""
+        QC and, behind the same copy, every other numeric stage.
+
+        The reference keeps `parallel` worker calls in flight (pipeline.py:96,204-205); here
+        calls from several threads of ONE process share the GPU context and overlap on it: a
+        call copies its samples into the spare input slot on the copy stream (pxg_batch_stage)
+        while the previous call's kernels run on the resident batch, becomes resident
+        (pxg_batch_swap) once that call has downloaded its records, launches, and builds its
+        result dicts while the next call computes.  Two locks, always taken in this order."""
         t = self.table if table is None else table
         rows, arena, offsets, calib = self.pack(t)
-        if len(rows):
-            if isinstance(arena, native.EncodedSamples):      # one-shot path: decode on the host
-                arena = arena.decode()
-            self.ctx.upload(arena, offsets, calib)
+        if not len(rows):
+            return
+        ctx = self.ctx
+        with self._stage_lock:
+            self.pin_bundle()
+            if isinstance(arena, native.EncodedSamples):      # compressed bundle: decoded on the GPU
+                ctx.stage_z(arena, offsets, calib)
+            else:
+                ctx.stage(arena, offsets, calib)
+            self._run_lock.acquire()                          # the previous call has its records
+            try:
+                ctx.swap()
+            except BaseException:
+                self._run_lock.release()
+                raise
+        try:
             self.run_resident(t, rows, offsets)
+        finally:
+            self._run_lock.release()
 
     def scan_unsplit_candidates(self, table, rows, offsets):
         """a18 + a19 numeric part for the resident batch: Guppy block means of every

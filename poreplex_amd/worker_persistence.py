@@ -8,11 +8,14 @@ GPU context (weights + HMM tables resident in HBM, stream, arenas): one
 """
 import os
 import sys
+import threading
 import types
 
 from . import native
 
 __all__ = ['WorkerPersistenceStorage']
+
+_INIT_LOCK = threading.Lock()
 
 
 class WorkerPersistenceStorage:
@@ -25,10 +28,11 @@ class WorkerPersistenceStorage:
         self.config = config
 
     def retrieve_objects(self, target):
-        if self.STORAGE_NAME not in sys.modules:
-            storage = self.init_persistence_objects(self.config)
-        else:
-            storage = sys.modules[self.STORAGE_NAME].storage
+        with _INIT_LOCK:              # worker calls may arrive on several threads at once
+            if self.STORAGE_NAME not in sys.modules:
+                storage = self.init_persistence_objects(self.config)
+            else:
+                storage = sys.modules[self.STORAGE_NAME].storage
         for varname in self.VARIABLES:
             if varname in storage:
                 setattr(target, varname, storage[varname])
@@ -70,4 +74,6 @@ class WorkerPersistenceStorage:
         """Drop the cached context (tests / device switch)."""
         mod = sys.modules.pop(cls.STORAGE_NAME, None)
         if mod is not None and 'ctx' in mod.storage:
+            if 'loader' in mod.storage:
+                mod.storage['loader'].unpin_bundle()
             mod.storage['ctx'].close()

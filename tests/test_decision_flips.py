@@ -170,6 +170,107 @@ def measure(n_reads=2048, samples=40000, seed=924):
     }
 
 
+def measure_viterbi(n_reads=2048, n_chimeras=512, samples=40000, seed=924):
+    """The Viterbi side (rows a6 / a7, and the a19 window scan): the oracle's paths against
+    every formula variant of tests/viterbi_variants.py on (a) the pooled + scaled signals of
+    `n_reads` bench reads under the segmentation HMM and (b) every scan window of those reads
+    AND of `n_chimeras` two-reads-in-one chimeras under the `unsplit` HMM (the model with
+    back-edges).  Counts decisions, not bits: reads with any segment boundary moved, reads
+    whose in-read adapter candidate list changed."""
+    import viterbi_variants as VV
+    from oracle.pxo import Oracle
+    orc = Oracle(default_config())
+    cfg = orc.cfg
+    stride = int(cfg.stride)
+    limit = int(cfg.segmentation_scan_limit) // stride
+    adapter = int(cfg.segmentation_model.adapter_state)
+
+    plain = synth_batch(n_reads, seed=seed, samples_per_read=samples, short_fraction=0.01)
+    # chimeras: two synthetic reads back to back, one DAQ setting (tools/make_golden.py:640-653)
+    cb = synth_batch(2 * n_chimeras, seed=seed + 7, samples_per_read=26000, jitter=0.2, fixed_calib=True,
+                     scale_sigma=0.0, shift_sigma=0.0)
+    co = cb['offsets']
+    chim = [np.concatenate([cb['arena'][co[2 * k]:co[2 * k + 1]], cb['arena'][co[2 * k + 1]:co[2 * k + 2]]])
+            for k in range(n_chimeras)]
+    c_arena, c_off = N.pack_reads(chim)
+    sets = (('bench', plain['arena'], plain['offsets'], plain['calib']),
+            ('chimera', c_arena, c_off, cb['calib'][::2]))
+
+    seg_x, seg_want = [], []                 # segmentation inputs / the oracle's segments
+    win_x, win_meta, reads_meta = [], [], []
+    want_cands = []
+    for tag, arena, off, cal in sets:
+        got = orc.process_batch(arena, off, cal)
+        for i in np.nonzero(got['status'] == 0)[0].tolist():
+            raw = arena[off[i]:off[i + 1]]
+            g = got[i]
+            sig = orc.pool_scale(raw, cal[i], g['scale'], g['shift'])
+            if tag == 'bench':
+                seg_x.append(sig[:limit])
+                seg_want.append((g['seg_first'].copy(), g['seg_last'].copy()))
+            if g['seg_first'][adapter] < 0:
+                continue
+            n_ev = len(raw) // stride
+            _, scaled = orc.guppy_event_means(raw, cal[i], 0, n_ev, g['scale'], g['shift'], stride)
+            payload = (int(g['seg_last'][adapter]) + 1) * stride
+            rate = float(cal[i]['sampling_rate'])
+            iv, _ = orc.unsplit_scan(scaled, 0, payload, rate, stride)
+            r = len(reads_meta)
+            reads_meta.append((tag, n_ev, payload, rate))
+            want_cands.append(iv.tolist())
+            for k0, k1 in VV.unsplit_windows(cfg, n_ev, 0, stride, payload, rate):
+                win_x.append(scaled[k0:k1 + 1])
+                win_meta.append((r, k0))
+
+    def padded(rows):
+        lens = np.array([len(r) for r in rows], dtype=np.int64)
+        x = np.zeros((len(rows), int(lens.max())), dtype=np.float32)
+        for k, r in enumerate(rows):
+            x[k, :len(r)] = r
+        return x, lens
+
+    seg_X, seg_L = padded(seg_x)
+    win_X, win_L = padded(win_x)
+    table = []
+    for name, knobs in VV.VARIANTS:
+        block = 256 if knobs.get('dtype') is np.longdouble else 512
+        # (a) segmentation model
+        moved, adapter_flip, dlogp = 0, 0, 0.0
+        m = VV.Model(cfg.segmentation_model, **knobs)
+        for a in range(0, len(seg_x), block):
+            paths, logp = VV.viterbi_batch(m, seg_X[a:a + block], seg_L[a:a + block])
+            for b in range(len(paths)):
+                f, l = VV.runs_to_segments(paths[b, :seg_L[a + b]], N.PXG_N_SEGMENTS)
+                wf, wl = seg_want[a + b]
+                moved += int(not (np.array_equal(f, wf) and np.array_equal(l, wl)))
+                adapter_flip += int((f[adapter] >= 0) != (wf[adapter] >= 0))
+        # (b) unsplit model, every scan window
+        m = VV.Model(cfg.unsplit_model, **knobs)
+        cands = [[] for _ in reads_meta]
+        for a in range(0, len(win_x), block):
+            paths, _ = VV.viterbi_batch(m, win_X[a:a + block], win_L[a:a + block])
+            for b in range(len(paths)):
+                r, k0 = win_meta[a + b]
+                tag, n_ev, payload, rate = reads_meta[r]
+                cands[r] += VV.unsplit_candidates(cfg, paths[b, :win_L[a + b]], k0, n_ev, 0, stride,
+                                                  payload, rate)
+        changed = {'bench': 0, 'chimera': 0}
+        for r, (tag, _, _, _) in enumerate(reads_meta):
+            changed[tag] += int(cands[r] != want_cands[r])
+        table.append({'variant': name, 'knobs': {k: (v.__name__ if isinstance(v, type) else v)
+                                                 for k, v in knobs.items()},
+                      'reads_with_a_segment_boundary_moved': moved,
+                      'adapter_found_flips': adapter_flip,
+                      'bench_reads_candidate_list_changed': changed['bench'],
+                      'chimera_reads_candidate_list_changed': changed['chimera']})
+    n_tag = {t: sum(1 for m_ in reads_meta if m_[0] == t) for t in ('bench', 'chimera')}
+    return {'reads_segmented': len(seg_x), 'scan_windows': len(win_x),
+            'reads_scanned': n_tag, 'reads_with_candidates': {
+                t: sum(1 for r, m_ in enumerate(reads_meta) if m_[0] == t and want_cands[r])
+                for t in ('bench', 'chimera')},
+            'seed': int(seed), 'variants': table}
+
+
 def test_decision_flips_bounded():
     # the float64 nets are thousands of small matmuls: BLAS worker threads only spin on them (and,
     # under a CPU quota, can stall the test for many minutes)
@@ -189,6 +290,26 @@ def test_decision_flips_bounded():
     assert r['adapter_found_or_window_gate_flips'] <= 2
 
 
+def test_viterbi_formula_variants_move_no_decision():
+    """Pipelines that differ ONLY in what pomegranate is free to do inside its Viterbi: the
+    canonical restatement must reproduce the oracle exactly, every other variant may move a
+    stated handful of decisions (none observed)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    r = measure_viterbi()
+    print(json.dumps(r))
+    assert r['reads_segmented'] >= 2000 and r['scan_windows'] >= 8000
+    assert r['reads_with_candidates']['chimera'] >= 0.8 * r['reads_scanned']['chimera']
+    first = r['variants'][0]
+    assert first['knobs'] == {}
+    for key in ('reads_with_a_segment_boundary_moved', 'adapter_found_flips',
+                'bench_reads_candidate_list_changed', 'chimera_reads_candidate_list_changed'):
+        assert first[key] == 0, (key, first)
+        for v in r['variants'][1:]:
+            assert v[key] <= 3, (key, v)
+
+
 if __name__ == '__main__':
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-    print(json.dumps(measure(n), indent=1))
+    out = {'lstm_side': measure(n), 'viterbi_side': measure_viterbi(n, max(n // 4, 8))}
+    print(json.dumps(out, indent=1))

@@ -117,6 +117,36 @@ def test_barcoding_quality_filter_guard(oracle_backed, ref_results):
     assert isinstance(out, tuple) and out[0] == -1 and 'barcoding-quality-filter' in out[1]
 
 
+def _overlapping_calls(ref_results, workers=3, calls=7):
+    """`calls` process_batch calls kept in flight `workers` at a time on ONE context, the way
+    pipeline.py:96,204-205 keeps `parallel` worker calls in flight (threads instead of
+    processes: one process per GPU).  Different slices per call, so a mix-up of two calls'
+    resident batches cannot go unnoticed."""
+    from concurrent.futures import ThreadPoolExecutor
+    from poreplex_amd.signal_analyzer import process_batch
+    cfg = facade_config(ref_results)
+    reads = [tuple(r) for r in ref_results['reads']]
+    slices = [reads[k % 5:len(reads) - (k % 3)] for k in range(calls)]
+    serial = [process_batch(100 + k, sl, cfg) for k, sl in enumerate(slices)]
+    with ThreadPoolExecutor(workers) as pool:
+        together = list(pool.map(lambda a: process_batch(100 + a[0], a[1], cfg), enumerate(slices)))
+    for one, two in zip(serial, together):
+        assert not (isinstance(two, tuple) and two[0] == -1), two
+        compare_results(two, [canon(r) for r in one], check_polya=True)
+    compare_results(together[0], [r for r in ref_results['results']], check_polya=True)
+
+
+def test_overlapping_process_batch_calls_share_one_context(oracle_backed, ref_results):
+    _overlapping_calls(ref_results)
+
+
+@pytest.mark.gpu
+def test_overlapping_process_batch_calls_on_the_gpu(ref_results):
+    WorkerPersistenceStorage.reset()
+    _overlapping_calls(ref_results, workers=3, calls=12)
+    WorkerPersistenceStorage.reset()
+
+
 @pytest.mark.gpu
 def test_process_batch_gpu_vs_reference(ref_results):
     from poreplex_amd.signal_analyzer import process_batch

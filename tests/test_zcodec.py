@@ -178,3 +178,73 @@ def test_fuzz_device_decoder_sample_for_sample(ctx):
             ctx.stage_z(enc, off[i0:i1 + 1] - off[i0], cal[i0:i1])
             ctx.swap()
             assert np.array_equal(ctx.download_samples(len(enc)), arena[off[i0]:off[i1]]), (trial, i0, i1)
+
+
+def _encoded(seed=11):
+    sb = synth_batch(6, seed=seed, samples_per_read=5000)
+    z, chunks, base = N.z_encode(sb['arena'], sb['offsets'])
+    return sb, z, chunks, base
+
+
+CORRUPTIONS = {
+    'length zero': lambda z, c: c['len'].__setitem__(2, 0),
+    'length beyond a chunk': lambda z, c: c['len'].__setitem__(2, 2000),
+    'destination moved': lambda z, c: c['dst'].__setitem__(3, c['dst'][3] + 7),
+    'destination before the arena': lambda z, c: c['dst'].__setitem__(0, -5),
+    'bytes before the stream': lambda z, c: c['data_off'].__setitem__(0, -128),
+    'bytes beyond the stream': lambda z, c: c['data_off'].__setitem__(len(c) - 1, len(z) + 4096),
+    'chunks overlap in the stream': lambda z, c: c['data_off'].__setitem__(4, c['data_off'][3]),
+}
+
+
+@pytest.mark.parametrize('what', sorted(CORRUPTIONS))
+def test_corrupt_chunk_records_are_refused_on_the_host(what):
+    """chunk records come from files -- a truncated or corrupt bundle must be an error
+    (PXG_E_INVALID / PxgError), never an out-of-bounds access in a decoder."""
+    sb, z, chunks, base = _encoded()
+    N.z_validate(z, chunks, len(sb['arena']))                  # the encoder's own output passes
+    bad = chunks.copy()
+    CORRUPTIONS[what](z, bad)
+    with pytest.raises(N.PxgError):
+        N.z_decode(z, bad, len(sb['arena']))
+    with pytest.raises(N.PxgError):                            # a truncated byte stream
+        N.z_decode(z[:len(z) // 2], chunks, len(sb['arena']))
+    with pytest.raises(N.PxgError):                            # records that do not cover the arena
+        N.z_decode(z, chunks[:-1], len(sb['arena']))
+
+
+def test_truncated_compressed_bundle_fails_at_load(tmp_path):
+    from poreplex_amd.fast5_file import write_bundle
+    sb, z, chunks, base = _encoded()
+    n = len(sb['offsets']) - 1
+    path = str(tmp_path / 'ok.pxr.npz')
+    write_bundle(path, sb['arena'], sb['offsets'], sb['calib'], ['f%d' % i for i in range(n)],
+                 ['r%d' % i for i in range(n)], compress=True)
+    ReadBundle(path)
+    with np.load(path, allow_pickle=False) as npz:
+        d = {k: npz[k] for k in npz.files}
+    for name, change in (('cut', lambda d: d.__setitem__('arena_z', d['arena_z'][:1000])),
+                         ('records', lambda d: d.__setitem__('z_chunks', d['z_chunks'][:-3])),
+                         ('span', lambda d: d['z_chunks']['dst'].__setitem__(slice(1, None), d['z_chunks']['dst'][1:] + 1))):
+        e = {k: v.copy() for k, v in d.items()}
+        change(e)
+        bad = str(tmp_path / (name + '.pxr.npz'))
+        np.savez(bad, **e)
+        with pytest.raises(N.PxgError):
+            ReadBundle(bad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('what', sorted(CORRUPTIONS))
+def test_corrupt_chunk_records_are_refused_by_stage_z(ctx, what):
+    sb, z, chunks, base = _encoded()
+    bad = chunks.copy()
+    CORRUPTIONS[what](z, bad)
+    with pytest.raises(N.PxgError, match='chunk records'):
+        ctx.stage_z(N.EncodedSamples(z, bad, 0, 0, len(sb['arena'])), sb['offsets'], sb['calib'])
+    with pytest.raises(N.PxgError, match='chunk records'):
+        ctx.stage_z(N.EncodedSamples(z[:len(z) // 2], chunks, 0, 0, len(sb['arena'])), sb['offsets'], sb['calib'])
+    # and the context is still usable: the good stream decodes to the arena
+    ctx.stage_z(N.EncodedSamples(z, chunks, 0, 0, len(sb['arena'])), sb['offsets'], sb['calib'])
+    ctx.swap()
+    assert np.array_equal(ctx.download_samples(len(sb['arena'])), sb['arena'])
