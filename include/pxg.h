@@ -33,11 +33,9 @@ extern "C" {
 #define PXG_N_SEGMENTS      8   /* seg_first/seg_last slots (= PXG_MAX_STATES)     */
 #define PXG_MAX_CLASSES     8   /* softmax width (reference: 1 decoy + 4 barcodes) */
 #define PXG_MAX_CALIBRATION 64  /* phred calibration table rows (reference: 29)    */
-#define PXG_MAX_SPIKES      64  /* poly(A) spike records kept per read             */
 
-/* per-read error codes pxg_batch_unsplit_scan stores in out_count (data problems are
+/* per-read error code pxg_batch_unsplit_scan stores in out_count (data problems are
  * per-read results, never call failures -- signal_analyzer.py:118-122) */
-#define PXG_UNSPLIT_E_WINDOW_CANDS (-2) /* one scan window produced more candidates than its slots */
 #define PXG_UNSPLIT_E_GEOMETRY     (-3) /* negative first_sample / n_blocks                  */
 
 /* ---- error codes (function return values) -------------------------------- */
@@ -208,15 +206,18 @@ typedef struct {
     float bc_score;                       /* max softmax                         */
     float probs[PXG_MAX_CLASSES];
     int8_t polya_called;
-    int8_t polya_n_spikes;
-    int16_t reserved;
+    int8_t reserved8;
+    int16_t reserved16;
+    int32_t polya_n_spikes;               /* every spike event of the tail (polya.py:109-115); the
+                                             rows themselves: pxg_batch_download_spikes          */
     int32_t polya_dwell_samples;          /* sum of poly(A)-event lengths        */
     int64_t polya_begin, polya_end;       /* raw-sample coordinates              */
 } pxg_read_result;
 
 /* poly(A) spike detail, kept OUT of the gathered record: one row per spike,
  * (length, mean of the event before, of the spike, of the event after) --
- * polya.py:111-114.  Arrays of PXG_MAX_SPIKES rows per read. */
+ * polya.py:111-114.  As many rows per read as the tail has spikes (the reference lists
+ * all of them): rows of all reads back to back in read order + offsets (CSR). */
 typedef struct {
     float v[4];
 } pxg_polya_spike;
@@ -248,6 +249,7 @@ typedef struct {
 } pxg_device_info;
 
 typedef struct pxg_ctx pxg_ctx;
+typedef struct pxg_z_chunk pxg_z_chunk;   /* defined with the sample codec below */
 
 /* ---- lifetime: replaces WorkerPersistenceStorage.init_persistence_objects
  * (worker_persistence.py:60-90): load models once per worker process. ------ */
@@ -265,6 +267,37 @@ int pxg_process_batch(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
                       const int64_t* raw_offsets, const pxg_calib* calib,
                       const float* scale_shift_or_null, uint32_t stage_mask,
                       pxg_read_result* out);
+
+/* The same call with everything a worker batch may need around the records, and the form
+ * the reference's `parallel` workers map onto (pipeline.py:96,204-205): SEVERAL HOST THREADS
+ * MAY CALL pxg_process_batch / pxg_process_batch_ex ON ONE CONTEXT AT THE SAME TIME.  Calls
+ * overlap on the device: a call copies its samples into the spare input slot on the copy
+ * stream while the previous call's kernels run on the resident batch, becomes resident when
+ * that call has its results, runs every stage, and returns with everything on the host --
+ * the copy of call k+1 under the kernels of call k, the caller's host work for call k-1
+ * (result dicts) under both.  Inputs: page-lock them (pxg_host_register) for DMA transfers.
+ * (Do not mix with the split calls pxg_batch_upload/stage/swap/run/... from other threads.)
+ *   z != NULL: the samples arrive encoded (pxg_batch_stage_z's arguments), raw_arena is NULL.
+ *   unsplit_first_sample != NULL: also run the a19 window scan (pxg_batch_unsplit_scan's
+ *     arguments) on the batch while it is resident; candidates of all reads back to back in
+ *     unsplit_intervals (cap pairs), unsplit_count per read, unsplit_total pairs found.
+ *   spikes != NULL (poly(A) stage): the spike rows of all reads in read order, spike_offsets
+ *     n_reads + 1, spike_total rows found.
+ * A variable-size output that did not fit its cap leaves its *_total set and the call returns
+ * PXG_E_NOMEM: call again with buffers of that size (records and counts are valid). */
+typedef struct {
+    uint32_t struct_bytes;                 /* sizeof(pxg_batch_extras): layout guard            */
+    int32_t unsplit_block_stride;
+    const float* scale_shift_or_null;
+    const uint8_t* z; int64_t z_bytes; const pxg_z_chunk* chunks; int64_t n_chunks;
+    int64_t data_base, dst_base;
+    const int64_t* unsplit_first_sample; const int64_t* unsplit_n_blocks;
+    int64_t unsplit_cap; int64_t* unsplit_intervals; int32_t* unsplit_count; int64_t unsplit_total;
+    int64_t spike_cap; pxg_polya_spike* spikes; int64_t* spike_offsets; int64_t spike_total;
+} pxg_batch_extras;
+int pxg_process_batch_ex(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena_or_null,
+                         const int64_t* raw_offsets, const pxg_calib* calib, uint32_t stage_mask,
+                         pxg_batch_extras* extras_or_null, pxg_read_result* out);
 
 /* Split form for device-resident batches (loader overlap, benchmarking):
  * upload = H2D copy into context-owned HBM arenas; run = enqueue all kernels
@@ -301,8 +334,10 @@ int pxg_batch_sync(pxg_ctx* ctx);
  * signal) is re-run with what it asked for before any record leaves the device, so a
  * record never depends on the size of a scratch buffer. */
 int pxg_batch_download(pxg_ctx* ctx, pxg_read_result* out);
-/* n_reads x PXG_MAX_SPIKES spike rows of the last run (poly(A) stage only) */
-int pxg_batch_download_spikes(pxg_ctx* ctx, pxg_polya_spike* out);
+/* spike rows of the last run (poly(A) stage only): offsets[r] .. offsets[r + 1] = the rows of
+ * read r (offsets has n_reads + 1 entries and is always filled; offsets[n_reads] = the sum of the
+ * records' polya_n_spikes).  PXG_E_NOMEM when cap_rows is smaller than that (no row written). */
+int pxg_batch_download_spikes(pxg_ctx* ctx, int64_t cap_rows, pxg_polya_spike* out, int64_t* offsets);
 int pxg_batch_times(pxg_ctx* ctx, pxg_stage_times* out);
 
 /* ---- per-stage hooks (parity tests call these through the same ABI) ------ */
@@ -351,7 +386,8 @@ int pxg_guppy_event_means(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_aren
  * end + 1) pairs, raw-sample coordinates, of all reads back to back in read
  * order in out_intervals (cap_intervals x 2); *out_total = pairs found (when it
  * exceeds cap_intervals only the first cap_intervals were written: call again
- * with a larger buffer).  Everything between the H2D of the two per-read arrays
+ * with a larger buffer).  A window keeps as many candidates as its length and the duration
+ * cut-offs of the config allow (the slots are sized from them): no fixed limit.  Everything between the H2D of the two per-read arrays
  * and the final D2H is enqueued without a host synchronisation. */
 int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample, const int64_t* n_blocks,
                            int32_t block_stride, int64_t cap_intervals, int64_t* out_intervals,
@@ -360,10 +396,13 @@ int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample, const int6
  * reads whose scaling and segmentation the caller supplies (seg_first/seg_last:
  * n x PXG_N_SEGMENTS, pooled right-inclusive, -1 absent, as pxg_viterbi returns
  * them).  out: n records of which only the polya_* fields (and status = OKAY) are
- * set; spikes_or_null n x PXG_MAX_SPIKES rows. */
+ * set; spike rows as pxg_batch_download_spikes returns them (spike_offsets_or_null n + 1
+ * entries; PXG_E_NOMEM with the offsets filled when spike_cap rows are too few).  Settles a
+ * resident batch's pending poly(A) retries first: safe between pxg_batch_run and its download. */
 int pxg_polya(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena, const int64_t* raw_offsets,
               const pxg_calib* calib, const float* scale_shift, const int32_t* seg_first,
-              const int32_t* seg_last, pxg_read_result* out, pxg_polya_spike* spikes_or_null);
+              const int32_t* seg_last, pxg_read_result* out, int64_t spike_cap,
+              pxg_polya_spike* spikes_or_null, int64_t* spike_offsets_or_null);
 /* a15: csupport.detect_events (src/csupport.c:70-124) on a batch of windows */
 int pxg_detect_events(pxg_ctx* ctx, int64_t n_windows, const float* signal_arena,
                       const int64_t* signal_offsets, int64_t max_events_per_window,
@@ -410,13 +449,13 @@ int64_t pxg_summary_rows(const pxg_summary_columns* cols, char* out, int64_t cap
  * pxg_z_encode / pxg_z_decode / pxg_z_count_chunks: host only (libpxghost.so). */
 #define PXG_Z_CHUNK 1024
 #define PXG_Z_CTRL_BYTES (PXG_Z_CHUNK / 8)
-typedef struct {
+struct pxg_z_chunk {
     int64_t data_off;      /* byte offset of the chunk (its control bytes) in the encoded stream */
     int64_t dst;           /* sample index of the chunk's first sample in the decoded arena */
     int16_t first;         /* sample 0 */
     int16_t len;           /* samples in the chunk, 1 .. PXG_Z_CHUNK */
     int32_t reserved;
-} pxg_z_chunk;
+};
 int64_t pxg_z_count_chunks(int64_t n_reads, const int64_t* offsets);
 /* -> bytes written (worst case PXG_Z_CTRL_BYTES * chunks + 2 * samples), PXG_E_NOMEM if cap is short */
 int64_t pxg_z_encode(int64_t n_reads, const int16_t* arena, const int64_t* offsets, uint8_t* out,

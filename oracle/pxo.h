@@ -94,7 +94,8 @@ void pxo_medfilt(const float* x, int64_t n, int k, float* out);
 /* a14+a16+a17 polya.py:50-187 on one read; fills polya_* fields of r */
 void pxo_polya(const pxg_config* cfg, const float* scaled_full, int64_t n_raw,
                int rough_begin, int rough_end_or_neg, double sampling_rate,
-               pxg_read_result* r, pxg_polya_spike* spikes_or_null);
+               pxg_read_result* r, pxg_polya_spike* spikes_or_null, int spike_cap);
+/* (every spike is counted in r->polya_n_spikes; the first spike_cap rows are stored) */
 /* a16 polya.py:156-187; is_polya/length per event; returns 1 and (i,j) or 0 */
 int pxo_best_polya_interval(const pxg_config* cfg, const uint8_t* is_polya,
                             const float* length, int n_events, int* out_i, int* out_j);
@@ -116,11 +117,12 @@ int pxo_unsplit_scan(const pxg_config* cfg, const float* scaled_mean, int64_t n_
 void pxo_process_read(const pxg_config* cfg, const int16_t* raw, int64_t n_raw,
                       const pxg_calib* cal, const float* scale_shift_or_null,
                       uint32_t stage_mask, pxg_read_result* out,
-                      pxg_polya_spike* spikes_or_null);
+                      pxg_polya_spike* spikes_or_null, int spike_cap);
 void pxo_process_batch(const pxg_config* cfg, int64_t n_reads, const int16_t* raw_arena,
                        const int64_t* raw_offsets, const pxg_calib* calib,
                        const float* scale_shift_or_null, uint32_t stage_mask,
-                       pxg_read_result* out, pxg_polya_spike* spikes_or_null);
+                       pxg_read_result* out, pxg_polya_spike* spikes_or_null /* n x spike_cap */,
+                       int spike_cap);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@ LIB_PATH = os.path.join(HERE, '_build', 'libpxo.so')
 REF_LIB_PATH = os.path.join(HERE, '_ref', 'libscrappie_ref.so')
 
 _lib = None
+SPIKE_ROWS = 64        # spike rows per read of the first try (every spike is counted: rerun if short)
 
 
 def build(force=False):
@@ -66,12 +67,12 @@ def lib():
             'pxo_barcode_call': (None, [cfgp, vp, vp]),
             'pxo_detect_events': (i64, [vp, i64, i64, i64, f32, f32, f32, vp, i64]),
             'pxo_medfilt': (None, [vp, i64, i32, vp]),
-            'pxo_polya': (None, [cfgp, vp, i64, i32, i32, f64, vp, vp]),
+            'pxo_polya': (None, [cfgp, vp, i64, i32, i32, f64, vp, vp, i32]),
             'pxo_best_polya_interval': (i32, [cfgp, vp, vp, i32, vp, vp]),
             'pxo_guppy_event_means': (i32, [vp, i64, vp, i64, i64, i32, f32, f32, vp, vp]),
             'pxo_unsplit_scan': (i32, [cfgp, vp, i64, i64, i32, i64, f64, vp, i32]),
-            'pxo_process_read': (None, [cfgp, vp, i64, vp, vp, C.c_uint32, vp, vp]),
-            'pxo_process_batch': (None, [cfgp, i64, vp, vp, vp, vp, C.c_uint32, vp, vp]),
+            'pxo_process_read': (None, [cfgp, vp, i64, vp, vp, C.c_uint32, vp, vp, i32]),
+            'pxo_process_batch': (None, [cfgp, i64, vp, vp, vp, vp, C.c_uint32, vp, vp, i32]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(_lib, name)
@@ -236,11 +237,15 @@ class Oracle:
     def polya(self, scaled_full, rough_begin, rough_end, sampling_rate):
         x = np.ascontiguousarray(scaled_full, dtype=np.float32)
         r = np.zeros(1, dtype=N.RESULT_DTYPE)
-        sp = np.zeros((N.PXG_MAX_SPIKES, 4), dtype=np.float32)
-        self.L.pxo_polya(C.byref(self.cfg), _p(x), len(x), int(rough_begin),
-                         -1 if rough_end is None else int(rough_end),
-                         float(sampling_rate), _p(r), _p(sp))
-        return r[0], sp
+        cap = SPIKE_ROWS
+        while True:                     # every spike is counted; rerun with room for all of them
+            sp = np.zeros((cap, 4), dtype=np.float32)
+            self.L.pxo_polya(C.byref(self.cfg), _p(x), len(x), int(rough_begin),
+                             -1 if rough_end is None else int(rough_end),
+                             float(sampling_rate), _p(r), _p(sp), cap)
+            if r[0]['polya_n_spikes'] <= cap:
+                return r[0], sp
+            cap = int(r[0]['polya_n_spikes'])
 
     # ---- events table / pseudo-fusion ------------------------------------
     def guppy_event_means(self, raw, calib_row, first_sample, n_events, scale, shift, stride=15):
@@ -273,10 +278,27 @@ class Oracle:
         if scale_shift is not None:
             scale_shift = np.ascontiguousarray(scale_shift, dtype=np.float32).reshape(n, 2)
         out = np.zeros(n, dtype=N.RESULT_DTYPE)
-        spikes = np.zeros((n, N.PXG_MAX_SPIKES, 4), dtype=np.float32) if want_spikes else None
-        self.L.pxo_process_batch(C.byref(self.cfg), n, _p(arena), _p(offsets), _p(calib),
-                                 _p(scale_shift), stage_mask, _p(out), _p(spikes))
+        cap = SPIKE_ROWS
+        while True:
+            spikes = np.zeros((n, cap, 4), dtype=np.float32) if want_spikes else None
+            self.L.pxo_process_batch(C.byref(self.cfg), n, _p(arena), _p(offsets), _p(calib),
+                                     _p(scale_shift), stage_mask, _p(out), _p(spikes), cap)
+            most = int(out['polya_n_spikes'].max()) if n else 0
+            if not want_spikes or most <= cap:
+                break
+            cap = most                  # a tail with more spikes than the rows on offer: all of them
         return (out, spikes) if want_spikes else out
+
+
+def spikes_csr(records, spikes):
+    """The oracle's dense [n, cap, 4] spike table as the product returns it: (rows [total, 4]
+    in read order, offsets [n + 1])."""
+    ns = np.where(records['polya_called'] != 0, records['polya_n_spikes'], 0).astype(np.int64)
+    off = np.zeros(len(ns) + 1, dtype=np.int64)
+    np.cumsum(ns, out=off[1:])
+    rows = np.concatenate([spikes[i, :ns[i]] for i in range(len(ns))]) if len(ns) and off[-1] \
+        else np.zeros((0, 4), dtype=np.float32)
+    return rows.reshape(-1, 4), off
 
 
 def reference_detect_events(sig, w1=7, w2=20, t1=3.0, t2=8.0, ph=4.0):

@@ -20,7 +20,8 @@ static void result_init(pxg_read_result* r)
 
 void pxo_process_read(const pxg_config* cfg, const int16_t* raw, int64_t n_raw,
                       const pxg_calib* cal, const float* ss_inject,
-                      uint32_t stage_mask, pxg_read_result* r, pxg_polya_spike* spikes)
+                      uint32_t stage_mask, pxg_read_result* r, pxg_polya_spike* spikes,
+                      int spike_cap)
 {
     const int stride = cfg->stride;
     result_init(r);
@@ -101,9 +102,9 @@ void pxo_process_read(const pxg_config* cfg, const int16_t* raw, int64_t n_raw,
         }
         if (PA >= 0 && r->seg_first[PA] >= 0)
             pxo_polya(cfg, full, n_raw, r->seg_first[PA], r->seg_last[PA],
-                      cal->sampling_rate, r, spikes);
+                      cal->sampling_rate, r, spikes, spike_cap);
         else
-            pxo_polya(cfg, full, n_raw, r->seg_last[A] + 1, -1, cal->sampling_rate, r, spikes);
+            pxo_polya(cfg, full, n_raw, r->seg_last[A] + 1, -1, cal->sampling_rate, r, spikes, spike_cap);
         free(full);
     }
     free(pooled);
@@ -112,10 +113,10 @@ void pxo_process_read(const pxg_config* cfg, const int16_t* raw, int64_t n_raw,
 void pxo_process_batch(const pxg_config* cfg, int64_t n_reads, const int16_t* raw_arena,
                        const int64_t* raw_offsets, const pxg_calib* calib,
                        const float* ss_inject, uint32_t stage_mask, pxg_read_result* out,
-                       pxg_polya_spike* spikes)
+                       pxg_polya_spike* spikes, int spike_cap)
 {
     for (int64_t i = 0; i < n_reads; i++)
         pxo_process_read(cfg, raw_arena + raw_offsets[i], raw_offsets[i + 1] - raw_offsets[i],
                          &calib[i], ss_inject ? ss_inject + 2 * i : NULL, stage_mask, &out[i],
-                         spikes ? spikes + (size_t)i * PXG_MAX_SPIKES : NULL);
+                         spikes ? spikes + (size_t)i * spike_cap : NULL, spike_cap);
 }

@@ -228,6 +228,7 @@ typedef struct {
     double sampling_rate;
     pxg_read_result* r;
     pxg_polya_spike* spikes;
+    int spike_cap;                 /* rows the caller gave `spikes`; every spike is COUNTED */
 } polya_ctx;
 
 typedef struct {
@@ -338,7 +339,7 @@ static void call_polya(polya_ctx* C, polya_win* W, int64_t sig_begin, int64_t si
             if (W->is_polya[k]) {
                 pl[np_++] = len[k];
             } else {
-                if (ns < PXG_MAX_SPIKES && C->spikes) {
+                if (ns < C->spike_cap && C->spikes) {
                     C->spikes[ns].v[0] = len[k];
                     C->spikes[ns].v[1] = k - 1 >= pi ? W->ev[k - 1].mean : NAN;
                     C->spikes[ns].v[2] = W->ev[k].mean;
@@ -353,7 +354,7 @@ static void call_polya(polya_ctx* C, polya_win* W, int64_t sig_begin, int64_t si
         r->polya_begin = pb + sig_begin;
         r->polya_end = pe + sig_begin;
         r->polya_dwell_samples = (int32_t)dwell;
-        r->polya_n_spikes = (int8_t)(ns > 127 ? 127 : ns);
+        r->polya_n_spikes = ns;            /* all of them (polya.py:109-115 lists every spike) */
         free(len);
         return;
     }
@@ -451,14 +452,14 @@ static void polya_entry(polya_ctx* C, int rough_begin, int rough_end, int has_en
 
 void pxo_polya(const pxg_config* cfg, const float* scaled_full, int64_t n_raw,
                int rough_begin, int rough_end_or_neg, double sampling_rate,
-               pxg_read_result* r, pxg_polya_spike* spikes)
+               pxg_read_result* r, pxg_polya_spike* spikes, int spike_cap)
 {
-    polya_ctx C = { cfg, scaled_full, n_raw, sampling_rate, r, spikes };
+    polya_ctx C = { cfg, scaled_full, n_raw, sampling_rate, r, spikes, spike_cap };
     r->polya_called = 0;
     r->polya_n_spikes = 0;
     r->polya_begin = r->polya_end = 0;
     r->polya_dwell_samples = 0;
-    if (spikes) memset(spikes, 0, sizeof(pxg_polya_spike) * PXG_MAX_SPIKES);
+    if (spikes) memset(spikes, 0, sizeof(pxg_polya_spike) * (size_t)(spike_cap > 0 ? spike_cap : 0));
     polya_entry(&C, rough_begin, rough_end_or_neg < 0 ? 0 : rough_end_or_neg,
                 rough_end_or_neg >= 0, 0, 0.0, 0.0, 0);
 }

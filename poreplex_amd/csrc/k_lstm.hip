@@ -1361,8 +1361,8 @@ int pxg_lstm_upload(pxg_ctx* ctx)
                     c.demux_dense.in_dim == 64 && c.demux_dense.out_dim <= PXG_MAX_CLASSES &&
                     (c.scaler_length / c.stride) % 4 == 0;
     if (!ok) {
-        ctx->err = "LSTM kernels are specialised for the MIN106-RNA001 model shapes "
-                   "(scaler 1-48-48-2, demux 1-2x48-64-5)";
+        pxg_set_err(ctx, "LSTM kernels are specialised for the MIN106-RNA001 model shapes "
+                   "(scaler 1-48-48-2, demux 1-2x48-64-5)");
         return PXG_E_UNSUPPORTED;
     }
     return PXG_OK;

@@ -25,6 +25,7 @@
 // by line and is bit-exact with it; the oracle is pinned by the real polya.py.
 #include <float.h>
 #include <algorithm>
+#include <string.h>
 #include "pxg_common.h"
 
 
@@ -124,6 +125,7 @@ __device__ __forceinline__ float filtered_at(const WindowSrc& S, int64_t j, int 
 #define PA_GL (64 / PXG_PA_LANES) // lanes per read
 #define PA_EVC 16                // event rows in the LDS chunk cache
 #define PA_XS 64                 // scaled-sample ring (needs filled-3 .. filled+2*PA_GL+3)
+#define PA_OVER_HEAD 4            // words in front of the read ids of the overflow list (polya_over)
 #define PA_PRE 128               // prefix-sum ring (needs i-31 .. i+31+16 around a 16-sample chunk)
 struct GroupLds {
     double2 pre[PA_PRE];         // pre[k & 127] = (sum, sum of squares) of filtered samples [0, k)
@@ -511,14 +513,25 @@ struct PolyaOut {
     int called, n_spikes, dwell;
     int64_t begin, end;
     int overflow;          // events the window needed when the scratch rows ran out (0 = fitted)
+    int spike_base;        // first row of this read's spikes in the batch's spike arena
+    int spill;             // the arena had no room left for them: the read is listed and re-run
+};
+
+// Spike rows of all reads share one arena; a called tail takes its rows with one atomic add
+// (every spike is kept: polya.py:109-115 lists them all -- no per-read limit).
+struct SpikeSink {
+    pxg_polya_spike* arena;    // null: count only
+    int cap;                   // rows in the arena
+    int32_t* cursor;           // rows handed out so far (may run past cap: that is the demand)
 };
 
 __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t n_full, double k,
                                double offset, float scale, float shift, int rough_begin,
                                int rough_end, int has_end0, GroupLds* L, int gl, int lane /* read slot of the wave */,
-                               Ev* ev, double2* snap_ring, PolyaOut& out, pxg_polya_spike* spikes)
+                               Ev* ev, double2* snap_ring, PolyaOut& out, SpikeSink sink)
 {
     out.called = 0; out.n_spikes = 0; out.dwell = 0; out.begin = 0; out.end = 0; out.overflow = 0;
+    out.spike_base = 0; out.spill = 0;
     const int stride = P.stride;
     const int min_unit = P.openend_expansion / stride;
     const double half = P.mean_scale * P.z_cutoff;
@@ -698,28 +711,35 @@ __device__ void polya_one_read(const PolyaParams& P, const int16_t* raw, int64_t
                     return ev_at(nth_matching(is_polya, pi, pj, (int)idx, pc)).length;
                 };
                 const float dwell = np_sum_f32(pl, np_, L, gl);
-                int ns = 0;
-                for (int q = pi; q <= pj; q++) {
+                // spikes = the events of the interval that are not poly(A): np_ of its events are
+                const int ns = (pj - pi + 1) - np_;
+                pxg_polya_spike* rows = nullptr;           // lane 0 of the group owns the stores
+                if (ns > 0 && sink.arena && gl == 0) {
+                    const int base = atomicAdd(sink.cursor, ns);
+                    out.spike_base = base;
+                    if ((int64_t)base + ns <= (int64_t)sink.cap) rows = sink.arena + base;
+                    else out.spill = 1;
+                }
+                int k = 0;
+                for (int q = pi; q <= pj && k < ns; q++) {
                     if (!is_polya(q)) {
-                        if (ns < PXG_MAX_SPIKES) {
-                            // the event fetches are group-uniform (all 16 lanes), the store is lane 0's
-                            const float s0 = ev_at(q).length;
-                            const float s1 = q - 1 >= pi ? ev_at(q - 1).mean : __builtin_nanf("");
-                            const float s2 = ev_at(q).mean;
-                            const float s3 = q + 1 <= pj ? ev_at(q + 1).mean : __builtin_nanf("");
-                            if (spikes) {
-                                spikes[ns].v[0] = s0; spikes[ns].v[1] = s1;
-                                spikes[ns].v[2] = s2; spikes[ns].v[3] = s3;
-                            }
+                        // the event fetches are group-uniform (all 16 lanes), the store is lane 0's
+                        const float s0 = ev_at(q).length;
+                        const float s1 = q - 1 >= pi ? ev_at(q - 1).mean : __builtin_nanf("");
+                        const float s2 = ev_at(q).mean;
+                        const float s3 = q + 1 <= pj ? ev_at(q + 1).mean : __builtin_nanf("");
+                        if (rows) {
+                            rows[k].v[0] = s0; rows[k].v[1] = s1;
+                            rows[k].v[2] = s2; rows[k].v[3] = s3;
                         }
-                        ns++;
+                        k++;
                     }
                 }
                 out.called = 1;
                 out.begin = (int64_t)e0.start + ib;
                 out.end = (int64_t)((double)e1.start + (double)e1.length) + ib;
                 out.dwell = (int)dwell;
-                out.n_spikes = ns > 127 ? 127 : ns;
+                out.n_spikes = ns;
                 state = DONE;
                 continue;
             }
@@ -775,9 +795,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PA_WAVES_PER
                                               const int32_t* __restrict__ segs, Ev* __restrict__ evbuf,
                                               double2* __restrict__ snapbuf,
                                               int32_t* __restrict__ pout /* n x 8 */,
-                                              pxg_polya_spike* __restrict__ spikes,
+                                              pxg_polya_spike* __restrict__ spikes, int spike_cap,
                                               const int32_t* __restrict__ subset /* read ids of a retry pass, or null */,
-                                              int32_t* __restrict__ over /* [0] count, [1] max events, [2..] read ids */)
+                                              int32_t* __restrict__ over /* [0] count, [1] max events, [2] spike rows handed out, [PA_OVER_HEAD..] read ids */)
 {
     __shared__ GroupLds lds[PXG_PA_LANES];
     const int grp = threadIdx.x / PA_GL, gl = threadIdx.x % PA_GL;     // read slot, lane inside it
@@ -787,7 +807,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PA_WAVES_PER
     int32_t* po = pout + r * 8;
     if (gl == 0)
         for (int q = 0; q < 8; q++) po[q] = 0;
-    pxg_polya_spike* sp = gl == 0 ? spikes + r * PXG_MAX_SPIKES : nullptr;
+    const SpikeSink sink = { spikes, spike_cap, over + 2 };
     if (status[r] != PXG_ST_OKAY) return;
     const int32_t* first = segs + r * 2 * PXG_N_SEGMENTS;
     const int32_t* last = first + PXG_N_SEGMENTS;
@@ -803,14 +823,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PA_WAVES_PER
     Ev* ev = evbuf + (size_t)blockIdx.x * P.ev_cap * PXG_PA_LANES;
     polya_one_read(P, raw + off[r], off[r + 1] - off[r], c.range / c.digitisation, c.offset,
                    ss[2 * r], ss[2 * r + 1], rb, re, has_end, &lds[grp], gl, grp, ev,
-                   snapbuf + ((size_t)blockIdx.x * PXG_PA_LANES + grp) * PA_PRE, out, sp);
+                   snapbuf + ((size_t)blockIdx.x * PXG_PA_LANES + grp) * PA_PRE, out, sink);
     if (gl != 0) return;
-    if (out.overflow) {
-        over[2 + atomicAdd(over, 1)] = (int32_t)r;
+    if (out.overflow || out.spill) {
+        over[PA_OVER_HEAD + atomicAdd(over, 1)] = (int32_t)r;
         atomicMax(over + 1, out.overflow);
     }
     po[0] = out.called;
     po[1] = out.n_spikes;
+    po[7] = out.spike_base;
     po[2] = out.dwell;
     po[3] = (int32_t)(out.begin & 0xFFFFFFFFll);
     po[4] = (int32_t)(out.begin >> 32);
@@ -867,25 +888,27 @@ int pxg_polya_supported(pxg_ctx* ctx)
     if ((c.polya_median_pre_filter != 7 && c.polya_median_pre_filter > 1) ||
         c.ed_window_length1 > 31 || c.ed_window_length2 > 31 || c.ed_window_length1 < 1 ||
         c.ed_window_length2 < 1) {
-        ctx->err = "poly(A) kernel supports median_pre_filter in {<=1, 7} and event windows <= 31";
+        pxg_set_err(ctx, "poly(A) kernel supports median_pre_filter in {<=1, 7} and event windows <= 31");
         return PXG_E_UNSUPPORTED;
     }
     return PXG_OK;
 }
 
 #define PA_EV_CAP 4096            // event rows per read of the first pass
+#define PA_SPIKES_PER_READ 2       // spike rows of the first pass, per read of the batch (the arena grows on demand)
 #define PA_RETRY_BYTES (1ll << 31) // event scratch of one retry launch
 
 static void launch_polya(pxg_ctx* ctx, int64_t n, int cap, const int32_t* subset, const int16_t* raw,
                          const int64_t* off, const pxg_calib* cal, const float* ss, const int32_t* status,
-                         const int32_t* segs, int32_t* pout, pxg_polya_spike* spikes)
+                         const int32_t* segs, int32_t* pout, DevBuf<pxg_polya_spike>& spikes)
 {
     const int64_t blocks = (n + PXG_PA_LANES - 1) / PXG_PA_LANES;
     const size_t ev_bytes = (size_t)blocks * cap * PXG_PA_LANES * sizeof(Ev);
     const PolyaParams P = make_params(ctx->cfg, cap, ctx->cfg.polya_median_pre_filter);
+    const int spike_cap = (int)std::min<size_t>(spikes.cap, 0x7fffffffu);
     hipLaunchKernelGGL(k_polya, dim3((unsigned)blocks), dim3(64), 0, ctx->stream, n, P, raw, off, cal,
                        ss, status, segs, (Ev*)ctx->polya_ev.p, (double2*)(ctx->polya_ev.p + ev_bytes),
-                       pout, spikes, subset, ctx->polya_over.p);
+                       pout, spikes.p, spike_cap, subset, ctx->polya_over.p);
 }
 
 static int reserve_polya(pxg_ctx* ctx, int64_t n, int cap)
@@ -896,58 +919,132 @@ static int reserve_polya(pxg_ctx* ctx, int64_t n, int cap)
     return pxg_reserve(ctx, ctx->polya_ev, ev_bytes + snap_bytes);
 }
 
+// grow an arena and keep what it holds (the spike rows of the reads that fitted)
+template <typename T>
+static int reserve_keep(pxg_ctx* ctx, DevBuf<T>& b, size_t n, size_t used)
+{
+    if (n <= b.cap && b.p) return PXG_OK;
+    DevBuf<T> bigger;
+    int rc = pxg_reserve(ctx, bigger, n);
+    if (rc) return rc;
+    if (b.p && used) {
+        hipError_t e = hipMemcpyAsync(bigger.p, b.p, std::min(used, b.cap) * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(bigger.p);
+            pxg_set_err(ctx, std::string("spike arena copy: ") + hipGetErrorString(e));
+            return PXG_E_HIP;
+        }
+    }
+    if (b.p) (void)hipFree(b.p);
+    b = bigger;
+    return PXG_OK;
+}
+
 int pxg_launch_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
                      const pxg_calib* cal, const float* ss, const int32_t* status,
-                     const int32_t* segs, int32_t* pout, pxg_polya_spike* spikes)
+                     const int32_t* segs, int32_t* pout, DevBuf<pxg_polya_spike>& spikes)
 {
     if (n <= 0) return PXG_OK;
     int rc = pxg_polya_supported(ctx);
     if (rc) return rc;
     if ((rc = reserve_polya(ctx, n, PA_EV_CAP))) return rc;
-    if ((rc = pxg_reserve(ctx, ctx->polya_over, (size_t)n + 2))) return rc;
-    PXG_HIP(ctx, hipMemsetAsync(ctx->polya_over.p, 0, 2 * sizeof(int32_t), ctx->stream));
+    if ((rc = pxg_reserve(ctx, ctx->polya_over, (size_t)n + PA_OVER_HEAD))) return rc;
+    if ((rc = pxg_reserve(ctx, spikes, (size_t)n * PA_SPIKES_PER_READ + 1024))) return rc;
+    PXG_HIP(ctx, hipMemsetAsync(ctx->polya_over.p, 0, PA_OVER_HEAD * sizeof(int32_t), ctx->stream));
     launch_polya(ctx, n, PA_EV_CAP, nullptr, raw, off, cal, ss, status, segs, pout, spikes);
     return PXG_OK;
 }
 
-// The first pass gives every read PA_EV_CAP event rows.  A window that needs more (tens of
-// thousands of samples of open-ended extension over a featureless signal) is listed by the
-// kernel and re-run here, alone, with as many rows as it asked for (doubled, so that a
-// further extension still fits; the loop ends at the latest when the rows cover a window of
-// the whole arena).  Synchronises the stream; *retried = reads that went through a retry.
-int pxg_polya_settle(pxg_ctx* ctx, int64_t n, int64_t n_samples, const int16_t* raw, const int64_t* off,
+// The first pass gives every read PA_EV_CAP event rows and the batch PA_SPIKES_PER_READ spike
+// rows per read.  A window that needs more event rows (tens of thousands of samples of
+// open-ended extension over a featureless signal), or a tail whose spikes found the arena full,
+// is listed by the kernel and re-run here with what it asked for: event rows doubled, so that a
+// further extension still fits (the loop ends at the latest when the rows cover the longest
+// read); the spike arena grown to twice the rows handed out so far, what it holds kept.
+// Synchronises the stream; *retried = reads that went through a retry; *spike_rows = rows
+// handed out (the arena's used prefix; the rows of re-run reads are simply left behind).
+int pxg_polya_settle(pxg_ctx* ctx, int64_t n, int64_t longest_read, const int16_t* raw, const int64_t* off,
                      const pxg_calib* cal, const float* ss, const int32_t* status, const int32_t* segs,
-                     int32_t* pout, pxg_polya_spike* spikes, int64_t* retried)
+                     int32_t* pout, DevBuf<pxg_polya_spike>& spikes, int64_t* retried, int64_t* spike_rows)
 {
     if (retried) *retried = 0;
+    if (spike_rows) *spike_rows = 0;
     if (n <= 0) return PXG_OK;
-    int cap = PA_EV_CAP;
+    int64_t cap = PA_EV_CAP;
     for (;;) {
-        int32_t head[2] = { 0, 0 };
+        int32_t head[PA_OVER_HEAD] = { 0, 0, 0, 0 };
         PXG_HIP(ctx, hipMemcpyAsync(head, ctx->polya_over.p, sizeof(head), hipMemcpyDeviceToHost, ctx->stream));
         PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         const int64_t m = head[0];
+        const int64_t handed_out = (int64_t)(uint32_t)head[2];
+        if (spike_rows) *spike_rows = handed_out;
         if (m <= 0) return PXG_OK;
-        if ((int64_t)cap > n_samples) {
-            ctx->err = "poly(A): event scratch overflow with rows for the whole arena";
-            return PXG_E_HIP;
-        }
         if (retried) *retried += m;
-        cap = (int)std::min<int64_t>(std::max<int64_t>(2 * (int64_t)head[1], 2 * (int64_t)cap), n_samples + 1);
+        if (head[1] > 0) {                      // somebody ran out of event rows
+            if (cap > longest_read) {
+                pxg_set_err(ctx, "poly(A): event scratch overflow with rows for the longest read of the batch");
+                return PXG_E_UNSUPPORTED;
+            }
+            cap = std::min<int64_t>(std::max<int64_t>(2 * (int64_t)head[1], 2 * cap), longest_read + 1);
+        }
+        if (handed_out >= (int64_t)0x3fffffff) {
+            pxg_set_err(ctx, "poly(A): more than 2^30 spike rows in one batch");
+            return PXG_E_UNSUPPORTED;
+        }
+        int rc;
+        if (handed_out > (int64_t)spikes.cap &&
+            (rc = reserve_keep(ctx, spikes, (size_t)(2 * handed_out + 1024), (size_t)handed_out)))
+            return rc;
         // the listed reads move to a list of their own: the kernel appends the next round's to polya_over
-        int rc = pxg_reserve(ctx, ctx->polya_retry, (size_t)m);
-        if (rc) return rc;
-        PXG_HIP(ctx, hipMemcpyAsync(ctx->polya_retry.p, ctx->polya_over.p + 2, (size_t)m * sizeof(int32_t),
+        if ((rc = pxg_reserve(ctx, ctx->polya_retry, (size_t)m))) return rc;
+        PXG_HIP(ctx, hipMemcpyAsync(ctx->polya_retry.p, ctx->polya_over.p + PA_OVER_HEAD, (size_t)m * sizeof(int32_t),
                                     hipMemcpyDeviceToDevice, ctx->stream));
-        PXG_HIP(ctx, hipMemsetAsync(ctx->polya_over.p, 0, 2 * sizeof(int32_t), ctx->stream));
+        PXG_HIP(ctx, hipMemsetAsync(ctx->polya_over.p, 0, 2 * sizeof(int32_t), ctx->stream));   // (the row cursor runs on)
         const int64_t per_launch = std::max<int64_t>(
-            PXG_PA_LANES, PA_RETRY_BYTES / ((int64_t)cap * (int64_t)sizeof(Ev)) / PXG_PA_LANES * PXG_PA_LANES);
-        if ((rc = reserve_polya(ctx, std::min(per_launch, m), cap))) return rc;
+            PXG_PA_LANES, PA_RETRY_BYTES / (cap * (int64_t)sizeof(Ev)) / PXG_PA_LANES * PXG_PA_LANES);
+        if ((rc = reserve_polya(ctx, std::min(per_launch, m), (int)cap))) return rc;
         for (int64_t at = 0; at < m; at += per_launch) {
             const int64_t k = std::min(per_launch, m - at);
-            launch_polya(ctx, k, cap, ctx->polya_retry.p + at, raw, off, cal, ss, status, segs, pout, spikes);
+            launch_polya(ctx, k, (int)cap, ctx->polya_retry.p + at, raw, off, cal, ss, status, segs, pout, spikes);
         }
     }
+}
+
+// Spike rows of a settled run in read order (CSR): offsets[r] .. offsets[r + 1] = rows of read r.
+// offsets is always filled; rows only if cap_rows holds them all (PXG_E_NOMEM otherwise).
+int pxg_polya_collect_spikes(pxg_ctx* ctx, int64_t n, const int32_t* pout, const DevBuf<pxg_polya_spike>& spikes,
+                             int64_t spike_rows, int64_t cap_rows, pxg_polya_spike* out, int64_t* offsets)
+{
+    if (n <= 0) { if (offsets) offsets[0] = 0; return PXG_OK; }
+    if (!offsets) { pxg_set_err(ctx, "spike offsets are required"); return PXG_E_INVALID; }
+    std::vector<int32_t> po((size_t)n * 8);
+    PXG_HIP(ctx, hipMemcpyAsync(po.data(), pout, po.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    offsets[0] = 0;
+    for (int64_t r = 0; r < n; r++)
+        offsets[r + 1] = offsets[r] + (po[(size_t)r * 8] ? (int64_t)po[(size_t)r * 8 + 1] : 0);
+    const int64_t total = offsets[n];
+    if (total > cap_rows || (total && !out)) {
+        pxg_set_err(ctx, "spike rows: the buffer is smaller than the sum of the records' polya_n_spikes");
+        return PXG_E_NOMEM;
+    }
+    if (!total) return PXG_OK;
+    const int64_t used = std::min<int64_t>(spike_rows, (int64_t)spikes.cap);
+    std::vector<pxg_polya_spike> arena((size_t)used);
+    PXG_HIP(ctx, hipMemcpyAsync(arena.data(), spikes.p, (size_t)used * sizeof(pxg_polya_spike), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t r = 0; r < n; r++) {
+        const int64_t ns = offsets[r + 1] - offsets[r], base = po[(size_t)r * 8 + 7];
+        if (!ns) continue;
+        if (base < 0 || base + ns > used) {
+            pxg_set_err(ctx, "spike rows: a read's rows lie outside the arena (unsettled run?)");
+            return PXG_E_STATE;
+        }
+        memcpy(out + offsets[r], arena.data() + base, (size_t)ns * sizeof(pxg_polya_spike));
+    }
+    return PXG_OK;
 }
 
 int pxg_launch_detect_events(pxg_ctx* ctx, int64_t n, const float* sig, const int64_t* off,

@@ -146,7 +146,7 @@ int pxg_launch_z_decode(pxg_ctx* ctx, hipStream_t stream, int64_t n_chunks, cons
 {
     if (n_chunks <= 0) return PXG_OK;
     if (n_chunks > 0x7fffffffLL) {
-        ctx->err = "pxg_batch_stage_z: too many chunks";
+        pxg_set_err(ctx, "pxg_batch_stage_z: too many chunks");
         return PXG_E_INVALID;
     }
     hipLaunchKernelGGL(k_z_decode, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, stream, n_chunks, z, z_bytes, chunks, data_base,
@@ -535,7 +535,7 @@ __global__ void k_finalize(int64_t n, FinalizeParams fp, const int64_t* __restri
     if ((fp.stage_mask & PXG_STAGE_POLYA) && polya && o.status == PXG_ST_OKAY) {
         const int32_t* po = polya + r * 8;
         o.polya_called = (int8_t)po[0];
-        o.polya_n_spikes = (int8_t)po[1];
+        o.polya_n_spikes = po[1];
         o.polya_dwell_samples = po[2];
         o.polya_begin = (int64_t)(((uint64_t)(uint32_t)po[4] << 32) | (uint32_t)po[3]);
         o.polya_end = (int64_t)(((uint64_t)(uint32_t)po[6] << 32) | (uint32_t)po[5]);

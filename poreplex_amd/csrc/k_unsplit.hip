@@ -18,8 +18,11 @@
 #define UN_READS 8
 #define UN_CHUNK 16
 #define UN_EM_STRIDE (UN_CHUNK * PXG_MAX_STATES + 8)
-#define UN_WCAND 16                        // candidate adapters kept per window (the preset's
-                                           // duration cut-offs allow at most 14 in an 8 s window)
+// Candidate adapters per window: NOT a constant.  The candidates of a window are disjoint
+// stretches of it, each at least min(loosen, strict)_full_length long and at least two blocks
+// (an adapter run and what separates it from the next), so a window of tmax blocks holds at most
+// pxg_unsplit_cand_slots() of them -- the slots are sized from the config and the batch's
+// sampling rates, like tmax itself, and a window can never overflow them (14 for the preset).
 
 // ---------------------------------------------------------------------------
 // a18: one thread per event block
@@ -105,7 +108,7 @@ int pxg_launch_guppy_event_means(pxg_ctx* ctx, int64_t n, const int16_t* raw, co
 {
     if (n <= 0) return PXG_OK;
     if (stride < 1 || stride > 16) {
-        ctx->err = "block_stride must be 1..16";
+        pxg_set_err(ctx, "block_stride must be 1..16");
         return PXG_E_UNSUPPORTED;
     }
     hipLaunchKernelGGL(k_guppy_event_means, dim3((unsigned)n, 16), dim3(256), 0, ctx->stream, n, raw, off,
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
     const int64_t* __restrict__ first_sample, const int64_t* __restrict__ ev_off,
     const int64_t* __restrict__ unit_off, const float* __restrict__ scaled,
     unsigned* __restrict__ bpbuf /* [wave][tmax][8 groups] */,
-    int64_t* __restrict__ cand /* n_units x UN_WCAND x 2 */, int32_t* __restrict__ cand_cnt,
+    int64_t* __restrict__ cand /* n_units x wcand x 2 */, int32_t* __restrict__ cand_cnt, int wcand,
     const double* __restrict__ lsetab_g, unsigned long long* __restrict__ queue)
 {
     __shared__ double em[UN_READS * UN_EM_STRIDE];
@@ -418,9 +421,9 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
             const int64_t adapter_duration = adapter_end - (g.first + (int64_t)P.stride * ev_first);
             const int strict = (leader_in_read - g.payload_start) <= g.strict_duration ? 1 : 0;
             if (total_duration >= g.cut_total[strict] && adapter_duration >= g.cut_adapter[strict]) {
-                if (s == 0 && count < UN_WCAND) {
-                    cand[(u * UN_WCAND + count) * 2] = leader_in_read;
-                    cand[(u * UN_WCAND + count) * 2 + 1] = 1 + adapter_end;
+                if (s == 0 && count < wcand) {
+                    cand[(u * wcand + count) * 2] = leader_in_read;
+                    cand[(u * wcand + count) * 2 + 1] = 1 + adapter_end;
                 }
                 count++;
             }
@@ -461,30 +464,25 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
         }
         if (phase == 1) finalize(a_first);
         else if (phase == 2) finalize(lead);
-        if (s == 0 && owned) cand_cnt[u] = too_long ? UN_WCAND + 1 : count;
+        if (s == 0 && owned) cand_cnt[u] = too_long ? 0 : (count < wcand ? count : wcand);
     }
 }
 
-// gather, pass 1: candidates per read (or PXG_UNSPLIT_E_WINDOW_CANDS for that read alone)
+// gather, pass 1: candidates per read
 __global__ void k_unsplit_count(int64_t n_reads, const int64_t* __restrict__ unit_off,
                                 const int32_t* __restrict__ cand_cnt, int32_t* __restrict__ out_cnt)
 {
     const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     int total = 0;
-    bool overflow = false;
-    for (int64_t u = unit_off[r]; u < unit_off[r + 1]; u++) {
-        const int c = cand_cnt[u];
-        if (c > UN_WCAND) overflow = true;
-        total += c < UN_WCAND ? c : UN_WCAND;
-    }
-    out_cnt[r] = overflow ? PXG_UNSPLIT_E_WINDOW_CANDS : total;
+    for (int64_t u = unit_off[r]; u < unit_off[r + 1]; u++) total += cand_cnt[u];
+    out_cnt[r] = total;
 }
 
 // gather, pass 2: the candidates of a read's windows in window order (the order the
 // reference appends them), all reads back to back; iv_off = exclusive scan of out_cnt
 __global__ void k_unsplit_gather(int64_t n_reads, const int64_t* __restrict__ unit_off,
-                                 const int64_t* __restrict__ cand, const int32_t* __restrict__ cand_cnt,
+                                 const int64_t* __restrict__ cand, const int32_t* __restrict__ cand_cnt, int wcand,
                                  const int32_t* __restrict__ out_cnt, const int64_t* __restrict__ iv_off,
                                  int64_t cap, int64_t* __restrict__ out_iv)
 {
@@ -492,11 +490,10 @@ __global__ void k_unsplit_gather(int64_t n_reads, const int64_t* __restrict__ un
     if (r >= n_reads || out_cnt[r] <= 0) return;
     int64_t at = iv_off[r];
     for (int64_t u = unit_off[r]; u < unit_off[r + 1]; u++) {
-        const int c = cand_cnt[u];
-        for (int q = (c < UN_WCAND ? c : UN_WCAND) - 1; q >= 0; q--, at++) {   // stored last-first
+        for (int q = cand_cnt[u] - 1; q >= 0; q--, at++) {   // stored last-first
             if (at < cap) {
-                out_iv[at * 2] = cand[(u * UN_WCAND + q) * 2];
-                out_iv[at * 2 + 1] = cand[(u * UN_WCAND + q) * 2 + 1];
+                out_iv[at * 2] = cand[(u * wcand + q) * 2];
+                out_iv[at * 2 + 1] = cand[(u * wcand + q) * 2 + 1];
             }
         }
     }
@@ -542,17 +539,27 @@ size_t pxg_unsplit_scratch_bytes(const pxg_ctx* ctx, int64_t units_bound, int tm
     return (size_t)pxg_unsplit_waves(ctx, units_bound) * (size_t)tmax * UN_READS * sizeof(unsigned);
 }
 
-size_t pxg_unsplit_cand_bytes(int64_t units_bound)
+// most candidates a window of tmax blocks can hold (see the top of the file)
+int pxg_unsplit_cand_slots(const pxg_ctx* ctx, int tmax, int stride)
 {
-    return (size_t)(units_bound > 0 ? units_bound : 1) * (UN_WCAND * 2 * sizeof(int64_t) + sizeof(int32_t));
+    const pxg_config& c = ctx->cfg;
+    const double shortest = std::min(c.unsplit_loosen_full_length, c.unsplit_strict_full_length);
+    const int64_t min_cut = (int64_t)(shortest * ctx->rate_min);           // samples, as the kernel cuts it
+    const int64_t span = (int64_t)tmax * stride + 1;
+    const int64_t by_blocks = (int64_t)tmax / 2 + 2;
+    const int64_t by_length = min_cut > 0 ? span / min_cut + 2 : by_blocks;
+    return (int)std::max<int64_t>(1, std::min(by_blocks, by_length));
 }
 
-int64_t pxg_unsplit_cand_slots(void) { return UN_WCAND; }
+size_t pxg_unsplit_cand_bytes(int64_t units_bound, int wcand)
+{
+    return (size_t)(units_bound > 0 ? units_bound : 1) * ((size_t)wcand * 2 * sizeof(int64_t) + sizeof(int32_t));
+}
 
 int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t units_bound, int tmax, const pxg_calib* cal,
                             const int32_t* status, const int32_t* segs, const int64_t* first_sample,
                             const int64_t* ev_off, const int64_t* unit_off, const float* scaled, int stride,
-                            void* scratch, void* candbuf, int32_t* out_cnt)
+                            void* scratch, void* candbuf, int wcand, int32_t* out_cnt)
 {
     if (n <= 0) return PXG_OK;
     const UnsplitParams P = unsplit_params(ctx, stride);
@@ -562,11 +569,11 @@ int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t units_bound, int tm
     (void)hipMemsetAsync(ctx->unsplit_q.p, 0, sizeof(unsigned long long), ctx->stream);
     unsigned* bp = (unsigned*)scratch;
     int64_t* cand = (int64_t*)candbuf;
-    int32_t* cand_cnt = (int32_t*)((char*)candbuf + (size_t)(units_bound > 0 ? units_bound : 1) * UN_WCAND * 2 * sizeof(int64_t));
+    int32_t* cand_cnt = (int32_t*)((char*)candbuf + (size_t)(units_bound > 0 ? units_bound : 1) * (size_t)wcand * 2 * sizeof(int64_t));
 #define SCAN(NIN)                                                                                      \
     hipLaunchKernelGGL(k_unsplit_scan<NIN>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, n,        \
                        tmax, ctx->hmm[1], P, cal, status, segs, first_sample, ev_off, unit_off,        \
-                       scaled, bp, cand, cand_cnt, ctx->d_lsetab, ctx->unsplit_q.p)
+                       scaled, bp, cand, cand_cnt, wcand, ctx->d_lsetab, ctx->unsplit_q.p)
     const int nin = ctx->hmm[1].max_in;
     if (nin <= 2) SCAN(2);
     else if (nin <= 3) SCAN(3);
@@ -579,13 +586,13 @@ int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t units_bound, int tm
 }
 
 int pxg_launch_unsplit_gather(pxg_ctx* ctx, int64_t n, int64_t units_bound, const int64_t* unit_off,
-                              const void* candbuf, const int32_t* out_cnt, const int64_t* iv_off,
+                              const void* candbuf, int wcand, const int32_t* out_cnt, const int64_t* iv_off,
                               int64_t cap, int64_t* out_iv)
 {
     if (n <= 0) return PXG_OK;
     const int64_t* cand = (const int64_t*)candbuf;
-    const int32_t* cand_cnt = (const int32_t*)((const char*)candbuf + (size_t)(units_bound > 0 ? units_bound : 1) * UN_WCAND * 2 * sizeof(int64_t));
+    const int32_t* cand_cnt = (const int32_t*)((const char*)candbuf + (size_t)(units_bound > 0 ? units_bound : 1) * (size_t)wcand * 2 * sizeof(int64_t));
     hipLaunchKernelGGL(k_unsplit_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
-                       unit_off, cand, cand_cnt, out_cnt, iv_off, cap, out_iv);
+                       unit_off, cand, cand_cnt, wcand, out_cnt, iv_off, cap, out_iv);
     return PXG_OK;
 }

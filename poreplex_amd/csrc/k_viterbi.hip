@@ -464,8 +464,8 @@ static int check_supported(pxg_ctx* ctx, int which)
 {
     const PxgHmmDev& H = ctx->hmm[which];
     if (!H.left_to_right) {
-        ctx->err = "Viterbi kernel: HMM is not left-to-right (models with back-edges run through "
-                   "the back-pointer scan of pxg_batch_unsplit_scan)";
+        pxg_set_err(ctx, "Viterbi kernel: HMM is not left-to-right (models with back-edges run through "
+                   "the back-pointer scan of pxg_batch_unsplit_scan)");
         return PXG_E_UNSUPPORTED;
     }
     return PXG_OK;

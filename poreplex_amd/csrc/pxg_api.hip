@@ -10,8 +10,8 @@ static std::string g_last_error;
 
 static int fail(pxg_ctx* ctx, int code, const std::string& msg)
 {
-    if (ctx) ctx->err = msg;
-    g_last_error = msg;
+    if (ctx) pxg_set_err(ctx, msg);
+    else g_last_error = msg;
     return code;
 }
 
@@ -167,7 +167,13 @@ extern "C" int pxg_abi_version(void) { return PXG_ABI_VERSION; }
 
 extern "C" const char* pxg_last_error(const pxg_ctx* ctx)
 {
-    return ctx ? ctx->err.c_str() : g_last_error.c_str();
+    if (!ctx) return g_last_error.c_str();
+    static thread_local std::string mine;       // a copy: another thread may fail while this one reads
+    {
+        std::lock_guard<std::mutex> g(const_cast<pxg_ctx*>(ctx)->mt_err);
+        mine = ctx->err;
+    }
+    return mine.c_str();
 }
 
 extern "C" int pxg_create(const pxg_config* cfg, pxg_ctx** out)
@@ -349,6 +355,13 @@ static int reserve_batch(pxg_ctx* ctx, int64_t n, int64_t n_samples)
 
 // sampling-rate range of a batch: sizes the window scratch of the chimera scan without a
 // device round trip (signal_analyzer.py:374-383: windows are int(seconds * rate) samples)
+static int64_t longest_of(const int64_t* off, int64_t n)
+{
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; i++) m = std::max(m, off[i + 1] - off[i]);
+    return m;
+}
+
 static void rate_range(const pxg_calib* calib, int64_t n, double& lo, double& hi)
 {
     lo = hi = n > 0 ? calib[0].sampling_rate : 0.0;
@@ -392,6 +405,7 @@ extern "C" int pxg_batch_upload(pxg_ctx* ctx, int64_t n_reads, const int16_t* ra
     PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host buffers may be reused on return
     ctx->n_reads = n_reads;
     ctx->n_samples = n_samples;
+    ctx->longest_read = longest_of(raw_offsets, n_reads);
     rate_range(calib, n_reads, ctx->rate_min, ctx->rate_max);
     return PXG_OK;
 }
@@ -451,6 +465,7 @@ extern "C" int pxg_batch_upload_tiled(pxg_ctx* ctx, int64_t n_reads, int64_t bas
     if (e != hipSuccess) return fail(ctx, PXG_E_HIP, std::string("pxg_batch_upload_tiled: ") + hipGetErrorString(e));
     ctx->n_reads = n_reads;
     ctx->n_samples = n_samples;
+    ctx->longest_read = longest_of(base_offsets, base_n);
     rate_range(base_calib, base_n, ctx->rate_min, ctx->rate_max);
     return PXG_OK;
 }
@@ -506,6 +521,7 @@ extern "C" int pxg_batch_stage(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw
     PXG_HIP(ctx, hipEventRecord(ctx->ev_staged, cs));
     sp.n_reads = n_reads;
     sp.n_samples = n_samples;
+    ctx->spare_longest_read = longest_of(raw_offsets, n_reads);
     rate_range(calib, n_reads, sp.rate_min, sp.rate_max);
     sp.staged = true;
     return PXG_OK;
@@ -560,6 +576,7 @@ extern "C" int pxg_batch_stage_z(pxg_ctx* ctx, int64_t n_reads, const uint8_t* z
     PXG_HIP(ctx, hipEventRecord(ctx->ev_staged, cs));
     sp.n_reads = n_reads;
     sp.n_samples = n_samples;
+    ctx->spare_longest_read = longest_of(raw_offsets, n_reads);
     rate_range(calib, n_reads, sp.rate_min, sp.rate_max);
     sp.staged = true;
     return PXG_OK;
@@ -585,6 +602,7 @@ extern "C" int pxg_batch_swap(pxg_ctx* ctx)
     if (rc) return rc;
     ctx->n_reads = sp.n_reads;
     ctx->n_samples = sp.n_samples;
+    ctx->longest_read = ctx->spare_longest_read;
     ctx->rate_min = sp.rate_min;
     ctx->rate_max = sp.rate_max;
     sp.staged = false;
@@ -667,11 +685,9 @@ extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
     ctx->polya_ran = false;
     if (stage_mask & PXG_STAGE_POLYA) {
         if ((rc = pxg_reserve(ctx, ctx->polya_out, (size_t)n * 8))) return rc;
-        if ((rc = pxg_reserve(ctx, ctx->spikes, (size_t)n * PXG_MAX_SPIKES))) return rc;
-        PXG_HIP(ctx, hipMemsetAsync(ctx->spikes.p, 0, (size_t)n * PXG_MAX_SPIKES * sizeof(pxg_polya_spike), ctx->stream));
         pxg_timer_begin(ctx, PXG_T_POLYA);
         if ((rc = pxg_launch_polya(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p,
-                                   ctx->status.p, ctx->segs.p, ctx->polya_out.p, ctx->spikes.p))) return rc;
+                                   ctx->status.p, ctx->segs.p, ctx->polya_out.p, ctx->spikes))) return rc;
         pxg_timer_end(ctx, PXG_T_POLYA);
         ctx->polya_ran = true;
     }
@@ -711,8 +727,9 @@ static int settle_polya(pxg_ctx* ctx)
     if (!ctx->polya_unsettled) return PXG_OK;
     ctx->polya_unsettled = false;
     int64_t retried = 0;
-    int rc = pxg_polya_settle(ctx, ctx->n_reads, ctx->n_samples, ctx->raw.p, ctx->offsets.p, ctx->calib.p,
-                              ctx->ss.p, ctx->status.p, ctx->segs.p, ctx->polya_out.p, ctx->spikes.p, &retried);
+    int rc = pxg_polya_settle(ctx, ctx->n_reads, ctx->longest_read, ctx->raw.p, ctx->offsets.p, ctx->calib.p,
+                              ctx->ss.p, ctx->status.p, ctx->segs.p, ctx->polya_out.p, ctx->spikes, &retried,
+                              &ctx->spike_rows);
     if (rc || !retried) return rc;
     return pxg_launch_finalize(ctx, ctx->n_reads, ctx->last_stage_mask);
 }
@@ -749,17 +766,16 @@ extern "C" int pxg_batch_download_samples(pxg_ctx* ctx, int16_t* out)
     return PXG_OK;
 }
 
-extern "C" int pxg_batch_download_spikes(pxg_ctx* ctx, pxg_polya_spike* out)
+extern "C" int pxg_batch_download_spikes(pxg_ctx* ctx, int64_t cap_rows, pxg_polya_spike* out, int64_t* offsets)
 {
-    if (!ctx || (!out && ctx->n_reads)) return PXG_E_INVALID;
-    if (ctx->n_reads <= 0) return PXG_OK;
+    if (!ctx || (!offsets && ctx->n_reads)) return PXG_E_INVALID;
+    if (ctx->n_reads <= 0) { if (offsets) offsets[0] = 0; return PXG_OK; }
     if (!ctx->polya_ran) return fail(ctx, PXG_E_STATE, "the last run had no poly(A) stage");
+    PXG_HIP(ctx, hipSetDevice(ctx->device));
     int rc = settle_polya(ctx);
     if (rc) return rc;
-    PXG_HIP(ctx, hipMemcpyAsync(out, ctx->spikes.p, (size_t)ctx->n_reads * PXG_MAX_SPIKES * sizeof(pxg_polya_spike),
-                                hipMemcpyDeviceToHost, ctx->stream));
-    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return PXG_OK;
+    return pxg_polya_collect_spikes(ctx, ctx->n_reads, ctx->polya_out.p, ctx->spikes, ctx->spike_rows, cap_rows,
+                                    out, offsets);
 }
 
 extern "C" int pxg_batch_times(pxg_ctx* ctx, pxg_stage_times* out)
@@ -778,17 +794,73 @@ extern "C" int pxg_batch_times(pxg_ctx* ctx, pxg_stage_times* out)
     return PXG_OK;
 }
 
+extern "C" int pxg_process_batch_ex(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
+                                    const int64_t* raw_offsets, const pxg_calib* calib, uint32_t stage_mask,
+                                    pxg_batch_extras* x, pxg_read_result* out);
+
 extern "C" int pxg_process_batch(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
                                  const int64_t* raw_offsets, const pxg_calib* calib,
                                  const float* scale_shift_or_null, uint32_t stage_mask,
                                  pxg_read_result* out)
 {
+    if (!scale_shift_or_null)
+        return pxg_process_batch_ex(ctx, n_reads, raw_arena, raw_offsets, calib, stage_mask, nullptr, out);
+    pxg_batch_extras x;
+    memset(&x, 0, sizeof(x));
+    x.struct_bytes = sizeof(x);
+    x.scale_shift_or_null = scale_shift_or_null;
+    return pxg_process_batch_ex(ctx, n_reads, raw_arena, raw_offsets, calib, stage_mask, &x, out);
+}
+
+extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample, const int64_t* n_blocks,
+                                      int32_t block_stride, int64_t cap_intervals, int64_t* out_intervals,
+                                      int32_t* out_count, int64_t* out_total);
+
+// One call per worker batch, from any number of host threads (include/pxg.h): the spare input
+// slot belongs to one call from its copy to its swap (mt_stage), the resident batch and every
+// per-batch intermediate from the swap to the last download (mt_run); always taken in this order.
+extern "C" int pxg_process_batch_ex(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
+                                    const int64_t* raw_offsets, const pxg_calib* calib, uint32_t stage_mask,
+                                    pxg_batch_extras* x, pxg_read_result* out)
+{
     if (!ctx) return PXG_E_INVALID;
-    if (n_reads == 0) return PXG_OK;
-    int rc = pxg_batch_upload(ctx, n_reads, raw_arena, raw_offsets, calib, scale_shift_or_null);
+    if (x && x->struct_bytes != sizeof(pxg_batch_extras))
+        return fail(ctx, PXG_E_INVALID, "pxg_batch_extras.struct_bytes does not match this library");
+    if (x) { x->unsplit_total = 0; x->spike_total = 0; }
+    if (n_reads == 0) {
+        if (x && x->spike_offsets) x->spike_offsets[0] = 0;
+        return PXG_OK;
+    }
+    if (!out) return fail(ctx, PXG_E_INVALID, "pxg_process_batch: out is null");
+    const float* inject = x ? x->scale_shift_or_null : nullptr;
+    int rc;
+    std::unique_lock<std::mutex> stage_lock(ctx->mt_stage);
+    if (x && x->z)
+        rc = pxg_batch_stage_z(ctx, n_reads, x->z, x->z_bytes, x->chunks, x->n_chunks, x->data_base, x->dst_base,
+                               raw_offsets, calib, inject);
+    else
+        rc = pxg_batch_stage(ctx, n_reads, raw_arena, raw_offsets, calib, inject);
+    if (rc) return rc;
+    std::unique_lock<std::mutex> run_lock(ctx->mt_run);      // the previous call has all its results
+    rc = pxg_batch_swap(ctx);
+    stage_lock.unlock();                                      // the next call may start its copy
     if (rc) return rc;
     if ((rc = pxg_batch_run(ctx, stage_mask))) return rc;
-    return pxg_batch_download(ctx, out);
+    int verdict = PXG_OK;
+    if (x && x->unsplit_first_sample) {
+        if ((rc = pxg_batch_unsplit_scan(ctx, x->unsplit_first_sample, x->unsplit_n_blocks, x->unsplit_block_stride,
+                                         x->unsplit_cap, x->unsplit_intervals, x->unsplit_count, &x->unsplit_total)))
+            return rc;
+        if (x->unsplit_total > x->unsplit_cap) verdict = PXG_E_NOMEM;
+    }
+    if ((rc = pxg_batch_download(ctx, out))) return rc;
+    if (x && x->spike_offsets && (stage_mask & PXG_STAGE_POLYA)) {
+        rc = pxg_batch_download_spikes(ctx, x->spike_cap, x->spikes, x->spike_offsets);
+        x->spike_total = x->spike_offsets[n_reads];
+        if (rc == PXG_E_NOMEM) verdict = PXG_E_NOMEM;
+        else if (rc) return rc;
+    }
+    return verdict;
 }
 
 // ---------------------------------------------------------------------------
@@ -1069,6 +1141,7 @@ extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
     if (step_min < 1 || win_max < 0 || win_max / block_stride + 2 > (1 << 22))
         return fail(ctx, PXG_E_INVALID, "unsplit_read_detection window_size / window_step out of range");
     const int tmax = (int)(win_max / block_stride + 2);
+    const int wcand = pxg_unsplit_cand_slots(ctx, tmax, block_stride);
     // per-read frames; a read with an impossible frame gets an empty one and its own error code
     std::vector<int64_t> eoff((size_t)n + 1, 0), first((size_t)n);
     std::vector<int64_t> bad;
@@ -1090,7 +1163,7 @@ extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
         (rc = pxg_reserve(ctx, ctx->unsplit_iv, (size_t)std::max<int64_t>(cap_intervals, 1) * 2)) ||
         (rc = pxg_reserve(ctx, ctx->unsplit_cnt, (size_t)n)) ||
         (rc = pxg_reserve(ctx, ctx->unsplit_scr, pxg_unsplit_scratch_bytes(ctx, units_bound, tmax))) ||
-        (rc = pxg_reserve(ctx, ctx->unsplit_cand, pxg_unsplit_cand_bytes(units_bound))))
+        (rc = pxg_reserve(ctx, ctx->unsplit_cand, pxg_unsplit_cand_bytes(units_bound, wcand))))
         return rc;
     int64_t* d_first = ctx->ev_first.p;
     int64_t* d_eoff = ctx->ev_off.p;
@@ -1109,9 +1182,9 @@ extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
         (rc = pxg_launch_exclusive_scan(ctx, n, ctx->n_win.p, ctx->unit_off.p)) ||
         (rc = pxg_launch_unsplit_scan(ctx, n, units_bound, tmax, ctx->calib.p, ctx->status.p, ctx->segs.p,
                                       d_first, d_eoff, ctx->unit_off.p, ctx->ev_scaled.p, block_stride,
-                                      ctx->unsplit_scr.p, ctx->unsplit_cand.p, ctx->unsplit_cnt.p)) ||
+                                      ctx->unsplit_scr.p, ctx->unsplit_cand.p, wcand, ctx->unsplit_cnt.p)) ||
         (rc = pxg_launch_exclusive_scan(ctx, n, ctx->unsplit_cnt.p, ctx->unsplit_ivoff.p)) ||
-        (rc = pxg_launch_unsplit_gather(ctx, n, units_bound, ctx->unit_off.p, ctx->unsplit_cand.p,
+        (rc = pxg_launch_unsplit_gather(ctx, n, units_bound, ctx->unit_off.p, ctx->unsplit_cand.p, wcand,
                                         ctx->unsplit_cnt.p, ctx->unsplit_ivoff.p, cap_intervals,
                                         ctx->unsplit_iv.p)))
         return rc;
@@ -1127,12 +1200,18 @@ extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
 
 extern "C" int pxg_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
                          const pxg_calib* calib, const float* scale_shift, const int32_t* seg_first,
-                         const int32_t* seg_last, pxg_read_result* out, pxg_polya_spike* spikes_or_null)
+                         const int32_t* seg_last, pxg_read_result* out, int64_t spike_cap,
+                         pxg_polya_spike* spikes_or_null, int64_t* spike_offsets_or_null)
 {
     HOOK_BEGIN
     if (n <= 0) return PXG_OK;
-    if (!off || !calib || !scale_shift || !seg_first || !seg_last || !out || (off[n] > 0 && !raw))
+    if (!off || !calib || !scale_shift || !seg_first || !seg_last || !out || (off[n] > 0 && !raw) ||
+        (spikes_or_null && !spike_offsets_or_null))
         return fail(ctx, PXG_E_INVALID, "pxg_polya: bad arguments");
+    // the hook shares the overflow list and the event scratch with the resident batch: a batch
+    // whose retries are still pending (run, not yet downloaded) is settled first
+    int rc = settle_polya(ctx);
+    if (rc) return rc;
     std::vector<int32_t> segs((size_t)n * 2 * PXG_N_SEGMENTS);
     for (int64_t i = 0; i < n; i++)
         for (int q = 0; q < PXG_N_SEGMENTS; q++) {
@@ -1146,17 +1225,19 @@ extern "C" int pxg_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int6
     int32_t* d_segs = S.put(segs.data(), segs.size(), ctx->stream);
     int32_t* d_status = S.alloc<int32_t>((size_t)n);
     int32_t* d_pout = S.alloc<int32_t>((size_t)n * 8);
-    pxg_polya_spike* d_spk = S.alloc<pxg_polya_spike>((size_t)n * PXG_MAX_SPIKES);
-    HOOK_CHECK(d_raw && d_off && d_cal && d_ss && d_segs && d_status && d_pout && d_spk);
+    HOOK_CHECK(d_raw && d_off && d_cal && d_ss && d_segs && d_status && d_pout);
+    struct Arena {                      // the hook's own spike arena, gone with the call
+        DevBuf<pxg_polya_spike> b;
+        ~Arena() { if (b.p) (void)hipFree(b.p); }
+    } arena;
     PXG_HIP(ctx, hipMemsetAsync(d_status, 0, (size_t)n * sizeof(int32_t), ctx->stream));
-    PXG_HIP(ctx, hipMemsetAsync(d_spk, 0, (size_t)n * PXG_MAX_SPIKES * sizeof(pxg_polya_spike), ctx->stream));
-    int rc = pxg_launch_polya(ctx, n, d_raw, d_off, d_cal, d_ss, d_status, d_segs, d_pout, d_spk);
-    if (rc) return rc;
-    if ((rc = pxg_polya_settle(ctx, n, off[n], d_raw, d_off, d_cal, d_ss, d_status, d_segs, d_pout, d_spk, nullptr)))
+    if ((rc = pxg_launch_polya(ctx, n, d_raw, d_off, d_cal, d_ss, d_status, d_segs, d_pout, arena.b))) return rc;
+    int64_t rows = 0;
+    if ((rc = pxg_polya_settle(ctx, n, longest_of(off, n), d_raw, d_off, d_cal, d_ss, d_status, d_segs, d_pout,
+                               arena.b, nullptr, &rows)))
         return rc;
     std::vector<int32_t> po((size_t)n * 8);
     HOOK_GET(po.data(), d_pout, po.size());
-    if (spikes_or_null) HOOK_GET(spikes_or_null, d_spk, (size_t)n * PXG_MAX_SPIKES);
     PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memset(out, 0, (size_t)n * sizeof(pxg_read_result));
     for (int64_t i = 0; i < n; i++) {
@@ -1172,10 +1253,13 @@ extern "C" int pxg_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int6
         o.shift = scale_shift[2 * i + 1];
         o.bc_label = -1;
         o.polya_called = (int8_t)q[0];
-        o.polya_n_spikes = (int8_t)q[1];
+        o.polya_n_spikes = q[1];
         o.polya_dwell_samples = q[2];
         o.polya_begin = (int64_t)(((uint64_t)(uint32_t)q[4] << 32) | (uint32_t)q[3]);
         o.polya_end = (int64_t)(((uint64_t)(uint32_t)q[6] << 32) | (uint32_t)q[5]);
     }
+    if (spike_offsets_or_null &&
+        (rc = pxg_polya_collect_spikes(ctx, n, d_pout, arena.b, rows, spike_cap, spikes_or_null, spike_offsets_or_null)))
+        return rc;
     HOOK_END
 }

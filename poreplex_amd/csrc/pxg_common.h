@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/pxg.h"
@@ -309,12 +310,16 @@ struct pxg_ctx {
     bool timeslice_used = false;
     DevBuf<pxg_read_result> results;
     DevBuf<char> polya_ev;       // event scratch, [wave][event][lane]
-    DevBuf<int32_t> polya_over;  // [0] reads whose window outgrew the scratch, [1] most events asked for, [2..] their ids
+    DevBuf<int32_t> polya_over;  // [0] reads to re-run, [1] most event rows asked for, [2] spike rows handed out, [4..] their ids
     DevBuf<int32_t> polya_retry; // the ids a retry launch works through
     bool polya_unsettled = false;   // K6 ran and its overflow list has not been looked at yet
     uint32_t last_stage_mask = 0;
-    DevBuf<int32_t> polya_out;   // n x 8: called, n_spikes, dwell, begin lo/hi, end lo/hi
-    DevBuf<pxg_polya_spike> spikes;   // n x PXG_MAX_SPIKES
+    DevBuf<int32_t> polya_out;   // n x 8: called, n_spikes, dwell, begin lo/hi, end lo/hi, first spike row
+    DevBuf<pxg_polya_spike> spikes;   // spike arena of the batch: rows handed out by K6 with one atomic per read
+    int64_t spike_rows = 0;      // rows handed out by the settled run
+    int64_t longest_read = 0, spare_longest_read = 0;   // samples of the longest read (host copy)
+    std::mutex mt_err;
+    std::mutex mt_stage, mt_run; // pxg_process_batch(_ex) from several host threads: spare slot / resident batch
     bool polya_ran = false;
     DevBuf<int64_t> ev_first, ev_off;   // K7: per-read first sample / event offsets
     DevBuf<float> ev_mean, ev_scaled;   // K7: Guppy block means
@@ -333,11 +338,19 @@ struct pxg_ctx {
     int64_t launches[PXG_N_TIMERS];
 };
 
+// the message of the last failure; written under a lock (pxg_process_batch may run on several
+// host threads of one context)
+static inline void pxg_set_err(pxg_ctx* ctx, std::string msg)
+{
+    std::lock_guard<std::mutex> g(ctx->mt_err);
+    ctx->err = std::move(msg);
+}
+
 #define PXG_HIP(ctx, call)                                                          \
     do {                                                                            \
         hipError_t e__ = (call);                                                    \
         if (e__ != hipSuccess) {                                                    \
-            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);        \
+            pxg_set_err((ctx), std::string(#call) + ": " + hipGetErrorString(e__)); \
             return PXG_E_HIP;                                                       \
         }                                                                           \
     } while (0)
@@ -352,7 +365,7 @@ static inline int pxg_reserve(pxg_ctx* ctx, DevBuf<T>& b, size_t n)
     size_t want = n + n / 8 + 64;
     hipError_t e = hipMalloc((void**)&b.p, want * sizeof(T));
     if (e != hipSuccess) {
-        ctx->err = std::string("hipMalloc: ") + hipGetErrorString(e);
+        pxg_set_err(ctx, std::string("hipMalloc: ") + hipGetErrorString(e));
         return PXG_E_NOMEM;
     }
     b.cap = want;
@@ -397,10 +410,12 @@ int pxg_lstm_upload(pxg_ctx* ctx);   // shape checks
 int pxg_polya_supported(pxg_ctx* ctx);
 int pxg_launch_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
                      const pxg_calib* cal, const float* ss, const int32_t* status,
-                     const int32_t* segs, int32_t* pout, pxg_polya_spike* spikes);
-int pxg_polya_settle(pxg_ctx* ctx, int64_t n, int64_t n_samples, const int16_t* raw, const int64_t* off,
+                     const int32_t* segs, int32_t* pout, DevBuf<pxg_polya_spike>& spikes);
+int pxg_polya_settle(pxg_ctx* ctx, int64_t n, int64_t longest_read, const int16_t* raw, const int64_t* off,
                      const pxg_calib* cal, const float* ss, const int32_t* status, const int32_t* segs,
-                     int32_t* pout, pxg_polya_spike* spikes, int64_t* retried);
+                     int32_t* pout, DevBuf<pxg_polya_spike>& spikes, int64_t* retried, int64_t* spike_rows);
+int pxg_polya_collect_spikes(pxg_ctx* ctx, int64_t n, const int32_t* pout, const DevBuf<pxg_polya_spike>& spikes,
+                             int64_t spike_rows, int64_t cap_rows, pxg_polya_spike* out, int64_t* offsets);
 int pxg_launch_detect_events(pxg_ctx* ctx, int64_t n, const float* sig, const int64_t* off,
                              int64_t cap, void* evbuf, int64_t* n_events);
 
@@ -417,13 +432,14 @@ int pxg_launch_unsplit_plan(pxg_ctx* ctx, int64_t n, const pxg_calib* cal, const
                             int stride, int32_t* n_win);
 int pxg_launch_exclusive_scan(pxg_ctx* ctx, int64_t n, const int32_t* in, int64_t* out /* n + 1 */);
 size_t pxg_unsplit_scratch_bytes(const pxg_ctx* ctx, int64_t units_bound, int tmax);
-size_t pxg_unsplit_cand_bytes(int64_t units_bound);
+int pxg_unsplit_cand_slots(const pxg_ctx* ctx, int tmax, int stride);
+size_t pxg_unsplit_cand_bytes(int64_t units_bound, int wcand);
 int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t units_bound, int tmax, const pxg_calib* cal,
                             const int32_t* status, const int32_t* segs, const int64_t* first_sample,
                             const int64_t* ev_off, const int64_t* unit_off, const float* scaled, int stride,
-                            void* scratch, void* candbuf, int32_t* out_cnt);
+                            void* scratch, void* candbuf, int wcand, int32_t* out_cnt);
 int pxg_launch_unsplit_gather(pxg_ctx* ctx, int64_t n, int64_t units_bound, const int64_t* unit_off,
-                              const void* candbuf, const int32_t* out_cnt, const int64_t* iv_off,
+                              const void* candbuf, int wcand, const int32_t* out_cnt, const int64_t* iv_off,
                               int64_t cap, int64_t* out_iv);
 
 void pxg_timer_begin(pxg_ctx* ctx, int t);

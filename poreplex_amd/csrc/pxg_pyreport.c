@@ -109,11 +109,11 @@ static PyObject* report(PyObject* self, PyObject* args)
     if (!PyArg_ParseTuple(args, "O!O", &PyDict_Type, &cols, &rows_obj)) return NULL;
     Buf rows, status, start_time, rate, duration, n_events, seq_len, qscore, has_summary, label, has_bc,
         barcode, guess, phred, seq_lazy, bundle_index, seq_arena, qual_arena, seq_off, polya_lazy, pa_begin,
-        pa_end, pa_dwell, pa_nspk, spikes, gpu_row;
+        pa_end, pa_dwell, pa_nspk, spikes, spike_off, gpu_row;
     Buf* all[] = { &rows, &status, &start_time, &rate, &duration, &n_events, &seq_len, &qscore, &has_summary,
                    &label, &has_bc, &barcode, &guess, &phred, &seq_lazy, &bundle_index, &seq_arena,
                    &qual_arena, &seq_off, &polya_lazy, &pa_begin, &pa_end, &pa_dwell, &pa_nspk, &spikes,
-                   &gpu_row };
+                   &spike_off, &gpu_row };
     for (size_t k = 0; k < sizeof(all) / sizeof(all[0]); k++) all[k]->held = 0;
     PyObject* out = NULL;
     rows.held = 0;
@@ -131,7 +131,8 @@ static PyObject* report(PyObject* self, PyObject* args)
         get_buf(cols, "qual_arena", &qual_arena, 1, 1) || get_buf(cols, "seq_offsets", &seq_off, 8, 1) ||
         get_buf(cols, "polya_lazy", &polya_lazy, 1, 0) || get_buf(cols, "polya_begin", &pa_begin, 8, 0) ||
         get_buf(cols, "polya_end", &pa_end, 8, 0) || get_buf(cols, "polya_dwell_time", &pa_dwell, 8, 0) ||
-        get_buf(cols, "polya_spike_count", &pa_nspk, 2, 0) || get_buf(cols, "spikes", &spikes, 4, 1) ||
+        get_buf(cols, "polya_spike_count", &pa_nspk, 4, 0) || get_buf(cols, "spikes", &spikes, 4, 1) ||
+        get_buf(cols, "spike_offsets", &spike_off, 8, 1) ||
         get_buf(cols, "gpu_row", &gpu_row, 8, 0))
         goto done;
     PyObject *filename = get_list(cols, "filename", 0), *read_id = get_list(cols, "read_id", 0),
@@ -148,8 +149,9 @@ static PyObject* report(PyObject* self, PyObject* args)
         const int64_t* R = (const int64_t*)rows.view.buf;
         const int8_t* st = (const int8_t*)status.view.buf;
         const Py_ssize_t n_seq_off = seq_off.held ? seq_off.view.len / 8 : 0;
-        const Py_ssize_t spike_cap = spikes.held && spikes.view.ndim == 3 ? spikes.view.shape[1] : 0;
-        const Py_ssize_t spike_rows = spikes.held && spikes.view.ndim == 3 ? spikes.view.shape[0] : 0;
+        /* spike rows of all GPU records back to back (CSR): rows of record g = [off[g], off[g + 1]) */
+        const Py_ssize_t spike_rows = spikes.held && spike_off.held ? spikes.view.len / 16 : 0;
+        const Py_ssize_t n_spike_off = spike_off.held ? spike_off.view.len / 8 : 0;
         out = PyList_New(n_rows);
         if (!out) goto done;
         for (Py_ssize_t k = 0; k < n_rows; k++) {
@@ -237,14 +239,20 @@ static PyObject* report(PyObject* self, PyObject* args)
                 Py_XDECREF(v);
                 bad |= !(v = PyFloat_FromDouble(((const double*)pa_dwell.view.buf)[i])) || PyDict_SetItem(p, KEYS[K_DWELL_TIME], v) < 0;
                 Py_XDECREF(v);
-                Py_ssize_t ns = ((const int16_t*)pa_nspk.view.buf)[i];
+                Py_ssize_t ns = ((const int32_t*)pa_nspk.view.buf)[i];
                 const int64_t g = ((const int64_t*)gpu_row.view.buf)[i];
-                if (!spikes.held || g < 0 || g >= spike_rows) ns = 0;
-                if (ns > spike_cap) ns = spike_cap;
-                PyObject* lst = PyList_New(ns > 0 ? ns : 0);
+                int64_t at = 0;
+                if (!spike_rows || g < 0 || g + 1 >= n_spike_off) ns = 0;
+                else at = ((const int64_t*)spike_off.view.buf)[g];
+                if (ns < 0 || at < 0 || at + ns > spike_rows) {
+                    PyErr_SetString(PyExc_IndexError, "report: spike rows outside the table");
+                    Py_DECREF(p);
+                    goto fail_row;
+                }
+                PyObject* lst = PyList_New(ns);
                 bad |= !lst;
                 for (Py_ssize_t s = 0; lst && s < ns; s++) {
-                    const float* row = (const float*)spikes.view.buf + ((size_t)g * spike_cap + s) * 4;
+                    const float* row = (const float*)spikes.view.buf + ((size_t)at + s) * 4;
                     PyObject* t = Py_BuildValue("(dddd)", (double)row[0], (double)row[1], (double)row[2], (double)row[3]);
                     if (!t) { bad = 1; break; }
                     PyList_SET_ITEM(lst, s, t);

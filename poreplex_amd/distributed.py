@@ -155,3 +155,16 @@ def reduce_counts(records, dist=None):
     t = torch.from_numpy(tbl).to(_device_for(dist))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()
+
+
+def agree_max(value, dist=None):
+    """max of one small integer over the ranks (value itself without a process group).  The
+    session driver uses it twice: the number of batch rounds every rank takes part in, and,
+    once per round, the abort flag -- 0, or 1 + the rank that failed -- so that ONE rank's
+    exception stops ALL ranks instead of leaving them waiting in the final collectives."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return int(value)
+    import torch
+    t = torch.tensor([int(value)], dtype=torch.int64, device=_device_for(dist))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())

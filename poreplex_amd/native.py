@@ -22,8 +22,6 @@ PXG_MAX_MIXTURE = 4
 PXG_N_SEGMENTS = 8
 PXG_MAX_CLASSES = 8
 PXG_MAX_CALIBRATION = 64
-PXG_MAX_SPIKES = 64
-UNSPLIT_E_WINDOW_CANDS = -2
 UNSPLIT_E_GEOMETRY = -3
 
 STATUS_NAMES = (
@@ -125,10 +123,23 @@ class PxgReadResult(C.Structure):
         ('bc_pushed', C.c_int8), ('bc_called', C.c_int8), ('bc_label', C.c_int8),
         ('bc_phred', C.c_uint8), ('bc_score', C.c_float),
         ('probs', C.c_float * PXG_MAX_CLASSES),
-        ('polya_called', C.c_int8), ('polya_n_spikes', C.c_int8), ('reserved', C.c_int16),
+        ('polya_called', C.c_int8), ('reserved8', C.c_int8), ('reserved16', C.c_int16),
+        ('polya_n_spikes', C.c_int32),
         ('polya_dwell_samples', C.c_int32),
         ('polya_begin', C.c_int64), ('polya_end', C.c_int64),
     ]
+
+
+class PxgBatchExtras(C.Structure):          # pxg_batch_extras (pxg_process_batch_ex)
+    _fields_ = [('struct_bytes', C.c_uint32), ('unsplit_block_stride', C.c_int32),
+                ('scale_shift_or_null', C.c_void_p),
+                ('z', C.c_void_p), ('z_bytes', C.c_int64), ('chunks', C.c_void_p), ('n_chunks', C.c_int64),
+                ('data_base', C.c_int64), ('dst_base', C.c_int64),
+                ('unsplit_first_sample', C.c_void_p), ('unsplit_n_blocks', C.c_void_p),
+                ('unsplit_cap', C.c_int64), ('unsplit_intervals', C.c_void_p),
+                ('unsplit_count', C.c_void_p), ('unsplit_total', C.c_int64),
+                ('spike_cap', C.c_int64), ('spikes', C.c_void_p), ('spike_offsets', C.c_void_p),
+                ('spike_total', C.c_int64)]
 
 
 class PxgEvent(C.Structure):
@@ -171,7 +182,7 @@ RESULT_DTYPE = np.dtype([
     ('scale', '<f4'), ('shift', '<f4'), ('scaler_pred', '<f4', (2,)),
     ('bc_pushed', 'i1'), ('bc_called', 'i1'), ('bc_label', 'i1'), ('bc_phred', 'u1'),
     ('bc_score', '<f4'), ('probs', '<f4', (PXG_MAX_CLASSES,)),
-    ('polya_called', 'i1'), ('polya_n_spikes', 'i1'), ('reserved', '<i2'),
+    ('polya_called', 'i1'), ('reserved8', 'i1'), ('reserved16', '<i2'), ('polya_n_spikes', '<i4'),
     ('polya_dwell_samples', '<i4'), ('polya_begin', '<i8'), ('polya_end', '<i8'),
 ], align=True)
 CALIB_DTYPE = np.dtype([('range', '<f8'), ('digitisation', '<f8'),
@@ -369,7 +380,9 @@ _SIGNATURES = {
     'pxg_batch_run': (C.c_int, [C.c_void_p, C.c_uint32]),
     'pxg_batch_sync': (C.c_int, [C.c_void_p]),
     'pxg_batch_download': (C.c_int, [C.c_void_p, C.c_void_p]),
-    'pxg_batch_download_spikes': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'pxg_batch_download_spikes': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'pxg_process_batch_ex': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                       C.POINTER(PxgBatchExtras), C.c_void_p]),
     'pxg_batch_times': (C.c_int, [C.c_void_p, C.POINTER(PxgStageTimes)]),
     'pxg_raw_to_pa': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pxg_head_pool': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -390,7 +403,7 @@ _SIGNATURES = {
     'pxg_batch_unsplit_scan': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     'pxg_polya': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'pxg_detect_events': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_int64, C.c_void_p, C.c_void_p]),
 }
@@ -751,11 +764,98 @@ class NativeContext:
         self._check(self.lib.pxg_batch_download(self.handle, _ptr(out)), 'pxg_batch_download')
         return out[:self.n_resident]
 
-    def download_spikes(self):
-        out = np.zeros((self.n_resident, PXG_MAX_SPIKES, 4), dtype=np.float32)
-        self._check(self.lib.pxg_batch_download_spikes(self.handle, _ptr(out)),
-                    'pxg_batch_download_spikes')
-        return out
+    def download_spikes(self, records=None):
+        """Spike rows of the last run as (rows [total, 4] float32, offsets [n + 1] int64):
+        rows[offsets[r]:offsets[r + 1]] are read r's spikes -- all of them (polya.py:109-115)."""
+        n = self.n_resident
+        off = np.zeros(n + 1, dtype=np.int64)
+        total = 0
+        if records is not None and len(records) == n:      # the records say how many rows there are
+            total = int(np.where(records['polya_called'] != 0, records['polya_n_spikes'], 0).sum())
+        while True:
+            rows = np.zeros((total, 4), dtype=np.float32)
+            rc = self.lib.pxg_batch_download_spikes(self.handle, total, _ptr(rows), _ptr(off))
+            if rc == PXG_E_NOMEM and int(off[-1]) > total:
+                total = int(off[-1])
+                continue
+            self._check(rc, 'pxg_batch_download_spikes')
+            return rows, off
+
+    def process_batch_ex(self, samples, offsets, calib, stage_mask=STAGE_ALL_DEMUX, scale_shift=None,
+                         unsplit=None, want_spikes=False):
+        """pxg_process_batch_ex: ONE call per worker batch, callable from several threads at once
+        (calls overlap on the device; the GIL is released for the whole call).  `samples`: an
+        int16 arena or EncodedSamples.  `unsplit`: (first_sample, n_blocks, block_stride) to run
+        the a19 window scan on the same resident batch.  Returns a dict: records, and when asked
+        spikes = (rows, offsets), unsplit = (intervals, count, start)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        calib = np.ascontiguousarray(calib, dtype=CALIB_DTYPE)
+        n = len(offsets) - 1
+        if len(calib) != n:
+            raise ValueError('calib must have one row per read')
+        x = PxgBatchExtras()
+        x.struct_bytes = C.sizeof(PxgBatchExtras)
+        keep = [offsets, calib]
+        if scale_shift is not None:
+            scale_shift = np.ascontiguousarray(scale_shift, dtype=np.float32).reshape(n, 2)
+            x.scale_shift_or_null = scale_shift.ctypes.data
+            keep.append(scale_shift)
+        arena = None
+        if isinstance(samples, EncodedSamples):
+            if int(offsets[-1]) != samples.n_samples:
+                raise ValueError('offsets describe {} samples, the encoded slice {}'.format(
+                    int(offsets[-1]), samples.n_samples))
+            z = np.ascontiguousarray(samples.z, dtype=np.uint8)
+            chunks = np.ascontiguousarray(samples.chunks, dtype=Z_CHUNK_DTYPE)
+            keep += [z, chunks]
+            x.z, x.z_bytes = z.ctypes.data if len(z) else None, len(z)
+            x.chunks, x.n_chunks = chunks.ctypes.data if len(chunks) else None, len(chunks)
+            x.data_base, x.dst_base = samples.data_base, samples.dst_base
+            if not len(z):                                 # nothing encoded: an empty int16 arena
+                arena = np.zeros(0, dtype=np.int16)
+        else:
+            arena = np.ascontiguousarray(samples, dtype=np.int16)
+        out = np.zeros(n, dtype=RESULT_DTYPE)
+        cnt = iv = None
+        if unsplit is not None:
+            first = np.ascontiguousarray(unsplit[0], dtype=np.int64)
+            nb = np.ascontiguousarray(unsplit[1], dtype=np.int64)
+            if len(first) != n or len(nb) != n:
+                raise ValueError('one first_sample / n_blocks entry per read')
+            keep += [first, nb]
+            cnt = np.zeros(n, dtype=np.int32)
+            x.unsplit_first_sample, x.unsplit_n_blocks = first.ctypes.data, nb.ctypes.data
+            x.unsplit_block_stride = int(unsplit[2])
+            x.unsplit_count = cnt.ctypes.data
+        iv_cap = max(getattr(self, '_unsplit_cap', 0), n // 4 + 1024) if unsplit is not None else 0
+        spike_cap = max(getattr(self, '_spike_cap', 0), 2 * n + 1024) if want_spikes else 0
+        spike_off = np.zeros(n + 1, dtype=np.int64) if want_spikes else None
+        while True:
+            if unsplit is not None:
+                iv = np.empty((iv_cap, 2), dtype=np.int64)
+                x.unsplit_cap, x.unsplit_intervals = iv_cap, iv.ctypes.data
+            rows = None
+            if want_spikes:
+                rows = np.zeros((spike_cap, 4), dtype=np.float32)
+                x.spike_cap, x.spikes, x.spike_offsets = spike_cap, rows.ctypes.data, spike_off.ctypes.data
+            rc = self.lib.pxg_process_batch_ex(self.handle, n, _ptr(arena), _ptr(offsets), _ptr(calib),
+                                               stage_mask, C.byref(x), _ptr(out))
+            if rc == PXG_E_NOMEM and (x.unsplit_total > iv_cap or x.spike_total > spike_cap):
+                # rare: a variable-size output outgrew the guess; the batch goes through again
+                iv_cap = max(iv_cap, int(x.unsplit_total) + 1024) if unsplit is not None else 0
+                spike_cap = max(spike_cap, int(x.spike_total) + 1024) if want_spikes else 0
+                continue
+            self._check(rc, 'pxg_process_batch_ex')
+            break
+        self._unsplit_cap, self._spike_cap = iv_cap, spike_cap
+        res = {'records': out}
+        if want_spikes:
+            res['spikes'] = (rows[:int(x.spike_total)], spike_off)
+        if unsplit is not None:
+            start = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(np.maximum(cnt, 0), out=start[1:])
+            res['unsplit'] = (iv[:int(x.unsplit_total)], cnt, start)
+        return res
 
     def stage_times(self):
         t = PxgStageTimes()
@@ -896,11 +996,18 @@ class NativeContext:
         sf = np.ascontiguousarray(seg_first, dtype=np.int32).reshape(n, PXG_N_SEGMENTS)
         sl = np.ascontiguousarray(seg_last, dtype=np.int32).reshape(n, PXG_N_SEGMENTS)
         out = np.zeros(n, dtype=RESULT_DTYPE)
-        spikes = np.zeros((n, PXG_MAX_SPIKES, 4), dtype=np.float32) if want_spikes else None
-        self._check(self.lib.pxg_polya(self.handle, n, _ptr(arena), _ptr(offsets), _ptr(calib),
-                                       _ptr(scale_shift), _ptr(sf), _ptr(sl), _ptr(out),
-                                       _ptr(spikes)), 'pxg_polya')
-        return out, spikes
+        off = np.zeros(n + 1, dtype=np.int64) if want_spikes else None
+        cap = 2 * n + 64
+        while True:
+            rows = np.zeros((cap, 4), dtype=np.float32) if want_spikes else None
+            rc = self.lib.pxg_polya(self.handle, n, _ptr(arena), _ptr(offsets), _ptr(calib),
+                                    _ptr(scale_shift), _ptr(sf), _ptr(sl), _ptr(out), cap, _ptr(rows), _ptr(off))
+            if rc == PXG_E_NOMEM and want_spikes and int(off[-1]) > cap:
+                cap = int(off[-1])
+                continue
+            self._check(rc, 'pxg_polya')
+            break
+        return out, ((rows[:int(off[-1])], off) if want_spikes else None)
 
     def detect_events(self, signals, max_events=None):
         sigs = [np.ascontiguousarray(s, dtype=np.float32) for s in signals]

@@ -21,36 +21,23 @@ class PolyASignalAnalyzer:
     def assign(self, table, rows, records):
         """set_polya_tail for many reads at once, as columns: begin / end / dwell time / spike
         count of every called tail go into the table, and the dict of polya.py:116-121 is built
-        from them (and the spike rows) when somebody asks for it (ReadTable.polya_of).  Returns
-        the positions whose tail cannot be reported faithfully (more spike events than the GPU
-        keeps): the caller runs those through __call__, which raises per read."""
+        from them (and the spike rows: all of them, the GPU keeps every spike) when somebody asks
+        for it (ReadTable.polya_of).  Returns the positions that need the per-read path: none."""
         called = np.nonzero(records['polya_called'])[0]
-        n_spikes = records['polya_n_spikes'][called].astype(np.int64)
-        if table.spikes is not None:
-            fits = n_spikes <= table.spikes.shape[1]
-            odd, called, n_spikes = called[~fits].tolist(), called[fits], n_spikes[fits]
-        else:
-            odd = []
         at = rows[called]
         table.polya_begin[at] = records['polya_begin'][called]
         table.polya_end[at] = records['polya_end'][called]
         table.polya_dwell_time[at] = records['polya_dwell_samples'][called] / table.sampling_rate[at]
-        table.polya_spike_count[at] = n_spikes
+        table.polya_spike_count[at] = records['polya_n_spikes'][called] if table.spikes is not None else 0
         table.polya_lazy[at] = True
-        return odd
+        return []
 
     def __call__(self, npread, rough_range=None, stride=None):
         rec = npread.native
         if rec is None or not rec['polya_called']:
             return
-        n_spikes = int(rec['polya_n_spikes'])
         rows = npread.native_spikes
-        if rows is None:
-            n_spikes = 0
-        elif n_spikes > len(rows):
-            # the GPU keeps PXG_MAX_SPIKES rows per read; the reference lists every spike,
-            # so a longer list cannot be reported faithfully: fail this read, loudly
-            raise Exception('poly(A) tail with more than {} spike events'.format(len(rows)))
+        n_spikes = 0 if rows is None else int(rec['polya_n_spikes'])
         npread.set_polya_tail({
             'begin': int(rec['polya_begin']),
             'end': int(rec['polya_end']),

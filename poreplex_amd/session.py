@@ -37,7 +37,11 @@ from . import sinks
 from .signal_analyzer import SignalAnalyzer
 from .signal_loader import ReadTable, summary_columns
 
-__all__ = ['GpuSession', 'enumerate_reads']
+__all__ = ['GpuSession', 'SessionAborted', 'enumerate_reads']
+
+
+class SessionAborted(RuntimeError):
+    """Another rank failed: this rank stopped with it (pipeline.py:207-213 semantics)."""
 
 
 def enumerate_reads(config, bundle=None):
@@ -103,10 +107,12 @@ class GpuSession:
                        'collect_s': 0.0, 'swap_run_s': 0.0, 'take_s': 0.0, 'stage_s': 0.0}
 
     # ---- loader thread: batch k+1 is opened and packed while batch k computes ---------
-    def _produce(self, batches, slots, out):
+    def _produce(self, batches, slots, out, stop):
         try:
             for k, reads in enumerate(batches):
                 staging = slots.get()                 # a staging arena nobody is copying from
+                if stop.is_set() or staging is None:  # the session is being torn down
+                    return
                 t0 = time.perf_counter()
                 batch = self.analyzer.prepare(reads, ReadTable())
                 need = int(batch.table.n_raw[np.asarray(batch.entered, dtype=np.int64)].sum()) if batch.entered else 0
@@ -121,7 +127,14 @@ class GpuSession:
         """Process this rank's share of `reads` (default: everything enumerate_reads finds).
         `presharded_at`: `reads` is already this rank's block of the run and starts at that
         global read index (each rank opened its own input shard).  Returns the run summary
-        dict on every rank; files are complete when it returns."""
+        dict on every rank; files are complete when it returns.
+
+        Failure path (pipeline.py:207-213,250-265: a failed batch or an early stop ends the
+        WHOLE run with one logged message): whatever goes wrong on this rank -- a loader
+        exception, a PxgError, the early stop -- the loader thread is drained and joined, the
+        staging arenas unpinned, the part files closed; with several ranks the abort flag is
+        agreed on once per batch round, so every rank leaves the loop in the same round and
+        raises SessionAborted instead of hanging in the final collectives."""
         cfg = self.config
         if reads is None:
             reads, lengths = enumerate_reads(cfg, self.loader.bundle)
@@ -149,16 +162,12 @@ class GpuSession:
                                                 header=self.rank == 0)
         fastq = sinks.FASTQWriter(outdir, layout, suffix=part) if cfg.get('fastq_output') else None
 
-        self.loader.pin_bundle()      # batches of consecutive bundle reads are staged in place
-        slots, ready = queue.Queue(), queue.Queue(maxsize=2)
+        slots, ready, stop = queue.Queue(), queue.Queue(maxsize=2), threading.Event()
         stagings = [_Staging(self.ctx), _Staging(self.ctx)]
-        for s in stagings:
-            slots.put(s)
-        thread = threading.Thread(target=self._produce, args=(batches, slots, ready), daemon=True)
-        thread.start()
-
+        thread = None
         records, status_seen = [], {}
         t_start = time.perf_counter()
+        state = {'done': 0}
 
         def take():
             item = ready.get()
@@ -177,41 +186,9 @@ class GpuSession:
                 return True
             return False
 
-        # pipeline: [k computes] [k+1 is copied under it] [k-1 is judged and written on the host].
-        # The copy of k+1 is enqueued the moment the spare slot is free -- right after k became
-        # resident -- so it runs under BOTH the kernels of k and the host work of k-1.
-        current = take()
-        nxt, nxt_staged = None, False
-        if current is not None:
-            if stage(current):
-                self.ctx.swap()
-                self.ctx.run(self.loader.stage_mask)      # asynchronous: kernels are enqueued
-            slots.put(current[1])
-            nxt = take()
-            nxt_staged = stage(nxt)
-        done = 0
-        while current is not None:
-            batch, staging, rows, arena, offsets, calib = current
-            t0 = time.perf_counter()
-            self.loader.collect_resident(batch.table, rows, offsets)   # D2H of the records: waits for run k
-            t1 = time.perf_counter()
-            self.timing['collect_s'] += t1 - t0
-            after = None
-            if nxt is not None:
-                if nxt_staged:
-                    self.ctx.swap()                       # k+1 resident (waits for its copy) ...
-                    self.ctx.run(self.loader.stage_mask)  # ... and computing while k is written out
-                t2 = time.perf_counter()
-                self.timing['swap_run_s'] += t2 - t1
-                slots.put(nxt[1])
-                after = take()                            # k+2, packed by the loader thread meanwhile
-                t3 = time.perf_counter()
-                self.timing['take_s'] += t3 - t2
-                after_staged = stage(after)               # its copy starts now, under run k+1
-                self.timing['stage_s'] += time.perf_counter() - t3
-            self.timing['gpu_wait_s'] += time.perf_counter() - t0
-
-            # ---- host side of batch k, under the kernels of k+1 ------------------------------
+        def host_side(current):
+            """Status rules, sinks and label records of one batch (under the next one's kernels)."""
+            batch = current[0]
             t0 = time.perf_counter()
             table = batch.table
             self.analyzer.settle(batch)
@@ -236,19 +213,93 @@ class GpuSession:
             if fastq is not None:
                 fastq.write_sequences(results)
             records.append(D.final_label_records_from_table(table, rows_in, positions, loose,
-                                                            first_index=lo + done))
-            done += len(rows_in) + len(loose)
+                                                            first_index=lo + state['done']))
+            state['done'] += len(rows_in) + len(loose)
             self.timing['sink_s'] += time.perf_counter() - t0
             self._check_early_stop(status_seen)
-            current = nxt
-            if nxt is not None:
-                nxt, nxt_staged = after, (after_staged if after is not None else False)
-        thread.join()
-        for s in stagings:
-            s.release()
-        summary.close()
-        if fastq is not None:
-            fastq.close()
+
+        failure = None
+        try:
+            self.loader.pin_bundle()      # batches of consecutive bundle reads are staged in place
+            for s_ in stagings:
+                slots.put(s_)
+            # every rank takes part in the same number of rounds (one abort agreement per round)
+            n_rounds = D.agree_max(len(batches), self.dist)
+            thread = threading.Thread(target=self._produce, args=(batches, slots, ready, stop), daemon=True)
+            thread.start()
+
+            # pipeline: [k computes] [k+1 is copied under it] [k-1 is judged and written on the host].
+            # The copy of k+1 is enqueued the moment the spare slot is free -- right after k became
+            # resident -- so it runs under BOTH the kernels of k and the host work of k-1.
+            current, nxt, nxt_staged, after, after_staged = None, None, False, None, False
+            for rnd in range(max(n_rounds, 1)):
+                try:
+                    if failure is None and rnd == 0:
+                        current = take()
+                        if current is not None:
+                            if stage(current):
+                                self.ctx.swap()
+                                self.ctx.run(self.loader.stage_mask)      # asynchronous: kernels are enqueued
+                            slots.put(current[1])
+                            nxt = take()
+                            nxt_staged = stage(nxt)
+                    if failure is None and current is not None:
+                        t0 = time.perf_counter()
+                        self.loader.collect_resident(current[0].table, current[2], current[4])   # D2H of the records: waits for run k
+                        t1 = time.perf_counter()
+                        self.timing['collect_s'] += t1 - t0
+                        after, after_staged = None, False
+                        if nxt is not None:
+                            if nxt_staged:
+                                self.ctx.swap()                       # k+1 resident (waits for its copy) ...
+                                self.ctx.run(self.loader.stage_mask)  # ... and computing while k is written out
+                            t2 = time.perf_counter()
+                            self.timing['swap_run_s'] += t2 - t1
+                            slots.put(nxt[1])
+                            after = take()                            # k+2, packed by the loader thread meanwhile
+                            t3 = time.perf_counter()
+                            self.timing['take_s'] += t3 - t2
+                            after_staged = stage(after)               # its copy starts now, under run k+1
+                            self.timing['stage_s'] += time.perf_counter() - t3
+                        self.timing['gpu_wait_s'] += time.perf_counter() - t0
+                        host_side(current)                            # under the kernels of k+1
+                        current, nxt, nxt_staged = nxt, after, after_staged
+                except Exception as exc:      # noqa: BLE001 -- agreed on below, raised after the cleanup
+                    failure = exc
+                flag = D.agree_max(0 if failure is None else 1 + self.rank, self.dist)
+                if flag:
+                    if failure is None:
+                        failure = SessionAborted('rank {} stopped the run (see its log)'.format(flag - 1))
+                    break
+        except BaseException as exc:          # KeyboardInterrupt and friends: clean up, do not agree
+            failure = exc
+        finally:
+            # drain and join the loader thread: it may sit in slots.get() or ready.put()
+            stop.set()
+            if thread is not None:
+                while thread.is_alive():
+                    slots.put(None)
+                    try:
+                        while True:
+                            ready.get_nowait()
+                    except queue.Empty:
+                        pass
+                    thread.join(timeout=0.05)
+            try:
+                self.ctx.sync()               # nothing may still read a staging arena
+            except Exception:                 # noqa: BLE001 -- the original failure is the one to report
+                pass
+            for s_ in stagings:
+                try:
+                    s_.release()
+                except Exception:             # noqa: BLE001
+                    pass
+            summary.close()
+            if fastq is not None:
+                fastq.close()
+        if failure is not None:
+            self.logger.error('Stopping the run: %s', failure)
+            raise failure
         wall = time.perf_counter() - t_start
 
         local = np.concatenate(records) if records else np.zeros(0, dtype=D.LABEL_DTYPE)

@@ -56,7 +56,7 @@ class ReadTable:
                ('unsplit_count', np.int32),
                # poly(A) tail as the GPU record has it; the dict of polya.py:116-121 is built on demand
                ('polya_lazy', np.bool_), ('polya_begin', np.int64), ('polya_end', np.int64),
-               ('polya_dwell_time', np.float64), ('polya_spike_count', np.int16))
+               ('polya_dwell_time', np.float64), ('polya_spike_count', np.int32))
 
     def __init__(self):
         self.n = 0
@@ -74,7 +74,8 @@ class ReadTable:
         # attached by the GPU pass
         self.gpu_row = np.zeros(0, dtype=np.int64)      # row -> index in `records`, -1 if not run
         self.records = None
-        self.spikes = None
+        self.spikes = None            # poly(A) spike rows of the GPU pass [total, 4] ...
+        self.spike_offsets = None     # ... rows of GPU record g: spikes[spike_offsets[g]:spike_offsets[g + 1]]
         self._opened = False          # some row holds its own samples / an open file
 
     def append(self, filename, read_id, source):
@@ -143,7 +144,8 @@ class ReadTable:
             ns = int(self.polya_spike_count[i])
             spikes = []
             if ns and self.spikes is not None:
-                spikes = [tuple(r) for r in self.spikes[self.gpu_row[i], :ns].astype(float).tolist()]
+                at = int(self.spike_offsets[self.gpu_row[i]])
+                spikes = [tuple(r) for r in self.spikes[at:at + ns].astype(float).tolist()]
             self.polya[i] = {'begin': int(self.polya_begin[i]), 'end': int(self.polya_end[i]),
                              'dwell_time': float(self.polya_dwell_time[i]), 'spikes': spikes}
             self.polya_lazy[i] = False
@@ -260,6 +262,7 @@ def _report_columns(self):
         c['seq_offsets'] = np.ascontiguousarray(d['seq_offsets'], dtype=np.int64)
     if self.spikes is not None:
         c['spikes'] = np.ascontiguousarray(self.spikes, dtype=np.float32)
+        c['spike_offsets'] = np.ascontiguousarray(self.spike_offsets, dtype=np.int64)
     return c
 
 
@@ -346,7 +349,9 @@ class NanoporeRead:
     @property
     def native_spikes(self):
         t, g = self.table, self.table.gpu_row[self.row]
-        return None if t.spikes is None or g < 0 else t.spikes[g]
+        if t.spikes is None or g < 0:
+            return None
+        return t.spikes[int(t.spike_offsets[g]):int(t.spike_offsets[g + 1])]
 
     # setters of the reference surface
     def set_status(self, newstatus, stop=False):
@@ -560,19 +565,38 @@ class SignalLoader:
         """Second half of run_resident: download the records of the run that was launched on
         the resident batch (waits for it) and attach them to `table`; the chimera window scan
         runs here because it needs the batch's samples still resident."""
-        t = table
         if not len(rows):
             return
-        t.records = rec = self.ctx.download()
-        t.spikes = self.ctx.download_spikes() if self.stage_mask & native.STAGE_POLYA else None
+        rec = self.ctx.download()
+        spikes = self.ctx.download_spikes(rec) if self.stage_mask & native.STAGE_POLYA else None
+        self.attach_records(table, rows, rec, spikes)
+        if self.scan_unsplit:
+            frame = self.unsplit_frames(table, rows, offsets)
+            for stride in np.unique(frame[frame[:, 1] > 0, 2]).tolist():
+                sel = (frame[:, 2] == stride) & (frame[:, 1] > 0)
+                self.attach_unsplit(table, rows, sel, self.ctx.unsplit_scan(
+                    frame[:, 0], np.where(sel, frame[:, 1], 0), int(stride)))
+
+    def attach_records(self, table, rows, rec, spikes):
+        """The GPU's records (and spike rows) become the batch table's: scaling-QC verdicts
+        (:108-109) and scaling parameters are set here, everything else is judged later."""
+        t = table
+        t.records = rec
+        t.spikes, t.spike_offsets = spikes if spikes is not None else (None, None)
         t.gpu_row[rows] = np.arange(len(rows))
-        qc_failed = rec['status'] == native.STATUS_CODE['scaling_qc_fail']   # :108-109
+        qc_failed = rec['status'] == native.STATUS_CODE['scaling_qc_fail']
         t.halt(rows[qc_failed], 'scaling_qc_fail')
         good = rows[~qc_failed]
         t.scale_shift[good, 0], t.scale_shift[good, 1] = rec['scale'][~qc_failed], rec['shift'][~qc_failed]
         t.has_scaling[good] = True
-        if self.scan_unsplit:
-            self.scan_unsplit_candidates(t, rows, offsets)
+
+    def attach_unsplit(self, table, rows, sel, scanned):
+        """Candidate lists of one window scan (reads `sel` of the batch took part)."""
+        iv, cnt, start = scanned
+        picked = np.nonzero(sel)[0]
+        table.unsplit_count[rows[picked]] = cnt[picked]
+        for k in picked[cnt[picked] > 0].tolist():
+            table.unsplit[rows[k]] = iv[start[k]:start[k + 1]].tolist()
 
     def pin_bundle(self):
         """Page-lock the bundle's sample arena (or its encoded bytes + chunk records) once, so
@@ -606,9 +630,28 @@ class SignalLoader:
         rows, arena, offsets, calib = self.pack(t)
         if not len(rows):
             return
+        self.pin_bundle()
+        polya = bool(self.stage_mask & native.STAGE_POLYA)
+        if hasattr(self.ctx, 'process_batch_ex'):
+            # one native call per worker batch: stage / swap / run / downloads happen inside it
+            # with the GIL released (include/pxg.h, pxg_process_batch_ex)
+            frame = self.unsplit_frames(t, rows, offsets) if self.scan_unsplit else None
+            strides = np.unique(frame[frame[:, 1] > 0, 2]).tolist() if frame is not None else []
+            scan = None
+            if len(strides) == 1:          # (several block strides in one batch: rare, scanned below)
+                sel = (frame[:, 2] == strides[0]) & (frame[:, 1] > 0)
+                scan = (frame[:, 0], np.where(sel, frame[:, 1], 0), int(strides[0]))
+            if len(strides) <= 1:
+                got = self.ctx.process_batch_ex(arena, offsets, calib, self.stage_mask, unsplit=scan,
+                                                want_spikes=polya)
+                self.attach_records(t, rows, got['records'], got.get('spikes'))
+                if scan is not None:
+                    self.attach_unsplit(t, rows, sel, got['unsplit'])
+                return
+        # the same steps from Python, under the two locks (a context double in the CPU tests,
+        # or a batch that mixes Guppy block strides)
         ctx = self.ctx
         with self._stage_lock:
-            self.pin_bundle()
             if isinstance(arena, native.EncodedSamples):      # compressed bundle: decoded on the GPU
                 ctx.stage_z(arena, offsets, calib)
             else:
@@ -624,11 +667,12 @@ class SignalLoader:
         finally:
             self._run_lock.release()
 
-    def scan_unsplit_candidates(self, table, rows, offsets):
-        """a18 + a19 numeric part for the resident batch: Guppy block means of every
-        basecalled read and the windowed Viterbi scan (signal_analyzer.py:366-418), on the
-        GPU.  Reads whose event frame cannot be built are left out here; load_events raises
-        for them later, per read."""
+    def unsplit_frames(self, table, rows, offsets):
+        """[n, 3] (first sample, Guppy blocks, block stride) of the batch's reads for the a18 +
+        a19 stages (Guppy block means of every basecalled read and the windowed Viterbi scan,
+        signal_analyzer.py:366-418, both on the GPU); blocks = 0 leaves a read out.  Reads whose
+        event frame cannot be built are left out here; load_events raises for them later, per
+        read.  Host-only: computed BEFORE the batch goes to the GPU."""
         t = table
         n = len(rows)
         frame = np.zeros((n, 3), dtype=np.int64)        # first sample, blocks, block stride
@@ -649,11 +693,4 @@ class SignalLoader:
                 frame[k] = NanoporeRead(t, rows[k]).guppy_event_geometry(n_raw[k])
             except Exception:
                 pass
-        for stride in np.unique(frame[frame[:, 1] > 0, 2]).tolist():
-            sel = (frame[:, 2] == stride) & (frame[:, 1] > 0)
-            iv, cnt, start = self.ctx.unsplit_scan(frame[:, 0], np.where(sel, frame[:, 1], 0),
-                                                   int(stride))
-            picked = np.nonzero(sel)[0]
-            t.unsplit_count[rows[picked]] = cnt[picked]
-            for k in picked[cnt[picked] > 0].tolist():
-                t.unsplit[rows[k]] = iv[start[k]:start[k + 1]].tolist()
+        return frame

@@ -60,3 +60,13 @@ def ctx(config):
     c = NativeContext(config, device_id=0)
     yield c
     c.close()
+
+
+def assert_spikes_equal(got, want_records, want_dense, msg=None):
+    """The product's spike rows (rows [total, 4], offsets [n + 1]: every spike of every tail)
+    against the oracle's dense per-read table."""
+    from oracle.pxo import spikes_csr
+    rows, off = got
+    wrows, woff = spikes_csr(want_records, want_dense)
+    assert np.array_equal(off, woff), msg
+    assert np.array_equal(rows, wrows, equal_nan=True), msg

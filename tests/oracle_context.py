@@ -68,8 +68,9 @@ class OracleBackedContext:
             return out[:len(self.res)]
         return self.res
 
-    def download_spikes(self):
-        return self.spk
+    def download_spikes(self, records=None):
+        from oracle.pxo import spikes_csr
+        return spikes_csr(self.res, self.spk)
 
     def stage_times(self):
         return {k: 0.0 for k in N.TIMER_NAMES}, {k: 0 for k in N.TIMER_NAMES}

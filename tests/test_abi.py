@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header_sizes():
     # sizes the C compiler gives the ABI structs (computed from the header by gcc)
     import subprocess, tempfile
-    src = '#include <stdio.h>\n#include "pxg.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu", sizeof(pxg_config), sizeof(pxg_read_result), sizeof(pxg_hmm), sizeof(pxg_event), sizeof(pxg_calib), sizeof(pxg_stage_times), sizeof(pxg_summary_columns));return 0;}'
+    src = '#include <stdio.h>\n#include "pxg.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu", sizeof(pxg_config), sizeof(pxg_read_result), sizeof(pxg_hmm), sizeof(pxg_event), sizeof(pxg_calib), sizeof(pxg_stage_times), sizeof(pxg_summary_columns), sizeof(pxg_batch_extras), sizeof(pxg_z_chunk));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, 'sz.c')
         open(c, 'w').write(src)
@@ -43,7 +43,7 @@ def test_struct_layouts_match_the_header_sizes():
         sizes = [int(v) for v in subprocess.check_output([exe]).split()]
     want = [ctypes.sizeof(N.PxgConfig), ctypes.sizeof(N.PxgReadResult), ctypes.sizeof(N.PxgHmm),
             ctypes.sizeof(N.PxgEvent), ctypes.sizeof(N.PxgCalib), ctypes.sizeof(N.PxgStageTimes),
-            ctypes.sizeof(N.PxgSummaryColumns)]
+            ctypes.sizeof(N.PxgSummaryColumns), ctypes.sizeof(N.PxgBatchExtras), N.Z_CHUNK_DTYPE.itemsize]
     assert sizes == want
 
 

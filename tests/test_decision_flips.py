@@ -170,7 +170,7 @@ def measure(n_reads=2048, samples=40000, seed=924):
     }
 
 
-def measure_viterbi(n_reads=2048, n_chimeras=512, samples=40000, seed=924):
+def measure_viterbi(n_reads=2048, n_chimeras=512, samples=40000, seed=924, only=None):
     """The Viterbi side (rows a6 / a7, and the a19 window scan): the oracle's paths against
     every formula variant of tests/viterbi_variants.py on (a) the pooled + scaled signals of
     `n_reads` bench reads under the segmentation HMM and (b) every scan window of those reads
@@ -193,14 +193,16 @@ def measure_viterbi(n_reads=2048, n_chimeras=512, samples=40000, seed=924):
     chim = [np.concatenate([cb['arena'][co[2 * k]:co[2 * k + 1]], cb['arena'][co[2 * k + 1]:co[2 * k + 2]]])
             for k in range(n_chimeras)]
     c_arena, c_off = N.pack_reads(chim)
-    sets = (('bench', plain['arena'], plain['offsets'], plain['calib']),
-            ('chimera', c_arena, c_off, cb['calib'][::2]))
+    # the generator's own (scale, shift) are injected: the Viterbi side does not depend on the
+    # scaler network (tested above), and the oracle's float32 LSTMs are 95 % of its run time
+    sets = (('bench', plain['arena'], plain['offsets'], plain['calib'], plain['scale_shift']),
+            ('chimera', c_arena, c_off, cb['calib'][::2], cb['scale_shift'][::2]))
 
     seg_x, seg_want = [], []                 # segmentation inputs / the oracle's segments
     win_x, win_meta, reads_meta = [], [], []
     want_cands = []
-    for tag, arena, off, cal in sets:
-        got = orc.process_batch(arena, off, cal)
+    for tag, arena, off, cal, inject in sets:
+        got = orc.process_batch(arena, off, cal, inject, N.STAGE_SEGMENT)
         for i in np.nonzero(got['status'] == 0)[0].tolist():
             raw = arena[off[i]:off[i + 1]]
             g = got[i]
@@ -232,7 +234,7 @@ def measure_viterbi(n_reads=2048, n_chimeras=512, samples=40000, seed=924):
     seg_X, seg_L = padded(seg_x)
     win_X, win_L = padded(win_x)
     table = []
-    for name, knobs in VV.VARIANTS:
+    for name, knobs in [v for k, v in enumerate(VV.VARIANTS) if only is None or k in only]:
         block = 256 if knobs.get('dtype') is np.longdouble else 512
         # (a) segmentation model
         moved, adapter_flip, dlogp = 0, 0, 0.0
@@ -295,7 +297,10 @@ def test_viterbi_formula_variants_move_no_decision():
     canonical restatement must reproduce the oracle exactly, every other variant may move a
     stated handful of decisions (none observed)."""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    r = measure_viterbi()
+    # the suite runs the restatement check and the "everything at once" variant in float64;
+    # `python tests/test_decision_flips.py` walks the whole table, longdouble included
+    # (profiles/r03/decision_flips.json)
+    r = measure_viterbi(only=(0, 6))
     print(json.dumps(r))
     assert r['reads_segmented'] >= 2000 and r['scan_windows'] >= 8000
     assert r['reads_with_candidates']['chimera'] >= 0.8 * r['reads_scanned']['chimera']

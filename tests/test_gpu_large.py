@@ -2,6 +2,8 @@
 import numpy as np
 import pytest
 
+from conftest import assert_spikes_equal
+
 from poreplex_amd import native as N
 from poreplex_amd.synth import synth_batch
 
@@ -53,9 +55,12 @@ def test_configs3_full_shape_100k_reads_60k_samples(ctx, oracle):
     res = ctx.download()
     spk = ctx.download_spikes()
     assert len(res) == n
+    rows, soff = spk
+    per_tile = int(soff[K])
     for k in range(1, n // K):
         assert res[k * K:(k + 1) * K].tobytes() == res[:K].tobytes(), k
-        assert spk[k * K:(k + 1) * K].tobytes() == spk[:K].tobytes(), k
+        assert np.array_equal(soff[k * K:(k + 1) * K + 1] - soff[k * K], soff[:K + 1]), k
+        assert rows[soff[k * K]:soff[(k + 1) * K]].tobytes() == rows[:per_tile].tobytes(), k
     tail = n - (n // K) * K
     assert res[-tail:].tobytes() == res[:tail].tobytes()
     assert (res['status'] == 0).mean() > 0.9 and res['polya_called'].mean() > 0.5
@@ -63,7 +68,7 @@ def test_configs3_full_shape_100k_reads_60k_samples(ctx, oracle):
                                      base['calib'][:256], None, mask, want_spikes=True)
     for f in res.dtype.names:
         assert np.array_equal(res[f][:256], want[f], equal_nan=True), f
-    assert np.array_equal(spk[:256], wsp, equal_nan=True)
+    assert_spikes_equal((rows[:soff[256]], soff[:257]), want, wsp)
     lens = np.diff(base['offsets'])[np.arange(n) % K]
     nb = lens // 15
     iv, cnt, start = ctx.unsplit_scan(np.zeros(n, np.int64), nb)

@@ -10,6 +10,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import assert_spikes_equal
+
 from poreplex_amd import native as N
 from poreplex_amd.synth import synth_batch
 
@@ -226,7 +228,7 @@ def test_polya_golden_bundle_vs_reference(ctx, oracle, bundle, ref_results):
     want, wspk = oracle.process_batch(bundle['arena'], bundle['offsets'], bundle['calib'],
                                       stage_mask=mask, want_spikes=True)
     assert_records_equal(got, want, ctxmsg='polya golden')
-    assert np.array_equal(spikes, wspk, equal_nan=True)
+    assert_spikes_equal(spikes, want, wspk)
     by_id = {r.get('read_id'): r for r in ref_results['results'] if 'read_id' in r}
     n = 0
     for i, rid in enumerate(bundle['read_id']):
@@ -236,8 +238,10 @@ def test_polya_golden_bundle_vs_reference(ctx, oracle, bundle, ref_results):
             assert (got['polya_begin'][i], got['polya_end'][i]) == (p['begin'], p['end'])
             assert got['polya_dwell_samples'][i] / float(bundle['calib'][i]['sampling_rate']) == p['dwell_time']
             assert got['polya_n_spikes'][i] == len(p['spikes'])
-            for k, sp in enumerate(p['spikes'][:N.PXG_MAX_SPIKES]):
-                assert np.array_equal(np.float32(sp), spikes[i, k]), (i, k)
+            rows = spikes[0][spikes[1][i]:spikes[1][i + 1]]
+            assert len(rows) == len(p['spikes'])
+            for k, sp in enumerate(p['spikes']):
+                assert np.array_equal(np.float32(sp), rows[k]), (i, k)
             n += 1
     assert n >= 15
 
@@ -253,7 +257,7 @@ def test_polya_synthetic_vs_oracle(ctx, oracle, seed, noise, dwell):
     want, wspk = oracle.process_batch(b['arena'], b['offsets'], b['calib'], b['scale_shift'],
                                       stage_mask=mask, want_spikes=True)
     assert_records_equal(got, want, ctxmsg='polya synthetic')
-    assert np.array_equal(spikes, wspk, equal_nan=True)
+    assert_spikes_equal(spikes, want, wspk)
     assert got['polya_called'].sum() > 60
 
 
@@ -562,7 +566,7 @@ def test_structured_reads_around_every_length_threshold(ctx, oracle):
     ctx.run(mask)
     got = ctx.download()
     assert_records_equal(got, want, ctxmsg='thresholds')
-    assert np.array_equal(ctx.download_spikes(), wsp, equal_nan=True)
+    assert_spikes_equal(ctx.download_spikes(), want, wsp)
     assert len(set(got['status'].tolist())) >= 2 and (got['bc_pushed'] == 0).any() and (got['bc_pushed'] == 1).any()
     first = np.zeros(len(reads), np.int64)
     nb = np.diff(off) // 15
@@ -618,7 +622,8 @@ def test_polya_hook_equals_stage(ctx):
     got, gsp = ctx.polya(arena, off, sb['calib'][idx], ss, want['seg_first'][idx], want['seg_last'][idx])
     for f in ('polya_called', 'polya_n_spikes', 'polya_dwell_samples', 'polya_begin', 'polya_end'):
         assert np.array_equal(got[f], want[f][idx]), f
-    assert np.array_equal(gsp, wsp[idx], equal_nan=True)
+    rows = np.concatenate([wsp[0][wsp[1][i]:wsp[1][i + 1]] for i in idx])
+    assert np.array_equal(gsp[0], rows, equal_nan=True) and gsp[1][-1] == len(rows)
 
 
 def test_polya_window_larger_than_first_pass_scratch(ctx, oracle):
@@ -642,10 +647,10 @@ def test_polya_window_larger_than_first_pass_scratch(ctx, oracle):
     got = ctx.download()
     for f in got.dtype.names:
         assert np.array_equal(got[f], want[f], equal_nan=True), f
-    assert np.array_equal(ctx.download_spikes(), wsp, equal_nan=True)
+    assert_spikes_equal(ctx.download_spikes(), want, wsp)
     # spikes first, records second: either download settles the stage
     ctx.run(mask)
-    assert np.array_equal(ctx.download_spikes(), wsp, equal_nan=True)
+    assert_spikes_equal(ctx.download_spikes(), want, wsp)
     assert np.array_equal(ctx.download()['polya_end'], want['polya_end'])
     ok = np.nonzero(want['status'] == 0)[0]
     ss = np.stack([want['scale'], want['shift']], axis=1).astype(np.float32)
@@ -654,4 +659,4 @@ def test_polya_window_larger_than_first_pass_scratch(ctx, oracle):
                             want_spikes=True)
     for f in ('polya_called', 'polya_n_spikes', 'polya_dwell_samples', 'polya_begin', 'polya_end'):
         assert np.array_equal(res[f], want[f][ok]), f
-    assert np.array_equal(spikes, wsp[ok], equal_nan=True)
+    assert_spikes_equal(spikes, want[ok], wsp[ok])

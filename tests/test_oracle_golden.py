@@ -199,7 +199,7 @@ def test_full_path_matches_reference_process_batch(oracle, bundle, ref_results):
             rate = float(bundle['calib'][i]['sampling_rate'])
             assert got['polya_dwell_samples'] / rate == p['dwell_time']
             assert got['polya_n_spikes'] == len(p['spikes'])
-            for k, sp in enumerate(p['spikes'][:N.PXG_MAX_SPIKES]):
+            for k, sp in enumerate(p['spikes']):
                 assert np.array_equal(np.float32(sp), spikes[i, k]), (i, k)
             n_polya += 1
             n_spike_reads += len(p['spikes']) > 0

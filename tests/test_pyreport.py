@@ -38,9 +38,12 @@ def random_table(rng, n):
     t.barcode[:n] = rng.integers(-1, 4, n)
     t.barcode_guess[:n] = rng.integers(-1, 4, n)
     t.barcode_phred[:n] = rng.integers(0, 30, n)
-    t.spikes = rng.normal(size=(n, 8, 4)).astype(np.float32)
     t.gpu_row[:n] = rng.permutation(n)
     t.gpu_row[:n][rng.random(n) < 0.1] = -1
+    per_record = rng.integers(0, 9, n)                      # spike rows of GPU record g (CSR)
+    per_record[rng.integers(0, n)] = 300                    # a tail with hundreds of spikes
+    t.spike_offsets = np.concatenate([[0], np.cumsum(per_record)]).astype(np.int64)
+    t.spikes = rng.normal(size=(int(t.spike_offsets[-1]), 4)).astype(np.float32)
     for i in range(n):
         u = rng.random()
         if u < 0.3:
@@ -54,7 +57,7 @@ def random_table(rng, n):
             t.polya_lazy[i] = True
             t.polya_begin[i], t.polya_end[i] = int(rng.integers(0, 10**5)), int(rng.integers(10**5, 10**6))
             t.polya_dwell_time[i] = float(rng.uniform(0, 3))
-            t.polya_spike_count[i] = int(rng.integers(0, 9))
+            t.polya_spike_count[i] = per_record[t.gpu_row[i]]
         elif u < 0.35:
             t.polya[i] = {'begin': 1, 'end': 2, 'dwell_time': 0.5, 'spikes': []}
     return t

@@ -227,3 +227,126 @@ def test_session_degenerate_inputs(oracle_backed, tmp_path):
     out = GpuSession(session_config(tmp_path / 'ghosts', 'chimera.pxr.npz'), batch_reads=3).run(ghosts)
     assert out['reads'] == 7 and len(out['labels']) == 7
     assert int(out['counts'].sum()) == 7
+
+
+# ---- failure path (pipeline.py:207-213,250-265: a failed batch / an early stop ends the run) ----
+def _threads_alive():
+    import threading
+    return [t for t in threading.enumerate() if t is not threading.main_thread() and t.is_alive()]
+
+
+def test_loader_exception_mid_run_unwinds_the_session(oracle_backed, tmp_path, monkeypatch):
+    """An exception in the loader thread (batch 2 of 4) surfaces on the caller, after the
+    thread is joined, the arenas released and the part files closed -- within seconds."""
+    import time
+    from poreplex_amd.session import GpuSession
+    from poreplex_amd.signal_analyzer import SignalAnalyzer
+    calls = {'n': 0}
+    real = SignalAnalyzer.prepare
+
+    def flaky(self, reads, table=None):
+        calls['n'] += 1
+        if calls['n'] == 3:
+            raise OSError('input volume went away')
+        return real(self, reads, table)
+    monkeypatch.setattr(SignalAnalyzer, 'prepare', flaky)
+    before = len(_threads_alive())
+    sess = GpuSession(session_config(tmp_path, 'chimera.pxr.npz'), batch_reads=3)
+    t0 = time.perf_counter()
+    with pytest.raises(OSError, match='input volume'):
+        sess.run(golden_reads('chimera.pxr.npz'))
+    assert time.perf_counter() - t0 < 30
+    assert len(_threads_alive()) == before                      # the loader thread is gone
+    part = tmp_path / 'sequencing_summary.txt.part0000'
+    assert part.exists() and part.read_text().count('\n') >= 1  # closed and flushed, header first
+    # ... and the context is usable again: a second run on the same worker completes
+    monkeypatch.setattr(SignalAnalyzer, 'prepare', real)
+    out = GpuSession(session_config(tmp_path / 'again', 'chimera.pxr.npz'), batch_reads=3).run(
+        golden_reads('chimera.pxr.npz'))
+    assert out['reads'] == 11
+
+
+def test_gpu_error_mid_run_unwinds_the_session(oracle_backed, tmp_path, monkeypatch):
+    from oracle_context import OracleBackedContext
+    from poreplex_amd.session import GpuSession
+    runs = {'n': 0}
+    real = OracleBackedContext.run
+
+    def failing_run(self, mask=N.STAGE_ALL_DEMUX):
+        runs['n'] += 1
+        if runs['n'] == 2:
+            raise N.PxgError('pxg_batch_run failed (-3): hipErrorLaunchFailure')
+        return real(self, mask)
+    monkeypatch.setattr(OracleBackedContext, 'run', failing_run)
+    before = len(_threads_alive())
+    with pytest.raises(N.PxgError, match='hipErrorLaunchFailure'):
+        GpuSession(session_config(tmp_path, 'chimera.pxr.npz'), batch_reads=3).run(
+            golden_reads('chimera.pxr.npz'))
+    assert len(_threads_alive()) == before
+
+
+def test_early_stop_is_a_clean_stop(oracle_backed, tmp_path, monkeypatch):
+    """pipeline.py:250-260: reads keep arriving without basecalls -> one message, run over."""
+    from poreplex_amd.session import GpuSession
+    from poreplex_amd.fast5_file import ReadBundle
+    real = ReadBundle.basecall_of
+    monkeypatch.setattr(ReadBundle, 'basecall_of', lambda self, i: None)
+    cfg = session_config(tmp_path, 'chimera.pxr.npz', nobasecall_stop_trigger=3)
+    sess = GpuSession(cfg, batch_reads=4)
+    sess.loader.bundle.d['bc_present'][:] = False
+    before = len(_threads_alive())
+    with pytest.raises(RuntimeError, match='Early stopping: '):
+        sess.run(golden_reads('chimera.pxr.npz'))
+    assert len(_threads_alive()) <= before
+
+
+ABORT_WORKER = textwrap.dedent("""
+    import os, sys, time
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests'))
+    import torch.distributed as dist
+    from poreplex_amd import native as N
+    from oracle_context import OracleBackedContext
+    N.NativeContext = OracleBackedContext          # test double: no GPU in this container
+    import test_session as TS
+    from poreplex_amd.session import GpuSession, SessionAborted
+    from poreplex_amd.signal_analyzer import SignalAnalyzer
+    dist.init_process_group('gloo')
+    rank = dist.get_rank()
+    if rank == 1:                                   # rank 1 loses its input in its second batch
+        real, calls = SignalAnalyzer.prepare, [0]
+        def flaky(self, reads, table=None):
+            calls[0] += 1
+            if calls[0] == 2:
+                raise OSError('rank 1 lost its input')
+            return real(self, reads, table)
+        SignalAnalyzer.prepare = flaky
+    t0 = time.perf_counter()
+    try:
+        GpuSession(TS.session_config({out!r}, {bundle!r}), dist=dist, batch_reads=2).run(TS.golden_reads({bundle!r}))
+        verdict = 'finished'
+    except SessionAborted as exc:
+        verdict = 'aborted: ' + str(exc)
+    except OSError as exc:
+        verdict = 'failed: ' + str(exc)
+    open(os.path.join({out!r}, 'rank%d.txt' % rank), 'w').write('%s|%.1f' % (verdict, time.perf_counter() - t0))
+    dist.destroy_process_group()
+""")
+
+
+def test_one_rank_failing_stops_every_rank(oracle_backed, tmp_path):
+    """2 ranks over gloo, rank 1 fails in its second batch: rank 0 must not hang in the final
+    collectives -- both leave the loop in the same round, within seconds."""
+    script = tmp_path / 'worker.py'
+    script.write_text(ABORT_WORKER.format(root=ROOT, out=str(tmp_path), bundle='chimera.pxr.npz'))
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    out = subprocess.run(
+        [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), str(script)],
+        capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    r0, r1 = [(tmp_path / ('rank%d.txt' % r)).read_text().split('|') for r in (0, 1)]
+    assert r1[0] == 'failed: rank 1 lost its input'
+    assert r0[0].startswith('aborted: rank 1 stopped the run')
+    assert float(r0[1]) < 60 and float(r1[1]) < 60

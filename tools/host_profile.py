@@ -67,8 +67,10 @@ class ReplayContext:
         k = np.arange(self.n_resident) % self.distinct
         return ReplayContext.records[k]
 
-    def download_spikes(self):
-        return ReplayContext.spikes[np.arange(self.n_resident) % self.distinct]
+    def download_spikes(self, records=None):
+        from oracle.pxo import spikes_csr
+        k = np.arange(self.n_resident) % self.distinct
+        return spikes_csr(ReplayContext.records[k], ReplayContext.spikes[k])
 
     def unsplit_scan(self, first, nb, stride=15):
         n = self.n_resident
