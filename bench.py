@@ -333,10 +333,18 @@ def process_batch_leg(args, base, which, lo, mask, local_rank, compressed, resid
             process_batch(1 + k, reads, cfg)
         serial = 2 * n / (time.perf_counter() - t0)
         calls = max(args.api_calls, 1)
+        from poreplex_amd import signal_analyzer as SA
+        SA.CALL_TRACE = trace = []
         with ThreadPoolExecutor(max(args.in_flight, 1)) as pool:
             t0 = time.perf_counter()
             outs = list(pool.map(lambda k: process_batch(10 + k, reads, cfg), range(calls)))
             wall = time.perf_counter() - t0
+        SA.CALL_TRACE = None
+        tr = np.array(trace)
+        phases = {'prepare_ms': float((tr[:, 1] - tr[:, 0]).mean() * 1e3),
+                  'gpu_pass_ms': float((tr[:, 2] - tr[:, 1]).mean() * 1e3),
+                  'result_dicts_ms': float((tr[:, 3] - tr[:, 2]).mean() * 1e3),
+                  'gpu_pass_done_spacing_ms': float(np.diff(np.sort(tr[:, 2])).mean() * 1e3) if len(tr) > 1 else None}
         bad = [r for r in outs if isinstance(r, tuple)]
         if bad:
             raise N.PxgError('process_batch failed: {}'.format(bad[0][1]))
@@ -346,7 +354,8 @@ def process_batch_leg(args, base, which, lo, mask, local_rank, compressed, resid
                'first_call_s': round(t_first, 3), 'bundle_write_s': round(t_write, 3),
                'compressed_bundle': bool(compressed), 'dicts_returned': len(last),
                'dict_builder': 'csrc/_pxgpy' if N.load_pyhost() is not None else 'python loop',
-               'results_identical_across_calls': bool(all(o_ == first for o_ in outs))}
+               'results_identical_across_calls': bool(all(o_ == first for o_ in outs)),
+               'mean_phase_ms_per_call': {k: (round(v, 2) if v is not None else None) for k, v in phases.items()}}
         if resident_records is not None and len(resident_records) == n:
             # the dicts against the records of the resident loop (same reads, same stages)
             st = [N.STATUS_NAMES[c] for c in resident_records['status'].tolist()]

@@ -476,6 +476,57 @@ int pxg_batch_stage_z(pxg_ctx* ctx, int64_t n_reads, const uint8_t* z, int64_t z
                       const int64_t* raw_offsets, const pxg_calib* calib,
                       const float* scale_shift_or_null);
 
+/* ---- FAST5 input without an HDF5 library (host only, libpxghost.so) ---------
+ * What the per-read processor needs from a FAST5 file (fast5_file.py:37-58 get_read_ids,
+ * :97-131 Fast5Reader metadata + int16 `Signal', :133-181 basecall summary), read straight from
+ * a memory map of the file: single- and multi-read layouts, contiguous / chunked datasets,
+ * gzip, shuffle and ONT's VBZ filter (csrc/pxg_h5.cpp lists the supported subset of the HDF5
+ * format; anything else is PXG_E_UNSUPPORTED with a message, never a guess).  The signals of a
+ * whole batch are decoded on host threads directly into the staging arena pxg_batch_stage
+ * copies from.  Per-read problems are DATA (pxg_h5_read_info.status, pxg_h5_load_signals'
+ * status array), as in the reference where a bad read is that read's outcome. */
+typedef struct pxg_h5 pxg_h5;
+typedef struct {
+    int32_t status;                 /* 0, or the pxg_error of THIS read (text in `error`)      */
+    int32_t bc_present;             /* a Basecall_1D_* group exists                            */
+    char read_id[64];
+    char channel_number[16];
+    char run_id[64];
+    char sample_id[128];
+    char error[160];
+    int64_t duration, start_time;   /* Raw attributes (fast5_file.py:97-109)                   */
+    int64_t n_samples;              /* length of the Signal dataset                            */
+    pxg_calib calib;                /* channel_id attributes (:110-115)                        */
+    int32_t bc_table;               /* 0 none, 1 Move, 2 Guppy Events, 3 albacore, 4 unsupported */
+    int32_t bc_block_stride;
+    int64_t bc_sequence_length, bc_num_events, bc_first_sample;
+    int64_t bc_n_moves, bc_move_sum;/* rows / sum of the move column (-1: no table)            */
+    int64_t bc_seq_len;             /* characters of the Fastq sequence line                   */
+    double bc_mean_qscore;
+} pxg_h5_read_info;
+int pxg_h5_open(const char* path, pxg_h5** out);
+void pxg_h5_close(pxg_h5* file);
+const char* pxg_h5_last_error(void);                       /* of the calling thread */
+int64_t pxg_h5_n_reads(const pxg_h5* file);
+int pxg_h5_is_multi(const pxg_h5* file);
+int pxg_h5_read_id(const pxg_h5* file, int64_t i, char* out, int64_t cap);
+int pxg_h5_info(const pxg_h5* file, int64_t first, int64_t n, pxg_h5_read_info* out);
+/* text = sequence '\n' quality string; move = the Move table / the Events table's move column */
+int pxg_h5_basecall(const pxg_h5* file, int64_t i, int64_t text_cap, char* text, int64_t move_cap,
+                    uint8_t* move, double* p_model_state_or_null, int32_t* has_p_model_state);
+/* int16 samples of many reads (any mix of open files) decoded on `threads` host threads into the
+ * caller's (staging) arena: read k -> arena[dst_start[k] .. dst_start[k] + n_samples[k]);
+ * status[k] = 0 or that read's own pxg_error */
+int pxg_h5_load_signals(int64_t n, const pxg_h5* const* files, const int64_t* index,
+                        const int64_t* dst_start, const int64_t* n_samples, int16_t* arena,
+                        int32_t threads, int32_t* status);
+/* sequences, quality strings and move tables of many reads into columnar arenas (lengths from
+ * pxg_h5_info: bc_seq_len, bc_n_moves) */
+int pxg_h5_basecall_many(int64_t n, const pxg_h5* const* files, const int64_t* index,
+                         const int64_t* seq_start, const int64_t* seq_len, uint8_t* seq_arena,
+                         uint8_t* qual_arena, const int64_t* move_start, const int64_t* n_moves,
+                         uint8_t* move_arena, int32_t threads, int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif

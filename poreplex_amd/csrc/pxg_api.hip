@@ -3,6 +3,9 @@
 #include <math.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
 #include "pxg_common.h"
 #include "pxg_zcheck.h"
 
@@ -834,18 +837,28 @@ extern "C" int pxg_process_batch_ex(pxg_ctx* ctx, int64_t n_reads, const int16_t
     if (!out) return fail(ctx, PXG_E_INVALID, "pxg_process_batch: out is null");
     const float* inject = x ? x->scale_shift_or_null : nullptr;
     int rc;
+    // PXG_TRACE=1: one stderr line per call with the milliseconds spent waiting for the spare slot,
+    // copying, waiting for the resident batch, computing and downloading
+    static const bool trace = getenv("PXG_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = trace ? now() : 0.0;
     std::unique_lock<std::mutex> stage_lock(ctx->mt_stage);
+    const double t1 = trace ? now() : 0.0;
     if (x && x->z)
         rc = pxg_batch_stage_z(ctx, n_reads, x->z, x->z_bytes, x->chunks, x->n_chunks, x->data_base, x->dst_base,
                                raw_offsets, calib, inject);
     else
         rc = pxg_batch_stage(ctx, n_reads, raw_arena, raw_offsets, calib, inject);
     if (rc) return rc;
+    const double t2 = trace ? now() : 0.0;
     std::unique_lock<std::mutex> run_lock(ctx->mt_run);      // the previous call has all its results
+    const double t3 = trace ? now() : 0.0;
     rc = pxg_batch_swap(ctx);
     stage_lock.unlock();                                      // the next call may start its copy
     if (rc) return rc;
+    const double t4 = trace ? now() : 0.0;
     if ((rc = pxg_batch_run(ctx, stage_mask))) return rc;
+    const double t5 = trace ? now() : 0.0;
     int verdict = PXG_OK;
     if (x && x->unsplit_first_sample) {
         if ((rc = pxg_batch_unsplit_scan(ctx, x->unsplit_first_sample, x->unsplit_n_blocks, x->unsplit_block_stride,
@@ -860,6 +873,9 @@ extern "C" int pxg_process_batch_ex(pxg_ctx* ctx, int64_t n_reads, const int16_t
         if (rc == PXG_E_NOMEM) verdict = PXG_E_NOMEM;
         else if (rc) return rc;
     }
+    if (trace)
+        fprintf(stderr, "[pxg] call at %.1f: wait-spare %.2f stage %.2f wait-resident %.2f swap %.2f launch %.2f "
+                        "results %.2f ms\n", t0, t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4, now() - t5);
     return verdict;
 }
 

@@ -1,25 +1,34 @@
-"""Read sources for the hot path: FAST5 (h5py, optional) and .pxr.npz bundles.
+"""Read sources for the hot path: FAST5 files and .pxr.npz bundles.
 
 Mirrors what the per-read processor needs from the reference's
 poreplex/fast5_file.py (`Fast5Reader`: metadata :97-120, raw samples :122-131,
 basecall summary :133-164).  The pA conversion itself is NOT done here: the
 reader hands int16 DAQ samples + calibration to the GPU (kernel a1).
 
-A *bundle* (`*.pxr.npz`) is this build's array container for many reads: the
-GPU boxes have no h5py, and the golden tests feed the same reads the reference
-saw as FAST5 files (tools/make_golden.py writes both).
+FAST5 files are read WITHOUT h5py: csrc/pxg_h5.cpp (libpxghost.so, host only) parses the
+subset of the HDF5 format FAST5 files are written in straight from a memory map and decodes
+the signals of a whole batch on host threads into the staging arena the GPU copies from
+(`Fast5Batch`); `Fast5Reader` / `get_read_ids` keep the reference's per-read surface on top of
+the same library.  A file it declines (dense link / attribute storage of `libver latest`)
+falls back to h5py where that is importable, and fails loudly where it is not.
+
+A *bundle* (`*.pxr.npz`) is this build's array container for many reads (columnar metadata,
+one sample arena); a batch of FAST5 reads becomes the same columns (`Fast5Batch.as_bundle`),
+so everything behind the loader is shared.
 """
 import json
 import os
+import threading
+from collections import OrderedDict
 
 import numpy as np
 
-try:  # optional: only needed for real FAST5 input
+try:  # optional: only for files the native reader declines
     import h5py
 except ImportError:  # pragma: no cover
     h5py = None
 
-__all__ = ['get_read_ids', 'open_read', 'ReadBundle', 'Fast5Reader', 'write_bundle']
+__all__ = ['get_read_ids', 'open_read', 'ReadBundle', 'Fast5Reader', 'Fast5File', 'Fast5Batch', 'write_bundle']
 
 
 TABLE_KINDS = ('', 'move', 'guppy_events', 'albacore', 'unsupported')   # '' = no event table
@@ -203,6 +212,26 @@ class ReadBundle:
                 'table': kind, 'move': move, 'p_model_state': pms}
 
 
+class _Fast5BatchBundle(ReadBundle):
+    """ReadBundle over the columns of a Fast5Batch (nothing on disk)."""
+
+    def __init__(self, d, batch):
+        self.d, self.batch = d, batch
+        self.filenames = [str(f) for f in d['filename']]
+        self.read_ids = [str(r) for r in d['read_id']]
+        self.keys = list(zip(self.filenames, self.read_ids))
+        self.index = {key: i for i, key in enumerate(self.keys)}
+        self.by_file = {}
+        for i, f in enumerate(self.filenames):
+            self.by_file.setdefault(f, []).append(i)
+        self.broken = set()
+
+    def basecall_of(self, i):
+        """The per-read path (chimera candidates, Events tables): straight from the file, so a
+        p_model_state column comes along."""
+        return self.batch.files[i].basecall(int(self.batch.index[i]))
+
+
 class BundleReader:
     """Same attribute surface as the reference's Fast5Reader."""
 
@@ -232,13 +261,292 @@ class BundleReader:
         return self.bundle.basecall_of(self.i)
 
 
+class Fast5Error(OSError):
+    pass
+
+
+class Fast5File:
+    """One FAST5 file opened by the native reader: read ids, per-read metadata columns
+    (pxg_h5_read_info) and handles for the batch loaders.  Cached per path (open_fast5)."""
+
+    def __init__(self, path):
+        from . import native
+        import ctypes as C
+        self.lib = native.load_text_library()
+        self.path = path
+        handle = C.c_void_p()
+        rc = self.lib.pxg_h5_open(os.fsencode(path), C.byref(handle))
+        if rc:
+            msg = (self.lib.pxg_h5_last_error() or b'').decode(errors='replace')
+            err = Fast5Error(msg or 'Unable to open file {!r}'.format(path))
+            err.code = rc
+            raise err
+        self.handle = handle
+        self.n = int(self.lib.pxg_h5_n_reads(handle))
+        self.multi = bool(self.lib.pxg_h5_is_multi(handle))
+        self._ids = self._info = self._index = None
+
+    def close(self):
+        handle, self.handle = getattr(self, 'handle', None), None
+        if handle:
+            self.lib.pxg_h5_close(handle)
+
+    __del__ = close
+
+    @property
+    def read_ids(self):
+        if self._ids is None:
+            import ctypes as C
+            buf = C.create_string_buffer(256)
+            ids = []
+            for i in range(self.n):
+                if self.lib.pxg_h5_read_id(self.handle, i, buf, 256):
+                    raise Fast5Error((self.lib.pxg_h5_last_error() or b'').decode(errors='replace'))
+                ids.append(buf.value.decode())
+            self._ids = ids
+            self._index = {r: i for i, r in enumerate(ids)}
+        return self._ids
+
+    def index_of(self, read_id):
+        self.read_ids
+        return self._index.get(read_id, -1)
+
+    @property
+    def info(self):
+        """pxg_h5_read_info of every read of the file (one native call, cached)."""
+        if self._info is None:
+            from . import native
+            out = np.zeros(self.n, dtype=native.H5_INFO_DTYPE)
+            rc = self.lib.pxg_h5_info(self.handle, 0, self.n, out.ctypes.data)
+            if rc:
+                raise Fast5Error('pxg_h5_info failed ({})'.format(rc))
+            self._info = out
+        return self._info
+
+    def signal(self, i):
+        info = self.info[i]
+        if info['status']:
+            raise Fast5Error(info['error'].decode(errors='replace'))
+        return load_signals([self], [i], [int(info['n_samples'])])[0]
+
+    def basecall(self, i):
+        """get_basecall()-style dict of read i (fast5_file.py:133-181), None if not basecalled."""
+        import ctypes as C
+        info = self.info[i]
+        if info['status']:
+            raise Fast5Error(info['error'].decode(errors='replace'))
+        if not info['bc_present']:
+            return None
+        text = C.create_string_buffer(2 * int(info['bc_seq_len']) + 16)
+        n_mv = max(int(info['bc_n_moves']), 0)
+        move = np.zeros(max(n_mv, 1), dtype=np.uint8)
+        pms = np.zeros(max(n_mv, 1), dtype=np.float64)
+        has = C.c_int32(0)
+        rc = self.lib.pxg_h5_basecall(self.handle, i, len(text), text, len(move), move.ctypes.data,
+                                      pms.ctypes.data, C.byref(has))
+        if rc:
+            raise Fast5Error((self.lib.pxg_h5_last_error() or b'').decode(errors='replace'))
+        seq, qual = text.value.decode('ascii').split('\n')
+        kind = TABLE_KINDS[int(info['bc_table'])] or None
+        return {'sequence': seq, 'qstring': qual, 'block_stride': int(info['bc_block_stride']),
+                'sequence_length': int(info['bc_sequence_length']),
+                'mean_qscore': float(info['bc_mean_qscore']), 'num_events': int(info['bc_num_events']),
+                'first_sample_template': int(info['bc_first_sample']), 'table': kind,
+                'move': move[:n_mv].tolist() if info['bc_n_moves'] >= 0 else None,
+                'p_model_state': pms[:n_mv].tolist() if has.value else None}
+
+
+_OPEN, _OPEN_LOCK, _OPEN_MAX = OrderedDict(), threading.Lock(), 128
+
+
+def open_fast5(path):
+    """Fast5File of `path` from a small LRU cache (a multi-read file serves thousands of reads;
+    keyed by path + mtime + size so that a rewritten file is opened again)."""
+    st = os.stat(path)
+    key = (path, st.st_mtime_ns, st.st_size)
+    with _OPEN_LOCK:
+        f = _OPEN.get(key)
+        if f is not None:
+            _OPEN.move_to_end(key)
+            return f
+    f = Fast5File(path)
+    with _OPEN_LOCK:
+        _OPEN[key] = f
+        while len(_OPEN) > _OPEN_MAX:
+            _OPEN.popitem(last=False)
+    return f
+
+
+def host_threads():
+    """Threads for the batch decoders: the cores this process may use, capped by a cgroup quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fh:
+            q, period = fh.read().split()
+        if q != 'max':
+            n = min(n, max(int(float(q) / float(period)), 1))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get('PXG_HOST_THREADS', 32))))
+
+
+def _handles(files):
+    import ctypes as C
+    return (C.c_void_p * len(files))(*[f.handle.value for f in files])
+
+
+def load_signals(files, index, n_samples, arena=None, dst_start=None, threads=None):
+    """int16 samples of reads (files[k], index[k]) decoded on host threads.  Without `arena`:
+    a list of arrays; with it: written at dst_start[k] (returns the per-read status array)."""
+    from . import native
+    lib = native.load_text_library()
+    n = len(files)
+    ns = np.ascontiguousarray(n_samples, dtype=np.int64)
+    idx = np.ascontiguousarray(index, dtype=np.int64)
+    own = arena is None
+    if own:
+        dst_start = np.zeros(n, dtype=np.int64)
+        np.cumsum(ns[:-1], out=dst_start[1:])
+        arena = np.empty(int(ns.sum()), dtype=np.int16)
+    dst = np.ascontiguousarray(dst_start, dtype=np.int64)
+    status = np.zeros(n, dtype=np.int32)
+    if n:
+        lib.pxg_h5_load_signals(n, _handles(files), idx.ctypes.data, dst.ctypes.data, ns.ctypes.data,
+                                arena.ctypes.data, threads or host_threads(), status.ctypes.data)
+    if own:
+        if status.any():
+            raise Fast5Error('signal of read {} cannot be decoded (code {})'.format(
+                int(np.nonzero(status)[0][0]), int(status[status != 0][0])))
+        return [arena[dst[k]:dst[k] + ns[k]] for k in range(n)]
+    return status
+
+
+class Fast5Batch:
+    """Many FAST5 reads as COLUMNS: what ReadBundle holds for a bundle's reads, built for one
+    worker batch from the files themselves -- metadata by one native call per file, signals and
+    basecall text decoded on host threads into arenas (the sample arena may be a page-locked
+    staging buffer).  `as_bundle()` is a ReadBundle, so the loader, the status rules and the
+    result-dict builder take exactly the paths they take for bundle reads."""
+
+    def __init__(self, files, index, names):
+        from . import native
+        self.files, self.index, self.names = list(files), np.asarray(index, dtype=np.int64), list(names)
+        info = np.zeros(len(self.files), dtype=native.H5_INFO_DTYPE)
+        by_file = {}
+        for k, f in enumerate(self.files):
+            by_file.setdefault(id(f), (f, []))[1].append(k)
+        for f, ks in by_file.values():
+            info[ks] = f.info[self.index[ks]]
+        self.info = info
+
+    def as_bundle(self, reserve=None, threads=None):
+        """ReadBundle over the batch (reads whose info failed must have been left out by the
+        caller).  `reserve(n_samples)` -> int16 arena to decode into (a staging buffer)."""
+        from . import native
+        lib = native.load_text_library()
+        info, n = self.info, len(self.files)
+        ns = info['n_samples'].astype(np.int64)
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(ns, out=offsets[1:])
+        arena = reserve(int(offsets[-1])) if reserve is not None else np.empty(int(offsets[-1]), dtype=np.int16)
+        status = load_signals(self.files, self.index, ns, arena, offsets[:-1], threads)
+        seq_len = np.where(info['bc_present'] != 0, info['bc_seq_len'], 0).astype(np.int64)
+        n_moves = np.where(info['bc_present'] != 0, np.maximum(info['bc_n_moves'], 0), 0).astype(np.int64)
+        seq_off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(seq_len, out=seq_off[1:])
+        move_off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(n_moves, out=move_off[1:])
+        seq_arena = np.zeros(int(seq_off[-1]), dtype=np.uint8)
+        qual_arena = np.zeros(int(seq_off[-1]), dtype=np.uint8)
+        move_arena = np.zeros(int(move_off[-1]), dtype=np.uint8)
+        bstatus = np.zeros(n, dtype=np.int32)
+        if n:
+            idx = np.ascontiguousarray(self.index)
+            s0, m0 = np.ascontiguousarray(seq_off[:-1]), np.ascontiguousarray(move_off[:-1])
+            lib.pxg_h5_basecall_many(n, _handles(self.files), idx.ctypes.data, s0.ctypes.data, seq_len.ctypes.data,
+                                     seq_arena.ctypes.data, qual_arena.ctypes.data, m0.ctypes.data,
+                                     n_moves.ctypes.data, move_arena.ctypes.data, threads or host_threads(),
+                                     bstatus.ctypes.data)
+        calib = np.zeros(n, dtype=native.CALIB_DTYPE)
+        for name in ('range', 'digitisation', 'offset', 'sampling_rate'):
+            calib[name] = info['calib'][name]
+        d = {'arena': arena[:offsets[-1]], 'offsets': offsets, 'calib': calib,
+             'filename': np.asarray(self.names), 'read_id': np.char.decode(info['read_id'], 'ascii'),
+             'duration': info['duration'].astype(np.int64), 'start_time': info['start_time'].astype(np.int64),
+             'channel_number': np.char.decode(info['channel_number'], 'ascii'),
+             'run_id': np.char.decode(info['run_id'], 'ascii'),
+             'sample_id': np.char.decode(info['sample_id'], 'utf-8'),
+             'broken_files': np.array([], dtype='<U1'), 'bundle_version': np.int64(2),
+             'bc_present': info['bc_present'] != 0, 'bc_sequence_length': info['bc_sequence_length'].astype(np.int64),
+             'bc_mean_qscore': info['bc_mean_qscore'].astype(np.float64),
+             'bc_num_events': info['bc_num_events'].astype(np.int64),
+             'bc_first_sample': info['bc_first_sample'].astype(np.int64),
+             'bc_block_stride': info['bc_block_stride'].astype(np.int32), 'bc_table': info['bc_table'].astype(np.int8),
+             'bc_n_moves': np.where(info['bc_present'] != 0, info['bc_n_moves'], -1).astype(np.int64),
+             'bc_move_sum': info['bc_move_sum'].astype(np.int64),
+             'seq_offsets': seq_off, 'seq_arena': seq_arena, 'qual_arena': qual_arena,
+             'move_offsets': move_off, 'move_arena': move_arena}
+        bundle = _Fast5BatchBundle(d, self)
+        bundle.signal_status, bundle.basecall_status = status, bstatus
+        return bundle
+
+
 class Fast5Reader:
-    """h5py-backed reader (single- and multi-read FAST5)."""
+    """The reference's per-read reader surface (fast5_file.py:60-131) on the native file."""
+
+    def __init__(self, path, read_id):
+        self.path = path
+        try:
+            self.file = open_fast5(path)
+        except Fast5Error as exc:
+            if getattr(exc, 'code', 0) == -6 and h5py is not None:      # a layout the native reader declines
+                self.__class__ = H5pyFast5Reader
+                H5pyFast5Reader.__init__(self, path, read_id)
+                return
+            raise OSError(str(exc))
+        f = self.file
+        if f.multi:
+            self.i = f.index_of(read_id)
+            if self.i < 0:
+                raise KeyError("Unable to open object (object 'read_{}' doesn't exist)".format(read_id))
+        else:
+            if not f.n:
+                raise KeyError("Unable to open object (object 'Reads' doesn't exist)")
+            self.i = 0
+        info = f.info[self.i]
+        if info['status']:
+            if info['status'] == -6 and h5py is not None:
+                self.__class__ = H5pyFast5Reader
+                H5pyFast5Reader.__init__(self, path, read_id)
+                return
+            raise OSError(info['error'].decode(errors='replace'))
+        self.duration, self.start_time = int(info['duration']), int(info['start_time'])
+        file_read_id = info['read_id'].decode()
+        self.read_id = file_read_id if read_id is None else read_id
+        if file_read_id != self.read_id:
+            raise ValueError('Unexpected read {} found in {}'.format(file_read_id, path))
+        self.channel_number = info['channel_number'].decode()
+        cal = info['calib']
+        self.digitization, self.offset = float(cal['digitisation']), float(cal['offset'])
+        self.range, self.sampling_rate = float(cal['range']), float(cal['sampling_rate'])
+        self.run_id, self.sample_id = info['run_id'].decode(), info['sample_id'].decode()
+
+    def close(self):
+        self.file = None
+
+    def get_raw_int16(self):
+        return self.file.signal(self.i)
+
+    def get_basecall(self, analysis_group='Basecall_1D'):
+        return self.file.basecall(self.i)
+
+
+class H5pyFast5Reader:
+    """h5py-backed reader: only for files the native reader declines, where h5py exists."""
 
     def __init__(self, path, read_id):
         if h5py is None:
-            raise RuntimeError('h5py is not installed: FAST5 input is unavailable here; '
-                               'use a .pxr.npz read bundle (config["read_bundle"])')
+            raise RuntimeError('h5py is not installed and the native FAST5 reader declined this file')
         self.path, self.read_id = path, read_id
         self.handle = h5py.File(path, 'r')
         if 'UniqueGlobalKey' not in self.handle:          # multi-read (:71-75)
@@ -321,8 +629,12 @@ def get_read_ids(filename, basedir, bundle=None):
     if bundle is not None and bundle.has_file(filename):
         return bundle.read_ids_of(filename)
     path = os.path.join(basedir, filename) if basedir is not None else filename
-    if h5py is None:
-        raise RuntimeError('h5py is not installed')
+    try:
+        f = open_fast5(path)
+        return [(filename, rid) for rid in f.read_ids]
+    except Fast5Error as exc:
+        if getattr(exc, 'code', 0) != -6 or h5py is None:
+            raise OSError(str(exc))
     with h5py.File(path, 'r') as f5:
         if 'UniqueGlobalKey' in f5:
             try:

@@ -354,8 +354,41 @@ _TEXT_SIGNATURES = {      # libpxghost.so: host-only helpers (sink text, sample 
     'pxg_z_encode': (C.c_int64, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'pxg_z_decode': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     'pxg_z_validate': (C.c_int, [C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
+    'pxg_h5_open': (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    'pxg_h5_close': (None, [C.c_void_p]),
+    'pxg_h5_last_error': (C.c_char_p, []),
+    'pxg_h5_n_reads': (C.c_int64, [C.c_void_p]),
+    'pxg_h5_is_multi': (C.c_int, [C.c_void_p]),
+    'pxg_h5_read_id': (C.c_int, [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64]),
+    'pxg_h5_info': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    'pxg_h5_basecall': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p,
+                                  C.c_void_p, C.POINTER(C.c_int32)]),
+    'pxg_h5_load_signals': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_int32, C.c_void_p]),
+    'pxg_h5_basecall_many': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
 }
 _text_lib = None
+
+
+class PxgH5ReadInfo(C.Structure):           # pxg_h5_read_info
+    _fields_ = [('status', C.c_int32), ('bc_present', C.c_int32), ('read_id', C.c_char * 64),
+                ('channel_number', C.c_char * 16), ('run_id', C.c_char * 64), ('sample_id', C.c_char * 128),
+                ('error', C.c_char * 160), ('duration', C.c_int64), ('start_time', C.c_int64),
+                ('n_samples', C.c_int64), ('calib', PxgCalib), ('bc_table', C.c_int32),
+                ('bc_block_stride', C.c_int32), ('bc_sequence_length', C.c_int64), ('bc_num_events', C.c_int64),
+                ('bc_first_sample', C.c_int64), ('bc_n_moves', C.c_int64), ('bc_move_sum', C.c_int64),
+                ('bc_seq_len', C.c_int64), ('bc_mean_qscore', C.c_double)]
+
+
+H5_INFO_DTYPE = np.dtype([
+    ('status', '<i4'), ('bc_present', '<i4'), ('read_id', 'S64'), ('channel_number', 'S16'), ('run_id', 'S64'),
+    ('sample_id', 'S128'), ('error', 'S160'), ('duration', '<i8'), ('start_time', '<i8'), ('n_samples', '<i8'),
+    ('calib', [('range', '<f8'), ('digitisation', '<f8'), ('offset', '<f8'), ('sampling_rate', '<f8')]),
+    ('bc_table', '<i4'), ('bc_block_stride', '<i4'), ('bc_sequence_length', '<i8'), ('bc_num_events', '<i8'),
+    ('bc_first_sample', '<i8'), ('bc_n_moves', '<i8'), ('bc_move_sum', '<i8'), ('bc_seq_len', '<i8'),
+    ('bc_mean_qscore', '<f8')], align=True)
+assert H5_INFO_DTYPE.itemsize == C.sizeof(PxgH5ReadInfo), (H5_INFO_DTYPE.itemsize, C.sizeof(PxgH5ReadInfo))
 
 _SIGNATURES = {
     'pxg_create': (C.c_int, [C.POINTER(PxgConfig), C.POINTER(C.c_void_p)]),

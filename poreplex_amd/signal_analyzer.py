@@ -17,6 +17,7 @@ GPU surfaces as the ``(-1, msg, traceback)`` tuple the pipeline treats as fatal
 """
 import os
 import sys
+import time
 import traceback
 from contextlib import AbstractContextManager
 from weakref import proxy
@@ -29,6 +30,8 @@ from .utils import union_intervals  # noqa: F401  (re-exported like the referenc
 from .worker_persistence import WorkerPersistenceStorage
 
 __all__ = ['SignalAnalyzer', 'SignalAnalysis', 'process_batch']
+
+CALL_TRACE = None     # a list: (start, prepared, GPU pass done, dicts built) of every process() call
 
 # the two message layouts downstream log parsers know (signal_analyzer.py:56-58,141-146)
 BATCH_ERROR_FORMAT = '[{filename}:{lineno}] Unhandled exception {name}: {msg}'
@@ -115,9 +118,15 @@ class SignalAnalyzer(AbstractContextManager):
     def process(self, reads):
         """Result list of signal_analyzer.py:82-134: whatever was decided before the GPU
         pass first (encounter order), then every read that entered it (input order)."""
+        t0 = time.perf_counter()
         batch = self.prepare(reads, ReadTable())    # a table of its own: calls may overlap (threads)
+        t1 = time.perf_counter()
         self.loader.fit_scalers(batch.table)     # scaling parameters AND every other numeric stage
-        return self.finish(batch)
+        t2 = time.perf_counter()
+        results = self.finish(batch)
+        if CALL_TRACE is not None:               # bench.py: where a worker call spends its time
+            CALL_TRACE.append((t0, t1, t2, time.perf_counter()))
+        return results
 
     def prepare(self, reads, table=None):
         """Host-only first phase: open every read into a batch table.  The session driver

@@ -135,12 +135,12 @@ def many_candidate_config():
     cfg = copy.deepcopy(default_config())
     cfg['unsplit_read_detection'].update(strict_full_length=0.03, strict_dna_length=0.01,
                                          loosen_full_length=0.03, loosen_dna_length=0.01,
-                                         window_size=3, window_step=1.5)
+                                         window_size=6, window_step=3)
     return cfg
 
 
 def test_windows_with_forty_candidates_equal_the_oracle():
-    """Duration cut-offs of 30 ms let a 3 s window hold ~40 leader -> adapter candidates; the
+    """Duration cut-offs of 30 ms let a 6 s window hold more than 40 leader -> adapter candidates; the
     slots follow the config (pxg_unsplit_cand_slots), every candidate comes back, in the
     reference's append order."""
     from oracle.pxo import Oracle
