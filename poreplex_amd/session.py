@@ -114,7 +114,7 @@ class GpuSession:
                 if stop.is_set() or staging is None:  # the session is being torn down
                     return
                 t0 = time.perf_counter()
-                batch = self.analyzer.prepare(reads, ReadTable())
+                batch = self.analyzer.prepare(reads, ReadTable(), reserve=staging.reserve)
                 need = int(batch.table.n_raw[np.asarray(batch.entered, dtype=np.int64)].sum()) if batch.entered else 0
                 rows, arena, offsets, calib = self.loader.pack(batch.table, staging, need)
                 self.timing['load_s'] += time.perf_counter() - t0

@@ -128,14 +128,15 @@ class SignalAnalyzer(AbstractContextManager):
             CALL_TRACE.append((t0, t1, t2, time.perf_counter()))
         return results
 
-    def prepare(self, reads, table=None):
+    def prepare(self, reads, table=None, reserve=None):
         """Host-only first phase: open every read into a batch table.  The session driver
-        runs this for batch k+1 while batch k is on the GPU."""
+        runs this for batch k+1 while batch k is on the GPU (`reserve`: its staging arena, so
+        FAST5 signals are decoded straight into page-locked memory)."""
         loader = self.loader
         table = loader.table if table is None else table
         batch = _Batch(table)
         reads = [tuple(r) for r in reads]
-        where = loader.prepare_many(reads, table)      # bundle reads: one column append
+        where = loader.prepare_many(reads, table, reserve)   # bundle / FAST5 reads: column appends
         bulk = np.nonzero(where >= 0)[0]
         stopped = table.stopped[where[bulk]]
         for position in np.nonzero(where < 0)[0].tolist():     # everything else, read by read

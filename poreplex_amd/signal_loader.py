@@ -494,15 +494,20 @@ class SignalLoader:
             t.raw[row], t.pending[row] = raw, True
         return NanoporeRead(t, row)
 
-    def prepare_many(self, reads, table):
-        """Bulk form of prepare_loading for reads that live in the read bundle: one column
-        append for all of them.  Returns an int array with one entry per input read: its row,
-        or -1 when the read needs the per-read path (not in the bundle, or its file is marked
-        corrupt)."""
+    def prepare_many(self, reads, table, reserve=None):
+        """Bulk form of prepare_loading: reads that live in the read bundle are one column
+        append; reads that live in FAST5 files become the same columns through the native
+        reader (fast5_file.Fast5Batch: metadata per file, signals and basecall text decoded on
+        host threads -- into `reserve(n_samples)`, the session's staging arena, when given).
+        Returns an int array with one entry per input read: its row, or -1 when the read needs
+        the per-read path (file gone or unreadable, read not in its file, bundle marked corrupt:
+        that path raises / reports exactly what the reference does)."""
         b = self.bundle
         where = np.full(len(reads), -1, dtype=np.int64)
-        if b is None or not len(reads):
+        if not len(reads):
             return where
+        if b is None or not b.has_file(reads[0][0]):
+            return self.prepare_fast5(reads, where, table, reserve)
         index, broken = b.index, b.broken
         # the usual worker batch is a run of consecutive bundle reads: one list comparison
         # instead of a dictionary lookup per read
@@ -521,6 +526,49 @@ class SignalLoader:
         table.halt(short, 'scaler_signal_too_short')
         table.pending[short] = False
         where[found] = rows
+        return where
+
+    def prepare_fast5(self, reads, where, table, reserve=None):
+        """The FAST5 half of prepare_many.  Only when the table holds no bundle rows yet (a
+        table has one column source)."""
+        from .fast5_file import Fast5Batch, Fast5Error, open_fast5
+        if table.n or table.bundle is not None:
+            return where
+        files, index, names, at = [], [], [], []
+        opened = {}
+        for pos, (filename, read_id) in enumerate(reads):
+            f = opened.get(filename, 0)
+            if f == 0:
+                try:
+                    f = open_fast5(os.path.join(self.fast5prefix, filename))
+                except (OSError, Fast5Error):
+                    f = None                     # vanished or unreadable: the per-read path says how
+                opened[filename] = f
+            if f is None:
+                continue
+            i = f.index_of(read_id) if f.multi else (0 if f.n and f.read_ids[0] == read_id else -1)
+            if i < 0 or f.info['status'][i]:
+                continue
+            files.append(f); index.append(i); names.append(filename); at.append(pos)
+        if not files:
+            return where
+        bundle = Fast5Batch(files, index, names).as_bundle(reserve)
+        rows = table.extend_from_bundle(bundle, np.arange(len(files)))
+        cfg = self.scaler_cfg      # length gate of load_padded_signal_head (:212-222)
+        usable = np.minimum(np.minimum(cfg['length'], table.duration[rows]), table.n_raw[rows])
+        short = rows[usable - usable % cfg['stride'] < cfg['min_length']]
+        table.halt(short, 'scaler_signal_too_short')
+        table.pending[short] = False
+        # a read whose signal or basecall text could not be decoded: its own unknown_error
+        bad = np.nonzero((bundle.signal_status != 0) | (bundle.basecall_status != 0))[0]
+        for k in bad.tolist():
+            table.halt(rows[k], 'unknown_error')
+            table.pending[rows[k]] = False
+            table.error_message[rows[k]] = (
+                '({}#{}) FAST5 {} cannot be decoded (native reader code {})'.format(
+                    names[k], bundle.read_ids[k], 'signal' if bundle.signal_status[k] else 'basecall',
+                    int(bundle.signal_status[k] or bundle.basecall_status[k])))
+        where[np.asarray(at, dtype=np.int64)] = rows
         return where
 
     # ---- the GPU pass, in the three steps the session driver overlaps ------------------
