@@ -93,11 +93,16 @@ def parse(argv=None):
                          '(poreplex_amd.signal_analyzer.process_batch(batchid, reads, config) -> list of result '
                          'dicts, pipeline.py:204-205), --in-flight calls kept in flight on one GPU context; the '
                          'default line carries the same figure in extra.process_batch_reads_per_s')
-    ap.add_argument('--in-flight', type=int, default=3,
+    ap.add_argument('--in-flight', type=int, default=5,
                     help='process_batch leg: worker calls in flight (threads of this process; the '
                          "reference's `parallel`, pipeline.py:96)")
     ap.add_argument('--api-calls', type=int, default=8, help='process_batch leg: timed calls')
     ap.add_argument('--no-api-leg', action='store_true', help='skip the process_batch leg of the default line')
+    ap.add_argument('--no-configs4', action='store_true',
+                    help='N > 1, weak scaling: skip the extra strong-scaling leg (BASELINE configs[4]: '
+                         '--total-reads sharded over the ranks) that the line carries as configs4_strong')
+    ap.add_argument('--strong-base-reads', type=int, default=2048,
+                    help='distinct reads of the configs4_strong leg (tiled on the device)')
     ap.add_argument('--context-factory', default=None,
                     help='TEST SEAM (module:attr): CPU rendezvous tests of the multi-rank driver '
                          'inject a stand-in context; the line then says data=TEST-STANDIN, value=null')
@@ -335,9 +340,24 @@ def process_batch_leg(args, base, which, lo, mask, local_rank, compressed, resid
         calls = max(args.api_calls, 1)
         from poreplex_amd import signal_analyzer as SA
         SA.CALL_TRACE = trace = []
+        # results are checked and DROPPED as they arrive, like a pipeline that hands them to its sinks
+        # (holding on to millions of dicts is not the API's cost: it makes the cyclic collector walk
+        # them all, under the GIL every worker thread needs)
+        verdict = {'bad': None, 'same': True, 'last': None}
+
+        def one_call(k):
+            r = process_batch(10 + k, reads, cfg)
+            if isinstance(r, tuple):
+                verdict['bad'] = r
+            else:
+                verdict['same'] = verdict['same'] and len(r) == len(first) and r[0] == first[0] and r[-1] == first[-1]
+                if k == calls - 1:
+                    verdict['same'] = verdict['same'] and r == first
+                    verdict['last'] = r
+            return k
         with ThreadPoolExecutor(max(args.in_flight, 1)) as pool:
             t0 = time.perf_counter()
-            outs = list(pool.map(lambda k: process_batch(10 + k, reads, cfg), range(calls)))
+            list(pool.map(one_call, range(calls)))
             wall = time.perf_counter() - t0
         SA.CALL_TRACE = None
         tr = np.array(trace)
@@ -345,16 +365,15 @@ def process_batch_leg(args, base, which, lo, mask, local_rank, compressed, resid
                   'gpu_pass_ms': float((tr[:, 2] - tr[:, 1]).mean() * 1e3),
                   'result_dicts_ms': float((tr[:, 3] - tr[:, 2]).mean() * 1e3),
                   'gpu_pass_done_spacing_ms': float(np.diff(np.sort(tr[:, 2])).mean() * 1e3) if len(tr) > 1 else None}
-        bad = [r for r in outs if isinstance(r, tuple)]
-        if bad:
-            raise N.PxgError('process_batch failed: {}'.format(bad[0][1]))
-        last = outs[-1]
+        if verdict['bad'] is not None:
+            raise N.PxgError('process_batch failed: {}'.format(verdict['bad'][1]))
+        last = verdict['last']
         out = {'reads_per_s': calls * n / wall, 'one_call_at_a_time_reads_per_s': serial,
                'calls': calls, 'in_flight': args.in_flight, 'reads_per_call': n, 'ms_per_call': wall / calls * 1e3,
                'first_call_s': round(t_first, 3), 'bundle_write_s': round(t_write, 3),
                'compressed_bundle': bool(compressed), 'dicts_returned': len(last),
                'dict_builder': 'csrc/_pxgpy' if N.load_pyhost() is not None else 'python loop',
-               'results_identical_across_calls': bool(all(o_ == first for o_ in outs)),
+               'results_identical_across_calls': bool(verdict['same']),
                'mean_phase_ms_per_call': {k: (round(v, 2) if v is not None else None) for k, v in phases.items()}}
         if resident_records is not None and len(resident_records) == n:
             # the dicts against the records of the resident loop (same reads, same stages)
@@ -377,6 +396,112 @@ def process_batch_leg(args, base, which, lo, mask, local_rank, compressed, resid
         return out
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def rank_stats(value, dist, standin):
+    """(min, mean, max) of one number over the ranks (RCCL / gloo all-reduce); None stays None."""
+    if dist is None:
+        return {'min': value, 'mean': value, 'max': value}
+    import torch
+    dev = 'cpu' if standin else 'cuda'
+    has = torch.tensor([0.0 if value is None else 1.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(has, op=dist.ReduceOp.MIN)
+    v = float(value) if value is not None else 0.0
+    lo, hi, tot = (torch.tensor([v], dtype=torch.float64, device=dev) for _ in range(3))
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    if float(has.item()) == 0.0:
+        return None
+    return {'min': float(lo.item()), 'mean': float(tot.item()) / dist.get_world_size(), 'max': float(hi.item())}
+
+
+def pcie_legs(ctx, base, inject, step, n_local, args, kernel_rate):
+    """PCIe-inclusive rates of THIS rank (never `value`): the double-buffered loader path with raw
+    int16 samples and with encoded samples, and the H2D ceiling of the link.  At N > 1 every rank
+    runs it at the same time: eight ranks staging ~57 GB/s each is the host-side load that can
+    fail to scale (host DRAM, NUMA, PCIe roots) while the kernels scale trivially."""
+    out = {}
+    nbytes_in = base['arena'].nbytes
+    ctx.pin(base['arena'])
+    n_over = min(args.steps, 5)
+    ctx.sync()
+    o0 = time.perf_counter()
+    for _ in range(n_over):
+        step()
+        ctx.stage(base['arena'], base['offsets'], base['calib'], inject)
+        ctx.download()
+        ctx.swap()
+    ctx.sync()
+    o_s = (time.perf_counter() - o0) / n_over
+    out['pcie_overlapped_reads_per_s'] = n_local / o_s
+    h0 = time.perf_counter()
+    for _ in range(2):
+        ctx.stage(base['arena'], base['offsets'], base['calib'], inject)
+        ctx.swap()                      # waits for the staged copies
+    h_s = (time.perf_counter() - h0) / 2
+    out['h2d_GBps'] = nbytes_in / h_s / 1e9
+    out['pcie_bound_reads_per_s'] = n_local / h_s
+    out['pcie_overlap_efficiency'] = (n_local / o_s) / min(n_local / h_s, kernel_rate)
+    ctx.unpin(base['arena'])
+    z, chunks, _ = N.z_encode(base['arena'], base['offsets'])        # offline step, not timed
+    enc = N.EncodedSamples(z, chunks, 0, 0, len(base['arena']))
+    ctx.pin(z)
+    ctx.pin(chunks)
+    ctx.sync()
+    z0 = time.perf_counter()
+    for _ in range(n_over):
+        step()
+        ctx.stage_z(enc, base['offsets'], base['calib'], inject)
+        ctx.download()
+        ctx.swap()
+    ctx.sync()
+    z_s = (time.perf_counter() - z0) / n_over
+    out['pcie_overlapped_encoded_reads_per_s'] = n_local / z_s
+    out['encoded_bytes_per_sample'] = (z.nbytes + chunks.nbytes) / max(len(base['arena']), 1)
+    ctx.unpin(z)
+    ctx.unpin(chunks)
+    return out
+
+
+def strong_leg(args, ctx, dist, rank, world, mask, standin, force_dist, barrier):
+    """BASELINE configs[4] beside the weak value: ONE seeded run of --total-reads reads, global
+    read i = distinct read i mod K, rank r owns shard_range(total, r, N) and tiles its shard on
+    the device; every step gathers the label records of the whole run."""
+    total = args.total_reads
+    lo, hi = shard_range(total, rank, world)
+    n_local = hi - lo
+    sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
+    K = max(1, min(args.strong_base_reads, total))
+    base = synth_batch(K, seed=args.seed, samples_per_read=args.samples)      # the same on every rank
+    ctx.upload_tiled(n_local, base['arena'], base['offsets'], base['calib'], None, phase=lo % K)
+    res_buf = np.zeros(n_local, dtype=N.RESULT_DTYPE)
+    if not standin:
+        ctx.pin(res_buf)
+    ctx.run(mask)
+    res = ctx.download(res_buf)
+    labels = gather_labels(res, dist, first_index=lo, sizes=sizes, force=force_dist)
+    barrier()
+    steps = max(2, min(args.steps, 3))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.run(mask)
+        res = ctx.download(res_buf)
+        labels = gather_labels(res, dist, first_index=lo, sizes=sizes, force=force_dist)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if standin else 'cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if not standin:
+        ctx.unpin(res_buf)
+    return {'value': None if standin else total * steps / elapsed, 'unit': 'reads/s', 'scaling': 'strong',
+            'total_reads': total, 'reads_per_gpu': sizes, 'steps': steps, 'ms_per_step': elapsed / steps * 1e3,
+            'distinct_reads': K, 'labels_gathered': int(len(labels)),
+            'labels_read_index_unique': bool(len(np.unique(labels['read_index'])) == len(labels) == total),
+            'reads_ok_this_rank': int((res['status'] == 0).sum())}
 
 
 def make_context(args, config, local_rank):
@@ -463,6 +588,12 @@ def main():
                           lo, total, mask, json_fd)
     ctx = make_context(args, config, local_rank)
     info = ctx.device_info()
+    # this rank's process (and, by first touch, the host memory it allocates from here on) goes
+    # to the NUMA node of ITS GPU; the batch that exists already is copied there
+    from poreplex_amd.distributed import bind_to_gpu_numa
+    numa = {'numa_node': None, 'cpus': None, 'pci': None} if standin else bind_to_gpu_numa(local_rank)
+    if numa['numa_node'] is not None:
+        base['arena'] = base['arena'].copy()
 
     # --filter-chimera: Guppy block frame of every read (first sample 0, stride 15)
     ev_first = np.zeros(n_local, dtype=np.int64)
@@ -530,6 +661,28 @@ def main():
         elapsed, n_ranks = float(t[0].item()), int(round(t[1].item()))
     value = total * args.steps / elapsed
 
+    # ---- legs every rank takes part in (N > 1: all ranks at the same time) -------------------
+    pcie_local, pcie_error = {}, None
+    if not n_base and not (args.no_overlap_test and world == 1):
+        try:
+            if args.no_overlap_test:
+                raise N.PxgError('skipped (--no-overlap-test)')
+            pcie_local = pcie_legs(ctx, base, inject, step, n_local, args, value / world)
+        except N.PxgError as exc:
+            pcie_error = str(exc)
+    pcie_ranks = None
+    if dist is not None:            # min / mean / max over the ranks, by collective
+        keys = ('pcie_overlapped_reads_per_s', 'pcie_overlapped_encoded_reads_per_s', 'h2d_GBps')
+        pcie_ranks = {k: rank_stats(pcie_local.get(k), dist, standin) for k in keys}
+    configs4 = None
+    if dist is not None and args.scaling == 'weak' and not args.no_configs4:
+        configs4 = strong_leg(args, ctx, dist, rank, world, mask, standin, force_dist, barrier)
+        # the weak batch again (the API / concordance legs below use it)
+        if n_base:
+            ctx.upload_tiled(n_local, base['arena'], base['offsets'], base['calib'], inject, phase=lo % n_base)
+        else:
+            ctx.upload(base['arena'], base['offsets'], base['calib'], inject)
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -592,58 +745,19 @@ def main():
 
     # ---- PCIe-inclusive rates (never `value`): (i) upload and compute alternating,
     # (ii) the double-buffered loader path: every step uploads a full batch from pinned host
-    # memory on the copy stream while the previous one computes (pxg_batch_stage / swap)
+    # memory on the copy stream while the previous one computes (pxg_batch_stage / swap),
+    # (iii) the same with encoded samples decoded on the device -- measured above on every rank
     if not n_base and not standin:
         extra['pcie_inclusive_reads_per_s'] = n_local / (elapsed / args.steps + t_upload)
-        nbytes_in = base['arena'].nbytes
-        try:
-            if args.no_overlap_test or world > 1:     # a one-GPU figure: the other ranks have left by now
-                raise N.PxgError('skipped (--no-overlap-test)' if args.no_overlap_test else
-                                 'skipped: PCIe figures are measured at N = 1')
-            ctx.pin(base['arena'])
-            n_over = min(args.steps, 5)
-            ctx.sync()
-            o0 = time.perf_counter()
-            for _ in range(n_over):
-                step()
-                ctx.stage(base['arena'], base['offsets'], base['calib'], inject)
-                ctx.download()
-                ctx.swap()
-            ctx.sync()
-            o_s = (time.perf_counter() - o0) / n_over
-            extra['pcie_overlapped_reads_per_s'] = n_local / o_s
-            # the ceiling this link sets for a batch of that size: H2D alone, pinned memory
-            h0 = time.perf_counter()
-            for _ in range(2):
-                ctx.stage(base['arena'], base['offsets'], base['calib'], inject)
-                ctx.swap()                      # waits for the staged copies
-            h_s = (time.perf_counter() - h0) / 2
-            extra['h2d_GBps'] = nbytes_in / h_s / 1e9
-            extra['pcie_bound_reads_per_s'] = n_local / h_s
-            extra['pcie_overlap_efficiency'] = (n_local / o_s) / min(n_local / h_s, value / world)
-            ctx.unpin(base['arena'])
-            # (iii) the same loop with the samples crossing the link ENCODED (zig-zag delta bytes in
-            # 1 024-sample chunks, pxg_batch_stage_z) and decoded on the device into the spare slot
-            z, chunks, _ = N.z_encode(base['arena'], base['offsets'])        # offline step, not timed
-            enc = N.EncodedSamples(z, chunks, 0, 0, len(base['arena']))
-            ctx.pin(z)
-            ctx.pin(chunks)
-            ctx.sync()
-            z0 = time.perf_counter()
-            for _ in range(n_over):
-                step()
-                ctx.stage_z(enc, base['offsets'], base['calib'], inject)
-                ctx.download()
-                ctx.swap()
-            ctx.sync()
-            z_s = (time.perf_counter() - z0) / n_over
-            extra['pcie_overlapped_encoded_reads_per_s'] = n_local / z_s
-            extra['encoded_bytes_per_sample'] = (z.nbytes + chunks.nbytes) / max(len(base['arena']), 1)
-            ctx.unpin(z)
-            ctx.unpin(chunks)
-        except N.PxgError as exc:
-            extra['pcie_overlapped_reads_per_s'] = None
-            extra['pcie_overlapped_error'] = str(exc)
+    extra.update(pcie_local)
+    if pcie_error is not None:
+        extra['pcie_overlapped_reads_per_s'] = None
+        extra['pcie_overlapped_error'] = pcie_error
+    if pcie_ranks is not None:
+        extra['pcie_over_ranks'] = pcie_ranks      # N > 1: all ranks staged at the same time
+    if configs4 is not None:
+        extra['configs4_strong'] = configs4
+    extra['numa'] = numa
 
     # ---- CPU baseline + concordance: the oracle, rank 0, bounded sample -------
     cpu = None

@@ -258,6 +258,10 @@ void pxg_destroy(pxg_ctx* ctx);
 const char* pxg_last_error(const pxg_ctx* ctx_or_null);
 int pxg_abi_version(void);
 int pxg_get_device_info(pxg_ctx* ctx, pxg_device_info* out);
+/* PCI address ("0000:c1:00.0") of HIP device `device`: what a launcher needs to put a rank's
+ * process and its page-locked staging memory on the NUMA node of ITS GPU (one worker process per
+ * device: pipeline.py:96).  No context needed. */
+int pxg_device_pci_bus_id(int device, char* out, int cap);
 
 /* ---- the hot path: replaces SignalAnalyzer.process for the numeric part
  * (signal_analyzer.py:82-134 phases 1-4).  raw_offsets has n_reads+1 entries

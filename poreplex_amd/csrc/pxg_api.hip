@@ -329,6 +329,17 @@ extern "C" int pxg_get_device_info(pxg_ctx* ctx, pxg_device_info* out)
     return PXG_OK;
 }
 
+extern "C" int pxg_device_pci_bus_id(int device, char* out, int cap)
+{
+    if (!out || cap < 16) return PXG_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return fail(nullptr, PXG_E_NODEVICE, "pxg_device_pci_bus_id: no such HIP device");
+    if (hipDeviceGetPCIBusId(out, cap, device) != hipSuccess)
+        return fail(nullptr, PXG_E_HIP, "hipDeviceGetPCIBusId failed");
+    return PXG_OK;
+}
+
 // ---------------------------------------------------------------------------
 // batch residency
 // ---------------------------------------------------------------------------

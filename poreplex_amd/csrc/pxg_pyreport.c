@@ -19,6 +19,10 @@
 #include <stdint.h>
 #include <string.h>
 
+#if PY_VERSION_HEX >= 0x030d0000 || !defined(_PyDict_NewPresized)
+PyAPI_FUNC(PyObject*) _PyDict_NewPresized(Py_ssize_t minused);   /* exported by libpython, not in every public header */
+#endif
+
 typedef struct {
     Py_buffer view;
     int held;
@@ -158,7 +162,7 @@ static PyObject* report(PyObject* self, PyObject* args)
             const int64_t i = R[k];
             PyObject* d = NULL;
             if (i < 0 || i >= n_table) { PyErr_SetString(PyExc_IndexError, "report: row outside the table"); goto fail_row; }
-            d = PyDict_New();
+            d = _PyDict_NewPresized(20);          /* 11 - 18 keys: no rehash on the way */
             if (!d) goto fail_row;
             PyObject* o;
             if (!(o = item(filename, i))) goto fail_row;

@@ -396,6 +396,7 @@ _SIGNATURES = {
     'pxg_last_error': (C.c_char_p, [C.c_void_p]),
     'pxg_abi_version': (C.c_int, []),
     'pxg_get_device_info': (C.c_int, [C.c_void_p, C.POINTER(PxgDeviceInfo)]),
+    'pxg_device_pci_bus_id': (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     'pxg_process_batch': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]),
     'pxg_batch_upload': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
@@ -464,6 +465,17 @@ def load_library(path=None):
             lib.pxg_abi_version(), PXG_ABI_VERSION))
     _lib = lib
     return lib
+
+
+def device_pci_bus_id(device=0):
+    """PCI address of HIP device `device` ('0000:c1:00.0'), or None when it cannot be told."""
+    buf = C.create_string_buffer(64)
+    try:
+        if load_library().pxg_device_pci_bus_id(int(device), buf, 64) != 0:
+            return None
+    except PxgError:
+        return None
+    return buf.value.decode().lower() or None
 
 
 def load_text_library(path=None):

@@ -14,6 +14,7 @@ signal_loader.py:165-198) -- but it is only a (table, row) handle.
 network + QC, pooling, segmentation, barcode classifier, optional poly(A) and
 the chimera window scan all run behind one upload.
 """
+import gc
 import os
 import threading
 from operator import itemgetter
@@ -206,7 +207,16 @@ class ReadTable:
         idx = np.ascontiguousarray(rows, dtype=np.int64)
         fast = native.load_pyhost()
         if fast is not None:
-            return fast.report(self._report_columns(), idx)
+            # ten thousand dicts + tuples in one C call: none of them can be part of a cycle, and the
+            # collector would walk the young ones some thirty times on the way (and, now and then,
+            # everything the process holds)
+            was_on = gc.isenabled()
+            gc.disable()
+            try:
+                return fast.report(self._report_columns(), idx)
+            finally:
+                if was_on:
+                    gc.enable()
         rows = idx.tolist()
         status = [native.STATUS_NAMES[c] for c in self.status[idx].tolist()]
         # Python's round (correctly rounded decimal), not np.round: part of the output contract

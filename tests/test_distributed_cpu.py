@@ -105,7 +105,7 @@ def test_bench_self_spawns_two_ranks_over_gloo():
     env = {k: v for k, v in os.environ.items()
            if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
     env['PYTHONPATH'] = os.path.join(ROOT, 'tests') + os.pathsep + env.get('PYTHONPATH', '')
-    for scaling, extra, total in (('weak', ['--reads', '12'], 24),
+    for scaling, extra, total in (('weak', ['--reads', '12', '--total-reads', '31', '--strong-base-reads', '5'], 24),
                                   ('strong', ['--total-reads', '25', '--base-reads', '7'], 25)):
         out = subprocess.run(
             [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
@@ -122,6 +122,21 @@ def test_bench_self_spawns_two_ranks_over_gloo():
         assert line['extra']['labels_gathered'] == total
         assert line['extra']['labels_read_index_unique'] is True
         assert sum(line['config']['reads_per_gpu']) == total
+        x = line['extra']
+        if scaling == 'weak':
+            # the legs the bare N > 1 call carries: every rank staged batches over "PCIe" at the same
+            # time (min / mean / max over the ranks by collective), and BASELINE configs[4] -- one
+            # seeded run sharded over the ranks -- ran beside the weak value
+            for key in ('pcie_overlapped_reads_per_s', 'pcie_overlapped_encoded_reads_per_s', 'h2d_GBps'):
+                st = x['pcie_over_ranks'][key]
+                assert st['min'] <= st['mean'] <= st['max'] and st['min'] > 0, (key, st)
+            c4 = x['configs4_strong']
+            assert c4['scaling'] == 'strong' and c4['total_reads'] == 31 and sum(c4['reads_per_gpu']) == 31
+            assert c4['labels_gathered'] == 31 and c4['labels_read_index_unique'] is True
+            assert c4['value'] is None and c4['distinct_reads'] == 5
+            assert 'numa' in x
+        else:
+            assert 'configs4_strong' not in x
 
 
 def test_bench_end_to_end_two_ranks_over_gloo():
