@@ -86,6 +86,11 @@ def parse(argv=None):
                          'double-buffered batches, facade, sequencing_summary.txt, RCCL all-gather / '
                          'all-reduce) processes it; value = reads / wall of the whole session')
     ap.add_argument('--batch-reads', type=int, default=10000, help='--end-to-end: reads per GPU batch')
+    ap.add_argument('--from-fast5', choices=['none', 'gzip', 'vbz'], default=None,
+                    help='--end-to-end: the shard is written as multi-read FAST5 files (4 000 reads each, '
+                         'Signal uncompressed / gzip / VBZ) and read back by the native reader '
+                         '(csrc/pxg_h5.cpp) instead of a read bundle')
+    ap.add_argument('--no-fast5-leg', action='store_true', help='skip the FAST5 ingest leg of the default line')
     ap.add_argument('--compressed-bundle', action='store_true',
                     help='--end-to-end: the bundle carries encoded samples (pxg_z_*), decoded on the GPU')
     ap.add_argument('--api', choices=['resident', 'process_batch'], default='resident',
@@ -226,9 +231,25 @@ def end_to_end(args, config, rank, local_rank, world, dist, standin, base, which
         names = ['shard{:02d}/read{:07d}.fast5'.format(rank, lo + j) for j in range(len(which))]
         ids = ['{:08x}-0000-4000-8000-{:012x}'.format(args.seed, lo + j) for j in range(len(which))]
         t0 = time.perf_counter()
-        path = os.path.join(work, 'shard.pxr.npz')
-        write_bundle(path, arena, off, base['calib'][which], names, ids,
-                     basecalls=synth_basecalls(shard, seed=args.seed + rank), compress=args.compressed_bundle)
+        bcs = synth_basecalls(shard, seed=args.seed + rank)
+        if args.from_fast5:
+            from poreplex_amd.fast5_write import Fast5Writer
+            per_file = 4000
+            names = []
+            for f0 in range(0, len(which), per_file):
+                rel = 'shard{:02d}/reads{:07d}.fast5'.format(rank, lo + f0)
+                os.makedirs(os.path.join(work, os.path.dirname(rel)), exist_ok=True)
+                with Fast5Writer(os.path.join(work, rel)) as w:
+                    for j in range(f0, min(f0 + per_file, len(which))):
+                        w.add_read(ids[j], arena[off[j]:off[j + 1]], base['calib'][which[j]], start_time=0,
+                                   channel_number='0', run_id='run', sample_id='sample', basecall=bcs[j],
+                                   compression=None if args.from_fast5 == 'none' else args.from_fast5)
+                        names.append(rel)
+            path = None
+        else:
+            path = os.path.join(work, 'shard.pxr.npz')
+            write_bundle(path, arena, off, base['calib'][which], names, ids,
+                         basecalls=bcs, compress=args.compressed_bundle)
         t_write = time.perf_counter() - t0
         cfg = default_config(inputdir=work, outputdir=outdir, read_bundle=path,
                              barcoding=True, measure_polya=bool(mask & N.STAGE_POLYA),
@@ -257,8 +278,8 @@ def end_to_end(args, config, rank, local_rank, world, dist, standin, base, which
             with open(os.path.join(cfg['outputdir'], 'sequencing_summary.txt')) as fh:
                 n_rows = sum(1 for _ in fh) - 1
             line = {
-                'metric': 'reads/s (end-to-end demux: read bundles on disk -> barcode labels + '
-                          'sequencing_summary.txt)',
+                'metric': 'reads/s (end-to-end demux: {} on disk -> barcode labels + '
+                          'sequencing_summary.txt)'.format('FAST5 files' if args.from_fast5 else 'read bundles'),
                 'value': None if standin else total / wall, 'unit': 'reads/s', 'n_gpus': world,
                 'steps': out['batches'], 'warmup': 0, 'ms_per_step': wall / max(out['batches'], 1) * 1e3,
                 'higher_is_better': True, 'scaling': args.scaling,
@@ -275,7 +296,7 @@ def end_to_end(args, config, rank, local_rank, world, dist, standin, base, which
                            'samples_per_read': args.samples, 'device': info['name'], 'arch': info['arch']},
                 'roofline': None, 'cpu_baseline': None, 'concordance': None,
                 'extra': {'session_timing_rank0': {k: round(v, 4) for k, v in out['timing'].items()},
-                          'bundle_write_s': round(t_write, 3), 'compressed_bundle': bool(args.compressed_bundle), 'context_and_bundle_open_s': round(t_open, 3),
+                          'bundle_write_s': round(t_write, 3), 'compressed_bundle': bool(args.compressed_bundle), 'from_fast5': args.from_fast5, 'context_and_bundle_open_s': round(t_open, 3),
                           'reads_labelled_pass': int(counts[LABEL_NAMES.index('pass')].sum()),
                           'reads_with_barcode': int(counts[:, 1:].sum()), 'summary_rows': n_rows,
                           'labels_gathered': int(len(out['labels'])),
@@ -393,6 +414,50 @@ def process_batch_leg(args, base, which, lo, mask, local_rank, compressed, resid
                 diff += int(r.get('barcode') != (label[j] if called[j] else None))
             out['barcode_or_status_mismatch_vs_resident_records'] = diff
         WorkerPersistenceStorage.reset()
+        return out
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def fast5_ingest_leg(args, base, which, n_reads=2048):
+    """FAST5 -> staging arena, host only (never `value`): `n_reads` of the batch written as
+    multi-read FAST5 files with poreplex_amd/fast5_write.py, then opened and decoded into one
+    arena by the native reader (csrc/pxg_h5.cpp: memory map, HDF5 structures parsed in C++, gzip /
+    zstd + streamvbyte undone on host threads) -- the rate the session's loader thread can feed
+    the GPU at from real files, per compression."""
+    import shutil
+    import tempfile
+    from poreplex_amd import fast5_file as F5
+    from poreplex_amd.fast5_write import Fast5Writer
+    from poreplex_amd.synth import synth_basecalls
+    out = {'reads': 0, 'threads': F5.host_threads()}
+    work = tempfile.mkdtemp(prefix='pxg_f5_')
+    try:
+        n = min(n_reads, len(which))
+        o = base['offsets']
+        raws = [base['arena'][o[b]:o[b + 1]] for b in which[:n]]
+        bcs = synth_basecalls({'offsets': np.concatenate([[0], np.cumsum([len(r) for r in raws])])}, seed=args.seed)
+        out['reads'] = n
+        for mode, count in (('none', n), ('vbz', n), ('gzip', min(n, 512))):
+            path = os.path.join(work, mode + '.fast5')
+            t0 = time.perf_counter()
+            try:
+                with Fast5Writer(path) as w:
+                    for j in range(count):
+                        w.add_read('{:08x}-0000-4000-8000-{:012x}'.format(args.seed, j), raws[j], base['calib'][which[j]],
+                                   start_time=j, channel_number=str(1 + j % 512), basecall=bcs[j],
+                                   compression=None if mode == 'none' else mode)
+            except OSError as exc:                       # no libzstd on this host: VBZ cannot be written
+                out[mode] = {'error': str(exc)}
+                continue
+            t_write = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            f = F5.Fast5File(path)
+            bundle = F5.Fast5Batch([f] * f.n, np.arange(f.n), [mode + '.fast5'] * f.n).as_bundle()
+            dt = time.perf_counter() - t0
+            assert not bundle.signal_status.any() and np.array_equal(bundle.samples(count - 1), raws[count - 1])
+            out[mode] = {'reads_per_s': count / dt, 'reads': count, 'file_MB': round(os.path.getsize(path) / 1e6, 1),
+                         'samples_GBps': float(bundle.d['offsets'][-1]) * 2 / dt / 1e9, 'write_s': round(t_write, 2)}
         return out
     finally:
         shutil.rmtree(work, ignore_errors=True)
@@ -833,6 +898,12 @@ def main():
             extra['process_batch_reads_per_s'] = None
             extra['process_batch_error'] = '{}: {}'.format(type(exc).__name__, exc)
             api = None
+
+    if not standin and world == 1 and not args.no_fast5_leg:
+        try:
+            extra['fast5_ingest'] = fast5_ingest_leg(args, base, which)
+        except Exception as exc:                       # reported, never hidden
+            extra['fast5_ingest'] = {'error': '{}: {}'.format(type(exc).__name__, exc)}
 
     line = {
         'metric': wl_metric,

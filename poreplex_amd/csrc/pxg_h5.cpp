@@ -544,20 +544,26 @@ struct pxg_h5 {
     // undo the filter pipeline of one chunk: `in` -> out (exactly want bytes)
     void unfilter(const Dataset& d, const uint8_t* in, uint64_t in_len, uint32_t mask, uint8_t* out, uint64_t want) const
     {
-        std::vector<uint8_t> cur(in, in + in_len);
+        std::vector<uint8_t> cur;
+        // (the first stage reads the mapped chunk itself: no copy of the compressed bytes)
+        struct View { const uint8_t* p; size_t n; };
+        bool first = true;
+        auto src = [&]() { return first ? View{ in, (size_t)in_len } : View{ cur.data(), cur.size() }; };
         for (int f = (int)d.filters.size() - 1; f >= 0; f--) {
             if (mask & (1u << f)) continue;
             const Filter& fl = d.filters[f];
+            if (first && (fl.id == 2 || fl.id == 3)) { cur.assign(in, in + in_len); first = false; }
             if (fl.id == 1) {                                          // deflate
                 std::vector<uint8_t> dst(want ? want : 1);
                 for (;;) {
                     uLongf got = (uLongf)dst.size();
-                    const int rc = uncompress(dst.data(), &got, cur.data(), (uLong)cur.size());
+                    const int rc = uncompress(dst.data(), &got, src().p, (uLong)src().n);
                     if (rc == Z_OK) { dst.resize(got); break; }
                     if (rc != Z_BUF_ERROR || dst.size() > (1ull << 33)) fail(PXG_E_INVALID, "HDF5: deflate stream is corrupt");
                     dst.resize(dst.size() * 2);
                 }
                 cur.swap(dst);
+                first = false;
             } else if (fl.id == 2) {
                 unshuffle(cur, fl.cd.empty() ? d.type.size : fl.cd[0]);
             } else if (fl.id == 3) {
@@ -575,32 +581,57 @@ struct pxg_h5 {
                 if (!zstd().decompress) fail(PXG_E_UNSUPPORTED, "VBZ: libzstd.so.1 is not on this host");
                 static const uint8_t MAGIC[4] = { 0x28, 0xB5, 0x2F, 0xFD };
                 size_t skip = 0;
-                if (cur.size() >= 8 && memcmp(cur.data(), MAGIC, 4) && memcmp(cur.data() + 4, MAGIC, 4) == 0) skip = 4;
+                const View zin = src();
+                if (zin.n >= 8 && memcmp(zin.p, MAGIC, 4) && memcmp(zin.p + 4, MAGIC, 4) == 0) skip = 4;
                 const uint64_t n = want / 2;
                 std::vector<uint8_t> svb((version ? (n + 7) / 8 + 2 * n : (n + 3) / 4 + 4 * n) + 16);
-                const size_t got = zstd().decompress(svb.data(), svb.size(), cur.data() + skip, cur.size() - skip);
+                const size_t got = zstd().decompress(svb.data(), svb.size(), zin.p + skip, zin.n - skip);
                 if (zstd().is_error(got)) fail(PXG_E_INVALID, "VBZ: zstd stream is corrupt");
                 const size_t keys = version ? (n + 7) / 8 : (n + 3) / 4;
                 if (got < keys) fail(PXG_E_INVALID, "VBZ: stream shorter than its control bits");
                 std::vector<uint8_t> dst(want);
                 const uint8_t* data = svb.data() + keys;
+                const size_t n_data = got - keys;
+                uint16_t* o16 = (uint16_t*)dst.data();
                 size_t pos = 0;
                 uint32_t prev = 0;
-                for (uint64_t i = 0; i < n; i++) {
+                uint64_t i = 0;
+                if (version == 1) {
+                    // eight samples per control byte; the byte offsets inside the group come from
+                    // the bits below each sample (no data-dependent branch per sample)
+                    for (; i + 8 <= n; i += 8) {
+                        const unsigned key = svb[i >> 3];
+                        const size_t group = 8 + (size_t)__builtin_popcount(key);
+                        if (pos + group > n_data) fail(PXG_E_INVALID, "VBZ: stream ends inside a sample");
+                        const uint8_t* g = data + pos;
+                        unsigned at_ = 0;
+                        for (unsigned q = 0; q < 8; q++) {
+                            const unsigned two = (key >> q) & 1u;
+                            uint32_t v = g[at_] | ((uint32_t)(g[at_ + two] & (0u - two)) << 8);
+                            at_ += 1 + two;
+                            if (zig) v = (v >> 1) ^ (0u - (v & 1));
+                            prev += v;
+                            o16[i + q] = (uint16_t)prev;
+                        }
+                        pos += group;
+                    }
+                }
+                for (; i < n; i++) {
                     const unsigned nb = version ? 1 + ((svb[i >> 3] >> (i & 7)) & 1) : 1 + ((svb[i >> 2] >> (2 * (i & 3))) & 3);
-                    if (keys + pos + nb > got) fail(PXG_E_INVALID, "VBZ: stream ends inside a sample");
+                    if (pos + nb > n_data) fail(PXG_E_INVALID, "VBZ: stream ends inside a sample");
                     uint32_t v = 0;
                     for (unsigned b = 0; b < nb; b++) v |= (uint32_t)data[pos++] << (8 * b);
                     if (zig) v = (v >> 1) ^ (0u - (v & 1));
                     prev += v;                                   // delta from the previous sample (first: from 0)
-                    dst[2 * i] = (uint8_t)prev; dst[2 * i + 1] = (uint8_t)(prev >> 8);
+                    o16[i] = (uint16_t)prev;
                 }
                 cur.swap(dst);
+                first = false;
             } else
                 fail(PXG_E_UNSUPPORTED, "HDF5: filter " + std::to_string(fl.id) + " is not read");
         }
-        if (cur.size() < want) fail(PXG_E_INVALID, "HDF5: chunk holds fewer bytes than its dataset");
-        memcpy(out, cur.data(), want);
+        if (src().n < want) fail(PXG_E_INVALID, "HDF5: chunk holds fewer bytes than its dataset");
+        memcpy(out, src().p, want);
     }
 
     void chunk_btree(const Dataset& d, uint64_t node, int depth, uint8_t* out, uint64_t total_el) const

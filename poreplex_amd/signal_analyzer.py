@@ -107,7 +107,13 @@ class SignalAnalyzer(AbstractContextManager):
         self.inputdir, self.outputdir = config['inputdir'], config['outputdir']
         self.batchid, self.formatted_batchid = batchid, format(batchid, '08d')
         if config.get('dump_adapter_signals') or config.get('dump_basecalls'):
-            raise NotImplementedError('HDF5 dump outputs are outside the hot path')
+            # signal_analyzer.py:155-211,450-466: per-worker HDF5 debug dumps (adapter-dumps/part-*.h5,
+            # events/part-*.h5).  Fenced, loudly and before any read is touched: the worker call
+            # returns the fatal (-1, message, traceback) tuple (tests/test_facade.py); the pooled +
+            # scaled adapter slice itself is available through the pxg_pool_scale hook.
+            raise NotImplementedError(
+                '--dump-adapter-signals / --dump-basecalls (per-worker HDF5 debug dumps) are not '
+                'produced by the GPU path; run without them (see DESIGN.md section 7)')
         self.loader.stage_mask = (
             native.STAGE_SCALER | native.STAGE_SEGMENT
             | (native.STAGE_BARCODE if config['barcoding'] else 0)

@@ -171,13 +171,17 @@ class Trainer:
             self.net.train()
             perm = train[torch.randperm(len(train), generator=g)]
             per_rank = (len(perm) + self.world - 1) // self.world
-            mine = perm[self.rank * per_rank:(self.rank + 1) * per_rank]
+            if len(perm) == 0:
+                raise ValueError('no training samples left after the validation split')
+            # every rank gets exactly per_rank samples: the permutation wraps around (what
+            # DistributedSampler does), so no rank ever steps on an empty or shorter batch -- an
+            # empty batch is a NaN loss that DDP all-reduces into every rank's weights
+            wrapped = perm[torch.arange(self.world * per_rank) % len(perm)]
+            mine = wrapped[self.rank * per_rank:(self.rank + 1) * per_rank]
             steps = (per_rank + self.batch_size - 1) // self.batch_size      # same on every rank
             total, count = 0.0, 0
             for k in range(steps):
                 idx = mine[k * self.batch_size:(k + 1) * self.batch_size]
-                if len(idx) == 0:                      # ragged tail: keep the collectives in step
-                    idx = mine[:1]
                 xb, yb = x[idx].to(self.device), y[idx].to(self.device)
                 self.opt.zero_grad(set_to_none=True)
                 loss = self.loss_fn(self.net(xb), yb)

@@ -111,6 +111,17 @@ def test_missing_gpu_is_fatal_tuple_not_fallback(ref_results, monkeypatch):
     WorkerPersistenceStorage.reset()
 
 
+@pytest.mark.parametrize('option', ['dump_adapter_signals', 'dump_basecalls'])
+def test_dump_options_are_fenced_before_any_read_is_touched(oracle_backed, ref_results, option):
+    """The one place the operator surface says no (signal_analyzer.py:155-211,450-466: HDF5 debug
+    dumps): the call fails as a WHOLE, with the reference's fatal-tuple convention and a message
+    that names the option -- never a silent run without the dump."""
+    from poreplex_amd.signal_analyzer import process_batch
+    out = process_batch(1, [tuple(r) for r in ref_results['reads'][:4]], facade_config(ref_results, **{option: True}))
+    assert isinstance(out, tuple) and out[0] == -1
+    assert 'NotImplementedError' in out[1] and 'dump' in out[1]
+
+
 def test_barcoding_quality_filter_guard(oracle_backed, ref_results):
     from poreplex_amd.signal_analyzer import process_batch
     out = process_batch(1, [], facade_config(ref_results, barcoding_quality_filter=40))
