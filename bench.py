@@ -101,7 +101,7 @@ def parse(argv=None):
     ap.add_argument('--in-flight', type=int, default=5,
                     help='process_batch leg: worker calls in flight (threads of this process; the '
                          "reference's `parallel`, pipeline.py:96)")
-    ap.add_argument('--api-calls', type=int, default=8, help='process_batch leg: timed calls')
+    ap.add_argument('--api-calls', type=int, default=16, help='process_batch leg: timed calls')
     ap.add_argument('--no-api-leg', action='store_true', help='skip the process_batch leg of the default line')
     ap.add_argument('--no-configs4', action='store_true',
                     help='N > 1, weak scaling: skip the extra strong-scaling leg (BASELINE configs[4]: '
@@ -569,6 +569,43 @@ def strong_leg(args, ctx, dist, rank, world, mask, standin, force_dist, barrier)
             'reads_ok_this_rank': int((res['status'] == 0).sum())}
 
 
+FLIPS_FILE = os.path.join('profiles', 'r03', 'decision_flips.json')
+
+
+def unpinned_rows_block():
+    """Rows whose third-party numerics (TensorFlow LSTMs: a4, a12; pomegranate Viterbi: a7) cannot
+    run in this image: "GPU == oracle" above proves the kernels, not the restatement.  What a
+    different-but-correct implementation could move is MEASURED by tests/test_decision_flips.py
+    (2 048 bench reads + 512 chimeras; float64 / longdouble Keras equations, every formula variant
+    of the pomegranate Viterbi); the committed numbers of that measurement ride along here --
+    static, from the file named, not re-measured by this run."""
+    out = {'unpinned_rows': ['a4', 'a7', 'a12']}
+    try:
+        with open(os.path.join(ROOT, FLIPS_FILE)) as fh:
+            d = json.load(fh)
+        ls, vs = d['lstm_side'], d['viterbi_side']
+        worst = {k: max(v[k] for v in vs['variants']) for k in (
+            'reads_with_a_segment_boundary_moved', 'adapter_found_flips',
+            'bench_reads_candidate_list_changed', 'chimera_reads_candidate_list_changed')}
+        out['unpinned_decision_flips'] = {
+            'source': 'static: {} (python tests/test_decision_flips.py)'.format(FLIPS_FILE),
+            'a4_a12_exact_float64_networks_vs_canonical_float32': {
+                'reads': ls['reads'], 'scaling_qc_flips': ls['scaling_qc_flips'],
+                'reads_with_a_segment_boundary_moved': ls['reads_with_a_segment_boundary_moved'],
+                'argmax_flips': ls['argmax_flips'],
+                'called_uncalled_flips_at_threshold': ls['called_uncalled_flips_at_threshold'],
+                'softmax_max_abs_diff_whole_pipeline': ls['softmax_max_abs_diff_whole_pipeline']},
+            'a7_viterbi_formula_variants': dict(
+                worst, variants=len(vs['variants']), reads_segmented=vs['reads_segmented'],
+                scan_windows=vs['scan_windows'], chimera_reads=vs['reads_scanned']['chimera'],
+                meaning='worst count over the variants (mixture as logsumexp / log-sum of pdfs, textbook '
+                        'log-pdf, bake() renormalisation, preset in-edge order, all at once, float64 and '
+                        'longdouble)')}
+    except (OSError, KeyError, ValueError):
+        out['unpinned_decision_flips'] = None
+    return out
+
+
 def make_context(args, config, local_rank):
     if args.context_factory:
         import importlib
@@ -696,6 +733,7 @@ def main():
     stage_acc = {k: 0.0 for k in N.TIMER_NAMES}
     t0 = time.perf_counter()
     pending, prev = None, None
+    step_done = [t0]
     for _ in range(args.steps):
         step()                           # enqueue this step's kernels
         if prev is not None:
@@ -706,6 +744,7 @@ def main():
                 labels = pending()
             pending = gather_labels_start(prev, dist, first_index=lo, sizes=shard_sizes, force=force_dist)
         res = ctx.download(res_buf)      # D2H of the result records is part of a step
+        step_done.append(time.perf_counter())
         prev = res
         times, _ = ctx.stage_times()
         for k in stage_acc:
@@ -803,6 +842,9 @@ def main():
         'barcode_called': int((res['bc_called'] == 1).sum()),
         'barcode_called_correct': int(((res['bc_called'] == 1) & (res['bc_label'] == truth_barcode)).sum()),
         'barcode_planted': int((truth_barcode >= 0).sum()),
+        # wall time of each step of the timed loop (records of step k on the host), this rank
+        'step_ms': {k: round(float(f(np.diff(step_done))) * 1e3, 4)
+                    for k, f in (('min', np.min), ('median', np.median), ('max', np.max))},
         'labels_gathered': int(len(labels)),
         'labels_read_index_unique': bool(len(np.unique(labels['read_index'])) == len(labels)),
         'ranks_counted_by_collective': n_ranks,
@@ -881,6 +923,7 @@ def main():
         }
         if cand_mismatch is not None:
             concordance['unsplit_candidate_mismatch'] = cand_mismatch
+        concordance.update(unpinned_rows_block())
         if world > 1:
             cpu = None
 

@@ -515,6 +515,7 @@ int64_t pxg_h5_n_reads(const pxg_h5* file);
 int pxg_h5_is_multi(const pxg_h5* file);
 int pxg_h5_read_id(const pxg_h5* file, int64_t i, char* out, int64_t cap);
 int pxg_h5_info(const pxg_h5* file, int64_t first, int64_t n, pxg_h5_read_info* out);
+int pxg_h5_info_mt(const pxg_h5* file, int64_t first, int64_t n, pxg_h5_read_info* out, int32_t threads);
 /* text = sequence '\n' quality string; move = the Move table / the Events table's move column */
 int pxg_h5_basecall(const pxg_h5* file, int64_t i, int64_t text_cap, char* text, int64_t move_cap,
                     uint8_t* move, double* p_model_state_or_null, int32_t* has_p_model_state);

@@ -948,12 +948,16 @@ extern "C" int pxg_h5_read_id(const pxg_h5* h, int64_t i, char* out, int64_t cap
     H5_GUARD_END(h)
 }
 
-// metadata + basecall summary of reads [first, first + n); a read that cannot be described gets
-// status != 0 (its own error, as data) and the others are still filled
-extern "C" int pxg_h5_info(const pxg_h5* h, int64_t first, int64_t n, pxg_h5_read_info* out)
+template <typename Fn>
+static void run_pool(int64_t n, int threads, Fn fn);
+
+// metadata + basecall summary of reads [first, first + n) on `threads` host threads (a 4 000-read
+// file is ~60 000 object headers); a read that cannot be described gets status != 0 (its own error,
+// as data) and the others are still filled
+extern "C" int pxg_h5_info_mt(const pxg_h5* h, int64_t first, int64_t n, pxg_h5_read_info* out, int32_t threads)
 {
     if (!h || first < 0 || n < 0 || first + n > (int64_t)h->reads.size() || (n && !out)) return PXG_E_INVALID;
-    for (int64_t k = 0; k < n; k++) {
+    run_pool(n, threads, [&](int64_t k) {
         pxg_h5_read_info& o = out[k];
         try {
             info_of(h, h->reads[(size_t)(first + k)], o);
@@ -965,8 +969,13 @@ extern "C" int pxg_h5_info(const pxg_h5* h, int64_t first, int64_t n, pxg_h5_rea
             o.status = PXG_E_NOMEM;
             put(o.error, sizeof(o.error), e.what(), true);
         }
-    }
+    });
     return PXG_OK;
+}
+
+extern "C" int pxg_h5_info(const pxg_h5* h, int64_t first, int64_t n, pxg_h5_read_info* out)
+{
+    return pxg_h5_info_mt(h, first, n, out, 1);
 }
 
 // sequence + '\n' + quality string, Move / Events `move' column, p_model_state of one read

@@ -317,7 +317,7 @@ class Fast5File:
         if self._info is None:
             from . import native
             out = np.zeros(self.n, dtype=native.H5_INFO_DTYPE)
-            rc = self.lib.pxg_h5_info(self.handle, 0, self.n, out.ctypes.data)
+            rc = self.lib.pxg_h5_info_mt(self.handle, 0, self.n, out.ctypes.data, host_threads())
             if rc:
                 raise Fast5Error('pxg_h5_info failed ({})'.format(rc))
             self._info = out
