@@ -45,7 +45,7 @@ PEAK_HBM = 8.0e12              # B/s
 # the only throughput the reference publishes (Poreplex 0.1, whole
 # pipeline incl. FAST5 I/O, 2x Xeon E5-2687W v3 = 20 cores): 1 339 070 reads in 1 h 37 min
 PUBLISHED_READS_PER_S = 1339070 / (97 * 60.0)
-TRAFFIC_FILE = os.path.join('profiles', 'r02', 'hbm_traffic.json')
+TRAFFIC_FILE = os.path.join('profiles', 'r03', 'hbm_traffic.json')
 
 STAGES = {
     'demux': (2, 'a1-a13 (scaler LSTM + Viterbi + barcode LSTMs)', 'reads/s (segment+barcode)'),
