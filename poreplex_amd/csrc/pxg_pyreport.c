@@ -209,6 +209,10 @@ static PyObject* report(PyObject* self, PyObject* args)
                 PyObject* z = q ? PyLong_FromLong(0) : NULL;
                 PyObject* t = z ? PyTuple_Pack(3, s, q, z) : NULL;
                 Py_XDECREF(s); Py_XDECREF(q); Py_XDECREF(z);
+                /* (str, str, int) cannot be part of a cycle: what the collector itself would find out on
+                 * its first pass.  An untracked tuple also leaves the read's dict untracked, so a batch
+                 * of plain results costs the cyclic collector nothing at all. */
+                if (t) PyObject_GC_UnTrack(t);
                 SET(d, KEYS[K_SEQUENCE], t);
             }
             if (!(o = item(error_message, i))) goto fail_row;
@@ -259,12 +263,18 @@ static PyObject* report(PyObject* self, PyObject* args)
                     const float* row = (const float*)spikes.view.buf + ((size_t)at + s) * 4;
                     PyObject* t = Py_BuildValue("(dddd)", (double)row[0], (double)row[1], (double)row[2], (double)row[3]);
                     if (!t) { bad = 1; break; }
+                    PyObject_GC_UnTrack(t);                  /* four floats */
                     PyList_SET_ITEM(lst, s, t);
                 }
                 if (lst) bad |= PyDict_SetItem(p, KEYS[K_SPIKES], lst) < 0;
                 Py_XDECREF(lst);
                 if (bad) { Py_DECREF(p); goto fail_row; }
                 SET(d, KEYS[K_POLYA], p);
+                /* no cycle can run through these (dict -> dict -> list -> tuples of floats).  A dict
+                 * tracks itself again the moment somebody stores a container in it; the spike list stays
+                 * tracked, so the collector still sees everything a caller could later tie into a cycle. */
+                PyObject_GC_UnTrack(p);
+                PyObject_GC_UnTrack(d);
             }
             PyList_SET_ITEM(out, k, d);
             continue;

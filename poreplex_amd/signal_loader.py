@@ -662,12 +662,17 @@ class SignalLoader:
         the bundle; stays pinned for the life of the worker (unpin_bundle)."""
         if self.bundle is None or self._pinned:
             return
-        d = self.bundle.d
-        arrays = [d['arena_z'], d['z_chunks']] if self.bundle.compressed else [d['arena']]
-        for a in arrays:
-            if a.nbytes:
-                self.ctx.pin(a)
-                self._pinned.append(a)
+        with self._stage_lock:           # worker calls may start on several threads at once
+            if self._pinned:
+                return
+            d = self.bundle.d
+            arrays = [d['arena_z'], d['z_chunks']] if self.bundle.compressed else [d['arena']]
+            pinned = []
+            for a in arrays:
+                if a.nbytes:
+                    self.ctx.pin(a)
+                    pinned.append(a)
+            self._pinned = pinned
 
     def unpin_bundle(self):
         pinned, self._pinned = self._pinned, []
