@@ -127,7 +127,8 @@ struct pxg_h5_read {               // one read of an open file
 struct pxg_h5 {
     int fd = -1;
     const uint8_t* p = nullptr;
-    size_t n = 0;
+    size_t n = 0, map_len = 0;
+    static constexpr size_t SLACK = 1 << 16;     // zero bytes mapped behind the file
     uint64_t base = 0;
     int so = 8, sl = 8;            // size of offsets / lengths
     uint64_t root = UNDEF;
@@ -239,15 +240,17 @@ struct pxg_h5 {
                     const int nd = q[2];
                     d.addr = off_at(q + 3);
                     d.chunk.clear();
+                    if (3 + (size_t)so + 4 * (size_t)nd > size) fail(PXG_E_INVALID, "HDF5: layout message too short");
                     for (int k = 0; k + 1 < nd; k++) d.chunk.push_back(rd(q + 3 + so + 4 * k, 4));
                 } else fail(PXG_E_UNSUPPORTED, "HDF5: virtual datasets are not read");
             } else if (ver == 4) {
                 const int cls = q[1];
-                if (cls == 0) { d.layout = 0; d.size = rd(q + 2, 2); d.compact = q + 4; }
+                if (cls == 0) { d.layout = 0; d.size = rd(q + 2, 2); d.compact = q + 4; if (4 + d.size > size) fail(PXG_E_INVALID, "HDF5: compact data runs off the message"); }
                 else if (cls == 1) { d.layout = 1; d.addr = off_at(q + 2); d.size = len_at(q + 2 + so); }
                 else if (cls == 2) {
                     const int flags = q[2], nd = q[3], enc = q[4];
                     size_t a = 5;
+                    if (enc < 1 || enc > 8 || a + (size_t)nd * enc + 1 + 2 * (size_t)sl + so > size + 16) fail(PXG_E_INVALID, "HDF5: layout message too short");
                     d.chunk.clear();
                     for (int k = 0; k < nd; k++, a += enc)
                         if (k + 1 < nd) d.chunk.push_back(rd(q + a, enc));
@@ -268,10 +271,11 @@ struct pxg_h5 {
                 size_t a = 8;
                 if (cls != 0) { d.addr = off_at(q + a); a += so; }
                 std::vector<uint64_t> dd;
+                if (a + 4 * (size_t)nd + 4 > size + 8) fail(PXG_E_INVALID, "HDF5: layout message too short");
                 for (int k = 0; k < nd; k++, a += 4) dd.push_back(rd(q + a, 4));
                 if (cls == 1) { d.layout = 1; d.size = 0; }
                 else if (cls == 2) { d.layout = 2; d.chunk.assign(dd.begin(), dd.end() - (dd.empty() ? 0 : 1)); }
-                else { d.layout = 0; d.size = rd(q + a, 4); d.compact = q + a + 4; }
+                else { d.layout = 0; d.size = rd(q + a, 4); d.compact = q + a + 4; if (a + 4 + d.size > size) fail(PXG_E_INVALID, "HDF5: compact data runs off the message"); }
             } else fail(PXG_E_UNSUPPORTED, "HDF5: unknown data layout message version");
             break;
         }
@@ -288,6 +292,7 @@ struct pxg_h5 {
                 a += 2;                                               // flags
                 const int ncd = (int)rd(q + a, 2); a += 2;
                 a += ver == 1 ? ((name_len + 7) & ~(size_t)7) : name_len;
+                if (a + 4 * (size_t)ncd > size) fail(PXG_E_INVALID, "HDF5: filter pipeline runs off the message");
                 for (int c = 0; c < ncd; c++, a += 4) fl.cd.push_back((uint32_t)rd(q + a, 4));
                 if (ver == 1 && (ncd & 1)) a += 4;
                 if (a > size) fail(PXG_E_INVALID, "HDF5: filter pipeline runs off the message");
@@ -662,10 +667,20 @@ struct pxg_h5 {
         }
     }
 
+    // A size that comes out of the file and is about to be allocated: no dataset of this file can
+    // hold more than its bytes times the best ratio of the filters read here (deflate: ~1030)
+    void sane_bytes(uint64_t n_el, uint64_t esz) const
+    {
+        const uint64_t cap = (uint64_t)n * 1100 + 65536;
+        if (esz == 0 || n_el > cap || n_el * esz > cap)
+            fail(PXG_E_INVALID, "HDF5: a dataset claims more bytes than this file could hold (corrupt dimensions)");
+    }
+
     // all bytes of a (1-D or scalar) dataset, fixed-size elements
     void read_dataset(const Dataset& d, uint8_t* out, uint64_t out_bytes) const
     {
         const uint64_t n_el = d.n_elements(), esz = d.type.size, total = n_el * esz;
+        sane_bytes(n_el, esz ? esz : 1);
         if (total != out_bytes) fail(PXG_E_INVALID, "HDF5: dataset size differs from what its reader expects");
         if (!total) return;
         if (d.dims.size() > 1) fail(PXG_E_UNSUPPORTED, "HDF5: datasets of more than one dimension are not read");
@@ -679,10 +694,12 @@ struct pxg_h5 {
             memset(out, 0, total);
             if (d.addr == UNDEF) return;
             if (d.chunk.size() != 1 || !d.chunk[0]) fail(PXG_E_UNSUPPORTED, "HDF5: chunked datasets must be one-dimensional");
+            sane_bytes(d.chunk[0], esz);
             chunk_btree(d, d.addr, 0, out, n_el);
             return;
         case 3: {
             if (d.chunk.size() != 1) fail(PXG_E_UNSUPPORTED, "HDF5: chunked datasets must be one-dimensional");
+            sane_bytes(d.chunk[0], esz);
             const uint64_t cbytes = d.chunk[0] * esz;
             if (d.filters.empty()) { memcpy(out, at(d.addr, total), total); return; }
             std::vector<uint8_t> whole(cbytes);
@@ -701,6 +718,7 @@ struct pxg_h5 {
     std::string dataset_string(const Dataset& d) const
     {
         if (d.type.cls == 3) {
+            sane_bytes(std::max<uint64_t>(d.n_elements(), 1), d.type.size);
             std::vector<uint8_t> buf((size_t)d.type.size * std::max<uint64_t>(d.n_elements(), 1));
             read_dataset(d, buf.data(), buf.size());
             return std::string((const char*)buf.data(), strnlen((const char*)buf.data(), d.type.size));
@@ -735,7 +753,7 @@ extern "C" const char* pxg_h5_last_error(void) { return t_h5_error.c_str(); }
 extern "C" void pxg_h5_close(pxg_h5* h)
 {
     if (!h) return;
-    if (h->p) munmap((void*)h->p, h->n);
+    if (h->p) munmap((void*)h->p, h->map_len);
     if (h->fd >= 0) close(h->fd);
     delete h;
 }
@@ -752,9 +770,14 @@ extern "C" int pxg_h5_open(const char* path, pxg_h5** out)
     struct stat st;
     if (fstat(h->fd, &st) || st.st_size < 64) fail(PXG_E_INVALID, std::string("Unable to open file '") + path + "' (file signature not found)");
     h->n = (size_t)st.st_size;
-    void* m = mmap(nullptr, h->n, PROT_READ, MAP_PRIVATE, h->fd, 0);
+    // The file is mapped over the head of a larger anonymous (zero) region: every structure's START
+    // is checked against the file size, and a fixed-size field read near the end of a truncated
+    // file then runs into zeros instead of off the map.
+    h->map_len = ((h->n + 4095) & ~(size_t)4095) + pxg_h5::SLACK;
+    void* m = mmap(nullptr, h->map_len, PROT_READ, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (m == MAP_FAILED) { h->p = nullptr; fail(PXG_E_NOMEM, "mmap failed"); }
     h->p = (const uint8_t*)m;
+    if (mmap(m, h->n, PROT_READ, MAP_PRIVATE | MAP_FIXED, h->fd, 0) == MAP_FAILED) fail(PXG_E_NOMEM, "mmap failed");
     static const uint8_t SIG[8] = { 0x89, 'H', 'D', 'F', '\r', '\n', 0x1a, '\n' };
     uint64_t sb = UNDEF;
     for (uint64_t o = 0; o + 64 <= h->n; o = o ? o * 2 : 512)
@@ -861,6 +884,10 @@ static void basecall_of(const pxg_h5* h, const pxg_h5_read& r, pxg_h5_read_info&
     size_t l4 = text.find('\n', l3 + 1);
     if (l4 == std::string::npos) l4 = text.size();
     o.bc_seq_len = (int64_t)(l2 - l1 - 1);
+    if (l4 - l3 - 1 != l2 - l1 - 1) fail(PXG_E_INVALID, "FAST5: Fastq sequence and quality lines differ in length");
+    for (size_t k = l1 + 1; k < l4; k++)                       // text columns downstream are ASCII by contract
+        if (k != l2 && k != l3 && (text[k] < 33 || text[k] > 126) && !(k > l2 && k < l3))
+            fail(PXG_E_INVALID, "FAST5: Fastq record holds bytes that are not printable ASCII");
     if (fastq) *fastq = text.substr(l1 + 1, l2 - l1 - 1) + "\n" + text.substr(l3 + 1, l4 - l3 - 1);
     const uint64_t sm = h->resolve(best_obj, "Summary/basecall_1d_template");
     if (sm == UNDEF) fail(PXG_E_INVALID, "FAST5: Summary/basecall_1d_template is missing");
@@ -884,6 +911,10 @@ static void basecall_of(const pxg_h5* h, const pxg_h5_read& r, pxg_h5_read_info&
         o.bc_table = (ncol <= 3 && mcol) ? 2 : (ncol == 14 ? 3 : 4);
         if (mcol) {
             const uint64_t n = d.n_elements();
+            h->sane_bytes(n, d.type.size);
+            if (mcol->size < 1 || mcol->size > 8 || (uint64_t)mcol->offset + mcol->size > d.type.size ||
+                (pcol && ((pcol->size != 4 && pcol->size != 8) || (uint64_t)pcol->offset + pcol->size > d.type.size)))
+                fail(PXG_E_INVALID, "FAST5: Events table columns lie outside its rows");
             std::vector<uint8_t> rows(n * d.type.size);
             h->read_dataset(d, rows.data(), rows.size());
             o.bc_n_moves = (int64_t)n;
@@ -905,6 +936,7 @@ static void basecall_of(const pxg_h5* h, const pxg_h5_read& r, pxg_h5_read_info&
         const Dataset d = h->object(mv).ds;
         if (d.type.cls != 0 || d.type.size != 1) fail(PXG_E_INVALID, "FAST5: Move is not a uint8 table");
         const uint64_t n = d.n_elements();
+        h->sane_bytes(n, 1);
         std::vector<uint8_t> local;
         std::vector<uint8_t>& buf = moves ? *moves : local;
         buf.resize(n);
@@ -936,6 +968,7 @@ static void info_of(const pxg_h5* h, const pxg_h5_read& r, pxg_h5_read_info& o)
     const Object sig = h->object(r.signal_obj);
     if (!sig.has_dataset || sig.ds.type.cls != 0 || sig.ds.type.size != 2)
         fail(PXG_E_INVALID, "FAST5: Signal is not a 16-bit integer dataset");
+    h->sane_bytes(sig.ds.n_elements(), 2);
     o.n_samples = (int64_t)sig.ds.n_elements();
 }
 

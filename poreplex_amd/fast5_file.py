@@ -346,7 +346,7 @@ class Fast5File:
                                       pms.ctypes.data, C.byref(has))
         if rc:
             raise Fast5Error((self.lib.pxg_h5_last_error() or b'').decode(errors='replace'))
-        seq, qual = text.value.decode('ascii').split('\n')
+        seq, qual = text.value.decode('ascii').split('\n')        # (validated printable ASCII by the library)
         kind = TABLE_KINDS[int(info['bc_table'])] or None
         return {'sequence': seq, 'qstring': qual, 'block_stride': int(info['bc_block_stride']),
                 'sequence_length': int(info['bc_sequence_length']),
