@@ -101,6 +101,13 @@ class GpuSession:
         self.world = dist.get_world_size() if dist is not None else 1
         self.batch_reads = int(batch_reads)
         self.logger = logger or logging.getLogger('poreplex')
+        # this rank's process -- loader thread, status rules, and by first touch the bundle arena and
+        # the staging arenas allocated from here on -- goes to the NUMA node of ITS GPU (N ranks staging
+        # ~57 GB/s each must not cross the socket interconnect); config['numa_bind'] = False opts out
+        self.numa = {'numa_node': None, 'cpus': None, 'pci': None}
+        if config.get('numa_bind', True) and native.NativeContext.__module__ == native.__name__:
+            device = int(config.get('device_id', os.environ.get('LOCAL_RANK', 0)))
+            self.numa = D.bind_to_gpu_numa(device)
         self.analyzer = SignalAnalyzer(config, batchid=self.rank)
         self.ctx, self.loader = self.analyzer.ctx, self.analyzer.loader
         self.timing = {'load_s': 0.0, 'gpu_wait_s': 0.0, 'facade_s': 0.0, 'sink_s': 0.0,
@@ -309,7 +316,7 @@ class GpuSession:
             self.dist.barrier()                                       # every part file is closed
         out = {'reads': int(counts.sum()), 'reads_this_rank': int(len(local)), 'wall_s': wall,
                'rank': self.rank, 'world': self.world, 'batches': len(batches),
-               'timing': dict(self.timing), 'labels': gathered, 'counts': counts}
+               'timing': dict(self.timing), 'labels': gathered, 'counts': counts, 'numa': self.numa}
         if self.rank == 0:
             self._stitch(outdir, 'sequencing_summary.txt')
             if fastq is not None:

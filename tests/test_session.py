@@ -244,11 +244,11 @@ def test_loader_exception_mid_run_unwinds_the_session(oracle_backed, tmp_path, m
     calls = {'n': 0}
     real = SignalAnalyzer.prepare
 
-    def flaky(self, reads, table=None):
+    def flaky(self, reads, table=None, reserve=None):
         calls['n'] += 1
         if calls['n'] == 3:
             raise OSError('input volume went away')
-        return real(self, reads, table)
+        return real(self, reads, table, reserve)
     monkeypatch.setattr(SignalAnalyzer, 'prepare', flaky)
     before = len(_threads_alive())
     sess = GpuSession(session_config(tmp_path, 'chimera.pxr.npz'), batch_reads=3)
@@ -314,11 +314,11 @@ ABORT_WORKER = textwrap.dedent("""
     rank = dist.get_rank()
     if rank == 1:                                   # rank 1 loses its input in its second batch
         real, calls = SignalAnalyzer.prepare, [0]
-        def flaky(self, reads, table=None):
+        def flaky(self, reads, table=None, reserve=None):
             calls[0] += 1
             if calls[0] == 2:
                 raise OSError('rank 1 lost its input')
-            return real(self, reads, table)
+            return real(self, reads, table, reserve)
         SignalAnalyzer.prepare = flaky
     t0 = time.perf_counter()
     try:
