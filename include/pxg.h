@@ -211,6 +211,7 @@ typedef struct {
     int32_t polya_n_spikes;               /* every spike event of the tail (polya.py:109-115); the
                                              rows themselves: pxg_batch_download_spikes          */
     int32_t polya_dwell_samples;          /* sum of poly(A)-event lengths        */
+    int32_t reserved32;                   /* 0 (no implicit padding: records compare byte for byte) */
     int64_t polya_begin, polya_end;       /* raw-sample coordinates              */
 } pxg_read_result;
 

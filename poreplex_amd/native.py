@@ -125,7 +125,7 @@ class PxgReadResult(C.Structure):
         ('probs', C.c_float * PXG_MAX_CLASSES),
         ('polya_called', C.c_int8), ('reserved8', C.c_int8), ('reserved16', C.c_int16),
         ('polya_n_spikes', C.c_int32),
-        ('polya_dwell_samples', C.c_int32),
+        ('polya_dwell_samples', C.c_int32), ('reserved32', C.c_int32),
         ('polya_begin', C.c_int64), ('polya_end', C.c_int64),
     ]
 
@@ -183,7 +183,7 @@ RESULT_DTYPE = np.dtype([
     ('bc_pushed', 'i1'), ('bc_called', 'i1'), ('bc_label', 'i1'), ('bc_phred', 'u1'),
     ('bc_score', '<f4'), ('probs', '<f4', (PXG_MAX_CLASSES,)),
     ('polya_called', 'i1'), ('reserved8', 'i1'), ('reserved16', '<i2'), ('polya_n_spikes', '<i4'),
-    ('polya_dwell_samples', '<i4'), ('polya_begin', '<i8'), ('polya_end', '<i8'),
+    ('polya_dwell_samples', '<i4'), ('reserved32', '<i4'), ('polya_begin', '<i8'), ('polya_end', '<i8'),
 ], align=True)
 CALIB_DTYPE = np.dtype([('range', '<f8'), ('digitisation', '<f8'),
                         ('offset', '<f8'), ('sampling_rate', '<f8')])
