@@ -14,7 +14,9 @@
  * buffer; nothing is retained after return (one exception: the arrays handed
  * to pxg_batch_stage are read until pxg_batch_swap returns); functions return 0 or a negative
  * pxg_error and never throw; per-read domain failures are DATA (the `status`
- * field), not errors.  A context is bound to one GPU and one host thread.
+ * field), not errors.  A context is bound to one GPU.  pxg_process_batch / pxg_process_batch_ex may be
+ * called from several host threads at once (the calls overlap on the device); every other entry point
+ * belongs to ONE host thread at a time.
  * Plain pointers and sizes only -- no torch / HIP types in any signature.
  */
 #ifndef PXG_H
