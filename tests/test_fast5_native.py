@@ -269,6 +269,27 @@ def test_session_from_fast5_equals_session_from_bundle(inputs, tmp_path, monkeyp
     assert a['labels'].tobytes() == b['labels'].tobytes() and np.array_equal(a['counts'], b['counts'])
 
 
+def test_converted_bundle_runs_like_the_files(inputs, tmp_path, monkeypatch):
+    """tools/fast5_to_bundle.py: FAST5 directory -> encoded read bundle, once; the session from
+    that bundle writes what the session from the files writes."""
+    import importlib.util
+    from oracle_context import OracleBackedContext
+    monkeypatch.setattr(N, 'NativeContext', OracleBackedContext)
+    spec = importlib.util.spec_from_file_location('fast5_to_bundle', os.path.join(ROOT, 'tools', 'fast5_to_bundle.py'))
+    tool = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tool)
+    top, t = inputs
+    out = str(tmp_path / 'converted.pxr.npz')
+    n, skipped = tool.convert(top, out, compress=True, log=lambda *a: None)
+    assert n == len(t['ids']) and not skipped
+    a, files_a = session_outputs(tmp_path / 'from_fast5', 9, inputdir=top)
+    b, files_b = session_outputs(tmp_path / 'from_converted', 9, inputdir='/nonexistent', read_bundle=out)
+    assert files_a.keys() == files_b.keys()
+    for name in files_a:
+        assert files_a[name] == files_b[name], name
+    assert a['labels'].tobytes() == b['labels'].tobytes()
+
+
 @pytest.mark.gpu
 def test_two_thousand_fast5_reads_through_the_gpu_session(tmp_path):
     """>= 2000 synthetic single- and multi-read FAST5 reads written on the box, streamed through
