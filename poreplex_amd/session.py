@@ -66,7 +66,7 @@ def enumerate_reads(config, bundle=None):
 class _Staging:
     """One int16 staging arena.  The loader thread only allocates (reserve); page-locking
     happens on the session's thread right before the copy (settle), because every call into
-    the GPU context belongs to one host thread (include/pxg.h)."""
+    the split calls of a GPU context belong to one host thread (include/pxg.h)."""
 
     def __init__(self, ctx):
         self.ctx, self.buf, self.pinned, self.retired = ctx, np.empty(0, dtype=np.int16), False, []
