@@ -165,8 +165,12 @@ struct pxg_h5 {
         t.size = (uint32_t)rd(q + 4, 4);
         size_t used = 8;
         switch (cls) {
-        case 0: t.is_signed = (bits >> 3) & 1; used += 4; break;
-        case 1: used += 12; break;
+        case 0:
+            if (bits & 1) fail(PXG_E_UNSUPPORTED, "HDF5: big-endian integers are not read");
+            t.is_signed = (bits >> 3) & 1; used += 4; break;
+        case 1:
+            if (bits & 1) fail(PXG_E_UNSUPPORTED, "HDF5: big-endian floats are not read");
+            used += 12; break;
         case 3: break;
         case 9: {
             t.vlen_string = (bits & 15) == 1;
