@@ -512,11 +512,14 @@ typedef struct {
     double bc_mean_qscore;
 } pxg_h5_read_info;
 int pxg_h5_open(const char* path, pxg_h5** out);
+int pxg_h5_open_mt(const char* path, int32_t threads, pxg_h5** out);   /* read groups walked on host threads */
 void pxg_h5_close(pxg_h5* file);
 const char* pxg_h5_last_error(void);                       /* of the calling thread */
 int64_t pxg_h5_n_reads(const pxg_h5* file);
 int pxg_h5_is_multi(const pxg_h5* file);
 int pxg_h5_read_id(const pxg_h5* file, int64_t i, char* out, int64_t cap);
+/* all ids, '\\n'-separated; returns the bytes needed (nothing written when that exceeds cap) */
+int64_t pxg_h5_read_ids(const pxg_h5* file, char* out, int64_t cap);
 int pxg_h5_info(const pxg_h5* file, int64_t first, int64_t n, pxg_h5_read_info* out);
 int pxg_h5_info_mt(const pxg_h5* file, int64_t first, int64_t n, pxg_h5_read_info* out, int32_t threads);
 /* text = sequence '\n' quality string; move = the Move table / the Events table's move column */

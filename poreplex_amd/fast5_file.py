@@ -275,7 +275,7 @@ class Fast5File:
         self.lib = native.load_text_library()
         self.path = path
         handle = C.c_void_p()
-        rc = self.lib.pxg_h5_open(os.fsencode(path), C.byref(handle))
+        rc = self.lib.pxg_h5_open_mt(os.fsencode(path), host_threads(), C.byref(handle))
         if rc:
             msg = (self.lib.pxg_h5_last_error() or b'').decode(errors='replace')
             err = Fast5Error(msg or 'Unable to open file {!r}'.format(path))
@@ -297,12 +297,11 @@ class Fast5File:
     def read_ids(self):
         if self._ids is None:
             import ctypes as C
-            buf = C.create_string_buffer(256)
-            ids = []
-            for i in range(self.n):
-                if self.lib.pxg_h5_read_id(self.handle, i, buf, 256):
-                    raise Fast5Error((self.lib.pxg_h5_last_error() or b'').decode(errors='replace'))
-                ids.append(buf.value.decode())
+            need = int(self.lib.pxg_h5_read_ids(self.handle, None, 0))
+            buf = C.create_string_buffer(max(need, 1))
+            if self.lib.pxg_h5_read_ids(self.handle, buf, need) != need:
+                raise Fast5Error('pxg_h5_read_ids failed')
+            ids = buf.raw[:need].decode().split('\n')[:-1] if need else []
             self._ids = ids
             self._index = {r: i for i, r in enumerate(ids)}
         return self._ids

@@ -355,11 +355,13 @@ _TEXT_SIGNATURES = {      # libpxghost.so: host-only helpers (sink text, sample 
     'pxg_z_decode': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     'pxg_z_validate': (C.c_int, [C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     'pxg_h5_open': (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    'pxg_h5_open_mt': (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]),
     'pxg_h5_close': (None, [C.c_void_p]),
     'pxg_h5_last_error': (C.c_char_p, []),
     'pxg_h5_n_reads': (C.c_int64, [C.c_void_p]),
     'pxg_h5_is_multi': (C.c_int, [C.c_void_p]),
     'pxg_h5_read_id': (C.c_int, [C.c_void_p, C.c_int64, C.c_char_p, C.c_int64]),
+    'pxg_h5_read_ids': (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
     'pxg_h5_info': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     'pxg_h5_info_mt': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32]),
     'pxg_h5_basecall': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p,
