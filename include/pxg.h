@@ -345,6 +345,12 @@ int pxg_batch_download(pxg_ctx* ctx, pxg_read_result* out);
  * read r (offsets has n_reads + 1 entries and is always filled; offsets[n_reads] = the sum of the
  * records' polya_n_spikes).  PXG_E_NOMEM when cap_rows is smaller than that (no row written). */
 int pxg_batch_download_spikes(pxg_ctx* ctx, int64_t cap_rows, pxg_polya_spike* out, int64_t* offsets);
+/* The pooled + scaled signal (a5, load_signal(pool=stride) with the scale / shift of the last
+ * run) of ONE stretch per read of the resident batch -- dump_adapter_signal's
+ * signal[adapter_first : adapter_last + 1] (signal_analyzer.py:450-466): read r contributes the
+ * pooled positions first[r] ... into out[out_offsets[r] : out_offsets[r + 1]] (n + 1 offsets from
+ * 0; an empty stretch leaves a read out).  Only for reads the scaler stage succeeded on. */
+int pxg_batch_pooled_signal(pxg_ctx* ctx, const int64_t* first, const int64_t* out_offsets, float* out);
 int pxg_batch_times(pxg_ctx* ctx, pxg_stage_times* out);
 
 /* ---- per-stage hooks (parity tests call these through the same ABI) ------ */

@@ -229,6 +229,46 @@ int pxg_launch_pool_scale(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int
     return PXG_OK;
 }
 
+// The same pooled + scaled signal for ONE stretch per read of the resident batch (the adapter
+// stretch of dump_adapter_signal, signal_analyzer.py:450-466): read r contributes the pooled
+// positions [first[r], first[r] + (ooff[r+1] - ooff[r])).  A stretch that leaves the read raises
+// the flag and writes nothing.
+__global__ void k_pooled_stretch(int64_t n_reads, const int16_t* __restrict__ raw,
+                                 const int64_t* __restrict__ off, const pxg_calib* __restrict__ cal,
+                                 const float* __restrict__ ss, const int64_t* __restrict__ first,
+                                 const int64_t* __restrict__ ooff, int stride, float* __restrict__ out,
+                                 int* __restrict__ flag)
+{
+    const int64_t r = blockIdx.x;
+    if (r >= n_reads) return;
+    const int64_t len = ooff[r + 1] - ooff[r];
+    if (len <= 0) return;
+    const int64_t P = (off[r + 1] - off[r]) / stride, p0 = first[r];
+    if (p0 < 0 || p0 + len > P) {
+        if (threadIdx.x == 0 && blockIdx.y == 0) atomicExch(flag, 1);
+        return;
+    }
+    const pxg_calib c = cal[r];
+    const double k = c.range / c.digitisation;
+    const float scale = ss[2 * r], shift = ss[2 * r + 1];
+    for (int64_t j = blockIdx.y * (int64_t)blockDim.x + threadIdx.x; j < len;
+         j += (int64_t)gridDim.y * blockDim.x) {
+        float m = pxg_block_mean(raw + off[r] + (p0 + j) * stride, stride, k, c.offset);
+        float y = scale * m;
+        out[ooff[r] + j] = y + shift;
+    }
+}
+
+int pxg_launch_pooled_stretch(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
+                              const pxg_calib* cal, const float* ss, const int64_t* first,
+                              const int64_t* ooff, float* out, int* flag)
+{
+    if (n <= 0) return PXG_OK;
+    hipLaunchKernelGGL(k_pooled_stretch, dim3((unsigned)n, 4), dim3(256), 0, ctx->stream, n, raw, off, cal,
+                       ss, first, ooff, ctx->cfg.stride, out, flag);
+    return PXG_OK;
+}
+
 // ---------------------------------------------------------------------------
 // a4: fl(fl(fl32(std)*p) + fl32(mean)); QC against float32-rounded bounds,
 // inclusive.  Rows come from the compacted index list (idx == nullptr: identity).

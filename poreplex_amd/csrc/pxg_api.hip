@@ -1007,6 +1007,38 @@ extern "C" int pxg_pool_scale(pxg_ctx* ctx, int64_t n, const int16_t* raw, const
     HOOK_END
 }
 
+extern "C" int pxg_batch_pooled_signal(pxg_ctx* ctx, const int64_t* first, const int64_t* out_offsets, float* out)
+{
+    HOOK_BEGIN
+    const int64_t n = ctx->n_reads;
+    if (n <= 0) return fail(ctx, PXG_E_STATE, "pxg_batch_pooled_signal: no resident batch");
+    if (!(ctx->last_stage_mask & (PXG_STAGE_SCALER | PXG_STAGE_SEGMENT)))    // (scale / shift: fitted or injected)
+        return fail(ctx, PXG_E_STATE, "pxg_batch_pooled_signal: nothing has been run on the resident batch");
+    if (!first || !out_offsets) return fail(ctx, PXG_E_INVALID, "pxg_batch_pooled_signal: bad arguments");
+    for (int64_t i = 0; i < n; i++)
+        if (out_offsets[i + 1] < out_offsets[i] || out_offsets[0] != 0)
+            return fail(ctx, PXG_E_INVALID, "pxg_batch_pooled_signal: out_offsets must start at 0 and not decrease");
+    const size_t total = (size_t)out_offsets[n];
+    if (!total) return PXG_OK;
+    if (!out) return fail(ctx, PXG_E_INVALID, "pxg_batch_pooled_signal: out is null");
+    int64_t* d_first = S.put(first, (size_t)n, ctx->stream);
+    int64_t* d_ooff = S.put(out_offsets, (size_t)n + 1, ctx->stream);
+    float* d_out = S.alloc<float>(total);
+    int* d_flag = S.alloc<int>(1);
+    HOOK_CHECK(d_first && d_ooff && d_out && d_flag);
+    PXG_HIP(ctx, hipMemsetAsync(d_flag, 0, sizeof(int), ctx->stream));
+    int rc = pxg_launch_pooled_stretch(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p, d_first, d_ooff,
+                                       d_out, d_flag);
+    if (rc) return rc;
+    int flag = 0;
+    HOOK_GET(out, d_out, total);
+    HOOK_GET(&flag, d_flag, 1);
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PXG_HIP(ctx, hipGetLastError());
+    if (flag) return fail(ctx, PXG_E_INVALID, "pxg_batch_pooled_signal: a stretch leaves its read");
+    return PXG_OK;
+}
+
 extern "C" int pxg_viterbi(pxg_ctx* ctx, int which_model, int64_t n, const float* signal_arena,
                            const int64_t* off, int32_t* seg_first, int32_t* seg_last,
                            int32_t* path_or_null, double* logp_or_null)

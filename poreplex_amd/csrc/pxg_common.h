@@ -380,6 +380,9 @@ int pxg_launch_raw_to_pa(pxg_ctx* ctx, int64_t n, const int16_t* raw, const pxg_
 int pxg_launch_pool_scale(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
                           const pxg_calib* cal, const float* ss, const int64_t* poff,
                           float* out);
+int pxg_launch_pooled_stretch(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
+                              const pxg_calib* cal, const float* ss, const int64_t* first,
+                              const int64_t* ooff, float* out, int* flag);
 int pxg_launch_scaler_transform(pxg_ctx* ctx, int64_t n, const float* pred, float* ss,
                                 int32_t* status, const int32_t* idx, const int32_t* count);
 // segmentation of raw reads (pool + scale + Viterbi + run summary)

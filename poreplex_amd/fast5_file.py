@@ -217,14 +217,30 @@ class _Fast5BatchBundle(ReadBundle):
 
     def __init__(self, d, batch):
         self.d, self.batch = d, batch
-        self.filenames = [str(f) for f in d['filename']]
-        self.read_ids = [str(r) for r in d['read_id']]
-        self.keys = list(zip(self.filenames, self.read_ids))
-        self.index = {key: i for i, key in enumerate(self.keys)}
-        self.by_file = {}
-        for i, f in enumerate(self.filenames):
-            self.by_file.setdefault(f, []).append(i)
+        self.filenames = batch.names
+        self.read_ids = batch.read_ids if batch.read_ids is not None else [str(r) for r in d['read_id']]
         self.broken = set()
+
+    # the lookup structures of a bundle on disk: built when somebody asks (the batch path does not)
+    @property
+    def keys(self):
+        if getattr(self, '_keys', None) is None:
+            self._keys = list(zip(self.filenames, self.read_ids))
+        return self._keys
+
+    @property
+    def index(self):
+        if getattr(self, '_index', None) is None:
+            self._index = {key: i for i, key in enumerate(self.keys)}
+        return self._index
+
+    @property
+    def by_file(self):
+        if getattr(self, '_by_file', None) is None:
+            self._by_file = {}
+            for i, f in enumerate(self.filenames):
+                self._by_file.setdefault(f, []).append(i)
+        return self._by_file
 
     def basecall_of(self, i):
         """The per-read path (chimera candidates, Events tables): straight from the file, so a
@@ -420,6 +436,14 @@ def load_signals(files, index, n_samples, arena=None, dst_start=None, threads=No
     return status
 
 
+def _text_column(col, encoding):
+    """Fixed-width bytes column -> str column (a run's run id / sample id columns hold one
+    value: decoded once)."""
+    if len(col) and (col == col[0]).all():
+        return np.full(len(col), col[0].decode(encoding))
+    return np.asarray([b.decode(encoding) for b in col.tolist()])
+
+
 class Fast5Batch:
     """Many FAST5 reads as COLUMNS: what ReadBundle holds for a bundle's reads, built for one
     worker batch from the files themselves -- metadata by one native call per file, signals and
@@ -427,15 +451,19 @@ class Fast5Batch:
     staging buffer).  `as_bundle()` is a ReadBundle, so the loader, the status rules and the
     result-dict builder take exactly the paths they take for bundle reads."""
 
-    def __init__(self, files, index, names):
+    def __init__(self, files, index, names, read_ids=None):
         from . import native
         self.files, self.index, self.names = list(files), np.asarray(index, dtype=np.int64), list(names)
+        self.read_ids = read_ids          # (known to the caller that looked the reads up by id)
         info = np.zeros(len(self.files), dtype=native.H5_INFO_DTYPE)
-        by_file = {}
-        for k, f in enumerate(self.files):
-            by_file.setdefault(id(f), (f, []))[1].append(k)
-        for f, ks in by_file.values():
-            info[ks] = f.info[self.index[ks]]
+        # reads of one file usually come as one run: a slice assignment per run
+        k, n = 0, len(self.files)
+        while k < n:
+            f, e = self.files[k], k + 1
+            while e < n and self.files[e] is f:
+                e += 1
+            info[k:e] = f.info[self.index[k:e]]
+            k = e
         self.info = info
 
     def as_bundle(self, reserve=None, threads=None):
@@ -470,11 +498,12 @@ class Fast5Batch:
         for name in ('range', 'digitisation', 'offset', 'sampling_rate'):
             calib[name] = info['calib'][name]
         d = {'arena': arena[:offsets[-1]], 'offsets': offsets, 'calib': calib,
-             'filename': np.asarray(self.names), 'read_id': np.char.decode(info['read_id'], 'ascii'),
+             'filename': np.asarray(self.names),
+             'read_id': np.asarray(self.read_ids) if self.read_ids is not None else _text_column(info['read_id'], 'ascii'),
              'duration': info['duration'].astype(np.int64), 'start_time': info['start_time'].astype(np.int64),
-             'channel_number': np.char.decode(info['channel_number'], 'ascii'),
-             'run_id': np.char.decode(info['run_id'], 'ascii'),
-             'sample_id': np.char.decode(info['sample_id'], 'utf-8'),
+             'channel_number': _text_column(info['channel_number'], 'ascii'),
+             'run_id': _text_column(info['run_id'], 'ascii'),
+             'sample_id': _text_column(info['sample_id'], 'utf-8'),
              'broken_files': np.array([], dtype='<U1'), 'bundle_version': np.int64(2),
              'bc_present': info['bc_present'] != 0, 'bc_sequence_length': info['bc_sequence_length'].astype(np.int64),
              'bc_mean_qscore': info['bc_mean_qscore'].astype(np.float64),

@@ -23,7 +23,7 @@ import zlib
 
 import numpy as np
 
-__all__ = ['Fast5Writer', 'write_single_read', 'vbz_encode']
+__all__ = ['Fast5Writer', 'write_single_read', 'vbz_encode', 'H5Writer']
 
 UNDEF = 0xFFFFFFFFFFFFFFFF
 LEAF_K, INTERNAL_K, CHUNK_K = 4, 16, 32
@@ -46,6 +46,36 @@ def _dt_float(size):
 
 def _dt_string(size):
     return struct.pack('<BBBBI', 0x13, 0, 0, 0, size)          # null-terminated ASCII
+
+
+def _dt_bytes(size):
+    return struct.pack('<BBBBI', 0x13, 1, 0, 0, size)          # fixed width, null-padded (numpy 'S<n>')
+
+
+def _dt_of(dtype):
+    """Datatype message of a numpy dtype: integers, floats, 'S<n>' and flat compounds of those
+    (version-1 compound members: name, byte offset, no dimensions, member type)."""
+    dtype = np.dtype(dtype)
+    if dtype.names:
+        body = b''
+        for name in dtype.names:
+            sub, offset = dtype.fields[name][:2]
+            if sub.names or sub.shape:
+                raise TypeError('nested / array members are not written')
+            body += _pad8(name.encode() + b'\0') + struct.pack('<IB3xII16x', offset, 0, 0, 0) + _dt_of(sub)
+        return struct.pack('<BBBBI', 0x16, len(dtype.names) & 0xFF, len(dtype.names) >> 8, 0, dtype.itemsize) + body
+    if dtype.kind == 'S':
+        return _dt_bytes(dtype.itemsize)
+    if dtype.kind in 'iu':
+        return _dt_int(dtype.itemsize, dtype.kind == 'i')
+    if dtype.kind == 'f' and dtype.itemsize in (4, 8):
+        return _dt_float(dtype.itemsize)
+    raise TypeError('dtype {} is not written'.format(dtype))
+
+
+def _little(a):
+    """The array's bytes with every number little-endian (a no-op on the hosts this runs on)."""
+    return np.ascontiguousarray(a).astype(a.dtype.newbyteorder('<'), copy=False).tobytes()
 
 
 def _space(dims):
@@ -197,11 +227,10 @@ def _dataset(f, data, compression=None, chunk=None, attrs=()):
         return f.put(_object_header(msgs + [_attribute(k, v) for k, v in attrs]))
     a = np.ascontiguousarray(data)
     n, esz = len(a), a.dtype.itemsize
-    if a.dtype.names:
-        raise TypeError('compound datasets are not written')
-    dt = _dt_int(esz, a.dtype.kind == 'i') if a.dtype.kind in 'iu' else _dt_float(esz)
-    msgs = [_message(0x0001, _space([n])), _message(0x0003, dt)]
-    raw = a.astype(a.dtype.newbyteorder('<')).tobytes()
+    if compression is not None and (a.dtype.names or a.dtype.kind == 'S'):
+        raise TypeError('compressed datasets are written for numbers')
+    msgs = [_message(0x0001, _space([n])), _message(0x0003, _dt_of(a.dtype))]
+    raw = _little(a)
     if compression is None:
         msgs += [_message(0x0005, struct.pack('<BBBB', 2, 2, 0, 0)),
                  _message(0x0008, struct.pack('<BBQQ', 3, 1, f.put(raw) if n else UNDEF, len(raw)))]
@@ -340,3 +369,63 @@ def write_single_read(path, read_id, raw, calib, start_time=0, channel_number='1
     root.children['UniqueGlobalKey'] = ugk.write(f)[0]
     root.children['Analyses'] = (analyses if analyses is not None else _Group()).write(f)[0]
     _finish(f, root, path)
+
+
+class H5Writer:
+    """A plain HDF5 file of groups, 1-D datasets (numbers, 'S<n>', flat compound records) and
+    scalar attributes, written whole on close -- the per-worker dump files of signal_analyzer.py
+    (adapter-dumps/part-*.h5, events/part-*.h5).
+
+        with H5Writer(path) as h5:
+            h5.create_dataset('adapter/00000003/<read id>', float32_array)
+            h5.create_dataset('catalog/adapter/00000003', records, attrs=[('n', np.int32(7))])
+    """
+
+    def __init__(self, path):
+        self.path, self.f = path, _File()
+        self.tree = {}                   # name -> sub-tree dict, or the address of a dataset header
+
+    def _walk(self, parts):
+        node = self.tree
+        for name in parts:
+            node = node.setdefault(name, {})
+            if not isinstance(node, dict):
+                raise ValueError('{!r} is a dataset'.format(name))
+        return node
+
+    def require_group(self, path):
+        self._walk([p for p in path.split('/') if p])
+
+    def __contains__(self, path):
+        node = self.tree
+        for name in [p for p in path.split('/') if p]:
+            if not isinstance(node, dict) or name not in node:
+                return False
+            node = node[name]
+        return True
+
+    def create_dataset(self, path, data, attrs=()):
+        parts = [p for p in path.split('/') if p]
+        parent = self._walk(parts[:-1])
+        if parts[-1] in parent:
+            raise ValueError('name already exists: ' + path)
+        parent[parts[-1]] = _dataset(self.f, data, attrs=attrs)
+
+    def _write(self, node):
+        g = _Group()
+        for name, child in node.items():
+            g.children[name] = self._write(child) if isinstance(child, dict) else child
+        return g.write(self.f)[0]
+
+    def close(self):
+        root = _Group()
+        for name, child in self.tree.items():
+            root.children[name] = self._write(child) if isinstance(child, dict) else child
+        _finish(self.f, root, self.path)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if exc[0] is None:
+            self.close()

@@ -439,6 +439,7 @@ _SIGNATURES = {
                                         C.c_void_p]),
     'pxg_batch_unsplit_scan': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    'pxg_batch_pooled_signal': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pxg_polya': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'pxg_detect_events': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
@@ -1037,6 +1038,21 @@ class NativeContext:
         start = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(np.maximum(cnt, 0), out=start[1:])
         return iv[:total.value], cnt, start
+
+    def pooled_signal(self, first, count):
+        """load_signal(pool=stride)[first[r] : first[r] + count[r]] of every resident read with the
+        scale / shift of the last run (count 0 leaves a read out).  Returns (values float32,
+        offsets [n + 1])."""
+        n = self.n_resident
+        first = np.ascontiguousarray(first, dtype=np.int64)
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        if len(first) != n or len(count) != n:
+            raise ValueError('one first / count entry per resident read')
+        np.cumsum(np.maximum(np.asarray(count, dtype=np.int64), 0), out=offsets[1:])
+        out = np.empty(int(offsets[-1]), dtype=np.float32)
+        self._check(self.lib.pxg_batch_pooled_signal(self.handle, _ptr(first), _ptr(offsets), _ptr(out)),
+                    'pxg_batch_pooled_signal')
+        return out, offsets
 
     def polya(self, arena, offsets, calib, scale_shift, seg_first, seg_last, want_spikes=True):
         """a14-a17 on caller-supplied scaling and segmentation (standalone hook)."""

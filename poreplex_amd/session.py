@@ -198,7 +198,10 @@ class GpuSession:
             batch = current[0]
             t0 = time.perf_counter()
             table = batch.table
+            if self.analyzer.dump_adapter:       # one dump file per batch, named by its first read
+                self.analyzer.begin_dumps(lo + state['done'])
             self.analyzer.settle(batch)
+            self.analyzer.flush_dumps()
             rows_in, positions, loose = batch.in_input_order()
             results = self.analyzer.finish(batch, input_order=True) if fastq is not None else None
             self.timing['facade_s'] += time.perf_counter() - t0

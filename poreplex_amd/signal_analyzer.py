@@ -15,11 +15,13 @@ basecall group run per read.  There is no CPU fallback: a missing library or
 GPU surfaces as the ``(-1, msg, traceback)`` tuple the pipeline treats as fatal
 (pipeline.py:207-213).
 """
+import multiprocessing as mp
 import os
 import sys
 import time
 import traceback
 from contextlib import AbstractContextManager
+from hashlib import sha1
 from weakref import proxy
 
 import numpy as np
@@ -106,14 +108,18 @@ class SignalAnalyzer(AbstractContextManager):
         self.config = config
         self.inputdir, self.outputdir = config['inputdir'], config['outputdir']
         self.batchid, self.formatted_batchid = batchid, format(batchid, '08d')
-        if config.get('dump_adapter_signals') or config.get('dump_basecalls'):
-            # signal_analyzer.py:155-211,450-466: per-worker HDF5 debug dumps (adapter-dumps/part-*.h5,
-            # events/part-*.h5).  Fenced, loudly and before any read is touched: the worker call
-            # returns the fatal (-1, message, traceback) tuple (tests/test_facade.py); the pooled +
-            # scaled adapter slice itself is available through the pxg_pool_scale hook.
+        if config.get('dump_basecalls'):
+            # signal_analyzer.py:165-197,260-263: the per-event table dump (events/part-*.h5) needs
+            # per-event standard deviations and k-mer columns nothing else on this path computes.
+            # Fenced, loudly and before any read is touched: the worker call returns the fatal
+            # (-1, message, traceback) tuple (tests/test_facade.py).
             raise NotImplementedError(
-                '--dump-adapter-signals / --dump-basecalls (per-worker HDF5 debug dumps) are not '
-                'produced by the GPU path; run without them (see DESIGN.md section 7)')
+                '--dump-basecalls (per-worker HDF5 dump of the basecalled event tables) is not '
+                'produced by the GPU path; run without it (see DESIGN.md section 7)')
+        self.dump_adapter = bool(config.get('dump_adapter_signals'))
+        self.loader.dump_adapter = self.dump_adapter
+        self.workerid = sha1(mp.current_process().name.encode()).hexdigest()[:16]
+        self.begin_dumps(batchid)
         self.loader.stage_mask = (
             native.STAGE_SCALER | native.STAGE_SEGMENT
             | (native.STAGE_BARCODE if config['barcoding'] else 0)
@@ -199,6 +205,8 @@ class SignalAnalyzer(AbstractContextManager):
         found = rec['seg_first'][:, adapter] >= 0
         t.halt(rows[~found], 'adapter_not_detected', 'fail')
         rows, rec = rows[found], rec[found]
+        if self.dump_adapter:            # before anything later can fail (:243-244)
+            self.queue_adapter_dumps(t, rows, rec)
 
         # barcodes are decided before anything base-space can fail, so reads that fail
         # later keep theirs (:243-244 queues the window first)
@@ -293,7 +301,53 @@ class SignalAnalyzer(AbstractContextManager):
         self.close()
 
     def close(self):
-        """Nothing to flush: the GPU context outlives the batch (worker_persistence)."""
+        """Flushes the dump file of the batch; the GPU context outlives it (worker_persistence)."""
+        self.flush_dumps()
+
+    # ---- --dump-adapter-signals (signal_analyzer.py:155-211,450-466) --------------------------
+    def begin_dumps(self, batchid):
+        """Start collecting the dumps of batch `batchid` (the session driver: once per batch)."""
+        self.formatted_dump_batchid = format(batchid, '08d')
+        self.adapter_dump_list, self.adapter_dump_seen = [], set()
+
+    def queue_adapter_dumps(self, t, rows, rec):
+        """dump_adapter_signal for the rows whose adapter was found: the pooled + scaled signal
+        of the adapter stretch (downloaded with the records, ReadTable.adapter_dump) and its
+        catalogue row (read id, first raw sample, raw sample behind the last).  A read id that
+        was dumped before in this batch keeps its first dataset and gets no second row."""
+        values, offsets = t.adapter_dump
+        adapter = self.ctx.state_names.index('adapter')
+        stride = int(self.loader.scaler_cfg['stride'])
+        first, last = rec['seg_first'][:, adapter], rec['seg_last'][:, adapter]
+        g = t.gpu_row[rows]
+        for k in np.nonzero(offsets[g + 1] > offsets[g])[0].tolist():
+            read_id = t.read_id[rows[k]]
+            if read_id in self.adapter_dump_seen:
+                continue
+            self.adapter_dump_seen.add(read_id)
+            self.adapter_dump_list.append((read_id, values[offsets[g[k]]:offsets[g[k] + 1]],
+                                           int(first[k]) * stride, (int(last[k]) + 1) * stride))
+
+    def flush_dumps(self):
+        """adapter-dumps/part-<worker>-<batch>.h5 with the reference's groups: the signals under
+        adapter/<batch>/<read id> (float32), the catalogue under catalog/adapter/<batch>.  The
+        reference appends every batch of a worker to ONE part-<worker>.h5; files are written whole
+        here, so a batch gets its own -- the inventory builder (io.py:351-366) takes
+        `part-*.h5` and whatever batch groups it finds in them."""
+        if not self.dump_adapter or self.adapter_dump_list is None:
+            return
+        from .fast5_write import H5Writer
+        batch = self.formatted_dump_batchid
+        top = os.path.join(self.outputdir, 'adapter-dumps')
+        os.makedirs(top, exist_ok=True)
+        catalog = np.array([(r.encode('ascii'), a, b) for r, _, a, b in self.adapter_dump_list],
+                           dtype=[('read_id', 'S36'), ('start', 'i8'), ('end', 'i8')])
+        with H5Writer(os.path.join(top, 'part-{}-{}.h5'.format(self.workerid, batch))) as h5:
+            h5.require_group('adapter/' + batch)
+            for read_id, values, _, _ in self.adapter_dump_list:
+                h5.create_dataset('adapter/{}/{}'.format(batch, read_id), np.asarray(values, dtype=np.float32))
+            h5.create_dataset('catalog/adapter/' + batch, catalog)
+        self.adapter_dump_list = None
 
 
 class SignalAnalysis:

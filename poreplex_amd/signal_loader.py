@@ -75,6 +75,7 @@ class ReadTable:
         # attached by the GPU pass
         self.gpu_row = np.zeros(0, dtype=np.int64)      # row -> index in `records`, -1 if not run
         self.records = None
+        self.adapter_dump = None      # --dump-adapter-signals: (values, offsets) by GPU row
         self.spikes = None            # poly(A) spike rows of the GPU pass [total, 4] ...
         self.spike_offsets = None     # ... rows of GPU record g: spikes[spike_offsets[g]:spike_offsets[g + 1]]
         self._opened = False          # some row holds its own samples / an open file
@@ -471,6 +472,7 @@ class SignalLoader:
         }
         self.stage_mask = native.STAGE_ALL_DEMUX
         self.scan_unsplit = False      # --filter-chimera: also run the a19 window scan
+        self.dump_adapter = False      # --dump-adapter-signals: the adapter stretch comes back with the records
         self.table = ReadTable()
         # several worker calls may be in flight on one context (threads: fit_scalers): one call
         # owns the spare input slot from stage to swap, one owns the resident batch from swap
@@ -544,25 +546,38 @@ class SignalLoader:
         from .fast5_file import Fast5Batch, Fast5Error, open_fast5
         if table.n or table.bundle is not None:
             return where
-        files, index, names, at = [], [], [], []
-        opened = {}
-        for pos, (filename, read_id) in enumerate(reads):
-            f = opened.get(filename, 0)
-            if f == 0:
-                try:
-                    f = open_fast5(os.path.join(self.fast5prefix, filename))
-                except (OSError, Fast5Error):
-                    f = None                     # vanished or unreadable: the per-read path says how
-                opened[filename] = f
-            if f is None:
-                continue
-            i = f.index_of(read_id) if f.multi else (0 if f.n and f.read_ids[0] == read_id else -1)
-            if i < 0 or f.info['status'][i]:
-                continue
-            files.append(f); index.append(i); names.append(filename); at.append(pos)
+        # per FILE, not per read: the positions of its reads in the request, their indices in
+        # the file by one dictionary pass, the readable ones by one mask over the info column
+        by_file = {}
+        for pos, key in enumerate(reads):
+            by_file.setdefault(key[0], []).append(pos)
+        files, index, at = [], [], []
+        for filename, positions in by_file.items():
+            try:
+                f = open_fast5(os.path.join(self.fast5prefix, filename))
+            except (OSError, Fast5Error):
+                continue                         # vanished or unreadable: the per-read path says how
+            if f.multi:
+                f.read_ids
+                lookup = f._index
+                i = np.array([lookup.get(reads[pos][1], -1) for pos in positions], dtype=np.int64)
+            else:
+                first = f.read_ids[0] if f.n else None
+                i = np.array([0 if reads[pos][1] == first else -1 for pos in positions], dtype=np.int64)
+            ok = i >= 0
+            ok[ok] = f.info['status'][i[ok]] == 0
+            if ok.any():
+                files.append((f, int(ok.sum())))
+                index.append(i[ok])
+                at.append(np.asarray(positions, dtype=np.int64)[ok])
         if not files:
             return where
-        bundle = Fast5Batch(files, index, names).as_bundle(reserve)
+        # (request order is kept within a file; files come in the order of their first read)
+        at, index = np.concatenate(at), np.concatenate(index)
+        names = [reads[pos][0] for pos in at.tolist()]
+        ids = [reads[pos][1] for pos in at.tolist()]
+        files = [f for f, k in files for _ in range(k)]
+        bundle = Fast5Batch(files, index, names, ids).as_bundle(reserve)
         rows = table.extend_from_bundle(bundle, np.arange(len(files)))
         cfg = self.scaler_cfg      # length gate of load_padded_signal_head (:212-222)
         usable = np.minimum(np.minimum(cfg['length'], table.duration[rows]), table.n_raw[rows])
@@ -578,7 +593,7 @@ class SignalLoader:
                 '({}#{}) FAST5 {} cannot be decoded (native reader code {})'.format(
                     names[k], bundle.read_ids[k], 'signal' if bundle.signal_status[k] else 'basecall',
                     int(bundle.signal_status[k] or bundle.basecall_status[k])))
-        where[np.asarray(at, dtype=np.int64)] = rows
+        where[at] = rows
         return where
 
     # ---- the GPU pass, in the three steps the session driver overlaps ------------------
@@ -628,6 +643,13 @@ class SignalLoader:
         rec = self.ctx.download()
         spikes = self.ctx.download_spikes(rec) if self.stage_mask & native.STAGE_POLYA else None
         self.attach_records(table, rows, rec, spikes)
+        if self.dump_adapter:
+            # signal[adapter_first : adapter_last + 1] of every read whose adapter was found
+            # (signal_analyzer.py:450-453), pooled and scaled where the samples are
+            adapter = self.ctx.state_names.index('adapter')
+            first, last = rec['seg_first'][:, adapter].astype(np.int64), rec['seg_last'][:, adapter].astype(np.int64)
+            count = np.where(first >= 0, last - first + 1, 0)
+            table.adapter_dump = self.ctx.pooled_signal(np.maximum(first, 0), count)
         if self.scan_unsplit:
             frame = self.unsplit_frames(table, rows, offsets)
             for stride in np.unique(frame[frame[:, 1] > 0, 2]).tolist():
@@ -695,7 +717,7 @@ class SignalLoader:
             return
         self.pin_bundle()
         polya = bool(self.stage_mask & native.STAGE_POLYA)
-        if hasattr(self.ctx, 'process_batch_ex'):
+        if hasattr(self.ctx, 'process_batch_ex') and not self.dump_adapter:
             # one native call per worker batch: stage / swap / run / downloads happen inside it
             # with the GIL released (include/pxg.h, pxg_process_batch_ex)
             frame = self.unsplit_frames(t, rows, offsets) if self.scan_unsplit else None

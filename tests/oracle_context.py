@@ -97,5 +97,16 @@ class OracleBackedContext:
         iv = np.concatenate(found) if found else np.zeros((0, 2), dtype=np.int64)
         return iv.reshape(-1, 2), cnt, start
 
+    def pooled_signal(self, first, count):
+        arena, offsets, calib, _ = self.batch
+        n = len(offsets) - 1
+        out_off = np.concatenate([[0], np.cumsum(np.maximum(np.asarray(count, dtype=np.int64), 0))]).astype(np.int64)
+        out = np.zeros(int(out_off[-1]), dtype=np.float32)
+        for i in np.nonzero(np.diff(out_off))[0].tolist():
+            r = self.res[i]
+            sig = self.oracle.pool_scale(arena[offsets[i]:offsets[i + 1]], calib[i], r['scale'], r['shift'])
+            out[out_off[i]:out_off[i + 1]] = sig[int(first[i]):int(first[i]) + int(count[i])]
+        return out, out_off
+
     def close(self):
         pass

@@ -111,15 +111,81 @@ def test_missing_gpu_is_fatal_tuple_not_fallback(ref_results, monkeypatch):
     WorkerPersistenceStorage.reset()
 
 
-@pytest.mark.parametrize('option', ['dump_adapter_signals', 'dump_basecalls'])
-def test_dump_options_are_fenced_before_any_read_is_touched(oracle_backed, ref_results, option):
-    """The one place the operator surface says no (signal_analyzer.py:155-211,450-466: HDF5 debug
-    dumps): the call fails as a WHOLE, with the reference's fatal-tuple convention and a message
-    that names the option -- never a silent run without the dump."""
+def test_dump_basecalls_is_fenced_before_any_read_is_touched(oracle_backed, ref_results):
+    """The one place the operator surface says no (signal_analyzer.py:165-197,260-263: the HDF5
+    dump of the basecalled event tables): the call fails as a WHOLE, with the reference's
+    fatal-tuple convention and a message that names the option -- never a silent run without
+    the dump."""
     from poreplex_amd.signal_analyzer import process_batch
-    out = process_batch(1, [tuple(r) for r in ref_results['reads'][:4]], facade_config(ref_results, **{option: True}))
+    out = process_batch(1, [tuple(r) for r in ref_results['reads'][:4]], facade_config(ref_results, dump_basecalls=True))
     assert isinstance(out, tuple) and out[0] == -1
     assert 'NotImplementedError' in out[1] and 'dump' in out[1]
+
+
+PY39 = '/opt/conda/bin/python3.9'
+READ_DUMP = """
+import glob, sys, h5py, numpy as np
+(part,) = glob.glob(sys.argv[1] + '/adapter-dumps/part-*.h5')
+with h5py.File(part, 'r') as h5:
+    batches = list(h5['adapter'])
+    assert batches == list(h5['catalog/adapter']) and len(batches) == 1
+    ids = sorted(h5['adapter/' + batches[0]])
+    sigs = [h5['adapter/' + batches[0] + '/' + k][:] for k in ids]
+    assert all(x.dtype == np.float32 for x in sigs)
+    cat = h5['catalog/adapter/' + batches[0]][:]
+    cat = cat.astype([(name, cat.dtype[name].str) for name in cat.dtype.names])      # (h5py hangs metadata on the fields)
+    np.savez(sys.argv[2], batch=np.array(batches[0]), catalog=cat, ids=np.array(ids),
+             offsets=np.concatenate([[0], np.cumsum([len(x) for x in sigs])]).astype(np.int64), values=np.concatenate(sigs))
+"""
+
+
+def check_adapter_dump(outdir, tmp_path, written=None):
+    """adapter-dumps/part-*.h5 of one batch-7 call against what the REAL reference dumped for
+    the same reads (tests/golden/dumps0.npz, tools/make_golden.py --only dumps0): the recorded
+    H5Writer calls, and -- where the image's python3.9 has h5py -- the file as the real HDF5
+    library reads it back."""
+    import subprocess
+    want = np.load(os.path.join(GOLDEN, 'dumps0.npz'))
+    cat = want['adapter_catalog']
+    if written is not None:
+        assert written['catalog/adapter/00000007'].dtype == cat.dtype
+        assert np.array_equal(written['catalog/adapter/00000007'], cat)
+        for k, rid in enumerate(want['adapter_ids'].tolist()):
+            sig = written['adapter/00000007/' + rid]
+            assert sig.dtype == np.float32
+            assert np.array_equal(sig, want['adapter_values'][want['adapter_offsets'][k]:want['adapter_offsets'][k + 1]]), rid
+        assert len(written) == len(want['adapter_ids']) + 1
+    if not os.path.exists(PY39) or subprocess.run([PY39, '-c', 'import h5py'], capture_output=True).returncode:
+        return False
+    back = str(tmp_path / 'readback.npz')
+    out = subprocess.run([PY39, '-c', READ_DUMP, outdir, back], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = np.load(back)
+    assert str(got['batch']) == '00000007' and got['catalog'].dtype == cat.dtype and np.array_equal(got['catalog'], cat)
+    assert got['ids'].tolist() == want['adapter_ids'].tolist()
+    assert np.array_equal(got['offsets'], want['adapter_offsets']) and np.array_equal(got['values'], want['adapter_values'])
+    return True
+
+
+def test_adapter_dumps_equal_the_reference_dump(oracle_backed, ref_results, tmp_path, monkeypatch):
+    """--dump-adapter-signals (signal_analyzer.py:155-163,199-208,450-466): same reads, same
+    pooled + scaled adapter stretches bit for bit, same catalogue rows in the same order, results
+    unchanged."""
+    from poreplex_amd import fast5_write
+    from poreplex_amd.signal_analyzer import process_batch
+    written = {}
+    create = fast5_write.H5Writer.create_dataset
+
+    def recording(self, path, data, attrs=()):
+        written[path] = np.array(data)
+        return create(self, path, data, attrs)
+    monkeypatch.setattr(fast5_write.H5Writer, 'create_dataset', recording)
+    cfg = facade_config(ref_results, dump_adapter_signals=True)
+    cfg['outputdir'] = str(tmp_path)
+    got = process_batch(ref_results['batchid'], [tuple(r) for r in ref_results['reads']], cfg)
+    assert not (isinstance(got, tuple) and got[0] == -1), got
+    compare_results(got, ref_results['results'], check_polya=True)
+    check_adapter_dump(str(tmp_path), tmp_path, written)
 
 
 def test_barcoding_quality_filter_guard(oracle_backed, ref_results):
@@ -167,6 +233,29 @@ def test_process_batch_gpu_vs_reference(ref_results):
     got = process_batch(ref_results['batchid'], reads, cfg)
     assert not (isinstance(got, tuple) and got[0] == -1), got
     compare_results(got, ref_results['results'], check_polya=True)
+    WorkerPersistenceStorage.reset()
+
+
+@pytest.mark.gpu
+def test_adapter_dumps_gpu_vs_reference(ref_results, tmp_path, monkeypatch):
+    """--dump-adapter-signals on the GPU: the stretches come from pxg_batch_pooled_signal on the
+    resident batch; file and catalogue equal the REAL reference's dump."""
+    from poreplex_amd import fast5_write
+    from poreplex_amd.signal_analyzer import process_batch
+    WorkerPersistenceStorage.reset()
+    written = {}
+    create = fast5_write.H5Writer.create_dataset
+
+    def recording(self, path, data, attrs=()):
+        written[path] = np.array(data)
+        return create(self, path, data, attrs)
+    monkeypatch.setattr(fast5_write.H5Writer, 'create_dataset', recording)
+    cfg = facade_config(ref_results, dump_adapter_signals=True)
+    cfg['outputdir'] = str(tmp_path)
+    got = process_batch(ref_results['batchid'], [tuple(r) for r in ref_results['reads']], cfg)
+    assert not (isinstance(got, tuple) and got[0] == -1), got
+    compare_results(got, ref_results['results'], check_polya=True)
+    check_adapter_dump(str(tmp_path), tmp_path, written)
     WorkerPersistenceStorage.reset()
 
 

@@ -110,6 +110,42 @@ def test_batch_columns_equal_per_read_access(inputs):
             assert b.d['bc_move_sum'][i] == int(want['move'].sum()) and b.d['bc_n_moves'][i] == len(want['move'])
 
 
+def test_prepare_many_maps_an_interleaved_request_onto_rows(inputs):
+    """Reads asked for in any order, from several files at once, with an id no file holds and a
+    file that is not there: every found read lands in ITS row, the others are left to the
+    per-read path (-1)."""
+    from poreplex_amd.signal_loader import ReadTable, SignalLoader
+    from poreplex_amd.config import default_config
+    top, t = inputs
+
+    class Cfg:
+        stride, scaler_length, scaler_min_length = 15, 30000, 4500
+        scaler_qc_scale, scaler_qc_shift = (0.0, 1e9), (-1e9, 1e9)
+
+    class Ctx:
+        cfg = Cfg()
+
+    loader = SignalLoader(default_config(inputdir=top, outputdir=top), top, Ctx())
+    n = len(t['ids'])
+    order = np.random.default_rng(3).permutation(n).tolist()
+    reads = [(t['where'][i], t['ids'][i]) for i in order]
+    reads.insert(5, (t['where'][order[0]], 'no-such-read'))
+    reads.insert(11, ('gone.fast5', t['ids'][0]))
+    table = ReadTable()
+    where = loader.prepare_many(reads, table)
+    assert where[5] == -1 and where[11] == -1 and (np.delete(where, [5, 11]) >= 0).all()
+    assert len(set(where[where >= 0].tolist())) == n == table.n
+    for pos, (filename, read_id) in enumerate(reads):
+        row = int(where[pos])
+        if row < 0:
+            continue
+        i = t['ids'].index(read_id)
+        assert (table.filename[row], table.read_id[row]) == (filename, read_id)
+        assert np.array_equal(table.samples_of(row), t['raws'][i])
+        assert table.channel[row] == t['meta'][i]['channel_number'] and table.start_time[row] == t['meta'][i]['start_time']
+        assert table.sample_id[row] == 'smp' and table.run_id[row] == 'r' * 40
+
+
 def test_the_real_hdf5_library_reads_the_writer(inputs, tmp_path):
     if not os.path.exists(PY39) or subprocess.run([PY39, '-c', 'import h5py'], capture_output=True).returncode:
         pytest.skip('no interpreter with h5py in this image')

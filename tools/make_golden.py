@@ -524,6 +524,50 @@ def main():
                        'minimum_sequence_length', 'barcoding_quality_filter')},
                    'results': jsonable(results)}, fh, indent=1)
 
+    # ---- the same batch with both HDF5 dump options on (signal_analyzer.py:155-211,450-466) ----
+    dump_out = os.path.join(TMP, 'out_dumps')
+    for sub in ('adapter-dumps', 'events'):
+        os.makedirs(os.path.join(dump_out, sub))
+    sys.stderr, saved = open(os.devnull, 'w'), sys.stderr
+    try:
+        dres = SA.process_batch(7, batch_reads, dict(refcfg, outputdir=dump_out, dump_adapter_signals=True,
+                                                     dump_basecalls=True))
+    finally:
+        sys.stderr = saved
+    assert [r['status'] for r in dres] == [r['status'] for r in results]
+    import glob
+    dumps = {}
+    (adapter_part,) = glob.glob(os.path.join(dump_out, 'adapter-dumps', 'part-*.h5'))
+    with h5py.File(adapter_part, 'r') as h5:
+        assert list(h5['adapter']) == ['00000007'] and list(h5['catalog/adapter']) == ['00000007']
+        dumps['adapter_catalog'] = h5['catalog/adapter/00000007'][:]
+        ids = sorted(h5['adapter/00000007'])
+        sigs = [h5['adapter/00000007/' + k][:] for k in ids]
+        assert all(x.dtype == np.float32 for x in sigs)
+        dumps['adapter_ids'] = np.array(ids)
+        dumps['adapter_offsets'] = np.concatenate([[0], np.cumsum([len(x) for x in sigs])]).astype(np.int64)
+        dumps['adapter_values'] = np.concatenate(sigs) if sigs else np.zeros(0, np.float32)
+    (events_part,) = glob.glob(os.path.join(dump_out, 'events', 'part-*.h5'))
+    with h5py.File(events_part, 'r') as h5:
+        ids = sorted(h5['basecalled_events/00000007'])
+        tabs = [h5['basecalled_events/00000007/' + k][:] for k in ids]
+        dumps['events_ids'] = np.array(ids)
+        dumps['events_offsets'] = np.concatenate([[0], np.cumsum([len(x) for x in tabs])]).astype(np.int64)
+        dumps['events_rows'] = np.concatenate(tabs)
+        attrs = {}
+        for k in ids:
+            a = {}
+            for name, v in h5['basecalled_events/00000007/' + k].attrs.items():
+                a[name] = [type(v).__name__ if not hasattr(v, 'dtype') else str(v.dtype),
+                           v.decode() if isinstance(v, bytes) else (v.item() if hasattr(v, 'item') else v)]
+            attrs[k] = a
+        dumps['events_attrs'] = np.array(json.dumps(attrs))
+    print('dumps: %d adapter signals, %d event tables' % (len(dumps['adapter_ids']), len(dumps['events_ids'])))
+    for key in ('adapter_catalog', 'events_rows'):        # plain field types (h5py hangs metadata on them)
+        a = dumps[key]
+        dumps[key] = a.astype([(name, a.dtype[name].str) for name in a.dtype.names])
+    np.savez_compressed(os.path.join(OUT, 'dumps0.npz'), **dumps)
+
     # ---- unit-level vectors straight from reference functions --------------
     unit = {}
     # a11 normalize_signal, a10 push rules
