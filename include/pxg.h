@@ -391,6 +391,12 @@ int pxg_guppy_event_means(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_aren
                           const float* scale_shift, const int64_t* first_sample,
                           const int64_t* events_offsets, int32_t block_stride,
                           float* mean, float* scaled_mean);
+/* a18 on the RESIDENT batch with the column the event-table dump adds (--dump-basecalls,
+ * signal_analyzer.py:183-190): mean, stdv (fast5_file.py:226-227) and scaled_mean
+ * (signal_analyzer.py:318) of every Guppy block of every read; events_offsets (n + 1, from 0)
+ * gives each read's blocks, none = the read is left out. */
+int pxg_batch_event_table(pxg_ctx* ctx, const int64_t* first_sample, const int64_t* events_offsets,
+                          int32_t block_stride, float* mean, float* stdv, float* scaled_mean);
 /* a19 (numeric part): the window scan of detect_unsplit_read
  * (signal_analyzer.py:366-418) on the RESIDENT batch after a run with the
  * segment stage: per read first_sample_template and the number of Guppy

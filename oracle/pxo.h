@@ -107,6 +107,9 @@ int pxo_best_polya_interval(const pxg_config* cfg, const uint8_t* is_polya,
 int pxo_guppy_event_means(const int16_t* raw, int64_t n_raw, const pxg_calib* cal,
                           int64_t first_sample, int64_t n_events, int stride, float scale,
                           float shift, float* mean, float* scaled);
+int pxo_guppy_event_table(const int16_t* raw, int64_t n_raw, const pxg_calib* cal,
+                          int64_t first, int64_t n_events, int stride, float scale,
+                          float shift, float* mean, float* stdv_or_null, float* scaled);
 /* a19 signal_analyzer.py:366-418: window scan -> candidate [leader start,
  * adapter end + 1] intervals; returns their number (stores at most cap) */
 int pxo_unsplit_scan(const pxg_config* cfg, const float* scaled_mean, int64_t n_events,

@@ -70,6 +70,7 @@ def lib():
             'pxo_polya': (None, [cfgp, vp, i64, i32, i32, f64, vp, vp, i32]),
             'pxo_best_polya_interval': (i32, [cfgp, vp, vp, i32, vp, vp]),
             'pxo_guppy_event_means': (i32, [vp, i64, vp, i64, i64, i32, f32, f32, vp, vp]),
+            'pxo_guppy_event_table': (i32, [vp, i64, vp, i64, i64, i32, f32, f32, vp, vp, vp]),
             'pxo_unsplit_scan': (i32, [cfgp, vp, i64, i64, i32, i64, f64, vp, i32]),
             'pxo_process_read': (None, [cfgp, vp, i64, vp, vp, C.c_uint32, vp, vp, i32]),
             'pxo_process_batch': (None, [cfgp, i64, vp, vp, vp, vp, C.c_uint32, vp, vp, i32]),
@@ -258,6 +259,17 @@ class Oracle:
         if rc != 0:
             raise Exception('Numbers of events and raw data strides does not match.')
         return mean, scaled
+
+    def guppy_event_table(self, raw, calib_row, first_sample, n_events, scale, shift, stride=15):
+        """(mean, stdv, scaled_mean) of convert_events_guppy + load_events."""
+        raw = np.ascontiguousarray(raw, dtype=np.int16)
+        mean, stdv, scaled = (np.zeros(n_events, dtype=np.float32) for _ in range(3))
+        rc = self.L.pxo_guppy_event_table(_p(raw), len(raw), _p(_cal(calib_row)), int(first_sample),
+                                          int(n_events), stride, np.float32(scale),
+                                          np.float32(shift), _p(mean), _p(stdv), _p(scaled))
+        if rc != 0:
+            raise Exception('Numbers of events and raw data strides does not match.')
+        return mean, stdv, scaled
 
     def unsplit_scan(self, scaled_mean, first_sample, payload_start, sampling_rate, stride=15):
         sm = np.ascontiguousarray(scaled_mean, dtype=np.float32)

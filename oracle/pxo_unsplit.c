@@ -14,6 +14,16 @@ int pxo_guppy_event_means(const int16_t* raw, int64_t n_raw, const pxg_calib* ca
                           int64_t first, int64_t n_events, int stride, float scale,
                           float shift, float* mean, float* scaled)
 {
+    return pxo_guppy_event_table(raw, n_raw, cal, first, n_events, stride, scale, shift, mean, NULL, scaled);
+}
+
+/* + the per-event standard deviation of convert_events_guppy (fast5_file.py:227,
+ * sigbyevents.std(axis=1) on float32: NumPy's _var -- the row mean, fl(x - mean), fl(d * d),
+ * the same pairwise row sum, / n, sqrt, every step rounded to float32) */
+int pxo_guppy_event_table(const int16_t* raw, int64_t n_raw, const pxg_calib* cal,
+                          int64_t first, int64_t n_events, int stride, float scale,
+                          float shift, float* mean, float* stdv_or_null, float* scaled)
+{
     /* fast5_file.py:212-218: rawdata = get_raw_data(first, last) (end clamped
      * to the dataset), medfilt(5) with zero padding */
     const int64_t last = first + (int64_t)stride * n_events;
@@ -48,6 +58,15 @@ int pxo_guppy_event_means(const int16_t* raw, int64_t n_raw, const pxg_calib* ca
         mean[k] = m;
         const float y = scale * m;                         /* signal_analyzer.py:318 */
         scaled[k] = y + shift;
+        if (stdv_or_null) {
+            float sq[128];
+            for (int j = 0; j < stride; j++) {
+                const float d = blk[j] - m;
+                sq[j] = d * d;
+            }
+            const float v = (0.0f + pxo_np_sum_f32(sq, stride)) / (float)stride;
+            stdv_or_null[k] = sqrtf(v);
+        }
     }
     free(pa); free(filt);
     return 0;

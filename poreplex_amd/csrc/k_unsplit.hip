@@ -37,11 +37,36 @@ __device__ __forceinline__ float med5(float a, float b, float c, float d, float 
     return c;
 }
 
+// NumPy's pairwise float32 sum of a row of `stride` values (the reduction of mean / std over
+// the contiguous axis of a [events, stride] array)
+__device__ __forceinline__ float np_row_sum(const float (&blk)[16], int stride)
+{
+    float s;
+    if (stride < 8) {
+        s = 0.0f;
+        for (int j = 0; j < stride; j++) s += blk[j];
+    } else {
+        float rsum[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) rsum[j] = blk[j];
+        int i = 8;
+        for (; i < stride - (stride % 8); i += 8)
+            for (int j = 0; j < 8; j++) rsum[j] += blk[i + j];
+        s = ((rsum[0] + rsum[1]) + (rsum[2] + rsum[3])) + ((rsum[4] + rsum[5]) + (rsum[6] + rsum[7]));
+        for (; i < stride; i++) s += blk[i];
+    }
+    return 0.0f + s;
+}
+
+// SD: also the per-event standard deviation of the dumped event table (fast5_file.py:227,
+// float32 NumPy _var: fl(x - mean), fl(d * d), the same row sum, / stride, sqrt)
+template <bool SD>
 __global__ void k_guppy_event_means(int64_t n_reads, const int16_t* __restrict__ raw,
                                     const int64_t* __restrict__ off, const pxg_calib* __restrict__ cal,
                                     const float* __restrict__ ss, const int64_t* __restrict__ first_sample,
                                     const int64_t* __restrict__ ev_off, int stride,
-                                    float* __restrict__ mean, float* __restrict__ scaled)
+                                    float* __restrict__ mean, float* __restrict__ scaled,
+                                    float* __restrict__ stdv)
 {
     const int64_t r = blockIdx.x;            // reads on x: gridDim.y stops at 65535
     if (r >= n_reads) return;
@@ -57,7 +82,6 @@ __global__ void k_guppy_event_means(int64_t n_reads, const int16_t* __restrict__
     for (int64_t e = blockIdx.y * (int64_t)blockDim.x + threadIdx.x; e < n_ev;
          e += (int64_t)gridDim.y * blockDim.x) {
         float blk[16];
-        float rsum[8];
         // pA of the stride + 4 samples this block's medians touch, zero outside [0, len)
         float w[20];
         const int64_t q0 = e * stride;
@@ -81,38 +105,41 @@ __global__ void k_guppy_event_means(int64_t n_reads, const int16_t* __restrict__
                 blk[j] = (q0 + j >= len) ? __builtin_nanf("") : med5(w[j], w[j + 1], w[j + 2], w[j + 3], w[j + 4]);
         }
         // NumPy pairwise float32 sum of `stride` (= 15) values, then / stride
-        float s;
-        if (stride < 8) {
-            s = 0.0f;
-            for (int j = 0; j < stride; j++) s += blk[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < 8; j++) rsum[j] = blk[j];
-            int i = 8;
-            for (; i < stride - (stride % 8); i += 8)
-                for (int j = 0; j < 8; j++) rsum[j] += blk[i + j];
-            s = ((rsum[0] + rsum[1]) + (rsum[2] + rsum[3])) + ((rsum[4] + rsum[5]) + (rsum[6] + rsum[7]));
-            for (; i < stride; i++) s += blk[i];
-        }
-        s = 0.0f + s;
+        const float s = np_row_sum(blk, stride);
         const float m = s / (float)stride;
         mean[ev_off[r] + e] = m;
         const float y = scale * m;
         scaled[ev_off[r] + e] = y + shift;
+        if (SD) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                if (j < stride) {
+                    const float d = blk[j] - m;
+                    blk[j] = d * d;
+                }
+            }
+            const float v = np_row_sum(blk, stride) / (float)stride;
+            stdv[ev_off[r] + e] = sqrtf(v);          // (correctly rounded: the default of hipcc)
+        }
     }
 }
 
 int pxg_launch_guppy_event_means(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
                                  const pxg_calib* cal, const float* ss, const int64_t* first,
-                                 const int64_t* ev_off, int stride, float* mean, float* scaled)
+                                 const int64_t* ev_off, int stride, float* mean, float* scaled,
+                                 float* stdv_or_null)
 {
     if (n <= 0) return PXG_OK;
     if (stride < 1 || stride > 16) {
         pxg_set_err(ctx, "block_stride must be 1..16");
         return PXG_E_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(k_guppy_event_means, dim3((unsigned)n, 16), dim3(256), 0, ctx->stream, n, raw, off,
-                       cal, ss, first, ev_off, stride, mean, scaled);
+    if (stdv_or_null)
+        hipLaunchKernelGGL(k_guppy_event_means<true>, dim3((unsigned)n, 16), dim3(256), 0, ctx->stream, n, raw, off,
+                           cal, ss, first, ev_off, stride, mean, scaled, stdv_or_null);
+    else
+        hipLaunchKernelGGL(k_guppy_event_means<false>, dim3((unsigned)n, 16), dim3(256), 0, ctx->stream, n, raw, off,
+                           cal, ss, first, ev_off, stride, mean, scaled, (float*)nullptr);
     return PXG_OK;
 }
 

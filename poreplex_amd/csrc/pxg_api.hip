@@ -1176,6 +1176,37 @@ extern "C" int pxg_guppy_event_means(pxg_ctx* ctx, int64_t n, const int16_t* raw
     HOOK_END
 }
 
+extern "C" int pxg_batch_event_table(pxg_ctx* ctx, const int64_t* first_sample, const int64_t* events_offsets,
+                                     int32_t block_stride, float* mean, float* stdv, float* scaled_mean)
+{
+    HOOK_BEGIN
+    const int64_t n = ctx->n_reads;
+    if (n <= 0) return fail(ctx, PXG_E_STATE, "pxg_batch_event_table: no resident batch");
+    if (!(ctx->last_stage_mask & (PXG_STAGE_SCALER | PXG_STAGE_SEGMENT)))
+        return fail(ctx, PXG_E_STATE, "pxg_batch_event_table: nothing has been run on the resident batch");
+    if (!first_sample || !events_offsets || events_offsets[0] != 0)
+        return fail(ctx, PXG_E_INVALID, "pxg_batch_event_table: bad arguments");
+    for (int64_t i = 0; i < n; i++)
+        if (events_offsets[i + 1] < events_offsets[i] || (events_offsets[i + 1] > events_offsets[i] && first_sample[i] < 0))
+            return fail(ctx, PXG_E_INVALID, "pxg_batch_event_table: bad first_sample / offsets");
+    const size_t ne = (size_t)events_offsets[n];
+    if (!ne) return PXG_OK;
+    if (!mean || !stdv || !scaled_mean) return fail(ctx, PXG_E_INVALID, "pxg_batch_event_table: an output is null");
+    int64_t* d_first = S.put(first_sample, (size_t)n, ctx->stream);
+    int64_t* d_eoff = S.put(events_offsets, (size_t)n + 1, ctx->stream);
+    float* d_mean = S.alloc<float>(ne);
+    float* d_sd = S.alloc<float>(ne);
+    float* d_scaled = S.alloc<float>(ne);
+    HOOK_CHECK(d_first && d_eoff && d_mean && d_sd && d_scaled);
+    int rc = pxg_launch_guppy_event_means(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p, d_first, d_eoff,
+                                          block_stride, d_mean, d_scaled, d_sd);
+    if (rc) return rc;
+    HOOK_GET(mean, d_mean, ne);
+    HOOK_GET(stdv, d_sd, ne);
+    HOOK_GET(scaled_mean, d_scaled, ne);
+    HOOK_END
+}
+
 extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
                                       const int64_t* n_blocks, int32_t block_stride,
                                       int64_t cap_intervals, int64_t* out_intervals,

@@ -429,7 +429,8 @@ int pxg_launch_detect_events(pxg_ctx* ctx, int64_t n, const float* sig, const in
 // K7: Guppy event means + pseudo-fusion window scan (k_unsplit.hip)
 int pxg_launch_guppy_event_means(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
                                  const pxg_calib* cal, const float* ss, const int64_t* first,
-                                 const int64_t* ev_off, int stride, float* mean, float* scaled);
+                                 const int64_t* ev_off, int stride, float* mean, float* scaled,
+                                 float* stdv_or_null = nullptr);
 int pxg_launch_unsplit_plan(pxg_ctx* ctx, int64_t n, const pxg_calib* cal, const int32_t* status,
                             const int32_t* segs, const int64_t* first_sample, const int64_t* ev_off,
                             int stride, int32_t* n_win);

@@ -440,6 +440,8 @@ _SIGNATURES = {
     'pxg_batch_unsplit_scan': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     'pxg_batch_pooled_signal': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'pxg_batch_event_table': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
     'pxg_polya': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'pxg_detect_events': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
@@ -1038,6 +1040,20 @@ class NativeContext:
         start = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(np.maximum(cnt, 0), out=start[1:])
         return iv[:total.value], cnt, start
+
+    def event_table(self, first_sample, n_blocks, block_stride=15):
+        """(mean, stdv, scaled_mean, offsets [n + 1]) of the Guppy blocks of the resident reads
+        (n_blocks 0 leaves a read out): the numeric columns of the dumped event table."""
+        n = self.n_resident
+        first = np.ascontiguousarray(first_sample, dtype=np.int64)
+        if len(first) != n or len(n_blocks) != n:
+            raise ValueError('one first_sample / n_blocks entry per resident read')
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.maximum(np.asarray(n_blocks, dtype=np.int64), 0), out=offsets[1:])
+        mean, stdv, scaled = (np.empty(int(offsets[-1]), dtype=np.float32) for _ in range(3))
+        self._check(self.lib.pxg_batch_event_table(self.handle, _ptr(first), _ptr(offsets), int(block_stride),
+                                                   _ptr(mean), _ptr(stdv), _ptr(scaled)), 'pxg_batch_event_table')
+        return mean, stdv, scaled, offsets
 
     def pooled_signal(self, first, count):
         """load_signal(pool=stride)[first[r] : first[r] + count[r]] of every resident read with the

@@ -198,7 +198,7 @@ class GpuSession:
             batch = current[0]
             t0 = time.perf_counter()
             table = batch.table
-            if self.analyzer.dump_adapter:       # one dump file per batch, named by its first read
+            if self.analyzer.dump_adapter or self.analyzer.dump_events:      # a dump file per batch, named by its first read
                 self.analyzer.begin_dumps(lo + state['done'])
             self.analyzer.settle(batch)
             self.analyzer.flush_dumps()

@@ -108,16 +108,9 @@ class SignalAnalyzer(AbstractContextManager):
         self.config = config
         self.inputdir, self.outputdir = config['inputdir'], config['outputdir']
         self.batchid, self.formatted_batchid = batchid, format(batchid, '08d')
-        if config.get('dump_basecalls'):
-            # signal_analyzer.py:165-197,260-263: the per-event table dump (events/part-*.h5) needs
-            # per-event standard deviations and k-mer columns nothing else on this path computes.
-            # Fenced, loudly and before any read is touched: the worker call returns the fatal
-            # (-1, message, traceback) tuple (tests/test_facade.py).
-            raise NotImplementedError(
-                '--dump-basecalls (per-worker HDF5 dump of the basecalled event tables) is not '
-                'produced by the GPU path; run without it (see DESIGN.md section 7)')
         self.dump_adapter = bool(config.get('dump_adapter_signals'))
         self.loader.dump_adapter = self.dump_adapter
+        self.dump_events = self.loader.dump_events = bool(config.get('dump_basecalls'))
         self.workerid = sha1(mp.current_process().name.encode()).hexdigest()[:16]
         self.begin_dumps(batchid)
         self.loader.stage_mask = (
@@ -216,6 +209,9 @@ class SignalAnalyzer(AbstractContextManager):
         if cfg['measure_polya']:
             for k in self.polyaanalyzer.assign(t, rows, rec):      # bulk; the odd ones per read
                 broken[k] = not self._guarded(t, rows[k], self.polyaanalyzer, NanoporeRead(t, rows[k]))
+        if self.dump_events:             # load_events + write_basecalled_events (:259-263), read by read
+            for k in np.nonzero(~broken)[0].tolist():
+                broken[k] = not self._guarded(t, rows[k], self.queue_event_dump, t, rows[k], rec[k])
         settled = self.bulk_base_space(t, rows, ~broken)
         for k in np.nonzero(~broken & ~settled)[0].tolist():
             broken[k] = not self._guarded(t, rows[k], self.base_space_checks, t, rows[k], rec[k])
@@ -309,6 +305,7 @@ class SignalAnalyzer(AbstractContextManager):
         """Start collecting the dumps of batch `batchid` (the session driver: once per batch)."""
         self.formatted_dump_batchid = format(batchid, '08d')
         self.adapter_dump_list, self.adapter_dump_seen = [], set()
+        self.event_dump_list, self.event_dump_seen = [], set()
 
     def queue_adapter_dumps(self, t, rows, rec):
         """dump_adapter_signal for the rows whose adapter was found: the pooled + scaled signal
@@ -334,6 +331,7 @@ class SignalAnalyzer(AbstractContextManager):
         reference appends every batch of a worker to ONE part-<worker>.h5; files are written whole
         here, so a batch gets its own -- the inventory builder (io.py:351-366) takes
         `part-*.h5` and whatever batch groups it finds in them."""
+        self.flush_event_dumps()
         if not self.dump_adapter or self.adapter_dump_list is None:
             return
         from .fast5_write import H5Writer
@@ -348,6 +346,84 @@ class SignalAnalyzer(AbstractContextManager):
                 h5.create_dataset('adapter/{}/{}'.format(batch, read_id), np.asarray(values, dtype=np.float32))
             h5.create_dataset('catalog/adapter/' + batch, catalog)
         self.adapter_dump_list = None
+
+
+    # ---- --dump-basecalls (signal_analyzer.py:63-69,156,165-197,259-263,288-309) -------------
+    EVENT_DUMP_FIELDS = [('mean', '<f4'), ('start', '<u8'), ('stdv', '<f4'), ('length', '<u8'),
+                         ('model_state', 'S5'), ('move', '<i4'), ('pos', '<u8'), ('end', '<u8'),
+                         ('scaled_mean', '<f8')]
+
+    def queue_event_dump(self, t, row, record):
+        """The event table load_events builds for one read (fast5_file.py:183-230,
+        signal_analyzer.py:311-326) and the attributes of get_dump_attributes.  The base-space
+        columns are made here from the basecall; mean, stdv and scaled_mean were computed on the
+        resident batch (ReadTable.event_dump).  Raises what load_events raises."""
+        read = NanoporeRead(t, row)
+        bcall = read.load_fast5_events()
+        if bcall.get('table', 'move') != 'move':
+            raise NotImplementedError(
+                '--dump-basecalls writes the tables of Move-table basecalls (Guppy >= 2.3.7); this '
+                'read carries an Events table')
+        first, n_blocks, stride = read.guppy_event_geometry(bcall=bcall)
+        g = int(t.gpu_row[row])
+        if tuple(t.event_frame[g]) != (first, n_blocks, stride):
+            raise Exception('event frame of the dump does not match the basecall')
+        mean, stdv, scaled, offsets = t.event_dump[stride]
+        at = slice(int(offsets[g]), int(offsets[g + 1]))
+        fields = list(self.EVENT_DUMP_FIELDS)
+        fields[4] = ('model_state', 'S{}'.format(self.kmersize))
+        moves = np.asarray(bcall['move'], dtype=np.int64)
+        seq = bcall['sequence']
+        kmer_size = len(seq) - int(moves.sum()) + 1
+        rev = seq[::-1].replace('U', 'T')
+        if kmer_size == 1:                       # flip-flop models: 1-mer frames shown as 5-mers
+            rev = '__' + rev + '__'
+        elif kmer_size != 5:
+            raise Exception('Move table is encoded with an unknown kmer-size.')
+        # revseq[pos : pos + 5] for pos = cumsum(move) - 1, as Python slices it (short or empty
+        # at and beyond the end, and for a table that starts with a stay)
+        text = np.frombuffer(rev.encode('ascii') + b'\0' * 5, dtype=np.uint8)
+        pos0 = np.cumsum(moves) - 1
+        pos0 = np.where((pos0 < 0) | (pos0 > len(rev)), len(rev), pos0)
+        kmers = np.ascontiguousarray(np.lib.stride_tricks.sliding_window_view(text, 5)[pos0]).view('S5').ravel()
+        table = np.zeros(n_blocks, dtype=fields)
+        start = first + stride * np.arange(n_blocks, dtype=np.int64)
+        table['mean'], table['stdv'], table['scaled_mean'] = mean[at], stdv[at], scaled[at]
+        table['start'], table['length'], table['model_state'] = start, stride, kmers
+        table['move'], table['pos'] = moves, np.cumsum(moves)
+        table['end'] = np.append(start[1:], start[-1:] + 1) if n_blocks else start
+        # get_dump_attributes (:288-309)
+        adapter = self.ctx.state_names.index('adapter')
+        pool = int(self.loader.scaler_cfg['stride'])
+        attrs = [('signal_scale', np.float32(t.scale_shift[row, 0])), ('signal_shift', np.float32(t.scale_shift[row, 1])),
+                 ('adapter_begin', np.uint32(int(record['seg_first'][adapter]) * pool)),
+                 ('adapter_end', np.uint32((int(record['seg_last'][adapter]) + 1) * pool))]
+        polya = t.polya_of(row)
+        if polya is not None:
+            tail = self.ctx.state_names.index('polya-tail') if 'polya-tail' in self.ctx.state_names else -1
+            if tail >= 0 and record['seg_first'][tail] >= 0:
+                attrs.append(('polya_end_debug', np.uint32((int(record['seg_last'][tail]) + 1) * pool)))
+            attrs += [('polya_begin', np.uint32(polya['begin'])), ('polya_end', np.uint32(polya['end'])),
+                      ('spikes', repr(polya['spikes']).encode())]
+        read_id = t.read_id[row]
+        if read_id not in self.event_dump_seen:       # (a second read of the same id keeps the first table)
+            self.event_dump_seen.add(read_id)
+            self.event_dump_list.append((read_id, table, attrs))
+
+    def flush_event_dumps(self):
+        """events/part-<worker>-<batch>.h5: basecalled_events/<batch>/<read id>, one compound
+        dataset per read with its attributes (one file per batch: see flush_dumps)."""
+        if not self.dump_events or self.event_dump_list is None:
+            return
+        from .fast5_write import H5Writer
+        batch = self.formatted_dump_batchid
+        top = os.path.join(self.outputdir, 'events')
+        os.makedirs(top, exist_ok=True)
+        with H5Writer(os.path.join(top, 'part-{}-{}.h5'.format(self.workerid, batch))) as h5:
+            h5.require_group('basecalled_events/' + batch)
+            for read_id, table, attrs in self.event_dump_list:
+                h5.create_dataset('basecalled_events/{}/{}'.format(batch, read_id), table, attrs=attrs)
+        self.event_dump_list = None
 
 
 class SignalAnalysis:

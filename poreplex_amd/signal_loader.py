@@ -76,6 +76,7 @@ class ReadTable:
         self.gpu_row = np.zeros(0, dtype=np.int64)      # row -> index in `records`, -1 if not run
         self.records = None
         self.adapter_dump = None      # --dump-adapter-signals: (values, offsets) by GPU row
+        self.event_frame = self.event_dump = None   # --dump-basecalls: frames by GPU row, columns by block stride
         self.spikes = None            # poly(A) spike rows of the GPU pass [total, 4] ...
         self.spike_offsets = None     # ... rows of GPU record g: spikes[spike_offsets[g]:spike_offsets[g + 1]]
         self._opened = False          # some row holds its own samples / an open file
@@ -473,6 +474,7 @@ class SignalLoader:
         self.stage_mask = native.STAGE_ALL_DEMUX
         self.scan_unsplit = False      # --filter-chimera: also run the a19 window scan
         self.dump_adapter = False      # --dump-adapter-signals: the adapter stretch comes back with the records
+        self.dump_events = False       # --dump-basecalls: so do mean / stdv / scaled mean of every Guppy block
         self.table = ReadTable()
         # several worker calls may be in flight on one context (threads: fit_scalers): one call
         # owns the spare input slot from stage to swap, one owns the resident batch from swap
@@ -650,8 +652,16 @@ class SignalLoader:
             first, last = rec['seg_first'][:, adapter].astype(np.int64), rec['seg_last'][:, adapter].astype(np.int64)
             count = np.where(first >= 0, last - first + 1, 0)
             table.adapter_dump = self.ctx.pooled_signal(np.maximum(first, 0), count)
+        frame = self.unsplit_frames(table, rows, offsets) if self.scan_unsplit or self.dump_events else None
+        if self.dump_events:
+            # the numeric columns of the dumped event tables (fast5_file.py:209-230,
+            # signal_analyzer.py:318), one call per Guppy block stride in the batch
+            table.event_frame, table.event_dump = frame, {}
+            for stride in np.unique(frame[frame[:, 1] > 0, 2]).tolist():
+                sel = (frame[:, 2] == stride) & (frame[:, 1] > 0)
+                table.event_dump[int(stride)] = self.ctx.event_table(
+                    frame[:, 0], np.where(sel, frame[:, 1], 0), int(stride))
         if self.scan_unsplit:
-            frame = self.unsplit_frames(table, rows, offsets)
             for stride in np.unique(frame[frame[:, 1] > 0, 2]).tolist():
                 sel = (frame[:, 2] == stride) & (frame[:, 1] > 0)
                 self.attach_unsplit(table, rows, sel, self.ctx.unsplit_scan(
@@ -717,7 +727,7 @@ class SignalLoader:
             return
         self.pin_bundle()
         polya = bool(self.stage_mask & native.STAGE_POLYA)
-        if hasattr(self.ctx, 'process_batch_ex') and not self.dump_adapter:
+        if hasattr(self.ctx, 'process_batch_ex') and not (self.dump_adapter or self.dump_events):
             # one native call per worker batch: stage / swap / run / downloads happen inside it
             # with the GIL released (include/pxg.h, pxg_process_batch_ex)
             frame = self.unsplit_frames(t, rows, offsets) if self.scan_unsplit else None

@@ -97,6 +97,18 @@ class OracleBackedContext:
         iv = np.concatenate(found) if found else np.zeros((0, 2), dtype=np.int64)
         return iv.reshape(-1, 2), cnt, start
 
+    def event_table(self, first_sample, n_blocks, block_stride=15):
+        arena, offsets, calib, _ = self.batch
+        n = len(offsets) - 1
+        off = np.concatenate([[0], np.cumsum(np.maximum(np.asarray(n_blocks, dtype=np.int64), 0))]).astype(np.int64)
+        mean, stdv, scaled = (np.zeros(int(off[-1]), dtype=np.float32) for _ in range(3))
+        for i in np.nonzero(np.diff(off))[0].tolist():
+            r = self.res[i]
+            mean[off[i]:off[i + 1]], stdv[off[i]:off[i + 1]], scaled[off[i]:off[i + 1]] = self.oracle.guppy_event_table(
+                arena[offsets[i]:offsets[i + 1]], calib[i], first_sample[i], n_blocks[i], r['scale'], r['shift'],
+                block_stride)
+        return mean, stdv, scaled, off
+
     def pooled_signal(self, first, count):
         arena, offsets, calib, _ = self.batch
         n = len(offsets) - 1

@@ -111,17 +111,6 @@ def test_missing_gpu_is_fatal_tuple_not_fallback(ref_results, monkeypatch):
     WorkerPersistenceStorage.reset()
 
 
-def test_dump_basecalls_is_fenced_before_any_read_is_touched(oracle_backed, ref_results):
-    """The one place the operator surface says no (signal_analyzer.py:165-197,260-263: the HDF5
-    dump of the basecalled event tables): the call fails as a WHOLE, with the reference's
-    fatal-tuple convention and a message that names the option -- never a silent run without
-    the dump."""
-    from poreplex_amd.signal_analyzer import process_batch
-    out = process_batch(1, [tuple(r) for r in ref_results['reads'][:4]], facade_config(ref_results, dump_basecalls=True))
-    assert isinstance(out, tuple) and out[0] == -1
-    assert 'NotImplementedError' in out[1] and 'dump' in out[1]
-
-
 PY39 = '/opt/conda/bin/python3.9'
 READ_DUMP = """
 import glob, sys, h5py, numpy as np
@@ -165,6 +154,83 @@ def check_adapter_dump(outdir, tmp_path, written=None):
     assert got['ids'].tolist() == want['adapter_ids'].tolist()
     assert np.array_equal(got['offsets'], want['adapter_offsets']) and np.array_equal(got['values'], want['adapter_values'])
     return True
+
+
+READ_EVENTS = """
+import glob, json, sys, h5py, numpy as np
+(part,) = glob.glob(sys.argv[1] + '/events/part-*.h5')
+with h5py.File(part, 'r') as h5:
+    (batch,) = list(h5['basecalled_events'])
+    ids = sorted(h5['basecalled_events/' + batch])
+    tabs = [h5['basecalled_events/' + batch + '/' + k][:] for k in ids]
+    rows = np.concatenate(tabs)
+    rows = rows.astype([(name, rows.dtype[name].str) for name in rows.dtype.names])
+    attrs = {}
+    for k in ids:
+        a = {}
+        for name, v in h5['basecalled_events/' + batch + '/' + k].attrs.items():
+            # (the text attribute is a fixed-width string here, a variable-width one in the
+            # reference's file: both read back as bytes)
+            a[name] = ['bytes', bytes(v).decode()] if isinstance(v, bytes) else [str(v.dtype), v.item()]
+        attrs[k] = a
+    np.savez(sys.argv[2], batch=np.array(batch), ids=np.array(ids), rows=rows, attrs=np.array(json.dumps(attrs)),
+             offsets=np.concatenate([[0], np.cumsum([len(x) for x in tabs])]).astype(np.int64))
+"""
+
+
+def check_event_dump(outdir, tmp_path, written):
+    """events/part-*.h5 of one batch-7 call against the REAL reference's --dump-basecalls
+    output for the same reads (tests/golden/dumps0.npz): every row of every table bit for bit,
+    every attribute with its type."""
+    import json
+    import subprocess
+    want = np.load(os.path.join(GOLDEN, 'dumps0.npz'))
+    want_attrs = json.loads(str(want['events_attrs']))
+    ids, off, rows = want['events_ids'].tolist(), want['events_offsets'], want['events_rows']
+    assert sorted(written) == ['basecalled_events/00000007/' + k for k in ids]
+    for k, rid in enumerate(ids):
+        table, attrs = written['basecalled_events/00000007/' + rid]
+        assert table.dtype == rows.dtype, rid
+        assert table.tobytes() == rows[off[k]:off[k + 1]].tobytes(), rid
+        got = {}
+        for name, v in attrs:
+            got[name] = ['bytes', v.decode()] if isinstance(v, bytes) else [str(v.dtype), v.item()]
+        assert got == want_attrs[rid], (rid, got, want_attrs[rid])
+    if not os.path.exists(PY39) or subprocess.run([PY39, '-c', 'import h5py'], capture_output=True).returncode:
+        return False
+    back = str(tmp_path / 'events_readback.npz')
+    out = subprocess.run([PY39, '-c', READ_EVENTS, outdir, back], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    got = np.load(back)
+    assert str(got['batch']) == '00000007' and got['ids'].tolist() == ids and np.array_equal(got['offsets'], off)
+    assert got['rows'].dtype == rows.dtype and got['rows'].tobytes() == rows.tobytes()
+    assert json.loads(str(got['attrs'])) == want_attrs
+    return True
+
+
+def run_with_event_dump(ref_results, tmp_path, monkeypatch):
+    from poreplex_amd import fast5_write
+    from poreplex_amd.signal_analyzer import process_batch
+    written = {}
+    create = fast5_write.H5Writer.create_dataset
+
+    def recording(self, path, data, attrs=()):
+        written[path] = (np.array(data), list(attrs))
+        return create(self, path, data, attrs)
+    monkeypatch.setattr(fast5_write.H5Writer, 'create_dataset', recording)
+    cfg = facade_config(ref_results, dump_basecalls=True)
+    cfg['outputdir'] = str(tmp_path)
+    got = process_batch(ref_results['batchid'], [tuple(r) for r in ref_results['reads']], cfg)
+    assert not (isinstance(got, tuple) and got[0] == -1), got
+    compare_results(got, ref_results['results'], check_polya=True)
+    check_event_dump(str(tmp_path), tmp_path, written)
+
+
+def test_event_dumps_equal_the_reference_dump(oracle_backed, ref_results, tmp_path, monkeypatch):
+    """--dump-basecalls (signal_analyzer.py:165-197,259-263,288-309): the event table of every
+    read that reaches load_events -- mean, start, stdv, length, model_state, move, pos, end,
+    scaled_mean -- and its attributes; results unchanged."""
+    run_with_event_dump(ref_results, tmp_path, monkeypatch)
 
 
 def test_adapter_dumps_equal_the_reference_dump(oracle_backed, ref_results, tmp_path, monkeypatch):
@@ -256,6 +322,15 @@ def test_adapter_dumps_gpu_vs_reference(ref_results, tmp_path, monkeypatch):
     assert not (isinstance(got, tuple) and got[0] == -1), got
     compare_results(got, ref_results['results'], check_polya=True)
     check_adapter_dump(str(tmp_path), tmp_path, written)
+    WorkerPersistenceStorage.reset()
+
+
+@pytest.mark.gpu
+def test_event_dumps_gpu_vs_reference(ref_results, tmp_path, monkeypatch):
+    """--dump-basecalls on the GPU: mean / stdv / scaled mean from pxg_batch_event_table on the
+    resident batch; tables and attributes equal the REAL reference's dump."""
+    WorkerPersistenceStorage.reset()
+    run_with_event_dump(ref_results, tmp_path, monkeypatch)
     WorkerPersistenceStorage.reset()
 
 

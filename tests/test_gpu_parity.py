@@ -369,6 +369,47 @@ def test_guppy_event_means_ragged_tail_vs_oracle(ctx, oracle):
     assert np.isnan(mean[eo[0]:eo[1]][-1])
 
 
+def test_batch_event_table_and_pooled_signal_vs_oracle(ctx, oracle):
+    """The two downloads of the dump options on a resident batch: mean / stdv / scaled mean of
+    every Guppy block (ragged tails, a NaN-padded last block, reads left out, block strides 15
+    and 10) and one pooled + scaled stretch per read -- bit-identical to the oracle, whose
+    event columns equal the REAL reference's dump (tests/golden/dumps0.npz, CPU suite)."""
+    from poreplex_amd.synth import synth_batch
+    sb = synth_batch(24, seed=77, samples_per_read=20000, jitter=0.6, short_fraction=0.0)
+    n = 24
+    reads = [sb['arena'][sb['offsets'][i]:sb['offsets'][i + 1]] for i in range(n)]
+    ctx.upload(sb['arena'], sb['offsets'], sb['calib'])
+    ctx.run(N.STAGE_SCALER | N.STAGE_SEGMENT)
+    recs = ctx.download()
+    rng = np.random.default_rng(9)
+    for stride in (15, 10):
+        first = rng.integers(0, 50, n)
+        nb = np.array([-(-(len(r) - f) // stride) for r, f in zip(reads, first)])      # the last block may be cut
+        nb[2], nb[7] = 0, 1
+        nb[11] = max(nb[11] - 300, 1)
+        mean, stdv, scaled, eo = ctx.event_table(first, nb, stride)
+        assert eo[-1] == nb.sum()
+        for i in range(n):
+            if not nb[i]:
+                continue
+            wm, wsd, wsc = oracle.guppy_event_table(reads[i], sb['calib'][i], first[i], nb[i], recs[i]['scale'],
+                                                    recs[i]['shift'], stride)
+            assert np.array_equal(mean[eo[i]:eo[i + 1]], wm, equal_nan=True), (stride, i)
+            assert np.array_equal(stdv[eo[i]:eo[i + 1]], wsd, equal_nan=True), (stride, i)
+            assert np.array_equal(scaled[eo[i]:eo[i + 1]], wsc, equal_nan=True), (stride, i)
+        assert np.isnan(stdv).sum() == np.isnan(mean).sum() > 0 and (stdv[~np.isnan(stdv)] >= 0).all()
+    pooled = np.array([len(r) // 15 for r in reads])
+    p0 = rng.integers(0, 200, n)
+    cnt = np.minimum(rng.integers(0, 900, n), pooled - p0)
+    cnt[4], p0[9], cnt[9] = 0, 0, pooled[9]                      # left out / the whole read
+    values, off = ctx.pooled_signal(p0, cnt)
+    for i in range(n):
+        want = oracle.pool_scale(reads[i], sb['calib'][i], recs[i]['scale'], recs[i]['shift'])[p0[i]:p0[i] + cnt[i]]
+        assert np.array_equal(values[off[i]:off[i + 1]], want), i
+    with pytest.raises(N.PxgError):                             # a stretch that leaves its read
+        ctx.pooled_signal(p0, np.where(np.arange(n) == 3, pooled[3] - p0[3] + 1, cnt))
+
+
 def test_unsplit_scan_vs_reference_candidates(ctx):
     """a19: the candidate in-read adapters of every window equal the list the REAL
     reference handed to union_intervals."""

@@ -102,16 +102,21 @@ def test_session_outputs_do_not_depend_on_batch_size(oracle_backed, tmp_path, bu
     assert not [f for f in os.listdir(tmp_path / 'b') if '.part' in f]
 
 
-def test_session_adapter_dumps_one_file_per_batch(oracle_backed, tmp_path, monkeypatch):
-    """--dump-adapter-signals through the session driver: a dump file per batch (named by the
-    batch's first read), and over all of them the same datasets and catalogue rows the REAL
-    reference dumped for these reads (tests/golden/dumps0.npz)."""
+def test_session_dumps_one_file_per_batch(oracle_backed, tmp_path, monkeypatch):
+    """--dump-adapter-signals / --dump-basecalls through the session driver: a dump file per
+    batch (named by the batch's first read), and over all of them the same datasets and
+    catalogue rows the REAL reference dumped for these reads (tests/golden/dumps0.npz)."""
     from poreplex_amd import fast5_write
     written, files = {}, []
     create, init = fast5_write.H5Writer.create_dataset, fast5_write.H5Writer.__init__
 
+    events = {}
+
     def recording(self, path, data, attrs=()):
-        written.setdefault(path.split('/')[-2 if path.startswith('adapter/') else -1], {})[path] = np.array(data)
+        if path.startswith('basecalled_events/'):
+            events[path.split('/')[-1]] = np.array(data)
+        else:
+            written.setdefault(path.split('/')[-2 if path.startswith('adapter/') else -1], {})[path] = np.array(data)
         return create(self, path, data, attrs)
 
     def opened(self, path):
@@ -119,9 +124,10 @@ def test_session_adapter_dumps_one_file_per_batch(oracle_backed, tmp_path, monke
         return init(self, path)
     monkeypatch.setattr(fast5_write.H5Writer, 'create_dataset', recording)
     monkeypatch.setattr(fast5_write.H5Writer, '__init__', opened)
-    out = run_session(tmp_path / 'a', 'batch0.pxr.npz', batch_reads=7, dump_adapter_signals=True)
-    assert out['batches'] == 5 and len(files) == 5 and len(set(files)) == 5
-    assert sorted(os.listdir(tmp_path / 'a' / 'adapter-dumps')) == sorted(files)
+    out = run_session(tmp_path / 'a', 'batch0.pxr.npz', batch_reads=7, dump_adapter_signals=True, dump_basecalls=True)
+    assert out['batches'] == 5 and len(files) == 10 and len(set(files)) == 5        # (same names in two directories)
+    assert sorted(os.listdir(tmp_path / 'a' / 'adapter-dumps')) == sorted(set(files))
+    assert sorted(os.listdir(tmp_path / 'a' / 'events')) == sorted(set(files))
     want = np.load(os.path.join(GOLDEN, 'dumps0.npz'))
     rows, sigs = [], {}
     for batch in sorted(written):                          # batch ids = first read of the batch: input order
@@ -134,6 +140,10 @@ def test_session_adapter_dumps_one_file_per_batch(oracle_backed, tmp_path, monke
     assert sorted(sigs) == want['adapter_ids'].tolist()
     for k, rid in enumerate(want['adapter_ids'].tolist()):
         assert np.array_equal(sigs[rid], want['adapter_values'][want['adapter_offsets'][k]:want['adapter_offsets'][k + 1]])
+    # --dump-basecalls: the same event tables, whichever batch a read fell into
+    assert sorted(events) == want['events_ids'].tolist()
+    for k, rid in enumerate(want['events_ids'].tolist()):
+        assert events[rid].tobytes() == want['events_rows'][want['events_offsets'][k]:want['events_offsets'][k + 1]].tobytes()
     # and the run's own outputs do not change
     plain = run_session(tmp_path / 'b', 'batch0.pxr.npz', batch_reads=7)
     assert (tmp_path / 'a' / 'sequencing_summary.txt').read_bytes() == (tmp_path / 'b' / 'sequencing_summary.txt').read_bytes()
