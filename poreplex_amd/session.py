@@ -115,12 +115,19 @@ class GpuSession:
 
     # ---- loader thread: batch k+1 is opened and packed while batch k computes ---------
     def _produce(self, batches, slots, out, stop):
+        ahead = None
         try:
             for k, reads in enumerate(batches):
                 staging = slots.get()                 # a staging arena nobody is copying from
                 if stop.is_set() or staging is None:  # the session is being torn down
                     return
                 t0 = time.perf_counter()
+                if ahead is not None:
+                    ahead.join()
+                ahead = None
+                if k + 1 < len(batches):              # the next batch's files are opened beside this one's decode
+                    ahead = threading.Thread(target=self.loader.prefetch_files, args=(batches[k + 1],), daemon=True)
+                    ahead.start()
                 batch = self.analyzer.prepare(reads, ReadTable(), reserve=staging.reserve)
                 need = int(batch.table.n_raw[np.asarray(batch.entered, dtype=np.int64)].sum()) if batch.entered else 0
                 rows, arena, offsets, calib = self.loader.pack(batch.table, staging, need)

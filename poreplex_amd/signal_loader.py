@@ -542,6 +542,20 @@ class SignalLoader:
         where[found] = rows
         return where
 
+    def prefetch_files(self, reads):
+        """Open the FAST5 files of a coming batch (handle, read ids, metadata columns: all cached by
+        fast5_file.open_fast5) -- the session's loader thread runs this beside the batch it is
+        decoding.  Errors are left to prepare_many, which reports them per read."""
+        from .fast5_file import open_fast5
+        if not reads or (self.bundle is not None and self.bundle.has_file(reads[0][0])):
+            return
+        for filename in dict.fromkeys(key[0] for key in reads):
+            try:
+                f = open_fast5(os.path.join(self.fast5prefix, filename))
+                f.read_ids, f.info
+            except Exception:             # noqa: BLE001
+                pass
+
     def prepare_fast5(self, reads, where, table, reserve=None):
         """The FAST5 half of prepare_many.  Only when the table holds no bundle rows yet (a
         table has one column source)."""
