@@ -402,6 +402,11 @@ def host_threads():
             n = min(n, max(int(float(q) / float(period)), 1))
     except (OSError, ValueError):
         pass
+    # several ranks on one host (torchrun sets LOCAL_WORLD_SIZE) share its cores: an equal share
+    # each, so that N loader pools do not oversubscribe the sockets they were pinned to
+    local = int(os.environ.get('LOCAL_WORLD_SIZE', 1) or 1)
+    if local > 1:
+        n = min(n, max((os.cpu_count() or n) // local, 1))
     return max(1, min(n, int(os.environ.get('PXG_HOST_THREADS', 32))))
 
 
