@@ -861,6 +861,9 @@ extern "C" int pxg_h5_open_mt(const char* path, int32_t threads, pxg_h5** out)
                 // fails later, on its own, when its metadata is asked for
                 hh->reads[(size_t)k].id = groups[(size_t)k].first.substr(5);
                 if (failed.fetch_add(1) == 0) { std::lock_guard<std::mutex> g(err_mu); first_error = e.msg; }
+            } catch (const std::exception&) {      // (an allocation: nothing may leave a pool thread)
+                hh->reads[(size_t)k] = pxg_h5_read();
+                failed.fetch_add(1);
             }
         });
     }
@@ -1089,7 +1092,12 @@ static void run_pool(int64_t n, int threads, Fn fn)
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n));
     if (nt == 1) { work(); return; }
     std::vector<std::thread> pool;
-    for (int t = 0; t < nt; t++) pool.emplace_back(work);
+    pool.reserve((size_t)nt);
+    for (int t = 1; t < nt; t++) {
+        try { pool.emplace_back(work); }
+        catch (const std::exception&) { break; }    // no more threads to be had: the ones we got, and this one
+    }
+    work();
     for (auto& t : pool) t.join();
 }
 
