@@ -146,6 +146,22 @@ def test_prepare_many_maps_an_interleaved_request_onto_rows(inputs):
         assert table.sample_id[row] == 'smp' and table.run_id[row] == 'r' * 40
 
 
+def test_host_threads_is_a_share_of_the_host(monkeypatch):
+    """One decode pool per rank: with several ranks on a host (torchrun's LOCAL_WORLD_SIZE) each
+    takes an equal share of the cores, never more than PXG_HOST_THREADS, never less than one."""
+    monkeypatch.delenv('PXG_HOST_THREADS', raising=False)
+    monkeypatch.delenv('LOCAL_WORLD_SIZE', raising=False)
+    alone = F5.host_threads()
+    assert 1 <= alone <= 32
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    assert F5.host_threads() == max(1, min(alone, (os.cpu_count() or alone) // 8))
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '100000')
+    assert F5.host_threads() == 1
+    monkeypatch.delenv('LOCAL_WORLD_SIZE')
+    monkeypatch.setenv('PXG_HOST_THREADS', '2')
+    assert F5.host_threads() == min(alone, 2)
+
+
 def test_the_real_hdf5_library_reads_the_writer(inputs, tmp_path):
     if not os.path.exists(PY39) or subprocess.run([PY39, '-c', 'import h5py'], capture_output=True).returncode:
         pytest.skip('no interpreter with h5py in this image')
