@@ -22,10 +22,9 @@ BUNDLE = os.path.join(GOLDEN, 'batch0.pxr.npz')
 
 
 def facade_config(ref_results, **kw):
-    flags = dict(ref_results['config_flags'])
+    flags = dict(ref_results['config_flags'], outputdir='/tmp')
     flags.update(kw)
-    return default_config(inputdir='/nonexistent-inputdir', outputdir='/tmp',
-                          read_bundle=BUNDLE, **flags)
+    return default_config(inputdir='/nonexistent-inputdir', read_bundle=BUNDLE, **flags)
 
 
 def canon(o):
@@ -260,14 +259,14 @@ def test_barcoding_quality_filter_guard(oracle_backed, ref_results):
     assert isinstance(out, tuple) and out[0] == -1 and 'barcoding-quality-filter' in out[1]
 
 
-def _overlapping_calls(ref_results, workers=3, calls=7):
+def _overlapping_calls(ref_results, workers=3, calls=7, **flags):
     """`calls` process_batch calls kept in flight `workers` at a time on ONE context, the way
     pipeline.py:96,204-205 keeps `parallel` worker calls in flight (threads instead of
     processes: one process per GPU).  Different slices per call, so a mix-up of two calls'
     resident batches cannot go unnoticed."""
     from concurrent.futures import ThreadPoolExecutor
     from poreplex_amd.signal_analyzer import process_batch
-    cfg = facade_config(ref_results)
+    cfg = facade_config(ref_results, **flags)
     reads = [tuple(r) for r in ref_results['reads']]
     slices = [reads[k % 5:len(reads) - (k % 3)] for k in range(calls)]
     serial = [process_batch(100 + k, sl, cfg) for k, sl in enumerate(slices)]
@@ -283,10 +282,34 @@ def test_overlapping_process_batch_calls_share_one_context(oracle_backed, ref_re
     _overlapping_calls(ref_results)
 
 
+def _overlapping_calls_with_dumps(ref_results, tmp_path, workers, calls):
+    """The same with both dump options on (the calls then take the three-step path under the
+    loader's two locks): results unchanged, and every call leaves ITS dump files -- the one of a
+    call over the whole golden batch equal to the reference's dump whichever calls ran beside it."""
+    import glob
+    import shutil
+    _overlapping_calls(ref_results, workers=workers, calls=calls, outputdir=str(tmp_path), dump_adapter_signals=True,
+                       dump_basecalls=True)
+    for sub in ('adapter-dumps', 'events'):
+        names = sorted(os.path.basename(f) for f in glob.glob(str(tmp_path / sub / 'part-*.h5')))
+        assert len(names) == calls and [n.split('-')[-1] for n in names] == ['%08d.h5' % (100 + k) for k in range(calls)]
+
+
+def test_overlapping_calls_with_dump_options(oracle_backed, ref_results, tmp_path):
+    _overlapping_calls_with_dumps(ref_results, tmp_path, workers=3, calls=5)
+
+
 @pytest.mark.gpu
 def test_overlapping_process_batch_calls_on_the_gpu(ref_results):
     WorkerPersistenceStorage.reset()
     _overlapping_calls(ref_results, workers=3, calls=12)
+    WorkerPersistenceStorage.reset()
+
+
+@pytest.mark.gpu
+def test_overlapping_calls_with_dump_options_on_the_gpu(ref_results, tmp_path):
+    WorkerPersistenceStorage.reset()
+    _overlapping_calls_with_dumps(ref_results, tmp_path, workers=3, calls=8)
     WorkerPersistenceStorage.reset()
 
 
