@@ -301,6 +301,7 @@ class Fast5File:
         self.n = int(self.lib.pxg_h5_n_reads(handle))
         self.multi = bool(self.lib.pxg_h5_is_multi(handle))
         self._ids = self._info = self._index = None
+        self.size = 0
 
     def close(self):
         handle, self.handle = getattr(self, 'handle', None), None
@@ -372,6 +373,7 @@ class Fast5File:
 
 
 _OPEN, _OPEN_LOCK, _OPEN_MAX = OrderedDict(), threading.Lock(), 128
+_OPEN_MAX_BYTES = int(os.environ.get('PXG_FAST5_CACHE_BYTES', 8 << 30))     # mapped file bytes kept open
 
 
 def open_fast5(path):
@@ -385,10 +387,14 @@ def open_fast5(path):
             _OPEN.move_to_end(key)
             return f
     f = Fast5File(path)
+    f.size = st.st_size
     with _OPEN_LOCK:
         _OPEN[key] = f
-        while len(_OPEN) > _OPEN_MAX:
-            _OPEN.popitem(last=False)
+        # a run walks its files once: what stays open (= mapped) is bounded in files and in bytes,
+        # the most recent ones first (a batch in flight keeps its own references)
+        total = sum(g.size for g in _OPEN.values())
+        while len(_OPEN) > _OPEN_MAX or (total > _OPEN_MAX_BYTES and len(_OPEN) > 2):
+            total -= _OPEN.popitem(last=False)[1].size
     return f
 
 

@@ -146,6 +146,25 @@ def test_prepare_many_maps_an_interleaved_request_onto_rows(inputs):
         assert table.sample_id[row] == 'smp' and table.run_id[row] == 'r' * 40
 
 
+def test_open_file_cache_is_bounded_in_bytes(inputs, monkeypatch):
+    """Open files are mapped files: the cache keeps the most recent ones up to a byte bound (at
+    least two), and a file a batch still refers to stays readable after it left the cache."""
+    top, t = inputs
+    paths = sorted({os.path.join(top, t['where'][i]) for i in range(len(t['ids']))})
+    assert len(paths) >= 4
+    monkeypatch.setattr(F5, '_OPEN_MAX_BYTES', 1)
+    F5._OPEN.clear()
+    first = F5.open_fast5(paths[0])
+    ids = list(first.read_ids)
+    for p in paths[1:]:
+        F5.open_fast5(p)
+    assert len(F5._OPEN) == 2 and [k[0] for k in F5._OPEN] == paths[-2:]
+    assert first.handle and list(F5.Fast5File(paths[0]).read_ids) == ids and first.info['status'][0] == 0
+    again = F5.open_fast5(paths[0])                      # opened afresh, the same content
+    assert again is not first and list(again.read_ids) == ids
+    F5._OPEN.clear()
+
+
 def test_host_threads_is_a_share_of_the_host(monkeypatch):
     """One decode pool per rank: with several ranks on a host (torchrun's LOCAL_WORLD_SIZE) each
     takes an equal share of the cores, never more than PXG_HOST_THREADS, never less than one."""
