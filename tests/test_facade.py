@@ -80,6 +80,47 @@ def test_process_batch_host_logic_vs_reference(oracle_backed, ref_results):
     assert 'read_id' not in got[1]
 
 
+def golden_batch_as_fast5(top, ref_results=None, bundle=None):
+    """The golden batch's reads as the single-read FAST5 files the reference was given (written
+    back from the committed bundle with the build's own writer, signal compression cycling),
+    the corrupt file, and no file at all for the one that had vanished."""
+    from poreplex_amd.fast5_file import ReadBundle
+    from poreplex_amd.fast5_write import write_single_read
+    b = ReadBundle(bundle or BUNDLE)
+    d = b.d
+    try:
+        from poreplex_amd.fast5_write import vbz_encode
+        vbz_encode(np.zeros(4, np.int16))
+        modes = (None, 'gzip', 'vbz')
+    except OSError:
+        modes = (None, 'gzip')
+    for i in range(len(d['read_id'])):
+        bc = b.basecall_of(i)
+        if bc is not None:
+            bc['move'] = np.asarray(bc['move'], dtype=np.uint8)
+        write_single_read(os.path.join(top, str(d['filename'][i])), str(d['read_id'][i]), b.samples(i), d['calib'][i],
+                          start_time=int(d['start_time'][i]), channel_number=str(d['channel_number'][i]),
+                          run_id=str(d['run_id'][i]), sample_id=str(d['sample_id'][i]), basecall=bc,
+                          compression=modes[i % len(modes)], chunk=4000 if i % 2 else None, read_number=100 + i)
+    with open(os.path.join(top, 'broken.fast5'), 'wb') as fh:
+        fh.write(b'this is not an HDF5 file')
+
+
+def test_process_batch_from_fast5_files_vs_reference(oracle_backed, ref_results, tmp_path):
+    """north_star: "outputs match the reference CPU path on the same FAST5 inputs".  No bundle
+    here: the reads are FAST5 files in inputdir, opened by the native reader a batch at a time,
+    and the result list equals what the REAL reference returned for its FAST5 files."""
+    from poreplex_amd.signal_analyzer import process_batch
+    golden_batch_as_fast5(str(tmp_path), ref_results)
+    flags = dict(ref_results['config_flags'])
+    cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path / 'out'), **flags)
+    assert not cfg.get('read_bundle')
+    got = process_batch(ref_results['batchid'], [tuple(r) for r in ref_results['reads']], cfg)
+    assert not (isinstance(got, tuple) and got[0] == -1), got
+    compare_results(got, ref_results['results'], check_polya=True)
+    assert [r['status'] for r in got[:3]] == ['unknown_error', 'disappeared', 'scaler_signal_too_short']
+
+
 def test_operator_surface(oracle_backed, ref_results):
     from poreplex_amd import signal_analyzer as SA
     assert SA.__all__ == ['SignalAnalyzer', 'SignalAnalysis', 'process_batch']
@@ -314,6 +355,20 @@ def test_overlapping_calls_with_dump_options_on_the_gpu(ref_results, tmp_path):
 
 
 @pytest.mark.gpu
+def test_process_batch_from_fast5_files_gpu_vs_reference(ref_results, tmp_path):
+    """The same on the GPU: FAST5 files -> native reader -> staging arena -> kernels -> the
+    REAL reference's result dicts."""
+    from poreplex_amd.signal_analyzer import process_batch
+    WorkerPersistenceStorage.reset()
+    golden_batch_as_fast5(str(tmp_path), ref_results)
+    cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path / 'out'), **dict(ref_results['config_flags']))
+    got = process_batch(ref_results['batchid'], [tuple(r) for r in ref_results['reads']], cfg)
+    assert not (isinstance(got, tuple) and got[0] == -1), got
+    compare_results(got, ref_results['results'], check_polya=True)
+    WorkerPersistenceStorage.reset()
+
+
+@pytest.mark.gpu
 def test_process_batch_gpu_vs_reference(ref_results):
     from poreplex_amd.signal_analyzer import process_batch
     WorkerPersistenceStorage.reset()
@@ -385,6 +440,27 @@ def test_filter_unsplit_reads_host_logic_vs_reference(oracle_backed):
     ref, cfg = chimera_case()
     assert cfg['filter_unsplit_reads']
     check_chimera(process_batch(ref['batchid'], [tuple(r) for r in ref['reads']], cfg), ref)
+
+
+def chimera_from_fast5(tmp_path):
+    """--filter-chimera with the reads as FAST5 files in inputdir (no bundle): the event frames
+    come from the files' Move tables through the native reader."""
+    from poreplex_amd.signal_analyzer import process_batch
+    ref, cfg = chimera_case()
+    golden_batch_as_fast5(str(tmp_path), bundle=CHIMERA_BUNDLE)
+    cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path / 'out'), **ref['config_flags'])
+    check_chimera(process_batch(ref['batchid'], [tuple(r) for r in ref['reads']], cfg), ref)
+
+
+def test_filter_unsplit_reads_from_fast5_files_vs_reference(oracle_backed, tmp_path):
+    chimera_from_fast5(tmp_path)
+
+
+@pytest.mark.gpu
+def test_filter_unsplit_reads_from_fast5_files_gpu_vs_reference(tmp_path):
+    WorkerPersistenceStorage.reset()
+    chimera_from_fast5(tmp_path)
+    WorkerPersistenceStorage.reset()
 
 
 def test_event_frame_base_space_columns_vs_reference(oracle_backed):
