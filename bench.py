@@ -46,6 +46,11 @@ PEAK_HBM = 8.0e12              # B/s
 # pipeline incl. FAST5 I/O, 2x Xeon E5-2687W v3 = 20 cores): 1 339 070 reads in 1 h 37 min
 PUBLISHED_READS_PER_S = 1339070 / (97 * 60.0)
 TRAFFIC_FILE = os.path.join('profiles', 'r03', 'hbm_traffic.json')
+# PXG_BENCH_SHARE_GPU=1: every rank of a torchrun launch uses GPU 0 and the collectives go over gloo --
+# the real multi-process path (sharding, barriers, max over ranks, label gather, NUMA binding, the
+# host-side legs on all ranks at once) with the real kernels on a ONE-GPU box.  A plumbing check:
+# the line says so and is not a scaling number.
+SHARE_GPU = os.environ.get('PXG_BENCH_SHARE_GPU') == '1'
 
 STAGES = {
     'demux': (2, 'a1-a13 (scaler LSTM + Viterbi + barcode LSTMs)', 'reads/s (segment+barcode)'),
@@ -267,7 +272,7 @@ def end_to_end(args, config, rank, local_rank, world, dist, standin, base, which
         n_ranks = 1
         if dist is not None:
             import torch
-            t = torch.tensor([wall, 1.0], dtype=torch.float64, device='cpu' if standin else 'cuda')
+            t = torch.tensor([wall, 1.0], dtype=torch.float64, device=collective_device(standin))
             dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
             dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)
             wall, n_ranks = float(t[0].item()), int(round(t[1].item()))
@@ -288,7 +293,7 @@ def end_to_end(args, config, rank, local_rank, world, dist, standin, base, which
                                      '(pre-basecalled FAST5 -> FASTQ), 20 Xeon cores -- the closest '
                                      'published counterpart of this end-to-end figure',
                 'dtype': 'f32 (LSTM MFMA) / f64 (Viterbi) / i16 in',
-                'data': 'TEST-STANDIN (no GPU work timed)' if standin else 'synthetic',
+                'data': 'TEST-STANDIN (no GPU work timed)' if standin else ('synthetic (ranks SHARING one GPU: a plumbing check, not a scaling number)' if SHARE_GPU else 'synthetic'),
                 'config': {'workload': 'BASELINE configs[4] shape: {} reads over {} GPU(s) x ~{} int16 samples, '
                                        'files -> session driver -> sinks, stages {}'.format(
                                            total, world, args.samples, STAGES[args.workload][1]),
@@ -463,12 +468,18 @@ def fast5_ingest_leg(args, base, which, n_reads=2048):
         shutil.rmtree(work, ignore_errors=True)
 
 
+def collective_device(standin):
+    """Where the tensors of the bench's own collectives live: the GPU under RCCL, the host under
+    gloo (the CPU test stand-in, and PXG_BENCH_SHARE_GPU=1 -- several ranks on ONE GPU)."""
+    return 'cpu' if standin or SHARE_GPU else 'cuda'
+
+
 def rank_stats(value, dist, standin):
     """(min, mean, max) of one number over the ranks (RCCL / gloo all-reduce); None stays None."""
     if dist is None:
         return {'min': value, 'mean': value, 'max': value}
     import torch
-    dev = 'cpu' if standin else 'cuda'
+    dev = collective_device(standin)
     has = torch.tensor([0.0 if value is None else 1.0], dtype=torch.float64, device=dev)
     dist.all_reduce(has, op=dist.ReduceOp.MIN)
     v = float(value) if value is not None else 0.0
@@ -557,7 +568,7 @@ def strong_leg(args, ctx, dist, rank, world, mask, standin, force_dist, barrier)
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cpu' if standin else 'cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device=collective_device(standin))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if not standin:
@@ -625,7 +636,7 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
     rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    local_rank = 0 if SHARE_GPU else int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus != world:
         raise SystemExit('bench.py: --gpus {} but WORLD_SIZE {} (launch with --nproc-per-node {} '
@@ -678,7 +689,7 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29531')
-        if standin:
+        if standin or SHARE_GPU:
             dist.init_process_group('gloo', rank=rank, world_size=world)
         else:
             torch.cuda.set_device(local_rank)
@@ -759,7 +770,7 @@ def main():
     if dist is not None:
         import torch
         t = torch.tensor([elapsed, 1.0], dtype=torch.float64,
-                         device='cpu' if standin else 'cuda')
+                         device=collective_device(standin))
         dist.all_reduce(t[:1], op=dist.ReduceOp.MAX)
         dist.all_reduce(t[1:], op=dist.ReduceOp.SUM)     # ranks that took part, counted by RCCL
         elapsed, n_ranks = float(t[0].item()), int(round(t[1].item()))
@@ -958,7 +969,7 @@ def main():
                              '(Poreplex 0.1, whole pipeline incl. FAST5 I/O, 20 Xeon cores): an '
                              'order-of-magnitude anchor, not a hot-path number; see cpu_baseline',
         'dtype': 'f32 (LSTM MFMA) / f64 (Viterbi) / i16 in',
-        'data': 'TEST-STANDIN (no GPU work timed)' if standin else 'synthetic',
+        'data': 'TEST-STANDIN (no GPU work timed)' if standin else ('synthetic (ranks SHARING one GPU: a plumbing check, not a scaling number)' if SHARE_GPU else 'synthetic'),
         'config': {'workload': 'BASELINE configs[{}]: {} x ~{} int16 samples, stages {}'.format(
                        4 if args.scaling == 'strong' else wl_cfg,
                        '{} reads sharded over {} GPU(s)'.format(total, world) if args.scaling == 'strong'
