@@ -8,6 +8,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from poreplex_amd import native as N
 from poreplex_amd import distributed as D
@@ -160,3 +161,34 @@ def test_bench_end_to_end_two_ranks_over_gloo():
     assert line['n_gpus'] == 2 and x['ranks_counted_by_collective'] == 2
     assert x['labels_gathered'] == 28 and x['labels_read_index_unique'] is True
     assert x['summary_rows'] == 28 and x['reads_labelled_pass'] >= 20
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_sharing_the_gpu_with_real_kernels():
+    """The same bare `bench.py --gpus 2` call with the REAL context: both ranks on GPU 0
+    (PXG_BENCH_SHARE_GPU=1, the bench's collectives over gloo).  Two processes drive the kernels
+    at the same time, every rank's records are bit-identical to the oracle's (concordance block of
+    rank 0), the labels of both ranks arrive once each, and configs[4] -- one seeded run sharded
+    over the ranks -- runs beside the weak value.  A plumbing check: the line says so."""
+    import json
+    env = {k: v for k, v in os.environ.items()
+           if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['PXG_BENCH_SHARE_GPU'] = '1'
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+         '--reads', '600', '--total-reads', '1500', '--strong-base-reads', '64', '--samples', '20000',
+         '--cpu-sample', '16', '--cpu-all-cores-sample', '0'],
+        env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    x = line['extra']
+    assert line['n_gpus'] == 2 and line['value'] > 0 and 'SHARING one GPU' in line['data']
+    assert x['ranks_counted_by_collective'] == 2 and x['labels_gathered'] == 1200 and x['labels_read_index_unique'] is True
+    assert x['configs4_strong']['labels_gathered'] == 1500 and x['configs4_strong']['labels_read_index_unique'] is True
+    assert sorted(x['configs4_strong']['reads_per_gpu']) == [750, 750]
+    for key in ('pcie_overlapped_reads_per_s', 'pcie_overlapped_encoded_reads_per_s', 'h2d_GBps'):
+        assert x['pcie_over_ranks'][key]['min'] > 0
+    c = line['concordance']
+    assert c is None or (c['status_mismatch'] == 0 and c['all_fields_bit_exact'])
