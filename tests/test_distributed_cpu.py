@@ -192,3 +192,13 @@ def test_bench_two_ranks_sharing_the_gpu_with_real_kernels():
         assert x['pcie_over_ranks'][key]['min'] > 0
     c = line['concordance']
     assert c is None or (c['status_mismatch'] == 0 and c['all_fields_bit_exact'])
+    # the session driver, two ranks, one GPU: loader threads, staging, sinks, label gather, count all-reduce
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--end-to-end', '--reads', '300',
+         '--batch-reads', '100', '--samples', '20000', '--cpu-sample', '0', '--cpu-all-cores-sample', '0'],
+        env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][0])
+    x = line['extra']
+    assert line['n_gpus'] == 2 and line['value'] > 0 and x['ranks_counted_by_collective'] == 2
+    assert x['labels_gathered'] == 600 and x['labels_read_index_unique'] is True and x['summary_rows'] == 600
