@@ -351,6 +351,12 @@ int pxg_batch_download_spikes(pxg_ctx* ctx, int64_t cap_rows, pxg_polya_spike* o
  * pooled positions first[r] ... into out[out_offsets[r] : out_offsets[r + 1]] (n + 1 offsets from
  * 0; an empty stretch leaves a read out).  Only for reads the scaler stage succeeded on. */
 int pxg_batch_pooled_signal(pxg_ctx* ctx, const int64_t* first, const int64_t* out_offsets, float* out);
+/* The barcode windows of the resident batch as the classifier saw them (a9-a11: the adapter
+ * stretch cut to / padded to signal_trim_length and normalised, barcoding.py:77-101), n x
+ * signal_trim_length; only the rows of reads whose record says bc_pushed are meaningful.  What a
+ * training set for the demultiplexer is made of (training/barcodes/scripts/prepare_training_data.py:
+ * 63-87 prepares its inputs exactly as inference does). */
+int pxg_batch_download_windows(pxg_ctx* ctx, float* out);
 int pxg_batch_times(pxg_ctx* ctx, pxg_stage_times* out);
 
 /* ---- per-stage hooks (parity tests call these through the same ABI) ------ */

@@ -780,6 +780,19 @@ extern "C" int pxg_batch_download_samples(pxg_ctx* ctx, int16_t* out)
     return PXG_OK;
 }
 
+extern "C" int pxg_batch_download_windows(pxg_ctx* ctx, float* out)
+{
+    if (!ctx || !out) return PXG_E_INVALID;
+    if (ctx->n_reads <= 0) return fail(ctx, PXG_E_STATE, "pxg_batch_download_windows: no resident batch");
+    if (!(ctx->last_stage_mask & PXG_STAGE_BARCODE))
+        return fail(ctx, PXG_E_STATE, "pxg_batch_download_windows: the last run had no barcode stage");
+    PXG_HIP(ctx, hipSetDevice(ctx->device));
+    PXG_HIP(ctx, hipMemcpyAsync(out, ctx->win.p, (size_t)ctx->n_reads * ctx->cfg.signal_trim_length * sizeof(float),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PXG_OK;
+}
+
 extern "C" int pxg_batch_download_spikes(pxg_ctx* ctx, int64_t cap_rows, pxg_polya_spike* out, int64_t* offsets)
 {
     if (!ctx || (!offsets && ctx->n_reads)) return PXG_E_INVALID;

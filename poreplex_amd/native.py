@@ -440,6 +440,7 @@ _SIGNATURES = {
     'pxg_batch_unsplit_scan': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
     'pxg_batch_pooled_signal': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'pxg_batch_download_windows': (C.c_int, [C.c_void_p, C.c_void_p]),
     'pxg_batch_event_table': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                         C.c_void_p]),
     'pxg_polya': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -1040,6 +1041,15 @@ class NativeContext:
         start = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(np.maximum(cnt, 0), out=start[1:])
         return iv[:total.value], cnt, start
+
+    def download_windows(self, records=None):
+        """[n, signal_trim_length] float32: the classifier's input windows of the resident batch
+        (rows of reads that were not pushed are zeroed when `records` is given)."""
+        out = np.empty((self.n_resident, self.cfg.signal_trim_length), dtype=np.float32)
+        self._check(self.lib.pxg_batch_download_windows(self.handle, _ptr(out)), 'pxg_batch_download_windows')
+        if records is not None:
+            out[records['bc_pushed'] == 0] = 0.0
+        return out
 
     def event_table(self, first_sample, n_blocks, block_stride=15):
         """(mean, stdv, scaled_mean, offsets [n + 1]) of the Guppy blocks of the resident reads

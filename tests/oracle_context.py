@@ -109,6 +109,16 @@ class OracleBackedContext:
                 block_stride)
         return mean, stdv, scaled, off
 
+    def download_windows(self, records=None):
+        arena, offsets, calib, _ = self.batch
+        a = int(self.cfg.segmentation_model.adapter_state)
+        out = np.zeros((len(offsets) - 1, int(self.cfg.signal_trim_length)), dtype=np.float32)
+        for i in np.nonzero(self.res['bc_pushed'])[0].tolist():
+            r = self.res[i]
+            sig = self.oracle.pool_scale(arena[offsets[i]:offsets[i + 1]], calib[i], r['scale'], r['shift'])
+            out[i] = self.oracle.barcode_window(sig[int(r['seg_first'][a]):int(r['seg_last'][a]) + 1])[0]
+        return out
+
     def pooled_signal(self, first, count):
         arena, offsets, calib, _ = self.batch
         n = len(offsets) - 1

@@ -153,6 +153,25 @@ def test_barcode_window_vs_reference_golden(ctx, unit):
             assert np.array_equal(out[k], unit['push_out'][k]), k
 
 
+def test_resident_batch_windows_vs_reference_golden(ctx, bundle, stages):
+    """pxg_batch_download_windows: the classifier input of every pushed read of a resident batch
+    (what a training set is made of) equals the window the REAL reference queued for that read
+    (BarcodeDemultiplexer.push, tests/golden/batch0.stages.npz; the scaling parameters of that run
+    came from the canonical scaler arithmetic, which is the GPU's)."""
+    ctx.upload(bundle['arena'], bundle['offsets'], bundle['calib'])
+    ctx.run(N.STAGE_ALL_DEMUX)
+    rec = ctx.download()
+    win = ctx.download_windows(rec)
+    pushed = stages['pushed'].astype(bool)
+    assert np.array_equal(rec['bc_pushed'].astype(bool), pushed) and pushed.sum() >= 20
+    assert np.array_equal(win[pushed], stages['window'][pushed])
+    assert not win[~pushed].any()
+    ctx.upload(bundle['arena'][:bundle['offsets'][2]], bundle['offsets'][:3], bundle['calib'][:2])
+    ctx.run(N.STAGE_SCALER)
+    with pytest.raises(N.PxgError):                              # no barcode stage in the last run
+        ctx.download_windows()
+
+
 @pytest.mark.parametrize('n', [1, 15, 33, 64])
 def test_demux_lstm_bit_exact(ctx, oracle, stages, n):
     wins = stages['demux_in']

@@ -143,3 +143,52 @@ def test_train_on_gpu_and_run_the_exported_bundles_through_the_kernels(tmp_path)
         assert np.abs(ctx.scaler_lstm(sx[:32].numpy()) - want).max() < 2e-4
     finally:
         ctx.close()
+
+
+def training_windows_of_the_golden_batch(tmp_path):
+    """tools/training_windows.py over the golden bundle: the windows of the pushed reads equal the
+    ones the REAL reference queued for its classifier (tests/golden/batch0.stages.npz), ids and
+    labels line up, and the file feeds the trainer."""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import training_windows as TW
+    golden = os.path.join(ROOT, 'tests', 'golden')
+    bundle = os.path.join(golden, 'batch0.pxr.npz')
+    cfg = default_config(inputdir=golden, outputdir=str(tmp_path), read_bundle=bundle, barcoding=True)
+    windows, ids, guess, score = TW.collect(cfg, batch_reads=9)          # four batches
+    st = np.load(os.path.join(golden, 'batch0.stages.npz'))
+    all_ids = [str(r) for r in np.load(bundle)['read_id']]
+    pushed = st['pushed'].astype(bool)
+    assert ids.tolist() == [r for r, p in zip(all_ids, pushed) if p]
+    assert windows.dtype == np.float32 and np.array_equal(windows, st['window'][pushed])
+    assert len(guess) == len(score) == len(windows) and ((guess >= -1) & (guess < 4)).all()
+    # ... and into the trainer: (windows, labels) -> one epoch
+    x = torch.from_numpy(windows)
+    y = torch.from_numpy((guess + 1).astype(np.int64))                   # class 0 = decoy
+    cost = TR.cost_matrix(5)
+    tr = TR.Trainer(TR.DemuxClassifier(), lambda lp, t: TR.weighted_cross_entropy(lp, t, cost), device='cpu',
+                    batch_size=8, epochs=1, lr=1e-3, patience=1, output_dir=str(tmp_path / 'fit'))
+    hist = tr.fit(x, y)
+    assert np.isfinite(hist[-1]['val_loss'])
+
+
+def test_training_windows_from_a_run(tmp_path, monkeypatch):
+    from poreplex_amd import native as N
+    from poreplex_amd.worker_persistence import WorkerPersistenceStorage
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from oracle_context import OracleBackedContext
+    WorkerPersistenceStorage.reset()
+    monkeypatch.setattr(N, 'NativeContext', OracleBackedContext)
+    try:
+        training_windows_of_the_golden_batch(tmp_path)
+    finally:
+        WorkerPersistenceStorage.reset()
+
+
+@pytest.mark.gpu
+def test_training_windows_from_a_run_on_the_gpu(tmp_path):
+    from poreplex_amd.worker_persistence import WorkerPersistenceStorage
+    WorkerPersistenceStorage.reset()
+    try:
+        training_windows_of_the_golden_batch(tmp_path)
+    finally:
+        WorkerPersistenceStorage.reset()
