@@ -96,6 +96,7 @@ def parse(argv=None):
                          'Signal uncompressed / gzip / VBZ) and read back by the native reader '
                          '(csrc/pxg_h5.cpp) instead of a read bundle')
     ap.add_argument('--no-fast5-leg', action='store_true', help='skip the FAST5 ingest leg of the default line')
+    ap.add_argument('--no-e2e-leg', action='store_true', help='skip the end-to-end session legs of the default line')
     ap.add_argument('--compressed-bundle', action='store_true',
                     help='--end-to-end: the bundle carries encoded samples (pxg_z_*), decoded on the GPU')
     ap.add_argument('--api', choices=['resident', 'process_batch'], default='resident',
@@ -466,6 +467,29 @@ def fast5_ingest_leg(args, base, which, n_reads=2048):
         return out
     finally:
         shutil.rmtree(work, ignore_errors=True)
+
+
+def end_to_end_legs(args):
+    """The session driver from files, as part of the DEFAULT line (so that the driver's own run
+    carries it): `bench.py --end-to-end` in a child process, once from an encoded read bundle and once
+    from uncompressed multi-read FAST5 (12 and 6 batches: fill and drain included; longer runs
+    are in profiles/).  Errors are reported, never hidden."""
+    import subprocess
+    out = {'batch_reads': 10000}
+    for name, reads, flags in (('encoded_bundle', 120000, ['--compressed-bundle']),
+                               ('fast5_uncompressed', 60000, ['--from-fast5', 'none'])):
+        cmd = [sys.executable, os.path.abspath(__file__), '--end-to-end', '--reads', str(reads), '--batch-reads', '10000',
+               '--samples', str(args.samples), '--seed', str(args.seed), '--cpu-sample', '0', '--cpu-all-cores-sample', '0'] + flags
+        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+        try:
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+            line = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+            out[name] = {'reads_per_s': line['value'], 'reads': reads, 'batches': line['steps'],
+                         'loader_s': line['extra']['session_timing_rank0']['load_s'],
+                         'summary_rows': line['extra']['summary_rows']}
+        except Exception as exc:                       # noqa: BLE001
+            out[name] = {'error': '{}: {}'.format(type(exc).__name__, exc)}
+    return out
 
 
 def collective_device(standin):
@@ -958,6 +982,10 @@ def main():
             extra['fast5_ingest'] = fast5_ingest_leg(args, base, which)
         except Exception as exc:                       # reported, never hidden
             extra['fast5_ingest'] = {'error': '{}: {}'.format(type(exc).__name__, exc)}
+
+    if not standin and world == 1 and not args.no_e2e_leg and not n_base and not use_inject and \
+            args.workload == 'demux' and not SHARE_GPU and not force_dist:
+        extra['end_to_end'] = end_to_end_legs(args)
 
     line = {
         'metric': wl_metric,
