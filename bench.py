@@ -482,7 +482,7 @@ def end_to_end_legs(args):
                '--samples', str(args.samples), '--seed', str(args.seed), '--cpu-sample', '0', '--cpu-all-cores-sample', '0'] + flags
         env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
         try:
-            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=180)
             line = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
             out[name] = {'reads_per_s': line['value'], 'reads': reads, 'batches': line['steps'],
                          'loader_s': line['extra']['session_timing_rank0']['load_s'],
