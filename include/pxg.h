@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PXG_ABI_VERSION 3
+#define PXG_ABI_VERSION 4
 
 #define PXG_MAX_STATES      8   /* HMM states per model (reference uses 6)        */
 #define PXG_MAX_MIXTURE     4   /* Gaussian components per state (reference <= 2) */
@@ -76,6 +76,18 @@ enum pxg_stage {
     PXG_STAGE_POLYA    = 1u << 3, /* a14-a17: event detection + interval DP     */
     PXG_STAGE_ALL_DEMUX = (1u << 0) | (1u << 1) | (1u << 2)
 };
+
+/* ---- arithmetic of the recurrent matrix products of a4 / a12 (pxg_config.lstm_arith) ----
+ * The reference hands both networks to TensorFlow (signal_loader.py:96-97, barcoding.py:106-107):
+ * float32 Keras LSTM equations, summation order unspecified.  Two canonical evaluations exist
+ * here, each restated bit for bit by oracle/pxo_core.c and selectable per context:
+ *   PXG_LSTM_Q8   hidden states and weights as 3-digit balanced base-256 fixed point (h: 2^-22,
+ *                 weights: 2^-p per matrix), the six leading digit products summed EXACTLY on the
+ *                 int8 matrix pipe (v_mfma_i32_16x16x64_i8), one float32 rounding per gate;
+ *                 integer sums are order-independent, so the result does not depend on how the
+ *                 hardware adds.  Default.
+ *   PXG_LSTM_F32  one k-ordered float32 fma chain per gate on v_mfma_f32_16x16x4_f32 (rounds 1-3). */
+enum pxg_lstm_arith { PXG_LSTM_Q8 = 0, PXG_LSTM_F32 = 1 };
 
 /* indices into pxg_stage_times.ms[] */
 enum pxg_timer {
@@ -140,7 +152,7 @@ typedef struct {
     int32_t stride;             /* rough_signal_stride = 15                      */
     int32_t scaler_length;      /* input_defs.length = 30000                     */
     int32_t scaler_min_length;  /* input_defs.min_length = 9000                  */
-    int32_t reserved0;
+    int32_t lstm_arith;         /* enum pxg_lstm_arith: arithmetic of the recurrent matmuls (a4, a12) */
     double scaler_xfrm[4];      /* scale_mean, scale_std, shift_mean, shift_std  */
     double scaler_qc_scale[2];  /* inclusive bounds, norm.ppf (signal_loader.py:65-68) */
     double scaler_qc_shift[2];

@@ -67,6 +67,12 @@ void pxo_demux_forward(const pxg_config* cfg, const float* x, int T, float* prob
 void pxo_lstm_layer(const pxg_lstm_layer* L, const float* x, int T, int reverse,
                     float* seq_out, float* h_last);
 
+/* the same layer in the exact fixed-point arithmetic (PXG_LSTM_Q8, see pxo_core.c): scalar inputs
+ * as floats xs[T] (input_dim 1) or vector inputs as q values xq[T][input_dim] (h = q * 2^-22);
+ * outputs are q values */
+void pxo_lstm_layer_q(const pxg_lstm_layer* L, const float* xs, const int32_t* xq, int T, int reverse,
+                      int32_t* seq_out, int32_t* q_last);
+
 /* a6+a7 worker_persistence.py:95-121 + pomegranate viterbi; returns logp */
 double pxo_viterbi(const pxg_hmm* hmm, const float* x, int T, int32_t* path);
 /* log emission density of state s at x (pomegranate Normal / GMM) */

@@ -283,6 +283,206 @@ void pxo_lstm_layer(const pxg_lstm_layer* L, const float* x, int T, int reverse,
     free(h); free(c); free(z);
 }
 
+/* ------------------------------------------------------------------------ *
+ * Canonical arithmetic "q8" (pxg_config.lstm_arith == PXG_LSTM_Q8).
+ * The Keras equations above with the matrix products evaluated in EXACT fixed point, so that
+ * the result does not depend on the order in which a machine adds the products:
+ *   hidden state  h_f = fl(o * tanh(c')) as before, then q = rint(h_f * 2^22) (ties to even),
+ *                 |q| <= 2^22; everything downstream sees h = q * 2^-22.
+ *   weights       per layer, all rows that multiply an h (vector-input rows, then recurrent
+ *                 rows) share one exponent p = the largest integer with max|W| * 2^p <= 8355711
+ *                 (= 127 + 127*256 + 127*65536); Wq = rint(W * 2^p).
+ *   digits        v = d0 + 256 d1 + 65536 d2 with every d in [-128, 127] (balanced base 256,
+ *                 unique); w0..w2 of Wq, h0..h2 of q.
+ *   products      the eight leading digit products, summed EXACTLY (they are small integers):
+ *                   A0 = sum_k w2 h2                      (weight 2^32)
+ *                   A1 = sum_k w2 h1 + w1 h2              (weight 2^24)
+ *                   A2 = sum_k w2 h0 + w1 h1 + w0 h2      (weight 2^16)
+ *                   A3 = sum_k w1 h0 + w0 h1              (weight 2^8)
+ *                 (w0 h0, below 2^-29 of a full-scale product, is dropped).
+ *   pre-activation, in table units (16 z for i, f, o; 32 z for the cell candidate):
+ *                   V = A0 * 256 + A1,  U = A2 * 256 + A3   (int32; no overflow for K <= 192:
+ *                                                            |h2| <= 64, every other digit <= 128)
+ *                   t = fma((float)V, 65536, (float)U)      -- both conversions round to nearest even
+ *                   u = fma(t, g * 2^(-p-14), start),  start = fma(x, g W_x, g b) (scalar input)
+ *                                                            or g b          (vector input)
+ *   gates         the spline sigmoid on u as above; C = 32 c carried; identical cell update.
+ * Dense layers read h = q * 2^-22 (exact in float32) and keep their fma chain.
+ * Here the integer sums are accumulated in float32 lanes -- every partial sum is an integer
+ * below 2^24, so each operation is exact and the compiler may vectorise freely.
+ * ------------------------------------------------------------------------ */
+#define Q_HSCALE 4194304.0f        /* 2^22 */
+#define Q_WMAX 8355711.0
+
+typedef struct {
+    int K, G, p;
+    float* w[3];                   /* digit planes [K][G] as float (exact small integers) */
+    float S[4];                    /* per gate block: g * 2^(-p-14) */
+} qmat;
+
+static void q_digits(int32_t v, int32_t d[3])
+{
+    d[0] = (int8_t)(uint8_t)(v & 255);
+    const int32_t r1 = (v - d[0]) / 256;           /* exact */
+    d[1] = (int8_t)(uint8_t)(r1 & 255);
+    d[2] = (r1 - d[1]) / 256;                       /* exact; in [-128, 127] for |v| <= 8355711 */
+}
+
+static qmat* qmat_build(const pxg_lstm_layer* L)
+{
+    const int H = L->units, G = 4 * H, I = L->input_dim;
+    const int Kin = I == 1 ? 0 : I, K = Kin + H;
+    qmat* M = (qmat*)calloc(1, sizeof(qmat));
+    M->K = K; M->G = G;
+    double m = 0.0;
+    for (int k = 0; k < K; k++) {
+        const float* row = k < Kin ? L->kernel + (size_t)k * G : L->recurrent + (size_t)(k - Kin) * G;
+        for (int j = 0; j < G; j++)
+            if (fabs((double)row[j]) > m) m = fabs((double)row[j]);
+    }
+    int p = 0;
+    if (m > 0.0) {
+        p = 40;
+        while (ldexp(m, p) > Q_WMAX) p--;
+    }
+    M->p = p;
+    for (int d = 0; d < 3; d++) M->w[d] = (float*)malloc(sizeof(float) * (size_t)K * G);
+    for (int k = 0; k < K; k++) {
+        const float* row = k < Kin ? L->kernel + (size_t)k * G : L->recurrent + (size_t)(k - Kin) * G;
+        for (int j = 0; j < G; j++) {
+            int32_t dg[3];
+            q_digits((int32_t)rint(ldexp((double)row[j], p)), dg);
+            for (int d = 0; d < 3; d++) M->w[d][(size_t)k * G + j] = (float)dg[d];
+        }
+    }
+    for (int g = 0; g < 4; g++) M->S[g] = (float)ldexp(g == 2 ? 32.0 : 16.0, -p - 14);
+    return M;
+}
+
+static void qmat_free(qmat* M)
+{
+    for (int d = 0; d < 3; d++) free(M->w[d]);
+    free(M);
+}
+
+/* the digit planes of a layer are built once per thread and kept (8 slots, keyed by a hash of
+ * the weights themselves: the same addresses may carry other weights later) */
+static uint64_t q_hash(const pxg_lstm_layer* L)
+{
+    const int G = 4 * L->units;
+    uint64_t h = 1469598103934665603ull ^ (uint64_t)L->units ^ ((uint64_t)L->input_dim << 20);
+    const size_t n[3] = { (size_t)L->input_dim * G, (size_t)L->units * G, (size_t)G };
+    const float* a[3] = { L->kernel, L->recurrent, L->bias };
+    for (int i = 0; i < 3; i++)
+        for (size_t k = 0; k < n[i]; k++) {
+            uint32_t b;
+            memcpy(&b, a[i] + k, 4);
+            h = (h ^ b) * 1099511628211ull;
+        }
+    return h;
+}
+
+static qmat* qmat_get(const pxg_lstm_layer* L)
+{
+    static __thread struct { uint64_t key; qmat* M; } slot[8];
+    static __thread int next;
+    const uint64_t key = q_hash(L);
+    for (int i = 0; i < 8; i++)
+        if (slot[i].M && slot[i].key == key) return slot[i].M;
+    const int i = next;
+    next = (next + 1) & 7;
+    if (slot[i].M) qmat_free(slot[i].M);
+    slot[i].key = key;
+    slot[i].M = qmat_build(L);
+    return slot[i].M;
+}
+
+/* spline sigmoid of an argument already in table units (u = 16 z) */
+static inline float sig_lookup_u(float u)
+{
+    if (!g_sig_ready) {
+        pxo_sigmoid_table(&g_sig_tab[0][0]);
+        g_sig_ready = 1;
+    }
+    u = fminf(fmaxf(u, -512.0f), 511.99997f);
+    const float fl = floorf(u);
+    const float s = u - fl;
+    const float* c = g_sig_tab[(int)fl + SIG_HALF];
+    float p = fmaf(c[3], s, c[2]);
+    p = fmaf(p, s, c[1]);
+    return fmaf(p, s, c[0]);
+}
+
+/* one step: qin = the vector input's q values (NULL for a scalar input xs), qh / C = state,
+ * scratch = 4 * G floats */
+static void lstm_step_q(const qmat* M, const pxg_lstm_layer* L, const float* xs, const int32_t* qin,
+                        int32_t* qh, float* C, float* scratch)
+{
+    const int H = L->units, G = M->G, K = M->K, Kin = K - H;
+    float *a0 = scratch, *a1 = scratch + G, *a2 = scratch + 2 * G, *a3 = scratch + 3 * G, *u = scratch + 4 * G;
+    memset(scratch, 0, sizeof(float) * 4 * (size_t)G);
+    for (int k = 0; k < K; k++) {
+        int32_t d[3];
+        q_digits(k < Kin ? qin[k] : qh[k - Kin], d);
+        const float h0 = (float)d[0], h1 = (float)d[1], h2 = (float)d[2];
+        const float *w0 = M->w[0] + (size_t)k * G, *w1 = M->w[1] + (size_t)k * G, *w2 = M->w[2] + (size_t)k * G;
+        for (int j = 0; j < G; j++) {          /* exact: integers below 2^24 */
+            a0[j] = fmaf(w2[j], h2, a0[j]);
+            a1[j] = fmaf(w2[j], h1, fmaf(w1[j], h2, a1[j]));
+            a2[j] = fmaf(w2[j], h0, fmaf(w1[j], h1, fmaf(w0[j], h2, a2[j])));
+            a3[j] = fmaf(w1[j], h0, fmaf(w0[j], h1, a3[j]));
+        }
+    }
+    for (int j = 0; j < G; j++) {
+        const int gate = j / H;
+        const float g = gate == 2 ? 32.0f : 16.0f;
+        const float start = L->input_dim == 1 ? fmaf(xs[0], L->kernel[j] * g, L->bias[j] * g) : L->bias[j] * g;
+        const int32_t V = (int32_t)a0[j] * 256 + (int32_t)a1[j];
+        const int32_t U = (int32_t)a2[j] * 256 + (int32_t)a3[j];
+        const float t = fmaf((float)V, 65536.0f, (float)U);
+        u[j] = fmaf(t, M->S[gate], start);
+    }
+    for (int n = 0; n < H; n++) {
+        const float ig = sig_lookup_u(u[n]);
+        const float fg = sig_lookup_u(u[H + n]);
+        const float Gc = fmaf(64.0f, sig_lookup_u(u[2 * H + n]), -32.0f);
+        const float og = sig_lookup_u(u[3 * H + n]);
+        const float fc = fg * C[n];
+        const float in = ig * Gc;
+        const float cn = fc + in;
+        C[n] = cn;
+        const float th = fmaf(2.0f, sig_lookup_u(cn), -1.0f);
+        const float hf = og * th;
+        qh[n] = (int32_t)rintf(hf * Q_HSCALE);
+    }
+}
+
+/* one layer over a sequence; x: float scalars [T] (input_dim 1) or q values [T][I];
+ * seq_out (q values, [T][H], stored at the original time index) and q_last may be NULL */
+void pxo_lstm_layer_q(const pxg_lstm_layer* L, const float* xs, const int32_t* xq, int T, int reverse,
+                      int32_t* seq_out, int32_t* q_last)
+{
+    const int H = L->units, I = L->input_dim;
+    const qmat* M = qmat_get(L);
+    int32_t* qh = (int32_t*)calloc(H, sizeof(int32_t));
+    float* C = (float*)calloc(H, sizeof(float));
+    float* scratch = (float*)malloc(sizeof(float) * 5 * (size_t)M->G);
+    for (int s = 0; s < T; s++) {
+        const int t = reverse ? T - 1 - s : s;
+        lstm_step_q(M, L, I == 1 ? xs + t : NULL, I == 1 ? NULL : xq + (size_t)t * I, qh, C, scratch);
+        if (seq_out)
+            memcpy(seq_out + (size_t)t * H, qh, sizeof(int32_t) * H);
+    }
+    if (q_last)
+        memcpy(q_last, qh, sizeof(int32_t) * H);
+    free(qh); free(C); free(scratch);
+}
+
+static void q_to_float(const int32_t* q, int n, float* out)
+{
+    for (int i = 0; i < n; i++) out[i] = (float)q[i] * (1.0f / Q_HSCALE);    /* exact */
+}
+
 static void dense_forward(const pxg_dense_layer* D, const float* x, float* out)
 {
     for (int j = 0; j < D->out_dim; j++) {
@@ -298,6 +498,17 @@ static void dense_forward(const pxg_dense_layer* D, const float* x, float* out)
 void pxo_scaler_forward(const pxg_config* cfg, const float* x, int T, float* pred)
 {
     const int H1 = cfg->scaler_lstm1.units, H2 = cfg->scaler_lstm2.units;
+    if (cfg->lstm_arith == PXG_LSTM_Q8) {
+        int32_t* seq = (int32_t*)malloc(sizeof(int32_t) * (size_t)T * H1);
+        int32_t* q2 = (int32_t*)malloc(sizeof(int32_t) * H2);
+        float* h2 = (float*)malloc(sizeof(float) * H2);
+        pxo_lstm_layer_q(&cfg->scaler_lstm1, x, NULL, T, 0, seq, NULL);
+        pxo_lstm_layer_q(&cfg->scaler_lstm2, NULL, seq, T, 0, NULL, q2);
+        q_to_float(q2, H2, h2);
+        dense_forward(&cfg->scaler_dense, h2, pred);
+        free(seq); free(q2); free(h2);
+        return;
+    }
     float* seq = (float*)malloc(sizeof(float) * (size_t)T * H1);
     float* h2 = (float*)malloc(sizeof(float) * H2);
     pxo_lstm_layer(&cfg->scaler_lstm1, x, T, 0, seq, NULL);
@@ -340,6 +551,21 @@ void pxo_demux_forward(const pxg_config* cfg, const float* x, int T, float* prob
     float* cat = (float*)malloc(sizeof(float) * (size_t)T * (Hf + Hb));
     float* ht = (float*)malloc(sizeof(float) * Ht);
     float z[PXG_MAX_CLASSES], e[PXG_MAX_CLASSES];
+    if (cfg->lstm_arith == PXG_LSTM_Q8) {
+        int32_t* qf = (int32_t*)malloc(sizeof(int32_t) * (size_t)T * Hf);
+        int32_t* qb = (int32_t*)malloc(sizeof(int32_t) * (size_t)T * Hb);
+        int32_t* qc = (int32_t*)malloc(sizeof(int32_t) * (size_t)T * (Hf + Hb));
+        int32_t* qt = (int32_t*)malloc(sizeof(int32_t) * Ht);
+        pxo_lstm_layer_q(&cfg->demux_fwd, x, NULL, T, 0, qf, NULL);
+        pxo_lstm_layer_q(&cfg->demux_bwd, x, NULL, T, 1, qb, NULL);
+        for (int t = 0; t < T; t++) {
+            memcpy(qc + (size_t)t * (Hf + Hb), qf + (size_t)t * Hf, sizeof(int32_t) * Hf);
+            memcpy(qc + (size_t)t * (Hf + Hb) + Hf, qb + (size_t)t * Hb, sizeof(int32_t) * Hb);
+        }
+        pxo_lstm_layer_q(&cfg->demux_top, NULL, qc, T, 0, NULL, qt);
+        q_to_float(qt, Ht, ht);
+        free(qf); free(qb); free(qc); free(qt);
+    } else {
     pxo_lstm_layer(&cfg->demux_fwd, x, T, 0, sf, NULL);
     pxo_lstm_layer(&cfg->demux_bwd, x, T, 1, sb, NULL);
     for (int t = 0; t < T; t++) {
@@ -347,6 +573,7 @@ void pxo_demux_forward(const pxg_config* cfg, const float* x, int T, float* prob
         memcpy(cat + (size_t)t * (Hf + Hb) + Hf, sb + (size_t)t * Hb, sizeof(float) * Hb);
     }
     pxo_lstm_layer(&cfg->demux_top, cat, T, 0, NULL, ht);
+    }
     dense_forward(&cfg->demux_dense, ht, z);
     float m = z[0];
     for (int j = 1; j < C; j++)

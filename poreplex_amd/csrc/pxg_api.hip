@@ -241,6 +241,10 @@ extern "C" int pxg_create(const pxg_config* cfg, pxg_ctx** out)
             if ((rc = upload(ctx, &ctx->d_lsetab, lt.data(), lt.size()))) break;
         }
         if ((rc = pxg_lstm_upload(ctx))) break;
+        if (cfg->lstm_arith != PXG_LSTM_Q8 && cfg->lstm_arith != PXG_LSTM_F32) {
+            rc = fail(ctx, PXG_E_INVALID, "pxg_config.lstm_arith: unknown arithmetic"); break;
+        }
+        if ((rc = pxg_q8_upload(ctx))) break;
     } while (0);
     // host pointers in the copied config are not retained
     ctx->cfg.scaler_lstm1.kernel = ctx->cfg.scaler_lstm1.recurrent = ctx->cfg.scaler_lstm1.bias = nullptr;
@@ -296,6 +300,7 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     if (ctx->scaler_dense.bias) (void)hipFree(ctx->scaler_dense.bias);
     if (ctx->demux_dense.kernel) (void)hipFree(ctx->demux_dense.kernel);
     if (ctx->demux_dense.bias) (void)hipFree(ctx->demux_dense.bias);
+    pxg_q8_free(ctx);
     if (ctx->d_calibration) (void)hipFree(ctx->d_calibration);
     if (ctx->d_sigtab) (void)hipFree(ctx->d_sigtab);
     if (ctx->d_lsetab) (void)hipFree(ctx->d_lsetab);
@@ -361,7 +366,7 @@ static int reserve_batch(pxg_ctx* ctx, int64_t n, int64_t n_samples)
     if ((rc = pxg_reserve(ctx, ctx->idx_demux, (size_t)n))) return rc;
     if ((rc = pxg_reserve(ctx, ctx->counters, 8))) return rc;
     if ((rc = pxg_reserve(ctx, ctx->win, (size_t)n * c.signal_trim_length))) return rc;
-    if ((rc = pxg_reserve(ctx, ctx->bidir, (size_t)n * c.signal_trim_length * 96))) return rc;
+    if ((rc = pxg_reserve(ctx, ctx->bidir, (size_t)((n + 15) / 16 * 16) * c.signal_trim_length * 96))) return rc;
     if ((rc = pxg_reserve(ctx, ctx->probs, (size_t)n * PXG_MAX_CLASSES))) return rc;
     if ((rc = pxg_reserve(ctx, ctx->results, (size_t)n))) return rc;
     return PXG_OK;
@@ -1112,7 +1117,7 @@ extern "C" int pxg_demux_lstm(pxg_ctx* ctx, int64_t n, const float* win, float* 
     const size_t trim = (size_t)ctx->cfg.signal_trim_length;
     const int C = ctx->cfg.demux_dense.out_dim;
     float* d_win = S.put(win, (size_t)n * trim, ctx->stream);
-    float* d_bidir = S.alloc<float>((size_t)n * trim * 96);
+    float* d_bidir = S.alloc<float>((size_t)((n + 15) / 16 * 16) * trim * 96);
     float* d_probs = S.alloc<float>((size_t)n * PXG_MAX_CLASSES);
     HOOK_CHECK(d_win && d_bidir && d_probs);
     int rc = pxg_launch_demux_lstm(ctx, n, nullptr, nullptr, d_win, d_bidir, d_probs,

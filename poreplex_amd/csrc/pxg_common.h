@@ -260,6 +260,12 @@ struct pxg_ctx {
     PxgHmmDev hmm[2];
     PxgLstmDev scaler1, scaler2, demux_fwd, demux_bwd, demux_top;
     PxgDenseDev scaler_dense, demux_dense;
+    struct {                     // PXG_LSTM_Q8: digit planes of the integer weight matrices in MFMA
+        int8_t* scaler_frag = nullptr;   // A-fragment order (k_lstm_q8.hip), 16 bytes per thread and fragment
+        int8_t* bidir_frag = nullptr;
+        int8_t* top_frag = nullptr;
+        float s_scaler1 = 0, s_scaler2 = 0, s_fwd = 0, s_bwd = 0, s_top = 0;   // 16 * 2^(-p-14) per layer
+    } q8;
     double* d_calibration = nullptr;
     float* d_sigtab = nullptr;   // PXG_SIG_NSEG x 4 spline coefficients
     double* d_lsetab = nullptr;  // PXG_LSE_TAB_DOUBLES: tables of pxg_log1pexp
@@ -410,6 +416,13 @@ int pxg_launch_z_decode(pxg_ctx* ctx, hipStream_t stream, int64_t n_chunks, cons
                         int64_t data_base, int64_t dst_base, int16_t* out);
 int pxg_launch_finalize(pxg_ctx* ctx, int64_t n, uint32_t stage_mask);
 int pxg_lstm_upload(pxg_ctx* ctx);   // shape checks
+// PXG_LSTM_Q8 (k_lstm_q8.hip)
+int pxg_q8_upload(pxg_ctx* ctx);
+void pxg_q8_free(pxg_ctx* ctx);
+int pxg_launch_scaler_lstm_q8(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, const int32_t* count,
+                              const float* head, float* pred);
+int pxg_launch_demux_lstm_q8(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, const int32_t* count,
+                             const float* win, float* bidir, float* probs, int timer_a, int timer_b);
 int pxg_polya_supported(pxg_ctx* ctx);
 int pxg_launch_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
                      const pxg_calib* cal, const float* ss, const int32_t* status,

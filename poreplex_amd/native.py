@@ -15,7 +15,8 @@ from . import config as _config
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'csrc', 'libpxg.so')
 
-PXG_ABI_VERSION = 3
+PXG_ABI_VERSION = 4
+LSTM_ARITH = {'q8': 0, 'f32': 1}      # enum pxg_lstm_arith
 PXG_E_NOMEM, PXG_E_UNSUPPORTED = -4, -6
 PXG_MAX_STATES = 8
 PXG_MAX_MIXTURE = 4
@@ -81,7 +82,7 @@ class PxgConfig(C.Structure):
     _fields_ = [
         ('abi_version', C.c_uint32), ('device_id', C.c_int32),
         ('stride', C.c_int32), ('scaler_length', C.c_int32),
-        ('scaler_min_length', C.c_int32), ('reserved0', C.c_int32),
+        ('scaler_min_length', C.c_int32), ('lstm_arith', C.c_int32),
         ('scaler_xfrm', C.c_double * 4),
         ('scaler_qc_scale', C.c_double * 2), ('scaler_qc_shift', C.c_double * 2),
         ('scaler_lstm1', PxgLstmLayer), ('scaler_lstm2', PxgLstmLayer),
@@ -260,6 +261,12 @@ class NativeConfig:
         cfg.device_id = device_id
 
         sp = config['signal_processing']
+        # arithmetic of the recurrent matmuls (include/pxg.h pxg_lstm_arith): 'q8' = exact fixed point on
+        # the int8 matrix pipe (default), 'f32' = float32 fma chains; PXG_LSTM_ARITH overrides the config
+        arith = os.environ.get('PXG_LSTM_ARITH') or str(sp.get('lstm_arith', 'q8'))
+        if arith not in LSTM_ARITH:
+            raise ValueError('lstm_arith must be one of %s' % sorted(LSTM_ARITH))
+        cfg.lstm_arith = LSTM_ARITH[arith]
         scaler = _config.load_model_arrays(sp['scaler_model'])
         cfg.stride = int(sp['rough_signal_stride'])
         cfg.scaler_length = int(scaler['input_length'])
