@@ -19,6 +19,7 @@ quoted on): a 10 000-read batch of ~60 000-sample reads per GPU, all stages a1-a
                                           per GPU, never materialised on the host)
 """
 import argparse
+import copy
 import json
 import os
 import socket
@@ -41,6 +42,15 @@ FLOP_SCALER = 2.0 * 2000 * (48 * 192 + 96 * 192) + 2000 * 192 * 2 + 2 * 48 * 2  
 FLOP_BIDIR = 2.0 * 300 * 2 * (48 * 192) + 300 * 2 * 192 * 2
 FLOP_TOP = 2.0 * 300 * (160 * 256) + 2 * 64 * 5
 PEAK_FP32_MFMA = 157.3e12      # MI355X_MICROARCH.md: dense fp32 MFMA peak, FLOP/s
+# dense int8 MFMA peak: 2 x the bf16 rate (MI355X_MICROARCH.md "I8 ~2x bf16 rate (2xK)", bf16 ~2.5 PF dense);
+# the guide's own micro-benchmark ceiling for v_mfma_i32_16x16x64_i8 is 3.944 POP/s
+PEAK_I8_MFMA = 5.0e15
+# PXG_LSTM_Q8 (k_lstm_q8.hip): every float32 multiply-add of a recurrent matrix product becomes EIGHT int8
+# digit products (four significance levels); executed MFMAs also multiply the zero bytes that pad a
+# 48-unit vector to the instruction's 64-wide k block
+Q8_PRODUCTS = 8
+OPS_SCALER_Q8 = Q8_PRODUCTS * 2.0 * 2000 * (48 * 192 + 96 * 192)              # algorithmic int8 ops per read
+OPS_SCALER_Q8_EXECUTED = 2001 * 4 * 72 * 32768.0 / 16                          # 4 waves x 72 MFMAs per 16 reads and step
 PEAK_HBM = 8.0e12              # B/s
 # the only throughput the reference publishes (Poreplex 0.1, whole
 # pipeline incl. FAST5 I/O, 2x Xeon E5-2687W v3 = 20 cores): 1 339 070 reads in 1 h 37 min
@@ -51,6 +61,9 @@ TRAFFIC_FILE = os.path.join('profiles', 'r03', 'hbm_traffic.json')
 # host-side legs on all ranks at once) with the real kernels on a ONE-GPU box.  A plumbing check:
 # the line says so and is not a scaling number.
 SHARE_GPU = os.environ.get('PXG_BENCH_SHARE_GPU') == '1'
+
+DTYPE = {'q8': 'i8 x 3 digits, int32 exact sums (LSTM matmuls on the int8 MFMA pipe) + f32 gates / f64 (Viterbi) / i16 in',
+         'f32': 'f32 (LSTM MFMA) / f64 (Viterbi) / i16 in'}
 
 STAGES = {
     'demux': (2, 'a1-a13 (scaler LSTM + Viterbi + barcode LSTMs)', 'reads/s (segment+barcode)'),
@@ -82,6 +95,10 @@ def parse(argv=None):
     ap.add_argument('--cpu-all-cores-sample', type=int, default=4096,
                     help='reads timed over all physical cores, one process each (0 = skip)')
     ap.add_argument('--seed', type=int, default=924)
+    ap.add_argument('--lstm-arith', choices=['q8', 'f32'], default=None,
+                    help='arithmetic of the recurrent matmuls (include/pxg.h pxg_lstm_arith); default: the '
+                         'config\'s (q8 = exact fixed point on the int8 matrix pipe)')
+    ap.add_argument('--no-f32-leg', action='store_true', help='skip the float32-arithmetic comparison leg of the default line')
     ap.add_argument('--no-overlap-test', action='store_true',
                     help='skip the extra PCIe-overlapped steps (profiling runs: keeps the kernel '
                          'statistics to the timed steps)')
@@ -175,6 +192,9 @@ _POOL = {}
 
 def _cpu_worker_init(config, base, mask, use_inject):
     from oracle.pxo import Oracle
+    config = copy.deepcopy(config)
+    config['signal_processing']['lstm_arith'] = 'f32'      # the CPU's own best arithmetic, see cpu_baseline
+    os.environ.pop('PXG_LSTM_ARITH', None)
     _POOL.update(oracle=Oracle(config), base=base, mask=mask, use_inject=use_inject)
 
 
@@ -641,6 +661,66 @@ def unpinned_rows_block():
     return out
 
 
+def f32_leg(args, config, local_rank, base, inject, mask, res_q8, stage_ms_q8):
+    """A second context in PXG_LSTM_F32 on the same resident batch: steps timed the same way (kernels +
+    D2H of the records), and the q8 records against the f32 records field by field."""
+    cfg = copy.deepcopy(config)
+    cfg['signal_processing']['lstm_arith'] = 'f32'
+    env_arith = os.environ.pop('PXG_LSTM_ARITH', None)
+    try:
+        c2 = N.NativeContext(cfg, device_id=local_rank)
+    finally:
+        if env_arith is not None:
+            os.environ['PXG_LSTM_ARITH'] = env_arith
+    try:
+        c2.upload(base['arena'], base['offsets'], base['calib'], inject)
+        buf = np.zeros(len(res_q8), dtype=N.RESULT_DTYPE)
+        for _ in range(2):
+            c2.run(mask)
+            r32 = c2.download(buf)
+        c2.sync()
+        steps = max(3, min(args.steps, 5))
+        acc = {k: 0.0 for k in N.TIMER_NAMES}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            c2.run(mask)
+            r32 = c2.download(buf)
+            times, _ = c2.stage_times()
+            for k in acc:
+                acc[k] += times[k]
+        c2.sync()
+        wall = time.perf_counter() - t0
+    finally:
+        c2.close()
+    both = (res_q8['status'] == 0) & (r32['status'] == 0)
+    pushed = both & (res_q8['bc_pushed'] == 1) & (r32['bc_pushed'] == 1)
+    return {
+        'reads_per_s': len(res_q8) * steps / wall, 'ms_per_step': wall / steps * 1e3, 'steps': steps,
+        'stage_ms': {k: round(v / steps, 4) for k, v in acc.items()},
+        'kernel': 'k_scaler_lstm_q (v_mfma_f32_16x16x4_f32)',
+        'roofline_frac_fp32_mfma': len(res_q8) * FLOP_SCALER / (acc['scaler_lstm'] / steps * 1e-3) / PEAK_FP32_MFMA
+        if acc['scaler_lstm'] else None,
+        'q8_speedup_scaler_lstm': (acc['scaler_lstm'] / steps) / stage_ms_q8['scaler_lstm'] if stage_ms_q8['scaler_lstm'] else None,
+        # decisions of the two arithmetics on the SAME reads
+        'q8_vs_f32': {
+            'reads': int(len(res_q8)),
+            'status_flips': int((res_q8['status'] != r32['status']).sum()),
+            'reads_with_a_segment_boundary_moved': int(((res_q8['seg_first'] != r32['seg_first']) |
+                                                        (res_q8['seg_last'] != r32['seg_last'])).any(1)[both].sum()),
+            'window_gate_flips': int((res_q8['bc_pushed'] != r32['bc_pushed'])[both].sum()),
+            'argmax_flips': int((res_q8['bc_label'] != r32['bc_label'])[pushed].sum()),
+            'called_uncalled_flips': int((res_q8['bc_called'] != r32['bc_called'])[pushed].sum()),
+            'phred_changes': int((res_q8['bc_phred'] != r32['bc_phred'])[pushed].sum()),
+            'scale_max_abs_diff': float(np.abs(res_q8['scale'][both] - r32['scale'][both]).max()) if both.any() else None,
+            'shift_max_abs_diff': float(np.abs(res_q8['shift'][both] - r32['shift'][both]).max()) if both.any() else None,
+            'softmax_max_abs_diff': float(np.abs(res_q8['probs'][pushed] - r32['probs'][pushed]).max()) if pushed.any() else None,
+            'polya_called_flips': int((res_q8['polya_called'] != r32['polya_called'])[both].sum()),
+            'polya_interval_changes': int(((res_q8['polya_begin'] != r32['polya_begin']) |
+                                           (res_q8['polya_end'] != r32['polya_end']))[both].sum()),
+        },
+    }
+
+
 def make_context(args, config, local_rank):
     if args.context_factory:
         import importlib
@@ -667,6 +747,10 @@ def main():
                          'or without a launcher)'.format(args.gpus, world, args.gpus))
     standin = args.context_factory is not None
     config = default_config()
+    if args.lstm_arith:
+        os.environ.pop('PXG_LSTM_ARITH', None)
+        config['signal_processing']['lstm_arith'] = args.lstm_arith
+    arith = os.environ.get('PXG_LSTM_ARITH') or str(config['signal_processing'].get('lstm_arith', 'q8'))
     wl_cfg, wl_stages, wl_metric = STAGES[args.workload]
     mask = {'demux': N.STAGE_ALL_DEMUX, 'chimera': N.STAGE_ALL_DEMUX,
             'polya': N.STAGE_ALL_DEMUX | N.STAGE_POLYA, 'full': N.STAGE_ALL_DEMUX | N.STAGE_POLYA,
@@ -838,12 +922,30 @@ def main():
         flops = n_scaled * FLOP_SCALER
         # k_lstm.hip pxg_launch_scaler_lstm: time-sliced kernel whenever the batch has more
         # 16-read tiles than the 2 x #CU resident workgroups
-        kernel = 'k_scaler_lstm_q' if (n_local + 15) // 16 > 2 * info['compute_units'] else 'k_scaler_lstm'
-        roofline = {'kernel': kernel, 'bound': 'mfma',
-                    'achieved': flops / dur / 1e12 if dur else None, 'peak': PEAK_FP32_MFMA / 1e12,
-                    'unit': 'TFLOP/s', 'frac': flops / dur / PEAK_FP32_MFMA if dur else None,
-                    'traffic': None, 'algorithmic_flop_per_read': FLOP_SCALER,
-                    'kernel_ms': stage_ms['scaler_lstm']}
+        if arith == 'q8':
+            # executed on the int8 matrix pipe: `achieved` = algorithmic int8 digit products (8 per float32
+            # multiply-add, no padding) / launch duration against the dense int8 MFMA peak; beside it the
+            # executed rate (padding included) and what the same launch is worth in the network's own
+            # float32 FLOPs against the fp32 MFMA roof the float32 arithmetic is bound by
+            ops = n_scaled * OPS_SCALER_Q8
+            roofline = {'kernel': 'k_scaler_lstm_q8', 'bound': 'mfma',
+                        'achieved': ops / dur / 1e12 if dur else None, 'peak': PEAK_I8_MFMA / 1e12,
+                        'unit': 'TOP/s (int8)', 'frac': ops / dur / PEAK_I8_MFMA if dur else None,
+                        'traffic': None, 'algorithmic_int8_op_per_read': OPS_SCALER_Q8,
+                        'executed_int8_TOPs': n_scaled * OPS_SCALER_Q8_EXECUTED / dur / 1e12 if dur else None,
+                        'executed_frac': n_scaled * OPS_SCALER_Q8_EXECUTED / dur / PEAK_I8_MFMA if dur else None,
+                        'algorithmic_fp32_TFLOPs': n_scaled * FLOP_SCALER / dur / 1e12 if dur else None,
+                        'frac_of_fp32_mfma_peak': n_scaled * FLOP_SCALER / dur / PEAK_FP32_MFMA if dur else None,
+                        'algorithmic_flop_per_read': FLOP_SCALER, 'kernel_ms': stage_ms['scaler_lstm'],
+                        'note': 'issue-bound: per wave and step 72 v_mfma_i32_16x16x64_i8 (~17.5 cycles each per '
+                                'SIMD) and ~470 VALU instructions share one issue stream (DESIGN.md 3.1)'}
+        else:
+            kernel = 'k_scaler_lstm_q' if (n_local + 15) // 16 > 2 * info['compute_units'] else 'k_scaler_lstm'
+            roofline = {'kernel': kernel, 'bound': 'mfma',
+                        'achieved': flops / dur / 1e12 if dur else None, 'peak': PEAK_FP32_MFMA / 1e12,
+                        'unit': 'TFLOP/s', 'frac': flops / dur / PEAK_FP32_MFMA if dur else None,
+                        'traffic': None, 'algorithmic_flop_per_read': FLOP_SCALER,
+                        'kernel_ms': stage_ms['scaler_lstm']}
     else:
         dur = stage_ms['segment'] * 1e-3
         nbytes = float(np.minimum(lens, 100000).sum() * 2 + n_local * 88)
@@ -906,7 +1008,19 @@ def main():
     concordance = None
     if args.cpu_sample > 0 and not standin:
         from oracle.pxo import Oracle
-        orc = Oracle(config)
+        # cpu_baseline is the oracle in FLOAT32 arithmetic -- one fma chain per gate is what a CPU's SIMD
+        # units run fastest (the q8 digit arithmetic is shaped for the int8 matrix pipe and costs the oracle
+        # about twice the time: timing THAT would flatter the GPU); the concordance check below uses the
+        # oracle in the arithmetic the GPU context runs
+        cfg_f32 = copy.deepcopy(config)
+        cfg_f32['signal_processing']['lstm_arith'] = 'f32'
+        env_arith = os.environ.pop('PXG_LSTM_ARITH', None)
+        orc_f32 = Oracle(cfg_f32)
+        config_c = copy.deepcopy(config)
+        config_c['signal_processing']['lstm_arith'] = arith
+        orc = orc_f32 if arith == 'f32' else Oracle(config_c)
+        if env_arith is not None:
+            os.environ['PXG_LSTM_ARITH'] = env_arith
         # N > 1: no cpu_baseline (it is an N = 1 figure), only the concordance check on a small sample
         ns = min(args.cpu_sample if world == 1 else min(args.cpu_sample, 128), n_local)
         parts = [base['arena'][base['offsets'][b]:base['offsets'][b + 1]] for b in which[:ns]]
@@ -914,12 +1028,19 @@ def main():
         s_cal = base['calib'][which[:ns]]
         inj = None if inject is None else inject[which[:ns]]
         c0 = time.perf_counter()
-        want = orc.process_batch(s_arena, s_off, s_cal, inj, mask)
+        want = orc_f32.process_batch(s_arena, s_off, s_cal, inj, mask)
+        cpu_core_s = time.perf_counter() - c0
+        if orc is not orc_f32:                # the checker, in the GPU's arithmetic (half the sample: it is slower)
+            ns_c = max(1, ns // 2)
+            want = orc.process_batch(s_arena[:s_off[ns_c]], s_off[:ns_c + 1], s_cal[:ns_c],
+                                     None if inj is None else inj[:ns_c], mask)
+        else:
+            ns_c = ns
         cand_mismatch = None
         if scan:
             iv, cnt, start = ctx.unsplit_scan(ev_first, ev_blocks)
             cand_mismatch = 0
-            for i in range(ns):
+            for i in range(ns_c):
                 w = want[i]
                 if w['status'] != 0 or w['seg_first'][3] < 0 or ev_blocks[i] <= 0:
                     cand_mismatch += int(cnt[i] != 0)
@@ -928,11 +1049,12 @@ def main():
                 wiv, wc = orc.unsplit_scan(sc, 0, (int(w['seg_last'][3]) + 1) * 15,
                                            float(s_cal[i]['sampling_rate']))
                 cand_mismatch += int(wc != cnt[i] or wiv.tolist() != iv[start[i]:start[i + 1]].tolist())
-        cpu_s = time.perf_counter() - c0
+        cpu_s = cpu_core_s
         model, physical, usable, quota = host_description()
         cpu = {'value': ns / cpu_s, 'unit': 'reads/s', 'cores': 1, 'kind': 'port',
                'sample': 'first {} reads of the same batch, same stages, oracle/libpxo.so '
-                         '(C restatement, gcc -O2 AVX2), single thread, {:.1f} s'.format(ns, cpu_s),
+                         '(C restatement, gcc -O2 AVX2, float32 LSTM arithmetic), single thread, {:.1f} s'.format(ns, cpu_s),
+               'arith': 'f32',
                'host_cpu': model, 'physical_cores': physical, 'usable_cores': usable,
                'cgroup_cpu_quota': quota,
                # what perfect scaling of the one-core rate over every physical core would give
@@ -944,10 +1066,10 @@ def main():
                                     'core, read shards; ProcessPoolExecutor shape of pipeline.py:96), '
                                     '{} s wall'.format(cpu_all['reads'], cpu_all['cores'], cpu_all['wall_s']))
             cpu['speedup_vs_all_cores'] = value / world / cpu_all['value']
-        got = res[:ns]
+        got = res[:ns_c]
         same = [f for f in got.dtype.names if np.array_equal(got[f], want[f], equal_nan=True)]
         concordance = {
-            'reads_compared': ns,
+            'reads_compared': ns_c, 'arith': arith,
             'status_mismatch': int((got['status'] != want['status']).sum()),
             'segment_mismatch': int(((got['seg_first'] != want['seg_first']) |
                                      (got['seg_last'] != want['seg_last'])).any(1).sum()),
@@ -961,6 +1083,14 @@ def main():
         concordance.update(unpinned_rows_block())
         if world > 1:
             cpu = None
+
+    # ---- the same batch in the OTHER arithmetic (float32 fma chains on the fp32 MFMA, rounds 1-3): its
+    # rate, and every decision the two arithmetics take differently over the whole batch ----------------
+    if arith == 'q8' and not standin and world == 1 and not n_base and not args.no_f32_leg and args.workload != 'segment':
+        try:
+            extra['f32_arith'] = f32_leg(args, config, local_rank, base, inject, mask, res, stage_ms)
+        except Exception as exc:                       # reported, never hidden
+            extra['f32_arith'] = {'error': '{}: {}'.format(type(exc).__name__, exc)}
 
     # ---- the reference-shaped API (never `value` of the default line): process_batch calls ----
     api = None
@@ -996,7 +1126,7 @@ def main():
         'vs_baseline_basis': 'BASELINE.md section 1: ~230 reads/s, the only published throughput '
                              '(Poreplex 0.1, whole pipeline incl. FAST5 I/O, 20 Xeon cores): an '
                              'order-of-magnitude anchor, not a hot-path number; see cpu_baseline',
-        'dtype': 'f32 (LSTM MFMA) / f64 (Viterbi) / i16 in',
+        'dtype': DTYPE[arith],
         'data': 'TEST-STANDIN (no GPU work timed)' if standin else ('synthetic (ranks SHARING one GPU: a plumbing check, not a scaling number)' if SHARE_GPU else 'synthetic'),
         'config': {'workload': 'BASELINE configs[{}]: {} x ~{} int16 samples, stages {}'.format(
                        4 if args.scaling == 'strong' else wl_cfg,

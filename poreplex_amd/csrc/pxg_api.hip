@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "pxg_common.h"
+#include <cctype>
 #include "pxg_zcheck.h"
 
 static std::string g_last_error;
@@ -326,6 +327,25 @@ extern "C" int pxg_get_device_info(pxg_ctx* ctx, pxg_device_info* out)
     memset(out, 0, sizeof(*out));
     strncpy(out->name, prop.name, sizeof(out->name) - 1);
     strncpy(out->arch, prop.gcnArchName, sizeof(out->arch) - 1);
+    if (!out->name[0]) {
+        // some containers give the HIP runtime no marketing name: ask the PCI device's sysfs node, then say
+        // what IS known instead of printing nothing
+        char bus[32] = {0};
+        if (hipDeviceGetPCIBusId(bus, sizeof(bus), ctx->device) == hipSuccess) {
+            for (char* c = bus; *c; c++) *c = (char)tolower(*c);
+            const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/product_name";
+            if (FILE* fh = fopen(path.c_str(), "r")) {
+                if (fgets(out->name, sizeof(out->name), fh)) {
+                    for (char* c = out->name; *c; c++)
+                        if (*c == '\n') *c = 0;
+                }
+                fclose(fh);
+            }
+        }
+        if (!out->name[0])
+            snprintf(out->name, sizeof(out->name), "AMD %.20s, %d CUs (no product name from the HIP runtime)",
+                     prop.gcnArchName, prop.multiProcessorCount);
+    }
     out->compute_units = prop.multiProcessorCount;
     out->wavefront_size = prop.warpSize;
     out->total_mem = (int64_t)prop.totalGlobalMem;

@@ -14,16 +14,55 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+# the suite chooses the arithmetic of the recurrent networks itself (both, see `arith` below)
+os.environ.pop('PXG_LSTM_ARITH', None)
+
+# Both arithmetics of a4 / a12 (include/pxg.h pxg_lstm_arith) are product paths: everything that
+# depends on the config runs once per arithmetic, each against the goldens the REAL reference glue
+# produced with the oracle's stand-in networks in that arithmetic (tools/make_golden.py --arith):
+# tests/golden/ holds the f32 set, tests/golden/q8/ the files of the q8 set that differ from it.
+ARITHS = ('q8', 'f32')
+
+
+def G(name):
+    """golden file of the arithmetic the running test is in (see _arith_env)"""
+    return golden_path(os.environ.get('PXG_LSTM_ARITH', 'f32'), name)
+
+
+def golden_path(arith, name):
+    p = os.path.join(GOLDEN, 'q8', name)
+    return p if arith == 'q8' and os.path.exists(p) else os.path.join(GOLDEN, name)
 
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu)')
 
 
+@pytest.fixture(scope='session', params=ARITHS)
+def arith(request):
+    return request.param
+
+
 @pytest.fixture(scope='session')
-def config():
+def config(arith):
     from poreplex_amd.config import default_config
-    return default_config()
+    cfg = default_config()
+    cfg['signal_processing']['lstm_arith'] = arith
+    return cfg
+
+
+@pytest.fixture(autouse=True)
+def _arith_env(request, monkeypatch):
+    """PXG_LSTM_ARITH overrides the config's lstm_arith (native.NativeConfig), for the product and the
+    oracle alike: a test that uses an arithmetic-dependent fixture runs with every config it builds in
+    THAT arithmetic; every other test (host logic against the f32 golden set) is pinned to f32."""
+    monkeypatch.setenv('PXG_LSTM_ARITH', request.getfixturevalue('arith') if 'arith' in request.fixturenames else 'f32')
+
+
+@pytest.fixture(scope='session')
+def golden(arith):
+    """path of a golden file of this arithmetic's set"""
+    return lambda name: golden_path(arith, name)
 
 
 @pytest.fixture(scope='session')
@@ -33,23 +72,23 @@ def oracle(config):
 
 
 @pytest.fixture(scope='session')
-def bundle():
-    return dict(np.load(os.path.join(GOLDEN, 'batch0.pxr.npz')))
+def bundle(golden):
+    return dict(np.load(golden('batch0.pxr.npz')))
 
 
 @pytest.fixture(scope='session')
-def stages():
-    return dict(np.load(os.path.join(GOLDEN, 'batch0.stages.npz')))
+def stages(golden):
+    return dict(np.load(golden('batch0.stages.npz')))
 
 
 @pytest.fixture(scope='session')
-def unit():
-    return dict(np.load(os.path.join(GOLDEN, 'unit.npz')))
+def unit(golden):
+    return dict(np.load(golden('unit.npz')))
 
 
 @pytest.fixture(scope='session')
-def ref_results():
-    with open(os.path.join(GOLDEN, 'batch0.results.json')) as fh:
+def ref_results(golden):
+    with open(golden('batch0.results.json')) as fh:
         return json.load(fh)
 
 

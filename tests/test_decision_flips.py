@@ -82,10 +82,14 @@ def demux_f64_batch(wins):
     return e / e.sum(axis=1, keepdims=True)
 
 
-def measure(n_reads=2048, samples=40000, seed=924):
+def measure(n_reads=2048, samples=40000, seed=924, arith='q8'):
+    """pipeline (i) = the oracle in `arith` (include/pxg.h pxg_lstm_arith), (ii) = float64 networks"""
     from oracle.pxo import Oracle
     config = default_config()
+    config['signal_processing']['lstm_arith'] = arith
+    os.environ.pop('PXG_LSTM_ARITH', None)
     orc = Oracle(config)
+    assert orc.cfg.lstm_arith == N.LSTM_ARITH[arith]
     cfg = orc.cfg
     sb = synth_batch(n_reads, seed=seed, samples_per_read=samples, short_fraction=0.01)
     off, cal = sb['offsets'], sb['calib']
@@ -152,6 +156,7 @@ def measure(n_reads=2048, samples=40000, seed=924):
     # the networks alone: exact float64 classifier on the CANONICAL pipeline's own windows
     p64_same_input = demux_f64_batch(np.stack(wins_can))
     return {
+        'arith': arith,
         'reads': int(n_reads), 'samples_per_read': int(samples), 'seed': int(seed),
         'reads_scored_by_scaler': int(len(scored)),
         'scaler_pred_max_abs_diff': [float(d_pred[0]), float(d_pred[1])],
@@ -179,6 +184,7 @@ def measure_viterbi(n_reads=2048, n_chimeras=512, samples=40000, seed=924, only=
     whose in-read adapter candidate list changed."""
     import viterbi_variants as VV
     from oracle.pxo import Oracle
+    os.environ['PXG_LSTM_ARITH'] = 'f32'      # (scaling is injected: no network runs on this side)
     orc = Oracle(default_config())
     cfg = orc.cfg
     stride = int(cfg.stride)
@@ -277,10 +283,13 @@ def test_decision_flips_bounded():
     # the float64 nets are thousands of small matmuls: BLAS worker threads only spin on them (and,
     # under a CPU quota, can stall the test for many minutes)
     from threadpoolctl import threadpool_limits
+    # the suite measures the DEFAULT arithmetic (q8) on 1 024 reads; `python tests/test_decision_flips.py`
+    # walks both arithmetics on 2 048 (profiles/r04/decision_flips.json), tools/decision_flips_gpu.py
+    # the 20 000-read and adversarial sets on the GPU
     with threadpool_limits(limits=1):
-        r = measure()
+        r = measure(1024)
     print(json.dumps(r))
-    assert r['reads'] >= 2000 and r['windows_compared'] >= 1500
+    assert r['reads'] >= 1000 and r['windows_compared'] >= 750
     # the networks themselves: north_star's tolerance on identical inputs
     assert r['softmax_max_abs_diff_same_input'] <= 1e-4
     assert r['scaler_pred_max_abs_diff'][0] <= 2e-4 and r['scaler_pred_max_abs_diff'][1] <= 2e-4
@@ -316,5 +325,6 @@ def test_viterbi_formula_variants_move_no_decision():
 if __name__ == '__main__':
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-    out = {'lstm_side': measure(n), 'viterbi_side': measure_viterbi(n, max(n // 4, 8))}
+    out = {'lstm_side': {a: measure(n, arith=a) for a in ('q8', 'f32')},
+           'viterbi_side': measure_viterbi(n, max(n // 4, 8))}
     print(json.dumps(out, indent=1))

@@ -345,9 +345,10 @@ def test_full_size_determinism_and_order_invariance(ctx):
 # ---- a18 / a19 ---------------------------------------------------------------
 def _chimera():
     import json
-    b = dict(np.load(os.path.join(GOLDEN, 'chimera.pxr.npz')))
-    st = dict(np.load(os.path.join(GOLDEN, 'chimera.stages.npz')))
-    with open(os.path.join(GOLDEN, 'chimera.results.json')) as fh:
+    from conftest import G
+    b = dict(np.load(G('chimera.pxr.npz')))
+    st = dict(np.load(G('chimera.stages.npz')))
+    with open(G('chimera.results.json')) as fh:
         res = json.load(fh)
     bc = [json.loads(str(x)) for x in b['basecall']]
     return b, st, res, bc

@@ -8,14 +8,11 @@ import pytest
 
 from poreplex_amd import native as N
 
-GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-
-
 @pytest.fixture(scope='module')
-def chim():
-    b = dict(np.load(os.path.join(GOLDEN, 'chimera.pxr.npz')))
-    st = dict(np.load(os.path.join(GOLDEN, 'chimera.stages.npz')))
-    with open(os.path.join(GOLDEN, 'chimera.results.json')) as fh:
+def chim(golden):
+    b = dict(np.load(golden('chimera.pxr.npz')))
+    st = dict(np.load(golden('chimera.stages.npz')))
+    with open(golden('chimera.results.json')) as fh:
         res = json.load(fh)
     return b, st, res
 

@@ -56,7 +56,13 @@ def _attr_get_bytes(self, name):
 
 h5py.AttributeManager.__getitem__ = _attr_get_bytes
 
-OUT = os.path.join(REPO, 'tests', 'golden')
+# --arith f32|q8: the arithmetic of the ORACLE's stand-in networks (include/pxg.h pxg_lstm_arith).  The
+# reference's glue is the same either way; what changes is the last digits of (scale, shift) and of the
+# softmax the stand-ins hand to it.  f32 -> tests/golden/ (rounds 1-3), q8 -> tests/golden/q8/.
+ARITH = sys.argv[sys.argv.index('--arith') + 1] if '--arith' in sys.argv else 'f32'
+assert ARITH in ('f32', 'q8')
+os.environ['PXG_LSTM_ARITH'] = ARITH
+OUT = os.path.join(REPO, 'tests', 'golden') if ARITH == 'f32' else os.path.join(REPO, 'tests', 'golden', 'q8')
 # `make_golden.py --only batch0` rewrites just the fixtures whose name starts with that prefix.
 # Every fixture is an (inputs, outputs-of-the-real-reference) pair that carries its own inputs,
 # so sets made by different revisions of the synthetic generator can coexist: unit / polya /
