@@ -295,7 +295,7 @@ int pxg_process_batch(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
  * that call has its results, runs every stage, and returns with everything on the host --
  * the copy of call k+1 under the kernels of call k, the caller's host work for call k-1
  * (result dicts) under both.  Inputs: page-lock them (pxg_host_register) for DMA transfers.
- * (Do not mix with the split calls pxg_batch_upload/stage/swap/run/... from other threads.)
+ * (The split calls pxg_batch_stage/swap/run/... may run beside it on other threads under pxg_ctx_lock.)
  *   z != NULL: the samples arrive encoded (pxg_batch_stage_z's arguments), raw_arena is NULL.
  *   unsplit_first_sample != NULL: also run the a19 window scan (pxg_batch_unsplit_scan's
  *     arguments) on the batch while it is resident; candidates of all reads back to back in
@@ -429,6 +429,22 @@ int pxg_batch_event_table(pxg_ctx* ctx, const int64_t* first_sample, const int64
 int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample, const int64_t* n_blocks,
                            int32_t block_stride, int64_t cap_intervals, int64_t* out_intervals,
                            int32_t* out_count, int64_t* out_total);
+/* a19 for reads whose basecall brings its OWN event table -- albacore's 14-column `Events', which
+ * Fast5Reader.load_events returns unchanged (fast5_file.py:178-179): n_events[r] rows of read r (0 leaves
+ * the read out, negative is that read's PXG_UNSPLIT_E_GEOMETRY), their `start' column (ascending, samples)
+ * and float32 `mean' column back to back in read order.  scaled_mean = fl(fl(scale * mean) + shift) on the
+ * device (signal_analyzer.py:318); a window holds the events with left <= start <= left + window_size
+ * (:384-386); an event ends where the next starts, the last one sample after its start (:321-324).
+ * Output and capacity handling as pxg_batch_unsplit_scan. */
+int pxg_batch_unsplit_scan_events(pxg_ctx* ctx, const int64_t* n_events, const int64_t* ev_start,
+                                  const float* ev_mean, int64_t cap_intervals, int64_t* out_intervals,
+                                  int32_t* out_count, int64_t* out_total);
+/* The two locks of pxg_process_batch_ex, for a caller that drives the split calls (stage / swap / run /
+ * scans / downloads) from several threads and mixes them with the one-call form: which = 0 the spare input
+ * slot (hold from pxg_batch_stage to pxg_batch_swap), 1 the resident batch (take before the swap, hold to
+ * the last download); always 0 before 1. */
+int pxg_ctx_lock(pxg_ctx* ctx, int which);
+int pxg_ctx_unlock(pxg_ctx* ctx, int which);
 /* a14-a17 as a standalone hook: PolyASignalAnalyzer.__call__ (polya.py:50-148) on
  * reads whose scaling and segmentation the caller supplies (seg_first/seg_last:
  * n x PXG_N_SEGMENTS, pooled right-inclusive, -1 absent, as pxg_viterbi returns
@@ -555,6 +571,15 @@ int pxg_h5_info_mt(const pxg_h5* file, int64_t first, int64_t n, pxg_h5_read_inf
 /* text = sequence '\n' quality string; move = the Move table / the Events table's move column */
 int pxg_h5_basecall(const pxg_h5* file, int64_t i, int64_t text_cap, char* text, int64_t move_cap,
                     uint8_t* move, double* p_model_state_or_null, int32_t* has_p_model_state);
+/* The columns of a read's BaseCalled_template/Events table that the per-read processor consumes when the
+ * table brings its own events (albacore's 14 columns, fast5_file.py:166-181): start, length, mean, stdv,
+ * move, p_model_state as float64 and model_state as text of model_state_cap bytes per row (any may be NULL).
+ * info[3 * k + {0, 1, 2}] = class (0 integer, 1 float, 3 text, -1 absent), byte width, signedness of column k
+ * in that order (model_state = 6): enough to rebuild the file's dtypes.  Returns the number of rows (0: no
+ * Events table); when that exceeds cap_rows nothing is written -- call again with room. */
+int64_t pxg_h5_events(const pxg_h5* file, int64_t i, int64_t cap_rows, int32_t* info, double* start,
+                      double* length, double* mean, double* stdv, double* move, double* p_model_state,
+                      char* model_state, int32_t model_state_cap);
 /* int16 samples of many reads (any mix of open files) decoded on `threads` host threads into the
  * caller's (staging) arena: read k -> arena[dst_start[k] .. dst_start[k] + n_samples[k]);
  * status[k] = 0 or that read's own pxg_error */

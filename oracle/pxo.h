@@ -122,6 +122,10 @@ int pxo_unsplit_scan(const pxg_config* cfg, const float* scaled_mean, int64_t n_
                      int64_t first_sample, int stride, int64_t payload_start,
                      double sampling_rate, int64_t* intervals, int cap);
 
+/* a19 over a table with its own events (albacore Events): starts[] ascending, see pxo_unsplit.c */
+int pxo_unsplit_scan_events(const pxg_config* cfg, const float* scaled_mean, const int64_t* starts,
+                            int64_t n_events, int64_t payload_start, double rate, int64_t* intervals, int cap);
+
 /* whole per-read path (signal_analyzer.py:82-134 phases 1-4, numeric part) */
 void pxo_process_read(const pxg_config* cfg, const int16_t* raw, int64_t n_raw,
                       const pxg_calib* cal, const float* scale_shift_or_null,

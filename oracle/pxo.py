@@ -72,6 +72,7 @@ def lib():
             'pxo_guppy_event_means': (i32, [vp, i64, vp, i64, i64, i32, f32, f32, vp, vp]),
             'pxo_guppy_event_table': (i32, [vp, i64, vp, i64, i64, i32, f32, f32, vp, vp, vp]),
             'pxo_unsplit_scan': (i32, [cfgp, vp, i64, i64, i32, i64, f64, vp, i32]),
+            'pxo_unsplit_scan_events': (i32, [cfgp, vp, vp, i64, i64, f64, vp, i32]),
             'pxo_process_read': (None, [cfgp, vp, i64, vp, vp, C.c_uint32, vp, vp, i32]),
             'pxo_process_batch': (None, [cfgp, i64, vp, vp, vp, vp, C.c_uint32, vp, vp, i32]),
         }
@@ -277,6 +278,19 @@ class Oracle:
         iv = np.zeros((cap, 2), dtype=np.int64)
         n = self.L.pxo_unsplit_scan(C.byref(self.cfg), _p(sm), len(sm), int(first_sample), stride,
                                     int(payload_start), float(sampling_rate), _p(iv), cap)
+        assert n <= cap
+        return iv[:n], n
+
+    def unsplit_scan_events(self, mean, starts, scale, shift, payload_start, sampling_rate):
+        """a19 over a table with its own events (albacore): float32 `mean', ascending int64 `start'."""
+        mean = np.ascontiguousarray(mean, dtype=np.float32)
+        sm = np.float32(scale) * mean                      # float32: fl(fl(scale * mean) + shift)
+        sm = sm + np.float32(shift)
+        st = np.ascontiguousarray(starts, dtype=np.int64)
+        cap = 4096
+        iv = np.zeros((cap, 2), dtype=np.int64)
+        n = self.L.pxo_unsplit_scan_events(C.byref(self.cfg), _p(sm), _p(st), len(sm), int(payload_start),
+                                           float(sampling_rate), _p(iv), cap)
         assert n <= cap
         return iv[:n], n
 

@@ -139,3 +139,69 @@ int pxo_unsplit_scan(const pxg_config* cfg, const float* scaled_mean, int64_t n_
     free(path);
     return count;
 }
+
+/* a19 over a table that brings its own events (albacore's 14-column Events, fast5_file.py:178-179):
+ * starts[k] = the table's `start' column (ascending), an event ends where the next starts, the last one a
+ * sample after its start (signal_analyzer.py:321-324); the window of `left' holds the events with
+ * left <= start <= left + window_size (:384-386: Series.between, both ends inclusive); everything else as
+ * pxo_unsplit_scan.  scaled_mean = fl(fl(scale * mean) + shift) (:318) is the caller's. */
+int pxo_unsplit_scan_events(const pxg_config* cfg, const float* scaled_mean, const int64_t* starts,
+                            int64_t n_events, int64_t payload_start, double rate, int64_t* intervals, int cap)
+{
+    const pxg_hmm* hmm = &cfg->unsplit_model;
+    const int A = hmm->adapter_state, LL = hmm->leader_low_state, LH = hmm->leader_high_state;
+    const int64_t window_size = (int64_t)(cfg->unsplit_window_size * rate);
+    const int64_t window_step = (int64_t)(cfg->unsplit_window_step * rate);
+    const int64_t strict_duration = (int64_t)(cfg->unsplit_strict_duration * rate);
+    const int64_t cut_total[2] = { (int64_t)(cfg->unsplit_loosen_full_length * rate),
+                                   (int64_t)(cfg->unsplit_strict_full_length * rate) };
+    const int64_t cut_adapter[2] = { (int64_t)(cfg->unsplit_loosen_dna_length * rate),
+                                     (int64_t)(cfg->unsplit_strict_dna_length * rate) };
+    if (n_events <= 0 || window_step <= 0)
+        return 0;
+    const int64_t last_end = starts[n_events - 1] + 1;
+    int count = 0;
+    int32_t* path = (int32_t*)malloc(sizeof(int32_t) * n_events);
+    for (int64_t left = payload_start; left < last_end; left += window_step) {
+        int64_t k0 = 0, k1 = n_events - 1;
+        while (k0 < n_events && starts[k0] < left) k0++;
+        while (k1 >= 0 && starts[k1] > left + window_size) k1--;
+        if (k1 < k0)
+            break;
+        const int T = (int)(k1 - k0 + 1);
+        pxo_viterbi(hmm, scaled_mean + k0, T, path);
+        int leader_start = -1;
+        int t = 0;
+        while (t < T) {
+            int e = t;
+            while (e + 1 < T && path[e + 1] == path[t])
+                e++;
+            const int st = path[t];
+            if (st != A && st != LH && st != LL) {
+                leader_start = -1;
+            } else {
+                if (leader_start < 0)
+                    leader_start = t;
+                if (st == A) {
+                    const int64_t ev_last = k0 + e;
+                    const int64_t adapter_end = ev_last == n_events - 1 ? starts[ev_last] + 1 : starts[ev_last + 1];
+                    const int64_t leader_in_read = starts[k0 + leader_start];
+                    const int64_t total_duration = adapter_end - leader_in_read;
+                    const int64_t adapter_duration = adapter_end - starts[k0 + t];
+                    const int strict = (leader_in_read - payload_start) <= strict_duration;
+                    if (total_duration >= cut_total[strict] && adapter_duration >= cut_adapter[strict]) {
+                        if (count < cap) {
+                            intervals[2 * count] = leader_in_read;
+                            intervals[2 * count + 1] = 1 + adapter_end;
+                        }
+                        count++;
+                    }
+                    leader_start = -1;
+                }
+            }
+            t = e + 1;
+        }
+    }
+    free(path);
+    return count;
+}

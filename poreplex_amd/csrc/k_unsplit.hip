@@ -143,6 +143,28 @@ int pxg_launch_guppy_event_means(pxg_ctx* ctx, int64_t n, const int16_t* raw, co
     return PXG_OK;
 }
 
+// scaled_mean of a table that brings its own event means (albacore Events): np.poly1d(float32[scale, shift])
+// (mean) = fl(fl(scale * mean) + shift), signal_analyzer.py:318.  One thread per event.
+__global__ void k_scale_event_means(int64_t n_reads, const int64_t* __restrict__ ev_off, const float* __restrict__ ss,
+                                    const float* __restrict__ mean, float* __restrict__ scaled)
+{
+    const int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (e >= ev_off[n_reads]) return;
+    int64_t lo = 0, hi = n_reads;              // largest r with ev_off[r] <= e
+    while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (ev_off[mid] <= e) lo = mid; else hi = mid; }
+    const float y = ss[2 * lo] * mean[e];
+    scaled[e] = y + ss[2 * lo + 1];
+}
+
+int pxg_launch_scale_event_means(pxg_ctx* ctx, int64_t n, int64_t n_events, const int64_t* ev_off, const float* ss,
+                                 const float* mean, float* scaled)
+{
+    if (n <= 0 || n_events <= 0) return PXG_OK;
+    hipLaunchKernelGGL(k_scale_event_means, dim3((unsigned)((n_events + 255) / 256)), dim3(256), 0, ctx->stream, n, ev_off,
+                       ss, mean, scaled);
+    return PXG_OK;
+}
+
 // ---------------------------------------------------------------------------
 // a19: window scan
 // ---------------------------------------------------------------------------
@@ -192,15 +214,28 @@ __device__ __forceinline__ double un_shfl_f64(double v, int src)
 struct UnsplitGeom {
     int64_t first, n_ev, payload_start, last_end, window_size, window_step, strict_duration;
     int64_t cut_total[2], cut_adapter[2];
+    const int64_t* starts;     // the table's own `start' column (albacore Events, ascending); null: Guppy blocks
     bool valid;
 };
+
+// sample at which event k of the frame starts / ends (signal_analyzer.py:321-324: end = next start,
+// the last event ends one sample after it starts)
+__device__ __forceinline__ int64_t un_ev_start(const UnsplitGeom& g, int stride, int64_t k)
+{
+    return g.starts ? g.starts[k] : g.first + (int64_t)stride * k;
+}
+__device__ __forceinline__ int64_t un_ev_end(const UnsplitGeom& g, int stride, int64_t k)
+{
+    return k == g.n_ev - 1 ? un_ev_start(g, stride, k) + 1 : un_ev_start(g, stride, k + 1);
+}
 
 __device__ __forceinline__ UnsplitGeom unsplit_geometry(int64_t r, int64_t n_reads, const UnsplitParams& P,
                                                         const pxg_calib* cal, const int32_t* status,
                                                         const int32_t* segs, const int64_t* first_sample,
-                                                        const int64_t* ev_off)
+                                                        const int64_t* ev_off, const int64_t* ev_start)
 {
     UnsplitGeom g;
+    g.starts = nullptr;
     g.valid = r < n_reads && status[r] == PXG_ST_OKAY;
     g.first = g.n_ev = g.payload_start = g.last_end = 0;
     g.window_size = 0; g.window_step = 1; g.strict_duration = 0;
@@ -211,9 +246,10 @@ __device__ __forceinline__ UnsplitGeom unsplit_geometry(int64_t r, int64_t n_rea
     g.n_ev = ev_off[r + 1] - ev_off[r];
     if (sf[P.seg_adapter_state] < 0 || g.n_ev <= 0) { g.valid = false; return g; }
     const double rate = cal[r].sampling_rate;
-    g.first = first_sample[r];
+    g.first = ev_start ? 0 : first_sample[r];
+    g.starts = ev_start ? ev_start + ev_off[r] : nullptr;
     g.payload_start = (int64_t)(a_last + 1) * P.pool_stride;          // :369
-    g.last_end = g.first + (int64_t)P.stride * (g.n_ev - 1) + 1;      // events.iloc[-1]['end']
+    g.last_end = un_ev_start(g, P.stride, g.n_ev - 1) + 1;            // events.iloc[-1]['end']
     g.window_size = (int64_t)(P.window_size * rate);                  // :374-383 int(config * rate)
     g.window_step = (int64_t)(P.window_step * rate);
     g.strict_duration = (int64_t)(P.strict_duration * rate);
@@ -227,6 +263,16 @@ __device__ __forceinline__ UnsplitGeom unsplit_geometry(int64_t r, int64_t n_rea
 __device__ __forceinline__ bool unsplit_window(const UnsplitGeom& g, int stride, int64_t left,
                                                int64_t& k0, int64_t& k1)
 {
+    if (g.starts) {            // first event with start >= left, last event with start <= left + window
+        const int64_t right = left + g.window_size;
+        int64_t lo = 0, hi = g.n_ev;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (g.starts[mid] < left) lo = mid + 1; else hi = mid; }
+        k0 = lo;
+        hi = g.n_ev;
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (g.starts[mid] <= right) lo = mid + 1; else hi = mid; }
+        k1 = lo - 1;
+        return k1 >= k0;
+    }
     k0 = (left - g.first) <= 0 ? 0 : (left - g.first + stride - 1) / stride;
     k1 = (left + g.window_size - g.first) < 0 ? -1 : (left + g.window_size - g.first) / stride;
     if (k1 > g.n_ev - 1) k1 = g.n_ev - 1;
@@ -237,11 +283,12 @@ __device__ __forceinline__ bool unsplit_window(const UnsplitGeom& g, int stride,
 __global__ void k_unsplit_plan(int64_t n_reads, UnsplitParams P, const pxg_calib* __restrict__ cal,
                                const int32_t* __restrict__ status, const int32_t* __restrict__ segs,
                                const int64_t* __restrict__ first_sample,
-                               const int64_t* __restrict__ ev_off, int32_t* __restrict__ n_win)
+                               const int64_t* __restrict__ ev_off, const int64_t* __restrict__ ev_start,
+                               int32_t* __restrict__ n_win)
 {
     const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
-    const UnsplitGeom g = unsplit_geometry(r, n_reads, P, cal, status, segs, first_sample, ev_off);
+    const UnsplitGeom g = unsplit_geometry(r, n_reads, P, cal, status, segs, first_sample, ev_off, ev_start);
     int cnt = 0;
     if (g.valid) {
         for (int64_t left = g.payload_start; left < g.last_end; left += g.window_step) {
@@ -301,7 +348,7 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
     int64_t n_reads, int tmax, PxgHmmDev H, UnsplitParams P, const pxg_calib* __restrict__ cal,
     const int32_t* __restrict__ status, const int32_t* __restrict__ segs,
     const int64_t* __restrict__ first_sample, const int64_t* __restrict__ ev_off,
-    const int64_t* __restrict__ unit_off, const float* __restrict__ scaled,
+    const int64_t* __restrict__ ev_start, const int64_t* __restrict__ unit_off, const float* __restrict__ scaled,
     unsigned* __restrict__ bpbuf /* [wave][tmax][8 groups] */,
     int64_t* __restrict__ cand /* n_units x wcand x 2 */, int32_t* __restrict__ cand_cnt, int wcand,
     const double* __restrict__ lsetab_g, unsigned long long* __restrict__ queue)
@@ -351,7 +398,7 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
             r = lo;
         }
         const UnsplitGeom g = unsplit_geometry(more ? r : n_reads, n_reads, P, cal, status, segs,
-                                               first_sample, ev_off);
+                                               first_sample, ev_off, ev_start);
         int64_t k0 = 0, k1 = -1;
         if (more) {
             const int64_t left = g.payload_start + (u - unit_off[r]) * g.window_step;
@@ -440,12 +487,10 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
         int a_last = -1, a_first = -1, lead = -1, count = 0;
         auto finalize = [&](int lead_t) {
             const int64_t ev_last = k0 + a_last, ev_lead = k0 + lead_t, ev_first = k0 + a_first;
-            const int64_t adapter_end = (ev_last == g.n_ev - 1)
-                ? g.first + (int64_t)P.stride * ev_last + 1
-                : g.first + (int64_t)P.stride * (ev_last + 1);
-            const int64_t leader_in_read = g.first + (int64_t)P.stride * ev_lead;
+            const int64_t adapter_end = un_ev_end(g, P.stride, ev_last);
+            const int64_t leader_in_read = un_ev_start(g, P.stride, ev_lead);
             const int64_t total_duration = adapter_end - leader_in_read;
-            const int64_t adapter_duration = adapter_end - (g.first + (int64_t)P.stride * ev_first);
+            const int64_t adapter_duration = adapter_end - un_ev_start(g, P.stride, ev_first);
             const int strict = (leader_in_read - g.payload_start) <= g.strict_duration ? 1 : 0;
             if (total_duration >= g.cut_total[strict] && adapter_duration >= g.cut_adapter[strict]) {
                 if (s == 0 && count < wcand) {
@@ -545,11 +590,11 @@ static UnsplitParams unsplit_params(const pxg_ctx* ctx, int stride)
 
 int pxg_launch_unsplit_plan(pxg_ctx* ctx, int64_t n, const pxg_calib* cal, const int32_t* status,
                             const int32_t* segs, const int64_t* first_sample, const int64_t* ev_off,
-                            int stride, int32_t* n_win)
+                            int stride, int32_t* n_win, const int64_t* ev_start)
 {
     if (n <= 0) return PXG_OK;
     hipLaunchKernelGGL(k_unsplit_plan, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
-                       unsplit_params(ctx, stride), cal, status, segs, first_sample, ev_off, n_win);
+                       unsplit_params(ctx, stride), cal, status, segs, first_sample, ev_off, ev_start, n_win);
     return PXG_OK;
 }
 
@@ -586,7 +631,7 @@ size_t pxg_unsplit_cand_bytes(int64_t units_bound, int wcand)
 int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t units_bound, int tmax, const pxg_calib* cal,
                             const int32_t* status, const int32_t* segs, const int64_t* first_sample,
                             const int64_t* ev_off, const int64_t* unit_off, const float* scaled, int stride,
-                            void* scratch, void* candbuf, int wcand, int32_t* out_cnt)
+                            void* scratch, void* candbuf, int wcand, int32_t* out_cnt, const int64_t* ev_start)
 {
     if (n <= 0) return PXG_OK;
     const UnsplitParams P = unsplit_params(ctx, stride);
@@ -599,7 +644,7 @@ int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t units_bound, int tm
     int32_t* cand_cnt = (int32_t*)((char*)candbuf + (size_t)(units_bound > 0 ? units_bound : 1) * (size_t)wcand * 2 * sizeof(int64_t));
 #define SCAN(NIN)                                                                                      \
     hipLaunchKernelGGL(k_unsplit_scan<NIN>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, n,        \
-                       tmax, ctx->hmm[1], P, cal, status, segs, first_sample, ev_off, unit_off,        \
+                       tmax, ctx->hmm[1], P, cal, status, segs, first_sample, ev_off, ev_start, unit_off, \
                        scaled, bp, cand, cand_cnt, wcand, ctx->d_lsetab, ctx->unsplit_q.p)
     const int nin = ctx->hmm[1].max_in;
     if (nin <= 2) SCAN(2);

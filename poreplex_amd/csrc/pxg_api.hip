@@ -292,7 +292,7 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     release(ctx->demux_q); release(ctx->demux_state);
     release(ctx->spare.raw); release(ctx->spare.offsets); release(ctx->spare.calib); release(ctx->spare.inject);
     release(ctx->results); release(ctx->spare.z); release(ctx->spare.zchunks); release(ctx->unsplit_q); release(ctx->vit_bp); release(ctx->polya_ev); release(ctx->polya_over); release(ctx->polya_retry); release(ctx->polya_out); release(ctx->spikes);
-    release(ctx->ev_first); release(ctx->ev_off); release(ctx->ev_mean); release(ctx->ev_scaled);
+    release(ctx->ev_tstart); release(ctx->ev_first); release(ctx->ev_off); release(ctx->ev_mean); release(ctx->ev_scaled);
     release(ctx->unsplit_scr); release(ctx->unsplit_iv); release(ctx->unsplit_cnt); release(ctx->unsplit_ivoff);
     release(ctx->unsplit_cand); release(ctx->unit_off); release(ctx->n_win);
     free_lstm(ctx->scaler1); free_lstm(ctx->scaler2); free_lstm(ctx->demux_fwd);
@@ -1324,6 +1324,119 @@ extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
     if (got > 0) HOOK_GET(out_intervals, ctx->unsplit_iv.p, (size_t)got * 2);
     for (int64_t i : bad) out_count[i] = PXG_UNSPLIT_E_GEOMETRY;
     HOOK_END
+}
+
+// a19 for reads whose basecall brings its own event table (albacore's 14-column `Events', which
+// fast5_file.py:178-179 passes through unchanged): the windows are the events with left <= start <= left +
+// window (signal_analyzer.py:384-386) of the table's own ascending `start' column, an event ends where the
+// next one starts (:321-324), scaled_mean = fl(fl(scale * mean) + shift) of the table's float32 `mean'
+// column (:318).  Same kernels as the Guppy block frame, with the starts read instead of computed.
+extern "C" int pxg_batch_unsplit_scan_events(pxg_ctx* ctx, const int64_t* n_events, const int64_t* ev_start,
+                                             const float* ev_mean, int64_t cap_intervals, int64_t* out_intervals,
+                                             int32_t* out_count, int64_t* out_total)
+{
+    HOOK_BEGIN
+    const int64_t n = ctx->n_reads;
+    if (out_total) *out_total = 0;
+    if (n <= 0) return PXG_OK;
+    if (!n_events || !out_count || !out_total || cap_intervals < 0 || (cap_intervals > 0 && !out_intervals))
+        return fail(ctx, PXG_E_INVALID, "pxg_batch_unsplit_scan_events: bad arguments");
+    const pxg_config& c = ctx->cfg;
+    const pxg_hmm& U = c.unsplit_model;
+    if (U.n_states < 1 || U.adapter_state < 0 || U.leader_low_state < 0 || U.leader_high_state < 0)
+        return fail(ctx, PXG_E_INVALID, "unsplit model lacks adapter / leader states");
+    const int64_t win_max = (int64_t)(c.unsplit_window_size * ctx->rate_max);
+    const int64_t step_min = (int64_t)(c.unsplit_window_step * ctx->rate_min);
+    if (step_min < 1 || win_max < 0) return fail(ctx, PXG_E_INVALID, "unsplit_read_detection window_size / window_step out of range");
+    // per-read tables; the most events any window [left, left + win_max] can hold bounds the back-pointer rows
+    std::vector<int64_t> eoff((size_t)n + 1, 0), zero((size_t)n, 0);
+    std::vector<int64_t> bad;
+    int64_t units_bound = 0, tmax64 = 2;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t ne = n_events[i] > 0 ? n_events[i] : 0;
+        eoff[i + 1] = eoff[i] + ne;
+        if (n_events[i] < 0) bad.push_back(i);
+    }
+    if (eoff[n] > 0 && (!ev_start || !ev_mean)) return fail(ctx, PXG_E_INVALID, "pxg_batch_unsplit_scan_events: null event columns");
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t ne = eoff[i + 1] - eoff[i];
+        if (!ne) continue;
+        const int64_t* st = ev_start + eoff[i];
+        bool sorted = st[0] >= 0;
+        for (int64_t k = 1; k < ne && sorted; k++) sorted = st[k] >= st[k - 1];
+        if (!sorted) return fail(ctx, PXG_E_INVALID, "pxg_batch_unsplit_scan_events: `start' column is not ascending");
+        units_bound += (st[ne - 1] + 1) / step_min + 2;
+        for (int64_t a = 0, b = 0; a < ne; a++) {          // events within win_max of event a
+            while (b < ne && st[b] <= st[a] + win_max) b++;
+            tmax64 = std::max(tmax64, b - a + 1);
+        }
+    }
+    if (tmax64 > (1 << 22)) return fail(ctx, PXG_E_INVALID, "event table too dense for the scan window");
+    const int tmax = (int)tmax64;
+    const double shortest = std::min(c.unsplit_loosen_full_length, c.unsplit_strict_full_length);
+    const int64_t min_cut = (int64_t)(shortest * ctx->rate_min);
+    const int64_t by_blocks = (int64_t)tmax / 2 + 2, by_length = min_cut > 0 ? (win_max + 1) / min_cut + 2 : by_blocks;
+    const int wcand = (int)std::max<int64_t>(1, std::min(by_blocks, by_length));
+    const size_t ne_all = (size_t)eoff[n];
+    int rc;
+    if ((rc = pxg_reserve(ctx, ctx->ev_first, (size_t)n)) || (rc = pxg_reserve(ctx, ctx->ev_off, (size_t)n + 1)) ||
+        (rc = pxg_reserve(ctx, ctx->ev_tstart, ne_all)) ||
+        (rc = pxg_reserve(ctx, ctx->ev_mean, ne_all)) || (rc = pxg_reserve(ctx, ctx->ev_scaled, ne_all)) ||
+        (rc = pxg_reserve(ctx, ctx->unit_off, (size_t)n + 1)) || (rc = pxg_reserve(ctx, ctx->n_win, (size_t)n)) ||
+        (rc = pxg_reserve(ctx, ctx->unsplit_ivoff, (size_t)n + 1)) ||
+        (rc = pxg_reserve(ctx, ctx->unsplit_iv, (size_t)std::max<int64_t>(cap_intervals, 1) * 2)) ||
+        (rc = pxg_reserve(ctx, ctx->unsplit_cnt, (size_t)n)) ||
+        (rc = pxg_reserve(ctx, ctx->unsplit_scr, pxg_unsplit_scratch_bytes(ctx, units_bound, tmax))) ||
+        (rc = pxg_reserve(ctx, ctx->unsplit_cand, pxg_unsplit_cand_bytes(units_bound, wcand))))
+        return rc;
+    PXG_HIP(ctx, hipMemcpyAsync(ctx->ev_first.p, zero.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    PXG_HIP(ctx, hipMemcpyAsync(ctx->ev_off.p, eoff.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    if (ne_all) {
+        PXG_HIP(ctx, hipMemcpyAsync(ctx->ev_tstart.p, ev_start, ne_all * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+        PXG_HIP(ctx, hipMemcpyAsync(ctx->ev_mean.p, ev_mean, ne_all * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    }
+    pxg_timer_begin(ctx, PXG_T_EVENT_MEANS);
+    if ((rc = pxg_launch_scale_event_means(ctx, n, (int64_t)ne_all, ctx->ev_off.p, ctx->ss.p, ctx->ev_mean.p, ctx->ev_scaled.p)))
+        return rc;
+    pxg_timer_end(ctx, PXG_T_EVENT_MEANS);
+    pxg_timer_begin(ctx, PXG_T_UNSPLIT);
+    if ((rc = pxg_launch_unsplit_plan(ctx, n, ctx->calib.p, ctx->status.p, ctx->segs.p, ctx->ev_first.p, ctx->ev_off.p, 1,
+                                      ctx->n_win.p, ctx->ev_tstart.p)) ||
+        (rc = pxg_launch_exclusive_scan(ctx, n, ctx->n_win.p, ctx->unit_off.p)) ||
+        (rc = pxg_launch_unsplit_scan(ctx, n, units_bound, tmax, ctx->calib.p, ctx->status.p, ctx->segs.p, ctx->ev_first.p,
+                                      ctx->ev_off.p, ctx->unit_off.p, ctx->ev_scaled.p, 1, ctx->unsplit_scr.p,
+                                      ctx->unsplit_cand.p, wcand, ctx->unsplit_cnt.p, ctx->ev_tstart.p)) ||
+        (rc = pxg_launch_exclusive_scan(ctx, n, ctx->unsplit_cnt.p, ctx->unsplit_ivoff.p)) ||
+        (rc = pxg_launch_unsplit_gather(ctx, n, units_bound, ctx->unit_off.p, ctx->unsplit_cand.p, wcand,
+                                        ctx->unsplit_cnt.p, ctx->unsplit_ivoff.p, cap_intervals, ctx->unsplit_iv.p)))
+        return rc;
+    pxg_timer_end(ctx, PXG_T_UNSPLIT);
+    HOOK_GET(out_count, ctx->unsplit_cnt.p, n);
+    HOOK_GET(out_total, ctx->unsplit_ivoff.p + n, 1);
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t got = std::min(*out_total, cap_intervals);
+    if (got > 0) HOOK_GET(out_intervals, ctx->unsplit_iv.p, (size_t)got * 2);
+    for (int64_t i : bad) out_count[i] = PXG_UNSPLIT_E_GEOMETRY;
+    HOOK_END
+}
+
+// The two mutexes of pxg_process_batch_ex for a caller that drives the split calls itself (a batch with
+// dump options, several Guppy block strides or albacore tables takes stage / swap / run / scans / downloads
+// one by one): which = 0 the spare input slot, 1 the resident batch; take 0, then 1, release 0 after the
+// swap and 1 after the last download -- the order the one-call form uses, so both forms may be mixed
+// from any number of threads.
+extern "C" int pxg_ctx_lock(pxg_ctx* ctx, int which)
+{
+    if (!ctx || which < 0 || which > 1) return PXG_E_INVALID;
+    (which ? ctx->mt_run : ctx->mt_stage).lock();
+    return PXG_OK;
+}
+
+extern "C" int pxg_ctx_unlock(pxg_ctx* ctx, int which)
+{
+    if (!ctx || which < 0 || which > 1) return PXG_E_INVALID;
+    (which ? ctx->mt_run : ctx->mt_stage).unlock();
+    return PXG_OK;
 }
 
 extern "C" int pxg_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,

@@ -328,6 +328,7 @@ struct pxg_ctx {
     std::mutex mt_stage, mt_run; // pxg_process_batch(_ex) from several host threads: spare slot / resident batch
     bool polya_ran = false;
     DevBuf<int64_t> ev_first, ev_off;   // K7: per-read first sample / event offsets
+    DevBuf<int64_t> ev_tstart;          // K7: `start' column of tables that bring their own events (albacore)
     DevBuf<float> ev_mean, ev_scaled;   // K7: Guppy block means
     DevBuf<char> unsplit_scr;           // K7: back-pointer + path scratch
     DevBuf<char> unsplit_cand;          // K7: per-window candidates
@@ -446,7 +447,9 @@ int pxg_launch_guppy_event_means(pxg_ctx* ctx, int64_t n, const int16_t* raw, co
                                  float* stdv_or_null = nullptr);
 int pxg_launch_unsplit_plan(pxg_ctx* ctx, int64_t n, const pxg_calib* cal, const int32_t* status,
                             const int32_t* segs, const int64_t* first_sample, const int64_t* ev_off,
-                            int stride, int32_t* n_win);
+                            int stride, int32_t* n_win, const int64_t* ev_start = nullptr);
+int pxg_launch_scale_event_means(pxg_ctx* ctx, int64_t n, int64_t n_events, const int64_t* ev_off, const float* ss,
+                                 const float* mean, float* scaled);
 int pxg_launch_exclusive_scan(pxg_ctx* ctx, int64_t n, const int32_t* in, int64_t* out /* n + 1 */);
 size_t pxg_unsplit_scratch_bytes(const pxg_ctx* ctx, int64_t units_bound, int tmax);
 int pxg_unsplit_cand_slots(const pxg_ctx* ctx, int tmax, int stride);
@@ -454,7 +457,7 @@ size_t pxg_unsplit_cand_bytes(int64_t units_bound, int wcand);
 int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t units_bound, int tmax, const pxg_calib* cal,
                             const int32_t* status, const int32_t* segs, const int64_t* first_sample,
                             const int64_t* ev_off, const int64_t* unit_off, const float* scaled, int stride,
-                            void* scratch, void* candbuf, int wcand, int32_t* out_cnt);
+                            void* scratch, void* candbuf, int wcand, int32_t* out_cnt, const int64_t* ev_start = nullptr);
 int pxg_launch_unsplit_gather(pxg_ctx* ctx, int64_t n, int64_t units_bound, const int64_t* unit_off,
                               const void* candbuf, int wcand, const int32_t* out_cnt, const int64_t* iv_off,
                               int64_t cap, int64_t* out_iv);

@@ -1075,6 +1075,81 @@ extern "C" int pxg_h5_basecall(const pxg_h5* h, int64_t i, int64_t text_cap, cha
     H5_GUARD_END(h)
 }
 
+// The columns of a read's BaseCalled_template/Events table the per-read processor uses when the table
+// brings its own events (albacore, 14 columns: fast5_file.py:166-181 returns it unchanged; consumers
+// signal_analyzer.py:311-326,366-443,183-190): start, length, mean, stdv, move, p_model_state as float64
+// (exact for every integer and float width a FAST5 holds below 2^53) and model_state as fixed-width text.
+// info = per column (in that order, then model_state): class (0 integer, 1 float, 3 string, -1 absent),
+// byte width, signedness -- what a caller needs to rebuild the file's own dtypes.
+extern "C" int64_t pxg_h5_events(const pxg_h5* h, int64_t i, int64_t cap_rows, int32_t* info /* 7 x 3 */,
+                                 double* start, double* length, double* mean, double* stdv, double* move,
+                                 double* p_model_state, char* model_state, int32_t model_state_cap)
+{
+    if (!h || i < 0 || i >= (int64_t)h->reads.size() || !info) return PXG_E_INVALID;
+    H5_GUARD_BEGIN
+    const pxg_h5_read& r = h->reads[(size_t)i];
+    if (r.analyses_obj == UNDEF) return 0;
+    const Object an = h->object(r.analyses_obj);
+    std::string best;
+    uint64_t best_obj = UNDEF;
+    for (const auto& c : h->children(an))
+        if (c.first.compare(0, 11, "Basecall_1D") == 0 && (best_obj == UNDEF || c.first > best)) { best = c.first; best_obj = c.second; }
+    if (best_obj == UNDEF) return 0;
+    const uint64_t ev = h->resolve(best_obj, "BaseCalled_template/Events");
+    if (ev == UNDEF) return 0;
+    const Dataset d = h->object(ev).ds;
+    if (d.type.cls != 6) fail(PXG_E_INVALID, "FAST5: Events is not a table");
+    const uint64_t n = d.n_elements();
+    h->sane_bytes(n, d.type.size);
+    static const char* names[7] = { "start", "length", "mean", "stdv", "move", "p_model_state", "model_state" };
+    double* outs[6] = { start, length, mean, stdv, move, p_model_state };
+    const Datatype::Member* col[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    for (const auto& m : d.type.members)
+        for (int k = 0; k < 7; k++)
+            if (m.name == names[k]) col[k] = &m;
+    for (int k = 0; k < 7; k++) {
+        info[3 * k] = col[k] ? col[k]->cls : -1;
+        info[3 * k + 1] = col[k] ? (int32_t)col[k]->size : 0;
+        info[3 * k + 2] = col[k] ? (int32_t)col[k]->is_signed : 0;
+        if (!col[k]) continue;
+        if ((uint64_t)col[k]->offset + col[k]->size > d.type.size) fail(PXG_E_INVALID, "FAST5: Events table columns lie outside its rows");
+        const bool numeric = k < 6;
+        if (numeric && !((col[k]->cls == 0 && (col[k]->size == 1 || col[k]->size == 2 || col[k]->size == 4 || col[k]->size == 8)) ||
+                         (col[k]->cls == 1 && (col[k]->size == 4 || col[k]->size == 8))))
+            fail(PXG_E_UNSUPPORTED, std::string("FAST5: Events column '") + names[k] + "' has a type this reader does not convert");
+        if (!numeric && col[k]->cls != 3) fail(PXG_E_UNSUPPORTED, "FAST5: Events column 'model_state' is not fixed-width text");
+    }
+    if ((int64_t)n > cap_rows) return (int64_t)n;          // the caller asks again with room for n rows
+    if (col[6] && model_state && (int32_t)col[6]->size > model_state_cap) fail(PXG_E_NOMEM, "model_state buffer too narrow");
+    std::vector<uint8_t> rows(n * d.type.size);
+    h->read_dataset(d, rows.data(), rows.size());
+    for (uint64_t q = 0; q < n; q++) {
+        const uint8_t* row = rows.data() + q * d.type.size;
+        for (int k = 0; k < 6; k++) {
+            if (!col[k] || !outs[k]) continue;
+            const uint8_t* v = row + col[k]->offset;
+            double x = 0.0;
+            if (col[k]->cls == 1) {
+                if (col[k]->size == 4) { float f; memcpy(&f, v, 4); x = f; } else memcpy(&x, v, 8);
+            } else {
+                uint64_t u = 0;
+                for (int b = (int)col[k]->size - 1; b >= 0; b--) u = (u << 8) | v[b];
+                if (col[k]->is_signed) {
+                    const int sh = 64 - 8 * (int)col[k]->size;
+                    x = (double)((int64_t)(u << sh) >> sh);
+                } else x = (double)u;
+            }
+            outs[k][q] = x;
+        }
+        if (col[6] && model_state) {
+            memset(model_state + q * (size_t)model_state_cap, 0, (size_t)model_state_cap);
+            memcpy(model_state + q * (size_t)model_state_cap, row + col[6]->offset, col[6]->size);
+        }
+    }
+    return (int64_t)n;
+    H5_GUARD_END(h)
+}
+
 // The int16 samples of many reads (any mix of open files), decoded on `threads` host threads
 // straight into `arena` (the caller's staging buffer): read k = (files[k], index[k]) goes to
 // arena[dst_start[k] .. dst_start[k] + n_samples[k]).  status[k] = 0 or that read's own error code.

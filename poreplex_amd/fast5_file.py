@@ -32,6 +32,8 @@ __all__ = ['get_read_ids', 'open_read', 'ReadBundle', 'Fast5Reader', 'Fast5File'
 
 
 TABLE_KINDS = ('', 'move', 'guppy_events', 'albacore', 'unsupported')   # '' = no event table
+EVENT_NUMERIC = ('start', 'length', 'mean', 'stdv', 'move', 'p_model_state')
+EVENT_COLUMNS = EVENT_NUMERIC + ('model_state',)
 
 # columnar basecall summary of a bundle (version 2); ragged columns have offsets[n+1]
 BASECALL_COLUMNS = ('bc_present', 'bc_sequence_length', 'bc_mean_qscore', 'bc_num_events',
@@ -73,6 +75,23 @@ def basecall_columns(basecalls):
         off = np.zeros(n + 1, dtype=np.int64)
         np.cumsum([len(p) for p in parts], out=off[1:])
         c[name + '_offsets'] = off
+    # tables that bring their own events (albacore's 14-column Events): the columns the processor consumes,
+    # ragged over the reads (float64 / text arenas + each read's own dtypes, so nothing of the file's typing
+    # -- which decides how the reference's pandas arithmetic promotes -- is lost)
+    tables = [bc.get('events') if bc else None for bc in basecalls]
+    if any(t is not None for t in tables):
+        eo = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(t['start']) if t is not None else 0 for t in tables], out=eo[1:])
+        c['ev_offsets'] = eo
+        for name in EVENT_NUMERIC:
+            c['ev_' + name] = np.concatenate([np.asarray(t[name], dtype=np.float64) if t is not None and name in t
+                                              else np.zeros(len(t['start']) if t is not None else 0)
+                                              for t in tables]) if eo[-1] else np.zeros(0)
+        c['ev_model_state'] = np.concatenate([np.asarray(t['model_state'], dtype='S8') if t is not None and 'model_state' in t
+                                              else np.zeros(len(t['start']) if t is not None else 0, dtype='S8')
+                                              for t in tables]) if eo[-1] else np.zeros(0, dtype='S8')
+        c['ev_dtypes'] = np.array([json.dumps({k: np.asarray(v).dtype.str for k, v in t.items()}) if t is not None else ''
+                                   for t in tables])
     c['seq_arena'] = np.frombuffer(b''.join(seqs), dtype=np.uint8).copy()
     c['qual_arena'] = np.frombuffer(b''.join(quals), dtype=np.uint8).copy()
     c['move_arena'] = np.concatenate(moves) if moves else np.zeros(0, np.uint8)
@@ -204,12 +223,16 @@ class ReadBundle:
         pms = None
         if 'bc_p_model_state' in d and str(d['bc_p_model_state'][i]):
             pms = json.loads(str(d['bc_p_model_state'][i]))
-        return {'sequence': seq, 'qstring': qual, 'block_stride': int(d['bc_block_stride'][i]),
-                'sequence_length': int(d['bc_sequence_length'][i]),
-                'mean_qscore': float(np.float32(d['bc_mean_qscore'][i])),
-                'num_events': int(d['bc_num_events'][i]),
-                'first_sample_template': int(d['bc_first_sample'][i]),
-                'table': kind, 'move': move, 'p_model_state': pms}
+        out = {'sequence': seq, 'qstring': qual, 'block_stride': int(d['bc_block_stride'][i]),
+               'sequence_length': int(d['bc_sequence_length'][i]),
+               'mean_qscore': float(np.float32(d['bc_mean_qscore'][i])),
+               'num_events': int(d['bc_num_events'][i]),
+               'first_sample_template': int(d['bc_first_sample'][i]),
+               'table': kind, 'move': move, 'p_model_state': pms}
+        if 'ev_dtypes' in d and str(d['ev_dtypes'][i]):
+            eo, dt = d['ev_offsets'], json.loads(str(d['ev_dtypes'][i]))
+            out['events'] = {k: d['ev_' + k][eo[i]:eo[i + 1]].astype(np.dtype(dt[k])) for k in EVENT_COLUMNS if k in dt}
+        return out
 
 
 class _Fast5BatchBundle(ReadBundle):
@@ -364,12 +387,35 @@ class Fast5File:
             raise Fast5Error((self.lib.pxg_h5_last_error() or b'').decode(errors='replace'))
         seq, qual = text.value.decode('ascii').split('\n')        # (validated printable ASCII by the library)
         kind = TABLE_KINDS[int(info['bc_table'])] or None
-        return {'sequence': seq, 'qstring': qual, 'block_stride': int(info['bc_block_stride']),
-                'sequence_length': int(info['bc_sequence_length']),
-                'mean_qscore': float(info['bc_mean_qscore']), 'num_events': int(info['bc_num_events']),
-                'first_sample_template': int(info['bc_first_sample']), 'table': kind,
-                'move': move[:n_mv].tolist() if info['bc_n_moves'] >= 0 else None,
-                'p_model_state': pms[:n_mv].tolist() if has.value else None}
+        out = {'sequence': seq, 'qstring': qual, 'block_stride': int(info['bc_block_stride']),
+               'sequence_length': int(info['bc_sequence_length']),
+               'mean_qscore': float(info['bc_mean_qscore']), 'num_events': int(info['bc_num_events']),
+               'first_sample_template': int(info['bc_first_sample']), 'table': kind,
+               'move': move[:n_mv].tolist() if info['bc_n_moves'] >= 0 else None,
+               'p_model_state': pms[:n_mv].tolist() if has.value else None}
+        if kind in ('albacore', 'guppy_events'):       # tables whose own columns are consumed downstream
+            out['events'] = self.events(i, n_mv)
+        return out
+
+    def events(self, i, n_rows):
+        """The consumed columns of read i's Events table in the file's own dtypes (pxg_h5_events)."""
+        import ctypes as C
+        n = max(int(n_rows), 1)
+        info = np.zeros(21, dtype=np.int32)
+        cols = {k: np.zeros(n, dtype=np.float64) for k in EVENT_NUMERIC}
+        text = np.zeros(n, dtype='S8')
+        got = self.lib.pxg_h5_events(self.handle, i, n, info.ctypes.data, *[cols[k].ctypes.data for k in EVENT_NUMERIC],
+                                     text.ctypes.data, 8)
+        if got < 0 or got > n:
+            raise Fast5Error((self.lib.pxg_h5_last_error() or b'').decode(errors='replace') or 'Events table changed size')
+        out = {}
+        for k, name in enumerate(EVENT_NUMERIC):
+            cls, size, signed = info[3 * k:3 * k + 3].tolist()
+            if cls >= 0:
+                out[name] = cols[name][:got].astype(np.dtype(('f' if cls == 1 else ('i' if signed else 'u')) + str(size)))
+        if info[18] >= 0:
+            out['model_state'] = text[:got].astype('S{}'.format(int(info[19])))
+        return out
 
 
 _OPEN, _OPEN_LOCK, _OPEN_MAX = OrderedDict(), threading.Lock(), 128
@@ -638,7 +684,7 @@ class H5pyFast5Reader:
         # event mapping (fast5_file.py:166-181): `Events' (albacore, guppy < 2.3.7) wins over
         # `Move' (guppy >= 2.3.7); Guppy tables only say which blocks moved, the block means
         # are re-cut from the raw signal (on the GPU here)
-        table, move, pms = None, None, None
+        table, move, pms, events = None, None, None, None
         if 'BaseCalled_template/Events' in analyses:
             ev = analyses['BaseCalled_template/Events'][()]
             cols = ev.dtype.names or ()
@@ -652,9 +698,11 @@ class H5pyFast5Reader:
                 move = ev['move'].tolist()
             if 'p_model_state' in cols:
                 pms = ev['p_model_state'].astype(np.float64).tolist()
+            if table in ('albacore', 'guppy_events'):
+                events = {k: np.array(ev[k]) for k in EVENT_COLUMNS if k in cols}
         elif 'BaseCalled_template/Move' in analyses:
             table, move = 'move', analyses['BaseCalled_template/Move'][()].tolist()
-        return {'sequence': fq[1], 'qstring': fq[3],
+        return {**({'events': events} if events is not None else {}), 'sequence': fq[1], 'qstring': fq[3],
                 'block_stride': int(sm.get('block_stride', 15)),
                 'sequence_length': int(sm['sequence_length']),
                 'mean_qscore': float(sm['mean_qscore']),

@@ -373,6 +373,8 @@ _TEXT_SIGNATURES = {      # libpxghost.so: host-only helpers (sink text, sample 
     'pxg_h5_info_mt': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32]),
     'pxg_h5_basecall': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p,
                                   C.c_void_p, C.POINTER(C.c_int32)]),
+    'pxg_h5_events': (C.c_int64, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     'pxg_h5_load_signals': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int32, C.c_void_p]),
     'pxg_h5_basecall_many': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -446,6 +448,10 @@ _SIGNATURES = {
                                         C.c_void_p]),
     'pxg_batch_unsplit_scan': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                          C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    'pxg_batch_unsplit_scan_events': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                                C.c_void_p, C.c_void_p, C.POINTER(C.c_int64)]),
+    'pxg_ctx_lock': (C.c_int, [C.c_void_p, C.c_int]),
+    'pxg_ctx_unlock': (C.c_int, [C.c_void_p, C.c_int]),
     'pxg_batch_pooled_signal': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pxg_batch_download_windows': (C.c_int, [C.c_void_p, C.c_void_p]),
     'pxg_batch_event_table': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
@@ -1048,6 +1054,41 @@ class NativeContext:
         start = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(np.maximum(cnt, 0), out=start[1:])
         return iv[:total.value], cnt, start
+
+    def unsplit_scan_events(self, n_events, ev_start, ev_mean):
+        """The same scan for reads whose basecall brings its own event table (albacore `Events'):
+        n_events [n] rows per resident read (0 leaves a read out), their ascending `start' column (int64
+        samples) and float32 `mean' column back to back.  Returns what unsplit_scan returns."""
+        n = self.n_resident
+        ne = np.ascontiguousarray(n_events, dtype=np.int64)
+        st = np.ascontiguousarray(ev_start, dtype=np.int64)
+        mean = np.ascontiguousarray(ev_mean, dtype=np.float32)
+        total_ev = int(np.maximum(ne, 0).sum())
+        if len(ne) != n or len(st) != total_ev or len(mean) != total_ev:
+            raise ValueError('one n_events entry per resident read, one start / mean per event')
+        cnt = np.empty(n, dtype=np.int32)
+        total = C.c_int64(0)
+        cap = max(getattr(self, '_unsplit_cap', 0), n // 4 + 1024)
+        while True:
+            iv = np.empty((cap, 2), dtype=np.int64)
+            self._check(self.lib.pxg_batch_unsplit_scan_events(self.handle, _ptr(ne), _ptr(st), _ptr(mean), cap,
+                                                               _ptr(iv), _ptr(cnt), C.byref(total)),
+                        'pxg_batch_unsplit_scan_events')
+            if total.value <= cap:
+                break
+            cap = int(total.value) + 1024
+        self._unsplit_cap = cap
+        start = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.maximum(cnt, 0), out=start[1:])
+        return iv[:total.value], cnt, start
+
+    def lock(self, which):
+        """pxg_ctx_lock: 0 = the spare input slot, 1 = the resident batch (the locks pxg_process_batch_ex
+        takes inside); blocks with the GIL released."""
+        self._check(self.lib.pxg_ctx_lock(self.handle, int(which)), 'pxg_ctx_lock')
+
+    def unlock(self, which):
+        self._check(self.lib.pxg_ctx_unlock(self.handle, int(which)), 'pxg_ctx_unlock')
 
     def download_windows(self, records=None):
         """[n, signal_trim_length] float32: the classifier's input windows of the resident batch

@@ -360,38 +360,61 @@ class SignalAnalyzer(AbstractContextManager):
         resident batch (ReadTable.event_dump).  Raises what load_events raises."""
         read = NanoporeRead(t, row)
         bcall = read.load_fast5_events()
-        if bcall.get('table', 'move') != 'move':
-            raise NotImplementedError(
-                '--dump-basecalls writes the tables of Move-table basecalls (Guppy >= 2.3.7); this '
-                'read carries an Events table')
-        first, n_blocks, stride = read.guppy_event_geometry(bcall=bcall)
-        g = int(t.gpu_row[row])
-        if tuple(t.event_frame[g]) != (first, n_blocks, stride):
-            raise Exception('event frame of the dump does not match the basecall')
-        mean, stdv, scaled, offsets = t.event_dump[stride]
-        at = slice(int(offsets[g]), int(offsets[g + 1]))
         fields = list(self.EVENT_DUMP_FIELDS)
         fields[4] = ('model_state', 'S{}'.format(self.kmersize))
-        moves = np.asarray(bcall['move'], dtype=np.int64)
-        seq = bcall['sequence']
-        kmer_size = len(seq) - int(moves.sum()) + 1
-        rev = seq[::-1].replace('U', 'T')
-        if kmer_size == 1:                       # flip-flop models: 1-mer frames shown as 5-mers
-            rev = '__' + rev + '__'
-        elif kmer_size != 5:
-            raise Exception('Move table is encoded with an unknown kmer-size.')
-        # revseq[pos : pos + 5] for pos = cumsum(move) - 1, as Python slices it (short or empty
-        # at and beyond the end, and for a table that starts with a stay)
-        text = np.frombuffer(rev.encode('ascii') + b'\0' * 5, dtype=np.uint8)
-        pos0 = np.cumsum(moves) - 1
-        pos0 = np.where((pos0 < 0) | (pos0 > len(rev)), len(rev), pos0)
-        kmers = np.ascontiguousarray(np.lib.stride_tricks.sliding_window_view(text, 5)[pos0]).view('S5').ravel()
-        table = np.zeros(n_blocks, dtype=fields)
-        start = first + stride * np.arange(n_blocks, dtype=np.int64)
-        table['mean'], table['stdv'], table['scaled_mean'] = mean[at], stdv[at], scaled[at]
-        table['start'], table['length'], table['model_state'] = start, stride, kmers
-        table['move'], table['pos'] = moves, np.cumsum(moves)
-        table['end'] = np.append(start[1:], start[-1:] + 1) if n_blocks else start
+        kind = bcall.get('table', 'move')
+        if kind == 'albacore':
+            # the table as the file holds it (fast5_file.py:178-179) + the three columns load_events adds
+            # (:318-324); scaled_mean = np.poly1d(float32[scale, shift])(mean) in the width of `mean'
+            frame = albacore_frame(bcall)
+            ev = frame['table']
+            for name in ('stdv', 'length', 'model_state'):
+                if name not in ev:
+                    raise KeyError(name)
+            n_rows = len(frame['start'])
+            table = np.zeros(n_rows, dtype=fields)
+            mean = np.asarray(ev['mean'])
+            scale, shift = (mean.dtype.type(v) for v in t.scale_shift[row]) if mean.dtype == np.float32 else \
+                (np.float64(np.float32(v)) for v in t.scale_shift[row])
+            scaled = scale * mean
+            scaled = scaled + shift
+            with np.errstate(all='ignore'):
+                table['mean'], table['stdv'], table['scaled_mean'] = mean, ev['stdv'], scaled
+                table['start'], table['length'], table['model_state'] = ev['start'], ev['length'], ev['model_state']
+                table['move'], table['pos'], table['end'] = frame['move'], frame['pos'], frame['end']
+        else:
+            first, n_blocks, stride = read.guppy_event_geometry(bcall=bcall)
+            g = int(t.gpu_row[row])
+            if tuple(t.event_frame[g]) != (first, n_blocks, stride):
+                raise Exception('event frame of the dump does not match the basecall')
+            mean, stdv, scaled, offsets = t.event_dump[stride]
+            at = slice(int(offsets[g]), int(offsets[g + 1]))
+            moves = np.asarray(bcall['move'], dtype=np.int64)
+            if kind == 'guppy_events':               # Events table of Guppy < 2.3.7: its own model_state column
+                ev = bcall.get('events') or {}
+                if 'model_state' not in ev:
+                    raise KeyError('model_state')
+                kmers = np.asarray(ev['model_state'])
+            else:
+                seq = bcall['sequence']
+                kmer_size = len(seq) - int(moves.sum()) + 1
+                rev = seq[::-1].replace('U', 'T')
+                if kmer_size == 1:                       # flip-flop models: 1-mer frames shown as 5-mers
+                    rev = '__' + rev + '__'
+                elif kmer_size != 5:
+                    raise Exception('Move table is encoded with an unknown kmer-size.')
+                # revseq[pos : pos + 5] for pos = cumsum(move) - 1, as Python slices it (short or empty
+                # at and beyond the end, and for a table that starts with a stay)
+                text = np.frombuffer(rev.encode('ascii') + b'\0' * 5, dtype=np.uint8)
+                pos0 = np.cumsum(moves) - 1
+                pos0 = np.where((pos0 < 0) | (pos0 > len(rev)), len(rev), pos0)
+                kmers = np.ascontiguousarray(np.lib.stride_tricks.sliding_window_view(text, 5)[pos0]).view('S5').ravel()
+            table = np.zeros(n_blocks, dtype=fields)
+            start = first + stride * np.arange(n_blocks, dtype=np.int64)
+            table['mean'], table['stdv'], table['scaled_mean'] = mean[at], stdv[at], scaled[at]
+            table['start'], table['length'], table['model_state'] = start, stride, kmers
+            table['move'], table['pos'] = moves, np.cumsum(moves)
+            table['end'] = np.append(start[1:], start[-1:] + 1) if n_blocks else start
         # get_dump_attributes (:288-309)
         adapter = self.ctx.state_names.index('adapter')
         pool = int(self.loader.scaler_cfg['stride'])
@@ -424,6 +447,29 @@ class SignalAnalyzer(AbstractContextManager):
             for read_id, table, attrs in self.event_dump_list:
                 h5.create_dataset('basecalled_events/{}/{}'.format(batch, read_id), table, attrs=attrs)
         self.event_dump_list = None
+
+
+def albacore_frame(bcall):
+    """Base-space view of a table that brings its own events (albacore's 14 columns), as load_events leaves
+    it (signal_analyzer.py:311-326): start as stored, end = start + hstack(diff(start), [1]), pos =
+    cumsum(move), p_model_state in the file's own float width."""
+    ev = bcall.get('events')
+    if ev is None:
+        raise Exception('Unsupported event table found.')
+    for name in ('start', 'mean', 'move'):
+        if name not in ev:
+            raise KeyError(name)
+    start = np.asarray(ev['start'])
+    signed = start.dtype.kind == 'i'
+    st = start.astype(np.int64) if start.dtype.kind in 'iu' else start.astype(np.float64)
+    if 'p_model_state' not in ev:
+        pms = None
+    else:
+        pms = np.asarray(ev['p_model_state'])
+    moves = np.asarray(ev['move'])
+    end = np.append(st[1:], st[-1:] + 1) if len(st) else st
+    return {'start': st, 'end': end, 'move': moves, 'pos': np.cumsum(moves), 'p_model_state': pms,
+            'end_is_float': not signed, 'table': ev}
 
 
 class SignalAnalysis:
@@ -468,6 +514,8 @@ class SignalAnalysis:
         """Base-space columns of the Guppy event table (fast5_file.py:183-208,
         signal_analyzer.py:319-324).  The signal-space columns (mean, scaled_mean) never
         leave the GPU: SignalLoader.scan_unsplit_candidates."""
+        if bcall.get('table') == 'albacore':             # the table's own events, unchanged (fast5_file.py:178-179)
+            return albacore_frame(bcall)
         first, n_blocks, stride = self.npread.guppy_event_geometry(bcall=bcall)
         moves = np.asarray(bcall['move'], dtype=np.uint8)
         if bcall.get('table') == 'guppy_events':         # Events table: the column is stored
@@ -501,6 +549,15 @@ class SignalAnalysis:
         if t.unsplit_count[row] < 0:
             raise Exception('chimera window scan failed for this read (code {})'.format(
                 int(t.unsplit_count[row])))
+        if events.get('end_is_float'):
+            # :385 range(payload_start, events.iloc[-1]['end'], window_step): `end' = start + duration is a
+            # float64 column whenever `start' is not a signed integer column (uint64 + int64 promotes, and
+            # albacore writes uint64), and range() refuses it -- the reference fails this read right here
+            raise TypeError("'numpy.float64' object cannot be interpreted as an integer")
+        if events.get('table') is not None and row not in getattr(t, 'own_table_scanned', ()):
+            # an albacore table the window scan did not take (a float64 `mean' column, starts that are not
+            # ascending): refused for this read alone, never silently passed
+            raise Exception('Unsupported event table found.')
         candidates = t.unsplit[row]
         if not candidates:
             return False
@@ -509,6 +566,8 @@ class SignalAnalysis:
         cuts = np.array([[0, payload_start]] + union_intervals(candidates) + [[np.inf, np.inf]])
         # sub-read k = events whose start lies in [cuts[k, 1], cuts[k + 1, 0]], both inclusive
         start, pos, pms = events['start'], events['pos'], events['p_model_state']
+        if pms is None:
+            raise KeyError('p_model_state')
         lo = np.searchsorted(start, cuts[:-1, 1], side='left')
         hi = np.searchsorted(start, cuts[1:, 0], side='right')
         # a base (one value of `pos`) counts when the best p_model_state among its events
@@ -520,8 +579,9 @@ class SignalAnalysis:
                 continue
             p = pos[a:b]
             heads = np.nonzero(np.r_[True, p[1:] != p[:-1]])[0]
-            hq.append(int((np.maximum.reduceat(pms[a:b], heads)
-                           > limits['basecount_quality_limit']).sum()))
+            # (a float32 column is compared in float32, as pandas / NumPy 1.x compare it with a Python float)
+            limit = pms.dtype.type(limits['basecount_quality_limit'])
+            hq.append(int((np.maximum.reduceat(pms[a:b], heads) > limit).sum()))
         later = sum(hq[1:])
         return bool(later > limits['subread_basecount_limit'] or
                     (later + 1) / (hq[0] + 1) > limits['subread_baseratio_limit'])

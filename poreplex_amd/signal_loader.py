@@ -443,10 +443,8 @@ class NanoporeRead:
             raise SignalAnalysisError('not_basecalled')
         if bcall.get('move') is None:
             raise Exception("Neither `Events' or `Move' table found in the basecall.")
-        if bcall.get('table') == 'albacore':
-            raise NotImplementedError(
-                'albacore 14-column Events tables carry their own event boundaries; the GPU '
-                'chimera filter handles Guppy block frames (Move / Guppy Events) only')
+        if bcall.get('table') == 'albacore':        # (its events are its own: SignalLoader.unsplit_event_tables)
+            raise Exception('an albacore Events table has no Guppy block frame')
         n_raw = int(t.n_raw[i]) if n_raw is None else int(n_raw)
         first, stride = int(bcall['first_sample_template']), int(bcall['block_stride'])
         n_blocks = len(bcall['move'])
@@ -680,6 +678,11 @@ class SignalLoader:
                 sel = (frame[:, 2] == stride) & (frame[:, 1] > 0)
                 self.attach_unsplit(table, rows, sel, self.ctx.unsplit_scan(
                     frame[:, 0], np.where(sel, frame[:, 1], 0), int(stride)))
+            own = self.unsplit_event_tables(table, rows)
+            if own is not None:          # reads whose basecall brings its own events (albacore)
+                n_events, starts, means = own
+                self.attach_unsplit(table, rows, n_events > 0, self.ctx.unsplit_scan_events(n_events, starts, means))
+                table.own_table_scanned = set(rows[n_events > 0].tolist())
 
     def attach_records(self, table, rows, rec, spikes):
         """The GPU's records (and spike rows) become the batch table's: scaling-QC verdicts
@@ -750,31 +753,91 @@ class SignalLoader:
             if len(strides) == 1:          # (several block strides in one batch: rare, scanned below)
                 sel = (frame[:, 2] == strides[0]) & (frame[:, 1] > 0)
                 scan = (frame[:, 0], np.where(sel, frame[:, 1], 0), int(strides[0]))
-            if len(strides) <= 1:
+            own_tables = self.scan_unsplit and self.has_own_event_tables(t, rows)
+            if len(strides) <= 1 and not own_tables:
                 got = self.ctx.process_batch_ex(arena, offsets, calib, self.stage_mask, unsplit=scan,
                                                 want_spikes=polya)
                 self.attach_records(t, rows, got['records'], got.get('spikes'))
                 if scan is not None:
                     self.attach_unsplit(t, rows, sel, got['unsplit'])
                 return
-        # the same steps from Python, under the two locks (a context double in the CPU tests,
-        # or a batch that mixes Guppy block strides)
+        # the same steps from Python (a context double in the CPU tests, dump options, a batch that mixes
+        # Guppy block strides or carries albacore tables) under the SAME two locks the one-call form takes
+        # inside the library (pxg_ctx_lock: calls of both forms may be in flight on other threads)
         ctx = self.ctx
-        with self._stage_lock:
+        native_locks = hasattr(ctx, 'lock')
+        lock = ctx.lock if native_locks else (lambda w: (self._run_lock if w else self._stage_lock).acquire())
+        unlock = ctx.unlock if native_locks else (lambda w: (self._run_lock if w else self._stage_lock).release())
+        lock(0)
+        try:
             if isinstance(arena, native.EncodedSamples):      # compressed bundle: decoded on the GPU
                 ctx.stage_z(arena, offsets, calib)
             else:
                 ctx.stage(arena, offsets, calib)
-            self._run_lock.acquire()                          # the previous call has its records
+            lock(1)                                           # the previous call has its records
             try:
                 ctx.swap()
             except BaseException:
-                self._run_lock.release()
+                unlock(1)
                 raise
+        finally:
+            unlock(0)
         try:
             self.run_resident(t, rows, offsets)
         finally:
-            self._run_lock.release()
+            unlock(1)
+
+    def has_own_event_tables(self, table, rows):
+        """Does any read of the batch carry an albacore Events table (its own event boundaries)?"""
+        t = table
+        if t.bundle is not None:
+            bi = t.bundle_index[rows]
+            if (t.bundle.d['bc_table'][np.where(bi >= 0, bi, 0)][bi >= 0] == 3).any():
+                return True
+            if (bi >= 0).all():
+                return False
+        for k in np.nonzero(t.bundle_index[rows] < 0)[0].tolist() if t.bundle is not None else range(len(rows)):
+            try:
+                bc = t.source_of(rows[k]).get_basecall()
+            except Exception:
+                continue
+            if bc is not None and bc.get('table') == 'albacore':
+                return True
+        return False
+
+    def unsplit_event_tables(self, table, rows):
+        """(n_events [n], start arena int64, mean arena float32) of the batch's reads whose basecall is an
+        albacore Events table the window scan can take as it is: a signed-integer, ascending `start'
+        column and a float32 `mean' column.  Every other such table is left out here and fails (or is
+        refused) per read, where the reference fails it (SignalAnalysis.detect_unsplit_read).  None when
+        the batch has no such read."""
+        t = table
+        n = len(rows)
+        n_events = np.zeros(n, dtype=np.int64)
+        starts, means = [], []
+        kinds = None
+        if t.bundle is not None:
+            bi = t.bundle_index[rows]
+            kinds = np.where(bi >= 0, t.bundle.d['bc_table'][np.where(bi >= 0, bi, 0)], -1)
+        for k in range(n):
+            if kinds is not None and kinds[k] >= 0 and kinds[k] != 3:
+                continue
+            try:
+                bc = t.source_of(rows[k]).get_basecall()
+            except Exception:
+                continue
+            ev = bc.get('events') if bc is not None and bc.get('table') == 'albacore' else None
+            if ev is None or 'start' not in ev or 'mean' not in ev:
+                continue
+            st, mean = np.asarray(ev['start']), np.asarray(ev['mean'])
+            if st.dtype.kind != 'i' or mean.dtype != np.float32 or not len(st) or st[0] < 0 or (np.diff(st) < 0).any():
+                continue
+            n_events[k] = len(st)
+            starts.append(st.astype(np.int64))
+            means.append(mean)
+        if not starts:
+            return None
+        return n_events, np.concatenate(starts), np.concatenate(means)
 
     def unsplit_frames(self, table, rows, offsets):
         """[n, 3] (first sample, Guppy blocks, block stride) of the batch's reads for the a18 +

@@ -97,6 +97,26 @@ class OracleBackedContext:
         iv = np.concatenate(found) if found else np.zeros((0, 2), dtype=np.int64)
         return iv.reshape(-1, 2), cnt, start
 
+    def unsplit_scan_events(self, n_events, ev_start, ev_mean):
+        arena, offsets, calib, _ = self.batch
+        n = len(offsets) - 1
+        found = []
+        cnt = np.zeros(n, dtype=np.int32)
+        a = int(self.cfg.segmentation_model.adapter_state)
+        eo = np.concatenate([[0], np.cumsum(np.maximum(np.asarray(n_events, dtype=np.int64), 0))]).astype(np.int64)
+        for i in range(n):
+            r = self.res[i]
+            if n_events[i] <= 0 or r['status'] != 0 or r['seg_first'][a] < 0:
+                continue
+            got, c = self.oracle.unsplit_scan_events(ev_mean[eo[i]:eo[i + 1]], ev_start[eo[i]:eo[i + 1]], r['scale'],
+                                                     r['shift'], (int(r['seg_last'][a]) + 1) * int(self.cfg.stride),
+                                                     float(calib[i]['sampling_rate']))
+            found.append(got)
+            cnt[i] = c
+        start = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+        iv = np.concatenate(found) if found else np.zeros((0, 2), dtype=np.int64)
+        return iv.reshape(-1, 2), cnt, start
+
     def event_table(self, first_sample, n_blocks, block_stride=15):
         arena, offsets, calib, _ = self.batch
         n = len(offsets) - 1

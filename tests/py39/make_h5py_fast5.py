@@ -34,6 +34,25 @@ with h5py.File(os.path.join(out,'single.fast5'),'w') as h5:
     fill(h5.create_group('Raw/Reads/Read_7'), h5.create_group('UniqueGlobalKey/channel_id'), h5.create_group('UniqueGlobalKey/tracking_id'), h5.create_group('Analyses'), 'rid-single', raw_of(0), 0)
 with h5py.File(os.path.join(out,'single_events.fast5'),'w') as h5:
     fill(h5.create_group('Raw/Reads/Read_8'), h5.create_group('UniqueGlobalKey/channel_id'), h5.create_group('UniqueGlobalKey/tracking_id'), h5.create_group('Analyses'), 'rid-events', raw_of(1), 1, events=True, compression='gzip', shuffle=True, chunks=(1500,))
+# albacore's 14-column Events table (uint64 start / length as albacore writes them), chunked + gzip
+ALB = [('mean','<f4'),('start','<u8'),('stdv','<f4'),('length','<u8'),('model_state','S5'),('move','<i4'),('weights','<f4'),
+       ('p_model_state','<f4'),('mp_state','S5'),('p_mp_state','<f4'),('p_A','<f4'),('p_C','<f4'),('p_G','<f4'),('p_T','<f4')]
+with h5py.File(os.path.join(out,'single_albacore.fast5'),'w') as h5:
+    raw = raw_of(3)
+    fill(h5.create_group('Raw/Reads/Read_10'), h5.create_group('UniqueGlobalKey/channel_id'), h5.create_group('UniqueGlobalKey/tracking_id'), h5.create_group('Analyses'), 'rid-albacore', raw, 3, bc=False)
+    g = h5['Analyses'].create_group('Basecall_1D_000'); t = g.create_group('BaseCalled_template')
+    n = 611
+    ev = np.zeros(n, dtype=ALB)
+    ev['length'] = rng.integers(2, 15, n); ev['start'] = 5 + np.concatenate([[0], np.cumsum(ev['length'][:-1])])
+    ev['mean'] = rng.normal(90, 12, n); ev['stdv'] = rng.random(n) * 3; ev['move'] = rng.integers(0, 3, n)
+    ev['model_state'] = np.array([''.join(k) for k in rng.choice(list('ACGT'), (n, 5))], dtype='S5'); ev['mp_state'] = ev['model_state']
+    ev['p_model_state'] = rng.random(n); ev['weights'] = 1
+    seq = ''.join(rng.choice(list('ACGU'), int(ev['move'].sum()))); q = ''.join(chr(40+int(x)) for x in rng.integers(0,20,len(seq)))
+    t.create_dataset('Fastq', data=np.string_('@rid-albacore\n%s\n+\n%s\n' % (seq, q)))
+    t.create_dataset('Events', data=ev, chunks=(100,), compression='gzip')
+    s_ = g.create_group('Summary/basecall_1d_template'); s_.attrs['sequence_length']=np.int32(len(seq)); s_.attrs['mean_qscore']=np.float32(9.5)
+    sg = h5['Analyses'].create_group('Segmentation_000/Summary/segmentation'); sg.attrs['num_events_template']=np.int32(n); sg.attrs['first_sample_template']=np.int32(5)
+    np.save(os.path.join(out, 'truth_albacore_events.npy'), ev)
 with h5py.File(os.path.join(out,'single_latest.fast5'),'w', libver='latest') as h5:
     fill(h5.create_group('Raw/Reads/Read_9'), h5.create_group('UniqueGlobalKey/channel_id'), h5.create_group('UniqueGlobalKey/tracking_id'), h5.create_group('Analyses'), 'rid-latest', raw_of(2), 2, bc=False)
 with h5py.File(os.path.join(out,'multi.fast5'),'w') as h5:

@@ -493,3 +493,76 @@ def test_filter_unsplit_reads_gpu_vs_reference():
     ref, cfg = chimera_case()
     check_chimera(process_batch(ref['batchid'], [tuple(r) for r in ref['reads']], cfg), ref)
     WorkerPersistenceStorage.reset()
+
+
+# ---- a18/a19 over albacore's 14-column Events tables (the reference's primary input: fast5_file.py:178-179) ----
+def albacore_case(tmp_path):
+    import json
+    with open(G('albacore.results.json')) as fh:
+        ref = json.load(fh)
+    cfg = default_config(inputdir='/nonexistent-inputdir', outputdir=str(tmp_path), read_bundle=G('albacore.pxr.npz'),
+                         **ref['config_flags'])
+    return ref, cfg
+
+
+def run_albacore(tmp_path, monkeypatch):
+    """--filter-chimera + --dump-basecalls over reads whose basecall is an albacore Events table (variable-
+    length events, their own `start' column) against what the REAL reference returned and dumped for the same
+    tables (tests/golden/albacore.*, tools/make_golden.py): result dicts, the in-read adapter candidates of
+    every read, every row and attribute of the dumped tables.  Two of the reads carry uint64 `start' columns,
+    the dtype albacore itself writes: there the reference's own arithmetic fails (float64 `end', range() at
+    signal_analyzer.py:385) and the read becomes unknown_error -- after its table was dumped."""
+    import json
+    from poreplex_amd import fast5_write, signal_loader
+    from poreplex_amd.signal_analyzer import process_batch
+    ref, cfg = albacore_case(tmp_path)
+    written, cands = {}, {}
+    create = fast5_write.H5Writer.create_dataset
+    attach = signal_loader.SignalLoader.attach_unsplit
+
+    def recording(self, path, data, attrs=()):
+        written[path] = (np.array(data), list(attrs))
+        return create(self, path, data, attrs)
+
+    def spying(self, table, rows, sel, scanned):
+        attach(self, table, rows, sel, scanned)
+        for k in np.nonzero(sel)[0].tolist():
+            cands[str(table.read_id[rows[k]])] = [list(map(int, iv)) for iv in (table.unsplit[rows[k]] or [])]
+    monkeypatch.setattr(fast5_write.H5Writer, 'create_dataset', recording)
+    monkeypatch.setattr(signal_loader.SignalLoader, 'attach_unsplit', spying)
+    got = process_batch(ref['batchid'], [tuple(r) for r in ref['reads']], cfg)
+    assert not (isinstance(got, tuple) and got[0] == -1), got
+    compare_results(got, ref['results'], check_polya=True)
+    statuses = [r['status'] for r in got]
+    assert statuses.count('unsplit_read') >= 2 and statuses.count('unknown_error') == 2 and statuses.count('okay') >= 2
+    # candidates: the reference's excessive_adapters list of every read it scanned (append order)
+    for (fn, rid), want in zip(ref['reads'], ref['candidates']):
+        if rid in cands:
+            assert cands[rid] == want, (rid, cands[rid], want)
+        else:
+            assert want == [], rid
+    assert sum(1 for c in ref['candidates'] if c) >= 2
+    # dumps
+    st = np.load(G('albacore.stages.npz'))
+    want_attrs = json.loads(str(st['events_attrs']))
+    ids, off, rows = st['events_ids'].tolist(), st['events_offsets'], st['events_rows']
+    assert sorted(written) == ['basecalled_events/00000009/' + k for k in ids]
+    for k, rid in enumerate(ids):
+        table, attrs = written['basecalled_events/00000009/' + rid]
+        assert table.dtype == rows.dtype, rid
+        assert table.tobytes() == rows[off[k]:off[k + 1]].tobytes(), rid
+        gota = {}
+        for name, v in attrs:
+            gota[name] = ['bytes', v.decode()] if isinstance(v, bytes) else [str(v.dtype), v.item()]
+        assert gota == want_attrs[rid], (rid, gota, want_attrs[rid])
+
+
+def test_albacore_events_tables_host_logic_vs_reference(oracle_backed, arith, tmp_path, monkeypatch):
+    run_albacore(tmp_path, monkeypatch)
+
+
+@pytest.mark.gpu
+def test_albacore_events_tables_gpu_vs_reference(arith, tmp_path, monkeypatch):
+    WorkerPersistenceStorage.reset()
+    run_albacore(tmp_path, monkeypatch)
+    WorkerPersistenceStorage.reset()

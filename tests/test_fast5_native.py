@@ -241,6 +241,15 @@ def test_native_reader_reads_what_the_real_library_wrote(tmp_path):
         assert f.info['run_id'][0].decode() == 'run' + 'ab' * 18 and f.info['sample_id'][0] == b'sampleX'
     assert n_checked >= 12
     assert F5.Fast5File(str(tmp_path / 'many.fast5')).read_ids == ['many%04d' % i for i in range(700)]
+    # albacore's 14-column Events table: the consumed columns come back in the file's own dtypes
+    f = F5.Fast5File(str(tmp_path / 'single_albacore.fast5'))
+    assert not f.info['status'].any() and f.info['bc_table'][0] == 3
+    want = np.load(str(tmp_path / 'truth_albacore_events.npy'))
+    bc = f.basecall(0)
+    assert bc['table'] == 'albacore' and bc['num_events'] == len(want) and bc['move'] == want['move'].tolist()
+    for name in ('start', 'length', 'mean', 'stdv', 'move', 'p_model_state', 'model_state'):
+        got = bc['events'][name]
+        assert got.dtype == want[name].dtype and np.array_equal(got, want[name]), name
     # `libver latest` with more than eight attributes on a group: dense storage, declined per read
     f = F5.Fast5File(str(tmp_path / 'single_latest.fast5'))
     assert f.info['status'][0] == N.PXG_E_UNSUPPORTED and b'dense attribute storage' in f.info['error'][0]

@@ -786,6 +786,149 @@ def main():
                        'minimum_sequence_length', 'barcoding_quality_filter')},
                    'candidates': cand_list, 'results': jsonable(cres)}, fh, indent=1)
 
+    # ---- a18/a19 over albacore's 14-column Events tables (fast5_file.py:178-179 passes them through) ----
+    # the chimera reads again, their events cut by the reference's own event detector (variable lengths),
+    # run through the REAL process_batch with --filter-chimera and --dump-basecalls.  `start' is int64 for
+    # most reads (the table the reference's arithmetic works on) and uint64 -- what albacore itself writes,
+    # signal_analyzer.py:66-67 mirrors its dtypes -- for two: there `end' = start + duration promotes to
+    # float64 and range() at :385 refuses it, so the reference turns those reads into unknown_error.
+    ALB = [('mean', '<f4'), ('start', '<i8'), ('stdv', '<f4'), ('length', '<i8'), ('model_state', 'S5'),
+           ('move', '<i4'), ('weights', '<f4'), ('p_model_state', '<f4'), ('mp_state', 'S5'),
+           ('p_mp_state', '<f4'), ('p_A', '<f4'), ('p_C', '<f4'), ('p_G', '<f4'), ('p_T', '<f4')]
+
+    def albacore_table(g, raw, cal, first, unsigned):
+        pa = np.array(float(cal['range']) / float(cal['digitisation']) * (raw[first:].astype(np.float64) + float(cal['offset'])),
+                      dtype=np.float32)
+        ev = ref_detect_events(pa, window_length1=3, window_length2=6, threshold1=1.4, threshold2=9.0, peak_height=0.2)
+        dt = [(n, t.replace('<i8', '<u8') if unsigned and n in ('start', 'length') else t) for n, t in ALB]
+        tab = np.zeros(len(ev), dtype=dt)
+        tab['mean'], tab['stdv'] = ev['mean'], ev['stdv']
+        tab['start'] = np.asarray(ev['start'], dtype=np.int64) + first
+        tab['length'] = np.asarray(ev['length'], dtype=np.int64)
+        tab['move'] = g.choice([0, 1, 2], len(ev), p=[0.45, 0.5, 0.05])
+        tab['move'][0] = 1
+        kmers = np.array([''.join(k) for k in g.choice(list('ACGT'), (len(ev), 5))], dtype='S5')
+        tab['model_state'], tab['mp_state'] = kmers, kmers
+        tab['p_model_state'] = g.uniform(0.05, 0.99, len(ev)).astype(np.float32)
+        tab['p_model_state'][g.random(len(ev)) < 0.02] = np.float32(0.4)      # exactly the quality limit
+        tab['weights'], tab['p_mp_state'] = 1.0, tab['p_model_state']
+        for c in ('p_A', 'p_C', 'p_G', 'p_T'):
+            tab[c] = 0.25
+        seq_len = int(tab['move'].sum())
+        seq = ''.join(g.choice(list('ACGU'), seq_len))
+        qs = ''.join(chr(33 + int(q)) for q in g.integers(3, 25, seq_len))
+        return tab, {'sequence': seq, 'qstring': qs, 'sequence_length': seq_len,
+                     'mean_qscore': float(np.round(g.uniform(7, 12), 3)), 'block_stride': 15,
+                     'num_events': int(len(ev)), 'first_sample_template': int(first)}
+
+    def write_albacore_fast5(path, read_id, raw, cal, meta, tab, bc):
+        write_fast5(path, read_id, raw, cal, meta, None)
+        with h5py.File(path, 'a') as h5:
+            g = h5.create_group('Analyses/Basecall_1D_000')
+            tpl = g.create_group('BaseCalled_template')
+            tpl.create_dataset('Fastq', data=np.string_('@{}\n{}\n+\n{}\n'.format(read_id, bc['sequence'], bc['qstring'])))
+            tpl.create_dataset('Events', data=tab)
+            sm = g.create_group('Summary/basecall_1d_template')
+            sm.attrs['sequence_length'] = np.int32(bc['sequence_length'])
+            sm.attrs['mean_qscore'] = np.float32(bc['mean_qscore'])
+            sg = h5.create_group('Analyses/Segmentation_000/Summary/segmentation')
+            sg.attrs['num_events_template'] = np.int32(bc['num_events'])
+            sg.attrs['first_sample_template'] = np.int32(bc['first_sample_template'])
+
+    ag = np.random.default_rng(9440)
+    ainput = os.path.join(TMP, 'in3')
+    os.makedirs(ainput)
+    aitems = []
+    alb_reads = [chim[k] for k in (0, 1, 2, 6, 7, 10)] + [('chimera_u8', chim[0][1]), ('plain_u8', chim[7][1])]
+    for i, (tag, raw) in enumerate(alb_reads):
+        rid = '%08x-0000-4000-8000-%012x' % (0x9440 + i, i)
+        fn = 'a%03d.fast5' % i
+        meta = {'read_number': 700 + i, 'start_time': int(ag.integers(10**5, 10**8)),
+                'channel_number': int(ag.integers(1, 513)), 'run_id': 'run' + 'ef' * 19, 'sample_id': 'synthetic'}
+        tab, bc = albacore_table(ag, raw, cb['calib'][0], int(ag.integers(0, 40)), tag.endswith('_u8'))
+        write_albacore_fast5(os.path.join(ainput, fn), rid, raw, cb['calib'][0], meta, tab, bc)
+        bcd = dict(bc, table='albacore', move=tab['move'].tolist(), p_model_state=None,
+                   events={k: np.array(tab[k]) for k in ('start', 'length', 'mean', 'stdv', 'move', 'p_model_state', 'model_state')})
+        aitems.append({'tag': tag, 'raw': raw, 'filename': fn, 'read_id': rid, 'meta': meta, 'basecall': bcd})
+    aout = os.path.join(TMP, 'out_alb')
+    os.makedirs(os.path.join(aout, 'events'))
+    acfg = dict(refcfg)
+    acfg.update({'inputdir': ainput, 'outputdir': aout, 'measure_polya': False, 'filter_unsplit_reads': True,
+                 'trim_adapter': False, 'dump_basecalls': True})
+    acap = {'cands': {}, 'scaled': {}}
+    acur = {}
+
+    def aload(self):
+        ev = orig_load(self)
+        acap['scaled'][self.npread.read_id] = np.array(ev['scaled_mean'])
+        return ev
+
+    def adet(self, events, segments, elspan):
+        acur['rid'] = self.npread.read_id
+        acap['cands'][acur['rid']] = []
+        return orig_det(self, events, segments, elspan)
+
+    def aunion(iset):
+        acap['cands'][acur['rid']] = [list(map(int, x)) for x in iset]
+        return orig_union(iset)
+
+    SA.SignalAnalysis.load_events, SA.SignalAnalysis.detect_unsplit_read, SA.union_intervals = aload, adet, aunion
+    sys.modules.pop('__poreplex_persistence', None)
+    sys.stderr, saved = open(os.devnull, 'w'), sys.stderr
+    try:
+        ares = SA.process_batch(9, [(it['filename'], it['read_id']) for it in aitems], acfg)
+    finally:
+        sys.stderr = saved
+        SA.SignalAnalysis.load_events, SA.SignalAnalysis.detect_unsplit_read, SA.union_intervals = orig_load, orig_det, orig_union
+    assert not (isinstance(ares, tuple) and ares[0] == -1), ares
+    print('albacore batch:', [(it['tag'], r['status'], r.get('label')) for it, r in zip(aitems, ares)])
+    import glob as _glob
+    (apart,) = _glob.glob(os.path.join(aout, 'events', 'part-*.h5'))
+    with h5py.File(apart, 'r') as h5:
+        ids = sorted(h5['basecalled_events/00000009'])
+        tabs = [h5['basecalled_events/00000009/' + k][:] for k in ids]
+        aattrs = {}
+        for k in ids:
+            a = {}
+            for name, v in h5['basecalled_events/00000009/' + k].attrs.items():
+                a[name] = [type(v).__name__ if not hasattr(v, 'dtype') else str(v.dtype),
+                           v.decode() if isinstance(v, bytes) else (v.item() if hasattr(v, 'item') else v)]
+            aattrs[k] = a
+    rows = np.concatenate(tabs)
+    rows = rows.astype([(name, rows.dtype[name].str) for name in rows.dtype.names])
+    from poreplex_amd.fast5_file import write_bundle
+    aarena, aoff = N.pack_reads([it['raw'] for it in aitems])
+    na = len(aitems)
+    write_bundle(os.path.join(OUT, 'albacore.pxr.npz'), aarena, aoff,
+                 np.array([tuple(cb['calib'][0])] * na, dtype=N.CALIB_DTYPE),
+                 [it['filename'] for it in aitems], [it['read_id'] for it in aitems],
+                 basecalls=[it['basecall'] for it in aitems],
+                 start_time=np.array([it['meta']['start_time'] for it in aitems], dtype=np.int64),
+                 channel_number=np.array([str(it['meta']['channel_number']) for it in aitems]),
+                 run_id=np.array([it['meta']['run_id'] for it in aitems]),
+                 sample_id=np.array([it['meta']['sample_id'] for it in aitems]),
+                 tag=np.array([it['tag'] for it in aitems]))
+    _b = dict(np.load(os.path.join(OUT, 'albacore.pxr.npz')))          # (the same arrays, deflated)
+    np.savez_compressed(os.path.join(OUT, 'albacore.pxr.npz'), **_b)
+    so = np.zeros(na + 1, np.int64)
+    sc = []
+    for i, it in enumerate(aitems):
+        v = acap['scaled'].get(it['read_id'], np.zeros(0, np.float32))
+        assert v.dtype == np.float32
+        so[i + 1] = so[i] + len(v)
+        sc.append(v)
+    np.savez_compressed(os.path.join(OUT, 'albacore.stages.npz'), scaled_offsets=so, scaled=np.concatenate(sc),
+                        events_ids=np.array(ids), events_rows=rows,
+                        events_offsets=np.concatenate([[0], np.cumsum([len(x) for x in tabs])]).astype(np.int64),
+                        events_attrs=np.array(json.dumps(aattrs)))
+    with open(os.path.join(OUT, 'albacore.results.json'), 'w') as fh:
+        json.dump({'batchid': 9, 'reads': [(it['filename'], it['read_id']) for it in aitems],
+                   'config_flags': {k: acfg[k] for k in (
+                       'barcoding', 'measure_polya', 'trim_adapter', 'filter_unsplit_reads', 'dump_basecalls',
+                       'minimum_sequence_length', 'barcoding_quality_filter')},
+                   'candidates': [acap['cands'].get(it['read_id'], []) for it in aitems],
+                   'results': jsonable(ares)}, fh, indent=1)
+
     # ---- a14/a17 poly(A): real PolyASignalAnalyzer on full-resolution reads
     class _PRead:
         def __init__(self, sig, rate):
