@@ -55,7 +55,7 @@ PEAK_HBM = 8.0e12              # B/s
 # the only throughput the reference publishes (Poreplex 0.1, whole
 # pipeline incl. FAST5 I/O, 2x Xeon E5-2687W v3 = 20 cores): 1 339 070 reads in 1 h 37 min
 PUBLISHED_READS_PER_S = 1339070 / (97 * 60.0)
-TRAFFIC_FILE = os.path.join('profiles', 'r03', 'hbm_traffic.json')
+TRAFFIC_FILE = os.path.join('profiles', 'r04', 'b_hbm_traffic.json')
 # PXG_BENCH_SHARE_GPU=1: every rank of a torchrun launch uses GPU 0 and the collectives go over gloo --
 # the real multi-process path (sharding, barriers, max over ranks, label gather, NUMA binding, the
 # host-side legs on all ranks at once) with the real kernels on a ONE-GPU box.  A plumbing check:
@@ -95,6 +95,10 @@ def parse(argv=None):
     ap.add_argument('--cpu-all-cores-sample', type=int, default=4096,
                     help='reads timed over all physical cores, one process each (0 = skip)')
     ap.add_argument('--seed', type=int, default=924)
+    ap.add_argument('--length-dist', choices=['lognormal'], default=None,
+                    help='read lengths as a sequencing run produces them (poreplex_amd.synth: median 40 000 samples, 15 %% '
+                         'below 30 000, a tail to 1 000 000) instead of --samples +- 10 %%')
+    ap.add_argument('--no-run-shaped-leg', action='store_true', help='skip the run-shaped (log-normal lengths) leg of the default line')
     ap.add_argument('--lstm-arith', choices=['q8', 'f32'], default=None,
                     help='arithmetic of the recurrent matmuls (include/pxg.h pxg_lstm_arith); default: the '
                          'config\'s (q8 = exact fixed point on the int8 matrix pipe)')
@@ -624,41 +628,100 @@ def strong_leg(args, ctx, dist, rank, world, mask, standin, force_dist, barrier)
             'reads_ok_this_rank': int((res['status'] == 0).sum())}
 
 
-FLIPS_FILE = os.path.join('profiles', 'r03', 'decision_flips.json')
+FLIPS_FILE = os.path.join('profiles', 'r04', 'decision_flips.json')
+FLIPS_GPU_FILE = os.path.join('profiles', 'r04', 'decision_flips_gpu.json')
+BOUNDS_FILE = os.path.join('profiles', 'r04', 'full_kernel_bounds.json')
 
 
 def unpinned_rows_block():
     """Rows whose third-party numerics (TensorFlow LSTMs: a4, a12; pomegranate Viterbi: a7) cannot
     run in this image: "GPU == oracle" above proves the kernels, not the restatement.  What a
-    different-but-correct implementation could move is MEASURED by tests/test_decision_flips.py
-    (2 048 bench reads + 512 chimeras; float64 / longdouble Keras equations, every formula variant
-    of the pomegranate Viterbi); the committed numbers of that measurement ride along here --
-    static, from the file named, not re-measured by this run."""
+    different-but-correct implementation could move is MEASURED -- tools/decision_flips_gpu.py (both product
+    arithmetics and the exact float64 Keras equations on >= 20 000 bench reads, an adversarial read set and
+    two sets built ON the scaling-QC bounds / the calling threshold) and tests/test_decision_flips.py (every
+    formula variant of the pomegranate Viterbi, bench + adversarial reads); the committed numbers of those
+    measurements ride along here -- static, from the files named, not re-measured by this run."""
     out = {'unpinned_rows': ['a4', 'a7', 'a12']}
+    block = {}
+    try:
+        with open(os.path.join(ROOT, FLIPS_GPU_FILE)) as fh:
+            d = json.load(fh)
+        keep = ('reads', 'scaling_qc_flips', 'status_flips', 'reads_with_a_segment_boundary_moved', 'adapter_found_flips',
+                'window_gate_flips', 'windows_compared', 'argmax_flips', 'called_uncalled_flips',
+                'called_uncalled_flips_at_threshold', 'barcodes_called', 'scaler_pred_max_abs_diff',
+                'softmax_max_abs_diff_whole_pipeline', 'softmax_max_abs_diff')
+        sets = {}
+        for st in d['sets']:
+            if 'q8_vs_f32' in st:
+                sets[st['set']] = {pair: {k: v for k, v in st[pair].items() if k in keep}
+                                   for pair in ('q8_vs_f32', 'q8_vs_f64', 'f32_vs_f64')}
+            else:
+                sets[st['set']] = {k: v for k, v in st.items() if k != 'set'}
+        block['a4_a12_q8_f32_and_exact_float64_networks'] = dict(
+            sets, source='static: {} (python tools/decision_flips_gpu.py, MI355X)'.format(FLIPS_GPU_FILE),
+            meaning='q8 / f32 = the two product arithmetics, f64 = exact Keras equations in float64 around the same '
+                    'pooling / Viterbi / window stages; qc-edge and call-edge are sets built within 1e-4 of a scaling-QC '
+                    'bound and within 1e-3 of the calling threshold')
+    except (OSError, KeyError, ValueError):
+        pass
     try:
         with open(os.path.join(ROOT, FLIPS_FILE)) as fh:
             d = json.load(fh)
-        ls, vs = d['lstm_side'], d['viterbi_side']
-        worst = {k: max(v[k] for v in vs['variants']) for k in (
-            'reads_with_a_segment_boundary_moved', 'adapter_found_flips',
-            'bench_reads_candidate_list_changed', 'chimera_reads_candidate_list_changed')}
-        out['unpinned_decision_flips'] = {
-            'source': 'static: {} (python tests/test_decision_flips.py)'.format(FLIPS_FILE),
-            'a4_a12_exact_float64_networks_vs_canonical_float32': {
-                'reads': ls['reads'], 'scaling_qc_flips': ls['scaling_qc_flips'],
-                'reads_with_a_segment_boundary_moved': ls['reads_with_a_segment_boundary_moved'],
-                'argmax_flips': ls['argmax_flips'],
-                'called_uncalled_flips_at_threshold': ls['called_uncalled_flips_at_threshold'],
-                'softmax_max_abs_diff_whole_pipeline': ls['softmax_max_abs_diff_whole_pipeline']},
-            'a7_viterbi_formula_variants': dict(
+        for key, name in (('viterbi_side', 'a7_viterbi_formula_variants'),
+                          ('viterbi_side_adversarial', 'a7_viterbi_formula_variants_adversarial_reads')):
+            vs = d.get(key)
+            if not vs:
+                continue
+            worst = {k: max(v[k] for v in vs['variants']) for k in (
+                'reads_with_a_segment_boundary_moved', 'adapter_found_flips',
+                'bench_reads_candidate_list_changed', 'chimera_reads_candidate_list_changed')}
+            block[name] = dict(
                 worst, variants=len(vs['variants']), reads_segmented=vs['reads_segmented'],
                 scan_windows=vs['scan_windows'], chimera_reads=vs['reads_scanned']['chimera'],
+                source='static: {} (python tests/test_decision_flips.py)'.format(FLIPS_FILE),
                 meaning='worst count over the variants (mixture as logsumexp / log-sum of pdfs, textbook '
                         'log-pdf, bake() renormalisation, preset in-edge order, all at once, float64 and '
-                        'longdouble)')}
+                        'longdouble)')
     except (OSError, KeyError, ValueError):
-        out['unpinned_decision_flips'] = None
+        pass
+    out['unpinned_decision_flips'] = block or None
     return out
+
+
+def run_shaped_leg(args, ctx, mask, n_reads, distinct=1024):
+    """The same stages over reads with a sequencing run's length distribution (synth.py length_dist=
+    'lognormal'): reads/s, samples/s and the per-stage times, measured like the headline (resident batch,
+    kernels + D2H of the records)."""
+    rb = synth_batch(distinct, seed=args.seed + 77, length_dist='lognormal')
+    lens = np.diff(rb['offsets'])
+    ctx.upload_tiled(n_reads, rb['arena'], rb['offsets'], rb['calib'], None, phase=0)
+    buf = np.zeros(n_reads, dtype=N.RESULT_DTYPE)
+    for _ in range(2):
+        ctx.run(mask)
+        res = ctx.download(buf)
+    ctx.sync()
+    steps = max(3, min(args.steps, 8))
+    acc = {k: 0.0 for k in N.TIMER_NAMES}
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.run(mask)
+        res = ctx.download(buf)
+        times, _ = ctx.stage_times()
+        for k in acc:
+            acc[k] += times[k]
+    ctx.sync()
+    wall = time.perf_counter() - t0
+    tiled = lens[np.arange(n_reads) % distinct]
+    return {
+        'reads_per_s': n_reads * steps / wall, 'ms_per_step': wall / steps * 1e3, 'steps': steps,
+        'samples_per_s': float(tiled.sum()) * steps / wall,
+        'stage_ms': {k: round(v / steps, 4) for k, v in acc.items()},
+        'reads': n_reads, 'distinct_reads': distinct, 'tiled_on_device': True,
+        'length_samples': {'min': int(lens.min()), 'median': float(np.median(lens)), 'mean': float(lens.mean()),
+                           'max': int(lens.max()), 'below_30000': float((lens < 30000).mean()),
+                           'above_100000': float((lens > 100000).mean())},
+        'statuses': {N.STATUS_NAMES[int(k)]: int(v) for k, v in zip(*np.unique(res['status'], return_counts=True))},
+    }
 
 
 def f32_leg(args, config, local_rank, base, inject, mask, res_q8, stage_ms_q8):
@@ -772,10 +835,10 @@ def main():
     n_base = args.base_reads if args.base_reads >= 0 else (0 if max(shard_sizes) <= 16384 else 2048)
     t_gen = time.perf_counter()
     if n_base:      # K distinct reads (same on every rank), global read i = base read i % K
-        base = synth_batch(n_base, seed=args.seed, samples_per_read=args.samples)
+        base = synth_batch(n_base, seed=args.seed, samples_per_read=args.samples, length_dist=args.length_dist)
         which = (lo + np.arange(n_local)) % n_base
     else:           # every read distinct: rank r draws its own block of the run
-        base = synth_batch(n_local, seed=args.seed + 1000 * rank, samples_per_read=args.samples)
+        base = synth_batch(n_local, seed=args.seed + 1000 * rank, samples_per_read=args.samples, length_dist=args.length_dist)
         which = np.arange(n_local)
     t_gen = time.perf_counter() - t_gen
     lens = np.diff(base['offsets'])[which]
@@ -969,6 +1032,10 @@ def main():
     alg_bytes = float(np.minimum(lens, 100000).sum() * 2 + n_local * 88)
     extra = {
         'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
+        # stage_ms['total'] spans pxg_batch_run only (K1 ... finalize, poly(A) included); the chimera filter's two
+        # stages (event_means, unsplit) run in their own call behind it and have their own timers:
+        'gpu_ms_per_step': round(stage_ms['total'] + stage_ms['event_means'] + stage_ms['unsplit'], 4),
+        # wall - GPU = the step's host share (D2H of the records, launches, the scan's one wait)
         'host_ms_per_step': round(elapsed / args.steps * 1e3 - stage_ms['total']
                                   - stage_ms['event_means'] - stage_ms['unsplit'], 4),
         'hbm_frac_whole_path': value / world * (alg_bytes / n_local) / PEAK_HBM,
@@ -1084,6 +1151,16 @@ def main():
         if world > 1:
             cpu = None
 
+    # ---- a run-shaped workload: the lengths a flow cell produces (9 000 ... 1 000 000 samples) instead of the
+    # uniform ~60 000 of the headline; 1 024 distinct reads tiled on the device to the same 10 000-read batch ----
+    if not standin and world == 1 and not n_base and not args.no_run_shaped_leg and args.length_dist is None and \
+            args.workload in ('demux', 'full', 'polya') and not use_inject:
+        try:
+            extra['run_shaped'] = run_shaped_leg(args, ctx, mask, n_local)
+            ctx.upload(base['arena'], base['offsets'], base['calib'], inject)        # the headline batch again
+        except Exception as exc:                       # reported, never hidden
+            extra['run_shaped'] = {'error': '{}: {}'.format(type(exc).__name__, exc)}
+
     # ---- the same batch in the OTHER arithmetic (float32 fma chains on the fp32 MFMA, rounds 1-3): its
     # rate, and every decision the two arithmetics take differently over the whole batch ----------------
     if arith == 'q8' and not standin and world == 1 and not n_base and not args.no_f32_leg and args.workload != 'segment':
@@ -1112,6 +1189,24 @@ def main():
             extra['fast5_ingest'] = fast5_ingest_leg(args, base, which)
         except Exception as exc:                       # reported, never hidden
             extra['fast5_ingest'] = {'error': '{}: {}'.format(type(exc).__name__, exc)}
+
+    if args.workload in ('full', 'polya', 'chimera'):
+        # what bounds the kernels beside K2 in this workload: counters of the committed PMC passes of
+        # `--workload full` (static, tools/prof.sh; derived figures in the file named)
+        try:
+            with open(os.path.join(ROOT, BOUNDS_FILE)) as fh:
+                kb = json.load(fh)['kernels']
+            extra['kernel_bounds'] = {
+                'source': 'static: {} (rocprofv3 PMC passes of --workload full)'.format(BOUNDS_FILE),
+                'k_polya': dict(kb['k_polya'], bound='latency / divergence of a per-read FSM: 40 % of the SIMD cycles issue '
+                                'VALU, a third of the instructions are scalar, waves wait 45 % of their cycles'),
+                'k_unsplit_scan': dict(kb['k_unsplit_scan'], bound='VALU issue (fp64 recurrence + DPP / bpermute shuffles): 70 % of '
+                                       'the SIMD cycles, LDS 48 % busy of which 27 % bank conflicts'),
+                'k_guppy_event_means': dict(kb['k_guppy_event_means'], bound='VALU issue 98 % (fp64 pA conversion, median-of-5 '
+                                            'network) at 3.1 TB/s of HBM traffic'),
+            }
+        except (OSError, KeyError, ValueError):
+            pass
 
     if not standin and world == 1 and not args.no_e2e_leg and not n_base and not use_inject and \
             args.workload == 'demux' and not SHARE_GPU and not force_dist:

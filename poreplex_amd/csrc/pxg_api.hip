@@ -342,9 +342,13 @@ extern "C" int pxg_get_device_info(pxg_ctx* ctx, pxg_device_info* out)
                 fclose(fh);
             }
         }
-        if (!out->name[0])
-            snprintf(out->name, sizeof(out->name), "AMD %.20s, %d CUs (no product name from the HIP runtime)",
-                     prop.gcnArchName, prop.multiProcessorCount);
+        // (sysfs often only says "AMD Radeon Graphics": add what identifies the part)
+        char arch[24] = {0};
+        strncpy(arch, prop.gcnArchName, sizeof(arch) - 1);
+        if (char* colon = strchr(arch, ':')) *colon = 0;
+        const std::string base = out->name[0] ? out->name : "AMD GPU";
+        snprintf(out->name, sizeof(out->name), "%.60s (%s, %d CUs; no product name from the HIP runtime)", base.c_str(), arch,
+                 prop.multiProcessorCount);
     }
     out->compute_units = prop.multiProcessorCount;
     out->wavefront_size = prop.warpSize;

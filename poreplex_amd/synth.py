@@ -65,8 +65,23 @@ def _draw_levels(rng, state_idx):
 def synth_batch(n_reads, seed=922, samples_per_read=60000, jitter=0.1, barcodes=None,
                 prototypes='auto', mean_dwell=9.0, sample_noise=1.5, with_polya=True,
                 short_fraction=0.0, scale_sigma=0.05, shift_mu=-5.0, shift_sigma=3.0,
-                fixed_calib=False):
+                fixed_calib=False, adversarial=None, length_dist=None):
     """Generate a ragged batch.
+
+    adversarial (dict, optional; drawn from a SEPARATE generator so every other batch keeps its bits):
+    reads built to sit ON the decisions instead of inside them (tests/test_decision_flips.py,
+    tools/decision_flips_gpu.py) --
+      'blend':  per read and state, with probability 1/2 the state's levels are shifted this fraction of
+                the way to the NEXT state's mean (0.5 = midway between neighbouring states);
+      'drift':  a linear drift of up to +-drift pA over the read;
+      'adapter_gate': with this probability (True = always) a read's adapter piece is made 260 or 3 000
+                pooled samples long +- a few (the gates of BarcodeDemultiplexer.push, barcoding.py:87-88)
+                instead of 4 000 - 9 000 raw samples.
+
+    length_dist='lognormal': read lengths as a sequencing run produces them instead of samples_per_read
+    +- jitter (the reference takes whatever the flow cell wrote, pipeline.py:303-337): 95 % log-normal around
+    a median of 40 000 samples with 15 % of the reads below 30 000 (so the scaler's zero padding and the
+    9 000-sample gate are in play), 5 % from a heavy tail up to 1 000 000 samples; clipped to [6 000, 1 000 000].
 
     Returns dict(arena int16, offsets int64[n+1], calib CALIB_DTYPE[n],
     scale_shift float32[n,2] (the TRUE per-read scaling: pA_model =
@@ -84,6 +99,13 @@ def synth_batch(n_reads, seed=922, samples_per_read=60000, jitter=0.1, barcodes=
     lens = np.maximum(
         (samples_per_read * (1.0 + jitter * rng.uniform(-1, 1, n_reads))).astype(np.int64),
         16)
+    if length_dist == 'lognormal':
+        lrng = np.random.Generator(np.random.PCG64(seed + 104729))
+        body = 40000.0 * np.exp(0.2776 * lrng.standard_normal(n_reads))
+        tail = 40000.0 * np.exp(0.5 + 1.1 * np.abs(lrng.standard_normal(n_reads)))
+        lens = np.clip(np.where(lrng.random(n_reads) < 0.05, tail, body), 6000, 1000000).astype(np.int64)
+    elif length_dist is not None:
+        raise ValueError('unknown length_dist')
     n_short = int(round(short_fraction * n_reads))
     if n_short:
         lens[rng.choice(n_reads, n_short, replace=False)] = rng.integers(2000, 8000, n_short)
@@ -103,8 +125,21 @@ def synth_batch(n_reads, seed=922, samples_per_read=60000, jitter=0.1, barcodes=
         if name == 'adapter':
             cur -= cur % 15
         bounds[:, pi + 1] = cur
+    adv = adversarial or {}
+    arng = np.random.Generator(np.random.PCG64(seed + 7919)) if adv else None
+    if adv.get('adapter_gate'):
+        gate = np.where(arng.random(n_reads) < 0.7, 260, 3000) + arng.integers(-3, 4, n_reads)
+        a_len = gate * 15 + arng.integers(-14, 15, n_reads)
+        p_gate = 1.0 if adv['adapter_gate'] is True else float(adv['adapter_gate'])
+        shift_by = np.where(arng.random(n_reads) < p_gate, (bounds[:, 3] + a_len) - bounds[:, 4], 0)
+        bounds[:, 4:6] += shift_by[:, None]
     bounds[:, 6] = np.maximum(lens, bounds[:, 5])
     bounds = np.minimum(bounds, lens[:, None])
+    if adv.get('blend'):
+        mu = np.array([sum(c[0] * c[2] for c in _EMIT[name]) / sum(c[2] for c in _EMIT[name]) for name in _PIECES])
+        toward = np.append(mu[1:], mu[-1]) - mu                       # to the next state's mean
+        blend_shift = (arng.random((n_reads, 6)) < 0.5) * (float(adv['blend']) * toward)[None, :]
+    drift_total = arng.uniform(-1, 1, n_reads) * float(adv['drift']) if adv.get('drift') else None
 
     scale = rng.normal(0.955, scale_sigma, n_reads).astype(np.float32)
     shift = rng.normal(shift_mu, shift_sigma, n_reads).astype(np.float32)
@@ -117,10 +152,24 @@ def synth_batch(n_reads, seed=922, samples_per_read=60000, jitter=0.1, barcodes=
         calib['range'], calib['offset'] = 1200.0, 10.0
 
     chunk = 512
-    for c0 in range(0, n_reads, chunk):
-        c1 = min(n_reads, c0 + chunk)
+    cuts = list(range(0, n_reads, chunk)) + [n_reads]
+    order = np.arange(n_reads)
+    if length_dist is not None:
+        # reads of similar length together (the event arrays of a chunk are dense, sized by its longest
+        # read), chunks of bounded reads x longest read
+        order = np.argsort(lens, kind='stable')
+        cuts, c0 = [0], 0
+        while c0 < n_reads:
+            c1 = c0
+            while c1 < n_reads and c1 - c0 < chunk and (c1 - c0 + 1) * int(lens[order[c1]]) <= chunk * 80000:
+                c1 += 1
+            c1 = max(c1, c0 + 1)
+            cuts.append(c1)
+            c0 = c1
+    for c0, c1 in zip(cuts[:-1], cuts[1:]):
         B = c1 - c0
-        L = lens[c0:c1]
+        sel = order[c0:c1]
+        L = lens[sel]
         Lmax = int(L.max())
         E = int(Lmax / mean_dwell * 1.25) + 64
         dwell = rng.geometric(1.0 / mean_dwell, size=(B, E)).astype(np.int64)
@@ -130,20 +179,25 @@ def synth_batch(n_reads, seed=922, samples_per_read=60000, jitter=0.1, barcodes=
         dwell[short, -1] += (L - (starts[:, -1] + dwell[:, -1]))[short]
         ends = np.minimum(starts + dwell, L[:, None])
         cnt = np.maximum(ends - np.minimum(starts, L[:, None]), 0)
-        state = (starts[:, :, None] >= bounds[c0:c1, None, 1:6]).sum(axis=2)
+        state = (starts[:, :, None] >= bounds[sel][:, None, 1:6]).sum(axis=2)
         level = _draw_levels(rng, state)
+        if adv.get('blend'):
+            level = level + np.take_along_axis(blend_shift[sel], state, axis=1).astype(np.float32)
         flat = np.repeat(level.ravel(), cnt.ravel())
         flat += rng.standard_normal(flat.shape[0], dtype=np.float32) * np.float32(sample_noise)
         roff = np.zeros(B + 1, dtype=np.int64)
         roff[1:] = np.cumsum(L)
+        if drift_total is not None:
+            pos = np.arange(flat.shape[0], dtype=np.float64) - np.repeat(roff[:-1], L)
+            flat += (np.repeat(drift_total[sel] / np.maximum(L, 1), L) * pos).astype(np.float32)
         # barcode prototype: last 300 pooled samples of the adapter piece
         if prototypes is not None:
             for b in range(B):
-                bc = int(barcodes[c0 + b])
+                bc = int(barcodes[sel[b]])
                 if bc < 0:
                     continue
-                a_end = int(bounds[c0 + b, 4])
-                a_beg = int(bounds[c0 + b, 3])
+                a_end = int(bounds[sel[b], 4])
+                a_beg = int(bounds[sel[b], 3])
                 w0 = a_end - 300 * 15
                 if w0 < a_beg or a_end > L[b]:
                     continue
@@ -153,13 +207,17 @@ def synth_batch(n_reads, seed=922, samples_per_read=60000, jitter=0.1, barcodes=
                     np.float32(sample_noise)
                 flat[roff[b] + w0:roff[b] + a_end] = seg
         # inverse scaling and DAQ quantisation
-        rs = np.repeat(scale[c0:c1], L)
-        rh = np.repeat(shift[c0:c1], L)
+        rs = np.repeat(scale[sel], L)
+        rh = np.repeat(shift[sel], L)
         pa_raw = (flat - rh) / rs
-        k = np.repeat(calib['digitisation'][c0:c1] / calib['range'][c0:c1], L)
-        off = np.repeat(calib['offset'][c0:c1], L)
-        q = np.rint(pa_raw * k - off)
-        arena[offsets[c0]:offsets[c1]] = np.clip(q, -32768, 32767).astype(np.int16)
+        k = np.repeat(calib['digitisation'][sel] / calib['range'][sel], L)
+        off = np.repeat(calib['offset'][sel], L)
+        q = np.clip(np.rint(pa_raw * k - off), -32768, 32767).astype(np.int16)
+        if length_dist is None:
+            arena[offsets[c0]:offsets[c1]] = q
+        else:
+            for b in range(B):
+                arena[offsets[sel[b]]:offsets[sel[b] + 1]] = q[roff[b]:roff[b + 1]]
 
     truth = np.stack([bounds[:, :6], bounds[:, 1:7]], axis=2).astype(np.int32)
     return {

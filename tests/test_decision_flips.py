@@ -175,7 +175,7 @@ def measure(n_reads=2048, samples=40000, seed=924, arith='q8'):
     }
 
 
-def measure_viterbi(n_reads=2048, n_chimeras=512, samples=40000, seed=924, only=None):
+def measure_viterbi(n_reads=2048, n_chimeras=512, samples=40000, seed=924, only=None, adversarial=None):
     """The Viterbi side (rows a6 / a7, and the a19 window scan): the oracle's paths against
     every formula variant of tests/viterbi_variants.py on (a) the pooled + scaled signals of
     `n_reads` bench reads under the segmentation HMM and (b) every scan window of those reads
@@ -191,10 +191,11 @@ def measure_viterbi(n_reads=2048, n_chimeras=512, samples=40000, seed=924, only=
     limit = int(cfg.segmentation_scan_limit) // stride
     adapter = int(cfg.segmentation_model.adapter_state)
 
-    plain = synth_batch(n_reads, seed=seed, samples_per_read=samples, short_fraction=0.01)
+    # adversarial: poreplex_amd.synth.synth_batch's generator of reads that sit ON the decisions
+    plain = synth_batch(n_reads, seed=seed, samples_per_read=samples, short_fraction=0.01, adversarial=adversarial)
     # chimeras: two synthetic reads back to back, one DAQ setting (tools/make_golden.py:640-653)
     cb = synth_batch(2 * n_chimeras, seed=seed + 7, samples_per_read=26000, jitter=0.2, fixed_calib=True,
-                     scale_sigma=0.0, shift_sigma=0.0)
+                     scale_sigma=0.0, shift_sigma=0.0, adversarial=adversarial)
     co = cb['offsets']
     chim = [np.concatenate([cb['arena'][co[2 * k]:co[2 * k + 1]], cb['arena'][co[2 * k + 1]:co[2 * k + 2]]])
             for k in range(n_chimeras)]
@@ -325,6 +326,9 @@ def test_viterbi_formula_variants_move_no_decision():
 if __name__ == '__main__':
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+    ADV = {'blend': 0.5, 'drift': 4.0, 'adapter_gate': 0.5}
     out = {'lstm_side': {a: measure(n, arith=a) for a in ('q8', 'f32')},
-           'viterbi_side': measure_viterbi(n, max(n // 4, 8))}
+           'viterbi_side': measure_viterbi(n, max(n // 4, 8)),
+           'viterbi_side_adversarial': dict(measure_viterbi(n, max(n // 4, 8), samples=60000, seed=500924, adversarial=ADV),
+                                            generator=ADV)}
     print(json.dumps(out, indent=1))
