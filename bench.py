@@ -631,6 +631,8 @@ def strong_leg(args, ctx, dist, rank, world, mask, standin, force_dist, barrier)
 FLIPS_FILE = os.path.join('profiles', 'r04', 'decision_flips.json')
 FLIPS_GPU_FILE = os.path.join('profiles', 'r04', 'decision_flips_gpu.json')
 BOUNDS_FILE = os.path.join('profiles', 'r04', 'full_kernel_bounds.json')
+ROCPROF_STATS = {'demux': os.path.join('profiles', 'r04', 'b_demux_kernel_stats.csv'),
+                 'full': os.path.join('profiles', 'r04', 'b_full_kernel_stats.csv')}
 
 
 def unpinned_rows_block():
@@ -1017,6 +1019,21 @@ def main():
                     'peak': PEAK_HBM / 1e9, 'unit': 'GB/s', 'frac': nbytes / dur / PEAK_HBM if dur else None,
                     'traffic': None, 'algorithmic_bytes_per_read': nbytes / n_local,
                     'kernel_ms': stage_ms['segment']}
+    # the same fraction from the committed rocprofv3 --kernel-trace --stats pass of this command (average over
+    # its launches, cold ones included): static, from profiles/; the live figure above is the HIP-event mean
+    if n_local == 10000 and args.samples == 60000 and args.seed == 924 and not n_base and args.length_dist is None:
+        try:
+            import csv
+            with open(os.path.join(ROOT, ROCPROF_STATS[args.workload if args.workload == 'full' else 'demux'])) as fh:
+                row = next(r for r in csv.DictReader(fh) if roofline['kernel'] + '(' in r['Name'] or r['Name'].startswith(roofline['kernel']))
+            avg_ms = float(row['AverageNs']) / 1e6
+            roofline['rocprof_avg_ms'] = avg_ms
+            roofline['rocprof_launches'] = int(row['Calls'])
+            if roofline.get('frac') and roofline.get('kernel_ms'):
+                roofline['frac_at_rocprof_avg'] = roofline['frac'] * roofline['kernel_ms'] / avg_ms
+            roofline['rocprof_source'] = 'static: ' + ROCPROF_STATS[args.workload if args.workload == 'full' else 'demux']
+        except (OSError, KeyError, StopIteration, ValueError):
+            pass
     # HBM bytes per launch of that kernel: NOT measured by this run (PMC counters need
     # rocprofv3); a static figure from the committed PMC passes of this exact default workload
     if n_local == 10000 and args.samples == 60000 and args.seed == 924 and not n_base:

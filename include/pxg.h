@@ -39,6 +39,8 @@ extern "C" {
 /* per-read error code pxg_batch_unsplit_scan stores in out_count (data problems are
  * per-read results, never call failures -- signal_analyzer.py:118-122) */
 #define PXG_UNSPLIT_E_GEOMETRY     (-3) /* negative first_sample / n_blocks                  */
+#define PXG_UNSPLIT_E_WINDOW       (-4) /* a scan window outgrew the slots the host sized for it (a bound of
+                                           the library proved wrong): the read fails loudly, no candidate is dropped */
 
 /* ---- error codes (function return values) -------------------------------- */
 enum pxg_error {

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lim = count ? min(*count, n_rows) : n_rows;
     const int n_tiles = (lim + 15) >> 4;
-    const int QBS = scaler_block_steps(n_tiles, (int)gridDim.x, T + 1);
+    const int QBS = queue[1] > 0 ? ((min(queue[1], T + 1) + 3) & ~3) : scaler_block_steps(n_tiles, (int)gridDim.x, T + 1);
     const int n_blocks = (T + 1 + QBS - 1) / QBS;
     const int n_tasks = n_tiles * n_blocks;
 
@@ -816,6 +816,11 @@ int pxg_launch_scaler_lstm_q8(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, 
         (rc = pxg_reserve(ctx, ctx->lstm_state, (size_t)2 * tiles * Q8S_STATE)))
         return rc;
     PXG_HIP(ctx, hipMemsetAsync(ctx->lstm_q.p, 0, (size_t)(2 + tiles) * sizeof(int), ctx->stream));
+    if (const char* forced = getenv("PXG_SCALER_BLOCK_STEPS")) {      // tuning knob: steps per task of K2
+        static int qbs;
+        qbs = atoi(forced);
+        PXG_HIP(ctx, hipMemcpyAsync(ctx->lstm_q.p + 1, &qbs, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    }
     const size_t lds = sizeof(float) * 4 * PXG_SIG_NSEG + 4 * Q8_HVEC + sizeof(float) * 16 * XS + 16 * 3 * 48 +
                        16 * 9 * LSTM_THREADS + sizeof(int) * 32;
     PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_scaler_lstm_q8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -536,7 +536,10 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
         }
         if (phase == 1) finalize(a_first);
         else if (phase == 2) finalize(lead);
-        if (s == 0 && owned) cand_cnt[u] = too_long ? 0 : (count < wcand ? count : wcand);
+        // a window that could not be scanned, or that found more candidates than its slots hold, must not
+        // pass for a clean one: both are impossible by the host-side sizing (pxg_unsplit_cand_slots, tmax) --
+        // if that bound is ever wrong the read gets its own error code instead of silently losing candidates
+        if (s == 0 && owned) cand_cnt[u] = (too_long || count > wcand) ? -1 : count;
     }
 }
 
@@ -547,8 +550,12 @@ __global__ void k_unsplit_count(int64_t n_reads, const int64_t* __restrict__ uni
     const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     int total = 0;
-    for (int64_t u = unit_off[r]; u < unit_off[r + 1]; u++) total += cand_cnt[u];
-    out_cnt[r] = total;
+    bool failed = false;
+    for (int64_t u = unit_off[r]; u < unit_off[r + 1]; u++) {
+        failed |= cand_cnt[u] < 0;             // a window that overflowed its slots / its back-pointer rows
+        total += cand_cnt[u] > 0 ? cand_cnt[u] : 0;
+    }
+    out_cnt[r] = failed ? PXG_UNSPLIT_E_WINDOW : total;
 }
 
 // gather, pass 2: the candidates of a read's windows in window order (the order the

@@ -73,7 +73,10 @@ struct Dataset {
     uint64_t n_elements() const
     {
         uint64_t n = 1;
-        for (uint64_t d : dims) n *= d;
+        for (uint64_t d : dims) {
+            if (d && n > (~0ull) / d) return ~0ull;          // overflow: no size check downstream lets this pass
+            n *= d;
+        }
         return n;
     }
 };
@@ -321,10 +324,13 @@ struct pxg_h5 {
             std::vector<uint64_t> dims;
             parse_dataspace(q + a, sl_, dims);
             a += pad(sl_);
-            at_.n = 1;
-            for (uint64_t d : dims) at_.n *= d;
             at_.data = q + a;
             at_.len = size - a;
+            at_.n = 1;
+            for (uint64_t d : dims) {        // (the product is checked while it is formed: it cannot wrap past the test below)
+                if (d && at_.n > at_.len / d + 1) fail(PXG_E_INVALID, "HDF5: attribute dimensions exceed its message");
+                at_.n *= d;
+            }
             if ((uint64_t)at_.type.size * at_.n > at_.len) fail(PXG_E_INVALID, "HDF5: attribute data runs off its message");
             o.attrs[name] = at_;
             break;
@@ -422,9 +428,19 @@ struct pxg_h5 {
     }
 
     // ---- groups -------------------------------------------------------------------------------
-    void group_btree(uint64_t node, const uint8_t* heap_data, uint64_t heap_size, int depth,
-                     std::vector<std::pair<std::string, uint64_t>>& out) const
+    // every B-tree walk spends from a node budget: a file of n bytes holds at most n / 24 nodes, and a node
+    // that names itself (or an ancestor) as its child would otherwise cost fan-out ^ depth visits
+    void spend_node(uint64_t& budget) const
     {
+        if (budget == 0) fail(PXG_E_INVALID, "HDF5: B-tree visits more nodes than the file can hold (cyclic?)");
+        budget--;
+    }
+    void group_btree(uint64_t node, const uint8_t* heap_data, uint64_t heap_size, int depth,
+                     std::vector<std::pair<std::string, uint64_t>>& out, uint64_t* budget_or_null = nullptr) const
+    {
+        uint64_t local = (uint64_t)n / 24 + 16;
+        uint64_t& budget = budget_or_null ? *budget_or_null : local;
+        spend_node(budget);
         if (depth > 32) fail(PXG_E_INVALID, "HDF5: group B-tree too deep");
         const uint8_t* t = at(node, 8 + 2 * so);
         if (memcmp(t, "TREE", 4) == 0) {
@@ -432,7 +448,7 @@ struct pxg_h5 {
             const int used = (int)rd(t + 6, 2);
             const uint8_t* e = at(node + 8 + 2 * so, (uint64_t)used * (sl + so) + sl);
             for (int k = 0; k < used; k++)
-                group_btree(off_at(e + sl + (size_t)k * (sl + so)), heap_data, heap_size, depth + 1, out);
+                group_btree(off_at(e + sl + (size_t)k * (sl + so)), heap_data, heap_size, depth + 1, out, &budget);
             return;
         }
         if (memcmp(t, "SNOD", 4)) fail(PXG_E_INVALID, "HDF5: bad group node signature");
@@ -505,7 +521,9 @@ struct pxg_h5 {
             const uint32_t idx = (uint32_t)rd(g + pos, 2);
             const uint64_t osz = len_at(g + pos + 8);
             if (idx == 0) break;
-            if (pos + 8 + sl + osz > csize) fail(PXG_E_INVALID, "HDF5: global heap object runs off its collection");
+            // (osz comes from the file: compared against what is LEFT, so that a value near 2^64 can neither
+            //  wrap the bound check nor make the step below add 0 and the loop spin)
+            if (osz > csize - pos - 8 - sl) fail(PXG_E_INVALID, "HDF5: global heap object runs off its collection");
             if (idx == index) {
                 const char* s = (const char*)g + pos + 8 + sl;
                 return std::string(s, strnlen(s, std::min(len, osz)));
@@ -644,8 +662,12 @@ struct pxg_h5 {
         memcpy(out, src().p, want);
     }
 
-    void chunk_btree(const Dataset& d, uint64_t node, int depth, uint8_t* out, uint64_t total_el) const
+    void chunk_btree(const Dataset& d, uint64_t node, int depth, uint8_t* out, uint64_t total_el,
+                     uint64_t* budget_or_null = nullptr) const
     {
+        uint64_t local = (uint64_t)n / 24 + 16;
+        uint64_t& budget = budget_or_null ? *budget_or_null : local;
+        spend_node(budget);
         if (depth > 32) fail(PXG_E_INVALID, "HDF5: chunk B-tree too deep");
         const int nd = (int)d.chunk.size() + 1;
         const uint8_t* t = at(node, 8 + 2 * so);
@@ -657,7 +679,7 @@ struct pxg_h5 {
         for (int k = 0; k < used; k++) {
             const uint8_t* key = e + (size_t)k * (ksz + so);
             const uint64_t child_ = off_at(key + ksz);
-            if (level > 0) { chunk_btree(d, child_, depth + 1, out, total_el); continue; }
+            if (level > 0) { chunk_btree(d, child_, depth + 1, out, total_el, &budget); continue; }
             const uint32_t csize = (uint32_t)rd(key, 4), mask = (uint32_t)rd(key + 4, 4);
             const uint64_t first = rd(key + 8, 8);
             if (first >= total_el) continue;
@@ -677,7 +699,7 @@ struct pxg_h5 {
     void sane_bytes(uint64_t n_el, uint64_t esz) const
     {
         const uint64_t cap = (uint64_t)n * 1100 + 65536;
-        if (esz == 0 || n_el > cap || n_el * esz > cap)
+        if (esz == 0 || n_el > cap || esz > cap || n_el * esz > cap)
             fail(PXG_E_INVALID, "HDF5: a dataset claims more bytes than this file could hold (corrupt dimensions)");
     }
 

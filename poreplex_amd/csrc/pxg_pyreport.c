@@ -149,7 +149,17 @@ static PyObject* report(PyObject* self, PyObject* args)
         goto done;
     {
         const Py_ssize_t n_rows = rows.view.len / 8;
-        const Py_ssize_t n_table = status.view.len;             /* int8 column: one byte per row */
+        /* rows of the table = the SHORTEST per-row column: every one of them is indexed with the row number */
+        Py_ssize_t n_table = status.view.len;                   /* int8 column: one byte per row */
+        {
+            Buf* per_row[] = { &start_time, &rate, &duration, &n_events, &seq_len, &qscore, &has_summary, &label, &has_bc,
+                               &barcode, &guess, &phred, &seq_lazy, &bundle_index, &polya_lazy, &pa_begin, &pa_end,
+                               &pa_dwell, &pa_nspk, &gpu_row };
+            for (size_t c = 0; c < sizeof(per_row) / sizeof(per_row[0]); c++) {
+                const Py_ssize_t rows_c = per_row[c]->view.len / (per_row[c]->view.itemsize > 0 ? per_row[c]->view.itemsize : 1);
+                if (rows_c < n_table) n_table = rows_c;
+            }
+        }
         const int64_t* R = (const int64_t*)rows.view.buf;
         const int8_t* st = (const int8_t*)status.view.buf;
         const Py_ssize_t n_seq_off = seq_off.held ? seq_off.view.len / 8 : 0;
@@ -270,11 +280,14 @@ static PyObject* report(PyObject* self, PyObject* args)
                 Py_XDECREF(lst);
                 if (bad) { Py_DECREF(p); goto fail_row; }
                 SET(d, KEYS[K_POLYA], p);
-                /* no cycle can run through these (dict -> dict -> list -> tuples of floats).  A dict
-                 * tracks itself again the moment somebody stores a container in it; the spike list stays
-                 * tracked, so the collector still sees everything a caller could later tie into a cycle. */
-                PyObject_GC_UnTrack(p);
-                PyObject_GC_UnTrack(d);
+                /* dict -> dict -> (empty) list: nothing a cycle can run through as built, and a dict tracks
+                 * itself again the moment somebody stores a container in it.  Dicts that hold a NON-empty
+                 * spike list stay tracked: the list is, and a caller who ties it into a cycle must still be
+                 * able to have that cycle collected. */
+                if (ns == 0) {
+                    PyObject_GC_UnTrack(p);
+                    PyObject_GC_UnTrack(d);
+                }
             }
             PyList_SET_ITEM(out, k, d);
             continue;

@@ -24,6 +24,7 @@ PXG_N_SEGMENTS = 8
 PXG_MAX_CLASSES = 8
 PXG_MAX_CALIBRATION = 64
 UNSPLIT_E_GEOMETRY = -3
+UNSPLIT_E_WINDOW = -4
 
 STATUS_NAMES = (
     'okay', 'disappeared', 'irregular_fast5', 'scaler_signal_too_short',
