@@ -1241,10 +1241,10 @@ static int pxg_timeslice_prepare(pxg_ctx* ctx)
 }
 
 int pxg_launch_scaler_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
-                           const int32_t* count, const float* head, float* pred)
+                           const int32_t* count, const float* head, float* pred, const int64_t* off)
 {
     if (n_rows <= 0) return PXG_OK;
-    if (ctx->cfg.lstm_arith == PXG_LSTM_Q8) return pxg_launch_scaler_lstm_q8(ctx, n_rows, idx, count, head, pred);
+    if (ctx->cfg.lstm_arith == PXG_LSTM_Q8) return pxg_launch_scaler_lstm_q8(ctx, n_rows, idx, count, head, pred, off);
     const int T = ctx->cfg.scaler_length / ctx->cfg.stride;
     const LstmGrid g = pick_grid(ctx, n_rows);
     const PxgLstmDev &l1 = ctx->scaler1, &l2 = ctx->scaler2;

@@ -139,6 +139,7 @@ __device__ __forceinline__ float q8_read_h(const unsigned char* hvec, int rd, in
 // than slots every tile is one task).  Fragments: [matrix 0 U1 | 1 W2 | 2 U2][nt][digit][thread].
 // ===========================================================================
 #define Q8S_STATE (2 * Q8_HVEC / 4 + 2 * LSTM_THREADS * 3)      // dwords per saved tile state
+#define Q8S_TRAJ 4          // the zero-input trajectory is kept every 4 steps (step blocks are multiples of 4)
 
 __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
     int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int T,
@@ -146,7 +147,10 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
     const float* __restrict__ W1 /* scalar-input kernel, table units */, const float* __restrict__ b1,
     const float* __restrict__ b2, float s1, float s2 /* 16 * 2^(-p-14) of layer 1 / 2 */,
     const float* __restrict__ Wd, const float* __restrict__ bd, float* __restrict__ pred,
-    int* __restrict__ queue, int* __restrict__ errflag, int* __restrict__ done, unsigned* __restrict__ state)
+    int* __restrict__ queue, int* __restrict__ errflag, int* __restrict__ done, unsigned* __restrict__ state,
+    const int64_t* __restrict__ off /* sample offsets of the reads, or null: no read is known to be padded */,
+    int head_limit, int stride, const unsigned* __restrict__ traj /* zero-input states every Q8S_TRAJ steps, or null */,
+    unsigned* __restrict__ traj_out /* not null: this launch records that table */)
 {
     constexpr int H = 48, NT = 3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -203,16 +207,37 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
         const int row_base = tile * 16;
         if (tid < 16) {
             const int row = row_base + tid;
-            ridx[tid] = row < lim ? (idx ? idx[row] : row) : -1;
+            const int rd = row < lim ? (idx ? idx[row] : row) : -1;
+            ridx[tid] = rd;
+            // The head is LEFT-padded with zeros (signal_loader.py:227-229; K1): until its first sample a read
+            // is the zero-input network started from zero, the same for every read.  A tile whose 16 reads
+            // all start at or after step b0 * QBS takes that state from the table and skips blocks < b0.
+            int pad = T + 1;
+            if (rd >= 0) {
+                pad = 0;
+                if (off && traj) {
+                    const int64_t len = off[rd + 1] - off[rd];
+                    pad = T - (int)((len < head_limit ? len : head_limit) / stride);
+                }
+            }
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) pad = min(pad, __shfl_xor(pad, d));
+            if (tid == 0) s_task[1] = min(max(pad, 0) / QBS, n_blocks - 1);
         }
+        __syncthreads();
+        const int b0 = s_task[1];
+        if (blk < b0) continue;            // nothing to do and nobody waits for it
         float c1[NT], c2[NT];
-        unsigned* st_in = state + ((size_t)((blk - 1) & 1) * n_tiles + tile) * Q8S_STATE;
+        // (a recording launch hands over THROUGH the table: one tile, its blocks in order)
+        const unsigned* st_in = traj_out ? traj_out + (size_t)(t0 / Q8S_TRAJ) * Q8S_STATE
+                                : blk == b0 ? traj + (size_t)(t0 / Q8S_TRAJ) * Q8S_STATE
+                                            : state + ((size_t)((blk - 1) & 1) * n_tiles + tile) * Q8S_STATE;
         if (blk == 0) {
             for (int i = tid; i < 4 * Q8_HVEC / 4; i += LSTM_THREADS) reinterpret_cast<unsigned*>(hv)[i] = 0u;
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) c1[nt] = c2[nt] = 0.0f;
         } else {
-            dq_wait(done, tile, blk, errflag, tid);
+            if (blk != b0) dq_wait(done, tile, blk, errflag, tid);
             const int rb = t0 & 1;         // (the other buffer is written completely by step t0)
             for (int i = tid; i < 2 * Q8_HVEC / 4; i += LSTM_THREADS)
                 reinterpret_cast<unsigned*>(hv + rb * 2 * Q8_HVEC)[i] = st_in[i];
@@ -306,7 +331,8 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
             }
         } else {
             // ---- hand the tile over: state of iteration t1 -> HBM, then publish -------------
-            unsigned* st_out = state + ((size_t)(blk & 1) * n_tiles + tile) * Q8S_STATE;
+            unsigned* st_out = traj_out ? traj_out + (size_t)(t1 / Q8S_TRAJ) * Q8S_STATE
+                                        : state + ((size_t)(blk & 1) * n_tiles + tile) * Q8S_STATE;
             const int rb = t1 & 1;
             for (int i = tid; i < 2 * Q8_HVEC / 4; i += LSTM_THREADS)
                 st_out[i] = reinterpret_cast<const unsigned*>(hv + rb * 2 * Q8_HVEC)[i];
@@ -798,10 +824,44 @@ void pxg_q8_free(pxg_ctx* ctx)
     if (ctx->q8.bidir_frag) (void)hipFree(ctx->q8.bidir_frag);
     if (ctx->q8.top_frag) (void)hipFree(ctx->q8.top_frag);
     ctx->q8.scaler_frag = ctx->q8.bidir_frag = ctx->q8.top_frag = nullptr;
+    if (ctx->scaler_traj.p) (void)hipFree(ctx->scaler_traj.p);
+    ctx->scaler_traj.p = nullptr;
+    ctx->scaler_traj.cap = 0;
+}
+
+static int q8_scaler_launch(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, const int32_t* count, const float* head,
+                            float* pred, const int64_t* off, unsigned* traj_out);
+
+// The zero-input trajectory of the scaler network, recorded by the kernel itself: one tile of 16 all-zero heads in
+// step blocks of Q8S_TRAJ, every hand-over written to the table instead of the ring.  (T / Q8S_TRAJ + 1 entries of
+// 12 KB: 6 MB for the shipped 2 000 steps; ~500 tasks on one workgroup, once per context.)
+int pxg_q8_scaler_trajectory(pxg_ctx* ctx)
+{
+    if (!ctx->prefix_skip || ctx->scaler_traj.p) return PXG_OK;
+    const int T = ctx->cfg.scaler_length / ctx->cfg.stride;
+    if (T % 4) return PXG_OK;          // (the x tile is loaded as float4: the kernel's own requirement)
+    DevBuf<float> zero_head, scratch_pred;
+    int rc;
+    if ((rc = pxg_reserve(ctx, zero_head, (size_t)16 * T)) || (rc = pxg_reserve(ctx, scratch_pred, 32)) ||
+        (rc = pxg_reserve(ctx, ctx->scaler_traj, (size_t)(T / Q8S_TRAJ + 1) * Q8S_STATE)))
+        return rc;
+    PXG_HIP(ctx, hipMemsetAsync(zero_head.p, 0, (size_t)16 * T * sizeof(float), ctx->stream));
+    PXG_HIP(ctx, hipMemsetAsync(ctx->scaler_traj.p, 0, (size_t)(T / Q8S_TRAJ + 1) * Q8S_STATE * sizeof(unsigned), ctx->stream));
+    rc = q8_scaler_launch(ctx, 16, nullptr, nullptr, zero_head.p, scratch_pred.p, nullptr, ctx->scaler_traj.p);
+    if (rc == PXG_OK) PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(zero_head.p);
+    (void)hipFree(scratch_pred.p);
+    return rc;
 }
 
 int pxg_launch_scaler_lstm_q8(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, const int32_t* count,
-                              const float* head, float* pred)
+                              const float* head, float* pred, const int64_t* off)
+{
+    return q8_scaler_launch(ctx, n_rows, idx, count, head, pred, off, nullptr);
+}
+
+static int q8_scaler_launch(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, const int32_t* count, const float* head,
+                            float* pred, const int64_t* off, unsigned* traj_out)
 {
     if (n_rows <= 0) return PXG_OK;
     const int T = ctx->cfg.scaler_length / ctx->cfg.stride;
@@ -816,11 +876,13 @@ int pxg_launch_scaler_lstm_q8(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, 
         (rc = pxg_reserve(ctx, ctx->lstm_state, (size_t)2 * tiles * Q8S_STATE)))
         return rc;
     PXG_HIP(ctx, hipMemsetAsync(ctx->lstm_q.p, 0, (size_t)(2 + tiles) * sizeof(int), ctx->stream));
-    if (const char* forced = getenv("PXG_SCALER_BLOCK_STEPS")) {      // tuning knob: steps per task of K2
-        static int qbs;
-        qbs = atoi(forced);
+    static int qbs;
+    const char* forced = getenv("PXG_SCALER_BLOCK_STEPS");           // tuning knob: steps per task of K2
+    if (traj_out || forced) {
+        qbs = traj_out ? Q8S_TRAJ : atoi(forced);
         PXG_HIP(ctx, hipMemcpyAsync(ctx->lstm_q.p + 1, &qbs, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     }
+    const unsigned* traj = (!traj_out && off && ctx->prefix_skip) ? reinterpret_cast<const unsigned*>(ctx->scaler_traj.p) : nullptr;
     const size_t lds = sizeof(float) * 4 * PXG_SIG_NSEG + 4 * Q8_HVEC + sizeof(float) * 16 * XS + 16 * 3 * 48 +
                        16 * 9 * LSTM_THREADS + sizeof(int) * 32;
     PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_scaler_lstm_q8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -829,7 +891,7 @@ int pxg_launch_scaler_lstm_q8(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, 
                        count, T, head, ctx->d_sigtab, reinterpret_cast<const v4i*>(ctx->q8.scaler_frag), l1.kernel,
                        l1.bias, l2.bias, ctx->q8.s_scaler1, ctx->q8.s_scaler2, ctx->scaler_dense.kernel,
                        ctx->scaler_dense.bias, pred, ctx->lstm_q.p, ctx->lstm_err.p, ctx->lstm_q.p + 2,
-                       reinterpret_cast<unsigned*>(ctx->lstm_state.p));
+                       reinterpret_cast<unsigned*>(ctx->lstm_state.p), off, ctx->cfg.scaler_length, ctx->cfg.stride, traj, traj_out);
     ctx->timeslice_used = true;
     PXG_HIP(ctx, hipGetLastError());
     return PXG_OK;

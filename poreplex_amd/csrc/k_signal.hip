@@ -314,11 +314,14 @@ int pxg_launch_scaler_transform(pxg_ctx* ctx, int64_t n, const float* pred, floa
 // ---------------------------------------------------------------------------
 // compaction of reads that go on to the scaler network
 // ---------------------------------------------------------------------------
-__global__ void k_compact_ok(int64_t n, const int32_t* __restrict__ status,
+// `ord` (or null): the reads in length order -- a wave keeps 64 neighbours of that order together,
+// so the 16-row tiles of K2 hold reads of one length class (and one zero-pad class)
+__global__ void k_compact_ok(int64_t n, const int32_t* __restrict__ status, const int32_t* __restrict__ ord,
                              int32_t* __restrict__ idx, int32_t* __restrict__ counter)
 {
-    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    const bool keep = r < n && status[r] == PXG_ST_OKAY;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t r = i < n ? (ord ? ord[i] : i) : 0;
+    const bool keep = i < n && status[r] == PXG_ST_OKAY;
     const unsigned long long m = __ballot(keep);
     const int lane = threadIdx.x & 63;
     int base = 0;
@@ -327,12 +330,86 @@ __global__ void k_compact_ok(int64_t n, const int32_t* __restrict__ status,
     if (keep) idx[base + __popcll(m & ((1ull << lane) - 1))] = (int32_t)r;
 }
 
-int pxg_launch_compact_scaler(pxg_ctx* ctx, int64_t n, const int32_t* status, int32_t* idx,
+int pxg_launch_compact_scaler(pxg_ctx* ctx, int64_t n, const int32_t* status, const int32_t* order, int32_t* idx,
                               int32_t* counter)
 {
     if (n <= 0) return PXG_OK;
     hipLaunchKernelGGL(k_compact_ok, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
-                       n, status, idx, counter);
+                       n, status, order, idx, counter);
+    return PXG_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Reads in length order, longest first (a counting sort over 1 024-sample length classes; inside a
+// class the order is whatever the atomics make it -- no result depends on it: every read's outputs
+// are functions of that read alone).  A sequencing run's lengths spread over two decades
+// (signal_analyzer.py:347-349 scans at most segmentation_scan_limit samples of each): blocks of K3
+// then hold eight reads of one class instead of waiting for their longest, and K2's tiles share
+// their zero-pad prefix (signal_loader.py:227-229).
+// ---------------------------------------------------------------------------
+#define ORD_CLASSES 1024
+__device__ __forceinline__ int order_class(int64_t len)
+{
+    const int64_t c = len >> 10;
+    return ORD_CLASSES - 1 - (int)(c < ORD_CLASSES - 1 ? c : ORD_CLASSES - 1);
+}
+
+__global__ __launch_bounds__(1024) void k_order_count(int64_t n, const int64_t* __restrict__ off, int32_t* __restrict__ hist)
+{
+    __shared__ int h[ORD_CLASSES];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r < n) atomicAdd(&h[order_class(off[r + 1] - off[r])], 1);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// counts -> first slot of every class (one workgroup; a Hillis-Steele scan over 1 024 ints)
+__global__ __launch_bounds__(1024) void k_order_starts(int32_t* __restrict__ hist)
+{
+    __shared__ int a[2][ORD_CLASSES];
+    const int t = threadIdx.x;
+    const int own = hist[t];
+    a[0][t] = own;
+    __syncthreads();
+    int cur = 0;
+    for (int d = 1; d < ORD_CLASSES; d <<= 1) {
+        a[cur ^ 1][t] = a[cur][t] + (t >= d ? a[cur][t - d] : 0);
+        cur ^= 1;
+        __syncthreads();
+    }
+    hist[t] = a[cur][t] - own;
+}
+
+__global__ __launch_bounds__(1024) void k_order_place(int64_t n, const int64_t* __restrict__ off, int32_t* __restrict__ cursor,
+                                                       int32_t* __restrict__ order)
+{
+    __shared__ int h[ORD_CLASSES], base[ORD_CLASSES];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int cls = 0, rank = 0;
+    if (r < n) {
+        cls = order_class(off[r + 1] - off[r]);
+        rank = atomicAdd(&h[cls], 1);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (r < n) order[base[cls] + rank] = (int32_t)r;
+}
+
+int pxg_launch_length_order(pxg_ctx* ctx, int64_t n, const int64_t* off, int32_t* order)
+{
+    if (n <= 0) return PXG_OK;
+    int rc = pxg_reserve(ctx, ctx->order_hist, ORD_CLASSES);
+    if (rc) return rc;
+    PXG_HIP(ctx, hipMemsetAsync(ctx->order_hist.p, 0, ORD_CLASSES * sizeof(int32_t), ctx->stream));
+    const unsigned blocks = (unsigned)((n + 1023) / 1024);
+    hipLaunchKernelGGL(k_order_count, dim3(blocks), dim3(1024), 0, ctx->stream, n, off, ctx->order_hist.p);
+    hipLaunchKernelGGL(k_order_starts, dim3(1), dim3(1024), 0, ctx->stream, ctx->order_hist.p);
+    hipLaunchKernelGGL(k_order_place, dim3(blocks), dim3(1024), 0, ctx->stream, n, off, ctx->order_hist.p, order);
     return PXG_OK;
 }
 

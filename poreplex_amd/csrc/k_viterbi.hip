@@ -178,7 +178,8 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
     const int64_t* __restrict__ off, const pxg_calib* __restrict__ cal,
     const float* __restrict__ ss, int stride, int scan_pooled, int head_width, int head_limit,
     int32_t* __restrict__ status, BT* __restrict__ bp /* [block][chunk][64 lanes] */, int bp_chunks,
-    int32_t* __restrict__ segs, double* __restrict__ logp_out, const double* __restrict__ lsetab_g)
+    int32_t* __restrict__ segs, double* __restrict__ logp_out, const double* __restrict__ lsetab_g,
+    const int32_t* __restrict__ ord /* reads in the order blocks take them (longest first), or null */)
 {
     constexpr int FB = BpFields<BT>::bits;
     static_assert((SPANS >> (1 << FB)) == 0, "span does not fit the back-pointer field");
@@ -192,7 +193,8 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
     const int rr = lane >> 3, s = lane & 7;
     const int S = H.n_states;
 
-    const int64_t r = blockIdx.x * (int64_t)VIT_READS + rr;
+    const int64_t slot = blockIdx.x * (int64_t)VIT_READS + rr;
+    const int64_t r = slot < n_reads ? (ord ? ord[slot] : slot) : n_reads;
     const bool valid_read = r < n_reads && (status == nullptr || status[r] == PXG_ST_OKAY);
     int T = 0;
     if (valid_read) {
@@ -215,7 +217,8 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
         // consecutive lanes pool consecutive 15-sample blocks (coalesced)
         const int item = (wv - 1) * 64 + lane;
         const int prr = item / VIT_CHUNK, ptt = item % VIT_CHUNK;
-        const int64_t pr = blockIdx.x * (int64_t)VIT_READS + prr;
+        const int64_t pslot = blockIdx.x * (int64_t)VIT_READS + prr;
+        const int64_t pr = pslot < n_reads ? (ord ? ord[pslot] : pslot) : n_reads;
         const bool pvalid = pr < n_reads && (status == nullptr || status[pr] == PXG_ST_OKAY);
         int pT = 0;
         int64_t base = 0;
@@ -453,8 +456,9 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
     //  this kernel: __syncthreads() has waited for the stores, no line of them is in the L1)
     __syncthreads();
     for (int q = wv; q < VIT_READS; q += VIT_THREADS / 64) {
-        const int64_t rq = blockIdx.x * (int64_t)VIT_READS + q;
-        if (rq >= n_reads) break;
+        const int64_t qslot = blockIdx.x * (int64_t)VIT_READS + q;
+        if (qslot >= n_reads) break;
+        const int64_t rq = ord ? ord[qslot] : qslot;
         viterbi_trace<BT>(H, bp + (size_t)blockIdx.x * bp_chunks * 64 + q * 8, steps_of[q], end_of[q], lane,
                           segs + rq * 2 * PXG_N_SEGMENTS, status ? status + rq : nullptr);
     }
@@ -475,7 +479,7 @@ static int check_supported(pxg_ctx* ctx, int which)
 template <bool RAW>
 static int launch_viterbi(pxg_ctx* ctx, const PxgHmmDev& H, int64_t n, const int16_t* raw, const float* sig,
                           const int64_t* off, const pxg_calib* cal, const float* ss, int stride, int scan,
-                          int max_steps, int32_t* status, int32_t* segs, double* logp)
+                          int max_steps, int32_t* status, int32_t* segs, double* logp, const int32_t* ord = nullptr)
 {
     const int head_width = ctx->cfg.scaler_length / ctx->cfg.stride, head_limit = ctx->cfg.scaler_length;
     const int64_t blocks = (n + VIT_READS - 1) / VIT_READS;
@@ -489,35 +493,35 @@ static int launch_viterbi(pxg_ctx* ctx, const PxgHmmDev& H, int64_t n, const int
         if (RAW && stride == 15)
             hipLaunchKernelGGL((k_viterbi_ltr<RAW, RAW ? 15 : GEN, 0x6u, uint32_t>), dim3((unsigned)blocks),
                                dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, head_width, head_limit, status,
-                               bp, bp_chunks, segs, logp, ctx->d_lsetab);
+                               bp, bp_chunks, segs, logp, ctx->d_lsetab, ord);
         else
             hipLaunchKernelGGL((k_viterbi_ltr<RAW, GEN, 0x6u, uint32_t>), dim3((unsigned)blocks),
                                dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, head_width, head_limit, status,
-                               bp, bp_chunks, segs, logp, ctx->d_lsetab);
+                               bp, bp_chunks, segs, logp, ctx->d_lsetab, ord);
     } else {
         uint64_t* bp = (uint64_t*)ctx->vit_bp.p;
         if (RAW && stride == 15)
             hipLaunchKernelGGL((k_viterbi_ltr<RAW, RAW ? 15 : GEN, 0xFEu, uint64_t>), dim3((unsigned)blocks),
                                dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, head_width, head_limit, status,
-                               bp, bp_chunks, segs, logp, ctx->d_lsetab);
+                               bp, bp_chunks, segs, logp, ctx->d_lsetab, ord);
         else
             hipLaunchKernelGGL((k_viterbi_ltr<RAW, GEN, 0xFEu, uint64_t>), dim3((unsigned)blocks),
                                dim3(VIT_THREADS), 0, ctx->stream, n, H, raw, sig, off, cal, ss, stride, scan, head_width, head_limit, status,
-                               bp, bp_chunks, segs, logp, ctx->d_lsetab);
+                               bp, bp_chunks, segs, logp, ctx->d_lsetab, ord);
     }
     return PXG_OK;
 }
 
 int pxg_launch_segment_raw(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
                            const pxg_calib* cal, const float* ss, const float* head_or_null,
-                           const int32_t* status, int32_t* segs)
+                           const int32_t* status, int32_t* segs, const int32_t* order)
 {
     if (n <= 0) return PXG_OK;
     int rc = check_supported(ctx, 0);
     if (rc) return rc;
     const int scan = ctx->cfg.segmentation_scan_limit / ctx->cfg.stride;
     return launch_viterbi<true>(ctx, ctx->hmm[0], n, raw, head_or_null, off, cal, ss, ctx->cfg.stride, scan, scan,
-                                (int32_t*)status, segs, nullptr);
+                                (int32_t*)status, segs, nullptr, order);
 }
 
 int pxg_launch_viterbi_f32(pxg_ctx* ctx, int which, int64_t n, const float* sig,

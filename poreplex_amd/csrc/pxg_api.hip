@@ -246,6 +246,10 @@ extern "C" int pxg_create(const pxg_config* cfg, pxg_ctx** out)
             rc = fail(ctx, PXG_E_INVALID, "pxg_config.lstm_arith: unknown arithmetic"); break;
         }
         if ((rc = pxg_q8_upload(ctx))) break;
+        // measurement knobs (results never depend on them; tests/test_gpu_parity.py checks that)
+        ctx->length_order = getenv("PXG_NO_LENGTH_ORDER") == nullptr;
+        ctx->prefix_skip = getenv("PXG_NO_PREFIX_SKIP") == nullptr;
+        if (cfg->lstm_arith == PXG_LSTM_Q8 && (rc = pxg_q8_scaler_trajectory(ctx))) break;
     } while (0);
     // host pointers in the copied config are not retained
     ctx->cfg.scaler_lstm1.kernel = ctx->cfg.scaler_lstm1.recurrent = ctx->cfg.scaler_lstm1.bias = nullptr;
@@ -684,6 +688,12 @@ extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
     int rc;
     pxg_timer_begin(ctx, PXG_T_TOTAL);
     if ((rc = pxg_launch_reset_batch(ctx, n))) return rc;
+    const int32_t* order = nullptr;
+    if (ctx->length_order && (stage_mask & (PXG_STAGE_SCALER | PXG_STAGE_SEGMENT))) {
+        if ((rc = pxg_reserve(ctx, ctx->order, (size_t)n)) ||
+            (rc = pxg_launch_length_order(ctx, n, ctx->offsets.p, ctx->order.p))) return rc;
+        order = ctx->order.p;
+    }
 
     if (stage_mask & PXG_STAGE_SCALER) {
         pxg_timer_begin(ctx, PXG_T_HEAD_POOL);
@@ -694,11 +704,11 @@ extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
             PXG_HIP(ctx, hipMemcpyAsync(ctx->ss.p, ctx->inject.p, (size_t)n * 2 * sizeof(float),
                                         hipMemcpyDeviceToDevice, ctx->stream));
         } else {
-            if ((rc = pxg_launch_compact_scaler(ctx, n, ctx->status.p, ctx->idx_scaler.p, ctx->counters.p)))
+            if ((rc = pxg_launch_compact_scaler(ctx, n, ctx->status.p, order, ctx->idx_scaler.p, ctx->counters.p)))
                 return rc;
             pxg_timer_begin(ctx, PXG_T_SCALER_LSTM);
             if ((rc = pxg_launch_scaler_lstm(ctx, n, ctx->idx_scaler.p, ctx->counters.p, ctx->head.p,
-                                             ctx->pred.p))) return rc;
+                                             ctx->pred.p, ctx->offsets.p))) return rc;
             pxg_timer_end(ctx, PXG_T_SCALER_LSTM);
             if ((rc = pxg_launch_scaler_transform(ctx, n, ctx->pred.p, ctx->ss.p, ctx->status.p,
                                                   ctx->idx_scaler.p, ctx->counters.p))) return rc;
@@ -712,7 +722,7 @@ extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
         // with the scaler stage in the same run K1's block means of the head are still in HBM
         const float* head = (stage_mask & PXG_STAGE_SCALER) ? ctx->head.p : nullptr;
         if ((rc = pxg_launch_segment_raw(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p,
-                                         head, ctx->status.p, ctx->segs.p))) return rc;
+                                         head, ctx->status.p, ctx->segs.p, order))) return rc;
         pxg_timer_end(ctx, PXG_T_SEGMENT);
     }
     if (stage_mask & PXG_STAGE_BARCODE) {

@@ -303,6 +303,10 @@ struct pxg_ctx {
     DevBuf<unsigned long long> unsplit_q;   // K7b unit queue
     DevBuf<char> vit_bp;         // K3 back-pointer fields, [block][chunk][64 lanes]
     DevBuf<int32_t> idx_scaler;  // compacted read indices
+    DevBuf<int32_t> order, order_hist;   // reads by length class (longest first) of the resident batch; class cursors
+    bool length_order = true;    // PXG_NO_LENGTH_ORDER=1 at pxg_create: blocks take the reads in batch order
+    DevBuf<unsigned> scaler_traj;   // PXG_LSTM_Q8: tile states of the zero-input scaler network every 4 steps
+    bool prefix_skip = true;     // PXG_NO_PREFIX_SKIP=1 at pxg_create: K2 runs every read from step 0
     DevBuf<int32_t> idx_demux;
     DevBuf<int32_t> counters;    // [0] scaler count, [1] demux count
     DevBuf<float> win;           // n x trim
@@ -395,7 +399,7 @@ int pxg_launch_scaler_transform(pxg_ctx* ctx, int64_t n, const float* pred, floa
 // segmentation of raw reads (pool + scale + Viterbi + run summary)
 int pxg_launch_segment_raw(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
                            const pxg_calib* cal, const float* ss, const float* head_or_null,
-                           const int32_t* status, int32_t* segs);
+                           const int32_t* status, int32_t* segs, const int32_t* order = nullptr);
 // Viterbi on already pooled float signals (test hook)
 int pxg_launch_viterbi_f32(pxg_ctx* ctx, int which, int64_t n, const float* sig,
                            const int64_t* off, int max_steps, int32_t* segs, double* logp);
@@ -405,10 +409,13 @@ int pxg_launch_barcode_window_raw(pxg_ctx* ctx, int64_t n, const int16_t* raw,
                                   int32_t* idx_demux, int32_t* counter);
 int pxg_launch_barcode_window_f32(pxg_ctx* ctx, int64_t n, const float* sig,
                                   const int64_t* off, float* win, int8_t* pushed);
-int pxg_launch_compact_scaler(pxg_ctx* ctx, int64_t n, const int32_t* status, int32_t* idx,
+int pxg_launch_compact_scaler(pxg_ctx* ctx, int64_t n, const int32_t* status, const int32_t* order, int32_t* idx,
                               int32_t* counter);
+// reads by length class, longest first (k_signal.hip)
+int pxg_launch_length_order(pxg_ctx* ctx, int64_t n, const int64_t* off, int32_t* order);
+// `off` (or null): sample offsets of the reads `head` was pooled from -- lets K2 skip the zero-pad prefix
 int pxg_launch_scaler_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
-                           const int32_t* count, const float* head, float* pred);
+                           const int32_t* count, const float* head, float* pred, const int64_t* off = nullptr);
 int pxg_launch_demux_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
                           const int32_t* count, const float* win, float* bidir, float* probs,
                           int timer_a, int timer_b);
@@ -421,7 +428,8 @@ int pxg_lstm_upload(pxg_ctx* ctx);   // shape checks
 int pxg_q8_upload(pxg_ctx* ctx);
 void pxg_q8_free(pxg_ctx* ctx);
 int pxg_launch_scaler_lstm_q8(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, const int32_t* count,
-                              const float* head, float* pred);
+                              const float* head, float* pred, const int64_t* off);
+int pxg_q8_scaler_trajectory(pxg_ctx* ctx);   // zero-input states of the scaler network (prefix skip), once per context
 int pxg_launch_demux_lstm_q8(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, const int32_t* count,
                              const float* win, float* bidir, float* probs, int timer_a, int timer_b);
 int pxg_polya_supported(pxg_ctx* ctx);

@@ -342,6 +342,39 @@ def test_full_size_determinism_and_order_invariance(ctx):
     assert np.abs(p.sum(1) - 1).max() < 1e-5
 
 
+def test_run_shaped_batch_length_order_and_pad_prefix_skip(ctx, oracle, config, monkeypatch):
+    """Lengths as a sequencing run has them (log-normal, 15 % of the reads shorter than the scaler's 30 000
+    samples, a tail up to 10^6): blocks of K3 take the reads in length order and K2 (q8) starts a tile behind
+    the zero-pad prefix its 16 reads share, from the recorded zero-input trajectory.  Both are exact: the
+    records equal the oracle's, and those of a context with both savings switched off."""
+    b = synth_batch(700, seed=931, length_dist='lognormal', short_fraction=0.02)
+    n_means = np.minimum(np.diff(b['offsets']), 30000) // 15
+    assert ((n_means < 2000) & (n_means >= 600)).sum() > 60      # padded heads are in play
+    got = ctx.process_batch(b['arena'], b['offsets'], b['calib'])
+    want = oracle.process_batch(b['arena'], b['offsets'], b['calib'])
+    assert_records_equal(got, want, ctxmsg='run-shaped batch vs oracle')
+    monkeypatch.setenv('PXG_NO_LENGTH_ORDER', '1')
+    monkeypatch.setenv('PXG_NO_PREFIX_SKIP', '1')
+    plain = N.NativeContext(config, device_id=0)
+    try:
+        assert_records_equal(plain.process_batch(b['arena'], b['offsets'], b['calib']), got, ctxmsg='savings off')
+    finally:
+        plain.close()
+    # every pad length of a tile's worth of reads, incl. heads of exactly 600 and 1 999 means: all 16 reads of a
+    # tile padded alike (the skip is the whole prefix) and mixed with unpadded ones (no skip)
+    lens = np.concatenate([np.repeat(np.arange(9000, 30015, 1500), 16), np.repeat([9000, 29985, 29999, 30000, 45000], 8)])
+    rng = np.random.default_rng(5)
+    pieces = [synth_batch(1, seed=4000 + i, samples_per_read=int(L), jitter=0.0) for i, L in enumerate(lens)]
+    arena, off = N.pack_reads([p['arena'] for p in pieces])
+    calib = np.concatenate([p['calib'] for p in pieces])
+    for perm in (np.arange(len(lens)), rng.permutation(len(lens))):
+        sig = [arena[off[i]:off[i + 1]] for i in perm]
+        a2, o2 = N.pack_reads(sig)
+        g = ctx.process_batch(a2, o2, calib[perm], None, N.STAGE_SCALER)
+        w = oracle.process_batch(a2, o2, calib[perm], None, N.STAGE_SCALER)
+        assert_records_equal(g, w, ctxmsg='pad ladder')
+
+
 # ---- a18 / a19 ---------------------------------------------------------------
 def _chimera():
     import json
