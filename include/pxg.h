@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PXG_ABI_VERSION 4
+#define PXG_ABI_VERSION 5
 
 #define PXG_MAX_STATES      8   /* HMM states per model (reference uses 6)        */
 #define PXG_MAX_MIXTURE     4   /* Gaussian components per state (reference <= 2) */
@@ -493,30 +493,44 @@ typedef struct {
 int64_t pxg_summary_rows(const pxg_summary_columns* cols, char* out, int64_t cap);
 
 /* ---- compressed samples across PCIe --------------------------------------
- * A read bundle may carry its samples as zig-zag deltas of one or two bytes (the variable-
- * byte stage of ONT's VBZ) in independent chunks of PXG_Z_CHUNK samples that never span
- * reads: 128 control bytes (bit i: sample i took two bytes) + the data bytes of samples
- * 1 .. len-1; sample 0 is in the chunk record.  pxg_batch_stage_z copies the bytes and the
- * chunk records of a batch to the device and decodes them there into the spare input slot
- * (a workgroup per chunk), so the link carries ~1.1 bytes per sample instead of 2; the
- * resident batch is the same int16 arena either way.  data_off / dst of the records may be
- * relative to any base: the call takes the bases of the slice it is given.
- * pxg_z_encode / pxg_z_decode / pxg_z_count_chunks: host only (libpxghost.so). */
+ * A read bundle may carry its samples as zig-zag deltas in independent chunks of PXG_Z_CHUNK
+ * samples that never span reads; sample 0 of a chunk is in its record.  Two encodings of the
+ * deltas, named by the record's `codec`:
+ *   PXG_Z_BYTES   one or two bytes each (the variable-byte stage of ONT's VBZ): 128 control bytes
+ *                 (bit i: sample i took two bytes) + the data bytes of samples 1 .. len-1;
+ *   PXG_Z_PACKED  bit-packed: 128 header bytes = 256 nibbles, the bit width of each group of FOUR
+ *                 deltas (code 15 = 16 bits; the chunk's delta 0 is 0; groups past `len` have
+ *                 width 0), then the groups' 4 x w bits back to back, least significant bit
+ *                 first, padded to a byte.  ~0.96 bytes per sample where PXG_Z_BYTES needs 1.19.
+ * pxg_batch_stage_z copies the bytes and the chunk records of a batch to the device and decodes
+ * them there into the spare input slot (a wave per chunk), so the link carries ~1 byte per
+ * sample instead of 2; the resident batch is the same int16 arena either way.  data_off / dst
+ * of the records may be relative to any base: the call takes the bases of the slice it is given.
+ * pxg_z_encode(_as) / pxg_z_decode(_n) / pxg_z_count_chunks: host only (libpxghost.so). */
 #define PXG_Z_CHUNK 1024
 #define PXG_Z_CTRL_BYTES (PXG_Z_CHUNK / 8)
+#define PXG_Z_BYTES 0
+#define PXG_Z_PACKED 1
 struct pxg_z_chunk {
-    int64_t data_off;      /* byte offset of the chunk (its control bytes) in the encoded stream */
+    int64_t data_off;      /* byte offset of the chunk (its control / header bytes) in the encoded stream */
     int64_t dst;           /* sample index of the chunk's first sample in the decoded arena */
     int16_t first;         /* sample 0 */
     int16_t len;           /* samples in the chunk, 1 .. PXG_Z_CHUNK */
-    int32_t reserved;
+    int32_t codec;         /* PXG_Z_BYTES (0: every bundle written before ABI 5) or PXG_Z_PACKED */
 };
 int64_t pxg_z_count_chunks(int64_t n_reads, const int64_t* offsets);
-/* -> bytes written (worst case PXG_Z_CTRL_BYTES * chunks + 2 * samples), PXG_E_NOMEM if cap is short */
+/* -> bytes written, PXG_E_NOMEM if cap is short (sufficient for either codec:
+ * (PXG_Z_CTRL_BYTES + 2 * PXG_Z_CHUNK + 8) * chunks); pxg_z_encode = PXG_Z_BYTES */
 int64_t pxg_z_encode(int64_t n_reads, const int16_t* arena, const int64_t* offsets, uint8_t* out,
                      int64_t cap, pxg_z_chunk* chunks);
+int64_t pxg_z_encode_as(int64_t n_reads, const int16_t* arena, const int64_t* offsets, uint8_t* out,
+                        int64_t cap, pxg_z_chunk* chunks, int32_t codec);
+/* pxg_z_decode_n is told the stream's size (reads of a packed chunk are clamped to it);
+ * pxg_z_decode: the caller vouches for 128 + 2 048 readable bytes behind every chunk start */
 int pxg_z_decode(int64_t n_chunks, const uint8_t* z, const pxg_z_chunk* chunks, int64_t data_base,
                  int64_t dst_base, int16_t* out);
+int pxg_z_decode_n(int64_t n_chunks, const uint8_t* z, int64_t z_bytes_or_0, const pxg_z_chunk* chunks,
+                   int64_t data_base, int64_t dst_base, int16_t* out);
 /* Chunk records come from files: PXG_OK iff the records tile [dst_base, dst_base + n_samples) in
  * order with 1 .. PXG_Z_CHUNK samples each and every chunk lies inside the z_bytes of the stream
  * (PXG_E_INVALID otherwise).  pxg_batch_stage_z runs the same check and refuses the batch; call

@@ -62,7 +62,7 @@ int pxg_launch_reset_batch(pxg_ctx* ctx, int64_t n)
 // version: a workgroup per chunk, four samples per thread, two block scans -- ten barriers per
 // chunk and 1.24 ms for a 10 000-read batch; this one 0.55 ms = 3.5 TB/s of reads + writes.)
 // ---------------------------------------------------------------------------
-#define ZD_STAGE_DW ((PXG_Z_CTRL_BYTES + 2 * PXG_Z_CHUNK) / 4 + 2)
+#define ZD_STAGE_DW ((PXG_Z_CTRL_BYTES + 2 * PXG_Z_CHUNK) / 4 + 2)      // + 1 below: the funnel shift's second word
 
 __device__ __forceinline__ int wave_exclusive_scan(int v, int lane, int& total)
 {
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void k_z_decode(int64_t n_chunks, const uint8_
                                                   const pxg_z_chunk* __restrict__ chunks, int64_t data_base,
                                                   int64_t dst_base, int16_t* __restrict__ out)
 {
-    __shared__ unsigned stage_all[4][ZD_STAGE_DW];
+    __shared__ unsigned stage_all[4][ZD_STAGE_DW + 2];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t g = blockIdx.x * 4ll + wv;
     if (g >= n_chunks) return;                              // whole waves leave; nothing below is block-wide
@@ -89,26 +89,55 @@ __global__ __launch_bounds__(256) void k_z_decode(int64_t n_chunks, const uint8_
     const uint8_t* src = z + (c.data_off - data_base);
     const int mis = (int)((uintptr_t)src & 3);
     const unsigned* src4 = reinterpret_cast<const unsigned*>(src - mis);
+    // never past the stream's buffer (z_bytes + 16 allocated): a chunk near the end that needs fewer bytes
+    // than its worst case must not read beyond it (the words not staged are never addressed by a
+    // well-formed chunk; pxg_z_check vouches for the rest)
+    const int64_t room64 = (z_bytes + 12 - ((c.data_off - data_base) - mis)) >> 2;
+    const int room = room64 < 0 ? 0 : (room64 > ZD_STAGE_DW ? ZD_STAGE_DW : (int)room64);
+    const int i0 = 16 * lane;                               // samples i0 .. i0 + 15 of the chunk
+    const int n_valid = c.len - i0 < 0 ? 0 : (c.len - i0 > 16 ? 16 : c.len - i0);
+    int d[16], sum = 0, total;
+    if (c.codec == PXG_Z_PACKED) {
+        // ---- bit-packed groups of four: header first (it says how many bytes follow), then the bits ----
+        int n_dw = min((mis + PXG_Z_CTRL_BYTES + 3) >> 2, room);
+        if (lane < n_dw) stage[lane] = src4[lane];          // <= 33 dwords
+        __builtin_amdgcn_wave_barrier();
+        const uint8_t* hdr = reinterpret_cast<const uint8_t*>(stage) + mis;
+        const unsigned codes = (unsigned)hdr[2 * lane] | ((unsigned)hdr[2 * lane + 1] << 8);   // this lane's 4 groups
+        int w[4], mine = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int code = (int)((codes >> (4 * j)) & 15u);
+            w[j] = (i0 + 4 * j < c.len) ? (code == 15 ? 16 : code) : 0;     // (a group past the end carries nothing)
+            mine += 4 * w[j];
+        }
+        int bit = wave_exclusive_scan(mine, lane, total) + 8 * (mis + PXG_Z_CTRL_BYTES);
+        __builtin_amdgcn_wave_barrier();                    // every lane has read its header bytes
+        n_dw = min((mis + PXG_Z_CTRL_BYTES + ((total + 7) >> 3) + 3) >> 2, room);
+        for (int k = lane; k < n_dw; k += 64) stage[k] = src4[k];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            const int wq = w[q >> 2];
+            const int at = bit >> 5;                        // (<= 128 + 2 048 bytes + 3: inside the stage buffer)
+            const unsigned v = __funnelshift_r(stage[at], stage[at + 1], (unsigned)(bit & 31));
+            const unsigned zz = v & ((1u << wq) - 1u);
+            bit += wq;
+            sum += (int)((zz >> 1) ^ (0u - (zz & 1u)));
+            d[q] = sum;
+        }
+    } else {
     // at most 128 + 2 (len - 1) bytes; the last dword may reach into the next chunk (or the 16
     // spare bytes behind the stream)
-    int n_dw = (mis + PXG_Z_CTRL_BYTES + 2 * (c.len - 1) + 3) >> 2;
-    // ... but never past the stream's buffer (z_bytes + 16 allocated): a chunk near the end that
-    // needs fewer bytes than its worst case must not read beyond it (the words not staged are
-    // never addressed by a well-formed chunk; pxg_z_check vouches for the rest)
-    const int64_t room = (z_bytes + 12 - ((c.data_off - data_base) - mis)) >> 2;
-    if ((int64_t)n_dw > room) n_dw = room < 0 ? 0 : (int)room;
+    const int n_dw = min((mis + PXG_Z_CTRL_BYTES + 2 * (c.len - 1) + 3) >> 2, room);
     for (int k = lane; k < n_dw; k += 64) stage[k] = src4[k];   // (LDS words not staged are only read for malformed chunks)
     __builtin_amdgcn_wave_barrier();
     const uint8_t* ctrl = reinterpret_cast<const uint8_t*>(stage) + mis;
     const uint8_t* data = ctrl + PXG_Z_CTRL_BYTES;
-    const int i0 = 16 * lane;                               // samples i0 .. i0 + 15 of the chunk
-    const int n_valid = c.len - i0 < 0 ? 0 : (c.len - i0 > 16 ? 16 : c.len - i0);
     unsigned bits = (unsigned)ctrl[2 * lane] | ((unsigned)ctrl[2 * lane + 1] << 8);
     bits &= (1u << n_valid) - 1u;                           // (sample 0's bit is never set)
     const int mine = n_valid + __builtin_popcount(bits) - ((lane == 0 && n_valid > 0) ? 1 : 0);
-    int total;
     int at = wave_exclusive_scan(mine, lane, total);
-    int d[16], sum = 0;
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const bool has = q < n_valid && (i0 + q) >= 1;      // sample 0 is in the record
@@ -119,6 +148,7 @@ __global__ __launch_bounds__(256) void k_z_decode(int64_t n_chunks, const uint8_
         at += has ? (two ? 2 : 1) : 0;
         sum += (int)((zz >> 1) ^ (0u - (zz & 1u)));         // zig-zag; only the low 16 bits matter
         d[q] = sum;                                          // inclusive, inside the lane
+    }
     }
     const int before = wave_exclusive_scan(sum, lane, total) + (int)c.first;
     int16_t* dst = out + (c.dst - dst_base) + i0;

@@ -4,7 +4,8 @@
 // error, not an out-of-bounds read or write on the device.  After this check every chunk
 //   * writes exactly its own samples, and the chunks tile [dst_base, dst_base + n_samples) in order;
 //   * starts inside the byte stream, and the stream holds at least the bytes the chunk cannot do
-//     without (control bytes + one byte per delta); the decoders clamp their reads to the stream,
+//     without (control bytes + one byte per delta; a packed chunk: its width header); the decoders clamp
+//     their reads to the stream,
 //     so flipped control bits can only produce wrong samples, never a stray access.
 #ifndef PXG_ZCHECK_H
 #define PXG_ZCHECK_H
@@ -22,7 +23,9 @@ static inline int pxg_z_check(int64_t n_chunks, const pxg_z_chunk* chunks, int64
         if (c.dst - dst_base != at) return PXG_E_INVALID;
         const int64_t off = c.data_off - data_base;
         if (off < byte || off > z_bytes) return PXG_E_INVALID;
-        const int64_t least = PXG_Z_CTRL_BYTES + (int64_t)(c.len - 1);
+        if (c.codec != PXG_Z_BYTES && c.codec != PXG_Z_PACKED) return PXG_E_INVALID;
+        // (a packed chunk may be all header: every width 0)
+        const int64_t least = PXG_Z_CTRL_BYTES + (c.codec == PXG_Z_BYTES ? (int64_t)(c.len - 1) : 0);
         if (z_bytes - off < least) return PXG_E_INVALID;
         byte = off + least;
         at += c.len;

@@ -15,7 +15,7 @@ from . import config as _config
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'csrc', 'libpxg.so')
 
-PXG_ABI_VERSION = 4
+PXG_ABI_VERSION = 5
 LSTM_ARITH = {'q8': 0, 'f32': 1}      # enum pxg_lstm_arith
 PXG_E_NOMEM, PXG_E_UNSUPPORTED = -4, -6
 PXG_MAX_STATES = 8
@@ -360,7 +360,9 @@ _TEXT_SIGNATURES = {      # libpxghost.so: host-only helpers (sink text, sample 
     'pxg_summary_rows': (C.c_int64, [C.POINTER(PxgSummaryColumns), C.c_char_p, C.c_int64]),
     'pxg_z_count_chunks': (C.c_int64, [C.c_int64, C.c_void_p]),
     'pxg_z_encode': (C.c_int64, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'pxg_z_encode_as': (C.c_int64, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32]),
     'pxg_z_decode': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    'pxg_z_decode_n': (C.c_int, [C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     'pxg_z_validate': (C.c_int, [C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]),
     'pxg_h5_open': (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     'pxg_h5_open_mt': (C.c_int, [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]),
@@ -550,12 +552,15 @@ def _ptr(a):
 # ---- compressed samples (include/pxg.h, pxg_zcodec.cpp) ---------------------------------------
 Z_CHUNK = 1024
 Z_CHUNK_DTYPE = np.dtype([('data_off', np.int64), ('dst', np.int64), ('first', np.int16),
-                          ('len', np.int16), ('reserved', np.int32)])
+                          ('len', np.int16), ('codec', np.int32)])
+Z_CODECS = {'bytes': 0, 'packed': 1}      # PXG_Z_BYTES (one or two bytes per delta), PXG_Z_PACKED (bit widths per 4 deltas)
 
 
-def z_encode(arena, offsets):
+def z_encode(arena, offsets, codec='packed'):
     """int16 samples of many reads -> (bytes uint8[], chunk records, chunk_base int64[n + 1]):
-    chunk_base[r] = index of read r's first chunk.  Host side, offline (bundle writing)."""
+    chunk_base[r] = index of read r's first chunk.  Host side, offline (bundle writing).  `codec`: 'packed'
+    (bit-packed deltas, ~0.96 bytes per sample) or 'bytes' (VBZ's byte codes, ~1.19; what bundles written
+    before ABI 5 hold -- the decoders take either, chunk by chunk)."""
     lib = load_text_library()
     arena = np.ascontiguousarray(arena, dtype=np.int16)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
@@ -565,10 +570,10 @@ def z_encode(arena, offsets):
     np.cumsum(per_read, out=chunk_base[1:])
     n_chunks = int(chunk_base[-1])
     chunks = np.zeros(n_chunks, dtype=Z_CHUNK_DTYPE)
-    out = np.empty(n_chunks * (Z_CHUNK // 8) + 2 * len(arena) + 16, dtype=np.uint8)
-    got = lib.pxg_z_encode(n, _ptr(arena), _ptr(offsets), _ptr(out), len(out), _ptr(chunks))
+    out = np.empty(n_chunks * (Z_CHUNK // 8 + 8) + 2 * (len(arena) + 3 * n_chunks) + 2 * Z_CHUNK + 16, dtype=np.uint8)
+    got = lib.pxg_z_encode_as(n, _ptr(arena), _ptr(offsets), _ptr(out), len(out), _ptr(chunks), Z_CODECS[codec])
     if got < 0:
-        raise PxgError('pxg_z_encode failed ({})'.format(got))
+        raise PxgError('pxg_z_encode_as failed ({})'.format(got))
     return out[:got].copy(), chunks, chunk_base
 
 
@@ -592,7 +597,7 @@ def z_decode(z, chunks, n_samples, data_base=0, dst_base=0):
     chunks = np.ascontiguousarray(chunks, dtype=Z_CHUNK_DTYPE)
     z_validate(z, chunks, n_samples, data_base, dst_base)
     out = np.zeros(int(n_samples), dtype=np.int16)
-    rc = lib.pxg_z_decode(len(chunks), _ptr(z), _ptr(chunks), int(data_base), int(dst_base), _ptr(out))
+    rc = lib.pxg_z_decode_n(len(chunks), _ptr(z), len(z), _ptr(chunks), int(data_base), int(dst_base), _ptr(out))
     if rc:
         raise PxgError('pxg_z_decode failed ({})'.format(rc))
     return out

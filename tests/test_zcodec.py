@@ -15,6 +15,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 
+@pytest.fixture(params=['packed', 'bytes'])
+def codec(request):
+    """Both encodings of the deltas (include/pxg.h: PXG_Z_PACKED, the default of ABI 5, and PXG_Z_BYTES, what
+    older bundles hold)."""
+    return request.param
+
+
 def adversarial_reads(rng):
     parts = []
     for n in (0, 1, 2, 7, 1023, 1024, 1025, 2047, 2048, 2049, 5000, 0, 3):
@@ -33,11 +40,12 @@ def adversarial_reads(rng):
     return parts
 
 
-def test_codec_round_trip_and_chunk_layout():
+def test_codec_round_trip_and_chunk_layout(codec):
     rng = np.random.default_rng(4)
     parts = adversarial_reads(rng)
     arena, off = N.pack_reads(parts)
-    z, chunks, base = N.z_encode(arena, off)
+    z, chunks, base = N.z_encode(arena, off, codec)
+    assert (chunks['codec'] == N.Z_CODECS[codec]).all()
     assert np.array_equal(N.z_decode(z, chunks, len(arena)), arena)
     # chunks never span reads; chunk_base indexes them by read
     per_read = (np.diff(off) + N.Z_CHUNK - 1) // N.Z_CHUNK
@@ -47,28 +55,49 @@ def test_codec_round_trip_and_chunk_layout():
         assert c['len'].sum() == len(parts[r])
         if len(c):
             assert c['dst'][0] == off[r] and np.array_equal(c['first'], arena[c['dst']])
-    # one byte per sample where the deltas are small, two where they are not
-    assert len(z) <= len(chunks) * (N.Z_CHUNK // 8) + 2 * len(arena)
+    # one byte per sample where the deltas are small, two where they are not (packed: groups of four round up)
+    assert len(z) <= len(chunks) * (N.Z_CHUNK // 8 + 8) + 2 * len(arena)
     sb = synth_batch(8, seed=3, samples_per_read=30000)
-    z2, ch2, _ = N.z_encode(sb['arena'], sb['offsets'])
+    z2, ch2, _ = N.z_encode(sb['arena'], sb['offsets'], codec)
     assert np.array_equal(N.z_decode(z2, ch2, len(sb['arena'])), sb['arena'])
-    assert len(z2) < 1.3 * len(sb['arena'])              # ~1.17 bytes per sample on bench-like signal
+    # bytes per sample on bench-like signal: ~1.17 as byte codes, ~0.96 bit-packed
+    assert len(z2) < (1.3 if codec == 'bytes' else 1.0) * len(sb['arena'])
 
 
-def compressed_copy(src, dst):
+def test_one_stream_may_mix_the_codecs_and_garbage_widths_stay_inside_the_stream():
+    """The codec is a property of the CHUNK: a stream whose first reads were written as byte codes and the rest
+    bit-packed decodes as one.  A packed chunk's widths come from the stream, so the host decoder is told where
+    the stream ends and reads nothing behind it, whatever the header says."""
+    sb = synth_batch(6, seed=12, samples_per_read=5000)
+    o = sb['offsets']
+    za, ca, _ = N.z_encode(sb['arena'][:o[3]], o[:4], 'bytes')
+    zb, cb, _ = N.z_encode(sb['arena'][o[3]:], o[3:] - o[3], 'packed')
+    cb = cb.copy()
+    cb['data_off'] += len(za)
+    cb['dst'] += o[3]
+    z, chunks = np.concatenate([za, zb]), np.concatenate([ca, cb])
+    assert np.array_equal(N.z_decode(z, chunks, len(sb['arena'])), sb['arena'])
+    bad = z.copy()
+    last = int(chunks['data_off'][-1])
+    bad[last:last + 128] = 0xFF                      # every group of the last chunk claims 16 bits
+    out = N.z_decode(bad, chunks, len(sb['arena']))  # wrong samples in that chunk, no stray read
+    assert np.array_equal(out[:chunks['dst'][-1]], sb['arena'][:chunks['dst'][-1]])
+
+
+def compressed_copy(src, dst, codec='packed'):
     """The same bundle with its arena replaced by the encoded form."""
     with np.load(src, allow_pickle=False) as npz:
         d = {k: npz[k] for k in npz.files}
-    z, chunks, base = N.z_encode(d.pop('arena'), d['offsets'])
+    z, chunks, base = N.z_encode(d.pop('arena'), d['offsets'], codec)
     d.update(arena_z=z, z_chunks=chunks, z_chunk_base=base, bundle_version=np.int64(3))
     np.savez(dst, **d)
     return dst
 
 
 @pytest.mark.parametrize('bundle', ['batch0.pxr.npz', 'chimera.pxr.npz'])
-def test_compressed_bundle_is_the_same_bundle(tmp_path, bundle):
+def test_compressed_bundle_is_the_same_bundle(tmp_path, bundle, codec):
     plain = ReadBundle(os.path.join(GOLDEN, bundle))
-    comp = ReadBundle(compressed_copy(os.path.join(GOLDEN, bundle), str(tmp_path / bundle)))
+    comp = ReadBundle(compressed_copy(os.path.join(GOLDEN, bundle), str(tmp_path / bundle), codec))
     assert comp.compressed and not plain.compressed
     n = len(plain.read_ids)
     for i in range(n):
@@ -102,7 +131,7 @@ def test_session_from_a_compressed_bundle_writes_the_same_files(tmp_path, monkey
 
 
 @pytest.mark.gpu
-def test_device_decoder_fills_the_arena_the_host_decoder_does(ctx, oracle):
+def test_device_decoder_fills_the_arena_the_host_decoder_does(ctx, oracle, codec):
     """pxg_batch_stage_z: bytes + chunk records cross the link, k_z_decode rebuilds the int16
     arena; every stage then gives the records of the uncompressed upload -- for adversarial
     sample patterns and for a slice of a larger encoded stream (non-zero bases)."""
@@ -112,7 +141,7 @@ def test_device_decoder_fills_the_arena_the_host_decoder_does(ctx, oracle):
     parts = [sb['arena'][o[i]:o[i + 1]] for i in range(40)] + adversarial_reads(rng)
     arena, off = N.pack_reads(parts)
     cal = np.concatenate([sb['calib'], np.repeat(sb['calib'][:1], len(parts) - 40)])
-    z, chunks, base = N.z_encode(arena, off)
+    z, chunks, base = N.z_encode(arena, off, codec)
     mask = N.STAGE_ALL_DEMUX | N.STAGE_POLYA
     ctx.upload(arena, off, cal)
     ctx.run(mask)
@@ -138,7 +167,7 @@ def test_device_decoder_fills_the_arena_the_host_decoder_does(ctx, oracle):
 
 
 @pytest.mark.gpu
-def test_fuzz_device_decoder_sample_for_sample(ctx):
+def test_fuzz_device_decoder_sample_for_sample(ctx, codec):
     """Random ragged batches of every sample pattern: the arena k_z_decode leaves in HBM equals
     the original, sample for sample (also through a slice with non-zero bases)."""
     rng = np.random.default_rng(int(os.environ.get('PXG_FUZZ_SEED', 31)))
@@ -164,7 +193,7 @@ def test_fuzz_device_decoder_sample_for_sample(ctx):
         arena, off = N.pack_reads(parts)
         cal = np.zeros(len(parts), dtype=N.CALIB_DTYPE)
         cal['range'], cal['digitisation'], cal['sampling_rate'] = 1400.0, 8192.0, 3012.0
-        z, chunks, base = N.z_encode(arena, off)
+        z, chunks, base = N.z_encode(arena, off, codec)
         ctx.stage_z(N.EncodedSamples(z, chunks, 0, 0, len(arena)), off, cal)
         ctx.swap()
         assert np.array_equal(ctx.download_samples(len(arena)), arena), trial
@@ -180,9 +209,9 @@ def test_fuzz_device_decoder_sample_for_sample(ctx):
             assert np.array_equal(ctx.download_samples(len(enc)), arena[off[i0]:off[i1]]), (trial, i0, i1)
 
 
-def _encoded(seed=11):
+def _encoded(seed=11, codec='packed'):
     sb = synth_batch(6, seed=seed, samples_per_read=5000)
-    z, chunks, base = N.z_encode(sb['arena'], sb['offsets'])
+    z, chunks, base = N.z_encode(sb['arena'], sb['offsets'], codec)
     return sb, z, chunks, base
 
 
@@ -194,14 +223,15 @@ CORRUPTIONS = {
     'bytes before the stream': lambda z, c: c['data_off'].__setitem__(0, -128),
     'bytes beyond the stream': lambda z, c: c['data_off'].__setitem__(len(c) - 1, len(z) + 4096),
     'chunks overlap in the stream': lambda z, c: c['data_off'].__setitem__(4, c['data_off'][3]),
+    'unknown codec': lambda z, c: c['codec'].__setitem__(1, 7),
 }
 
 
 @pytest.mark.parametrize('what', sorted(CORRUPTIONS))
-def test_corrupt_chunk_records_are_refused_on_the_host(what):
+def test_corrupt_chunk_records_are_refused_on_the_host(what, codec):
     """chunk records come from files -- a truncated or corrupt bundle must be an error
     (PXG_E_INVALID / PxgError), never an out-of-bounds access in a decoder."""
-    sb, z, chunks, base = _encoded()
+    sb, z, chunks, base = _encoded(codec=codec)
     N.z_validate(z, chunks, len(sb['arena']))                  # the encoder's own output passes
     bad = chunks.copy()
     CORRUPTIONS[what](z, bad)
@@ -245,6 +275,25 @@ def test_corrupt_chunk_records_are_refused_by_stage_z(ctx, what):
     with pytest.raises(N.PxgError, match='chunk records'):
         ctx.stage_z(N.EncodedSamples(z[:len(z) // 2], chunks, 0, 0, len(sb['arena'])), sb['offsets'], sb['calib'])
     # and the context is still usable: the good stream decodes to the arena
+    ctx.stage_z(N.EncodedSamples(z, chunks, 0, 0, len(sb['arena'])), sb['offsets'], sb['calib'])
+    ctx.swap()
+    assert np.array_equal(ctx.download_samples(len(sb['arena'])), sb['arena'])
+
+
+@pytest.mark.gpu
+def test_garbage_width_headers_stay_inside_the_stream_on_the_device(ctx):
+    """A packed chunk's widths are data: with every header nibble of the LAST chunk of the stream claiming 16 bits
+    the device decoder reads no byte behind the stream's buffer (clamped staging) -- that chunk's samples are
+    wrong, every other chunk's are right, and the context carries on."""
+    sb, z, chunks, base = _encoded(codec='packed')
+    bad = z.copy()
+    last = int(chunks['data_off'][-1])
+    bad[last:last + 128] = 0xFF
+    ctx.stage_z(N.EncodedSamples(bad, chunks, 0, 0, len(sb['arena'])), sb['offsets'], sb['calib'])
+    ctx.swap()
+    got = ctx.download_samples(len(sb['arena']))
+    cut = int(chunks['dst'][-1])
+    assert np.array_equal(got[:cut], sb['arena'][:cut])
     ctx.stage_z(N.EncodedSamples(z, chunks, 0, 0, len(sb['arena'])), sb['offsets'], sb['calib'])
     ctx.swap()
     assert np.array_equal(ctx.download_samples(len(sb['arena'])), sb['arena'])
