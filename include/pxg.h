@@ -544,6 +544,20 @@ int pxg_batch_stage_z(pxg_ctx* ctx, int64_t n_reads, const uint8_t* z, int64_t z
                       const pxg_z_chunk* chunks, int64_t n_chunks, int64_t data_base, int64_t dst_base,
                       const int64_t* raw_offsets, const pxg_calib* calib,
                       const float* scale_shift_or_null);
+/* The same two calls for a batch whose stages read only the first `prefix_limit` samples of a read (0 = all):
+ * without the poly(A) stage and the chimera scan nothing reads behind max(scaler_length,
+ * segmentation_scan_limit) (signal_analyzer.py:347-349 scans the first segmentation_scan_limit samples; the
+ * scaler's head and the barcode window lie inside them), so the rest of a long read stays on the host.  The
+ * resident arena keeps the layout of the whole reads (offsets, n_pooled and every result are those of the full
+ * call); stages and hooks that read whole reads (PXG_STAGE_POLYA, pxg_batch_unsplit_scan, pxg_batch_event_table,
+ * pxg_batch_download_samples) refuse such a batch with PXG_E_STATE when one of its reads is longer than the
+ * limit.  pxg_process_batch(_ex) chooses the limit itself from its stage mask and extras. */
+int pxg_batch_stage_prefix(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena, const int64_t* raw_offsets,
+                           const pxg_calib* calib, const float* scale_shift_or_null, int64_t prefix_limit);
+int pxg_batch_stage_z_prefix(pxg_ctx* ctx, int64_t n_reads, const uint8_t* z, int64_t z_bytes,
+                             const pxg_z_chunk* chunks, int64_t n_chunks, int64_t data_base, int64_t dst_base,
+                             const int64_t* raw_offsets, const pxg_calib* calib,
+                             const float* scale_shift_or_null, int64_t prefix_limit);
 
 /* ---- FAST5 input without an HDF5 library (host only, libpxghost.so) ---------
  * What the per-read processor needs from a FAST5 file (fast5_file.py:37-58 get_read_ids,

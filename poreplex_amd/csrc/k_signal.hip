@@ -78,13 +78,25 @@ __device__ __forceinline__ int wave_exclusive_scan(int v, int lane, int& total)
 
 __global__ __launch_bounds__(256) void k_z_decode(int64_t n_chunks, const uint8_t* __restrict__ z, int64_t z_bytes,
                                                   const pxg_z_chunk* __restrict__ chunks, int64_t data_base,
-                                                  int64_t dst_base, int16_t* __restrict__ out)
+                                                  int64_t dst_base, int16_t* __restrict__ out,
+                                                  const int64_t* __restrict__ off, int64_t n_reads, int64_t prefix_limit)
 {
     __shared__ unsigned stage_all[4][ZD_STAGE_DW + 2];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t g = blockIdx.x * 4ll + wv;
     if (g >= n_chunks) return;                              // whole waves leave; nothing below is block-wide
     const pxg_z_chunk c = chunks[g];
+    if (prefix_limit > 0) {
+        // pxg_batch_stage_z_prefix: only the chunks that hold the first `prefix_limit` samples of their read
+        // crossed the link -- the read is the last one that starts at or before the chunk
+        const int64_t at = c.dst - dst_base;
+        int64_t lo = 0, hi = n_reads;              // off[lo] <= at < off[hi]
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (off[mid] <= at) lo = mid; else hi = mid;
+        }
+        if (at - off[lo] >= prefix_limit) return;
+    }
     unsigned* stage = stage_all[wv];
     const uint8_t* src = z + (c.data_off - data_base);
     const int mis = (int)((uintptr_t)src & 3);
@@ -172,7 +184,8 @@ __global__ __launch_bounds__(256) void k_z_decode(int64_t n_chunks, const uint8_
 }
 
 int pxg_launch_z_decode(pxg_ctx* ctx, hipStream_t stream, int64_t n_chunks, const uint8_t* z, int64_t z_bytes,
-                        const pxg_z_chunk* chunks, int64_t data_base, int64_t dst_base, int16_t* out)
+                        const pxg_z_chunk* chunks, int64_t data_base, int64_t dst_base, int16_t* out, const int64_t* off,
+                        int64_t n_reads, int64_t prefix_limit)
 {
     if (n_chunks <= 0) return PXG_OK;
     if (n_chunks > 0x7fffffffLL) {
@@ -180,7 +193,7 @@ int pxg_launch_z_decode(pxg_ctx* ctx, hipStream_t stream, int64_t n_chunks, cons
         return PXG_E_INVALID;
     }
     hipLaunchKernelGGL(k_z_decode, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0, stream, n_chunks, z, z_bytes, chunks, data_base,
-                       dst_base, out);
+                       dst_base, out, off, n_reads, off ? prefix_limit : 0);
     return PXG_OK;
 }
 

@@ -453,6 +453,7 @@ extern "C" int pxg_batch_upload(pxg_ctx* ctx, int64_t n_reads, const int16_t* ra
     ctx->n_reads = n_reads;
     ctx->n_samples = n_samples;
     ctx->longest_read = longest_of(raw_offsets, n_reads);
+    ctx->resident_limit = 0;
     rate_range(calib, n_reads, ctx->rate_min, ctx->rate_max);
     return PXG_OK;
 }
@@ -513,6 +514,7 @@ extern "C" int pxg_batch_upload_tiled(pxg_ctx* ctx, int64_t n_reads, int64_t bas
     ctx->n_reads = n_reads;
     ctx->n_samples = n_samples;
     ctx->longest_read = longest_of(base_offsets, base_n);
+    ctx->resident_limit = 0;
     rate_range(base_calib, base_n, ctx->rate_min, ctx->rate_max);
     return PXG_OK;
 }
@@ -536,7 +538,47 @@ extern "C" int pxg_batch_stage(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw
                                const int64_t* raw_offsets, const pxg_calib* calib,
                                const float* scale_shift_or_null)
 {
+    return pxg_batch_stage_prefix(ctx, n_reads, raw_arena, raw_offsets, calib, scale_shift_or_null, 0);
+}
+
+// The first `limit` samples of every read (0: all of them), the arena laid out as if all had come: reads not
+// longer than the limit travel in one copy with their neighbours, a longer one ends the run.
+static int copy_read_prefixes(pxg_ctx* ctx, hipStream_t cs, int16_t* dst, const int16_t* src, const int64_t* off,
+                              int64_t n, int64_t limit)
+{
+    int64_t run0 = 0;
+    auto flush = [&](int64_t end) -> int {
+        if (end > run0)
+            PXG_HIP(ctx, hipMemcpyAsync(dst + run0, src + run0, (size_t)(end - run0) * sizeof(int16_t), hipMemcpyHostToDevice, cs));
+        return PXG_OK;
+    };
+    int rc;
+    if (limit > 0)
+        for (int64_t r = 0; r < n; r++)
+            if (off[r + 1] - off[r] > limit) {
+                if ((rc = flush(off[r] + limit))) return rc;
+                run0 = off[r + 1];
+            }
+    return flush(off[n]);
+}
+
+// the stages a resident batch staged with a prefix limit cannot serve (they read whole reads)
+static int need_whole_reads(pxg_ctx* ctx, const char* who)
+{
+    if (ctx->resident_limit > 0 && ctx->longest_read > ctx->resident_limit) {
+        pxg_set_err(ctx, std::string(who) + ": the resident batch was staged with a prefix limit (pxg_batch_stage_prefix) "
+                                            "shorter than its longest read");
+        return PXG_E_STATE;
+    }
+    return PXG_OK;
+}
+
+extern "C" int pxg_batch_stage_prefix(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena,
+                                      const int64_t* raw_offsets, const pxg_calib* calib,
+                                      const float* scale_shift_or_null, int64_t prefix_limit)
+{
     if (!ctx) return PXG_E_INVALID;
+    if (prefix_limit < 0) return fail(ctx, PXG_E_INVALID, "pxg_batch_stage_prefix: negative limit");
     int rc = check_batch_args(ctx, n_reads, raw_arena, raw_offsets, calib, "pxg_batch_stage");
     if (rc) return rc;
     if (n_reads == 0) return fail(ctx, PXG_E_INVALID, "pxg_batch_stage: empty batch");
@@ -554,9 +596,8 @@ extern "C" int pxg_batch_stage(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw
     if (ctx->run_recorded[ctx->cur ^ 1])
         PXG_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_run_done[ctx->cur ^ 1], 0));
     hipStream_t cs = ctx->copy_stream;
-    if (n_samples)
-        PXG_HIP(ctx, hipMemcpyAsync(sp.raw.p, raw_arena, (size_t)n_samples * sizeof(int16_t),
-                                    hipMemcpyHostToDevice, cs));
+    if (n_samples && (rc = copy_read_prefixes(ctx, cs, sp.raw.p, raw_arena, raw_offsets, n_reads, prefix_limit))) return rc;
+    sp.limit = prefix_limit;
     PXG_HIP(ctx, hipMemcpyAsync(sp.offsets.p, raw_offsets, (size_t)(n_reads + 1) * sizeof(int64_t),
                                 hipMemcpyHostToDevice, cs));
     PXG_HIP(ctx, hipMemcpyAsync(sp.calib.p, calib, (size_t)n_reads * sizeof(pxg_calib),
@@ -581,7 +622,39 @@ extern "C" int pxg_batch_stage_z(pxg_ctx* ctx, int64_t n_reads, const uint8_t* z
                                  int64_t dst_base, const int64_t* raw_offsets, const pxg_calib* calib,
                                  const float* scale_shift_or_null)
 {
+    return pxg_batch_stage_z_prefix(ctx, n_reads, z, z_bytes, chunks, n_chunks, data_base, dst_base, raw_offsets, calib,
+                                    scale_shift_or_null, 0);
+}
+
+// Byte ranges of the chunks that hold the first `limit` samples of every read.  false: some chunk spans two
+// reads (the encoder never writes one, the records may still say so) -- the caller then copies everything.
+static bool z_prefix_ranges(const pxg_z_chunk* chunks, int64_t n_chunks, int64_t data_base, int64_t z_bytes,
+                            const int64_t* off, int64_t n, int64_t limit, std::vector<std::pair<int64_t, int64_t>>& ranges)
+{
+    const int64_t keep = (limit + PXG_Z_CHUNK - 1) / PXG_Z_CHUNK;      // chunks of a read that are needed
+    auto byte_of = [&](int64_t g) { return g < n_chunks ? chunks[g].data_off - data_base : z_bytes; };
+    int64_t g = 0, run0 = 0;
+    for (int64_t r = 0; r < n; r++) {
+        const int64_t g0 = g;
+        int64_t need = off[r + 1] - off[r];
+        while (need > 0 && g < n_chunks) need -= chunks[g++].len;
+        if (need != 0) return false;
+        if (g - g0 > keep) {
+            if (byte_of(g0 + keep) > run0) ranges.emplace_back(run0, byte_of(g0 + keep));
+            run0 = byte_of(g);
+        }
+    }
+    if (z_bytes > run0) ranges.emplace_back(run0, z_bytes);
+    return g == n_chunks;
+}
+
+extern "C" int pxg_batch_stage_z_prefix(pxg_ctx* ctx, int64_t n_reads, const uint8_t* z, int64_t z_bytes,
+                                        const pxg_z_chunk* chunks, int64_t n_chunks, int64_t data_base,
+                                        int64_t dst_base, const int64_t* raw_offsets, const pxg_calib* calib,
+                                        const float* scale_shift_or_null, int64_t prefix_limit)
+{
     if (!ctx) return PXG_E_INVALID;
+    if (prefix_limit < 0) return fail(ctx, PXG_E_INVALID, "pxg_batch_stage_z_prefix: negative limit");
     int rc = check_batch_args(ctx, n_reads, (const int16_t*)z, raw_offsets, calib, "pxg_batch_stage_z");
     if (rc) return rc;
     if (n_reads == 0) return fail(ctx, PXG_E_INVALID, "pxg_batch_stage_z: empty batch");
@@ -605,7 +678,16 @@ extern "C" int pxg_batch_stage_z(pxg_ctx* ctx, int64_t n_reads, const uint8_t* z
     if (ctx->run_recorded[ctx->cur ^ 1])
         PXG_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_run_done[ctx->cur ^ 1], 0));
     hipStream_t cs = ctx->copy_stream;
-    if (z_bytes) PXG_HIP(ctx, hipMemcpyAsync(sp.z.p, z, (size_t)z_bytes, hipMemcpyHostToDevice, cs));
+    std::vector<std::pair<int64_t, int64_t>> ranges;
+    if (prefix_limit > 0 && !z_prefix_ranges(chunks, n_chunks, data_base, z_bytes, raw_offsets, n_reads, prefix_limit, ranges))
+        prefix_limit = 0;
+    if (prefix_limit == 0) {
+        ranges.clear();
+        if (z_bytes) ranges.emplace_back(0, z_bytes);
+    }
+    for (const auto& rg : ranges)
+        PXG_HIP(ctx, hipMemcpyAsync(sp.z.p + rg.first, z + rg.first, (size_t)(rg.second - rg.first), hipMemcpyHostToDevice, cs));
+    sp.limit = prefix_limit;
     if (n_chunks)
         PXG_HIP(ctx, hipMemcpyAsync(sp.zchunks.p, chunks, (size_t)n_chunks * sizeof(pxg_z_chunk),
                                     hipMemcpyHostToDevice, cs));
@@ -617,7 +699,8 @@ extern "C" int pxg_batch_stage_z(pxg_ctx* ctx, int64_t n_reads, const uint8_t* z
     if (sp.have_inject)
         PXG_HIP(ctx, hipMemcpyAsync(sp.inject.p, scale_shift_or_null, (size_t)n_reads * 2 * sizeof(float),
                                     hipMemcpyHostToDevice, cs));
-    if ((rc = pxg_launch_z_decode(ctx, cs, n_chunks, sp.z.p, z_bytes, sp.zchunks.p, data_base, dst_base, sp.raw.p)))
+    if ((rc = pxg_launch_z_decode(ctx, cs, n_chunks, sp.z.p, z_bytes, sp.zchunks.p, data_base, dst_base, sp.raw.p,
+                                  sp.offsets.p, n_reads, prefix_limit)))
         return rc;
     PXG_HIP(ctx, hipGetLastError());
     PXG_HIP(ctx, hipEventRecord(ctx->ev_staged, cs));
@@ -650,6 +733,7 @@ extern "C" int pxg_batch_swap(pxg_ctx* ctx)
     ctx->n_reads = sp.n_reads;
     ctx->n_samples = sp.n_samples;
     ctx->longest_read = ctx->spare_longest_read;
+    ctx->resident_limit = sp.limit;
     ctx->rate_min = sp.rate_min;
     ctx->rate_max = sp.rate_max;
     sp.staged = false;
@@ -682,6 +766,10 @@ extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
         return fail(ctx, PXG_E_INVALID, "barcode stage needs the segment stage");
     if ((stage_mask & PXG_STAGE_SEGMENT) && !(stage_mask & PXG_STAGE_SCALER) && !ctx->have_inject)
         return fail(ctx, PXG_E_INVALID, "segment stage needs the scaler stage or injected scaling");
+    if ((stage_mask & PXG_STAGE_POLYA) && need_whole_reads(ctx, "pxg_batch_run (poly(A) stage)")) return PXG_E_STATE;
+    if (ctx->resident_limit > 0 && ctx->resident_limit < std::max(ctx->cfg.scaler_length, ctx->cfg.segmentation_scan_limit) &&
+        need_whole_reads(ctx, "pxg_batch_run (the scaler reads scaler_length, the segmentation segmentation_scan_limit samples)"))
+        return PXG_E_STATE;
     PXG_HIP(ctx, hipSetDevice(ctx->device));
     memset(ctx->ev_used, 0, sizeof(ctx->ev_used));
     memset(ctx->launches, 0, sizeof(ctx->launches));
@@ -812,6 +900,7 @@ extern "C" int pxg_batch_download_samples(pxg_ctx* ctx, int16_t* out)
 {
     if (!ctx || (!out && ctx->n_samples)) return PXG_E_INVALID;
     if (ctx->n_reads <= 0) return fail(ctx, PXG_E_STATE, "pxg_batch_download_samples: no resident batch");
+    if (need_whole_reads(ctx, "pxg_batch_download_samples")) return PXG_E_STATE;
     if (ctx->n_samples <= 0) return PXG_OK;
     PXG_HIP(ctx, hipMemcpyAsync(out, ctx->raw.p, (size_t)ctx->n_samples * sizeof(int16_t), hipMemcpyDeviceToHost,
                                 ctx->stream));
@@ -907,11 +996,15 @@ extern "C" int pxg_process_batch_ex(pxg_ctx* ctx, int64_t n_reads, const int16_t
     const double t0 = trace ? now() : 0.0;
     std::unique_lock<std::mutex> stage_lock(ctx->mt_stage);
     const double t1 = trace ? now() : 0.0;
+    // signal_analyzer.py:347-349: without poly(A) and the chimera scan no stage reads a sample behind the
+    // segmentation's scan limit (the scaler's head and the barcode window lie inside it) -- they stay on the host
+    const int64_t limit = ((stage_mask & PXG_STAGE_POLYA) || (x && x->unsplit_first_sample)) ? 0
+                          : (int64_t)std::max(ctx->cfg.scaler_length, ctx->cfg.segmentation_scan_limit);
     if (x && x->z)
-        rc = pxg_batch_stage_z(ctx, n_reads, x->z, x->z_bytes, x->chunks, x->n_chunks, x->data_base, x->dst_base,
-                               raw_offsets, calib, inject);
+        rc = pxg_batch_stage_z_prefix(ctx, n_reads, x->z, x->z_bytes, x->chunks, x->n_chunks, x->data_base, x->dst_base,
+                                      raw_offsets, calib, inject, limit);
     else
-        rc = pxg_batch_stage(ctx, n_reads, raw_arena, raw_offsets, calib, inject);
+        rc = pxg_batch_stage_prefix(ctx, n_reads, raw_arena, raw_offsets, calib, inject, limit);
     if (rc) return rc;
     const double t2 = trace ? now() : 0.0;
     std::unique_lock<std::mutex> run_lock(ctx->mt_run);      // the previous call has all its results
@@ -1234,6 +1327,7 @@ extern "C" int pxg_batch_event_table(pxg_ctx* ctx, const int64_t* first_sample, 
     HOOK_BEGIN
     const int64_t n = ctx->n_reads;
     if (n <= 0) return fail(ctx, PXG_E_STATE, "pxg_batch_event_table: no resident batch");
+    if (need_whole_reads(ctx, "pxg_batch_event_table")) return PXG_E_STATE;
     if (!(ctx->last_stage_mask & (PXG_STAGE_SCALER | PXG_STAGE_SEGMENT)))
         return fail(ctx, PXG_E_STATE, "pxg_batch_event_table: nothing has been run on the resident batch");
     if (!first_sample || !events_offsets || events_offsets[0] != 0)
@@ -1268,6 +1362,7 @@ extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
     const int64_t n = ctx->n_reads;
     if (out_total) *out_total = 0;
     if (n <= 0) return PXG_OK;
+    if (need_whole_reads(ctx, "pxg_batch_unsplit_scan")) return PXG_E_STATE;
     if (!first_sample || !n_blocks || !out_count || !out_total || cap_intervals < 0 ||
         (cap_intervals > 0 && !out_intervals))
         return fail(ctx, PXG_E_INVALID, "pxg_batch_unsplit_scan: bad arguments");

@@ -287,6 +287,7 @@ struct pxg_ctx {
         int64_t n_reads = 0, n_samples = 0;
         bool have_inject = false, staged = false;
         double rate_min = 0.0, rate_max = 0.0;
+        int64_t limit = 0;           // samples of each read that were copied (0: all)
         DevBuf<uint8_t> z;           // encoded samples of a pxg_batch_stage_z batch ...
         DevBuf<pxg_z_chunk> zchunks; // ... and their chunk records, decoded into `raw` on the copy stream
     } spare;
@@ -327,6 +328,7 @@ struct pxg_ctx {
     DevBuf<int32_t> polya_out;   // n x 8: called, n_spikes, dwell, begin lo/hi, end lo/hi, first spike row
     DevBuf<pxg_polya_spike> spikes;   // spike arena of the batch: rows handed out by K6 with one atomic per read
     int64_t spike_rows = 0;      // rows handed out by the settled run
+    int64_t resident_limit = 0;  // the resident batch holds only this many samples of each read (0: all)
     int64_t longest_read = 0, spare_longest_read = 0;   // samples of the longest read (host copy)
     std::mutex mt_err;
     std::mutex mt_stage, mt_run; // pxg_process_batch(_ex) from several host threads: spare slot / resident batch
@@ -421,7 +423,8 @@ int pxg_launch_demux_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
                           int timer_a, int timer_b);
 int pxg_launch_reset_batch(pxg_ctx* ctx, int64_t n);
 int pxg_launch_z_decode(pxg_ctx* ctx, hipStream_t stream, int64_t n_chunks, const uint8_t* z, int64_t z_bytes, const pxg_z_chunk* chunks,
-                        int64_t data_base, int64_t dst_base, int16_t* out);
+                        int64_t data_base, int64_t dst_base, int16_t* out, const int64_t* off = nullptr, int64_t n_reads = 0,
+                        int64_t prefix_limit = 0);
 int pxg_launch_finalize(pxg_ctx* ctx, int64_t n, uint32_t stage_mask);
 int pxg_lstm_upload(pxg_ctx* ctx);   // shape checks
 // PXG_LSTM_Q8 (k_lstm_q8.hip)

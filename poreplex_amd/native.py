@@ -418,6 +418,10 @@ _SIGNATURES = {
                                    C.c_void_p, C.c_void_p]),
     'pxg_batch_stage': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p]),
+    'pxg_batch_stage_prefix': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int64]),
+    'pxg_batch_stage_z_prefix': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                           C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
     'pxg_batch_download_samples': (C.c_int, [C.c_void_p, C.c_void_p]),
     'pxg_batch_stage_z': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                     C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -771,14 +775,24 @@ class NativeContext:
             _ptr(scale_shift)), 'pxg_batch_upload_tiled')
         self.n_resident = int(n_reads)
 
-    def stage(self, arena, offsets, calib, scale_shift=None):
+    def stage(self, arena, offsets, calib, scale_shift=None, prefix_limit=0):
         """Copy the NEXT batch into the spare input slot on the copy stream while the
-        resident batch computes; the arrays are kept alive until swap()."""
+        resident batch computes; the arrays are kept alive until swap().  prefix_limit > 0: only that many
+        samples of each read cross the link (include/pxg.h, pxg_batch_stage_prefix: enough for runs without
+        poly(A) / chimera scan when it is prefix_limit_for(mask))."""
         arena, offsets, calib, scale_shift, n = self._prep(arena, offsets, calib, scale_shift)
         self._staged = (arena, offsets, calib, scale_shift, n)
-        self._check(self.lib.pxg_batch_stage(
-            self.handle, n, _ptr(arena), _ptr(offsets), _ptr(calib), _ptr(scale_shift)),
+        self._check(self.lib.pxg_batch_stage_prefix(
+            self.handle, n, _ptr(arena), _ptr(offsets), _ptr(calib), _ptr(scale_shift), int(prefix_limit)),
             'pxg_batch_stage')
+
+    def prefix_limit_for(self, stage_mask, whole_read_hooks=False):
+        """Samples of a read the stages of `stage_mask` can reach (0 = all of them): without poly(A) and without
+        the hooks that walk whole reads (chimera scan, event table) nothing reads behind the segmentation's scan
+        limit (signal_analyzer.py:347-349)."""
+        if (stage_mask & STAGE_POLYA) or whole_read_hooks:
+            return 0
+        return int(max(self.cfg.scaler_length, self.cfg.segmentation_scan_limit))
 
     def download_samples(self, n_samples):
         """The resident batch's int16 samples (what stage_z decoded on the device)."""
@@ -786,9 +800,9 @@ class NativeContext:
         self._check(self.lib.pxg_batch_download_samples(self.handle, _ptr(out)), 'pxg_batch_download_samples')
         return out
 
-    def stage_z(self, enc, offsets, calib, scale_shift=None):
+    def stage_z(self, enc, offsets, calib, scale_shift=None, prefix_limit=0):
         """stage() for samples that arrive encoded (EncodedSamples): the bytes cross the link
-        and are decoded on the device into the spare input slot."""
+        and are decoded on the device into the spare input slot (prefix_limit: as in stage())."""
         offsets = np.ascontiguousarray(offsets, dtype=np.int64)
         calib = np.ascontiguousarray(calib, dtype=CALIB_DTYPE)
         n = len(offsets) - 1
@@ -799,9 +813,9 @@ class NativeContext:
         if int(offsets[-1]) != enc.n_samples:
             raise ValueError('offsets describe {} samples, the encoded slice {}'.format(int(offsets[-1]), enc.n_samples))
         self._staged = ((z, chunks), offsets, calib, scale_shift, n)
-        self._check(self.lib.pxg_batch_stage_z(
+        self._check(self.lib.pxg_batch_stage_z_prefix(
             self.handle, n, _ptr(z), len(z), _ptr(chunks), len(chunks), enc.data_base, enc.dst_base,
-            _ptr(offsets), _ptr(calib), _ptr(scale_shift)), 'pxg_batch_stage_z')
+            _ptr(offsets), _ptr(calib), _ptr(scale_shift), int(prefix_limit)), 'pxg_batch_stage_z')
 
     def swap(self):
         """Make the staged batch the resident one (waits for its copies)."""

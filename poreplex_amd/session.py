@@ -189,14 +189,21 @@ class GpuSession:
                 raise item
             return item
 
+        # without poly(A), the chimera scan and the event dump no stage reads behind the segmentation's scan
+        # limit: the tail of a longer read stays on the host (pxg_batch_stage_prefix)
+        limit = {}
+        if hasattr(self.ctx, 'prefix_limit_for'):
+            whole = bool(self.loader.scan_unsplit or self.analyzer.dump_events)
+            limit = {'prefix_limit': self.ctx.prefix_limit_for(self.loader.stage_mask, whole)}
+
         def stage(item):
             """Start the H2D copy of a packed batch into the spare input slot (copy stream)."""
             if item is not None and len(item[2]):
                 item[1].settle()
                 if isinstance(item[3], native.EncodedSamples):     # compressed bundle: bytes + chunk records
-                    self.ctx.stage_z(item[3], item[4], item[5])
+                    self.ctx.stage_z(item[3], item[4], item[5], **limit)
                 else:
-                    self.ctx.stage(item[3], item[4], item[5])
+                    self.ctx.stage(item[3], item[4], item[5], **limit)
                 return True
             return False
 

@@ -770,10 +770,14 @@ class SignalLoader:
         unlock = ctx.unlock if native_locks else (lambda w: (self._run_lock if w else self._stage_lock).release())
         lock(0)
         try:
+            limit = {}
+            if hasattr(ctx, 'prefix_limit_for'):              # (dumps and scans walk whole reads)
+                whole = bool(self.scan_unsplit or self.dump_events)
+                limit = {'prefix_limit': ctx.prefix_limit_for(self.stage_mask, whole)}
             if isinstance(arena, native.EncodedSamples):      # compressed bundle: decoded on the GPU
-                ctx.stage_z(arena, offsets, calib)
+                ctx.stage_z(arena, offsets, calib, **limit)
             else:
-                ctx.stage(arena, offsets, calib)
+                ctx.stage(arena, offsets, calib, **limit)
             lock(1)                                           # the previous call has its records
             try:
                 ctx.swap()

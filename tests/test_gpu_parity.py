@@ -785,3 +785,40 @@ def test_polya_window_larger_than_first_pass_scratch(ctx, oracle):
     for f in ('polya_called', 'polya_n_spikes', 'polya_dwell_samples', 'polya_begin', 'polya_end'):
         assert np.array_equal(res[f], want[f][ok]), f
     assert_spikes_equal(spikes, want[ok], wsp[ok])
+
+
+def test_prefix_staging_keeps_the_tail_of_long_reads_on_the_host(ctx, oracle, config):
+    """pxg_batch_stage(_z)_prefix / pxg_process_batch: without poly(A) and the chimera scan no stage reads behind the
+    segmentation's scan limit (signal_analyzer.py:347-349), so only that prefix of a long read crosses the link --
+    records identical to the whole upload's (raw and encoded samples), whole-read stages refuse such a batch."""
+    b = synth_batch(80, seed=933, length_dist='lognormal')
+    lens = np.diff(b['offsets'])
+    limit = ctx.prefix_limit_for(N.STAGE_ALL_DEMUX)
+    assert limit == 100000 and (lens > limit).sum() >= 2 and ctx.prefix_limit_for(N.STAGE_ALL_DEMUX | N.STAGE_POLYA) == 0
+    ctx.upload(b['arena'], b['offsets'], b['calib'])
+    ctx.run(N.STAGE_ALL_DEMUX)
+    want = ctx.download().copy()
+    assert_records_equal(want, oracle.process_batch(b['arena'], b['offsets'], b['calib'], None, N.STAGE_ALL_DEMUX))
+    # poison the device arena first: what is not copied must not matter
+    junk = np.full(len(b['arena']), 12345, dtype=np.int16)
+    z, chunks, _ = N.z_encode(b['arena'], b['offsets'])
+    for form in ('raw', 'encoded'):
+        ctx.stage(junk, b['offsets'], b['calib'])
+        ctx.swap()
+        ctx.stage(junk, b['offsets'], b['calib'])
+        ctx.swap()                                   # both input slots hold junk now
+        if form == 'raw':
+            ctx.stage(b['arena'], b['offsets'], b['calib'], prefix_limit=limit)
+        else:
+            ctx.stage_z(N.EncodedSamples(z, chunks, 0, 0, len(b['arena'])), b['offsets'], b['calib'], prefix_limit=limit)
+        ctx.swap()
+        ctx.run(N.STAGE_ALL_DEMUX)
+        assert_records_equal(ctx.download(), want, ctxmsg='prefix staging, ' + form)
+        with pytest.raises(N.PxgError, match='prefix limit'):
+            ctx.run(N.STAGE_ALL_DEMUX | N.STAGE_POLYA)
+        with pytest.raises(N.PxgError, match='prefix limit'):
+            ctx.download_samples(len(b['arena']))
+    # the one-call form picks the limit from its mask
+    assert_records_equal(ctx.process_batch(b['arena'], b['offsets'], b['calib'], None, N.STAGE_ALL_DEMUX), want)
+    full = ctx.process_batch(b['arena'], b['offsets'], b['calib'], None, N.STAGE_ALL_DEMUX | N.STAGE_POLYA)
+    assert_records_equal(full, oracle.process_batch(b['arena'], b['offsets'], b['calib'], None, N.STAGE_ALL_DEMUX | N.STAGE_POLYA))
