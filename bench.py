@@ -690,34 +690,55 @@ def unpinned_rows_block():
     return out
 
 
-def run_shaped_leg(args, ctx, mask, n_reads, distinct=1024):
+def run_shaped_leg(args, ctx, mask, n_reads, distinct=1024, config=None, local_rank=0):
     """The same stages over reads with a sequencing run's length distribution (synth.py length_dist=
     'lognormal'): reads/s, samples/s and the per-stage times, measured like the headline (resident batch,
-    kernels + D2H of the records)."""
+    kernels + D2H of the records) -- and once more on a context with the two exact savings such a run exposes
+    switched off (reads in length order, K2 behind the shared zero-pad prefix: DESIGN 3, round 4), records
+    compared."""
     rb = synth_batch(distinct, seed=args.seed + 77, length_dist='lognormal')
     lens = np.diff(rb['offsets'])
-    ctx.upload_tiled(n_reads, rb['arena'], rb['offsets'], rb['calib'], None, phase=0)
-    buf = np.zeros(n_reads, dtype=N.RESULT_DTYPE)
-    for _ in range(2):
-        ctx.run(mask)
-        res = ctx.download(buf)
-    ctx.sync()
-    steps = max(3, min(args.steps, 8))
-    acc = {k: 0.0 for k in N.TIMER_NAMES}
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        ctx.run(mask)
-        res = ctx.download(buf)
-        times, _ = ctx.stage_times()
-        for k in acc:
-            acc[k] += times[k]
-    ctx.sync()
-    wall = time.perf_counter() - t0
+
+    def measure(c):
+        c.upload_tiled(n_reads, rb['arena'], rb['offsets'], rb['calib'], None, phase=0)
+        buf = np.zeros(n_reads, dtype=N.RESULT_DTYPE)
+        for _ in range(2):
+            c.run(mask)
+            res = c.download(buf)
+        c.sync()
+        steps = max(3, min(args.steps, 8))
+        acc = {k: 0.0 for k in N.TIMER_NAMES}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            c.run(mask)
+            res = c.download(buf)
+            times, _ = c.stage_times()
+            for k in acc:
+                acc[k] += times[k]
+        c.sync()
+        return time.perf_counter() - t0, steps, acc, res.copy()
+
+    wall, steps, acc, res = measure(ctx)
+    plain = None
+    if config is not None:
+        os.environ['PXG_NO_LENGTH_ORDER'] = os.environ['PXG_NO_PREFIX_SKIP'] = '1'
+        try:
+            c2 = N.NativeContext(config, device_id=local_rank)
+        finally:
+            del os.environ['PXG_NO_LENGTH_ORDER'], os.environ['PXG_NO_PREFIX_SKIP']
+        try:
+            w2, s2, a2, r2 = measure(c2)
+            plain = {'reads_per_s': n_reads * s2 / w2, 'ms_per_step': w2 / s2 * 1e3,
+                     'stage_ms': {k: round(v / s2, 4) for k, v in a2.items() if k in ('scaler_lstm', 'segment', 'total')},
+                     'records_identical': bool(res.tobytes() == r2.tobytes())}
+        finally:
+            c2.close()
     tiled = lens[np.arange(n_reads) % distinct]
     return {
         'reads_per_s': n_reads * steps / wall, 'ms_per_step': wall / steps * 1e3, 'steps': steps,
         'samples_per_s': float(tiled.sum()) * steps / wall,
         'stage_ms': {k: round(v / steps, 4) for k, v in acc.items()},
+        'without_length_order_and_prefix_skip': plain,
         'reads': n_reads, 'distinct_reads': distinct, 'tiled_on_device': True,
         'length_samples': {'min': int(lens.min()), 'median': float(np.median(lens)), 'mean': float(lens.mean()),
                            'max': int(lens.max()), 'below_30000': float((lens < 30000).mean()),
@@ -1173,7 +1194,7 @@ def main():
     if not standin and world == 1 and not n_base and not args.no_run_shaped_leg and args.length_dist is None and \
             args.workload in ('demux', 'full', 'polya') and not use_inject:
         try:
-            extra['run_shaped'] = run_shaped_leg(args, ctx, mask, n_local)
+            extra['run_shaped'] = run_shaped_leg(args, ctx, mask, n_local, config=config, local_rank=local_rank)
             ctx.upload(base['arena'], base['offsets'], base['calib'], inject)        # the headline batch again
         except Exception as exc:                       # reported, never hidden
             extra['run_shaped'] = {'error': '{}: {}'.format(type(exc).__name__, exc)}

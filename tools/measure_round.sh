@@ -6,8 +6,10 @@ TAG=${1:-final}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
-B="python bench.py --cpu-sample 0 --cpu-all-cores-sample 0 --no-api-leg --no-fast5-leg --no-e2e-leg"
+B="python bench.py --cpu-sample 0 --cpu-all-cores-sample 0 --no-api-leg --no-fast5-leg --no-e2e-leg --no-f32-leg --no-run-shaped-leg"
+T0=$(date +%s)
 python bench.py --steps 20 --warmup 5 > $OUT/bench_demux.json 2> $OUT/bench_demux.err          # the driver's form
+echo "driver form: $(( $(date +%s) - T0 )) s" > $OUT/wallclock.txt
 for w in segment polya chimera full; do
   $B --workload $w --steps 10 --warmup 3 > $OUT/bench_$w.json 2> $OUT/bench_$w.err
 done
@@ -26,6 +28,14 @@ for c in none vbz gzip; do
   $B --end-to-end --from-fast5 $c --reads $r --batch-reads 10000 > $OUT/bench_end_to_end_fast5_$c.json 2>> $OUT/e2e.err
 done
 python tools/fast5_ingest_profile.py 10000 > $OUT/fast5_ingest_profile.txt 2>&1
+# round 4: the float32 arithmetic, run-shaped lengths, the bare --gpus 8 command under the driver's clock
+$B --lstm-arith f32 --steps 10 --warmup 3 > $OUT/bench_demux_f32_arith.json 2> $OUT/f32.err
+$B --length-dist lognormal --steps 10 --warmup 3 > $OUT/bench_demux_lognormal.json 2> $OUT/lognormal.err
+$B --length-dist lognormal --workload full --steps 10 --warmup 3 > $OUT/bench_full_lognormal.json 2>> $OUT/lognormal.err
+python bench.py --api process_batch --length-dist lognormal --in-flight 5 --api-calls 24 --cpu-sample 0 --cpu-all-cores-sample 0 --no-overlap-test --no-fast5-leg --no-e2e-leg --no-f32-leg --no-run-shaped-leg > $OUT/bench_api_process_batch_lognormal.json 2>> $OUT/api.err
+T1=$(date +%s)
+PXG_BENCH_SHARE_GPU=1 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 8 --steps 20 --warmup 5 > $OUT/bench_8_ranks_sharing_one_gpu.json 2> $OUT/share8.err
+echo "bare --gpus 8 (--steps 20 --warmup 5) with 8 ranks on ONE GPU: $(( $(date +%s) - T1 )) s" >> $OUT/wallclock.txt
 PXG_BENCH_FORCE_DIST=1 python bench.py --steps 10 --warmup 3 --cpu-sample 128 --cpu-all-cores-sample 0 --no-api-leg --no-fast5-leg --no-e2e-leg > $OUT/bench_force_dist_one_gpu.json 2> $OUT/dist.err
 bash tools/prof.sh ${TAG}_demux > /dev/null 2>&1
 bash tools/prof.sh ${TAG}_full --workload full > /dev/null 2>&1
