@@ -55,7 +55,7 @@ PEAK_HBM = 8.0e12              # B/s
 # the only throughput the reference publishes (Poreplex 0.1, whole
 # pipeline incl. FAST5 I/O, 2x Xeon E5-2687W v3 = 20 cores): 1 339 070 reads in 1 h 37 min
 PUBLISHED_READS_PER_S = 1339070 / (97 * 60.0)
-TRAFFIC_FILE = os.path.join('profiles', 'r04', 'b_hbm_traffic.json')
+TRAFFIC_FILE = os.path.join('profiles', 'r04', 'd_hbm_traffic.json')
 # PXG_BENCH_SHARE_GPU=1: every rank of a torchrun launch uses GPU 0 and the collectives go over gloo --
 # the real multi-process path (sharding, barriers, max over ranks, label gather, NUMA binding, the
 # host-side legs on all ranks at once) with the real kernels on a ONE-GPU box.  A plumbing check:
@@ -593,17 +593,31 @@ def strong_leg(args, ctx, dist, rank, world, mask, standin, force_dist, barrier)
     read i = distinct read i mod K, rank r owns shard_range(total, r, N) and tiles its shard on
     the device; every step gathers the label records of the whole run."""
     total = args.total_reads
+    if SHARE_GPU:                      # the ranks' shards share ONE GPU's HBM here: a quarter of the run
+        total = min(total, 250000)
     lo, hi = shard_range(total, rank, world)
     n_local = hi - lo
     sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
     K = max(1, min(args.strong_base_reads, total))
     base = synth_batch(K, seed=args.seed, samples_per_read=args.samples)      # the same on every rank
-    ctx.upload_tiled(n_local, base['arena'], base['offsets'], base['calib'], None, phase=lo % K)
     res_buf = np.zeros(n_local, dtype=N.RESULT_DTYPE)
-    if not standin:
-        ctx.pin(res_buf)
-    ctx.run(mask)
-    res = ctx.download(res_buf)
+    failure = None
+    try:                               # a rank that cannot hold its shard must not leave the others in a collective
+        ctx.upload_tiled(n_local, base['arena'], base['offsets'], base['calib'], None, phase=lo % K)
+        if not standin:
+            ctx.pin(res_buf)
+        ctx.run(mask)
+        res = ctx.download(res_buf)
+    except Exception as exc:
+        failure = '{}: {}'.format(type(exc).__name__, exc)
+    if dist is not None:
+        import torch
+        ok = torch.tensor([0 if failure else 1], dtype=torch.int32, device=collective_device(standin))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and failure is None:
+            failure = 'another rank could not hold its shard'
+    if failure:
+        return {'value': None, 'error': failure, 'total_reads': total, 'reads_per_gpu': sizes}
     labels = gather_labels(res, dist, first_index=lo, sizes=sizes, force=force_dist)
     barrier()
     steps = max(2, min(args.steps, 3))
@@ -631,8 +645,8 @@ def strong_leg(args, ctx, dist, rank, world, mask, standin, force_dist, barrier)
 FLIPS_FILE = os.path.join('profiles', 'r04', 'decision_flips.json')
 FLIPS_GPU_FILE = os.path.join('profiles', 'r04', 'decision_flips_gpu.json')
 BOUNDS_FILE = os.path.join('profiles', 'r04', 'full_kernel_bounds.json')
-ROCPROF_STATS = {'demux': os.path.join('profiles', 'r04', 'b_demux_kernel_stats.csv'),
-                 'full': os.path.join('profiles', 'r04', 'b_full_kernel_stats.csv')}
+ROCPROF_STATS = {'demux': os.path.join('profiles', 'r04', 'd_demux_kernel_stats.csv'),
+                 'full': os.path.join('profiles', 'r04', 'd_full_kernel_stats.csv')}
 
 
 def unpinned_rows_block():
