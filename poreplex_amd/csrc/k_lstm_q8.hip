@@ -876,11 +876,10 @@ static int q8_scaler_launch(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, co
         (rc = pxg_reserve(ctx, ctx->lstm_state, (size_t)2 * tiles * Q8S_STATE)))
         return rc;
     PXG_HIP(ctx, hipMemsetAsync(ctx->lstm_q.p, 0, (size_t)(2 + tiles) * sizeof(int), ctx->stream));
-    static int qbs;
     const char* forced = getenv("PXG_SCALER_BLOCK_STEPS");           // tuning knob: steps per task of K2
     if (traj_out || forced) {
-        qbs = traj_out ? Q8S_TRAJ : atoi(forced);
-        PXG_HIP(ctx, hipMemcpyAsync(ctx->lstm_q.p + 1, &qbs, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        ctx->q8.forced_block_steps = traj_out ? Q8S_TRAJ : atoi(forced);      // (the copy reads it later: a field of the context, not a local)
+        PXG_HIP(ctx, hipMemcpyAsync(ctx->lstm_q.p + 1, &ctx->q8.forced_block_steps, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     }
     const unsigned* traj = (!traj_out && off && ctx->prefix_skip) ? reinterpret_cast<const unsigned*>(ctx->scaler_traj.p) : nullptr;
     const size_t lds = sizeof(float) * 4 * PXG_SIG_NSEG + 4 * Q8_HVEC + sizeof(float) * 16 * XS + 16 * 3 * 48 +

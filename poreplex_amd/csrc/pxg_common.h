@@ -265,6 +265,7 @@ struct pxg_ctx {
         int8_t* bidir_frag = nullptr;
         int8_t* top_frag = nullptr;
         float s_scaler1 = 0, s_scaler2 = 0, s_fwd = 0, s_bwd = 0, s_top = 0;   // 16 * 2^(-p-14) per layer
+        int forced_block_steps = 0;      // host copy of K2's steps-per-task override (trajectory recording, tuning knob)
     } q8;
     double* d_calibration = nullptr;
     float* d_sigtab = nullptr;   // PXG_SIG_NSEG x 4 spline coefficients
