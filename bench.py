@@ -643,7 +643,7 @@ def strong_leg(args, ctx, dist, rank, world, mask, standin, force_dist, barrier)
 
 
 FLIPS_FILE = os.path.join('profiles', 'r04', 'decision_flips.json')
-FLIPS_GPU_FILE = os.path.join('profiles', 'r04', 'decision_flips_gpu.json')
+FLIPS_GPU_FILE = os.path.join('profiles', 'r04', 'decision_flips_gpu_160k_reads.json')
 BOUNDS_FILE = os.path.join('profiles', 'r04', 'full_kernel_bounds.json')
 ROCPROF_STATS = {'demux': os.path.join('profiles', 'r04', 'd_demux_kernel_stats.csv'),
                  'full': os.path.join('profiles', 'r04', 'd_full_kernel_stats.csv')}
