@@ -105,7 +105,9 @@ __device__ __forceinline__ int scaler_block_steps(int n_tiles, int slots, int T1
     for (int nb = 1; nb <= SQ_MAXBLK; nb++) {
         const int qb = (((T1 + nb - 1) / nb) + 3) & ~3;
         const int blocks = (T1 + qb - 1) / qb;
-        const int rounds = (blocks * n_tiles + slots - 1) / slots;
+        // (the blocks of ONE tile run one after the other: with fewer tiles than slots the chain, not the rounds, is
+        //  the launch's length -- a small batch takes its tiles whole)
+        const int rounds = max((blocks * n_tiles + slots - 1) / slots, blocks);
         const int cost = rounds * (qb + SQ_HANDOVER);
         if (cost < best_cost) { best_cost = cost; best = qb; }
     }
@@ -130,7 +132,8 @@ __device__ __forceinline__ int demux_blocks(int n_tiles, int slots, int T)
     for (int nb = 1; nb <= DQ_MAXBLK; nb++) {
         const int tasks = nb * n_tiles;
         const int full = tasks / slots, rem = tasks - full * slots;
-        const float rounds = (float)full + (rem == 0 ? 0.0f : (2 * rem <= slots ? 0.5f : 1.0f));
+        const float rounds = fmaxf((float)full + (rem == 0 ? 0.0f : (2 * rem <= slots ? 0.5f : 1.0f)),
+                                   nb > 1 ? (float)nb : 0.0f);      // a tile's blocks are a chain
         const float cost = rounds * (float)((T + nb - 1) / nb) + (float)((nb - 1) * DQ_HANDOVER);
         if (cost < 0.96f * best_cost) { best_cost = cost; best = nb; }      // more blocks must pay clearly
     }
