@@ -426,6 +426,13 @@ def process_batch_leg(args, base, which, lo, mask, local_rank, compressed, resid
                'dict_builder': 'csrc/_pxgpy' if N.load_pyhost() is not None else 'python loop',
                'results_identical_across_calls': bool(verdict['same']),
                'mean_phase_ms_per_call': {k: (round(v, 2) if v is not None else None) for k, v in phases.items()}}
+        try:                               # small calls that met in the pipeline ran as one batch (include/pxg.h)
+            probe = SA.SignalAnalyzer(cfg, 0)
+            groups, merged = probe.ctx.merge_stats()
+            probe.close()
+            out['merge_stats'] = {'batches': groups, 'calls_they_carried': merged}
+        except Exception:
+            pass
         if resident_records is not None and len(resident_records) == n:
             # the dicts against the records of the resident loop (same reads, same stages)
             st = [N.STATUS_NAMES[c] for c in resident_records['status'].tolist()]

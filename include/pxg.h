@@ -319,6 +319,15 @@ typedef struct {
 int pxg_process_batch_ex(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena_or_null,
                          const int64_t* raw_offsets, const pxg_calib* calib, uint32_t stage_mask,
                          pxg_batch_extras* extras_or_null, pxg_read_result* out);
+/* SMALL CALLS SHARE A BATCH.  The reference hands a worker 128 reads at a time (commandline.py:402 `--batch-size`),
+ * and 128 reads cost the kernels what 4 000 cost (their latency floor, ~5.5 ms).  Calls of at most 4 096 reads with
+ * plain inputs (int16 samples; no injected scaling, encoded samples, window scan or spike rows) that arrive from
+ * several threads while the pipeline is full -- one batch computing, one staged -- are gathered and run as ONE
+ * batch: the first caller of a group waits for the spare slot on everybody's behalf, copies each call's samples
+ * from where they lie, runs the stages and hands every call its slice of the records.  A lone call starts at once;
+ * groups grow with the load.  Records are those of separate calls (each is a function of its read alone).
+ * pxg_merge_stats: groups run so far and the calls they carried (PXG_NO_CALL_MERGE=1 at pxg_create switches it off). */
+int pxg_merge_stats(pxg_ctx* ctx, int64_t* groups, int64_t* calls);
 
 /* Split form for device-resident batches (loader overlap, benchmarking):
  * upload = H2D copy into context-owned HBM arenas; run = enqueue all kernels

@@ -249,6 +249,7 @@ extern "C" int pxg_create(const pxg_config* cfg, pxg_ctx** out)
         // measurement knobs (results never depend on them; tests/test_gpu_parity.py checks that)
         ctx->length_order = getenv("PXG_NO_LENGTH_ORDER") == nullptr;
         ctx->prefix_skip = getenv("PXG_NO_PREFIX_SKIP") == nullptr;
+        ctx->merge_small_calls = getenv("PXG_NO_CALL_MERGE") == nullptr;
         if (cfg->lstm_arith == PXG_LSTM_Q8 && (rc = pxg_q8_scaler_trajectory(ctx))) break;
     } while (0);
     // host pointers in the copied config are not retained
@@ -971,6 +972,138 @@ extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
                                       int32_t block_stride, int64_t cap_intervals, int64_t* out_intervals,
                                       int32_t* out_count, int64_t* out_total);
 
+// ---- small calls share a batch -----------------------------------------------------------------------
+// A call of at most PXG_MERGE_MAX_READS reads with plain inputs (int16 samples, no injected scaling, no window
+// scan, no spike rows) joins the group that is waiting for the spare input slot.  The first caller of a group leads:
+// it waits for the slot -- which is exactly as long as the pipeline is full (one batch computing, one staged), so
+// groups grow with the load and a lone call starts at once --, takes everything that has gathered, stages the
+// reads of all calls back to back (each call's arena is copied from where it lies), runs the batch, and hands
+// every call its slice of the records.  Results are those of separate calls: every record is a function of its
+// read alone (tests/test_gpu_parity.py::test_small_calls_are_merged_into_one_batch).
+#define PXG_MERGE_MAX_READS 4096
+
+static int merged_process(pxg_ctx* ctx, pxg_ctx::MergeItem& mine, uint32_t stage_mask, bool& bypass)
+{
+    auto& mq = ctx->merge;
+    bypass = false;
+    std::unique_lock<std::mutex> lk(mq.m);
+    if (!mq.pending.empty() && mq.mask != stage_mask) {       // another stage mask is gathering: go alone
+        bypass = true;
+        return PXG_OK;
+    }
+    mq.pending.push_back(&mine);
+    mq.mask = stage_mask;
+    if (mq.leader) {
+        mq.cv.wait(lk, [&] { return mine.done; });
+        return mine.rc;
+    }
+    mq.leader = true;
+    lk.unlock();
+    std::unique_lock<std::mutex> stage_lock(ctx->mt_stage);   // <- the group grows while this waits
+    lk.lock();
+    std::vector<pxg_ctx::MergeItem*> items;
+    items.swap(mq.pending);
+    mq.leader = false;
+    mq.groups++;
+    mq.calls += (int64_t)items.size();
+    lk.unlock();
+
+    int rc = PXG_OK;
+    std::unique_lock<std::mutex> run_lock(ctx->mt_run, std::defer_lock);
+    do {
+        int64_t n = 0, n_samples = 0, zb = 0, zc = 0;
+        for (auto* it : items) {
+            n += it->n;
+            n_samples += it->off[it->n];
+            if (!it->arena) { zb += it->z_bytes; zc += it->n_chunks; }
+        }
+        mq.h_off.resize((size_t)n + 1);
+        mq.h_cal.resize((size_t)n);
+        int64_t r = 0, s0 = 0;
+        for (auto* it : items) {
+            for (int64_t i = 0; i < it->n; i++) mq.h_off[(size_t)(r + i)] = s0 + it->off[i];
+            memcpy(mq.h_cal.data() + r, it->cal, (size_t)it->n * sizeof(pxg_calib));
+            r += it->n;
+            s0 += it->off[it->n];
+        }
+        mq.h_off[(size_t)n] = n_samples;
+        if ((rc = hipSetDevice(ctx->device) == hipSuccess ? PXG_OK : fail(ctx, PXG_E_HIP, "hipSetDevice"))) break;
+        auto& sp = ctx->spare;
+        sp.staged = false;
+        if ((rc = pxg_reserve(ctx, sp.raw, (size_t)n_samples + 64)) || (rc = pxg_reserve(ctx, sp.offsets, (size_t)n + 1)) ||
+            (rc = pxg_reserve(ctx, sp.calib, (size_t)n)) || (rc = pxg_reserve(ctx, sp.inject, (size_t)n * 2)) ||
+            (zc && ((rc = pxg_reserve(ctx, sp.z, (size_t)zb + 16)) || (rc = pxg_reserve(ctx, sp.zchunks, (size_t)zc + 1)))))
+            break;
+        hipStream_t cs = ctx->copy_stream;
+        if (ctx->run_recorded[ctx->cur ^ 1] &&
+            hipStreamWaitEvent(cs, ctx->ev_run_done[ctx->cur ^ 1], 0) != hipSuccess) { rc = fail(ctx, PXG_E_HIP, "hipStreamWaitEvent"); break; }
+        const int64_t limit = ((stage_mask & PXG_STAGE_POLYA) || zc) ? 0 : (int64_t)std::max(ctx->cfg.scaler_length, ctx->cfg.segmentation_scan_limit);
+        s0 = 0;
+        int64_t z0 = 0, c0 = 0;
+        for (auto* it : items) {
+            if (it->arena) {
+                if (it->off[it->n] && (rc = copy_read_prefixes(ctx, cs, sp.raw.p + s0, it->arena, it->off, it->n, limit))) break;
+            } else if (it->n_chunks) {
+                // an encoded call: its bytes and chunk records behind the others', decoded with ITS bases into its
+                // stretch of the arena (whole reads: the prefix rule is for calls that come alone)
+                if ((it->z_bytes && hipMemcpyAsync(sp.z.p + z0, it->z, (size_t)it->z_bytes, hipMemcpyHostToDevice, cs) != hipSuccess) ||
+                    hipMemcpyAsync(sp.zchunks.p + c0, it->chunks, (size_t)it->n_chunks * sizeof(pxg_z_chunk), hipMemcpyHostToDevice, cs) != hipSuccess) {
+                    rc = fail(ctx, PXG_E_HIP, "merged stage: copy of encoded samples");
+                    break;
+                }
+                if ((rc = pxg_launch_z_decode(ctx, cs, it->n_chunks, sp.z.p + z0, it->z_bytes, sp.zchunks.p + c0, it->data_base,
+                                              it->dst_base, sp.raw.p + s0)))
+                    break;
+                z0 += it->z_bytes;
+                c0 += it->n_chunks;
+            }
+            s0 += it->off[it->n];
+        }
+        if (rc) break;
+        if (hipMemcpyAsync(sp.offsets.p, mq.h_off.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, cs) != hipSuccess ||
+            hipMemcpyAsync(sp.calib.p, mq.h_cal.data(), (size_t)n * sizeof(pxg_calib), hipMemcpyHostToDevice, cs) != hipSuccess ||
+            hipEventRecord(ctx->ev_staged, cs) != hipSuccess) { rc = fail(ctx, PXG_E_HIP, "merged stage: copy"); break; }
+        sp.limit = limit;
+        sp.have_inject = false;
+        sp.n_reads = n;
+        sp.n_samples = n_samples;
+        ctx->spare_longest_read = longest_of(mq.h_off.data(), n);
+        rate_range(mq.h_cal.data(), n, sp.rate_min, sp.rate_max);
+        sp.staged = true;
+        run_lock.lock();                              // the previous batch has all its results
+        rc = pxg_batch_swap(ctx);
+        stage_lock.unlock();                          // the next group (or call) may start its copy
+        if (rc) break;
+        if ((rc = pxg_batch_run(ctx, stage_mask))) break;
+        mq.h_out.resize((size_t)n);
+        if ((rc = pxg_batch_download(ctx, mq.h_out.data()))) break;
+        r = 0;
+        for (auto* it : items) {
+            memcpy(it->out, mq.h_out.data() + r, (size_t)it->n * sizeof(pxg_read_result));
+            r += it->n;
+        }
+    } while (0);
+    if (run_lock.owns_lock()) run_lock.unlock();
+    if (stage_lock.owns_lock()) stage_lock.unlock();
+    lk.lock();
+    for (auto* it : items) {
+        it->rc = rc;
+        it->done = true;
+    }
+    lk.unlock();
+    mq.cv.notify_all();
+    return rc;
+}
+
+extern "C" int pxg_merge_stats(pxg_ctx* ctx, int64_t* groups, int64_t* calls)
+{
+    if (!ctx || !groups || !calls) return PXG_E_INVALID;
+    std::lock_guard<std::mutex> g(ctx->merge.m);
+    *groups = ctx->merge.groups;
+    *calls = ctx->merge.calls;
+    return PXG_OK;
+}
+
 // One call per worker batch, from any number of host threads (include/pxg.h): the spare input
 // slot belongs to one call from its copy to its swap (mt_stage), the resident batch and every
 // per-batch intermediate from the swap to the last download (mt_run); always taken in this order.
@@ -989,6 +1122,22 @@ extern "C" int pxg_process_batch_ex(pxg_ctx* ctx, int64_t n_reads, const int16_t
     if (!out) return fail(ctx, PXG_E_INVALID, "pxg_process_batch: out is null");
     const float* inject = x ? x->scale_shift_or_null : nullptr;
     int rc;
+    const bool encoded = x && x->z;
+    if (ctx->merge_small_calls && n_reads <= PXG_MERGE_MAX_READS && (raw_arena || encoded) && !inject &&
+        !(x && (x->unsplit_first_sample || (x->spike_offsets && (stage_mask & PXG_STAGE_POLYA))))) {
+        if ((rc = check_batch_args(ctx, n_reads, encoded ? (const int16_t*)x->z : raw_arena, raw_offsets, calib, "pxg_process_batch")))
+            return rc;
+        if (encoded && (x->z_bytes < 0 || x->n_chunks < 0 || (x->n_chunks && !x->chunks) ||
+                        pxg_z_check(x->n_chunks, x->chunks, x->data_base, x->z_bytes, x->dst_base, raw_offsets[n_reads]) != PXG_OK))
+            return fail(ctx, PXG_E_INVALID, "pxg_batch_stage_z: the chunk records do not describe this byte "
+                                            "stream / sample arena (truncated or corrupt bundle)");
+        pxg_ctx::MergeItem item = { n_reads, encoded ? nullptr : raw_arena, raw_offsets, calib, out,
+                                    encoded ? x->z : nullptr, encoded ? x->z_bytes : 0, encoded ? x->chunks : nullptr,
+                                    encoded ? x->n_chunks : 0, encoded ? x->data_base : 0, encoded ? x->dst_base : 0, PXG_OK, false };
+        bool bypass = false;
+        rc = merged_process(ctx, item, stage_mask, bypass);
+        if (!bypass) return rc;
+    }
     // PXG_TRACE=1: one stderr line per call with the milliseconds spent waiting for the spare slot,
     // copying, waiting for the resident batch, computing and downloading
     static const bool trace = getenv("PXG_TRACE") != nullptr;

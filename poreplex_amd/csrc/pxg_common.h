@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <mutex>
+#include <condition_variable>
 #include <string>
 #include <vector>
 #include "../../include/pxg.h"
@@ -332,6 +333,27 @@ struct pxg_ctx {
     int64_t resident_limit = 0;  // the resident batch holds only this many samples of each read (0: all)
     int64_t longest_read = 0, spare_longest_read = 0;   // samples of the longest read (host copy)
     std::mutex mt_err;
+    // Small pxg_process_batch calls that arrive while the pipeline is full are run as ONE batch (pxg_api.hip,
+    // merged_process): the reference hands its workers 128 reads at a time (commandline.py:402), and a 128-read
+    // batch costs the latency floor of the kernels (5.5 ms) like a 4 000-read one.
+    struct MergeItem {
+        int64_t n; const int16_t* arena; const int64_t* off; const pxg_calib* cal; pxg_read_result* out;
+        // arena == NULL: the samples arrive encoded (pxg_batch_stage_z's arguments)
+        const uint8_t* z; int64_t z_bytes; const pxg_z_chunk* chunks; int64_t n_chunks, data_base, dst_base;
+        int rc; bool done;
+    };
+    struct {
+        std::mutex m;
+        std::condition_variable cv;
+        std::vector<MergeItem*> pending;
+        uint32_t mask = 0;
+        bool leader = false;                 // a caller is waiting for the spare slot on behalf of `pending`
+        std::vector<int64_t> h_off;          // merged offsets / calibration / records of the group in flight
+        std::vector<pxg_calib> h_cal;
+        std::vector<pxg_read_result> h_out;
+        int64_t groups = 0, calls = 0;       // statistics: groups run, calls they carried
+    } merge;
+    bool merge_small_calls = true;           // PXG_NO_CALL_MERGE=1 at pxg_create: every call is its own batch
     std::mutex mt_stage, mt_run; // pxg_process_batch(_ex) from several host threads: spare slot / resident batch
     bool polya_ran = false;
     DevBuf<int64_t> ev_first, ev_off;   // K7: per-read first sample / event offsets

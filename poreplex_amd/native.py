@@ -436,6 +436,7 @@ _SIGNATURES = {
     'pxg_batch_download_spikes': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'pxg_process_batch_ex': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                        C.POINTER(PxgBatchExtras), C.c_void_p]),
+    'pxg_merge_stats': (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'pxg_batch_times': (C.c_int, [C.c_void_p, C.POINTER(PxgStageTimes)]),
     'pxg_raw_to_pa': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     'pxg_head_pool': (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -941,6 +942,13 @@ class NativeContext:
             np.cumsum(np.maximum(cnt, 0), out=start[1:])
             res['unsplit'] = (iv[:int(x.unsplit_total)], cnt, start)
         return res
+
+    def merge_stats(self):
+        """(groups, calls): merged batches run so far and the small process_batch calls they carried
+        (include/pxg.h, "small calls share a batch")."""
+        g, c = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.pxg_merge_stats(self.handle, C.byref(g), C.byref(c)), 'pxg_merge_stats')
+        return int(g.value), int(c.value)
 
     def stage_times(self):
         t = PxgStageTimes()

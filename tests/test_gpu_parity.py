@@ -822,3 +822,52 @@ def test_prefix_staging_keeps_the_tail_of_long_reads_on_the_host(ctx, oracle, co
     assert_records_equal(ctx.process_batch(b['arena'], b['offsets'], b['calib'], None, N.STAGE_ALL_DEMUX), want)
     full = ctx.process_batch(b['arena'], b['offsets'], b['calib'], None, N.STAGE_ALL_DEMUX | N.STAGE_POLYA)
     assert_records_equal(full, oracle.process_batch(b['arena'], b['offsets'], b['calib'], None, N.STAGE_ALL_DEMUX | N.STAGE_POLYA))
+
+
+def test_small_calls_are_merged_into_one_batch(ctx, oracle):
+    """The reference's workers get 128 reads per call (commandline.py:402); calls that arrive from several threads
+    while the pipeline is full run as ONE batch (include/pxg.h "small calls share a batch").  48 calls of 1 .. 300
+    reads from 12 threads, two stage masks mixed in: every call gets exactly the records a call of its own gets,
+    and calls were in fact merged."""
+    import threading
+    b = synth_batch(1500, seed=941, samples_per_read=20000, jitter=0.5, short_fraction=0.03)
+    o = b['offsets']
+    want = ctx.process_batch(b['arena'], o, b['calib'])           # one call on its own
+    assert_records_equal(want[:200], oracle.process_batch(b['arena'][:o[200]], o[:201], b['calib'][:200]))
+    rng = np.random.default_rng(3)
+    cuts = np.sort(rng.choice(np.arange(1, 1500), 47, replace=False))
+    spans = list(zip(np.r_[0, cuts], np.r_[cuts, 1500]))
+    masks = [N.STAGE_ALL_DEMUX if k % 7 else (N.STAGE_SCALER | N.STAGE_SEGMENT) for k in range(len(spans))]
+    got, errors = [None] * len(spans), []
+    g0, c0 = ctx.merge_stats()
+
+    z, chunks, cbase = N.z_encode(b['arena'], o)
+
+    def worker(ks):
+        try:
+            for k in ks:
+                lo, hi = spans[k]
+                if k % 3 == 1:            # every third call brings its samples encoded (decoded into its stretch of the batch)
+                    c0, c1 = int(cbase[lo]), int(cbase[hi])
+                    b0 = int(chunks['data_off'][c0]) if c0 < len(chunks) else len(z)
+                    b1 = int(chunks['data_off'][c1]) if c1 < len(chunks) else len(z)
+                    enc = N.EncodedSamples(z[b0:b1], chunks[c0:c1], b0, int(o[lo]), int(o[hi] - o[lo]))
+                    got[k] = ctx.process_batch_ex(enc, o[lo:hi + 1] - o[lo], b['calib'][lo:hi], masks[k])['records']
+                    continue
+                got[k] = ctx.process_batch(b['arena'][o[lo]:o[hi]], o[lo:hi + 1] - o[lo], b['calib'][lo:hi], None, masks[k])
+        except BaseException as exc:      # noqa: B902 (reported below)
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(range(t, len(spans), 12),)) for t in range(12)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    seg_only = ctx.process_batch(b['arena'], o, b['calib'], None, N.STAGE_SCALER | N.STAGE_SEGMENT)
+    for k, (lo, hi) in enumerate(spans):
+        ref = want if masks[k] == N.STAGE_ALL_DEMUX else seg_only
+        assert_records_equal(got[k], ref[lo:hi], ctxmsg='merged call %d' % k)
+    g1, c1 = ctx.merge_stats()
+    # fewer batches than calls: merging happened (calls that met a group of the OTHER stage mask went alone, uncounted)
+    assert c1 - c0 >= 24 and g1 - g0 < c1 - c0, (g0, c0, g1, c1)
