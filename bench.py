@@ -1238,6 +1238,13 @@ def main():
             extra['process_batch_reads_per_s'] = api['raw']['reads_per_s']
             extra['process_batch_encoded_bundle_reads_per_s'] = api['encoded']['reads_per_s']
             extra['process_batch'] = api
+            if args.api != 'process_batch' and len(which) >= 128:
+                # the reference's OWN batch size (commandline.py:402: 128 reads per call) from 32 worker threads:
+                # calls that meet in the pipeline run as one GPU batch (include/pxg.h "small calls share a batch")
+                small = copy.copy(args)
+                small.in_flight, small.api_calls = 32, 320
+                api['reference_batch_size_128'] = process_batch_leg(small, base, which[:128], lo, mask, local_rank, False, res[:128])
+                extra['process_batch_128_read_calls_reads_per_s'] = api['reference_batch_size_128']['reads_per_s']
         except Exception as exc:                       # reported, never hidden
             extra['process_batch_reads_per_s'] = None
             extra['process_batch_error'] = '{}: {}'.format(type(exc).__name__, exc)
