@@ -167,6 +167,17 @@ void pxo_sigmoid_table(float* out)
     }
 }
 
+/* Position of a look-up argument inside its table segment: u - floor(u), kept BELOW 1 -- for a tiny negative u
+ * (-2^-25 < u < 0) the float subtraction u - (-1) rounds to 1.0, which is not a position inside segment -1; the
+ * definition takes the largest float below 1 there.  (This is what the GPU's v_fract_f32 returns for every float,
+ * checked exhaustively: tools/ubench/fract_check.hip; rounds 1-3 evaluated the segment's cubic AT 1.0 in that case,
+ * about twice per 10 000-read batch.) */
+static inline float sig_position(float u, float fl)
+{
+    const float s = u - fl;
+    return s >= 1.0f ? 0.99999994f : s;
+}
+
 /* sigmoid(zscale/16 * z): zscale = 16 for the gates, 32 inside tanh */
 static inline float sig_lookup(float z, float zscale, float zlo, float zhi)
 {
@@ -177,7 +188,7 @@ static inline float sig_lookup(float z, float zscale, float zlo, float zhi)
     z = fminf(fmaxf(z, zlo), zhi);
     const float u = z * zscale;
     const float fl = floorf(u);
-    const float s = u - fl;
+    const float s = sig_position(u, fl);
     const float* c = g_sig_tab[(int)fl + SIG_HALF];
     float p = fmaf(c[3], s, c[2]);
     p = fmaf(p, s, c[1]);
@@ -406,7 +417,7 @@ static inline float sig_lookup_u(float u)
     }
     u = fminf(fmaxf(u, -512.0f), 511.99997f);
     const float fl = floorf(u);
-    const float s = u - fl;
+    const float s = sig_position(u, fl);
     const float* c = g_sig_tab[(int)fl + SIG_HALF];
     float p = fmaf(c[3], s, c[2]);
     p = fmaf(p, s, c[1]);

@@ -47,9 +47,8 @@ __device__ __forceinline__ void cells_update(const float4* tab, const f32x4 (&ac
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const float u = __builtin_amdgcn_fmed3f(acc[nt][r], -512.0f, 511.99997f);
-            const float fl = __builtin_floorf(u);
-            s[nt][r] = u - fl;
-            c[nt][r] = tab[(int)fl + PXG_SIG_HALF];
+            s[nt][r] = pxg_sig_position(u);
+            c[nt][r] = tab[pxg_sig_segment(u) + PXG_SIG_HALF];
         }
     float s2[NT], og[NT];
     float4 c2[NT];
@@ -69,9 +68,8 @@ __device__ __forceinline__ void cells_update(const float4* tab, const f32x4 (&ac
         C[nt] = cn;
         og[nt] = g[3];
         const float u = __builtin_amdgcn_fmed3f(cn, -512.0f, 511.99997f);
-        const float fl = __builtin_floorf(u);
-        s2[nt] = u - fl;
-        c2[nt] = tab[(int)fl + PXG_SIG_HALF];
+        s2[nt] = pxg_sig_position(u);
+        c2[nt] = tab[pxg_sig_segment(u) + PXG_SIG_HALF];
     }
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {

@@ -31,14 +31,29 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PXG_SIG_NSEG 1024
 #define PXG_SIG_HALF 512
 
+// Segment and position of a look-up argument u (table units, already clamped to the table): floor(u) as the
+// index, u - floor(u) as the position -- ONE instruction each.  v_fract_f32 is min(RN(u - floor(u)), 0x1.fffffep-1f)
+// and v_cvt_flr_i32_f32 is (int)floor(u) for EVERY float with |u| <= 1024 (tools/ubench/fract_check.hip, all 2.3e9 of
+// them, profiles/r04/ubench_fract_check.txt); the clamp below 1 (u a tiny negative number: u + 1 rounds to 1) is part
+// of the arithmetic's definition (oracle/pxo_core.c sig_position).  v_floor + v_sub + v_cvt were three.
+__device__ __forceinline__ int pxg_sig_segment(float u)
+{
+    int i;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(i) : "v"(u));
+    return i;
+}
+__device__ __forceinline__ float pxg_sig_position(float u)
+{
+    return __builtin_amdgcn_fractf(u);
+}
+
 __device__ __forceinline__ float pxg_sig_lookup(const float4* tab, float z, float zscale,
                                                 float zlo, float zhi)
 {
     z = __builtin_amdgcn_fmed3f(z, zlo, zhi);
     const float u = z * zscale;
-    const float fl = __builtin_floorf(u);
-    const float s = u - fl;
-    const float4 c = tab[(int)fl + PXG_SIG_HALF];
+    const float s = pxg_sig_position(u);
+    const float4 c = tab[pxg_sig_segment(u) + PXG_SIG_HALF];
     float p = __builtin_fmaf(c.w, s, c.z);
     p = __builtin_fmaf(p, s, c.y);
     return __builtin_fmaf(p, s, c.x);
@@ -50,9 +65,8 @@ __device__ __forceinline__ float pxg_sig_lookup(const float4* tab, float z, floa
 __device__ __forceinline__ float pxg_sig_lookup_u(const float4* tab, float u)
 {
     u = __builtin_amdgcn_fmed3f(u, -512.0f, 511.99997f);
-    const float fl = __builtin_floorf(u);
-    const float s = u - fl;
-    const float4 c = tab[(int)fl + PXG_SIG_HALF];
+    const float s = pxg_sig_position(u);
+    const float4 c = tab[pxg_sig_segment(u) + PXG_SIG_HALF];
     float p = __builtin_fmaf(c.w, s, c.z);
     p = __builtin_fmaf(p, s, c.y);
     return __builtin_fmaf(p, s, c.x);

@@ -871,3 +871,44 @@ def test_small_calls_are_merged_into_one_batch(ctx, oracle):
     g1, c1 = ctx.merge_stats()
     # fewer batches than calls: merging happened (calls that met a group of the OTHER stage mask went alone, uncounted)
     assert c1 - c0 >= 24 and g1 - g0 < c1 - c0, (g0, c0, g1, c1)
+
+
+def test_spline_position_is_kept_below_one_for_tiny_negative_arguments(config, tmp_path, arith):
+    """The position of a look-up argument inside its table segment is min(u - floor(u), largest float below 1)
+    (oracle/pxo_core.c sig_position; on the device one v_fract_f32, checked for every float by
+    tools/ubench/fract_check.hip).  A scaler network whose recurrent and input weights are zero has gate arguments that
+    are exactly its biases: a ladder of tiny negative values (where u + 1 rounds to 1.0), -0.0, denormals, integers,
+    values just below integers and both table ends in the biases of both layers -- the kernels must give the oracle's
+    outputs bit for bit (they differ in the last bits if either side evaluates the cubic AT 1.0)."""
+    import copy
+    from oracle.pxo import Oracle
+    from poreplex_amd.config import load_model_arrays
+    m = load_model_arrays(config['signal_processing']['scaler_model'])
+    ladder = np.array([-1e-9, -2.0 ** -26, -2.0 ** -27, -1e-12, -1e-30, -1e-40, -0.0, 0.0, 1e-40, -2.0 ** -25, -3e-8, -5.96e-8,
+                       -1.0, -1.0000001, -0.99999994, 3.0, 2.9999998, -3.0000002, 40.0, -40.0, 31.999998, -32.0, 0.5, -0.5],
+                      dtype=np.float32)
+    rng = np.random.default_rng(17)
+    for key in ('lstm1_bias', 'lstm2_bias'):
+        b = ladder[rng.integers(0, len(ladder), 192)].astype(np.float32)
+        b[:len(ladder)] = ladder
+        b[48:48 + len(ladder)] = ladder[::-1]
+        b[96:96 + len(ladder)] = ladder / np.float32(2.0)         # tanh columns: table units are 32 z
+        b[144:144 + len(ladder)] = ladder
+        m[key] = b / np.float32(16.0)                              # table units are 16 z: u = 16 b exactly
+    for key in ('lstm1_kernel', 'lstm1_recurrent', 'lstm2_kernel', 'lstm2_recurrent'):
+        m[key] = np.zeros_like(m[key])
+    m['lstm2_kernel'] = (rng.choice([0.0, 2.0 ** -30, -2.0 ** -31], m['lstm2_kernel'].shape)).astype(np.float32)
+    m['dense_kernel'] = rng.normal(0, 1, m['dense_kernel'].shape).astype(np.float32)
+    path = str(tmp_path / 'edge_scaler.npz')
+    np.savez(path, **m)
+    cfg = copy.deepcopy(config)
+    cfg['signal_processing']['scaler_model'] = path
+    head = rng.normal(0, 1, (40, 2000)).astype(np.float32)
+    orc = Oracle(cfg)
+    c = N.NativeContext(cfg, device_id=0)
+    try:
+        got = c.scaler_lstm(head)
+    finally:
+        c.close()
+    want = np.stack([orc.scaler_forward(h) for h in head])
+    assert np.array_equal(got, want), np.abs(got - want).max()

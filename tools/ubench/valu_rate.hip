@@ -61,6 +61,18 @@ __global__ void k(float* out, int iters, long long* cyc)
                 asm volatile("v_fma_f32 %0, %0, %1, %2\nv_fma_f32 %0, %0, %1, %2\nv_fma_f32 %0, %0, %1, %2\nv_fma_f32 %0, %0, %1, %2\n"
                              "v_fma_f32 %0, %0, %1, %2\nv_fma_f32 %0, %0, %1, %2\nv_fma_f32 %0, %0, %1, %2\nv_fma_f32 %0, %0, %1, %2\n"
                              : "+v"(a0) : "v"(b), "v"(c));
+            } else if (OP == 12) { // v_fract_f32
+                asm volatile("v_fract_f32 %0, %0\nv_fract_f32 %1, %1\nv_fract_f32 %2, %2\nv_fract_f32 %3, %3\nv_fract_f32 %4, %4\nv_fract_f32 %5, %5\nv_fract_f32 %6, %6\nv_fract_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (OP == 13) { // v_cvt_flr_i32_f32
+                asm volatile("v_cvt_flr_i32_f32 %0, %0\nv_cvt_flr_i32_f32 %1, %1\nv_cvt_flr_i32_f32 %2, %2\nv_cvt_flr_i32_f32 %3, %3\nv_cvt_flr_i32_f32 %4, %4\nv_cvt_flr_i32_f32 %5, %5\nv_cvt_flr_i32_f32 %6, %6\nv_cvt_flr_i32_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (OP == 14) { // v_floor_f32
+                asm volatile("v_floor_f32 %0, %0\nv_floor_f32 %1, %1\nv_floor_f32 %2, %2\nv_floor_f32 %3, %3\nv_floor_f32 %4, %4\nv_floor_f32 %5, %5\nv_floor_f32 %6, %6\nv_floor_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+            } else if (OP == 15) { // v_cvt_i32_f32
+                asm volatile("v_cvt_i32_f32 %0, %0\nv_cvt_i32_f32 %1, %1\nv_cvt_i32_f32 %2, %2\nv_cvt_i32_f32 %3, %3\nv_cvt_i32_f32 %4, %4\nv_cvt_i32_f32 %5, %5\nv_cvt_i32_f32 %6, %6\nv_cvt_i32_f32 %7, %7\n"
+                             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
             } else if (OP == 8) { // v_med3_f32
                 asm volatile("v_med3_f32 %0, %0, %8, %9\nv_med3_f32 %1, %1, %8, %9\nv_med3_f32 %2, %2, %8, %9\nv_med3_f32 %3, %3, %8, %9\nv_med3_f32 %4, %4, %8, %9\nv_med3_f32 %5, %5, %8, %9\nv_med3_f32 %6, %6, %8, %9\nv_med3_f32 %7, %7, %8, %9\n"
                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));
@@ -101,6 +113,7 @@ int main()
         run<0>("v_fma_f32", w); run<1>("v_pk_fma_f32", w); run<2>("v_cndmask_b32", w); run<3>("v_mov_b32_dpp", w);
         run<4>("v_rcp_f32", w); run<5>("v_add_f32", w); run<6>("cvt+lshl_add", w); run<7>("v_fma_f64", w); run<8>("v_med3_f32", w);
         run<9>("v_cndmask_e64_sgpr", w); run<10>("v_fmac_f32", w); run<11>("v_fma_f32 dependent", w);
+        run<12>("v_fract_f32", w); run<13>("v_cvt_flr_i32_f32", w); run<14>("v_floor_f32", w); run<15>("v_cvt_i32_f32", w);
     }
     return 0;
 }
