@@ -1044,8 +1044,10 @@ def main():
                         'algorithmic_fp32_TFLOPs': n_scaled * FLOP_SCALER / dur / 1e12 if dur else None,
                         'frac_of_fp32_mfma_peak': n_scaled * FLOP_SCALER / dur / PEAK_FP32_MFMA if dur else None,
                         'algorithmic_flop_per_read': FLOP_SCALER, 'kernel_ms': stage_ms['scaler_lstm'],
-                        'note': 'issue-bound: per wave and step 72 v_mfma_i32_16x16x64_i8 (~17.5 cycles each per '
-                                'SIMD) and ~470 VALU instructions share one issue stream (DESIGN.md 3.1)'}
+                        'note': 'per wave and step: 72 v_mfma_i32_16x16x64_i8 (~17.5 cycles each per SIMD, their full issue '
+                                'time: nothing overlaps an MFMA on a SIMD), ~440 VALU instructions (about a third of their '
+                                'slots exposed), 54 ds_read_b128 (the spline rows cost 11 %) and one barrier (3 %): '
+                                'profiles/r04/k2_ablation.txt, DESIGN.md 3.1 / 8'}
         else:
             kernel = 'k_scaler_lstm_q' if (n_local + 15) // 16 > 2 * info['compute_units'] else 'k_scaler_lstm'
             roofline = {'kernel': kernel, 'bound': 'mfma',
