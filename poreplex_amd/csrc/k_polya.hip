@@ -1019,8 +1019,8 @@ int pxg_polya_collect_spikes(pxg_ctx* ctx, int64_t n, const int32_t* pout, const
     if (n <= 0) { if (offsets) offsets[0] = 0; return PXG_OK; }
     if (!offsets) { pxg_set_err(ctx, "spike offsets are required"); return PXG_E_INVALID; }
     std::vector<int32_t> po((size_t)n * 8);
-    PXG_HIP(ctx, hipMemcpyAsync(po.data(), pout, po.size() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = pxg_d2h_sync(ctx, po.data(), pout, po.size() * sizeof(int32_t));
+    if (rc) return rc;
     offsets[0] = 0;
     for (int64_t r = 0; r < n; r++)
         offsets[r + 1] = offsets[r] + (po[(size_t)r * 8] ? (int64_t)po[(size_t)r * 8 + 1] : 0);
@@ -1032,9 +1032,7 @@ int pxg_polya_collect_spikes(pxg_ctx* ctx, int64_t n, const int32_t* pout, const
     if (!total) return PXG_OK;
     const int64_t used = std::min<int64_t>(spike_rows, (int64_t)spikes.cap);
     std::vector<pxg_polya_spike> arena((size_t)used);
-    PXG_HIP(ctx, hipMemcpyAsync(arena.data(), spikes.p, (size_t)used * sizeof(pxg_polya_spike), hipMemcpyDeviceToHost,
-                                ctx->stream));
-    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = pxg_d2h_sync(ctx, arena.data(), spikes.p, (size_t)used * sizeof(pxg_polya_spike)))) return rc;
     for (int64_t r = 0; r < n; r++) {
         const int64_t ns = offsets[r + 1] - offsets[r], base = po[(size_t)r * 8 + 7];
         if (!ns) continue;

@@ -310,6 +310,7 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     if (ctx->d_calibration) (void)hipFree(ctx->d_calibration);
     if (ctx->d_sigtab) (void)hipFree(ctx->d_sigtab);
     if (ctx->d_lsetab) (void)hipFree(ctx->d_lsetab);
+    if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
     if (ctx->stream) {
         for (int t = 0; t < PXG_N_TIMERS; t++) {
             (void)hipEventDestroy(ctx->ev_start[t]);
@@ -885,15 +886,44 @@ extern "C" int pxg_batch_sync(pxg_ctx* ctx)
     return check_timeslice_flag(ctx);
 }
 
+int pxg_d2h_sync(pxg_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!bytes) return PXG_OK;
+    bool direct = bytes < (256u << 10);                 // small copies are staged by the runtime itself
+    if (!direct) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, dst) == hipSuccess) direct = at.type == hipMemoryTypeHost;    // page-locked by the caller
+        else (void)hipGetLastError();                   // (an unknown pointer is an error state of the runtime: clear it)
+    }
+    if (direct) {
+        PXG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return PXG_OK;
+    }
+    if (ctx->h_bounce_bytes < bytes) {
+        if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
+        ctx->h_bounce = nullptr;
+        ctx->h_bounce_bytes = 0;
+        const size_t want = bytes + bytes / 4;
+        if (hipHostMalloc(&ctx->h_bounce, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(ctx, PXG_E_NOMEM, "page-locked bounce buffer");
+        }
+        ctx->h_bounce_bytes = want;
+    }
+    PXG_HIP(ctx, hipMemcpyAsync(ctx->h_bounce, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(dst, ctx->h_bounce, bytes);
+    return PXG_OK;
+}
+
 extern "C" int pxg_batch_download(pxg_ctx* ctx, pxg_read_result* out)
 {
     if (!ctx || (!out && ctx->n_reads)) return PXG_E_INVALID;
     if (ctx->n_reads <= 0) return PXG_OK;
     int rc = settle_polya(ctx);
     if (rc) return rc;
-    PXG_HIP(ctx, hipMemcpyAsync(out, ctx->results.p, (size_t)ctx->n_reads * sizeof(pxg_read_result),
-                                hipMemcpyDeviceToHost, ctx->stream));
-    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = pxg_d2h_sync(ctx, out, ctx->results.p, (size_t)ctx->n_reads * sizeof(pxg_read_result)))) return rc;
     return check_timeslice_flag(ctx);
 }
 
@@ -903,10 +933,7 @@ extern "C" int pxg_batch_download_samples(pxg_ctx* ctx, int16_t* out)
     if (ctx->n_reads <= 0) return fail(ctx, PXG_E_STATE, "pxg_batch_download_samples: no resident batch");
     if (need_whole_reads(ctx, "pxg_batch_download_samples")) return PXG_E_STATE;
     if (ctx->n_samples <= 0) return PXG_OK;
-    PXG_HIP(ctx, hipMemcpyAsync(out, ctx->raw.p, (size_t)ctx->n_samples * sizeof(int16_t), hipMemcpyDeviceToHost,
-                                ctx->stream));
-    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return PXG_OK;
+    return pxg_d2h_sync(ctx, out, ctx->raw.p, (size_t)ctx->n_samples * sizeof(int16_t));
 }
 
 extern "C" int pxg_batch_download_windows(pxg_ctx* ctx, float* out)
@@ -916,10 +943,7 @@ extern "C" int pxg_batch_download_windows(pxg_ctx* ctx, float* out)
     if (!(ctx->last_stage_mask & PXG_STAGE_BARCODE))
         return fail(ctx, PXG_E_STATE, "pxg_batch_download_windows: the last run had no barcode stage");
     PXG_HIP(ctx, hipSetDevice(ctx->device));
-    PXG_HIP(ctx, hipMemcpyAsync(out, ctx->win.p, (size_t)ctx->n_reads * ctx->cfg.signal_trim_length * sizeof(float),
-                                hipMemcpyDeviceToHost, ctx->stream));
-    PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return PXG_OK;
+    return pxg_d2h_sync(ctx, out, ctx->win.p, (size_t)ctx->n_reads * ctx->cfg.signal_trim_length * sizeof(float));
 }
 
 extern "C" int pxg_batch_download_spikes(pxg_ctx* ctx, int64_t cap_rows, pxg_polya_spike* out, int64_t* offsets)
@@ -1212,8 +1236,11 @@ struct Scratch {               // RAII device temporaries for the hooks
     PXG_HIP(ctx, hipSetDevice(ctx->device));                 \
     Scratch S;
 #define HOOK_CHECK(p) if (!(p)) return fail(ctx, PXG_E_NOMEM, "hook scratch allocation failed")
-#define HOOK_GET(dst, src, n) \
-    PXG_HIP(ctx, hipMemcpyAsync(dst, src, (size_t)(n) * sizeof(*(dst)), hipMemcpyDeviceToHost, ctx->stream))
+#define HOOK_GET(dst, src, n)                                                                         \
+    do {                                                                                              \
+        const int rc_get__ = pxg_d2h_sync(ctx, dst, src, (size_t)(n) * sizeof(*(dst)));               \
+        if (rc_get__) return rc_get__;                                                                \
+    } while (0)
 #define HOOK_END                                             \
     PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));         \
     PXG_HIP(ctx, hipGetLastError());                         \

@@ -367,6 +367,14 @@ struct pxg_ctx {
         std::vector<pxg_read_result> h_out;
         int64_t groups = 0, calls = 0;       // statistics: groups run, calls they carried
     } merge;
+    // Device -> host copies whose destination is ordinary (pageable) memory go through this page-locked buffer and a
+    // memcpy: the HIP runtime would otherwise pin the destination's pages on the fly for anything above ~1 MB and keep
+    // that mapping cached -- with destinations that are allocated and freed around every call (NumPy result arrays,
+    // std::vectors) a cached mapping can outlive its pages (heap trimmed, address reused), and the next copy to that
+    // address faults on the GPU (seen once in ~40 runs of bench.py --workload full: "Memory access fault by GPU" at a
+    // heap address).  Destinations the caller page-locked (pxg_host_register) are written directly.
+    void* h_bounce = nullptr;
+    size_t h_bounce_bytes = 0;
     bool merge_small_calls = true;           // PXG_NO_CALL_MERGE=1 at pxg_create: every call is its own batch
     std::mutex mt_stage, mt_run; // pxg_process_batch(_ex) from several host threads: spare slot / resident batch
     bool polya_ran = false;
@@ -459,6 +467,9 @@ int pxg_launch_demux_lstm(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx,
                           const int32_t* count, const float* win, float* bidir, float* probs,
                           int timer_a, int timer_b);
 int pxg_launch_reset_batch(pxg_ctx* ctx, int64_t n);
+// device -> host on the context's stream, synchronised: directly into page-locked destinations, through the context's
+// page-locked bounce buffer otherwise (pxg_api.hip; callers hold the run lock or are the only user of the context)
+int pxg_d2h_sync(pxg_ctx* ctx, void* dst, const void* src, size_t bytes);
 int pxg_launch_z_decode(pxg_ctx* ctx, hipStream_t stream, int64_t n_chunks, const uint8_t* z, int64_t z_bytes, const pxg_z_chunk* chunks,
                         int64_t data_base, int64_t dst_base, int16_t* out, const int64_t* off = nullptr, int64_t n_reads = 0,
                         int64_t prefix_limit = 0);
