@@ -607,7 +607,7 @@ def strong_leg(args, ctx, dist, rank, world, mask, standin, force_dist, barrier)
     sizes = [shard_range(total, r, world)[1] - shard_range(total, r, world)[0] for r in range(world)]
     K = max(1, min(args.strong_base_reads, total))
     base = synth_batch(K, seed=args.seed, samples_per_read=args.samples)      # the same on every rank
-    res_buf = np.zeros(n_local, dtype=N.RESULT_DTYPE)
+    res_buf = N.page_exclusive(n_local, N.RESULT_DTYPE, fill=0)
     failure = None
     try:                               # a rank that cannot hold its shard must not leave the others in a collective
         ctx.upload_tiled(n_local, base['arena'], base['offsets'], base['calib'], None, phase=lo % K)
@@ -948,7 +948,7 @@ def main():
                 torch.cuda.synchronize()
 
     # the result records land in ONE page-locked host buffer, reused by every step
-    res_buf = np.zeros(n_local, dtype=N.RESULT_DTYPE)
+    res_buf = N.page_exclusive(n_local, N.RESULT_DTYPE, fill=0)
     if not standin:
         ctx.pin(res_buf)
     for _ in range(args.warmup):

@@ -311,6 +311,9 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     if (ctx->d_sigtab) (void)hipFree(ctx->d_sigtab);
     if (ctx->d_lsetab) (void)hipFree(ctx->d_lsetab);
     if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
+    for (auto& set : ctx->h_meta)
+        for (auto& m : set)
+            if (m.p) (void)hipHostFree(m.p);
     if (ctx->stream) {
         for (int t = 0; t < PXG_N_TIMERS; t++) {
             (void)hipEventDestroy(ctx->ev_start[t]);
@@ -443,14 +446,13 @@ extern "C" int pxg_batch_upload(pxg_ctx* ctx, int64_t n_reads, const int16_t* ra
     if (n_samples)
         PXG_HIP(ctx, hipMemcpyAsync(ctx->raw.p, raw_arena, (size_t)n_samples * sizeof(int16_t),
                                     hipMemcpyHostToDevice, ctx->stream));
-    PXG_HIP(ctx, hipMemcpyAsync(ctx->offsets.p, raw_offsets, (size_t)(n_reads + 1) * sizeof(int64_t),
-                                hipMemcpyHostToDevice, ctx->stream));
-    PXG_HIP(ctx, hipMemcpyAsync(ctx->calib.p, calib, (size_t)n_reads * sizeof(pxg_calib),
-                                hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pxg_h2d_meta(ctx, 1, 0, ctx->offsets.p, raw_offsets, (size_t)(n_reads + 1) * sizeof(int64_t), ctx->stream)) ||
+        (rc = pxg_h2d_meta(ctx, 1, 1, ctx->calib.p, calib, (size_t)n_reads * sizeof(pxg_calib), ctx->stream)))
+        return rc;
     ctx->have_inject = scale_shift_or_null != nullptr;
-    if (ctx->have_inject)
-        PXG_HIP(ctx, hipMemcpyAsync(ctx->inject.p, scale_shift_or_null, (size_t)n_reads * 2 * sizeof(float),
-                                    hipMemcpyHostToDevice, ctx->stream));
+    if (ctx->have_inject &&
+        (rc = pxg_h2d_meta(ctx, 1, 2, ctx->inject.p, scale_shift_or_null, (size_t)n_reads * 2 * sizeof(float), ctx->stream)))
+        return rc;
     PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));   // host buffers may be reused on return
     ctx->n_reads = n_reads;
     ctx->n_samples = n_samples;
@@ -600,14 +602,13 @@ extern "C" int pxg_batch_stage_prefix(pxg_ctx* ctx, int64_t n_reads, const int16
     hipStream_t cs = ctx->copy_stream;
     if (n_samples && (rc = copy_read_prefixes(ctx, cs, sp.raw.p, raw_arena, raw_offsets, n_reads, prefix_limit))) return rc;
     sp.limit = prefix_limit;
-    PXG_HIP(ctx, hipMemcpyAsync(sp.offsets.p, raw_offsets, (size_t)(n_reads + 1) * sizeof(int64_t),
-                                hipMemcpyHostToDevice, cs));
-    PXG_HIP(ctx, hipMemcpyAsync(sp.calib.p, calib, (size_t)n_reads * sizeof(pxg_calib),
-                                hipMemcpyHostToDevice, cs));
+    if ((rc = pxg_h2d_meta(ctx, 0, 0, sp.offsets.p, raw_offsets, (size_t)(n_reads + 1) * sizeof(int64_t), cs)) ||
+        (rc = pxg_h2d_meta(ctx, 0, 1, sp.calib.p, calib, (size_t)n_reads * sizeof(pxg_calib), cs)))
+        return rc;
     sp.have_inject = scale_shift_or_null != nullptr;
-    if (sp.have_inject)
-        PXG_HIP(ctx, hipMemcpyAsync(sp.inject.p, scale_shift_or_null, (size_t)n_reads * 2 * sizeof(float),
-                                    hipMemcpyHostToDevice, cs));
+    if (sp.have_inject &&
+        (rc = pxg_h2d_meta(ctx, 0, 2, sp.inject.p, scale_shift_or_null, (size_t)n_reads * 2 * sizeof(float), cs)))
+        return rc;
     PXG_HIP(ctx, hipEventRecord(ctx->ev_staged, cs));
     sp.n_reads = n_reads;
     sp.n_samples = n_samples;
@@ -693,14 +694,13 @@ extern "C" int pxg_batch_stage_z_prefix(pxg_ctx* ctx, int64_t n_reads, const uin
     if (n_chunks)
         PXG_HIP(ctx, hipMemcpyAsync(sp.zchunks.p, chunks, (size_t)n_chunks * sizeof(pxg_z_chunk),
                                     hipMemcpyHostToDevice, cs));
-    PXG_HIP(ctx, hipMemcpyAsync(sp.offsets.p, raw_offsets, (size_t)(n_reads + 1) * sizeof(int64_t),
-                                hipMemcpyHostToDevice, cs));
-    PXG_HIP(ctx, hipMemcpyAsync(sp.calib.p, calib, (size_t)n_reads * sizeof(pxg_calib),
-                                hipMemcpyHostToDevice, cs));
+    if ((rc = pxg_h2d_meta(ctx, 0, 0, sp.offsets.p, raw_offsets, (size_t)(n_reads + 1) * sizeof(int64_t), cs)) ||
+        (rc = pxg_h2d_meta(ctx, 0, 1, sp.calib.p, calib, (size_t)n_reads * sizeof(pxg_calib), cs)))
+        return rc;
     sp.have_inject = scale_shift_or_null != nullptr;
-    if (sp.have_inject)
-        PXG_HIP(ctx, hipMemcpyAsync(sp.inject.p, scale_shift_or_null, (size_t)n_reads * 2 * sizeof(float),
-                                    hipMemcpyHostToDevice, cs));
+    if (sp.have_inject &&
+        (rc = pxg_h2d_meta(ctx, 0, 2, sp.inject.p, scale_shift_or_null, (size_t)n_reads * 2 * sizeof(float), cs)))
+        return rc;
     if ((rc = pxg_launch_z_decode(ctx, cs, n_chunks, sp.z.p, z_bytes, sp.zchunks.p, data_base, dst_base, sp.raw.p,
                                   sp.offsets.p, n_reads, prefix_limit)))
         return rc;
@@ -917,6 +917,26 @@ int pxg_d2h_sync(pxg_ctx* ctx, void* dst, const void* src, size_t bytes)
     return PXG_OK;
 }
 
+int pxg_h2d_meta(pxg_ctx* ctx, int set, int which, void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+    if (!bytes) return PXG_OK;
+    auto& m = ctx->h_meta[set][which];
+    if (m.cap < bytes) {
+        if (m.p) (void)hipHostFree(m.p);
+        m.p = nullptr;
+        m.cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(&m.p, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(ctx, PXG_E_NOMEM, "page-locked mirror of a batch's small arrays");
+        }
+        m.cap = want;
+    }
+    memcpy(m.p, src, bytes);
+    PXG_HIP(ctx, hipMemcpyAsync(dst, m.p, bytes, hipMemcpyHostToDevice, st));
+    return PXG_OK;
+}
+
 extern "C" int pxg_batch_download(pxg_ctx* ctx, pxg_read_result* out)
 {
     if (!ctx || (!out && ctx->n_reads)) return PXG_E_INVALID;
@@ -1084,9 +1104,10 @@ static int merged_process(pxg_ctx* ctx, pxg_ctx::MergeItem& mine, uint32_t stage
             s0 += it->off[it->n];
         }
         if (rc) break;
-        if (hipMemcpyAsync(sp.offsets.p, mq.h_off.data(), (size_t)(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, cs) != hipSuccess ||
-            hipMemcpyAsync(sp.calib.p, mq.h_cal.data(), (size_t)n * sizeof(pxg_calib), hipMemcpyHostToDevice, cs) != hipSuccess ||
-            hipEventRecord(ctx->ev_staged, cs) != hipSuccess) { rc = fail(ctx, PXG_E_HIP, "merged stage: copy"); break; }
+        if ((rc = pxg_h2d_meta(ctx, 0, 0, sp.offsets.p, mq.h_off.data(), (size_t)(n + 1) * sizeof(int64_t), cs)) ||
+            (rc = pxg_h2d_meta(ctx, 0, 1, sp.calib.p, mq.h_cal.data(), (size_t)n * sizeof(pxg_calib), cs)))
+            break;
+        if (hipEventRecord(ctx->ev_staged, cs) != hipSuccess) { rc = fail(ctx, PXG_E_HIP, "merged stage: event"); break; }
         sp.limit = limit;
         sp.have_inject = false;
         sp.n_reads = n;

@@ -375,6 +375,10 @@ struct pxg_ctx {
     // heap address).  Destinations the caller page-locked (pxg_host_register) are written directly.
     void* h_bounce = nullptr;
     size_t h_bounce_bytes = 0;
+    // ... and the small host arrays of a batch (offsets, calibration, injected scaling, chunk-record-free metadata)
+    // are copied into page-locked mirrors first and sent from there: [0] the staging calls (one stage at a time:
+    // mt_stage / the caller's own order), [1] pxg_batch_upload.
+    struct HostMirror { void* p = nullptr; size_t cap = 0; } h_meta[2][3];
     bool merge_small_calls = true;           // PXG_NO_CALL_MERGE=1 at pxg_create: every call is its own batch
     std::mutex mt_stage, mt_run; // pxg_process_batch(_ex) from several host threads: spare slot / resident batch
     bool polya_ran = false;
@@ -470,6 +474,9 @@ int pxg_launch_reset_batch(pxg_ctx* ctx, int64_t n);
 // device -> host on the context's stream, synchronised: directly into page-locked destinations, through the context's
 // page-locked bounce buffer otherwise (pxg_api.hip; callers hold the run lock or are the only user of the context)
 int pxg_d2h_sync(pxg_ctx* ctx, void* dst, const void* src, size_t bytes);
+// host -> device of a small array through page-locked mirror h_meta[set][which] (asynchronous on `st`; the mirror is
+// reused by the next call of the same set, which by construction starts after this copy has completed)
+int pxg_h2d_meta(pxg_ctx* ctx, int set, int which, void* dst, const void* src, size_t bytes, hipStream_t st);
 int pxg_launch_z_decode(pxg_ctx* ctx, hipStream_t stream, int64_t n_chunks, const uint8_t* z, int64_t z_bytes, const pxg_z_chunk* chunks,
                         int64_t data_base, int64_t dst_base, int16_t* out, const int64_t* off = nullptr, int64_t n_reads = 0,
                         int64_t prefix_limit = 0);

@@ -554,6 +554,22 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def page_exclusive(n, dtype, fill=None):
+    """An array of n items that shares no memory page with any other allocation (whole pages of an over-sized
+    buffer): what a caller should hand to NativeContext.pin() when the array is small enough to come from the
+    malloc heap -- hipHostRegister works on pages, and a page-locked page that ALSO holds the start of somebody
+    else's array makes the runtime treat that array as page-locked too."""
+    dtype = np.dtype(dtype)
+    nbytes = int(n) * dtype.itemsize
+    page = 4096
+    raw = np.empty(nbytes + 2 * page, dtype=np.uint8)
+    start = (-raw.ctypes.data) % page
+    out = raw[start:start + nbytes].view(dtype)
+    if fill is not None:
+        out[...] = fill
+    return out          # (out.base keeps `raw` alive)
+
+
 # ---- compressed samples (include/pxg.h, pxg_zcodec.cpp) ---------------------------------------
 Z_CHUNK = 1024
 Z_CHUNK_DTYPE = np.dtype([('data_off', np.int64), ('dst', np.int64), ('first', np.int16),
