@@ -570,6 +570,16 @@ def page_exclusive(n, dtype, fill=None):
     return out          # (out.base keeps `raw` alive)
 
 
+def pinnable(array):
+    """`array` itself when it is large enough to have its own pages (glibc maps allocations above 32 MB on their
+    own), otherwise a page_exclusive() copy of it: what to page-lock instead of a small heap array."""
+    if array.nbytes >= (64 << 20) or array.nbytes == 0:
+        return array
+    out = page_exclusive(array.size, array.dtype).reshape(array.shape)
+    out[...] = array
+    return out
+
+
 # ---- compressed samples (include/pxg.h, pxg_zcodec.cpp) ---------------------------------------
 Z_CHUNK = 1024
 Z_CHUNK_DTYPE = np.dtype([('data_off', np.int64), ('dst', np.int64), ('first', np.int16),

@@ -75,7 +75,7 @@ class _Staging:
         if n_samples > len(self.buf):
             if self.pinned:
                 self.retired.append(self.buf)          # still registered: unpin in settle()
-            self.buf, self.pinned = np.empty(int(n_samples * 1.1) + 4096, dtype=np.int16), False
+            self.buf, self.pinned = native.page_exclusive(int(n_samples * 1.1) + 4096, np.int16), False
         return self.buf
 
     def settle(self):

@@ -715,10 +715,12 @@ class SignalLoader:
             if self._pinned:
                 return
             d = self.bundle.d
-            arrays = [d['arena_z'], d['z_chunks']] if self.bundle.compressed else [d['arena']]
             pinned = []
-            for a in arrays:
-                if a.nbytes:
+            for key in (('arena_z', 'z_chunks') if self.bundle.compressed else ('arena',)):
+                if d[key].nbytes:
+                    # (a small array comes from the malloc heap and shares pages with its neighbours: page-lock a
+                    #  copy that has its pages to itself -- native.pinnable)
+                    d[key] = a = native.pinnable(d[key])
                     self.ctx.pin(a)
                     pinned.append(a)
             self._pinned = pinned
