@@ -1054,6 +1054,7 @@ static int merged_process(pxg_ctx* ctx, pxg_ctx::MergeItem& mine, uint32_t stage
 
     int rc = PXG_OK;
     std::unique_lock<std::mutex> run_lock(ctx->mt_run, std::defer_lock);
+    try {       // (whatever happens, the calls that wait on this one are released below)
     do {
         int64_t n = 0, n_samples = 0, zb = 0, zc = 0;
         for (auto* it : items) {
@@ -1128,6 +1129,9 @@ static int merged_process(pxg_ctx* ctx, pxg_ctx::MergeItem& mine, uint32_t stage
             r += it->n;
         }
     } while (0);
+    } catch (const std::exception& e) {
+        rc = fail(ctx, PXG_E_NOMEM, std::string("merged calls: ") + e.what());
+    }
     if (run_lock.owns_lock()) run_lock.unlock();
     if (stage_lock.owns_lock()) stage_lock.unlock();
     lk.lock();
