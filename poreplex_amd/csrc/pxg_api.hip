@@ -900,6 +900,7 @@ int pxg_d2h_sync(pxg_ctx* ctx, void* dst, const void* src, size_t bytes)
         PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return PXG_OK;
     }
+    std::lock_guard<std::mutex> bounce_lock(ctx->mt_bounce);
     if (ctx->h_bounce_bytes < bytes) {
         if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
         ctx->h_bounce = nullptr;

@@ -375,6 +375,7 @@ struct pxg_ctx {
     // heap address).  Destinations the caller page-locked (pxg_host_register) are written directly.
     void* h_bounce = nullptr;
     size_t h_bounce_bytes = 0;
+    std::mutex mt_bounce;        // the stage hooks take no other lock: two threads may download at once
     // ... and the small host arrays of a batch (offsets, calibration, injected scaling, chunk-record-free metadata)
     // are copied into page-locked mirrors first and sent from there: [0] the staging calls (one stage at a time:
     // mt_stage / the caller's own order), [1] pxg_batch_upload.
