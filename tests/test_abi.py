@@ -51,3 +51,23 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.setattr(N, '_lib', None)
     with pytest.raises(N.PxgError, match='no CPU fallback'):
         N.load_library(str(tmp_path / 'absent.so'))
+
+
+def test_page_exclusive_arrays_own_their_pages():
+    """native.page_exclusive / pinnable: what gets page-locked shares no page with another allocation (hipHostRegister
+    works on pages)."""
+    import numpy as np
+    from poreplex_amd import native as N
+    for n, dt in ((1, np.int16), (1000, N.RESULT_DTYPE), (4096, np.uint8), (100001, np.int64)):
+        a = N.page_exclusive(n, dt, fill=0)
+        assert a.shape == (n,) and a.ctypes.data % 4096 == 0 and a.base is not None
+        lo, hi = a.ctypes.data, a.ctypes.data + a.nbytes
+        raw = a.base if isinstance(a.base, np.ndarray) else a.base.base
+        # every page the array touches lies inside the buffer it was cut from
+        assert raw.ctypes.data <= lo and (hi + 4095) // 4096 * 4096 <= raw.ctypes.data + raw.nbytes
+    small = np.arange(1000, dtype=np.int16)
+    p = N.pinnable(small)
+    assert p is not small and np.array_equal(p, small) and p.ctypes.data % 4096 == 0
+    chunks = np.zeros(7, dtype=N.Z_CHUNK_DTYPE)
+    chunks['len'] = 5
+    assert np.array_equal(N.pinnable(chunks), chunks)
