@@ -300,9 +300,12 @@ void pxo_lstm_layer(const pxg_lstm_layer* L, const float* x, int T, int reverse,
  * the result does not depend on the order in which a machine adds the products:
  *   hidden state  h_f = fl(o * tanh(c')) as before, then q = rint(h_f * 2^22) (ties to even),
  *                 |q| <= 2^22; everything downstream sees h = q * 2^-22.
- *   weights       per layer, all rows that multiply an h (vector-input rows, then recurrent
- *                 rows) share one exponent p = the largest integer with max|W| * 2^p <= 8355711
- *                 (= 127 + 127*256 + 127*65536); Wq = rint(W * 2^p).
+ *   weights       per layer and GATE BLOCK (the i, f, c, o columns), all rows that multiply an h
+ *                 (vector-input rows, then recurrent rows) share one exponent p = the largest
+ *                 integer with max|W_block| * 2^p <= 8355711 (= 127 + 127*256 + 127*65536);
+ *                 Wq = rint(W * 2^p).  (Round 4 had one p per layer; per block the coherent
+ *                 2^-23-of-the-largest-weight perturbation is taken against each block's own
+ *                 largest weight: tools/decision_flips_gpu.py)
  *   digits        v = d0 + 256 d1 + 65536 d2 with every d in [-128, 127] (balanced base 256,
  *                 unique); w0..w2 of Wq, h0..h2 of q.
  *   products      the eight leading digit products, summed EXACTLY (they are small integers):
@@ -326,7 +329,7 @@ void pxo_lstm_layer(const pxg_lstm_layer* L, const float* x, int T, int reverse,
 #define Q_WMAX 8355711.0
 
 typedef struct {
-    int K, G, p;
+    int K, G, p[4];                /* p: one exponent per gate block */
     float* w[3];                   /* digit planes [K][G] as float (exact small integers) */
     float S[4];                    /* per gate block: g * 2^(-p-14) */
 } qmat;
@@ -345,28 +348,31 @@ static qmat* qmat_build(const pxg_lstm_layer* L)
     const int Kin = I == 1 ? 0 : I, K = Kin + H;
     qmat* M = (qmat*)calloc(1, sizeof(qmat));
     M->K = K; M->G = G;
-    double m = 0.0;
-    for (int k = 0; k < K; k++) {
-        const float* row = k < Kin ? L->kernel + (size_t)k * G : L->recurrent + (size_t)(k - Kin) * G;
-        for (int j = 0; j < G; j++)
-            if (fabs((double)row[j]) > m) m = fabs((double)row[j]);
+    /* one exponent per gate block (i, f, c, o): the largest with max|W_gate| * 2^p <= Q_WMAX */
+    for (int g = 0; g < 4; g++) {
+        double m = 0.0;
+        for (int k = 0; k < K; k++) {
+            const float* row = k < Kin ? L->kernel + (size_t)k * G : L->recurrent + (size_t)(k - Kin) * G;
+            for (int j = g * H; j < (g + 1) * H; j++)
+                if (fabs((double)row[j]) > m) m = fabs((double)row[j]);
+        }
+        int p = 0;
+        if (m > 0.0) {
+            p = 40;
+            while (ldexp(m, p) > Q_WMAX) p--;
+        }
+        M->p[g] = p;
     }
-    int p = 0;
-    if (m > 0.0) {
-        p = 40;
-        while (ldexp(m, p) > Q_WMAX) p--;
-    }
-    M->p = p;
     for (int d = 0; d < 3; d++) M->w[d] = (float*)malloc(sizeof(float) * (size_t)K * G);
     for (int k = 0; k < K; k++) {
         const float* row = k < Kin ? L->kernel + (size_t)k * G : L->recurrent + (size_t)(k - Kin) * G;
         for (int j = 0; j < G; j++) {
             int32_t dg[3];
-            q_digits((int32_t)rint(ldexp((double)row[j], p)), dg);
+            q_digits((int32_t)rint(ldexp((double)row[j], M->p[j / H])), dg);
             for (int d = 0; d < 3; d++) M->w[d][(size_t)k * G + j] = (float)dg[d];
         }
     }
-    for (int g = 0; g < 4; g++) M->S[g] = (float)ldexp(g == 2 ? 32.0 : 16.0, -p - 14);
+    for (int g = 0; g < 4; g++) M->S[g] = (float)ldexp(g == 2 ? 32.0 : 16.0, -M->p[g] - 14);
     return M;
 }
 

@@ -38,16 +38,21 @@ __device__ __forceinline__ float q8_combine(int a0, int a1, int a2, int a3, floa
     return __builtin_fmaf(t, S, start);
 }
 
+// g * 2^(-p-14) of the four gate blocks (i, f, c, o) of one layer: every block has its own weight exponent p (the largest
+// that keeps the block's biggest weight within three balanced digits), g = 16 or 32 = the table units (kernel argument:
+// four scalar registers, no vector register)
+struct Q8Scale { float g[4]; };
+inline Q8Scale q8_scale(const float (&s)[4]) { return Q8Scale{{s[0], s[1], s[2], s[3]}}; }
+
 template <int NT>
-__device__ __forceinline__ void q8_combine_tiles(f32x4 (&u)[NT], const Q8Acc (&A)[NT], float s_sig, float s_tanh,
+__device__ __forceinline__ void q8_combine_tiles(f32x4 (&u)[NT], const Q8Acc (&A)[NT], const Q8Scale& S,
                                                  const f32x4 (&start)[NT])
 {
 #pragma unroll
     for (int nt = 0; nt < NT; nt++)
 #pragma unroll
         for (int r = 0; r < 4; r++)
-            u[nt][r] = q8_combine(A[nt].a0[r], A[nt].a1[r], A[nt].a2[r], A[nt].a3[r], r == 2 ? s_tanh : s_sig,
-                                  start[nt][r]);
+            u[nt][r] = q8_combine(A[nt].a0[r], A[nt].a1[r], A[nt].a2[r], A[nt].a3[r], S.g[r], start[nt][r]);
 }
 
 // q + 0x808080 of q = rint(h * 2^22): its three low bytes, each XOR 0x80, are the balanced digits

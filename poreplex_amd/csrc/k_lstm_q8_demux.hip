@@ -16,7 +16,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir_q8(
     int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int T,
     const float* __restrict__ win, const float* __restrict__ sigtab, const v4i* __restrict__ frag,
     const float* __restrict__ Wf, const float* __restrict__ bf, const float* __restrict__ Wb,
-    const float* __restrict__ bb, float sf, float sb, unsigned char* __restrict__ bidir,
+    const float* __restrict__ bb, Q8Scale sf, Q8Scale sb, unsigned char* __restrict__ bidir,
     int* __restrict__ queue, int* __restrict__ errflag, int* __restrict__ done, unsigned* __restrict__ state)
 {
     constexpr int H = 48, NT = 3;
@@ -53,7 +53,6 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir_q8(
         gvec[i] = make_float4(src[unit], src[H + unit], src[2 * H + unit], src[3 * H + unit]);
     }
     const int gv = slice * 12 + ul;
-    const float sft = 2.0f * sf, sbt = 2.0f * sb;
     constexpr int NST = (2 * Q8_HVEC / 16 + LSTM_THREADS - 1) / LSTM_THREADS;     // float4 per thread and step
 
     for (;;) {
@@ -135,7 +134,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir_q8(
                     st[nt][0] = __builtin_fmaf(x1, w.x, b.x); st[nt][1] = __builtin_fmaf(x1, w.y, b.y);
                     st[nt][2] = __builtin_fmaf(x1, w.z, b.z); st[nt][3] = __builtin_fmaf(x1, w.w, b.w);
                 }
-                q8_combine_tiles<NT>(u, A, sf, sft, st);
+                q8_combine_tiles<NT>(u, A, sf, st);
             }
             Q8Acc B[NT];
 #pragma unroll
@@ -155,7 +154,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir_q8(
                     st[nt][0] = __builtin_fmaf(x2, w.x, b.x); st[nt][1] = __builtin_fmaf(x2, w.y, b.y);
                     st[nt][2] = __builtin_fmaf(x2, w.z, b.z); st[nt][3] = __builtin_fmaf(x2, w.w, b.w);
                 }
-                q8_combine_tiles<NT>(u, B, sb, sbt, st);
+                q8_combine_tiles<NT>(u, B, sb, st);
                 float hn[NT];
                 unsigned plane[3];
                 cells_update<NT>(tab, u, cb, hn);
@@ -191,7 +190,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_bidir_q8(
 __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top_q8(
     int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int T,
     const unsigned char* __restrict__ bidir, const float* __restrict__ sigtab, const v4i* __restrict__ frag,
-    const float* __restrict__ b3, float s3, const float* __restrict__ Wd, const float* __restrict__ bd,
+    const float* __restrict__ b3, Q8Scale s3, const float* __restrict__ Wd, const float* __restrict__ bd,
     int n_classes, float* __restrict__ probs, int* __restrict__ queue, int* __restrict__ errflag,
     int* __restrict__ done, unsigned* __restrict__ state)
 {
@@ -229,7 +228,6 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top_q8(
     }
     for (int i = tid; i < H; i += LSTM_THREADS) gvec[i] = make_float4(b3[i], b3[H + i], b3[2 * H + i], b3[3 * H + i]);
     const int gv = slice * 16 + ul;
-    const float s3t = 2.0f * s3;
     constexpr int NPF = (2 * Q8_HVEC / 16 + LSTM_THREADS - 1) / LSTM_THREADS;
 
     for (;;) {
@@ -304,7 +302,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_demux_top_q8(
                     const float4 b = gvec[gv + (2 * half + k) * 4];
                     st[k][0] = b.x; st[k][1] = b.y; st[k][2] = b.z; st[k][3] = b.w;
                 }
-                q8_combine_tiles<2>(u2, A2, s3, s3t, st);
+                q8_combine_tiles<2>(u2, A2, s3, st);
                 float cc[2] = { c3[2 * half], c3[2 * half + 1] };
                 float hh[2];
                 cells_update<2>(tab, u2, cc, hh);
@@ -399,7 +397,7 @@ int pxg_launch_demux_lstm_q8(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, c
         pxg_timer_begin(ctx, timer_a);
         hipLaunchKernelGGL(k_demux_bidir_q8, dim3((unsigned)grid), dim3(LSTM_THREADS), lds, ctx->stream, (int)n_rows, idx,
                            count, T, win, ctx->d_sigtab, reinterpret_cast<const v4i*>(ctx->q8.bidir_frag), f.kernel, f.bias,
-                           b.kernel, b.bias, ctx->q8.s_fwd, ctx->q8.s_bwd, reinterpret_cast<unsigned char*>(bidir), qa,
+                           b.kernel, b.bias, q8_scale(ctx->q8.s_fwd), q8_scale(ctx->q8.s_bwd), reinterpret_cast<unsigned char*>(bidir), qa,
                            ctx->lstm_err.p, qa + 2, st);
         pxg_timer_end(ctx, timer_a);
     }
@@ -410,7 +408,7 @@ int pxg_launch_demux_lstm_q8(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, c
         pxg_timer_begin(ctx, timer_b);
         hipLaunchKernelGGL(k_demux_top_q8, dim3((unsigned)grid), dim3(LSTM_THREADS), lds, ctx->stream, (int)n_rows, idx, count,
                            T, reinterpret_cast<const unsigned char*>(bidir), ctx->d_sigtab,
-                           reinterpret_cast<const v4i*>(ctx->q8.top_frag), t3.bias, ctx->q8.s_top, ctx->demux_dense.kernel,
+                           reinterpret_cast<const v4i*>(ctx->q8.top_frag), t3.bias, q8_scale(ctx->q8.s_top), ctx->demux_dense.kernel,
                            ctx->demux_dense.bias, ctx->demux_dense.out_dim, probs, qb, ctx->lstm_err.p, qb + 2, st);
         pxg_timer_end(ctx, timer_b);
     }

@@ -629,21 +629,26 @@ extern "C" int pxg_batch_stage_z(pxg_ctx* ctx, int64_t n_reads, const uint8_t* z
                                     scale_shift_or_null, 0);
 }
 
-// Byte ranges of the chunks that hold the first `limit` samples of every read.  false: some chunk spans two
-// reads (the encoder never writes one, the records may still say so) -- the caller then copies everything.
+// Byte ranges of the chunks that hold the first `limit` samples of every read: a chunk is kept while its first
+// sample lies less than `limit` samples into its read -- the rule k_z_decode applies (a foreign record may
+// carry short chunks in the middle of a read; counting chunks instead of samples would then leave chunks the
+// kernel decodes uncopied).  false: some chunk spans two reads (the encoder never writes one, the records may
+// still say so) -- the caller then copies everything.
 static bool z_prefix_ranges(const pxg_z_chunk* chunks, int64_t n_chunks, int64_t data_base, int64_t z_bytes,
                             const int64_t* off, int64_t n, int64_t limit, std::vector<std::pair<int64_t, int64_t>>& ranges)
 {
-    const int64_t keep = (limit + PXG_Z_CHUNK - 1) / PXG_Z_CHUNK;      // chunks of a read that are needed
     auto byte_of = [&](int64_t g) { return g < n_chunks ? chunks[g].data_off - data_base : z_bytes; };
     int64_t g = 0, run0 = 0;
     for (int64_t r = 0; r < n; r++) {
-        const int64_t g0 = g;
-        int64_t need = off[r + 1] - off[r];
-        while (need > 0 && g < n_chunks) need -= chunks[g++].len;
-        if (need != 0) return false;
-        if (g - g0 > keep) {
-            if (byte_of(g0 + keep) > run0) ranges.emplace_back(run0, byte_of(g0 + keep));
+        const int64_t len = off[r + 1] - off[r];
+        int64_t at = 0, first_dropped = -1;                 // samples of the read before chunk g
+        while (at < len && g < n_chunks) {
+            if (at >= limit && first_dropped < 0) first_dropped = g;
+            at += chunks[g++].len;
+        }
+        if (at != len) return false;
+        if (first_dropped >= 0) {
+            if (byte_of(first_dropped) > run0) ranges.emplace_back(run0, byte_of(first_dropped));
             run0 = byte_of(g);
         }
     }

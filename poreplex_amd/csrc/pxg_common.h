@@ -279,7 +279,7 @@ struct pxg_ctx {
         int8_t* scaler_frag = nullptr;   // A-fragment order (k_lstm_q8.hip), 16 bytes per thread and fragment
         int8_t* bidir_frag = nullptr;
         int8_t* top_frag = nullptr;
-        float s_scaler1 = 0, s_scaler2 = 0, s_fwd = 0, s_bwd = 0, s_top = 0;   // 16 * 2^(-p-14) per layer
+        float s_scaler1[4] = {}, s_scaler2[4] = {}, s_fwd[4] = {}, s_bwd[4] = {}, s_top[4] = {};   // g * 2^(-p-14) per layer and gate block
         int forced_block_steps = 0;      // host copy of K2's steps-per-task override (trajectory recording, tuning knob)
     } q8;
     double* d_calibration = nullptr;
