@@ -45,6 +45,7 @@ PEAK_FP32_MFMA = 157.3e12      # MI355X_MICROARCH.md: dense fp32 MFMA peak, FLOP
 # dense int8 MFMA peak: 2 x the bf16 rate (MI355X_MICROARCH.md "I8 ~2x bf16 rate (2xK)", bf16 ~2.5 PF dense);
 # the guide's own micro-benchmark ceiling for v_mfma_i32_16x16x64_i8 is 3.944 POP/s
 PEAK_I8_MFMA = 5.0e15
+PEAK_I8_MFMA_MEASURED = 3.944e15     # the guide's measured v_mfma_i32_16x16x64_i8 ceiling (MI355X_MICROARCH.md, matrix-core table)
 # PXG_LSTM_Q8 (k_lstm_q8.hip): every float32 multiply-add of a recurrent matrix product becomes EIGHT int8
 # digit products (four significance levels); executed MFMAs also multiply the zero bytes that pad a
 # 48-unit vector to the instruction's 64-wide k block
@@ -103,6 +104,7 @@ def parse(argv=None):
                     help='arithmetic of the recurrent matmuls (include/pxg.h pxg_lstm_arith); default: the '
                          'config\'s (q8 = exact fixed point on the int8 matrix pipe)')
     ap.add_argument('--no-f32-leg', action='store_true', help='skip the float32-arithmetic comparison leg of the default line')
+    ap.add_argument('--no-full-leg', action='store_true', help='skip the configs[3] (poly(A) + chimera filter) leg of the default line')
     ap.add_argument('--no-overlap-test', action='store_true',
                     help='skip the extra PCIe-overlapped steps (profiling runs: keeps the kernel '
                          'statistics to the timed steps)')
@@ -828,6 +830,129 @@ def f32_leg(args, config, local_rank, base, inject, mask, res_q8, stage_ms_q8):
     }
 
 
+def full_leg(args, ctx, base, lens, inject, orc, n_check=64, big_reads=100000):
+    """BASELINE configs[3] inside the default line: the demux stages + poly(A) (K6) + the Guppy block means (K7a) + the
+    pseudo-fusion window scan (K7b) on the SAME resident 10 000-read batch, timed like the headline (kernels + D2H of
+    the records + the scan's candidate lists, every step), the records and the candidate lists of the first reads
+    against the oracle, and once more at configs[3]'s stated batch size -- `big_reads` reads, the batch tiled on the
+    device.  Per-kernel bounds: live HIP-event times beside the committed counters of the rocprofv3 passes of
+    `--workload full` (static files, named)."""
+    mask = N.STAGE_ALL_DEMUX | N.STAGE_POLYA
+    n = len(lens)
+
+    def measure(n_reads, lens_n, steps, warm=2):
+        ev_first = np.zeros(n_reads, dtype=np.int64)
+        ev_blocks = lens_n // 15
+        buf = np.zeros(n_reads, dtype=N.RESULT_DTYPE)
+        for _ in range(warm):
+            ctx.run(mask)
+            cand = ctx.unsplit_scan(ev_first, ev_blocks)
+            res = ctx.download(buf)
+        ctx.sync()
+        acc = {k: 0.0 for k in N.TIMER_NAMES}
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.run(mask)
+            cand = ctx.unsplit_scan(ev_first, ev_blocks)
+            res = ctx.download(buf)
+            times, _ = ctx.stage_times()
+            for k in acc:
+                acc[k] += times[k]
+        ctx.sync()
+        wall = time.perf_counter() - t0
+        return wall, {k: v / steps for k, v in acc.items()}, res, cand, ev_blocks
+
+    steps = max(3, min(args.steps, 10))
+    wall, stage_ms, res, cand, ev_blocks = measure(n, lens, steps)
+    out = {
+        'config': 'BASELINE configs[3] stages (a1-a19) on the headline batch: {} reads x ~{} samples, resident'.format(n, args.samples),
+        'reads_per_s': n * steps / wall, 'ms_per_step': wall / steps * 1e3, 'steps': steps,
+        'stage_ms': {k: round(v, 4) for k, v in stage_ms.items()},
+        'gpu_ms_per_step': round(stage_ms['total'] + stage_ms['event_means'] + stage_ms['unsplit'], 4),
+        'polya_called': int((res['polya_called'] == 1).sum()),
+        'reads_with_fusion_candidates': int((np.asarray(cand[1]) > 0).sum()),
+        'statuses': {N.STATUS_NAMES[int(k)]: int(v) for k, v in zip(*np.unique(res['status'], return_counts=True))},
+    }
+    # ---- concordance, poly(A) and candidate lists included --------------------------------------------------
+    if orc is not None:
+        ns = min(n_check, n)
+        parts = [base['arena'][base['offsets'][b]:base['offsets'][b + 1]] for b in range(ns)]
+        s_arena, s_off = N.pack_reads(parts)
+        s_cal = base['calib'][:ns]
+        want = orc.process_batch(s_arena, s_off, s_cal, None if inject is None else inject[:ns], mask)
+        got = res[:ns]
+        same = [f for f in got.dtype.names if np.array_equal(got[f], want[f], equal_nan=True)]
+        iv, cnt, start = cand
+        cand_mismatch = 0
+        for i in range(ns):
+            w = want[i]
+            if w['status'] != 0 or w['seg_first'][3] < 0 or ev_blocks[i] <= 0:
+                cand_mismatch += int(cnt[i] != 0)
+                continue
+            _, sc = orc.guppy_event_means(parts[i], s_cal[i], 0, int(ev_blocks[i]), w['scale'], w['shift'])
+            wiv, wc = orc.unsplit_scan(sc, 0, (int(w['seg_last'][3]) + 1) * 15, float(s_cal[i]['sampling_rate']))
+            cand_mismatch += int(wc != cnt[i] or wiv.tolist() != iv[start[i]:start[i + 1]].tolist())
+        out['concordance'] = {
+            'reads_compared': ns, 'all_fields_bit_exact': len(same) == len(got.dtype.names),
+            'fields_differing': [f for f in got.dtype.names if f not in same],
+            'polya_called_mismatch': int((got['polya_called'] != want['polya_called']).sum()),
+            'polya_interval_mismatch': int(((got['polya_begin'] != want['polya_begin']) |
+                                            (got['polya_end'] != want['polya_end'])).sum()),
+            'polya_tails_in_sample': int((want['polya_called'] == 1).sum()),
+            'unsplit_candidate_mismatch': cand_mismatch,
+            'checker': 'oracle/libpxo.so in the context\'s arithmetic: process_batch (all record fields) + '
+                       'guppy_event_means / unsplit_scan (candidate lists)'}
+    # ---- per-kernel bounds -----------------------------------------------------------------------------------
+    n_scaled = int((res['status'] != N.STATUS_CODE['scaler_signal_too_short']).sum())
+    roof = []
+    dur = stage_ms['scaler_lstm'] * 1e-3
+    if dur:
+        roof.append({'kernel': 'k_scaler_lstm_q8 (K2)', 'bound': 'mfma', 'kernel_ms': round(stage_ms['scaler_lstm'], 4),
+                     'achieved': n_scaled * OPS_SCALER_Q8 / dur / 1e12, 'unit': 'TOP/s (int8)',
+                     'peak': PEAK_I8_MFMA / 1e12, 'frac': n_scaled * OPS_SCALER_Q8 / dur / PEAK_I8_MFMA,
+                     'frac_of_measured_int8_ceiling': n_scaled * OPS_SCALER_Q8 / dur / PEAK_I8_MFMA_MEASURED})
+    static = {}
+    try:
+        with open(os.path.join(ROOT, BOUNDS_FILE)) as fh:
+            static = json.load(fh)['kernels']
+    except (OSError, KeyError, ValueError):
+        pass
+    samples = float(lens.sum())
+    blocks = float((lens // 15).sum())
+    for name, timer, alg_bytes, what in (
+            ('k_polya (K6)', 'polya', None, 'serial peak FSM + interval DP per read (16 lanes per read): issue / latency bound'),
+            ('k_guppy_event_means (K7a)', 'event_means', samples * 2 + blocks * 4,
+             'every int16 sample in once, one float32 block mean out; fp64 pA conversion: VALU issue at HBM rate'),
+            ('k_unsplit_scan (K7b)', 'unsplit', None, 'fp64 Viterbi recurrence of ~6 overlapping windows per read: issue bound')):
+        ms = stage_ms[timer]
+        row = {'kernel': name, 'bound': 'hbm' if alg_bytes else 'issue', 'kernel_ms': round(ms, 4), 'what': what}
+        if alg_bytes and ms:
+            row.update({'achieved': alg_bytes / (ms * 1e-3) / 1e9, 'unit': 'GB/s', 'peak': PEAK_HBM / 1e9,
+                        'frac': alg_bytes / (ms * 1e-3) / PEAK_HBM, 'algorithmic_bytes': alg_bytes})
+        key = name.split(' ')[0]
+        if key in static:
+            row['counters_static'] = {k: static[key][k] for k in (
+                'avg_ms', 'valu_issue_frac_of_simd_cycles', 'wait_any_frac_of_wave_cycles',
+                'lds_bank_conflict_frac_of_lds_cycles', 'hbm_bytes', 'hbm_GBps') if k in static[key]}
+            row['counters_source'] = 'static: ' + BOUNDS_FILE
+        roof.append(row)
+    out['roofline'] = roof
+    # ---- configs[3]'s stated batch size: tiled on the device -----------------------------------------------
+    try:
+        ctx.upload_tiled(big_reads, base['arena'], base['offsets'], base['calib'], inject, phase=0)
+        lens_big = lens[np.arange(big_reads) % n]
+        w2, st2, res2, cand2, _ = measure(big_reads, lens_big, 3, warm=1)
+        out['at_{}_reads'.format(big_reads)] = {
+            'reads_per_s': big_reads * 3 / w2, 'ms_per_step': w2 / 3 * 1e3, 'steps': 3,
+            'distinct_reads': n, 'tiled_on_device': True,
+            'stage_ms': {k: round(v, 4) for k, v in st2.items()},
+            'records_equal_to_the_10000_read_run': bool(res2[:n].tobytes() == res.tobytes()),
+            'polya_called': int((res2['polya_called'] == 1).sum())}
+    except N.PxgError as exc:
+        out['at_{}_reads'.format(big_reads)] = {'error': str(exc)}
+    return out
+
+
 def make_context(args, config, local_rank):
     if args.context_factory:
         import importlib
@@ -1038,6 +1163,10 @@ def main():
             roofline = {'kernel': 'k_scaler_lstm_q8', 'bound': 'mfma',
                         'achieved': ops / dur / 1e12 if dur else None, 'peak': PEAK_I8_MFMA / 1e12,
                         'unit': 'TOP/s (int8)', 'frac': ops / dur / PEAK_I8_MFMA if dur else None,
+                        # the guide lists no int8 spec figure: `peak` is 2 x its dense bf16 figure (nominal, 2.4 GHz);
+                        # beside it the fraction of the guide's MEASURED v_mfma_i32_16x16x64_i8 ceiling
+                        'peak_guide_measured': PEAK_I8_MFMA_MEASURED / 1e12,
+                        'frac_of_guide_measured_ceiling': ops / dur / PEAK_I8_MFMA_MEASURED if dur else None,
                         'traffic': None, 'algorithmic_int8_op_per_read': OPS_SCALER_Q8,
                         'executed_int8_TOPs': n_scaled * OPS_SCALER_Q8_EXECUTED / dur / 1e12 if dur else None,
                         'executed_frac': n_scaled * OPS_SCALER_Q8_EXECUTED / dur / PEAK_I8_MFMA if dur else None,
@@ -1229,6 +1358,16 @@ def main():
             extra['f32_arith'] = f32_leg(args, config, local_rank, base, inject, mask, res, stage_ms)
         except Exception as exc:                       # reported, never hidden
             extra['f32_arith'] = {'error': '{}: {}'.format(type(exc).__name__, exc)}
+
+    # ---- BASELINE configs[3] (a1-a19: + poly(A) + Guppy block means + window scan) in THIS line: the stages the
+    # `full` workload times, on the headline batch and at 100 000 reads tiled on the device ---------------------
+    if not standin and world == 1 and not n_base and not args.no_full_leg and args.workload == 'demux' and \
+            args.length_dist is None and not use_inject:
+        try:
+            extra['full'] = full_leg(args, ctx, base, lens, inject, orc if (args.cpu_sample > 0) else None)
+        except Exception as exc:                       # reported, never hidden
+            extra['full'] = {'error': '{}: {}'.format(type(exc).__name__, exc)}
+        ctx.upload(base['arena'], base['offsets'], base['calib'], inject)        # the headline batch again
 
     # ---- the reference-shaped API (never `value` of the default line): process_batch calls ----
     api = None

@@ -325,7 +325,10 @@ int pxg_process_batch_ex(pxg_ctx* ctx, int64_t n_reads, const int16_t* raw_arena
  * several threads while the pipeline is full -- one batch computing, one staged -- are gathered and run as ONE
  * batch: the first caller of a group waits for the spare slot on everybody's behalf, copies each call's samples
  * from where they lie, runs the stages and hands every call its slice of the records.  A lone call starts at once;
- * groups grow with the load.  Records are those of separate calls (each is a function of its read alone).
+ * groups grow with the load, up to 65 536 reads (a call that would overfill a group runs alone behind it).  Records
+ * are those of separate calls (each is a function of its read alone).  What a merged call does NOT keep to itself: an
+ * error of the shared batch (out of memory, a HIP error) is returned to every call of the group with a message that
+ * starts "merged", and pxg_batch_times / the resident-batch queries after such a call describe the whole group.
  * pxg_merge_stats: groups run so far and the calls they carried (PXG_NO_CALL_MERGE=1 at pxg_create switches it off). */
 int pxg_merge_stats(pxg_ctx* ctx, int64_t* groups, int64_t* calls);
 

@@ -28,78 +28,7 @@
 // ds_read_b128, conflict-free.  Weight fragments are laid out by the host in exactly the register
 // order (pxg_q8_upload) and stay in VGPRs for the whole launch.
 #include "k_lstm_q8.h"
-#include <type_traits>
-#ifndef Q8S_SCHED
-#define Q8S_SCHED 0
-#endif
 
-
-// ---- hand-placed interleave (Q8S_SCHED == 2) ----------------------------------------------------------------
-template <int I, int N, typename F>
-__device__ __forceinline__ void q8_static_for(F&& f)
-{
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        q8_static_for<I + 1, N>(f);
-    }
-}
-
-// the J-th (0..7) digit product of one 64-wide k block (the order of q8_block)
-template <int J, bool FIRST>
-__device__ __forceinline__ void q8_product(Q8Acc& A, v4i w2, v4i w1, v4i w0, const v4i (&h)[3])
-{
-    const v4i z = {0, 0, 0, 0};
-    if constexpr (J == 0) A.a0 = mfma8(w2, h[2], FIRST ? z : A.a0);
-    if constexpr (J == 1) A.a1 = mfma8(w2, h[1], FIRST ? z : A.a1);
-    if constexpr (J == 2) A.a2 = mfma8(w2, h[0], FIRST ? z : A.a2);
-    if constexpr (J == 3) A.a3 = mfma8(w1, h[0], FIRST ? z : A.a3);
-    if constexpr (J == 4) A.a1 = mfma8(w1, h[2], A.a1);
-    if constexpr (J == 5) A.a2 = mfma8(w1, h[1], A.a2);
-    if constexpr (J == 6) A.a3 = mfma8(w0, h[1], A.a3);
-    if constexpr (J == 7) A.a2 = mfma8(w0, h[2], A.a2);
-}
-
-// cells_update (k_lstm_shared.h) with the clamp and the position of the NT * 4 gate arguments already taken
-template <int NT>
-__device__ __forceinline__ void cells_update_pre(const float4* tab, const float (&uc)[NT * 4], const float (&sp)[NT * 4],
-                                                 float (&C)[NT], float (&h)[NT])
-{
-    float4 c[NT][4];
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) c[nt][r] = tab[pxg_sig_segment(uc[nt * 4 + r]) + PXG_SIG_HALF];
-    float s2[NT], og[NT];
-    float4 c2[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-        float g[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const float s = sp[nt * 4 + r];
-            float p = __builtin_fmaf(c[nt][r].w, s, c[nt][r].z);
-            p = __builtin_fmaf(p, s, c[nt][r].y);
-            g[r] = __builtin_fmaf(p, s, c[nt][r].x);
-        }
-        const float G = __builtin_fmaf(64.0f, g[2], -32.0f);
-        const float fc = g[1] * C[nt];
-        const float in = g[0] * G;
-        const float cn = fc + in;
-        C[nt] = cn;
-        og[nt] = g[3];
-        const float u = __builtin_amdgcn_fmed3f(cn, -512.0f, 511.99997f);
-        s2[nt] = pxg_sig_position(u);
-        c2[nt] = tab[pxg_sig_segment(u) + PXG_SIG_HALF];
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; nt++) {
-        float p = __builtin_fmaf(c2[nt].w, s2[nt], c2[nt].z);
-        p = __builtin_fmaf(p, s2[nt], c2[nt].y);
-        const float st = __builtin_fmaf(p, s2[nt], c2[nt].x);
-        const float th = __builtin_fmaf(2.0f, st, -1.0f);
-        h[nt] = og[nt] * th;
-    }
-}
 
 // ===========================================================================
 // K2: scaler, time-sliced (tasks = (step block, tile) as in k_scaler_lstm_q; with no more tiles
@@ -215,12 +144,19 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
         }
         __syncthreads();
 
-        // One step: layer 1 at t, layer 2 at t - 1.  DO1 / DO2 = the layer's cells are updated (layer 1 not at t = T,
-        // layer 2 not at t = 0): the interior steps are ONE basic block, so that the scheduler may run layer 1's cell
-        // update between layer 2's MFMAs (Q8S_SCHED: two VALU instructions in the shadow of each -- tools/ubench/
-        // i8_mfma_32x32.hip: up to two per v_mfma_i32_16x16x64_i8 issue for free, the third costs its full slot).
-        auto step = [&](int t, auto do1, auto do2) __attribute__((always_inline)) {
-            constexpr bool DO1 = decltype(do1)::value, DO2 = decltype(do2)::value;
+        for (int t = t0; t < t1; t++) {
+            if (((t - t0) % XCH) == 0 && t < T) {        // refill the x tile (rows x XCH steps)
+                __syncthreads();
+                for (int i = tid; i < 16 * (XCH / 4); i += LSTM_THREADS) {
+                    const int row = i / (XCH / 4), c4 = i % (XCH / 4);
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int rd = ridx[row];
+                    if (rd >= 0 && t + c4 * 4 < T)
+                        v = *reinterpret_cast<const float4*>(head + (size_t)rd * T + t + c4 * 4);
+                    *reinterpret_cast<float4*>(xb + row * XS + c4 * 4) = v;
+                }
+                __syncthreads();
+            }
             const unsigned char* hr = hv + (t & 1) * 2 * Q8_HVEC;
             unsigned char* hw = hv + ((t + 1) & 1) * 2 * Q8_HVEC;
             v4i g1[3], g2[3];
@@ -230,20 +166,6 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
 
             // ---- layer 1, step t ---------------------------------------------------------
             f32x4 u[NT];
-#if Q8S_SCHED == 2
-            Q8Acc Al[NT];
-            f32x4 stl[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++)
-                q8_block<true>(Al[nt], wA[nt][1], wA[nt][0], w0s[(0 * NT + nt) * LSTM_THREADS + tid], g1);
-#pragma unroll
-            for (int nt = 0; nt < NT; nt++) {
-                const float4 b = gvec[gv + nt * 4], w = gvec[H + gv + nt * 4];
-                stl[nt][0] = __builtin_fmaf(x, w.x, b.x); stl[nt][1] = __builtin_fmaf(x, w.y, b.y);
-                stl[nt][2] = __builtin_fmaf(x, w.z, b.z); stl[nt][3] = __builtin_fmaf(x, w.w, b.w);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#else
             {
                 Q8Acc A[NT];
 #pragma unroll
@@ -258,64 +180,6 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
                 }
                 q8_combine_tiles<NT>(u, A, s1, st);
             }
-#endif
-#if Q8S_SCHED == 2
-            // ---- layer 2's 48 MFMAs, each followed by two VALU instructions of layer 1's combine / look-up preparation
-            Q8Acc B[NT];
-            if constexpr (DO1) {
-                int V[NT * 4], U[NT * 4];
-                float fV[NT * 4], fU[NT * 4], uc[NT * 4], sp[NT * 4];
-                v4i w0cur;
-                // The order is pinned twice: a data dependence through an empty asm statement after every {MFMA, two
-                // VALU} group (instruction selection emits a block in dependence order and would otherwise sink
-                // the MFMAs below the whole combine) and a sched_barrier for the machine scheduler.
-                q8_static_for<0, 48>([&](auto ic) {
-                    constexpr int I = decltype(ic)::value, nt = I / 16, blk = (I / 8) & 1, J = I & 7;
-                    // (the digit-0 fragment of a block is requested with the block's first product and used by its last two)
-                    if constexpr (J == 0) w0cur = w0s[((1 + blk) * NT + nt) * LSTM_THREADS + tid];
-                    if constexpr (blk == 0) q8_product<J, true>(B[nt], wB[nt][1], wB[nt][0], w0cur, g1);
-                    else q8_product<J, false>(B[nt], wC[nt][1], wC[nt][0], w0cur, g2);
-                    v4i& acc = (J == 0) ? B[nt].a0 : (J == 1 || J == 4) ? B[nt].a1 : (J == 3 || J == 6) ? B[nt].a3 : B[nt].a2;
-                    if constexpr (I < 36) {
-                        constexpr int g = I / 3, k = I % 3, gn = g >> 2, gr = g & 3;
-                        if constexpr (k == 0) {
-                            V[g] = (Al[gn].a0[gr] << 8) + Al[gn].a1[gr];
-                            U[g] = (Al[gn].a2[gr] << 8) + Al[gn].a3[gr];
-                            asm volatile("" : "+v"(acc), "+v"(V[g]), "+v"(U[g]), "+v"(g1[0]), "+v"(g1[1]), "+v"(g1[2]), "+v"(g2[0]), "+v"(g2[1]), "+v"(g2[2]));
-                        } else if constexpr (k == 1) {
-                            fV[g] = (float)V[g];
-                            fU[g] = (float)U[g];
-                            asm volatile("" : "+v"(acc), "+v"(fV[g]), "+v"(fU[g]), "+v"(g1[0]), "+v"(g1[1]), "+v"(g1[2]), "+v"(g2[0]), "+v"(g2[1]), "+v"(g2[2]));
-                        } else {
-                            float tt = __builtin_fmaf(fV[g], 65536.0f, fU[g]);
-                            float uu = __builtin_fmaf(tt, s1.g[gr], stl[gn][gr]);
-                            // (the next group's inputs -- a gate's four levels -- wait here as well)
-                            constexpr int g2n = (g + 1 < 12 ? g + 1 : 11) >> 2;
-                            asm volatile("" : "+v"(acc), "+v"(uu), "+v"(g1[0]), "+v"(g1[1]), "+v"(g1[2]), "+v"(g2[0]), "+v"(g2[1]), "+v"(g2[2]),
-                                         "+v"(Al[g2n].a0), "+v"(Al[g2n].a1), "+v"(Al[g2n].a2), "+v"(Al[g2n].a3));
-                            u[gn][gr] = uu;
-                        }
-                    } else {
-                        constexpr int g = I - 36, gn = g >> 2, gr = g & 3;
-                        uc[g] = __builtin_amdgcn_fmed3f(u[gn][gr], -512.0f, 511.99997f);
-                        sp[g] = pxg_sig_position(uc[g]);
-                        asm volatile("" : "+v"(acc), "+v"(uc[g]), "+v"(sp[g]), "+v"(g1[0]), "+v"(g1[1]), "+v"(g1[2]), "+v"(g2[0]), "+v"(g2[1]), "+v"(g2[2]));
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                float hn[NT];
-                unsigned plane[3];
-                cells_update_pre<NT>(tab, uc, sp, c1, hn);
-                q8_pack<NT>(hn, plane);
-                q8_store_h(hw, plane, slice, lane);
-            } else {
-#pragma unroll
-                for (int nt = 0; nt < NT; nt++) {
-                    q8_block<true>(B[nt], wB[nt][1], wB[nt][0], w0s[(1 * NT + nt) * LSTM_THREADS + tid], g1);
-                    q8_block<false>(B[nt], wC[nt][1], wC[nt][0], w0s[(2 * NT + nt) * LSTM_THREADS + tid], g2);
-                }
-            }
-#else
             // ---- layer 2, step t - 1: inputs h1(t-1), h2(t-2); layer 1's cells under its MFMAs -----
             Q8Acc B[NT];
 #pragma unroll
@@ -323,14 +187,13 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
                 q8_block<true>(B[nt], wB[nt][1], wB[nt][0], w0s[(1 * NT + nt) * LSTM_THREADS + tid], g1);
                 q8_block<false>(B[nt], wC[nt][1], wC[nt][0], w0s[(2 * NT + nt) * LSTM_THREADS + tid], g2);
             }
-            if constexpr (DO1) {
+            if (t < T) {
                 float hn[NT];
                 unsigned plane[3];
                 cells_update<NT>(tab, u, c1, hn);
                 q8_pack<NT>(hn, plane);
                 q8_store_h(hw, plane, slice, lane);
             }
-#endif
             {
                 f32x4 st[NT];
 #pragma unroll
@@ -340,43 +203,14 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
                 }
                 q8_combine_tiles<NT>(u, B, s2, st);
             }
-            if constexpr (DO2) {
+            if (t >= 1) {
                 float hn[NT];
                 unsigned plane[3];
                 cells_update<NT>(tab, u, c2, hn);
                 q8_pack<NT>(hn, plane);
                 q8_store_h(hw + Q8_HVEC, plane, slice, lane);
             }
-#if Q8S_SCHED == 1
-            if constexpr (DO1 && DO2) {
-                // layer 1's 24 MFMAs back to back (nothing independent of them is ready yet), then 48 x {1 MFMA, 2 VALU}
-                __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
-#pragma unroll
-                for (int i = 0; i < 48; i++) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                }
-            }
-#endif
             __syncthreads();
-        };
-
-        for (int t = t0; t < t1; t++) {
-            if (((t - t0) % XCH) == 0 && t < T) {        // refill the x tile (rows x XCH steps)
-                __syncthreads();
-                for (int i = tid; i < 16 * (XCH / 4); i += LSTM_THREADS) {
-                    const int row = i / (XCH / 4), c4 = i % (XCH / 4);
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const int rd = ridx[row];
-                    if (rd >= 0 && t + c4 * 4 < T)
-                        v = *reinterpret_cast<const float4*>(head + (size_t)rd * T + t + c4 * 4);
-                    *reinterpret_cast<float4*>(xb + row * XS + c4 * 4) = v;
-                }
-                __syncthreads();
-            }
-            if (t == 0) step(t, std::true_type{}, std::false_type{});
-            else if (t == T) step(t, std::false_type{}, std::true_type{});
-            else step(t, std::true_type{}, std::true_type{});
         }
 
         if (t1 == T + 1) {

@@ -1031,6 +1031,7 @@ extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
 // every call its slice of the records.  Results are those of separate calls: every record is a function of its
 // read alone (tests/test_gpu_parity.py::test_small_calls_are_merged_into_one_batch).
 #define PXG_MERGE_MAX_READS 4096
+#define PXG_MERGE_MAX_GROUP_READS 65536
 
 static int merged_process(pxg_ctx* ctx, pxg_ctx::MergeItem& mine, uint32_t stage_mask, bool& bypass)
 {
@@ -1041,7 +1042,18 @@ static int merged_process(pxg_ctx* ctx, pxg_ctx::MergeItem& mine, uint32_t stage
         bypass = true;
         return PXG_OK;
     }
-    mq.pending.push_back(&mine);
+    // a group never grows beyond what ONE call could stage (PXG_MERGE_MAX_GROUP_READS reads): a call that would
+    // overfill it goes alone, behind the group
+    if (mq.pending_reads + mine.n > PXG_MERGE_MAX_GROUP_READS) {
+        bypass = true;
+        return PXG_OK;
+    }
+    try {
+        mq.pending.push_back(&mine);
+    } catch (const std::exception& e) {
+        return fail(ctx, PXG_E_NOMEM, std::string("merged calls: ") + e.what());
+    }
+    mq.pending_reads += mine.n;
     mq.mask = stage_mask;
     if (mq.leader) {
         mq.cv.wait(lk, [&] { return mine.done; });
@@ -1053,6 +1065,7 @@ static int merged_process(pxg_ctx* ctx, pxg_ctx::MergeItem& mine, uint32_t stage
     lk.lock();
     std::vector<pxg_ctx::MergeItem*> items;
     items.swap(mq.pending);
+    mq.pending_reads = 0;
     mq.leader = false;
     mq.groups++;
     mq.calls += (int64_t)items.size();
@@ -1138,6 +1151,9 @@ static int merged_process(pxg_ctx* ctx, pxg_ctx::MergeItem& mine, uint32_t stage
     } catch (const std::exception& e) {
         rc = fail(ctx, PXG_E_NOMEM, std::string("merged calls: ") + e.what());
     }
+    // a failed group may have copies of the callers' arenas queued: nobody is released (and frees its arena) before
+    // they have run
+    if (rc != PXG_OK) (void)hipStreamSynchronize(ctx->copy_stream);
     if (run_lock.owns_lock()) run_lock.unlock();
     if (stage_lock.owns_lock()) stage_lock.unlock();
     lk.lock();
@@ -1262,6 +1278,16 @@ struct Scratch {               // RAII device temporaries for the hooks
     }
 };
 
+// an early `return rc` behind the first asynchronous copy / launch of a call leaves work queued that reads buffers the
+// caller may free next: the stream is drained on every exit the success path has not dismissed
+struct StreamSyncOnError {
+    hipStream_t st;
+    bool armed = true;
+    explicit StreamSyncOnError(hipStream_t s) : st(s) {}
+    void dismiss() { armed = false; }
+    ~StreamSyncOnError() { if (armed) (void)hipStreamSynchronize(st); }
+};
+
 #define HOOK_BEGIN                                           \
     if (!ctx) return PXG_E_INVALID;                          \
     PXG_HIP(ctx, hipSetDevice(ctx->device));                 \
@@ -1373,6 +1399,17 @@ extern "C" int pxg_batch_pooled_signal(pxg_ctx* ctx, const int64_t* first, const
     const size_t total = (size_t)out_offsets[n];
     if (!total) return PXG_OK;
     if (!out) return fail(ctx, PXG_E_INVALID, "pxg_batch_pooled_signal: out is null");
+    // a batch staged with a prefix limit holds only the first `resident_limit` samples of each read: a stretch that
+    // ends behind them would be pooled from whatever the arena held before
+    if (ctx->resident_limit > 0) {
+        const int64_t stride = ctx->cfg.stride;
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t len = out_offsets[i + 1] - out_offsets[i];
+            if (len > 0 && (first[i] < 0 || (first[i] + len) * stride > ctx->resident_limit))
+                return fail(ctx, PXG_E_STATE, "pxg_batch_pooled_signal: a stretch ends behind the prefix this batch was "
+                                              "staged with (pxg_batch_stage_prefix); stage whole reads for it");
+        }
+    }
     int64_t* d_first = S.put(first, (size_t)n, ctx->stream);
     int64_t* d_ooff = S.put(out_offsets, (size_t)n + 1, ctx->stream);
     float* d_out = S.alloc<float>(total);
@@ -1611,8 +1648,12 @@ extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
         return rc;
     int64_t* d_first = ctx->ev_first.p;
     int64_t* d_eoff = ctx->ev_off.p;
-    PXG_HIP(ctx, hipMemcpyAsync(d_first, first.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-    PXG_HIP(ctx, hipMemcpyAsync(d_eoff, eoff.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    // (through the context's page-locked mirrors, like every other small host array of a batch: the runtime is never
+    //  handed pageable memory whose lifetime ends with this call -- ADVICE r4, profiles/r05/fault_hunt.md)
+    if ((rc = pxg_h2d_meta(ctx, 2, 0, d_first, first.data(), (size_t)n * sizeof(int64_t), ctx->stream)) ||
+        (rc = pxg_h2d_meta(ctx, 2, 1, d_eoff, eoff.data(), ((size_t)n + 1) * sizeof(int64_t), ctx->stream)))
+        return rc;
+    StreamSyncOnError guard(ctx->stream);
     pxg_timer_begin(ctx, PXG_T_EVENT_MEANS);
     rc = pxg_launch_guppy_event_means(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p,
                                       d_first, d_eoff, block_stride, ctx->ev_mean.p, ctx->ev_scaled.p);
@@ -1636,6 +1677,7 @@ extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
     HOOK_GET(out_count, ctx->unsplit_cnt.p, n);
     HOOK_GET(out_total, ctx->unsplit_ivoff.p + n, 1);
     PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    guard.dismiss();
     const int64_t got = std::min(*out_total, cap_intervals);
     if (got > 0) HOOK_GET(out_intervals, ctx->unsplit_iv.p, (size_t)got * 2);
     for (int64_t i : bad) out_count[i] = PXG_UNSPLIT_E_GEOMETRY;
@@ -1665,7 +1707,7 @@ extern "C" int pxg_batch_unsplit_scan_events(pxg_ctx* ctx, const int64_t* n_even
     const int64_t step_min = (int64_t)(c.unsplit_window_step * ctx->rate_min);
     if (step_min < 1 || win_max < 0) return fail(ctx, PXG_E_INVALID, "unsplit_read_detection window_size / window_step out of range");
     // per-read tables; the most events any window [left, left + win_max] can hold bounds the back-pointer rows
-    std::vector<int64_t> eoff((size_t)n + 1, 0), zero((size_t)n, 0);
+    std::vector<int64_t> eoff((size_t)n + 1, 0);
     std::vector<int64_t> bad;
     int64_t units_bound = 0, tmax64 = 2;
     for (int64_t i = 0; i < n; i++) {
@@ -1705,12 +1747,12 @@ extern "C" int pxg_batch_unsplit_scan_events(pxg_ctx* ctx, const int64_t* n_even
         (rc = pxg_reserve(ctx, ctx->unsplit_scr, pxg_unsplit_scratch_bytes(ctx, units_bound, tmax))) ||
         (rc = pxg_reserve(ctx, ctx->unsplit_cand, pxg_unsplit_cand_bytes(units_bound, wcand))))
         return rc;
-    PXG_HIP(ctx, hipMemcpyAsync(ctx->ev_first.p, zero.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-    PXG_HIP(ctx, hipMemcpyAsync(ctx->ev_off.p, eoff.data(), ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-    if (ne_all) {
-        PXG_HIP(ctx, hipMemcpyAsync(ctx->ev_tstart.p, ev_start, ne_all * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
-        PXG_HIP(ctx, hipMemcpyAsync(ctx->ev_mean.p, ev_mean, ne_all * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    }
+    PXG_HIP(ctx, hipMemsetAsync(ctx->ev_first.p, 0, (size_t)n * sizeof(int64_t), ctx->stream));
+    if ((rc = pxg_h2d_meta(ctx, 2, 1, ctx->ev_off.p, eoff.data(), ((size_t)n + 1) * sizeof(int64_t), ctx->stream)) ||
+        (ne_all && ((rc = pxg_h2d_meta(ctx, 2, 2, ctx->ev_tstart.p, ev_start, ne_all * sizeof(int64_t), ctx->stream)) ||
+                    (rc = pxg_h2d_meta(ctx, 2, 3, ctx->ev_mean.p, ev_mean, ne_all * sizeof(float), ctx->stream)))))
+        return rc;
+    StreamSyncOnError guard(ctx->stream);
     pxg_timer_begin(ctx, PXG_T_EVENT_MEANS);
     if ((rc = pxg_launch_scale_event_means(ctx, n, (int64_t)ne_all, ctx->ev_off.p, ctx->ss.p, ctx->ev_mean.p, ctx->ev_scaled.p)))
         return rc;
@@ -1730,6 +1772,7 @@ extern "C" int pxg_batch_unsplit_scan_events(pxg_ctx* ctx, const int64_t* n_even
     HOOK_GET(out_count, ctx->unsplit_cnt.p, n);
     HOOK_GET(out_total, ctx->unsplit_ivoff.p + n, 1);
     PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    guard.dismiss();
     const int64_t got = std::min(*out_total, cap_intervals);
     if (got > 0) HOOK_GET(out_intervals, ctx->unsplit_iv.p, (size_t)got * 2);
     for (int64_t i : bad) out_count[i] = PXG_UNSPLIT_E_GEOMETRY;

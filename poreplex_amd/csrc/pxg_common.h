@@ -360,6 +360,7 @@ struct pxg_ctx {
         std::mutex m;
         std::condition_variable cv;
         std::vector<MergeItem*> pending;
+        int64_t pending_reads = 0;           // reads of `pending` (a group is capped at PXG_MERGE_MAX_GROUP_READS)
         uint32_t mask = 0;
         bool leader = false;                 // a caller is waiting for the spare slot on behalf of `pending`
         std::vector<int64_t> h_off;          // merged offsets / calibration / records of the group in flight
@@ -379,7 +380,7 @@ struct pxg_ctx {
     // ... and the small host arrays of a batch (offsets, calibration, injected scaling, chunk-record-free metadata)
     // are copied into page-locked mirrors first and sent from there: [0] the staging calls (one stage at a time:
     // mt_stage / the caller's own order), [1] pxg_batch_upload.
-    struct HostMirror { void* p = nullptr; size_t cap = 0; } h_meta[2][3];
+    struct HostMirror { void* p = nullptr; size_t cap = 0; } h_meta[3][4];     // [spare slot | resident batch | scan hooks][array]
     bool merge_small_calls = true;           // PXG_NO_CALL_MERGE=1 at pxg_create: every call is its own batch
     std::mutex mt_stage, mt_run; // pxg_process_batch(_ex) from several host threads: spare slot / resident batch
     bool polya_ran = false;

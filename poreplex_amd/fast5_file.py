@@ -399,13 +399,20 @@ class Fast5File:
 
     def events(self, i, n_rows):
         """The consumed columns of read i's Events table in the file's own dtypes (pxg_h5_events)."""
-        import ctypes as C
-        n = max(int(n_rows), 1)
+        n, width = max(int(n_rows), 1), 8
         info = np.zeros(21, dtype=np.int32)
-        cols = {k: np.zeros(n, dtype=np.float64) for k in EVENT_NUMERIC}
-        text = np.zeros(n, dtype='S8')
-        got = self.lib.pxg_h5_events(self.handle, i, n, info.ctypes.data, *[cols[k].ctypes.data for k in EVENT_NUMERIC],
-                                     text.ctypes.data, 8)
+        for _attempt in range(2):
+            # sized from the move count and the usual 5-mer text first; the reader fills `info` and returns the row count
+            # it needs BEFORE it converts anything, so a longer table or a wider model_state column costs one more call
+            cols = {k: np.zeros(n, dtype=np.float64) for k in EVENT_NUMERIC}
+            text = np.zeros(n, dtype='S{}'.format(width))
+            got = self.lib.pxg_h5_events(self.handle, i, n, info.ctypes.data,
+                                         *[cols[k].ctypes.data for k in EVENT_NUMERIC], text.ctypes.data, width)
+            need_w = int(info[19]) if info[18] >= 0 else 0
+            if got > n or need_w > width:
+                n, width = max(int(got), n, 1), max(need_w, width)
+                continue
+            break
         if got < 0 or got > n:
             raise Fast5Error((self.lib.pxg_h5_last_error() or b'').decode(errors='replace') or 'Events table changed size')
         out = {}

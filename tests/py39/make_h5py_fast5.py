@@ -53,6 +53,20 @@ with h5py.File(os.path.join(out,'single_albacore.fast5'),'w') as h5:
     s_ = g.create_group('Summary/basecall_1d_template'); s_.attrs['sequence_length']=np.int32(len(seq)); s_.attrs['mean_qscore']=np.float32(9.5)
     sg = h5['Analyses'].create_group('Segmentation_000/Summary/segmentation'); sg.attrs['num_events_template']=np.int32(n); sg.attrs['first_sample_template']=np.int32(5)
     np.save(os.path.join(out, 'truth_albacore_events.npy'), ev)
+# the same table with an 11-character model_state column (wider than the 5-mers of the shipped models)
+ALBW = [(k, 'S11' if k in ('model_state', 'mp_state') else d) for k, d in ALB]
+with h5py.File(os.path.join(out,'single_albacore_wide.fast5'),'w') as h5:
+    fill(h5.create_group('Raw/Reads/Read_11'), h5.create_group('UniqueGlobalKey/channel_id'), h5.create_group('UniqueGlobalKey/tracking_id'), h5.create_group('Analyses'), 'rid-albacore-wide', raw, 3, bc=False)
+    g = h5['Analyses'].create_group('Basecall_1D_000'); t = g.create_group('BaseCalled_template')
+    evw = np.zeros(n, dtype=ALBW)
+    for k, _d in ALB:
+        evw[k] = ev[k]
+    evw['model_state'] = np.array([''.join(k) for k in rng.choice(list('ACGT'), (n, 11))], dtype='S11'); evw['mp_state'] = evw['model_state']
+    t.create_dataset('Fastq', data=np.string_('@rid-albacore-wide\n%s\n+\n%s\n' % (seq, q)))
+    t.create_dataset('Events', data=evw)
+    s_ = g.create_group('Summary/basecall_1d_template'); s_.attrs['sequence_length']=np.int32(len(seq)); s_.attrs['mean_qscore']=np.float32(9.5)
+    sg = h5['Analyses'].create_group('Segmentation_000/Summary/segmentation'); sg.attrs['num_events_template']=np.int32(n); sg.attrs['first_sample_template']=np.int32(5)
+    np.save(os.path.join(out, 'truth_albacore_wide_events.npy'), evw)
 with h5py.File(os.path.join(out,'single_latest.fast5'),'w', libver='latest') as h5:
     fill(h5.create_group('Raw/Reads/Read_9'), h5.create_group('UniqueGlobalKey/channel_id'), h5.create_group('UniqueGlobalKey/tracking_id'), h5.create_group('Analyses'), 'rid-latest', raw_of(2), 2, bc=False)
 with h5py.File(os.path.join(out,'multi.fast5'),'w') as h5:

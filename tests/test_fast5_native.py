@@ -250,6 +250,15 @@ def test_native_reader_reads_what_the_real_library_wrote(tmp_path):
     for name in ('start', 'length', 'mean', 'stdv', 'move', 'p_model_state', 'model_state'):
         got = bc['events'][name]
         assert got.dtype == want[name].dtype and np.array_equal(got, want[name]), name
+    # a row guess that is too small, and a model_state column wider than the 5-mers the buffers start with: the
+    # reader says what it needs and is asked again (the h5py reader accepts both)
+    small = f.events(0, 1)
+    assert all(np.array_equal(small[k], want[k]) for k in small) and len(small['start']) == len(want)
+    f = F5.Fast5File(str(tmp_path / 'single_albacore_wide.fast5'))
+    want = np.load(str(tmp_path / 'truth_albacore_wide_events.npy'))
+    bc = f.basecall(0)
+    assert bc['events']['model_state'].dtype == np.dtype('S11') and np.array_equal(bc['events']['model_state'], want['model_state'])
+    assert np.array_equal(bc['events']['start'], want['start'])
     # `libver latest` with more than eight attributes on a group: dense storage, declined per read
     f = F5.Fast5File(str(tmp_path / 'single_latest.fast5'))
     assert f.info['status'][0] == N.PXG_E_UNSUPPORTED and b'dense attribute storage' in f.info['error'][0]
