@@ -543,6 +543,285 @@ __global__ __launch_bounds__(64) void k_unsplit_scan(
     }
 }
 
+// ---- round 5: one WINDOW per lane ----------------------------------------------------------------------------------
+// k_unsplit_scan above spreads the <= 8 states of a window over 8 lanes: every step fetches the in-edge values through
+// the LDS crossbar (two ds_bpermute per double and edge), takes the maxima with ballot-mask selects and ORs the
+// sources together over three DPP steps -- ~45 wave instructions per step for 8 windows, 70 % VALU issue and a
+// quarter of the LDS cycles bank conflicts (profiles/r04/full_kernel_bounds.json).  A batch has ~6 windows per read
+// (60 000 per 10 000 reads), so a LANE can own a window: its states live in its own registers, a step is
+// v'[j] = max_i (v[i] + A[i][j]) + e[j] over a DENSE matrix with static register indices (a missing edge is -inf and
+// never wins: strict >) -- no cross-lane traffic, no LDS on the recurrence, a step's back pointers are one coalesced
+// 256-byte store.  The kernel works in RANK space (state = its position in the name-sorted order, the host permutes
+// the model: UnsplitDense), so that running over the sources i = 0 .. n-1 IS the name-sorted slot order of the
+// reference's argmax (worker_persistence.py:95-121 via pomegranate's edge order) and ties break as before.
+// Same arithmetic, operation for operation.  For models of up to UD_S states (the reference's has 6); larger ones keep
+// the 8-lane kernel.
+#define UD_S 6
+struct UnsplitDense {
+    int n_states;
+    int adapter_rank, ll_rank, lh_rank;
+    int n_mix[UD_S];
+    double A[UD_S][UD_S];            // log p(rank i -> rank j), -inf: no edge
+    double start[UD_S];
+    double mu[UD_S][PXG_MAX_MIXTURE], lssp[UD_S][PXG_MAX_MIXTURE], tss[UD_S][PXG_MAX_MIXTURE], logw[UD_S][PXG_MAX_MIXTURE];
+};
+
+// The emissions of rank q for the XC steps of a round from parameter rows in LDS ([4 kinds: mu, lssp, tss, logw][rank]
+// [mixture]): the values and the operations of un_emission, written round-wide so that a rank's parameters are read
+// once and the XC log-sum-exp chains of a mixture run side by side (their table reads are what a lone wave waits for).
+template <int XC, int NS>
+__device__ __forceinline__ void un_emission_round(const double* par, int n_mix, const double* lsetab, int q,
+                                                  const float (&xc)[XC], double (&em)[XC][NS])
+{
+    constexpr int K = UD_S * PXG_MAX_MIXTURE;
+    const double* row = par + q * PXG_MAX_MIXTURE;
+    {
+        const double mu = row[0], lssp = row[K], tss = row[2 * K];
+#pragma unroll
+        for (int j = 0; j < XC; j++) {
+            const double d = (double)xc[j] - mu;
+            em[j][q] = lssp - (d * d) * tss;
+        }
+    }
+    if (n_mix > 1) {
+        const double lw0 = row[3 * K];
+#pragma unroll
+        for (int j = 0; j < XC; j++) em[j][q] = em[j][q] + lw0;
+        for (int k = 1; k < n_mix; k++) {
+            const double mu = row[k], lssp = row[K + k], tss = row[2 * K + k], lw = row[3 * K + k];
+#pragma unroll
+            for (int j = 0; j < XC; j++) {
+                const double d = (double)xc[j] - mu;
+                const double l = (lssp - (d * d) * tss) + lw;
+                const double a = em[j][q], b = l;
+                const bool agb = a > b;
+                const double m = agb ? a : b, lo = agb ? b : a;
+                const double r = m + pxg_log1pexp(lsetab, lo - m);
+                em[j][q] = (m == -__builtin_inf()) ? m : ((m == __builtin_inf()) ? m : r);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_unsplit_scan_w(
+    int64_t n_reads, int tmax, UnsplitDense D, UnsplitParams P, const pxg_calib* __restrict__ cal,
+    const int32_t* __restrict__ status, const int32_t* __restrict__ segs,
+    const int64_t* __restrict__ first_sample, const int64_t* __restrict__ ev_off,
+    const int64_t* __restrict__ ev_start, const int64_t* __restrict__ unit_off, const float* __restrict__ scaled,
+    unsigned* __restrict__ bpbuf /* [wave][tmax][64 lanes] */,
+    int64_t* __restrict__ cand /* n_units x wcand x 2 */, int32_t* __restrict__ cand_cnt, int wcand,
+    const double* __restrict__ lsetab_g, unsigned long long* __restrict__ queue)
+{
+    constexpr int NS = UD_S;
+    __shared__ double lsetab[PXG_LSE_TAB_DOUBLES];
+    __shared__ double par[4 * NS * PXG_MAX_MIXTURE];
+    __shared__ double At[NS * NS];            // [destination rank][source rank]
+    for (int i = threadIdx.x; i < PXG_LSE_TAB_DOUBLES; i += blockDim.x) lsetab[i] = lsetab_g[i];
+    if (threadIdx.x == 0) {
+        constexpr int K = NS * PXG_MAX_MIXTURE;
+#pragma unroll
+        for (int i = 0; i < NS; i++)
+#pragma unroll
+            for (int j = 0; j < NS; j++) At[j * NS + i] = D.A[i][j];
+#pragma unroll
+        for (int q = 0; q < NS; q++)
+#pragma unroll
+            for (int k = 0; k < PXG_MAX_MIXTURE; k++) {
+                par[q * PXG_MAX_MIXTURE + k] = D.mu[q][k];
+                par[K + q * PXG_MAX_MIXTURE + k] = D.lssp[q][k];
+                par[2 * K + q * PXG_MAX_MIXTURE + k] = D.tss[q][k];
+                par[3 * K + q * PXG_MAX_MIXTURE + k] = D.logw[q][k];
+            }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x;
+    const int S = D.n_states;
+    unsigned* bpm = bpbuf + (size_t)blockIdx.x * tmax * 64 + lane;
+    const int64_t n_units = unit_off[n_reads];
+    constexpr int XC = 4;                    // steps per round: the emissions of a round are taken rank by rank
+    // (the transition matrix is read from LDS where it is used -- one address for all lanes, a broadcast: 36 scalar
+    //  pairs beside everything else get spilled into vector lanes and come back through v_readlane, 72 vector registers
+    //  push the round's emissions into AGPRs and come back through v_accvgpr_read, both on the serial path)
+
+    for (;;) {
+        unsigned long long claimed = 0ull;
+        if (lane == 0) claimed = atomicAdd(queue, 64ull);
+        const int64_t ubase = (int64_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(claimed >> 32)) << 32)
+                                        | (unsigned)__builtin_amdgcn_readfirstlane((int)claimed));
+        if (ubase >= n_units) break;
+        // ---- this lane's (read, window) ---------------------------------------------
+        const int64_t u = ubase + lane;
+        int64_t r = 0;
+        bool more = u < n_units;
+        const bool owned = more;
+        if (more) {              // largest r with unit_off[r] <= u
+            int64_t lo = 0, hi = n_reads;
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (unit_off[mid] <= u) lo = mid; else hi = mid;
+            }
+            r = lo;
+        }
+        const UnsplitGeom g = unsplit_geometry(more ? r : n_reads, n_reads, P, cal, status, segs,
+                                               first_sample, ev_off, ev_start);
+        int64_t k0 = 0, k1 = -1;
+        if (more) {
+            const int64_t left = g.payload_start + (u - unit_off[r]) * g.window_step;
+            more = g.valid && unsplit_window(g, P.stride, left, k0, k1);
+        }
+        int T = more ? (int)(k1 - k0 + 1) : 0;
+        const bool too_long = T > tmax;  // cannot happen: tmax is sized from the largest window the
+        if (too_long) T = 0;             // config and the batch's sampling rates allow (host side)
+        // (a lane without a window reads the first words of the log-sum-exp table instead: a batch may have no
+        //  event at all, and then there is no `scaled` to read from)
+        const float* x = more ? scaled + ev_off[r] + k0 : reinterpret_cast<const float*>(lsetab_g);
+        int Tmax = T;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const int o = __shfl_xor(Tmax, d);
+            Tmax = o > Tmax ? o : Tmax;
+        }
+        Tmax = __builtin_amdgcn_readfirstlane(Tmax);   // (the same in every lane: scalar loop control)
+        // block means are loaded unconditionally at a clamped index (a step behind a lane's window changes nothing:
+        // `act`), so that the loads of the NEXT round can stay in flight while this one is worked on -- loads under
+        // lane masks are waited for as a group
+        const int t_last = T > 0 ? T - 1 : 0;
+
+        // ---- forward pass: the lane's states in its own registers -------------------
+        double v[NS];
+#pragma unroll
+        for (int q = 0; q < NS; q++) v[q] = -__builtin_inf();
+        float xn[XC];
+#pragma unroll
+        for (int j = 0; j < XC; j++) xn[j] = x[j < t_last ? j : t_last];
+        for (int c0 = 0; c0 < Tmax; c0 += XC) {
+            float xc[XC];
+#pragma unroll
+            for (int j = 0; j < XC; j++) {
+                xc[j] = xn[j];
+                const int t = c0 + XC + j;
+                xn[j] = x[t < t_last ? t : t_last];    // the next round's means, requested a round ahead
+            }
+            // emissions of the round, rank by rank (a rank's parameters are read once per round)
+            double em[XC][NS];
+#pragma unroll
+            for (int q = 0; q < NS; q++) un_emission_round<XC, NS>(par, D.n_mix[q], lsetab, q, xc, em);
+#pragma unroll
+            for (int j = 0; j < XC; j++) {
+                const int t = c0 + j;
+                const bool act = t < T;                // (a round runs to its end: steps behind T change nothing)
+                asm volatile("" ::: "memory");         // At is read HERE, once per step (broadcast reads), not kept across steps
+                double nv[NS];
+                unsigned tbl = 0u;
+#pragma unroll
+                for (int q = 0; q < NS; q++) {
+                    double best = -__builtin_inf();
+                    unsigned arg = 7u;
+#pragma unroll
+                    for (int i = 0; i < NS; i++) {
+                        const double cand_v = v[i] + At[q * NS + i];
+                        arg = cand_v > best ? (unsigned)i : arg;          // strict: the first of equal candidates stays
+                        best = __builtin_fmax(best, cand_v);               // (no NaN can arise: nothing is +inf)
+                    }
+                    const double stepped = (t == 0) ? (D.start[q] + em[j][q]) : (best + em[j][q]);
+                    nv[q] = act ? stepped : v[q];
+                    tbl |= arg << (3 * q);
+                }
+#pragma unroll
+                for (int q = 0; q < NS; q++) v[q] = nv[q];
+                if (act) bpm[(size_t)t * 64] = tbl;    // 64 lanes, 256 contiguous bytes
+            }
+        }
+        // ---- termination: ranks in order = the name-sorted order ---------------------
+        double bestv = -__builtin_inf();
+        int cur = 0;
+#pragma unroll
+        for (int q = 0; q < NS; q++)
+            if (q < S && (q == 0 || v[q] > bestv)) { bestv = v[q]; cur = q; }
+        // ---- traceback + run analysis (signal_analyzer.py:393-418, backwards) --------
+        int phase = 0;                   // 0 none, 1 inside an adapter run, 2 leader runs before it
+        int a_last = -1, a_first = -1, lead = -1, count = 0;
+        auto finalize = [&](int lead_t) {
+            const int64_t ev_last = k0 + a_last, ev_lead = k0 + lead_t, ev_first = k0 + a_first;
+            const int64_t adapter_end = un_ev_end(g, P.stride, ev_last);
+            const int64_t leader_in_read = un_ev_start(g, P.stride, ev_lead);
+            const int64_t total_duration = adapter_end - leader_in_read;
+            const int64_t adapter_duration = adapter_end - un_ev_start(g, P.stride, ev_first);
+            const int strict = (leader_in_read - g.payload_start) <= g.strict_duration ? 1 : 0;
+            if (total_duration >= g.cut_total[strict] && adapter_duration >= g.cut_adapter[strict]) {
+                if (count < wcand) {
+                    cand[(u * wcand + count) * 2] = leader_in_read;
+                    cand[(u * wcand + count) * 2 + 1] = 1 + adapter_end;
+                }
+                count++;
+            }
+        };
+        // (a lane reads back only the words it stored itself: program order is enough)
+        constexpr int TBW = 16;
+        unsigned mn[TBW];
+        auto fetch = [&](int tb) {
+#pragma unroll
+            for (int q = 0; q < TBW; q++)
+                mn[q] = (tb >= 0 && tb + q < T) ? bpm[(size_t)(tb + q) * 64] : 0u;
+        };
+        const int tb_first = Tmax > 0 ? ((Tmax - 1) / TBW) * TBW : 0;
+        fetch(Tmax > 0 ? tb_first : -1);
+        for (int tb = tb_first; tb >= 0 && Tmax > 0; tb -= TBW) {
+            unsigned m[TBW];
+#pragma unroll
+            for (int q = 0; q < TBW; q++) m[q] = mn[q];
+            fetch(tb - TBW);
+#pragma unroll
+            for (int q = TBW - 1; q >= 0; q--) {
+                const int t = tb + q;
+                if (t >= T) continue;
+                const bool isA = cur == D.adapter_rank;
+                const bool isL = cur == D.ll_rank || cur == D.lh_rank;
+                // a candidate closes when the runs in front of its adapter stop being leaders
+                if ((phase == 1 && !isA && !isL) || (phase == 2 && !isL))
+                    finalize(phase == 1 ? a_first : lead);
+                if (isA && phase != 1) a_last = t;
+                if (isA) a_first = t;
+                if (isL && phase != 0) lead = t;
+                phase = isA ? 1 : ((isL && phase != 0) ? 2 : 0);
+                const int src = (int)((m[q] >> (3 * cur)) & 7u);
+                if (t > 0 && src != 7) cur = src;
+            }
+        }
+        if (phase == 1) finalize(a_first);
+        else if (phase == 2) finalize(lead);
+        if (owned) cand_cnt[u] = (too_long || count > wcand) ? -1 : count;
+    }
+}
+
+// the unsplit model in rank space (host side)
+static UnsplitDense unsplit_dense(const PxgHmmDev& H, const UnsplitParams& P)
+{
+    UnsplitDense D;
+    const int S = H.n_states;
+    int rank_of[PXG_MAX_STATES];
+    for (int q = 0; q < PXG_MAX_STATES; q++) rank_of[q] = -1;
+    for (int i = 0; i < S; i++) rank_of[H.order[i]] = i;
+    D.n_states = S;
+    D.adapter_rank = P.adapter_state >= 0 && P.adapter_state < S ? rank_of[P.adapter_state] : -1;
+    D.ll_rank = P.ll_state >= 0 && P.ll_state < S ? rank_of[P.ll_state] : -1;
+    D.lh_rank = P.lh_state >= 0 && P.lh_state < S ? rank_of[P.lh_state] : -1;
+    for (int i = 0; i < UD_S; i++) {
+        D.n_mix[i] = 1;
+        D.start[i] = -__builtin_inf();
+        for (int j = 0; j < UD_S; j++) D.A[i][j] = -__builtin_inf();
+        for (int k = 0; k < PXG_MAX_MIXTURE; k++) { D.mu[i][k] = 0.0; D.lssp[i][k] = -__builtin_inf(); D.tss[i][k] = 0.0; D.logw[i][k] = 0.0; }
+    }
+    for (int j = 0; j < S; j++) {
+        const int q = H.order[j];
+        D.n_mix[j] = H.n_mix[q];
+        D.start[j] = H.log_start[q];
+        for (int k = 0; k < PXG_MAX_MIXTURE; k++) { D.mu[j][k] = H.mu[q][k]; D.lssp[j][k] = H.lssp[q][k]; D.tss[j][k] = H.tss[q][k]; D.logw[j][k] = H.logw[q][k]; }
+        for (int d = 0; d < PXG_MAX_STATES; d++)
+            if (H.in_src[q][d] >= 0) D.A[rank_of[H.in_src[q][d]]][j] = H.in_logp[q][d];
+    }
+    return D;
+}
+
 // gather, pass 1: candidates per read
 __global__ void k_unsplit_count(int64_t n_reads, const int64_t* __restrict__ unit_off,
                                 const int32_t* __restrict__ cand_cnt, int32_t* __restrict__ out_cnt)
@@ -606,16 +885,23 @@ int pxg_launch_unsplit_plan(pxg_ctx* ctx, int64_t n, const pxg_calib* cal, const
 }
 
 // persistent grid: enough waves to fill the chip; the unit count is only known on the device
+// a model with more states than UD_S takes the 8-lane kernel; PXG_UNSPLIT_8_LANES=1 sends every model there (read at
+// every call: the tests run both kernels against the oracle in one process)
+static bool unsplit_lane_windows() { return !getenv("PXG_UNSPLIT_8_LANES"); }
+
 int pxg_unsplit_waves(const pxg_ctx* ctx, int64_t units_bound)
 {
-    const int64_t need = (units_bound + UN_READS - 1) / UN_READS;
-    const int64_t cap = (int64_t)ctx->n_cu * 16;
+    const bool lanes = unsplit_lane_windows() && ctx->hmm[1].n_states <= UD_S;
+    const int per_wave = lanes ? 64 : UN_READS;
+    const int64_t need = (units_bound + per_wave - 1) / per_wave;
+    const int64_t cap = (int64_t)ctx->n_cu * (lanes ? 8 : 16);
     return (int)(need < cap ? (need > 0 ? need : 1) : cap);
 }
 
 size_t pxg_unsplit_scratch_bytes(const pxg_ctx* ctx, int64_t units_bound, int tmax)
 {
-    return (size_t)pxg_unsplit_waves(ctx, units_bound) * (size_t)tmax * UN_READS * sizeof(unsigned);
+    const bool lanes = unsplit_lane_windows() && ctx->hmm[1].n_states <= UD_S;
+    return (size_t)pxg_unsplit_waves(ctx, units_bound) * (size_t)tmax * (lanes ? 64 : UN_READS) * sizeof(unsigned);
 }
 
 // most candidates a window of tmax blocks can hold (see the top of the file)
@@ -649,15 +935,21 @@ int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t units_bound, int tm
     unsigned* bp = (unsigned*)scratch;
     int64_t* cand = (int64_t*)candbuf;
     int32_t* cand_cnt = (int32_t*)((char*)candbuf + (size_t)(units_bound > 0 ? units_bound : 1) * (size_t)wcand * 2 * sizeof(int64_t));
-#define SCAN(NIN)                                                                                      \
-    hipLaunchKernelGGL(k_unsplit_scan<NIN>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, n,        \
+#define SCAN(K, NIN)                                                                                   \
+    hipLaunchKernelGGL(K<NIN>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, n,                     \
                        tmax, ctx->hmm[1], P, cal, status, segs, first_sample, ev_off, ev_start, unit_off, \
                        scaled, bp, cand, cand_cnt, wcand, ctx->d_lsetab, ctx->unsplit_q.p)
     const int nin = ctx->hmm[1].max_in;
-    if (nin <= 2) SCAN(2);
-    else if (nin <= 3) SCAN(3);
-    else if (nin <= 5) SCAN(5);
-    else SCAN(8);
+    if (unsplit_lane_windows() && ctx->hmm[1].n_states <= UD_S) {
+        hipLaunchKernelGGL(k_unsplit_scan_w, dim3((unsigned)waves), dim3(64), 0, ctx->stream, n, tmax,
+                           unsplit_dense(ctx->hmm[1], P), P, cal, status, segs, first_sample, ev_off, ev_start, unit_off,
+                           scaled, bp, cand, cand_cnt, wcand, ctx->d_lsetab, ctx->unsplit_q.p);
+    } else {
+        if (nin <= 2) SCAN(k_unsplit_scan, 2);
+        else if (nin <= 3) SCAN(k_unsplit_scan, 3);
+        else if (nin <= 5) SCAN(k_unsplit_scan, 5);
+        else SCAN(k_unsplit_scan, 8);
+    }
 #undef SCAN
     hipLaunchKernelGGL(k_unsplit_count, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n,
                        unit_off, cand_cnt, out_cnt);

@@ -518,6 +518,17 @@ def test_unsplit_scan_synthetic_vs_oracle(ctx, oracle, config):
     assert cnt2[7] == N.UNSPLIT_E_GEOMETRY
     keep = np.arange(len(reads)) != 7
     assert np.array_equal(cnt2[keep], cnt[keep])
+    # the 8-lanes-per-window kernel (models of more than six states take it; PXG_UNSPLIT_8_LANES sends every
+    # model there) gives the same lists, and a batch without a single event is scanned without touching the
+    # (empty) table
+    os.environ['PXG_UNSPLIT_8_LANES'] = '1'
+    try:
+        iv3, cnt3, start3 = ctx.unsplit_scan(first, nb)
+    finally:
+        del os.environ['PXG_UNSPLIT_8_LANES']
+    assert np.array_equal(cnt3, cnt) and np.array_equal(iv3, iv) and np.array_equal(start3, start)
+    _, cnt4, _ = ctx.unsplit_scan(first, np.zeros_like(nb))
+    assert not cnt4.any()
     for i in np.nonzero(keep)[0]:
         assert iv2[start2[i]:start2[i + 1]].tolist() == iv[start[i]:start[i + 1]].tolist(), i
 
