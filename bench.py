@@ -490,13 +490,19 @@ def fast5_ingest_leg(args, base, which, n_reads=2048):
                 out[mode] = {'error': str(exc)}
                 continue
             t_write = time.perf_counter() - t0
+            before = dict(F5.TIMING)
             t0 = time.perf_counter()
             f = F5.Fast5File(path)
             bundle = F5.Fast5Batch([f] * f.n, np.arange(f.n), [mode + '.fast5'] * f.n).as_bundle()
             dt = time.perf_counter() - t0
             assert not bundle.signal_status.any() and np.array_equal(bundle.samples(count - 1), raws[count - 1])
             out[mode] = {'reads_per_s': count / dt, 'reads': count, 'file_MB': round(os.path.getsize(path) / 1e6, 1),
-                         'samples_GBps': float(bundle.d['offsets'][-1]) * 2 / dt / 1e9, 'write_s': round(t_write, 2)}
+                         'samples_GBps': float(bundle.d['offsets'][-1]) * 2 / dt / 1e9, 'write_s': round(t_write, 2),
+                         # where the loader's time goes: group walk + metadata, copy / decode of the samples, basecall text
+                         'ms': {'total': round(dt * 1e3, 2),
+                                'walk': round((F5.TIMING['walk_s'] - before['walk_s']) * 1e3, 2),
+                                'signals': round((F5.TIMING['signals_s'] - before['signals_s']) * 1e3, 2),
+                                'text': round((F5.TIMING['text_s'] - before['text_s']) * 1e3, 2)}}
         return out
     finally:
         shutil.rmtree(work, ignore_errors=True)

@@ -25,6 +25,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <emmintrin.h>
 
 #include <algorithm>
 #include <atomic>
@@ -145,6 +146,55 @@ struct pxg_h5 {
         if (off == UNDEF || off + base < off || off + base > n || len > n - (off + base))
             fail(PXG_E_INVALID, "HDF5: a structure points outside the file (truncated or corrupt)");
         return p + base + off;
+    }
+    // `len` raw bytes of the file at `off` into `out`.  A big stretch (a read's uncompressed Signal: ~120 KB) is
+    // fetched with pread(): the kernel copies page cache -> `out` directly, where a memcpy from the mapping takes a
+    // minor fault and a TLB fill for every 4 KB page it has not touched before -- 300 000 of them per 10 000-read
+    // batch, on all loader threads at once, against the same address space the group walk of the NEXT file is
+    // faulting in.  Measured on the GPU box (16-core quota, profiles/r05/fast5_ingest_*.txt): the copy itself is
+    // memory-bound at 46 GB/s either way, the loader call for 10 000 reads 52 ms with pread against 62 (memcpy) and
+    // 64 (non-temporal stores from the mapping: a third less traffic, but the faults stay).
+    // PXG_H5_COPY=memcpy|pread|nt selects the path (A/B; default pread).
+    static int copy_mode()
+    {
+        static const int mode = [] {
+            const char* e = getenv("PXG_H5_COPY");
+            return !e ? 1 : (!strcmp(e, "memcpy") ? 0 : (!strcmp(e, "nt") ? 2 : 1));
+        }();
+        return mode;
+    }
+    void copy_out(uint8_t* out, uint64_t off, uint64_t len) const
+    {
+        const uint8_t* src = at(off, len);
+        const int mode = len >= (64u << 10) ? copy_mode() : 0;
+        if (mode == 1 && fd >= 0) {
+            uint64_t done = 0;
+            while (done < len) {
+                const ssize_t got = pread(fd, out + done, (size_t)(len - done), (off_t)(base + off + done));
+                if (got < 0 && errno == EINTR) continue;
+                if (got <= 0) break;                       // (a file shrinking under the map: take the mapping's zeros)
+                done += (uint64_t)got;
+            }
+            if (done < len) memcpy(out + done, src + done, (size_t)(len - done));
+            return;
+        }
+        if (mode == 2) {
+            const size_t head = (size_t)((16 - ((uintptr_t)out & 15)) & 15);
+            memcpy(out, src, head);
+            size_t i = head;
+            for (; i + 64 <= len; i += 64) {
+                const __m128i a = _mm_loadu_si128((const __m128i*)(src + i)), b = _mm_loadu_si128((const __m128i*)(src + i + 16));
+                const __m128i c = _mm_loadu_si128((const __m128i*)(src + i + 32)), d = _mm_loadu_si128((const __m128i*)(src + i + 48));
+                _mm_stream_si128((__m128i*)(out + i), a);
+                _mm_stream_si128((__m128i*)(out + i + 16), b);
+                _mm_stream_si128((__m128i*)(out + i + 32), c);
+                _mm_stream_si128((__m128i*)(out + i + 48), d);
+            }
+            _mm_sfence();
+            memcpy(out + i, src + i, (size_t)len - i);
+            return;
+        }
+        memcpy(out, src, (size_t)len);
     }
     static uint64_t rd(const uint8_t* q, int bytes)
     {
@@ -715,7 +765,7 @@ struct pxg_h5 {
         case 0: if (d.size < total) fail(PXG_E_INVALID, "HDF5: compact dataset too short"); memcpy(out, d.compact, total); return;
         case 1:
             if (d.addr == UNDEF) { memset(out, 0, total); return; }      // never written: fill value 0
-            memcpy(out, at(d.addr, total), total);
+            copy_out(out, d.addr, total);
             return;
         case 2:
             memset(out, 0, total);
@@ -728,7 +778,7 @@ struct pxg_h5 {
             if (d.chunk.size() != 1) fail(PXG_E_UNSUPPORTED, "HDF5: chunked datasets must be one-dimensional");
             sane_bytes(d.chunk[0], esz);
             const uint64_t cbytes = d.chunk[0] * esz;
-            if (d.filters.empty()) { memcpy(out, at(d.addr, total), total); return; }
+            if (d.filters.empty()) { copy_out(out, d.addr, total); return; }
             std::vector<uint8_t> whole(cbytes);
             unfilter(d, at(d.addr, d.single_size), d.single_size, 0, whole.data(), cbytes);
             memcpy(out, whole.data(), std::min(total, cbytes));
@@ -736,7 +786,7 @@ struct pxg_h5 {
         }
         case 4:
             if (!d.filters.empty()) fail(PXG_E_INVALID, "HDF5: implicit chunk index with filters");
-            memcpy(out, at(d.addr, total), total);
+            copy_out(out, d.addr, total);
             return;
         default: fail(PXG_E_INVALID, "HDF5: dataset without a data layout");
         }

@@ -304,6 +304,16 @@ class Fast5Error(OSError):
     pass
 
 
+# seconds spent in the native reader, by phase (walk = group walk at open + metadata columns, signals = copy / decode
+# of the samples, text = basecall text and move tables): bench.py's ingest leg and the session print them
+TIMING = {'walk_s': 0.0, 'signals_s': 0.0, 'text_s': 0.0}
+
+
+def _timed(key, t0):
+    import time
+    TIMING[key] += time.perf_counter() - t0
+
+
 class Fast5File:
     """One FAST5 file opened by the native reader: read ids, per-read metadata columns
     (pxg_h5_read_info) and handles for the batch loaders.  Cached per path (open_fast5)."""
@@ -314,7 +324,10 @@ class Fast5File:
         self.lib = native.load_text_library()
         self.path = path
         handle = C.c_void_p()
+        import time
+        t0 = time.perf_counter()
         rc = self.lib.pxg_h5_open_mt(os.fsencode(path), host_threads(), C.byref(handle))
+        _timed('walk_s', t0)
         if rc:
             msg = (self.lib.pxg_h5_last_error() or b'').decode(errors='replace')
             err = Fast5Error(msg or 'Unable to open file {!r}'.format(path))
@@ -356,7 +369,10 @@ class Fast5File:
         if self._info is None:
             from . import native
             out = np.zeros(self.n, dtype=native.H5_INFO_DTYPE)
+            import time
+            t0 = time.perf_counter()
             rc = self.lib.pxg_h5_info_mt(self.handle, 0, self.n, out.ctypes.data, host_threads())
+            _timed('walk_s', t0)
             if rc:
                 raise Fast5Error('pxg_h5_info failed ({})'.format(rc))
             self._info = out
@@ -490,8 +506,11 @@ def load_signals(files, index, n_samples, arena=None, dst_start=None, threads=No
     dst = np.ascontiguousarray(dst_start, dtype=np.int64)
     status = np.zeros(n, dtype=np.int32)
     if n:
+        import time
+        t0 = time.perf_counter()
         lib.pxg_h5_load_signals(n, _handles(files), idx.ctypes.data, dst.ctypes.data, ns.ctypes.data,
                                 arena.ctypes.data, threads or host_threads(), status.ctypes.data)
+        _timed('signals_s', t0)
     if own:
         if status.any():
             raise Fast5Error('signal of read {} cannot be decoded (code {})'.format(
@@ -554,10 +573,13 @@ class Fast5Batch:
         if n:
             idx = np.ascontiguousarray(self.index)
             s0, m0 = np.ascontiguousarray(seq_off[:-1]), np.ascontiguousarray(move_off[:-1])
+            import time
+            t0 = time.perf_counter()
             lib.pxg_h5_basecall_many(n, _handles(self.files), idx.ctypes.data, s0.ctypes.data, seq_len.ctypes.data,
                                      seq_arena.ctypes.data, qual_arena.ctypes.data, m0.ctypes.data,
                                      n_moves.ctypes.data, move_arena.ctypes.data, threads or host_threads(),
                                      bstatus.ctypes.data)
+            _timed('text_s', t0)
         calib = np.zeros(n, dtype=native.CALIB_DTYPE)
         for name in ('range', 'digitisation', 'offset', 'sampling_rate'):
             calib[name] = info['calib'][name]

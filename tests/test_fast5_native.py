@@ -93,6 +93,32 @@ def test_native_reader_returns_what_the_writer_wrote(inputs):
             assert bc[k] == want[k], (i, k)
 
 
+
+def test_big_uncompressed_signals_take_the_bulk_copy(tmp_path):
+    """A Signal of 64 KB or more does not go through memcpy (pxg_h5.cpp copy_out: pread, or PXG_H5_COPY=nt /
+    memcpy in a fresh process): odd lengths and destinations that are not 16-byte aligned, against the samples
+    that were written."""
+    rng = np.random.default_rng(7)
+    lens = [32768, 40001, 65537, 123457]
+    raws = [rng.integers(-3000, 3000, n).astype(np.int16) for n in lens]
+    cal = np.zeros(1, dtype=N.CALIB_DTYPE)
+    cal['range'], cal['digitisation'], cal['offset'], cal['sampling_rate'] = 1400.0, 8192.0, 5.0, 3012.0
+    path = str(tmp_path / 'big.fast5')
+    from poreplex_amd.fast5_write import Fast5Writer
+    with Fast5Writer(path) as w:
+        for j, r in enumerate(raws):
+            w.add_read('big%d' % j, r, cal[0])
+    f = F5.Fast5File(path)
+    ns = np.array(lens, dtype=np.int64)
+    for shift in (0, 1, 3, 7):                       # element offsets: 0, 2, 6, 14 bytes off a 16-byte boundary
+        dst = shift + np.concatenate([[0], np.cumsum(ns)[:-1] + np.arange(1, len(lens))]).astype(np.int64)
+        arena = np.full(int(ns.sum()) + 64, 12345, dtype=np.int16)
+        st = F5.load_signals([f] * len(lens), np.arange(len(lens)), ns, arena, dst, threads=2)
+        assert not st.any()
+        for j, r in enumerate(raws):
+            assert np.array_equal(arena[dst[j]:dst[j] + lens[j]], r), (shift, j)
+            assert arena[dst[j] + lens[j]] == 12345
+
 def test_batch_columns_equal_per_read_access(inputs):
     top, t = inputs
     files = [F5.open_fast5(os.path.join(top, t['where'][i])) for i in range(len(t['ids']))]

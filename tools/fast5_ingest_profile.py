@@ -53,7 +53,8 @@ def loader_call(path, count, arena):
     return best
 
 
-for mode in (None, 'vbz', 'gzip'):
+MODES = [None if m == 'none' else m for m in os.environ.get('PXG_PROF_MODES', 'none,vbz,gzip').split(',')]
+for mode in MODES:
     count = n if mode != 'gzip' else min(n, 1000)
     path = os.path.join(work, str(mode) + '.fast5')
     with Fast5Writer(path) as w:
