@@ -51,7 +51,7 @@ PEAK_I8_MFMA_MEASURED = 3.944e15     # the guide's measured v_mfma_i32_16x16x64_
 # 48-unit vector to the instruction's 64-wide k block
 Q8_PRODUCTS = 8
 OPS_SCALER_Q8 = Q8_PRODUCTS * 2.0 * 2000 * (48 * 192 + 96 * 192)              # algorithmic int8 ops per read
-OPS_SCALER_Q8_EXECUTED = 2001 * 4 * 72 * 32768.0 / 16                          # 4 waves x 72 MFMAs per 16 reads and step
+OPS_SCALER_Q8_EXECUTED = 2001 * 4 * 63 * 32768.0 / 16                          # 4 waves x 63 MFMAs per 16 reads and step (round 5: layer 2 unpadded)
 PEAK_HBM = 8.0e12              # B/s
 # the only throughput the reference publishes (Poreplex 0.1, whole
 # pipeline incl. FAST5 I/O, 2x Xeon E5-2687W v3 = 20 cores): 1 339 070 reads in 1 h 37 min
@@ -1179,10 +1179,11 @@ def main():
                         'algorithmic_fp32_TFLOPs': n_scaled * FLOP_SCALER / dur / 1e12 if dur else None,
                         'frac_of_fp32_mfma_peak': n_scaled * FLOP_SCALER / dur / PEAK_FP32_MFMA if dur else None,
                         'algorithmic_flop_per_read': FLOP_SCALER, 'kernel_ms': stage_ms['scaler_lstm'],
-                        'note': 'per wave and step: 72 v_mfma_i32_16x16x64_i8 (~17.5 cycles each per SIMD, their full issue '
-                                'time: nothing overlaps an MFMA on a SIMD), ~440 VALU instructions (about a third of their '
-                                'slots exposed), 54 ds_read_b128 (the spline rows cost 11 %) and one barrier (3 %): '
-                                'profiles/r04/k2_ablation.txt, DESIGN.md 3.1 / 8'}
+                        'note': 'per wave and step: 63 v_mfma_i32_16x16x64_i8 (72 until layer 2 lost its k padding, round 5; '
+                                '~16.5 cycles each per SIMD) + ~440 VALU instructions at ~3.5 cycles: a SIMD issues one or the '
+                                'other -- with two waves per SIMD the shadow of one wave\'s MFMAs is already filled by the '
+                                'other wave\'s VALU (profiles/r05/ubench_i8_mfma_32x32.txt, ab_k2_sched.txt), the spline rows '
+                                'cost 11 % and the step barrier 3 % (profiles/r04/k2_ablation.txt); DESIGN.md 3.1'}
         else:
             kernel = 'k_scaler_lstm_q' if (n_local + 15) // 16 > 2 * info['compute_units'] else 'k_scaler_lstm'
             roofline = {'kernel': kernel, 'bound': 'mfma',

@@ -32,10 +32,42 @@
 
 // ===========================================================================
 // K2: scaler, time-sliced (tasks = (step block, tile) as in k_scaler_lstm_q; with no more tiles
-// than slots every tile is one task).  Fragments: [matrix 0 U1 | 1 W2 | 2 U2][nt][digit][thread].
+// than slots every tile is one task).
+//
+// Round 5: layer 2's k extent without padding.  Layer 2 multiplies [h1(t-1) | h2(t-2)] = 96 units; as two 64-wide
+// blocks with every fourth byte zero that was 16 MFMAs per gate tile.  Now the two hidden vectors of a read share ONE
+// 96-byte row per digit plane:
+//   block 0 (k groups 0-3, 64 bytes): lane (wave w, ul) owns bytes 4 ul .. 4 ul + 3 of group w =
+//            its three layer-1 cells and its FIRST layer-2 cell -- one ds_write_b32 per plane, as before;
+//   block 1' (k groups 4-5, 32 bytes): its other two layer-2 cells, bytes 2 (4 w + ul), + 1 -- one ds_write_b16.
+// Layer 1 takes block 0 with zero weights at the layer-2 bytes (8 MFMAs per tile, as before: a 48-unit layer cannot
+// fill 64-wide blocks level by level).  Layer 2 takes block 0 whole (8 MFMAs, the SAME B fragments) and block 1' as
+// HALF blocks paired by significance level -- an MFMA may sum any products of one level:
+//   F1 = [h1' | h2'], F2 = [h0' | h1']  (digit planes of block 1'; per lane ONE ds_read_b128 at a plane / group that
+//                                        depends on the lane's k group)
+//   A0 += [ 0 | w2'] F1      A1 += [w2' | w1'] F1      A2 += [w2' | w1'] F2 + [ 0 | w0'] F1      A3 += [w1' | w0'] F2
+// 5 MFMAs instead of 8: 13 per layer-2 tile, 63 per wave and step instead of 72, 5 B fragments instead of 6.  The
+// sums are the same integers (the oracle does not know about blocks).
+// Fragments: [nt][10 ids][thread]: 0-2 layer 1 (w2, w1, w0 over block 0), 3-5 layer 2 over block 0, 6 [w2'|w1'],
+// 7 [w1'|w0'], 8 [0|w2'], 9 [0|w0'].
 // ===========================================================================
-#define Q8S_STATE (2 * Q8_HVEC / 4 + 2 * LSTM_THREADS * 3)      // dwords per saved tile state
+#define Q2_PLANE (6 * 256)                  // one digit plane: [6 k groups][16 reads][16 bytes]
+#define Q2_HVEC (3 * Q2_PLANE)              // both hidden vectors of a tile's 16 reads
+#define Q2_FRAGS 10
+#define Q2_LDS_FRAGS 4                      // ids 2, 5, 7, 9 are read from LDS where they are used
+#define Q8S_STATE (Q2_HVEC / 4 + 2 * LSTM_THREADS * 3)      // dwords per saved tile state
 #define Q8S_TRAJ 4          // the zero-input trajectory is kept every 4 steps (step blocks are multiples of 4)
+
+// h (float, exact) of layer-2 unit `unit` (wave-major numbering, 12 units per wave) of read `rd`
+__device__ __forceinline__ float q2_read_h2(const unsigned char* hvec, int rd, int unit)
+{
+    const int w = unit / 12, nt = (unit % 12) >> 2, ul = unit & 3;
+    const int off = nt == 0 ? (((w * 16 + rd) << 4) + (ul << 2) + 3)
+                            : ((((4 + (w >> 1)) * 16 + rd) << 4) + 2 * (4 * (w & 1) + ul) + (nt - 1));
+    const int q = (int)(signed char)hvec[off] + 256 * (int)(signed char)hvec[Q2_PLANE + off] +
+                  65536 * (int)(signed char)hvec[2 * Q2_PLANE + off];
+    return (float)q * (1.0f / 4194304.0f);
+}
 
 __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
     int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int T,
@@ -57,31 +89,31 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
     const int n_tasks = n_tiles * n_blocks;
 
     float4* tab = reinterpret_cast<float4*>(smem);                             // [1024] sigmoid spline
-    unsigned char* hv = reinterpret_cast<unsigned char*>(smem + 4 * PXG_SIG_NSEG);   // [2 buffers][2 layers][Q8_HVEC]
-    float* xb = reinterpret_cast<float*>(hv + 4 * Q8_HVEC);                    // [16][XS]
+    unsigned char* hv = reinterpret_cast<unsigned char*>(smem + 4 * PXG_SIG_NSEG);   // [2 buffers][Q2_HVEC]
+    float* xb = reinterpret_cast<float*>(hv + 2 * Q2_HVEC);                    // [16][XS]
     float4* gvec = reinterpret_cast<float4*>(xb + 16 * XS);                    // [3: b1, W1, b2][4 waves][NT][4 ul]
-    v4i* w0s = reinterpret_cast<v4i*>(gvec + 3 * 48);                          // [3 matrices][NT][thread]: digit-0 fragments
-    int* ridx = reinterpret_cast<int*>(w0s + 3 * NT * LSTM_THREADS);           // [16]
+    v4i* wl = reinterpret_cast<v4i*>(gvec + 3 * 48);                           // [NT][Q2_LDS_FRAGS][thread]
+    int* ridx = reinterpret_cast<int*>(wl + NT * Q2_LDS_FRAGS * LSTM_THREADS); // [16]
     int* s_task = ridx + 16;
 
     const int tid = threadIdx.x, lane = tid & 63, slice = tid >> 6;
     const int rd_l = lane & 15, ul = lane >> 4;
 
     load_sigtab(tab, sigtab, tid);
-    // U1, W2, U2 digit fragments of this wave's gate tiles: digits 2 and 1 in VGPRs for the whole launch,
-    // digit 0 (two of the eight products) in LDS -- 108 + 36 registers of weights do not leave room for
-    // the accumulators and the 12 table rows a cell update keeps in flight
-    v4i wA[NT][2], wB[NT][2], wC[NT][2];
+    // weight fragments of this wave's gate tiles: six per tile in VGPRs for the whole launch (72 registers, as
+    // before), the four that carry digit 0 in LDS -- with all ten in registers nothing is left for the accumulators
+    // and the table rows a cell update keeps in flight
+    v4i wA[NT][2], wB[NT][2], wH[NT][2];       // [w2, w1] of layer 1 / layer 2 over block 0; [w2'|w1'], [0|w2']
 #pragma unroll
     for (int nt = 0; nt < NT; nt++) {
-#pragma unroll
-        for (int d = 1; d < 3; d++) {
-            wA[nt][d - 1] = frag[((0 * NT + nt) * 3 + d) * LSTM_THREADS + tid];
-            wB[nt][d - 1] = frag[((1 * NT + nt) * 3 + d) * LSTM_THREADS + tid];
-            wC[nt][d - 1] = frag[((2 * NT + nt) * 3 + d) * LSTM_THREADS + tid];
-        }
-#pragma unroll
-        for (int m = 0; m < 3; m++) w0s[(m * NT + nt) * LSTM_THREADS + tid] = frag[((m * NT + nt) * 3 + 0) * LSTM_THREADS + tid];
+        const v4i* f = frag + (size_t)nt * Q2_FRAGS * LSTM_THREADS + tid;
+        wA[nt][0] = f[0 * LSTM_THREADS]; wA[nt][1] = f[1 * LSTM_THREADS];
+        wB[nt][0] = f[3 * LSTM_THREADS]; wB[nt][1] = f[4 * LSTM_THREADS];
+        wH[nt][0] = f[6 * LSTM_THREADS]; wH[nt][1] = f[8 * LSTM_THREADS];
+        wl[(nt * Q2_LDS_FRAGS + 0) * LSTM_THREADS + tid] = f[2 * LSTM_THREADS];
+        wl[(nt * Q2_LDS_FRAGS + 1) * LSTM_THREADS + tid] = f[5 * LSTM_THREADS];
+        wl[(nt * Q2_LDS_FRAGS + 2) * LSTM_THREADS + tid] = f[7 * LSTM_THREADS];
+        wl[(nt * Q2_LDS_FRAGS + 3) * LSTM_THREADS + tid] = f[9 * LSTM_THREADS];
     }
     for (int i = tid; i < 3 * H; i += LSTM_THREADS) {      // (i, f, g, o) of one unit per float4
         const int v = i / H, unit = i % H;
@@ -89,6 +121,14 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
         gvec[i] = make_float4(src[unit], src[H + unit], src[2 * H + unit], src[3 * H + unit]);
     }
     const int gv = slice * 12 + ul;                        // + nt * 4: this lane's units
+    // byte offsets inside a hidden-vector buffer: the block-0 fragment of plane 0, the two half-block fragments
+    // (their plane depends on the lane's k group), this lane's dword of block 0 and its half word of block 1'
+    const int off_g = ((ul * 16 + rd_l) << 4);
+    const int off_h = (((4 + (ul & 1)) * 16 + rd_l) << 4);
+    const int off_f1 = (ul < 2 ? 1 : 2) * Q2_PLANE + off_h;
+    const int off_f2 = (ul < 2 ? 0 : 1) * Q2_PLANE + off_h;
+    const int off_w0 = ((slice * 16 + rd_l) << 4) + (ul << 2);
+    const int off_w1 = (((4 + (slice >> 1)) * 16 + rd_l) << 4) + 2 * (4 * (slice & 1) + ul);
 
     for (;;) {
         __syncthreads();                       // everybody is done with the previous task's LDS
@@ -128,18 +168,18 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
                                 : blk == b0 ? traj + (size_t)(t0 / Q8S_TRAJ) * Q8S_STATE
                                             : state + ((size_t)((blk - 1) & 1) * n_tiles + tile) * Q8S_STATE;
         if (blk == 0) {
-            for (int i = tid; i < 4 * Q8_HVEC / 4; i += LSTM_THREADS) reinterpret_cast<unsigned*>(hv)[i] = 0u;
+            for (int i = tid; i < 2 * Q2_HVEC / 4; i += LSTM_THREADS) reinterpret_cast<unsigned*>(hv)[i] = 0u;
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) c1[nt] = c2[nt] = 0.0f;
         } else {
             if (blk != b0) dq_wait(done, tile, blk, errflag, tid);
             const int rb = t0 & 1;         // (the other buffer is written completely by step t0)
-            for (int i = tid; i < 2 * Q8_HVEC / 4; i += LSTM_THREADS)
-                reinterpret_cast<unsigned*>(hv + rb * 2 * Q8_HVEC)[i] = st_in[i];
+            for (int i = tid; i < Q2_HVEC / 4; i += LSTM_THREADS)
+                reinterpret_cast<unsigned*>(hv + rb * Q2_HVEC)[i] = st_in[i];
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
-                c1[nt] = __uint_as_float(st_in[2 * Q8_HVEC / 4 + nt * LSTM_THREADS + tid]);
-                c2[nt] = __uint_as_float(st_in[2 * Q8_HVEC / 4 + (NT + nt) * LSTM_THREADS + tid]);
+                c1[nt] = __uint_as_float(st_in[Q2_HVEC / 4 + nt * LSTM_THREADS + tid]);
+                c2[nt] = __uint_as_float(st_in[Q2_HVEC / 4 + (NT + nt) * LSTM_THREADS + tid]);
             }
         }
         __syncthreads();
@@ -157,11 +197,13 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
                 }
                 __syncthreads();
             }
-            const unsigned char* hr = hv + (t & 1) * 2 * Q8_HVEC;
-            unsigned char* hw = hv + ((t + 1) & 1) * 2 * Q8_HVEC;
-            v4i g1[3], g2[3];
-            q8_load_b(g1, hr, lane);                  // h1(t-1)
-            q8_load_b(g2, hr + Q8_HVEC, lane);        // h2(t-2)
+            const unsigned char* hr = hv + (t & 1) * Q2_HVEC;
+            unsigned char* hw = hv + ((t + 1) & 1) * Q2_HVEC;
+            v4i g[3];                                  // block 0 of the three planes: h1(t-1) and a quarter of h2(t-2)
+#pragma unroll
+            for (int d = 0; d < 3; d++) g[d] = *reinterpret_cast<const v4i*>(hr + d * Q2_PLANE + off_g);
+            const v4i f1 = *reinterpret_cast<const v4i*>(hr + off_f1);      // [h1' | h2'] of block 1'
+            const v4i f2 = *reinterpret_cast<const v4i*>(hr + off_f2);      // [h0' | h1']
             const float x = xb[rd_l * XS + ((t - t0) % XCH)];
 
             // ---- layer 1, step t ---------------------------------------------------------
@@ -170,7 +212,7 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
                 Q8Acc A[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++)
-                    q8_block<true>(A[nt], wA[nt][1], wA[nt][0], w0s[(0 * NT + nt) * LSTM_THREADS + tid], g1);
+                    q8_block<true>(A[nt], wA[nt][0], wA[nt][1], wl[(nt * Q2_LDS_FRAGS + 0) * LSTM_THREADS + tid], g);
                 f32x4 st[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; nt++) {
@@ -180,19 +222,22 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
                 }
                 q8_combine_tiles<NT>(u, A, s1, st);
             }
-            // ---- layer 2, step t - 1: inputs h1(t-1), h2(t-2); layer 1's cells under its MFMAs -----
+            // ---- layer 2, step t - 1: block 0 whole, block 1' as level-paired halves; layer 1's cells under its MFMAs
             Q8Acc B[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
-                q8_block<true>(B[nt], wB[nt][1], wB[nt][0], w0s[(1 * NT + nt) * LSTM_THREADS + tid], g1);
-                q8_block<false>(B[nt], wC[nt][1], wC[nt][0], w0s[(2 * NT + nt) * LSTM_THREADS + tid], g2);
+                q8_block<true>(B[nt], wB[nt][0], wB[nt][1], wl[(nt * Q2_LDS_FRAGS + 1) * LSTM_THREADS + tid], g);
+                B[nt].a0 = mfma8(wH[nt][1], f1, B[nt].a0);                                              // [ 0 | w2'] [h1' | h2']
+                B[nt].a1 = mfma8(wH[nt][0], f1, B[nt].a1);                                              // [w2'|w1'] [h1' | h2']
+                B[nt].a2 = mfma8(wH[nt][0], f2, B[nt].a2);                                              // [w2'|w1'] [h0' | h1']
+                B[nt].a3 = mfma8(wl[(nt * Q2_LDS_FRAGS + 2) * LSTM_THREADS + tid], f2, B[nt].a3);       // [w1'|w0'] [h0' | h1']
+                B[nt].a2 = mfma8(wl[(nt * Q2_LDS_FRAGS + 3) * LSTM_THREADS + tid], f1, B[nt].a2);       // [ 0 | w0'] [h1' | h2']
             }
+            unsigned plane1[3] = {0u, 0u, 0u}, plane2[3] = {0u, 0u, 0u};
             if (t < T) {
                 float hn[NT];
-                unsigned plane[3];
                 cells_update<NT>(tab, u, c1, hn);
-                q8_pack<NT>(hn, plane);
-                q8_store_h(hw, plane, slice, lane);
+                q8_pack<NT>(hn, plane1);
             }
             {
                 f32x4 st[NT];
@@ -205,23 +250,28 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
             }
             if (t >= 1) {
                 float hn[NT];
-                unsigned plane[3];
                 cells_update<NT>(tab, u, c2, hn);
-                q8_pack<NT>(hn, plane);
-                q8_store_h(hw + Q8_HVEC, plane, slice, lane);
+                q8_pack<NT>(hn, plane2);
+            }
+            // this lane's bytes of the next row: three layer-1 digits + the first layer-2 digit as one dword of
+            // block 0, the other two layer-2 digits as one half word of block 1'
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                *reinterpret_cast<unsigned*>(hw + d * Q2_PLANE + off_w0) = plane1[d] | (plane2[d] << 24);
+                *reinterpret_cast<unsigned short*>(hw + d * Q2_PLANE + off_w1) = (unsigned short)(plane2[d] >> 8);
             }
             __syncthreads();
         }
 
         if (t1 == T + 1) {
             // ---- Dense(2): fma chain over k = 0..47 from the bias, on h = q * 2^-22 ----------
-            const unsigned char* hf = hv + ((T + 1) & 1) * 2 * Q8_HVEC + Q8_HVEC;
+            const unsigned char* hf = hv + ((T + 1) & 1) * Q2_HVEC;
             for (int i = tid; i < 16 * 2; i += LSTM_THREADS) {
                 const int row = i >> 1, j = i & 1;
                 const int rd = ridx[row];
                 if (rd < 0) continue;
                 float acc = bd[j];
-                for (int k = 0; k < H; k++) acc = __builtin_fmaf(q8_read_h<12>(hf, row, k), Wd[k * 2 + j], acc);
+                for (int k = 0; k < H; k++) acc = __builtin_fmaf(q2_read_h2(hf, row, k), Wd[k * 2 + j], acc);
                 pred[(size_t)rd * 2 + j] = acc;
             }
         } else {
@@ -229,12 +279,12 @@ __global__ __launch_bounds__(LSTM_THREADS, 2) void k_scaler_lstm_q8(
             unsigned* st_out = traj_out ? traj_out + (size_t)(t1 / Q8S_TRAJ) * Q8S_STATE
                                         : state + ((size_t)(blk & 1) * n_tiles + tile) * Q8S_STATE;
             const int rb = t1 & 1;
-            for (int i = tid; i < 2 * Q8_HVEC / 4; i += LSTM_THREADS)
-                st_out[i] = reinterpret_cast<const unsigned*>(hv + rb * 2 * Q8_HVEC)[i];
+            for (int i = tid; i < Q2_HVEC / 4; i += LSTM_THREADS)
+                st_out[i] = reinterpret_cast<const unsigned*>(hv + rb * Q2_HVEC)[i];
 #pragma unroll
             for (int nt = 0; nt < NT; nt++) {
-                st_out[2 * Q8_HVEC / 4 + nt * LSTM_THREADS + tid] = __float_as_uint(c1[nt]);
-                st_out[2 * Q8_HVEC / 4 + (NT + nt) * LSTM_THREADS + tid] = __float_as_uint(c2[nt]);
+                st_out[Q2_HVEC / 4 + nt * LSTM_THREADS + tid] = __float_as_uint(c1[nt]);
+                st_out[Q2_HVEC / 4 + (NT + nt) * LSTM_THREADS + tid] = __float_as_uint(c2[nt]);
             }
             dq_publish(done, tile, blk, tid);
         }
@@ -311,6 +361,52 @@ void q8_fragments(std::vector<int8_t>& out, const Q8Mat& M, int row0, int src_up
             }
 }
 
+// One A fragment (16 x 64 weight digits of gate tile `nt` for every wave: 256 threads x 16 bytes) from a k map:
+// `at(kpos)` says which row of M and which digit sits at k position `kpos` of the MFMA (row < 0: zero).  The gate
+// rows are those of q8_fragments (H_out units, out_upw per wave).
+template <typename F>
+void q8_fragment_kmap(std::vector<int8_t>& out, const Q8Mat& M, int H_out, int out_upw, int nt, const F& at)
+{
+    for (int tid = 0; tid < LSTM_THREADS; tid++) {
+        const int w = tid >> 6, lane = tid & 63, i = lane & 15, g = lane >> 4;
+        const int col = (i & 3) * H_out + w * out_upw + nt * 4 + (i >> 2);
+        for (int b = 0; b < 16; b++) {
+            int row = -1, digit = 0;
+            at(16 * g + b, row, digit);
+            out.push_back(row < 0 ? (int8_t)0 : (int8_t)q8_digit(M.w[(size_t)row * M.G + col], digit));
+        }
+    }
+}
+
+// K2's ten fragments per gate tile (k_scaler_lstm_q8): the k positions of the shared hidden-vector row
+//   block 0:  position 16 w + 4 ul + j, j < 3: layer-1 unit 12 w + 4 j + ul; j == 3: layer-2 unit 12 w + ul (nt 0)
+//   block 1': position q = 2 (4 w + ul) + jj of its 32 bytes: layer-2 unit 12 w + 4 (1 + jj) + ul
+// m1 = layer 1 (48 recurrent rows), m2 = layer 2 (rows 0-47 multiply h1, rows 48-95 its own h2).
+void q8_scaler_fragments(std::vector<int8_t>& out, const Q8Mat& m1, const Q8Mat& m2)
+{
+    auto block0 = [](int kpos, int& l1_unit, int& l2_unit) {
+        const int w = kpos >> 4, ulx = (kpos >> 2) & 3, j = kpos & 3;
+        l1_unit = j < 3 ? 12 * w + 4 * j + ulx : -1;
+        l2_unit = j == 3 ? 12 * w + ulx : -1;
+    };
+    auto half_unit = [](int q) { const int t = q >> 1, w = t >> 2, ulx = t & 3, jj = q & 1; return 12 * w + 4 * (1 + jj) + ulx; };
+    for (int nt = 0; nt < 3; nt++) {
+        for (int d = 2; d >= 0; d--)          // 0-2: layer 1, digits 2, 1, 0 over block 0 (zero at the layer-2 bytes)
+            q8_fragment_kmap(out, m1, 48, 12, nt, [&](int k, int& row, int& digit) {
+                int u1, u2; block0(k, u1, u2); row = u1; digit = d; });
+        for (int d = 2; d >= 0; d--)          // 3-5: layer 2 over block 0: W2 rows at the layer-1 bytes, U2 rows at its own
+            q8_fragment_kmap(out, m2, 48, 12, nt, [&](int k, int& row, int& digit) {
+                int u1, u2; block0(k, u1, u2); row = u1 >= 0 ? u1 : 48 + u2; digit = d; });
+        // 6-9: the half blocks of layer 2 (U2 rows): [first half digit | second half digit], -1 = zeros
+        static const int halves[4][2] = { {2, 1}, {1, 0}, {-1, 2}, {-1, 0} };
+        for (int f = 0; f < 4; f++)
+            q8_fragment_kmap(out, m2, 48, 12, nt, [&](int k, int& row, int& digit) {
+                const int dg = halves[f][k >> 5];
+                row = dg < 0 ? -1 : 48 + half_unit(k & 31);
+                digit = dg < 0 ? 0 : dg; });
+    }
+}
+
 template <typename T>
 int q8_to_device(pxg_ctx* ctx, T** dst, const std::vector<T>& src)
 {
@@ -331,9 +427,7 @@ int pxg_q8_upload(pxg_ctx* ctx)
     {   // scaler: U1 | W2 | U2
         const Q8Mat m1 = q8_quantise(c.scaler_lstm1), m2 = q8_quantise(c.scaler_lstm2);
         std::vector<int8_t> f;
-        q8_fragments(f, m1, 0, 12, 48, 48, 12, 3);
-        q8_fragments(f, m2, 0, 12, 48, 48, 12, 3);
-        q8_fragments(f, m2, 48, 12, 48, 48, 12, 3);
+        q8_scaler_fragments(f, m1, m2);
         if ((rc = q8_to_device(ctx, &ctx->q8.scaler_frag, f))) return rc;
         m1.scales(ctx->q8.s_scaler1);
         m2.scales(ctx->q8.s_scaler2);
@@ -423,8 +517,8 @@ static int q8_scaler_launch(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, co
         PXG_HIP(ctx, hipMemcpyAsync(ctx->lstm_q.p + 1, &ctx->q8.forced_block_steps, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     }
     const unsigned* traj = (!traj_out && off && ctx->prefix_skip) ? reinterpret_cast<const unsigned*>(ctx->scaler_traj.p) : nullptr;
-    const size_t lds = sizeof(float) * 4 * PXG_SIG_NSEG + 4 * Q8_HVEC + sizeof(float) * 16 * XS + 16 * 3 * 48 +
-                       16 * 9 * LSTM_THREADS + sizeof(int) * 32;
+    const size_t lds = sizeof(float) * 4 * PXG_SIG_NSEG + 2 * Q2_HVEC + sizeof(float) * 16 * XS + 16 * 3 * 48 +
+                       16 * 3 * Q2_LDS_FRAGS * LSTM_THREADS + sizeof(int) * 32;
     PXG_HIP(ctx, hipFuncSetAttribute((const void*)k_scaler_lstm_q8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const PxgLstmDev &l1 = ctx->scaler1, &l2 = ctx->scaler2;
     const Q8Scale s1 = q8_scale(ctx->q8.s_scaler1), s2 = q8_scale(ctx->q8.s_scaler2);
