@@ -207,6 +207,9 @@ extern "C" int pxg_create(const pxg_config* cfg, pxg_ctx** out)
         ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&ctx->scan_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_scan_gate, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_scan_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_staged, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_run_done[0], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_run_done[1], hipEventDisableTiming) != hipSuccess) {
@@ -249,6 +252,7 @@ extern "C" int pxg_create(const pxg_config* cfg, pxg_ctx** out)
         // measurement knobs (results never depend on them; tests/test_gpu_parity.py checks that)
         ctx->length_order = getenv("PXG_NO_LENGTH_ORDER") == nullptr;
         ctx->prefix_skip = getenv("PXG_NO_PREFIX_SKIP") == nullptr;
+        ctx->scan_overlap = getenv("PXG_NO_SCAN_OVERLAP") == nullptr;
         ctx->merge_small_calls = getenv("PXG_NO_CALL_MERGE") == nullptr;
         if (cfg->lstm_arith == PXG_LSTM_Q8 && (rc = pxg_q8_scaler_trajectory(ctx))) break;
     } while (0);
@@ -321,6 +325,9 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
         }
         (void)hipStreamDestroy(ctx->stream);
         if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+        if (ctx->scan_stream) (void)hipStreamDestroy(ctx->scan_stream);
+        if (ctx->ev_scan_gate) (void)hipEventDestroy(ctx->ev_scan_gate);
+        if (ctx->ev_scan_done) (void)hipEventDestroy(ctx->ev_scan_done);
         if (ctx->ev_staged) (void)hipEventDestroy(ctx->ev_staged);
         for (int q = 0; q < 2; q++)
             if (ctx->ev_run_done[q]) (void)hipEventDestroy(ctx->ev_run_done[q]);
@@ -831,8 +838,13 @@ extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
                                         PXG_T_DEMUX_TOP))) return rc;
     }
     ctx->polya_ran = false;
+    ctx->scan_gate_set = false;
     if (stage_mask & PXG_STAGE_POLYA) {
         if ((rc = pxg_reserve(ctx, ctx->polya_out, (size_t)n * 8))) return rc;
+        if (ctx->scan_overlap) {        // a window scan called next may start here, beside K6 (pxg_common.h scan_stream)
+            PXG_HIP(ctx, hipEventRecord(ctx->ev_scan_gate, ctx->stream));
+            ctx->scan_gate_set = true;
+        }
         pxg_timer_begin(ctx, PXG_T_POLYA);
         if ((rc = pxg_launch_polya(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p,
                                    ctx->status.p, ctx->segs.p, ctx->polya_out.p, ctx->spikes))) return rc;
@@ -1288,6 +1300,39 @@ struct StreamSyncOnError {
     ~StreamSyncOnError() { if (armed) (void)hipStreamSynchronize(st); }
 };
 
+// The scan calls enqueue on the scan stream when the last run left a gate (see pxg_common.h): for their duration
+// ctx->stream IS the scan stream (every launch helper and timer takes ctx->stream), put back on every exit; `join`
+// makes the main stream wait for what was enqueued, so that the downloads behind it see the scan's results.
+struct ScanStreamScope {
+    pxg_ctx* ctx;
+    hipStream_t main;
+    bool on = false;
+    explicit ScanStreamScope(pxg_ctx* c) : ctx(c), main(c->stream)
+    {
+        if (c->scan_gate_set && c->scan_stream &&
+            hipStreamWaitEvent(c->scan_stream, c->ev_scan_gate, 0) == hipSuccess) {
+            c->stream = c->scan_stream;
+            on = true;
+        }
+    }
+    int join()
+    {
+        if (!on) return PXG_OK;
+        on = false;
+        const hipError_t e1 = hipEventRecord(ctx->ev_scan_done, ctx->scan_stream);
+        ctx->stream = main;
+        const hipError_t e2 = hipStreamWaitEvent(main, ctx->ev_scan_done, 0);
+        return (e1 == hipSuccess && e2 == hipSuccess) ? PXG_OK : PXG_E_HIP;
+    }
+    ~ScanStreamScope()
+    {
+        if (on) {                       // an error exit: nothing of the scan may still be running when the caller goes on
+            (void)hipStreamSynchronize(ctx->scan_stream);
+            ctx->stream = main;
+        }
+    }
+};
+
 #define HOOK_BEGIN                                           \
     if (!ctx) return PXG_E_INVALID;                          \
     PXG_HIP(ctx, hipSetDevice(ctx->device));                 \
@@ -1648,6 +1693,7 @@ extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
         return rc;
     int64_t* d_first = ctx->ev_first.p;
     int64_t* d_eoff = ctx->ev_off.p;
+    ScanStreamScope scan(ctx);          // beside K6 when the last run had the poly(A) stage
     // (through the context's page-locked mirrors, like every other small host array of a batch: the runtime is never
     //  handed pageable memory whose lifetime ends with this call -- ADVICE r4, profiles/r05/fault_hunt.md)
     if ((rc = pxg_h2d_meta(ctx, 2, 0, d_first, first.data(), (size_t)n * sizeof(int64_t), ctx->stream)) ||
@@ -1674,6 +1720,7 @@ extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
                                         ctx->unsplit_iv.p)))
         return rc;
     pxg_timer_end(ctx, PXG_T_UNSPLIT);
+    if (scan.join()) return fail(ctx, PXG_E_HIP, "pxg_batch_unsplit_scan: joining the scan stream");
     HOOK_GET(out_count, ctx->unsplit_cnt.p, n);
     HOOK_GET(out_total, ctx->unsplit_ivoff.p + n, 1);
     PXG_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -308,6 +308,13 @@ struct pxg_ctx {
         DevBuf<pxg_z_chunk> zchunks; // ... and their chunk records, decoded into `raw` on the copy stream
     } spare;
     hipStream_t copy_stream = nullptr;
+    // The window scan of the pseudo-fusion filter (K7a / K7b) reads only what the segmentation stage left behind, and
+    // so does poly(A) (K6): a scan call that follows a run with the poly(A) stage puts its kernels on this stream,
+    // behind the event recorded just before K6's launch -- two latency-bound kernels side by side on the chip
+    // instead of one after the other (PXG_NO_SCAN_OVERLAP=1 at pxg_create: everything on `stream`).
+    hipStream_t scan_stream = nullptr;
+    hipEvent_t ev_scan_gate = nullptr, ev_scan_done = nullptr;
+    bool scan_gate_set = false, scan_overlap = true;
     hipEvent_t ev_staged = nullptr;
     hipEvent_t ev_run_done[2] = { nullptr, nullptr };   // last run on the resident / the spare inputs
     bool run_recorded[2] = { false, false };
