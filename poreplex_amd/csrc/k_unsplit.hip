@@ -603,6 +603,10 @@ __device__ __forceinline__ void un_emission_round(const double* par, int n_mix, 
     }
 }
 
+// XC = steps per round.  4: 264 VGPRs, one wave per SIMD -- the faster kernel while a batch has no more 64-window
+// groups than the chip has SIMDs (10 000 reads: 940; 2.0 ms against 2.85); 2: 234 VGPRs, two waves per SIMD, which is
+// what a bigger batch needs to hide the LDS round trips (100 000 reads: 14.0 ms against 19.6).  Chosen at launch.
+template <int XC>
 __global__ __launch_bounds__(64) void k_unsplit_scan_w(
     int64_t n_reads, int tmax, UnsplitDense D, UnsplitParams P, const pxg_calib* __restrict__ cal,
     const int32_t* __restrict__ status, const int32_t* __restrict__ segs,
@@ -638,7 +642,6 @@ __global__ __launch_bounds__(64) void k_unsplit_scan_w(
     const int S = D.n_states;
     unsigned* bpm = bpbuf + (size_t)blockIdx.x * tmax * 64 + lane;
     const int64_t n_units = unit_off[n_reads];
-    constexpr int XC = 4;                    // steps per round: the emissions of a round are taken rank by rank
     // (the transition matrix is read from LDS where it is used -- one address for all lanes, a broadcast: 36 scalar
     //  pairs beside everything else get spilled into vector lanes and come back through v_readlane, 72 vector registers
     //  push the round's emissions into AGPRs and come back through v_accvgpr_read, both on the serial path)
@@ -941,9 +944,15 @@ int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t units_bound, int tm
                        scaled, bp, cand, cand_cnt, wcand, ctx->d_lsetab, ctx->unsplit_q.p)
     const int nin = ctx->hmm[1].max_in;
     if (unsplit_lane_windows() && ctx->hmm[1].n_states <= UD_S) {
-        hipLaunchKernelGGL(k_unsplit_scan_w, dim3((unsigned)waves), dim3(64), 0, ctx->stream, n, tmax,
-                           unsplit_dense(ctx->hmm[1], P), P, cal, status, segs, first_sample, ev_off, ev_start, unit_off,
-                           scaled, bp, cand, cand_cnt, wcand, ctx->d_lsetab, ctx->unsplit_q.p);
+        const UnsplitDense D = unsplit_dense(ctx->hmm[1], P);
+        if ((units_bound + 63) / 64 <= (int64_t)ctx->n_cu * 4)
+            hipLaunchKernelGGL(k_unsplit_scan_w<4>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, n, tmax, D, P, cal, status,
+                               segs, first_sample, ev_off, ev_start, unit_off, scaled, bp, cand, cand_cnt, wcand,
+                               ctx->d_lsetab, ctx->unsplit_q.p);
+        else
+            hipLaunchKernelGGL(k_unsplit_scan_w<2>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, n, tmax, D, P, cal, status,
+                               segs, first_sample, ev_off, ev_start, unit_off, scaled, bp, cand, cand_cnt, wcand,
+                               ctx->d_lsetab, ctx->unsplit_q.p);
     } else {
         if (nin <= 2) SCAN(k_unsplit_scan, 2);
         else if (nin <= 3) SCAN(k_unsplit_scan, 3);
