@@ -945,7 +945,9 @@ int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t units_bound, int tm
     const int nin = ctx->hmm[1].max_in;
     if (unsplit_lane_windows() && ctx->hmm[1].n_states <= UD_S) {
         const UnsplitDense D = unsplit_dense(ctx->hmm[1], P);
-        if ((units_bound + 63) / 64 <= (int64_t)ctx->n_cu * 4)
+        // (units_bound is the host's upper bound, about 1.4 x the windows a batch really has: 10 000 reads of ~4 000
+        //  blocks = 86 000 by the bound, 60 000 on the device = 940 groups for 1 024 SIMDs)
+        if ((units_bound + 63) / 64 <= (int64_t)ctx->n_cu * 6)
             hipLaunchKernelGGL(k_unsplit_scan_w<4>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, n, tmax, D, P, cal, status,
                                segs, first_sample, ev_off, ev_start, unit_off, scaled, bp, cand, cand_cnt, wcand,
                                ctx->d_lsetab, ctx->unsplit_q.p);

@@ -208,6 +208,7 @@ extern "C" int pxg_create(const pxg_config* cfg, pxg_ctx** out)
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&ctx->scan_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_segmented, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_scan_gate, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_scan_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_staged, hipEventDisableTiming) != hipSuccess ||
@@ -327,6 +328,7 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
         if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
         if (ctx->scan_stream) (void)hipStreamDestroy(ctx->scan_stream);
         if (ctx->ev_scan_gate) (void)hipEventDestroy(ctx->ev_scan_gate);
+        if (ctx->ev_segmented) (void)hipEventDestroy(ctx->ev_segmented);
         if (ctx->ev_scan_done) (void)hipEventDestroy(ctx->ev_scan_done);
         if (ctx->ev_staged) (void)hipEventDestroy(ctx->ev_staged);
         for (int q = 0; q < 2; q++)
@@ -826,6 +828,8 @@ extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
         if ((rc = pxg_launch_segment_raw(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p,
                                          head, ctx->status.p, ctx->segs.p, order))) return rc;
         pxg_timer_end(ctx, PXG_T_SEGMENT);
+        if (ctx->scan_overlap && (stage_mask & PXG_STAGE_POLYA))     // (the block means of a scan call may be taken from here on)
+            PXG_HIP(ctx, hipEventRecord(ctx->ev_segmented, ctx->stream));
     }
     if (stage_mask & PXG_STAGE_BARCODE) {
         pxg_timer_begin(ctx, PXG_T_BARCODE_WINDOW);
@@ -1310,11 +1314,13 @@ struct ScanStreamScope {
     explicit ScanStreamScope(pxg_ctx* c) : ctx(c), main(c->stream)
     {
         if (c->scan_gate_set && c->scan_stream &&
-            hipStreamWaitEvent(c->scan_stream, c->ev_scan_gate, 0) == hipSuccess) {
+            hipStreamWaitEvent(c->scan_stream, c->ev_segmented, 0) == hipSuccess) {
             c->stream = c->scan_stream;
             on = true;
         }
     }
+    // the second gate: what is enqueued from here on starts with K6 (the block means before it: with the barcode kernels)
+    int gate_polya() { return (!on || hipStreamWaitEvent(ctx->scan_stream, ctx->ev_scan_gate, 0) == hipSuccess) ? PXG_OK : PXG_E_HIP; }
     int join()
     {
         if (!on) return PXG_OK;
@@ -1705,6 +1711,7 @@ extern "C" int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample,
                                       d_first, d_eoff, block_stride, ctx->ev_mean.p, ctx->ev_scaled.p);
     if (rc) return rc;
     pxg_timer_end(ctx, PXG_T_EVENT_MEANS);
+    if (scan.gate_polya()) return fail(ctx, PXG_E_HIP, "pxg_batch_unsplit_scan: scan stream gate");
     pxg_timer_begin(ctx, PXG_T_UNSPLIT);
     // plan -> unit offsets -> scan -> per-read counts -> interval offsets -> compact gather,
     // all on the stream: nothing here waits for the device

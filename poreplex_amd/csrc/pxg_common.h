@@ -310,10 +310,12 @@ struct pxg_ctx {
     hipStream_t copy_stream = nullptr;
     // The window scan of the pseudo-fusion filter (K7a / K7b) reads only what the segmentation stage left behind, and
     // so does poly(A) (K6): a scan call that follows a run with the poly(A) stage puts its kernels on this stream,
-    // behind the event recorded just before K6's launch -- two latency-bound kernels side by side on the chip
-    // instead of one after the other (PXG_NO_SCAN_OVERLAP=1 at pxg_create: everything on `stream`).
+    // with two gates: the block means (K7a, VALU-bound) may start once the segmentation is done, beside the barcode
+    // kernels; the window scan (K7b, latency-bound) behind the event recorded just before K6's launch -- two
+    // latency-bound kernels side by side on the chip instead of one after the other, and K7a out of their way (started
+    // at the same gate it took 2.75 ms instead of 0.53).  PXG_NO_SCAN_OVERLAP=1 at pxg_create: everything on `stream`.
     hipStream_t scan_stream = nullptr;
-    hipEvent_t ev_scan_gate = nullptr, ev_scan_done = nullptr;
+    hipEvent_t ev_segmented = nullptr, ev_scan_gate = nullptr, ev_scan_done = nullptr;
     bool scan_gate_set = false, scan_overlap = true;
     hipEvent_t ev_staged = nullptr;
     hipEvent_t ev_run_done[2] = { nullptr, nullptr };   // last run on the resident / the spare inputs
