@@ -56,7 +56,7 @@ PEAK_HBM = 8.0e12              # B/s
 # the only throughput the reference publishes (Poreplex 0.1, whole
 # pipeline incl. FAST5 I/O, 2x Xeon E5-2687W v3 = 20 cores): 1 339 070 reads in 1 h 37 min
 PUBLISHED_READS_PER_S = 1339070 / (97 * 60.0)
-TRAFFIC_FILE = os.path.join('profiles', 'r04', 'h_hbm_traffic.json')
+TRAFFIC_FILE = os.path.join('profiles', 'r05', 'h_hbm_traffic.json')
 # PXG_BENCH_SHARE_GPU=1: every rank of a torchrun launch uses GPU 0 and the collectives go over gloo --
 # the real multi-process path (sharding, barriers, max over ranks, label gather, NUMA binding, the
 # host-side legs on all ranks at once) with the real kernels on a ONE-GPU box.  A plumbing check:
@@ -658,10 +658,10 @@ def strong_leg(args, ctx, dist, rank, world, mask, standin, force_dist, barrier)
 
 
 FLIPS_FILE = os.path.join('profiles', 'r04', 'decision_flips.json')
-FLIPS_GPU_FILE = os.path.join('profiles', 'r04', 'decision_flips_gpu_160k_reads.json')
-BOUNDS_FILE = os.path.join('profiles', 'r04', 'full_kernel_bounds.json')
-ROCPROF_STATS = {'demux': os.path.join('profiles', 'r04', 'h_demux_kernel_stats.csv'),
-                 'full': os.path.join('profiles', 'r04', 'h_full_kernel_stats.csv')}
+FLIPS_GPU_FILE = os.path.join('profiles', 'r05', 'decision_flips_gpu_160k_reads.json')
+BOUNDS_FILE = os.path.join('profiles', 'r05', 'full_kernel_bounds.json')
+ROCPROF_STATS = {'demux': os.path.join('profiles', 'r05', 'h_demux_kernel_stats.csv'),
+                 'full': os.path.join('profiles', 'r05', 'h_full_kernel_stats.csv')}
 
 
 def unpinned_rows_block():
@@ -931,7 +931,7 @@ def full_leg(args, ctx, base, lens, inject, orc, n_check=64, big_reads=100000):
             ('k_polya (K6)', 'polya', None, 'serial peak FSM + interval DP per read (16 lanes per read): issue / latency bound'),
             ('k_guppy_event_means (K7a)', 'event_means', samples * 2 + blocks * 4,
              'every int16 sample in once, one float32 block mean out; fp64 pA conversion: VALU issue at HBM rate'),
-            ('k_unsplit_scan (K7b)', 'unsplit', None, 'fp64 Viterbi recurrence of ~6 overlapping windows per read: issue bound')):
+            ('k_unsplit_scan (K7b)', 'unsplit', None, 'fp64 Viterbi recurrence, one window per lane, ~6 overlapping windows per read: fp64 issue + LDS latency at one wave per SIMD')):
         ms = stage_ms[timer]
         row = {'kernel': name, 'bound': 'hbm' if alg_bytes else 'issue', 'kernel_ms': round(ms, 4), 'what': what}
         if alg_bytes and ms:
@@ -1214,6 +1214,13 @@ def main():
             if roofline.get('frac') and roofline.get('kernel_ms'):
                 roofline['frac_at_rocprof_avg'] = roofline['frac'] * roofline['kernel_ms'] / avg_ms
             roofline['rocprof_source'] = 'static: ' + ROCPROF_STATS[args.workload if args.workload == 'full' else 'demux']
+            # the clock the kernel really ran at in the committed PMC pass (GRBM_GUI_ACTIVE / 8 XCDs / duration): the
+            # nominal peaks are quoted at 2.4 GHz
+            with open(os.path.join(ROOT, BOUNDS_FILE)) as fh:
+                kb_ = json.load(fh)['kernels'].get(roofline['kernel'], {})
+            if kb_.get('clock_GHz'):
+                roofline['clock_GHz_in_profile'] = kb_['clock_GHz']
+                roofline['clock_source'] = 'static: ' + BOUNDS_FILE + ' (PMC pass of --workload full)'
         except (OSError, KeyError, StopIteration, ValueError):
             pass
     # HBM bytes per launch of that kernel: NOT measured by this run (PMC counters need
@@ -1421,8 +1428,8 @@ def main():
                 'source': 'static: {} (rocprofv3 PMC passes of --workload full)'.format(BOUNDS_FILE),
                 'k_polya': dict(kb['k_polya'], bound='latency / divergence of a per-read FSM: 40 % of the SIMD cycles issue '
                                 'VALU, a third of the instructions are scalar, waves wait 45 % of their cycles'),
-                'k_unsplit_scan': dict(kb['k_unsplit_scan'], bound='VALU issue (fp64 recurrence + DPP / bpermute shuffles): 70 % of '
-                                       'the SIMD cycles, LDS 48 % busy of which 27 % bank conflicts'),
+                'k_unsplit_scan': dict(kb['k_unsplit_scan'], bound='one window per lane (round 5): fp64 issue + LDS round trips at one '
+                                       'wave per SIMD (the 8-lane kernel of round 4: 70 % VALU issue, 2.95 ms)'),
                 'k_guppy_event_means': dict(kb['k_guppy_event_means'], bound='VALU issue 98 % (fp64 pA conversion, median-of-5 '
                                             'network) at 3.1 TB/s of HBM traffic'),
             }
