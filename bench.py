@@ -327,7 +327,7 @@ def end_to_end(args, config, rank, local_rank, world, dist, standin, base, which
                            'reads_per_gpu': [out['reads_this_rank']], 'batch_reads': args.batch_reads,
                            'samples_per_read': args.samples, 'device': info['name'], 'arch': info['arch']},
                 'roofline': None, 'cpu_baseline': None, 'concordance': None,
-                'extra': {'session_timing_rank0': {k: round(v, 4) for k, v in out['timing'].items()},
+                'extra': {'session_timing_rank0': {k: (round(v, 4) if isinstance(v, float) else v) for k, v in out['timing'].items()},
                           'bundle_write_s': round(t_write, 3), 'compressed_bundle': bool(args.compressed_bundle), 'from_fast5': args.from_fast5, 'context_and_bundle_open_s': round(t_open, 3),
                           'reads_labelled_pass': int(counts[LABEL_NAMES.index('pass')].sum()),
                           'reads_with_barcode': int(counts[:, 1:].sum()), 'summary_rows': n_rows,

@@ -26,10 +26,15 @@
 #include <unistd.h>
 #include <zlib.h>
 #include <emmintrin.h>
+#include <tmmintrin.h>
 
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -103,6 +108,10 @@ typedef unsigned (*zstd_iserror_fn)(size_t);
 struct Zstd {
     zstd_decompress_fn decompress = nullptr;
     zstd_iserror_fn is_error = nullptr;
+    // (optional: a decompression context kept per thread saves the workspace set-up of every call)
+    void* (*create_dctx)() = nullptr;
+    size_t (*free_dctx)(void*) = nullptr;
+    size_t (*decompress_dctx)(void*, void*, size_t, const void*, size_t) = nullptr;
     Zstd()
     {
         for (const char* name : { "libzstd.so.1", "libzstd.so" }) {
@@ -110,15 +119,89 @@ struct Zstd {
             if (!h) continue;
             decompress = (zstd_decompress_fn)dlsym(h, "ZSTD_decompress");
             is_error = (zstd_iserror_fn)dlsym(h, "ZSTD_isError");
+            create_dctx = (void* (*)())dlsym(h, "ZSTD_createDCtx");
+            free_dctx = (size_t (*)(void*))dlsym(h, "ZSTD_freeDCtx");
+            decompress_dctx = (size_t (*)(void*, void*, size_t, const void*, size_t))dlsym(h, "ZSTD_decompressDCtx");
+            if (!create_dctx || !free_dctx || !decompress_dctx) create_dctx = nullptr;
             if (decompress && is_error) return;
         }
         decompress = nullptr;
     }
+    size_t run(void* dst, size_t cap, const void* src, size_t n) const;
 };
 const Zstd& zstd()
 {
     static Zstd z;
     return z;
+}
+struct ZstdThread {
+    void* ctx = nullptr;
+    ~ZstdThread() { if (ctx) zstd().free_dctx(ctx); }
+};
+size_t Zstd::run(void* dst, size_t cap, const void* src, size_t n) const
+{
+    if (create_dctx) {
+        static thread_local ZstdThread t;
+        if (!t.ctx) t.ctx = create_dctx();
+        if (t.ctx) return decompress_dctx(t.ctx, dst, cap, src, n);
+    }
+    return decompress(dst, cap, src, n);
+}
+
+// ---- VBZ version 1: eight 16-bit samples per control byte, sample q is 1 + bit q bytes long ----------------
+// One pshufb spreads the 8..16 data bytes of a group over eight 16-bit lanes (a 256 x 16-byte table of byte
+// positions), zig-zag and the running sum stay in the vector: ~12 instructions per 8 samples where the scalar
+// loop takes ~50.  Same integers as the scalar loop (sums modulo 2^16); PXG_H5_SCALAR=1 or a CPU without SSSE3
+// keeps the scalar loop.
+struct SvbTable {
+    alignas(16) uint8_t shuf[256][16];
+    uint8_t len[256];
+    SvbTable()
+    {
+        for (int k = 0; k < 256; k++) {
+            int at = 0;
+            for (int q = 0; q < 8; q++) {
+                const int two = (k >> q) & 1;
+                shuf[k][2 * q] = (uint8_t)at;
+                shuf[k][2 * q + 1] = two ? (uint8_t)(at + 1) : 0x80;
+                at += 1 + two;
+            }
+            len[k] = (uint8_t)at;
+        }
+    }
+};
+static bool svb_simd_ok()
+{
+    static const bool ok = !getenv("PXG_H5_SCALAR") && __builtin_cpu_supports("ssse3");
+    return ok;
+}
+// groups [0, n_groups) of `keys` / `data` -> o16; returns the data bytes used, or (size_t)-1 when the stream ends
+// inside a group.  `data` must be readable 16 bytes past every group start (the caller pads its buffer).
+__attribute__((target("ssse3")))
+static size_t svb1_groups_ssse3(const uint8_t* keys, const uint8_t* data, size_t n_data, uint64_t n_groups, bool zig,
+                                uint16_t* o16, uint32_t& prev_io)
+{
+    static const SvbTable T;
+    size_t pos = 0;
+    __m128i prev = _mm_set1_epi16((short)prev_io);
+    const __m128i one = _mm_set1_epi16(1), zero = _mm_setzero_si128();
+    const __m128i last = _mm_set_epi8(15, 14, 15, 14, 15, 14, 15, 14, 15, 14, 15, 14, 15, 14, 15, 14);
+    for (uint64_t g = 0; g < n_groups; g++) {
+        const unsigned key = keys[g];
+        const size_t group = T.len[key];
+        if (pos + group > n_data) return (size_t)-1;
+        __m128i v = _mm_shuffle_epi8(_mm_loadu_si128((const __m128i*)(data + pos)), _mm_load_si128((const __m128i*)T.shuf[key]));
+        if (zig) v = _mm_xor_si128(_mm_srli_epi16(v, 1), _mm_sub_epi16(zero, _mm_and_si128(v, one)));
+        v = _mm_add_epi16(v, _mm_slli_si128(v, 2));
+        v = _mm_add_epi16(v, _mm_slli_si128(v, 4));
+        v = _mm_add_epi16(v, _mm_slli_si128(v, 8));
+        v = _mm_add_epi16(v, prev);
+        _mm_storeu_si128((__m128i*)(o16 + 8 * g), v);
+        prev = _mm_shuffle_epi8(v, last);
+        pos += group;
+    }
+    prev_io = (uint32_t)(uint16_t)_mm_extract_epi16(prev, 0);
+    return pos;
 }
 
 }  // namespace
@@ -148,18 +231,20 @@ struct pxg_h5 {
         return p + base + off;
     }
     // `len` raw bytes of the file at `off` into `out`.  A big stretch (a read's uncompressed Signal: ~120 KB) is
-    // fetched with pread(): the kernel copies page cache -> `out` directly, where a memcpy from the mapping takes a
-    // minor fault and a TLB fill for every 4 KB page it has not touched before -- 300 000 of them per 10 000-read
-    // batch, on all loader threads at once, against the same address space the group walk of the NEXT file is
-    // faulting in.  Measured on the GPU box (16-core quota, profiles/r05/fast5_ingest_*.txt): the copy itself is
-    // memory-bound at 46 GB/s either way, the loader call for 10 000 reads 52 ms with pread against 62 (memcpy) and
-    // 64 (non-temporal stores from the mapping: a third less traffic, but the faults stay).
-    // PXG_H5_COPY=memcpy|pread|nt selects the path (A/B; default pread).
+    // fetched with pread() instead of a memcpy from the mapping, which takes a minor fault and a TLB fill for every
+    // 4 KB page it has not touched before -- 300 000 of them per 10 000-read batch, on all loader threads at once,
+    // against the same address space the group walk of the NEXT file is faulting in.  The copy is memory-bound
+    // (16-core quota of the GPU box: 46-52 GB/s), so the default goes through a 256 KB buffer that stays in the
+    // core's L2 and leaves with non-temporal stores: the destination is never read for ownership, two passes over
+    // memory instead of three.  Loader call for 10 000 reads (profiles/r05/fast5_ingest_*.txt, ab_h5_copy.txt):
+    // memcpy 62 ms, nt (non-temporal stores from the mapping: the faults stay) 64, pread 52; with the reader's
+    // shared worker threads pread 31.9, bounce 27.7.
+    // PXG_H5_COPY=memcpy|pread|nt|bounce selects the path (A/B; default bounce).
     static int copy_mode()
     {
         static const int mode = [] {
             const char* e = getenv("PXG_H5_COPY");
-            return !e ? 1 : (!strcmp(e, "memcpy") ? 0 : (!strcmp(e, "nt") ? 2 : 1));
+            return !e ? 3 : (!strcmp(e, "memcpy") ? 0 : (!strcmp(e, "nt") ? 2 : (!strcmp(e, "pread") ? 1 : 3)));
         }();
         return mode;
     }
@@ -175,6 +260,45 @@ struct pxg_h5 {
                 if (got <= 0) break;                       // (a file shrinking under the map: take the mapping's zeros)
                 done += (uint64_t)got;
             }
+            if (done < len) memcpy(out + done, src + done, (size_t)(len - done));
+            return;
+        }
+        if (mode == 3 && fd >= 0) {
+            // pread into a buffer that stays in this core's L2, then non-temporal stores: the destination is
+            // never read for ownership (two passes over memory instead of three)
+            static thread_local std::vector<uint8_t> bounce;
+            const size_t CH = 256u << 10;
+            if (bounce.size() < CH + 64) bounce.resize(CH + 64);
+            uint8_t* b = (uint8_t*)(((uintptr_t)bounce.data() + 63) & ~(uintptr_t)63);
+            uint64_t done = 0;
+            bool ok = true;
+            while (done < len && ok) {
+                // keep (out + done) 16-byte aligned after the first piece
+                size_t want = (size_t)std::min<uint64_t>(CH, len - done);
+                if (done == 0) want = std::min<size_t>(want, ((16 - ((uintptr_t)out & 15)) & 15) + (CH - 16));
+                size_t have = 0;
+                while (have < want) {
+                    const ssize_t got = pread(fd, b + have, want - have, (off_t)(base + off + done + have));
+                    if (got < 0 && errno == EINTR) continue;
+                    if (got <= 0) { ok = false; break; }
+                    have += (size_t)got;
+                }
+                if (!ok) break;
+                uint8_t* o = out + done;
+                size_t i = std::min<size_t>(have, (size_t)((16 - ((uintptr_t)o & 15)) & 15));
+                memcpy(o, b, i);
+                for (; i + 64 <= have; i += 64) {
+                    const __m128i x0 = _mm_loadu_si128((const __m128i*)(b + i)), x1 = _mm_loadu_si128((const __m128i*)(b + i + 16));
+                    const __m128i x2 = _mm_loadu_si128((const __m128i*)(b + i + 32)), x3 = _mm_loadu_si128((const __m128i*)(b + i + 48));
+                    _mm_stream_si128((__m128i*)(o + i), x0);
+                    _mm_stream_si128((__m128i*)(o + i + 16), x1);
+                    _mm_stream_si128((__m128i*)(o + i + 32), x2);
+                    _mm_stream_si128((__m128i*)(o + i + 48), x3);
+                }
+                memcpy(o + i, b + i, have - i);
+                done += have;
+            }
+            _mm_sfence();
             if (done < len) memcpy(out + done, src + done, (size_t)(len - done));
             return;
         }
@@ -662,19 +786,31 @@ struct pxg_h5 {
                 const View zin = src();
                 if (zin.n >= 8 && memcmp(zin.p, MAGIC, 4) && memcmp(zin.p + 4, MAGIC, 4) == 0) skip = 4;
                 const uint64_t n = want / 2;
-                std::vector<uint8_t> svb((version ? (n + 7) / 8 + 2 * n : (n + 3) / 4 + 4 * n) + 16);
-                const size_t got = zstd().decompress(svb.data(), svb.size(), zin.p + skip, zin.n - skip);
+                // (scratch kept per thread: a 120 KB read would otherwise pay for two zero-filled vectors)
+                static thread_local std::vector<uint8_t> svb;
+                const size_t svb_cap = (size_t)(version ? (n + 7) / 8 + 2 * n : (n + 3) / 4 + 4 * n);
+                if (svb.size() < svb_cap + 32) svb.resize(svb_cap + 32);
+                const size_t got = zstd().run(svb.data(), svb_cap, zin.p + skip, zin.n - skip);
                 if (zstd().is_error(got)) fail(PXG_E_INVALID, "VBZ: zstd stream is corrupt");
                 const size_t keys = version ? (n + 7) / 8 : (n + 3) / 4;
                 if (got < keys) fail(PXG_E_INVALID, "VBZ: stream shorter than its control bits");
-                std::vector<uint8_t> dst(want);
+                memset(svb.data() + got, 0, 32);                    // what a 16-byte load at the last group may see
+                // the last stage of the pipeline writes the samples where they belong
+                bool last_stage = true;
+                for (int g = f - 1; g >= 0; g--) last_stage &= (mask & (1u << g)) != 0;
+                std::vector<uint8_t> dst;
+                if (!last_stage) dst.resize(want);
                 const uint8_t* data = svb.data() + keys;
                 const size_t n_data = got - keys;
-                uint16_t* o16 = (uint16_t*)dst.data();
+                uint16_t* o16 = (uint16_t*)(last_stage ? out : dst.data());
                 size_t pos = 0;
                 uint32_t prev = 0;
                 uint64_t i = 0;
-                if (version == 1) {
+                if (version == 1 && svb_simd_ok()) {
+                    pos = svb1_groups_ssse3(svb.data(), data, n_data, n / 8, zig != 0, o16, prev);
+                    if (pos == (size_t)-1) fail(PXG_E_INVALID, "VBZ: stream ends inside a sample");
+                    i = n / 8 * 8;
+                } else if (version == 1) {
                     // eight samples per control byte; the byte offsets inside the group come from
                     // the bits below each sample (no data-dependent branch per sample)
                     for (; i + 8 <= n; i += 8) {
@@ -703,6 +839,7 @@ struct pxg_h5 {
                     prev += v;                                   // delta from the previous sample (first: from 0)
                     o16[i] = (uint16_t)prev;
                 }
+                if (last_stage) return;
                 cur.swap(dst);
                 first = false;
             } else
@@ -836,7 +973,7 @@ extern "C" void pxg_h5_close(pxg_h5* h)
 }
 
 template <typename Fn>
-static void run_pool(int64_t n, int threads, Fn fn);
+static void run_pool(int64_t n, int threads, Fn fn, int64_t grain = 1);
 
 // `threads`: host threads that walk the read groups of a multi-read file (a 4 000-read file is
 // 4 000 groups of four children each: 7 ms on one thread)
@@ -884,8 +1021,11 @@ extern "C" int pxg_h5_open_mt(const char* path, int32_t threads, pxg_h5** out)
     } else
         fail(PXG_E_UNSUPPORTED, "HDF5: unknown superblock version");
     // ---- the reads of the file (fast5_file.py:37-58, :71-82) ---------------------------------
+    const bool trace = getenv("PXG_H5_TRACE") != nullptr;
+    const auto tr0 = std::chrono::steady_clock::now();
     const Object root = h->object(h->root);
     const auto top = h->children(root);
+    const auto tr1 = std::chrono::steady_clock::now();
     bool single = false;
     for (const auto& c : top) single |= c.first == "UniqueGlobalKey";
     h->multi = !single;
@@ -937,8 +1077,13 @@ extern "C" int pxg_h5_open_mt(const char* path, int32_t threads, pxg_h5** out)
                 hh->reads[(size_t)k] = pxg_h5_read();
                 failed.fetch_add(1);
             }
-        });
+        }, 16);
     }
+    if (trace)
+        fprintf(stderr, "pxg_h5_open: root listing %.2f ms, read groups %.2f ms (%zu reads, %d threads)\n",
+                std::chrono::duration<double, std::milli>(tr1 - tr0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr1).count(),
+                h->reads.size(), (int)threads);
     *out = h;
     h = nullptr;                     // released to the caller
     return PXG_OK;
@@ -1117,7 +1262,7 @@ extern "C" int pxg_h5_info_mt(const pxg_h5* h, int64_t first, int64_t n, pxg_h5_
             o.status = PXG_E_NOMEM;
             put(o.error, sizeof(o.error), e.what(), true);
         }
-    });
+    }, 8);
     return PXG_OK;
 }
 
@@ -1222,32 +1367,128 @@ extern "C" int64_t pxg_h5_events(const pxg_h5* h, int64_t i, int64_t cap_rows, i
     H5_GUARD_END(h)
 }
 
+// Host threads of the reader: ONE set of worker threads per process, started on first use and
+// parked on a condition variable between calls.  A loader call is four short parallel phases
+// (read groups, metadata, samples, basecall text) of a few milliseconds each: starting and joining
+// 15 threads per phase cost more than the phase's own work on a 16-core host.  One job at a time;
+// a caller that finds the workers busy (two loader threads) starts threads of its own as before.
+// Nothing may leave fn (the callers catch inside their lambdas).
+struct PoolJob {
+    void (*call)(void*, int64_t, int64_t);
+    void* ctx;
+    int64_t n, grain;
+    std::atomic<int64_t> next{ 0 };
+    void drain()
+    {
+        for (;;) {
+            const int64_t k = next.fetch_add(grain);
+            if (k >= n) return;
+            call(ctx, k, std::min(n, k + grain));
+        }
+    }
+};
+
+struct Pool {
+    std::mutex submit;                  // one job at a time
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    PoolJob* job = nullptr;
+    uint64_t gen = 0;
+    int slots = 0;                      // workers that may still join the current job
+    int running = 0;                    // workers inside it
+    int n_workers = 0;
+
+    void worker()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        uint64_t seen = 0;
+        for (;;) {
+            cv.wait(lk, [&] { return job && gen != seen && slots > 0; });
+            seen = gen;
+            slots--;
+            running++;
+            PoolJob* j = job;
+            lk.unlock();
+            j->drain();
+            lk.lock();
+            if (--running == 0) cv_done.notify_all();
+        }
+    }
+
+    // true = the job ran here (on the caller and up to threads - 1 workers)
+    bool run(PoolJob& j, int threads)
+    {
+        std::unique_lock<std::mutex> one(submit, std::try_to_lock);
+        if (!one.owns_lock()) return false;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            while (n_workers < threads - 1) {
+                try { std::thread(&Pool::worker, this).detach(); }
+                catch (const std::exception&) { break; }        // no more threads to be had: the ones we got
+                n_workers++;
+            }
+            job = &j;
+            gen++;
+            slots = std::min(threads - 1, n_workers);
+            running = 0;
+        }
+        cv.notify_all();
+        j.drain();
+        std::unique_lock<std::mutex> lk(mu);
+        slots = 0;                      // nobody joins a job whose queue is empty
+        cv_done.wait(lk, [&] { return running == 0; });
+        job = nullptr;
+        return true;
+    }
+};
+
+// (never destroyed: its threads outlive main(); a forked child starts with a pool of its own,
+//  the parent's worker threads do not exist there)
+static std::atomic<Pool*> g_pool{ nullptr };
+static void pool_after_fork() { g_pool.store(nullptr); }
+static Pool* the_pool()
+{
+    Pool* p = g_pool.load();
+    if (p) return p;
+    static std::mutex mk;
+    std::lock_guard<std::mutex> lk(mk);
+    p = g_pool.load();
+    if (!p) {
+        static bool hooked = false;
+        if (!hooked) { pthread_atfork(nullptr, nullptr, pool_after_fork); hooked = true; }
+        p = new Pool();
+        g_pool.store(p);
+    }
+    return p;
+}
+
+// fn(k) for k in [0, n) on `threads` host threads, `grain` consecutive k per queue access
+template <typename Fn>
+static void run_pool(int64_t n, int threads, Fn fn, int64_t grain)
+{
+    if (n <= 0) return;
+    grain = std::max<int64_t>(1, grain);
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads, (n + grain - 1) / grain));
+    PoolJob j;
+    j.call = [](void* c, int64_t a, int64_t b) { Fn& f = *(Fn*)c; for (int64_t k = a; k < b; k++) f(k); };
+    j.ctx = &fn;
+    j.n = n;
+    j.grain = grain;
+    if (nt == 1) { j.drain(); return; }
+    if (!getenv("PXG_H5_SPAWN_THREADS") && the_pool()->run(j, nt)) return;
+    std::vector<std::thread> own;
+    own.reserve((size_t)nt);
+    for (int t = 1; t < nt; t++) {
+        try { own.emplace_back([&j] { j.drain(); }); }
+        catch (const std::exception&) { break; }    // no more threads to be had: the ones we got, and this one
+    }
+    j.drain();
+    for (auto& t : own) t.join();
+}
+
 // The int16 samples of many reads (any mix of open files), decoded on `threads` host threads
 // straight into `arena` (the caller's staging buffer): read k = (files[k], index[k]) goes to
 // arena[dst_start[k] .. dst_start[k] + n_samples[k]).  status[k] = 0 or that read's own error code.
-template <typename Fn>
-static void run_pool(int64_t n, int threads, Fn fn)
-{
-    std::atomic<int64_t> next{ 0 };
-    auto work = [&]() {
-        for (;;) {
-            const int64_t k = next.fetch_add(1);
-            if (k >= n) return;
-            fn(k);
-        }
-    };
-    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads, n));
-    if (nt == 1) { work(); return; }
-    std::vector<std::thread> pool;
-    pool.reserve((size_t)nt);
-    for (int t = 1; t < nt; t++) {
-        try { pool.emplace_back(work); }
-        catch (const std::exception&) { break; }    // no more threads to be had: the ones we got, and this one
-    }
-    work();
-    for (auto& t : pool) t.join();
-}
-
 extern "C" int pxg_h5_load_signals(int64_t n, const pxg_h5* const* files, const int64_t* index,
                                    const int64_t* dst_start, const int64_t* n_samples, int16_t* arena,
                                    int32_t threads, int32_t* status)

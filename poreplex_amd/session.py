@@ -111,10 +111,13 @@ class GpuSession:
         self.analyzer = SignalAnalyzer(config, batchid=self.rank)
         self.ctx, self.loader = self.analyzer.ctx, self.analyzer.loader
         self.timing = {'load_s': 0.0, 'gpu_wait_s': 0.0, 'facade_s': 0.0, 'sink_s': 0.0,
-                       'collect_s': 0.0, 'swap_run_s': 0.0, 'take_s': 0.0, 'stage_s': 0.0}
+                       'collect_s': 0.0, 'swap_run_s': 0.0, 'take_s': 0.0, 'stage_s': 0.0,
+                       'fill_s': 0.0, 'load_ms': [],       # fill_s: until batch 0 computes and batch 1 is on its way
+                       'load_phases_ms': []}               # per batch: FAST5 walk, signals, text (all threads' calls), wait for the prefetch, prepare
 
     # ---- loader thread: batch k+1 is opened and packed while batch k computes ---------
     def _produce(self, batches, slots, out, stop):
+        from .fast5_file import TIMING as f5_timing
         ahead = None
         try:
             for k, reads in enumerate(batches):
@@ -122,16 +125,22 @@ class GpuSession:
                 if stop.is_set() or staging is None:  # the session is being torn down
                     return
                 t0 = time.perf_counter()
+                before = dict(f5_timing)
                 if ahead is not None:
                     ahead.join()
                 ahead = None
                 if k + 1 < len(batches):              # the next batch's files are opened beside this one's decode
                     ahead = threading.Thread(target=self.loader.prefetch_files, args=(batches[k + 1],), daemon=True)
                     ahead.start()
+                t_join = time.perf_counter()
                 batch = self.analyzer.prepare(reads, ReadTable(), reserve=staging.reserve)
+                t_prep = time.perf_counter()
                 need = int(batch.table.n_raw[np.asarray(batch.entered, dtype=np.int64)].sum()) if batch.entered else 0
                 rows, arena, offsets, calib = self.loader.pack(batch.table, staging, need)
                 self.timing['load_s'] += time.perf_counter() - t0
+                self.timing['load_ms'].append(round((time.perf_counter() - t0) * 1e3, 1))
+                self.timing['load_phases_ms'].append([round((f5_timing[key] - before[key]) * 1e3, 1) for key in ('walk_s', 'signals_s', 'text_s')]
+                                                     + [round((t_join - t0) * 1e3, 1), round((t_prep - t_join) * 1e3, 1)])
                 out.put((batch, staging, rows, arena, offsets, calib))
             out.put(None)
         except BaseException as exc:                   # surfaces in run() on the main thread
@@ -259,6 +268,7 @@ class GpuSession:
             for rnd in range(max(n_rounds, 1)):
                 try:
                     if failure is None and rnd == 0:
+                        t_fill = time.perf_counter()
                         current = take()
                         if current is not None:
                             if stage(current):
@@ -267,6 +277,7 @@ class GpuSession:
                             slots.put(current[1])
                             nxt = take()
                             nxt_staged = stage(nxt)
+                        self.timing['fill_s'] += time.perf_counter() - t_fill
                     if failure is None and current is not None:
                         t0 = time.perf_counter()
                         self.loader.collect_resident(current[0].table, current[2], current[4])   # D2H of the records: waits for run k

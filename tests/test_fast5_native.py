@@ -95,9 +95,9 @@ def test_native_reader_returns_what_the_writer_wrote(inputs):
 
 
 def test_big_uncompressed_signals_take_the_bulk_copy(tmp_path):
-    """A Signal of 64 KB or more does not go through memcpy (pxg_h5.cpp copy_out: pread, or PXG_H5_COPY=nt /
-    memcpy in a fresh process): odd lengths and destinations that are not 16-byte aligned, against the samples
-    that were written."""
+    """A Signal of 64 KB or more does not go through memcpy (pxg_h5.cpp copy_out: pread into an L2-resident buffer +
+    non-temporal stores; PXG_H5_COPY=pread / nt / memcpy in a fresh process): odd lengths and destinations that are
+    not 16-byte aligned, against the samples that were written."""
     rng = np.random.default_rng(7)
     lens = [32768, 40001, 65537, 123457]
     raws = [rng.integers(-3000, 3000, n).astype(np.int16) for n in lens]
@@ -118,6 +118,106 @@ def test_big_uncompressed_signals_take_the_bulk_copy(tmp_path):
         for j, r in enumerate(raws):
             assert np.array_equal(arena[dst[j]:dst[j] + lens[j]], r), (shift, j)
             assert arena[dst[j] + lens[j]] == 12345
+    # the selectable paths, each in a process of its own (the mode is read once)
+    code = ('import sys, numpy as np; sys.path.insert(0, %r); from poreplex_amd import fast5_file as F5\n'
+            'f = F5.Fast5File(%r); ns = f.info["n_samples"].astype(np.int64)\n'
+            'dst = 3 + np.concatenate([[0], np.cumsum(ns)[:-1]]).astype(np.int64); a = np.zeros(int(ns.sum()) + 8, dtype=np.int16)\n'
+            'st = F5.load_signals([f] * f.n, np.arange(f.n), ns, a, dst, threads=2)\n'
+            'print(int(st.any()), int((a.astype(np.int64) * (1 + np.arange(len(a)) %% 7)).sum()))' % (ROOT, path))
+    flat = np.concatenate([np.zeros(3, np.int16)] + raws + [np.zeros(5, np.int16)]).astype(np.int64)
+    want = ['0', str(int((flat * (1 + np.arange(len(flat)) % 7)).sum()))]
+    for mode in ('memcpy', 'pread', 'nt', 'bounce'):
+        out = subprocess.run([os.sys.executable, '-c', code], env=dict(os.environ, PXG_H5_COPY=mode),
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.split() == want, mode
+
+
+@pytest.mark.skipif(not have_zstd(), reason='libzstd is not on this host')
+def test_vbz_decoder_vector_and_scalar(tmp_path):
+    """VBZ streams (pxg_h5.cpp unfilter: zstd + one control bit per 16-bit zig-zag delta) through the pshufb
+    decoder and, in a process with PXG_H5_SCALAR=1, the scalar loop: full-range samples (two-byte codes, sums that
+    wrap modulo 2^16), flat stretches (one-byte codes), lengths around the 8-sample groups, chunked and whole."""
+    rng = np.random.default_rng(23)
+    lens = [1, 7, 8, 9, 15, 16, 17, 4097, 60001]
+    raws = []
+    for k, n in enumerate(lens):
+        wild = rng.integers(-32768, 32768, n).astype(np.int16)
+        calm = (500 + np.cumsum(rng.integers(-40, 41, n))).astype(np.int16)
+        raws.append(np.where(rng.random(n) < (0.5 if k % 2 else 0.05), wild, calm).astype(np.int16))
+    cal = np.zeros(1, dtype=N.CALIB_DTYPE)
+    cal['range'], cal['digitisation'], cal['offset'], cal['sampling_rate'] = 1400.0, 8192.0, 5.0, 3012.0
+    path = str(tmp_path / 'vbz.fast5')
+    with Fast5Writer(path) as w:
+        for j, r in enumerate(raws):
+            w.add_read('v%02d' % j, r, cal[0], compression='vbz', chunk=None if j % 2 else 1024)
+    f = F5.Fast5File(path)
+    ns = f.info['n_samples'].astype(np.int64)
+    assert ns.tolist() == lens
+    dst = np.concatenate([[0], np.cumsum(ns)[:-1]]).astype(np.int64)
+    arena = np.zeros(int(ns.sum()), dtype=np.int16)
+    assert not F5.load_signals([f] * f.n, np.arange(f.n), ns, arena, dst, threads=2).any()
+    flat = np.concatenate(raws)
+    assert np.array_equal(arena, flat)
+    code = ('import sys, numpy as np; sys.path.insert(0, %r); from poreplex_amd import fast5_file as F5\n'
+            'f = F5.Fast5File(%r); ns = f.info["n_samples"].astype(np.int64)\n'
+            'dst = np.concatenate([[0], np.cumsum(ns)[:-1]]).astype(np.int64); a = np.zeros(int(ns.sum()), dtype=np.int16)\n'
+            'st = F5.load_signals([f] * f.n, np.arange(f.n), ns, a, dst, threads=1)\n'
+            'print(int(st.any()), int((a.astype(np.int64) * (1 + np.arange(len(a)) %% 11)).sum()))' % (ROOT, path))
+    out = subprocess.run([os.sys.executable, '-c', code], env=dict(os.environ, PXG_H5_SCALAR='1'),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ['0', str(int((flat.astype(np.int64) * (1 + np.arange(len(flat)) % 11)).sum()))]
+
+
+def test_reader_threads_are_shared_between_calls_and_survive_a_fork(tmp_path):
+    """The reader's worker threads are started once per process (pxg_h5.cpp run_pool).  Calls that overlap
+    (two loader threads: one gets the workers, the other starts threads of its own), a child forked after the
+    workers exist (they do not exist there: it starts its own), and the per-call threads of
+    PXG_H5_SPAWN_THREADS=1 all deliver the samples that were written."""
+    import threading
+    rng = np.random.default_rng(11)
+    lens = rng.integers(2000, 90000, 96)
+    raws = [rng.integers(-3000, 3000, int(n)).astype(np.int16) for n in lens]
+    cal = np.zeros(1, dtype=N.CALIB_DTYPE)
+    cal['range'], cal['digitisation'], cal['offset'], cal['sampling_rate'] = 1400.0, 8192.0, 5.0, 3012.0
+    path = str(tmp_path / 'pool.fast5')
+    with Fast5Writer(path) as w:
+        for j, r in enumerate(raws):
+            w.add_read('p%03d' % j, r, cal[0])
+    ns = np.asarray(lens, dtype=np.int64)
+    dst = np.concatenate([[0], np.cumsum(ns)[:-1]]).astype(np.int64)
+
+    def one_pass(threads):
+        F5._OPEN.clear()
+        f = F5.Fast5File(path)                           # the read groups: a pool job of its own
+        arena = np.zeros(int(ns.sum()), dtype=np.int16)
+        st = F5.load_signals([f] * len(lens), np.arange(len(lens)), ns, arena, dst, threads=threads)
+        return not st.any() and all(np.array_equal(arena[dst[j]:dst[j] + lens[j]], raws[j]) for j in range(len(lens)))
+
+    assert one_pass(4)
+    ok = []
+    ts = [threading.Thread(target=lambda: ok.append(all(one_pass(3 + (k % 3)) for k in range(6)))) for _ in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert ok == [True] * 4
+    pid = os.fork()
+    if pid == 0:                                          # the child: no worker thread came along
+        os._exit(0 if one_pass(4) and one_pass(2) else 1)
+    assert os.waitpid(pid, 0)[1] == 0
+    assert one_pass(5)                                    # more workers than the pool had so far
+    code = ('import sys, numpy as np; sys.path.insert(0, %r); from poreplex_amd import fast5_file as F5\n'
+            'f = F5.Fast5File(%r); info = f.info; ns = info["n_samples"].astype(np.int64)\n'
+            'dst = np.concatenate([[0], np.cumsum(ns)[:-1]]).astype(np.int64); a = np.zeros(int(ns.sum()), dtype=np.int16)\n'
+            'st = F5.load_signals([f] * f.n, np.arange(f.n), ns, a, dst, threads=4); print(int(st.any()), int(a.astype(np.int64).sum()))'
+            % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), path))
+    env = dict(os.environ, PXG_H5_SPAWN_THREADS='1')
+    out = subprocess.run([os.sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ['0', str(int(sum(int(r.astype(np.int64).sum()) for r in raws)))]
+
 
 def test_batch_columns_equal_per_read_access(inputs):
     top, t = inputs
