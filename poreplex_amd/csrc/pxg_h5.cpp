@@ -38,6 +38,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -212,7 +213,17 @@ struct pxg_h5_read {               // one read of an open file
     uint64_t signal_obj = UNDEF, channel_obj = UNDEF, tracking_obj = UNDEF, analyses_obj = UNDEF;
 };
 
+// Where a read's basecall text and move table lie in the file, noted by the metadata pass (pxg_h5_info has
+// walked Analyses/Basecall_1D_xxx, read and validated the Fastq record and summed the moves): the batch decoder
+// then copies three byte ranges instead of walking five groups again.  Only for the plain layouts (fixed-length
+// Fastq string and uint8 Move table stored contiguously, unfiltered); everything else takes the walk.
+struct BcWhere {
+    std::atomic<int> state{ 0 };   // 0 unknown, 2 being written, 1 usable
+    uint64_t seq_at = 0, qual_at = 0, len = 0, move_at = UNDEF, n_moves = 0;
+};
+
 struct pxg_h5 {
+    mutable std::unique_ptr<BcWhere[]> bc_where;      // one per read (allocated when the reads are known)
     int fd = -1;
     const uint8_t* p = nullptr;
     size_t n = 0, map_len = 0;
@@ -1079,6 +1090,7 @@ extern "C" int pxg_h5_open_mt(const char* path, int32_t threads, pxg_h5** out)
             }
         }, 16);
     }
+    if (!getenv("PXG_H5_NO_TEXT_NOTES")) h->bc_where.reset(new BcWhere[h->reads.size() ? h->reads.size() : 1]);
     if (trace)
         fprintf(stderr, "pxg_h5_open: root listing %.2f ms, read groups %.2f ms (%zu reads, %d threads)\n",
                 std::chrono::duration<double, std::milli>(tr1 - tr0).count(),
@@ -1104,8 +1116,10 @@ static void put(char* dst, size_t cap, const std::string& s, bool may_cut = fals
 }
 
 static void basecall_of(const pxg_h5* h, const pxg_h5_read& r, pxg_h5_read_info& o, std::string* fastq,
-                        std::vector<uint8_t>* moves, std::vector<double>* pms)
+                        std::vector<uint8_t>* moves, std::vector<double>* pms, BcWhere* note = nullptr)
 {
+    bool plain = false;                      // the text's place can be noted
+    uint64_t n_seq_at = 0, n_qual_at = 0, n_len = 0, n_move_at = UNDEF, n_moves_noted = 0;
     o.bc_present = 0; o.bc_table = 0; o.bc_block_stride = 15; o.bc_n_moves = -1; o.bc_move_sum = 0;
     if (r.analyses_obj == UNDEF) return;
     const Object an = h->object(r.analyses_obj);
@@ -1122,7 +1136,8 @@ static void basecall_of(const pxg_h5* h, const pxg_h5_read& r, pxg_h5_read_info&
     o.bc_first_sample = h->attr_int(h->need(sego, "first_sample_template"));
     const uint64_t fq = h->resolve(best_obj, "BaseCalled_template/Fastq");
     if (fq == UNDEF) fail(PXG_E_INVALID, "FAST5: BaseCalled_template/Fastq is missing");
-    const std::string text = h->dataset_string(h->object(fq).ds);
+    const Dataset fqd = h->object(fq).ds;
+    const std::string text = h->dataset_string(fqd);
     // '@name\nSEQ\n+\nQUAL\n'
     size_t l1 = text.find('\n'), l2 = l1 == std::string::npos ? l1 : text.find('\n', l1 + 1);
     size_t l3 = l2 == std::string::npos ? l2 : text.find('\n', l2 + 1);
@@ -1135,6 +1150,10 @@ static void basecall_of(const pxg_h5* h, const pxg_h5_read& r, pxg_h5_read_info&
         if (k != l2 && k != l3 && (text[k] < 33 || text[k] > 126) && !(k > l2 && k < l3))
             fail(PXG_E_INVALID, "FAST5: Fastq record holds bytes that are not printable ASCII");
     if (fastq) *fastq = text.substr(l1 + 1, l2 - l1 - 1) + "\n" + text.substr(l3 + 1, l4 - l3 - 1);
+    if (fqd.type.cls == 3 && fqd.layout == 1 && fqd.filters.empty() && fqd.addr != UNDEF && fqd.n_elements() <= 1) {
+        plain = true;
+        n_seq_at = fqd.addr + l1 + 1; n_qual_at = fqd.addr + l3 + 1; n_len = l2 - l1 - 1;
+    }
     const uint64_t sm = h->resolve(best_obj, "Summary/basecall_1d_template");
     if (sm == UNDEF) fail(PXG_E_INVALID, "FAST5: Summary/basecall_1d_template is missing");
     const Object smo = h->object(sm);
@@ -1148,6 +1167,7 @@ static void basecall_of(const pxg_h5* h, const pxg_h5_read& r, pxg_h5_read_info&
     const Object to = h->object(tmpl);
     const uint64_t ev = h->child(to, "Events"), mv = h->child(to, "Move");
     if (ev != UNDEF) {
+        plain = false;
         const Dataset d = h->object(ev).ds;
         if (d.type.cls != 6) fail(PXG_E_INVALID, "FAST5: Events is not a table");
         const Datatype::Member* mcol = nullptr;
@@ -1190,6 +1210,15 @@ static void basecall_of(const pxg_h5* h, const pxg_h5_read& r, pxg_h5_read_info&
         o.bc_table = 1;
         o.bc_n_moves = (int64_t)n;
         for (uint64_t k = 0; k < n; k++) o.bc_move_sum += buf[k];
+        if (n == 0) n_move_at = UNDEF;
+        else if (d.layout == 1 && d.filters.empty() && d.addr != UNDEF) { n_move_at = d.addr; n_moves_noted = n; }
+        else plain = false;
+    }
+    int unknown = 0;
+    if (note && plain && note->state.compare_exchange_strong(unknown, 2)) {
+        note->seq_at = n_seq_at; note->qual_at = n_qual_at; note->len = n_len;
+        note->move_at = n_move_at; note->n_moves = n_moves_noted;
+        note->state.store(1, std::memory_order_release);
     }
 }
 
@@ -1254,7 +1283,8 @@ extern "C" int pxg_h5_info_mt(const pxg_h5* h, int64_t first, int64_t n, pxg_h5_
         pxg_h5_read_info& o = out[k];
         try {
             info_of(h, h->reads[(size_t)(first + k)], o);
-            basecall_of(h, h->reads[(size_t)(first + k)], o, nullptr, nullptr, nullptr);
+            basecall_of(h, h->reads[(size_t)(first + k)], o, nullptr, nullptr, nullptr,
+                        h->bc_where ? &h->bc_where[(size_t)(first + k)] : nullptr);
         } catch (const H5Error& e) {
             o.status = e.code;
             put(o.error, sizeof(o.error), e.msg, true);
@@ -1530,6 +1560,18 @@ extern "C" int pxg_h5_basecall_many(int64_t n, const pxg_h5* const* files, const
         try {
             const pxg_h5* h = files[k];
             if (!h || index[k] < 0 || index[k] >= (int64_t)h->reads.size()) fail(PXG_E_INVALID, "bad read index");
+            if (h->bc_where) {
+                const BcWhere& w = h->bc_where[(size_t)index[k]];
+                if (w.state.load(std::memory_order_acquire) == 1 && (int64_t)w.len == seq_len[k] &&
+                    (n_moves[k] <= 0 || (w.move_at != UNDEF && (int64_t)w.n_moves == n_moves[k]))) {
+                    if (seq_len[k] > 0) {
+                        memcpy(seq_arena + seq_start[k], h->at(w.seq_at, w.len), (size_t)w.len);
+                        memcpy(qual_arena + seq_start[k], h->at(w.qual_at, w.len), (size_t)w.len);
+                    }
+                    if (n_moves[k] > 0) memcpy(move_arena + move_start[k], h->at(w.move_at, w.n_moves), (size_t)w.n_moves);
+                    return;
+                }
+            }
             pxg_h5_read_info o;
             memset(&o, 0, sizeof(o));
             std::string fq;

@@ -551,6 +551,8 @@ class SignalLoader:
             try:
                 f = open_fast5(os.path.join(self.fast5prefix, filename))
                 f.read_ids, f.info
+                if f.multi:
+                    f.read_ids_array, f.keys_for(filename)
             except Exception:             # noqa: BLE001
                 pass
 
@@ -560,6 +562,10 @@ class SignalLoader:
         from .fast5_file import Fast5Batch, Fast5Error, open_fast5
         if table.n or table.bundle is not None:
             return where
+        runs = self.fast5_runs(reads)
+        if runs is not None:
+            bundle = Fast5Batch.from_runs(runs).as_bundle(reserve)
+            return self.enter_fast5_bundle(bundle, bundle.filenames, np.arange(len(reads)), where, table)
         # per FILE, not per read: the positions of its reads in the request, their indices in
         # the file by one dictionary pass, the readable ones by one mask over the info column
         by_file = {}
@@ -592,7 +598,34 @@ class SignalLoader:
         ids = [reads[pos][1] for pos in at.tolist()]
         files = [f for f, k in files for _ in range(k)]
         bundle = Fast5Batch(files, index, names, ids).as_bundle(reserve)
-        rows = table.extend_from_bundle(bundle, np.arange(len(files)))
+        return self.enter_fast5_bundle(bundle, names, at, where, table)
+
+    def fast5_runs(self, reads):
+        """[(Fast5File, name, first read, count)] when the request is stretches of readable multi-read files in
+        file order -- a worker batch of a run --, recognised by one list comparison per file; None for anything
+        else (single-read files, a shuffled or interleaved request, unreadable reads: the general path)."""
+        from .fast5_file import Fast5Error, open_fast5
+        runs, pos, n = [], 0, len(reads)
+        while pos < n:
+            name, read_id = reads[pos]
+            try:
+                f = open_fast5(os.path.join(self.fast5prefix, name))
+            except (OSError, Fast5Error):
+                return None
+            first = f.index_of(read_id) if f.multi else -1
+            if first < 0:
+                return None
+            count = min(f.n - first, n - pos)
+            if reads[pos:pos + count] != f.keys_for(name)[first:first + count] or f.info['status'][first:first + count].any():
+                return None
+            runs.append((f, name, first, count))
+            pos += count
+        return runs
+
+    def enter_fast5_bundle(self, bundle, names, at, where, table):
+        """Rows for the reads of a Fast5Batch bundle (request positions `at`), the length gate and the reads whose
+        samples or text could not be decoded."""
+        rows = table.extend_from_bundle(bundle, np.arange(len(at)))
         cfg = self.scaler_cfg      # length gate of load_padded_signal_head (:212-222)
         usable = np.minimum(np.minimum(cfg['length'], table.duration[rows]), table.n_raw[rows])
         short = rows[usable - usable % cfg['stride'] < cfg['min_length']]

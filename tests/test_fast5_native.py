@@ -236,6 +236,27 @@ def test_batch_columns_equal_per_read_access(inputs):
             assert b.d['bc_move_sum'][i] == int(want['move'].sum()) and b.d['bc_n_moves'][i] == len(want['move'])
 
 
+def test_basecall_text_by_noted_ranges_equals_the_walk(inputs):
+    """The batch decoder copies the byte ranges the metadata pass noted (pxg_h5.cpp BcWhere); with
+    PXG_H5_NO_TEXT_NOTES=1 it walks the groups of every read again: same arenas."""
+    top, t = inputs
+    code = ('import sys, os, zlib, numpy as np; sys.path.insert(0, %r); from poreplex_amd import fast5_file as F5\n'
+            'top = %r; names = sorted(n for n in os.listdir(top) if n.startswith("multi_"))\n'
+            'files, index, where = [], [], []\n'
+            'for n in names:\n'
+            '    f = F5.open_fast5(os.path.join(top, n)); files += [f] * f.n; index += list(range(f.n)); where += [n] * f.n\n'
+            'b = F5.Fast5Batch(files, index, where).as_bundle(threads=3)\n'
+            'assert not b.basecall_status.any()\n'
+            'print(len(files), *[zlib.crc32(b.d[k].tobytes()) for k in ("seq_arena", "qual_arena", "move_arena", "seq_offsets", "move_offsets")])'
+            % (ROOT, top))
+    outs = []
+    for env in ({}, {'PXG_H5_NO_TEXT_NOTES': '1'}):
+        out = subprocess.run([os.sys.executable, '-c', code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        outs.append(out.stdout.split())
+    assert outs[0] == outs[1] and int(outs[0][0]) > 20
+
+
 def test_prepare_many_maps_an_interleaved_request_onto_rows(inputs):
     """Reads asked for in any order, from several files at once, with an id no file holds and a
     file that is not there: every found read lands in ITS row, the others are left to the
@@ -270,6 +291,50 @@ def test_prepare_many_maps_an_interleaved_request_onto_rows(inputs):
         assert np.array_equal(table.samples_of(row), t['raws'][i])
         assert table.channel[row] == t['meta'][i]['channel_number'] and table.start_time[row] == t['meta'][i]['start_time']
         assert table.sample_id[row] == 'smp' and table.run_id[row] == 'r' * 40
+
+
+def test_a_request_in_file_order_takes_the_run_path_and_equals_the_general_one(inputs, monkeypatch):
+    """A worker batch of a run -- stretches of multi-read files in file order, starting inside a file -- is
+    recognised by SignalLoader.fast5_runs and built from slices (Fast5Batch.from_runs); the same request with
+    that recognition switched off goes read by read: same rows, same columns, same samples and text."""
+    from poreplex_amd.signal_loader import ReadTable, SignalLoader
+    top, t = inputs
+
+    class Cfg:
+        stride, scaler_length, scaler_min_length = 15, 30000, 4500
+        scaler_qc_scale, scaler_qc_shift = (0.0, 1e9), (-1e9, 1e9)
+
+    class Ctx:
+        cfg = Cfg()
+
+    multi = [i for i in range(len(t['ids'])) if t['where'][i].startswith('multi_')]
+    reads = [(t['where'][i], t['ids'][i]) for i in multi[5:]]          # (multi lists the reads in file order)
+    tables = []
+    for general in (False, True):
+        loader = SignalLoader(default_config(inputdir=top, outputdir=top), top, Ctx())
+        assert loader.fast5_runs(reads) is not None and len(loader.fast5_runs(reads)) >= 2
+        if general:
+            monkeypatch.setattr(SignalLoader, 'fast5_runs', lambda self, reads: None)
+        table = ReadTable()
+        where = loader.prepare_many(reads, table)
+        assert where.tolist() == list(range(len(reads)))
+        tables.append(table)
+    a, b = tables
+    assert a.filename == b.filename and a.read_id == b.read_id and a.channel == b.channel
+    assert a.run_id == b.run_id and a.sample_id == b.sample_id
+    for name in ('status', 'start_time', 'duration', 'n_raw', 'sampling_rate', 'pending'):
+        assert np.array_equal(getattr(a, name)[:a.n], getattr(b, name)[:b.n]), name
+    assert a.calib[:a.n].tobytes() == b.calib[:b.n].tobytes()
+    for k in ('bc_present', 'bc_sequence_length', 'bc_mean_qscore', 'bc_n_moves', 'bc_move_sum', 'seq_offsets',
+              'seq_arena', 'qual_arena', 'move_offsets', 'move_arena', 'filename', 'read_id', 'channel_number'):
+        assert np.array_equal(a.bundle.d[k], b.bundle.d[k]), k
+    for row, i in enumerate(multi[5:]):
+        assert np.array_equal(a.samples_of(row), t['raws'][i]) and np.array_equal(b.samples_of(row), t['raws'][i])
+    # anything else is left to the general path
+    loader = SignalLoader(default_config(inputdir=top, outputdir=top), top, Ctx())
+    assert loader.fast5_runs(reads[::-1]) is None and loader.fast5_runs(reads[:3] + reads[4:]) is None
+    assert loader.fast5_runs([(t['where'][0], t['ids'][0])]) is None                  # a single-read file
+    assert loader.fast5_runs([('gone.fast5', 'x')]) is None
 
 
 def test_open_file_cache_is_bounded_in_bytes(inputs, monkeypatch):
