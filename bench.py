@@ -296,6 +296,9 @@ def end_to_end(args, config, rank, local_rank, world, dist, standin, base, which
         t0 = time.perf_counter()
         out = session.run(list(zip(names, ids)), presharded_at=lo)
         wall = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        session.close()                   # the staging arenas' page locks come off here (reported, not in `value`)
+        t_close = time.perf_counter() - t0
         n_ranks = 1
         if dist is not None:
             import torch
@@ -328,7 +331,7 @@ def end_to_end(args, config, rank, local_rank, world, dist, standin, base, which
                            'samples_per_read': args.samples, 'device': info['name'], 'arch': info['arch']},
                 'roofline': None, 'cpu_baseline': None, 'concordance': None,
                 'extra': {'session_timing_rank0': {k: (round(v, 4) if isinstance(v, float) else v) for k, v in out['timing'].items()},
-                          'bundle_write_s': round(t_write, 3), 'compressed_bundle': bool(args.compressed_bundle), 'from_fast5': args.from_fast5, 'context_and_bundle_open_s': round(t_open, 3),
+                          'bundle_write_s': round(t_write, 3), 'compressed_bundle': bool(args.compressed_bundle), 'from_fast5': args.from_fast5, 'context_and_bundle_open_s': round(t_open, 3), 'session_close_s': round(t_close, 3),
                           'reads_labelled_pass': int(counts[LABEL_NAMES.index('pass')].sum()),
                           'reads_with_barcode': int(counts[:, 1:].sum()), 'summary_rows': n_rows,
                           'labels_gathered': int(len(out['labels'])),
@@ -477,6 +480,8 @@ def fast5_ingest_leg(args, base, which, n_reads=2048):
         raws = [base['arena'][o[b]:o[b + 1]] for b in which[:n]]
         bcs = synth_basecalls({'offsets': np.concatenate([[0], np.cumsum([len(r) for r in raws])])}, seed=args.seed)
         out['reads'] = n
+        stage = np.empty(sum(len(r) for r in raws) + 16, dtype=np.int16)
+        stage.fill(0)                  # a staging arena that has been used before, like the session's from its third batch on
         for mode, count in (('none', n), ('vbz', n), ('gzip', min(n, 512))):
             path = os.path.join(work, mode + '.fast5')
             t0 = time.perf_counter()
@@ -493,7 +498,7 @@ def fast5_ingest_leg(args, base, which, n_reads=2048):
             before = dict(F5.TIMING)
             t0 = time.perf_counter()
             f = F5.Fast5File(path)
-            bundle = F5.Fast5Batch([f] * f.n, np.arange(f.n), [mode + '.fast5'] * f.n).as_bundle()
+            bundle = F5.Fast5Batch.from_runs([(f, mode + '.fast5', 0, f.n)]).as_bundle(reserve=lambda k: stage[:k])
             dt = time.perf_counter() - t0
             assert not bundle.signal_status.any() and np.array_equal(bundle.samples(count - 1), raws[count - 1])
             out[mode] = {'reads_per_s': count / dt, 'reads': count, 'file_MB': round(os.path.getsize(path) / 1e6, 1),
@@ -511,20 +516,25 @@ def fast5_ingest_leg(args, base, which, n_reads=2048):
 def end_to_end_legs(args):
     """The session driver from files, as part of the DEFAULT line (so that the driver's own run
     carries it): `bench.py --end-to-end` in a child process, once from an encoded read bundle and once
-    from uncompressed multi-read FAST5 (12 and 6 batches: fill and drain included; longer runs
-    are in profiles/).  Errors are reported, never hidden."""
+    from uncompressed multi-read FAST5 (12 batches each: fill and drain included -- the first two batches of a
+    session load into staging arenas nobody has touched yet, the last one drains alone; `loader_ms_per_batch` is
+    the median of the loader thread's time per batch from the third batch on; longer runs are in profiles/).
+    Errors are reported, never hidden."""
     import subprocess
     out = {'batch_reads': 10000}
     for name, reads, flags in (('encoded_bundle', 120000, ['--compressed-bundle']),
-                               ('fast5_uncompressed', 60000, ['--from-fast5', 'none'])):
+                               ('fast5_uncompressed', 120000, ['--from-fast5', 'none'])):
         cmd = [sys.executable, os.path.abspath(__file__), '--end-to-end', '--reads', str(reads), '--batch-reads', '10000',
                '--samples', str(args.samples), '--seed', str(args.seed), '--cpu-sample', '0', '--cpu-all-cores-sample', '0'] + flags
         env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
         try:
-            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=180)
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
             line = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+            timing = line['extra']['session_timing_rank0']
+            steady = sorted(timing.get('load_ms', [])[2:])
             out[name] = {'reads_per_s': line['value'], 'reads': reads, 'batches': line['steps'],
-                         'loader_s': line['extra']['session_timing_rank0']['load_s'],
+                         'loader_s': timing['load_s'],
+                         'loader_ms_per_batch': steady[len(steady) // 2] if steady else None,
                          'summary_rows': line['extra']['summary_rows']}
         except Exception as exc:                       # noqa: BLE001
             out[name] = {'error': '{}: {}'.format(type(exc).__name__, exc)}

@@ -110,10 +110,16 @@ class GpuSession:
             self.numa = D.bind_to_gpu_numa(device)
         self.analyzer = SignalAnalyzer(config, batchid=self.rank)
         self.ctx, self.loader = self.analyzer.ctx, self.analyzer.loader
+        # the two staging arenas live as long as the session: page-locking them happens with the first batches,
+        # taking the lock off again (hipHostUnregister: ~45 ms per 1.3 GB arena on the MI355X host) in close()
+        self.stagings = None
         self.timing = {'load_s': 0.0, 'gpu_wait_s': 0.0, 'facade_s': 0.0, 'sink_s': 0.0,
                        'collect_s': 0.0, 'swap_run_s': 0.0, 'take_s': 0.0, 'stage_s': 0.0,
                        'fill_s': 0.0, 'load_ms': [],       # fill_s: until batch 0 computes and batch 1 is on its way
-                       'load_phases_ms': []}               # per batch: FAST5 walk, signals, text (all threads' calls), wait for the prefetch, prepare
+                       'load_phases_ms': [],
+                       # the run outside the batch loop: before the loader starts, the loop itself, releasing the
+                       # staging arenas / closing the sinks, the final collectives + stitching
+                       'setup_s': 0.0, 'loop_s': 0.0, 'teardown_s': 0.0, 'finish_s': 0.0}               # per batch: FAST5 walk, signals, text (all threads' calls), wait for the prefetch, prepare
 
     # ---- loader thread: batch k+1 is opened and packed while batch k computes ---------
     def _produce(self, batches, slots, out, stop):
@@ -159,6 +165,7 @@ class GpuSession:
         agreed on once per batch round, so every rank leaves the loop in the same round and
         raises SessionAborted instead of hanging in the final collectives."""
         cfg = self.config
+        t_enter = t_loop = time.perf_counter()
         if reads is None:
             reads, lengths = enumerate_reads(cfg, self.loader.bundle)
         if presharded_at is not None:
@@ -186,7 +193,9 @@ class GpuSession:
         fastq = sinks.FASTQWriter(outdir, layout, suffix=part) if cfg.get('fastq_output') else None
 
         slots, ready, stop = queue.Queue(), queue.Queue(maxsize=2), threading.Event()
-        stagings = [_Staging(self.ctx), _Staging(self.ctx)]
+        if self.stagings is None:
+            self.stagings = [_Staging(self.ctx), _Staging(self.ctx)]
+        stagings = self.stagings
         thread = None
         records, status_seen = [], {}
         t_start = time.perf_counter()
@@ -260,6 +269,8 @@ class GpuSession:
             n_rounds = D.agree_max(len(batches), self.dist)
             thread = threading.Thread(target=self._produce, args=(batches, slots, ready, stop), daemon=True)
             thread.start()
+            self.timing['setup_s'] = time.perf_counter() - t_enter
+            t_loop = time.perf_counter()
 
             # pipeline: [k computes] [k+1 is copied under it] [k-1 is judged and written on the host].
             # The copy of k+1 is enqueued the moment the spare slot is free -- right after k became
@@ -309,6 +320,8 @@ class GpuSession:
         except BaseException as exc:          # KeyboardInterrupt and friends: clean up, do not agree
             failure = exc
         finally:
+            t_down = time.perf_counter()
+            self.timing['loop_s'] = t_down - t_loop
             # drain and join the loader thread: it may sit in slots.get() or ready.put()
             stop.set()
             if thread is not None:
@@ -324,18 +337,17 @@ class GpuSession:
                 self.ctx.sync()               # nothing may still read a staging arena
             except Exception:                 # noqa: BLE001 -- the original failure is the one to report
                 pass
-            for s_ in stagings:
-                try:
-                    s_.release()
-                except Exception:             # noqa: BLE001
-                    pass
+            if failure is not None:           # a failed run leaves nothing page-locked behind
+                self.close()
             summary.close()
             if fastq is not None:
                 fastq.close()
+            self.timing['teardown_s'] = time.perf_counter() - t_down
         if failure is not None:
             self.logger.error('Stopping the run: %s', failure)
             raise failure
         wall = time.perf_counter() - t_start
+        t_finish = time.perf_counter()
 
         local = np.concatenate(records) if records else np.zeros(0, dtype=D.LABEL_DTYPE)
         counts = D.reduce_counts(local, self.dist)                    # all-reduce (RCCL / gloo)
@@ -355,7 +367,20 @@ class GpuSession:
             out['tracker'] = tracker
         if self.dist is not None:
             self.dist.barrier()
+        out['timing']['finish_s'] = time.perf_counter() - t_finish
         return out
+
+    def close(self):
+        """Release the staging arenas (idempotent; also runs when the session object goes away)."""
+        stagings, self.stagings = getattr(self, 'stagings', None), None
+        for s_ in stagings or []:
+            try:
+                s_.release()
+            except Exception:                 # noqa: BLE001 -- e.g. the context is gone already
+                pass
+
+    def __del__(self):
+        self.close()
 
     def _check_early_stop(self, seen):
         """pipeline.py:250-260: stop when reads keep arriving without basecalls."""

@@ -24,9 +24,10 @@ $B --end-to-end --compressed-bundle --workload full --reads 120000 --batch-reads
 python bench.py --api process_batch --in-flight 5 --api-calls 24 --cpu-sample 0 --cpu-all-cores-sample 0 --no-overlap-test --no-full-leg --no-fast5-leg --no-e2e-leg > $OUT/bench_api_process_batch.json 2> $OUT/api.err
 python bench.py --api process_batch --workload full --in-flight 5 --api-calls 12 --cpu-sample 0 --cpu-all-cores-sample 0 --no-overlap-test --no-full-leg --no-fast5-leg --no-e2e-leg > $OUT/bench_api_process_batch_full.json 2>> $OUT/api.err
 for c in none vbz gzip; do
-  r=60000; [ $c = gzip ] && r=30000        # (the pure-Python FAST5 writer is what takes the time here)
+  r=120000; [ $c = vbz ] && r=60000; [ $c = gzip ] && r=30000        # (the pure-Python FAST5 writer is what takes the time here)
   $B --end-to-end --from-fast5 $c --reads $r --batch-reads 10000 > $OUT/bench_end_to_end_fast5_$c.json 2>> $OUT/e2e.err
 done
+tools/dev/e2e_fast5.sh $OUT/e2e_fast5_per_batch.txt none 300000 1 > /dev/null 2>&1      # 30 batches, the loader's time per batch
 python tools/fast5_ingest_profile.py 10000 > $OUT/fast5_ingest_profile.txt 2>&1
 # round 4: the float32 arithmetic, run-shaped lengths, the bare --gpus 8 command under the driver's clock
 $B --lstm-arith f32 --steps 10 --warmup 3 > $OUT/bench_demux_f32_arith.json 2> $OUT/f32.err
