@@ -316,6 +316,10 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     if (ctx->d_sigtab) (void)hipFree(ctx->d_sigtab);
     if (ctx->d_lsetab) (void)hipFree(ctx->d_lsetab);
     if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
+    for (int k = 0; k < 2; k++) {
+        if (ctx->ev_up[k]) { (void)hipEventSynchronize(ctx->ev_up[k]); (void)hipEventDestroy(ctx->ev_up[k]); }
+        if (ctx->h_up[k]) (void)hipHostFree(ctx->h_up[k]);
+    }
     for (auto& set : ctx->h_meta)
         for (auto& m : set)
             if (m.p) (void)hipHostFree(m.p);
@@ -452,9 +456,8 @@ extern "C" int pxg_batch_upload(pxg_ctx* ctx, int64_t n_reads, const int16_t* ra
     if (n_reads > (1LL << 30)) return fail(ctx, PXG_E_INVALID, "too many reads");
     int rc = reserve_batch(ctx, n_reads, n_samples);
     if (rc) return rc;
-    if (n_samples)
-        PXG_HIP(ctx, hipMemcpyAsync(ctx->raw.p, raw_arena, (size_t)n_samples * sizeof(int16_t),
-                                    hipMemcpyHostToDevice, ctx->stream));
+    if (n_samples && (rc = pxg_h2d_big(ctx, ctx->raw.p, raw_arena, (size_t)n_samples * sizeof(int16_t), ctx->stream)))
+        return rc;
     if ((rc = pxg_h2d_meta(ctx, 1, 0, ctx->offsets.p, raw_offsets, (size_t)(n_reads + 1) * sizeof(int64_t), ctx->stream)) ||
         (rc = pxg_h2d_meta(ctx, 1, 1, ctx->calib.p, calib, (size_t)n_reads * sizeof(pxg_calib), ctx->stream)))
         return rc;
@@ -504,8 +507,7 @@ extern "C" int pxg_batch_upload_tiled(pxg_ctx* ctx, int64_t n_reads, int64_t bas
     DevBuf<int16_t> base;                                   // the distinct reads, once over PCIe
     if ((rc = pxg_reserve(ctx, base, (size_t)base_samples + 64))) return rc;
     hipStream_t st = ctx->stream;
-    hipError_t e = hipMemcpyAsync(base.p, base_arena, (size_t)base_samples * sizeof(int16_t),
-                                  hipMemcpyHostToDevice, st);
+    hipError_t e = pxg_h2d_big(ctx, base.p, base_arena, (size_t)base_samples * sizeof(int16_t), st) == PXG_OK ? hipSuccess : hipErrorUnknown;
     // cyclic replication: [phase .. base_n) then whole copies of the base set
     int64_t at = 0, src = base_offsets[phase];
     while (e == hipSuccess && at < n_samples) {
@@ -562,7 +564,7 @@ static int copy_read_prefixes(pxg_ctx* ctx, hipStream_t cs, int16_t* dst, const 
     int64_t run0 = 0;
     auto flush = [&](int64_t end) -> int {
         if (end > run0)
-            PXG_HIP(ctx, hipMemcpyAsync(dst + run0, src + run0, (size_t)(end - run0) * sizeof(int16_t), hipMemcpyHostToDevice, cs));
+            return pxg_h2d_big(ctx, dst + run0, src + run0, (size_t)(end - run0) * sizeof(int16_t), cs);
         return PXG_OK;
     };
     int rc;
@@ -703,11 +705,9 @@ extern "C" int pxg_batch_stage_z_prefix(pxg_ctx* ctx, int64_t n_reads, const uin
         if (z_bytes) ranges.emplace_back(0, z_bytes);
     }
     for (const auto& rg : ranges)
-        PXG_HIP(ctx, hipMemcpyAsync(sp.z.p + rg.first, z + rg.first, (size_t)(rg.second - rg.first), hipMemcpyHostToDevice, cs));
+        if ((rc = pxg_h2d_big(ctx, sp.z.p + rg.first, z + rg.first, (size_t)(rg.second - rg.first), cs))) return rc;
     sp.limit = prefix_limit;
-    if (n_chunks)
-        PXG_HIP(ctx, hipMemcpyAsync(sp.zchunks.p, chunks, (size_t)n_chunks * sizeof(pxg_z_chunk),
-                                    hipMemcpyHostToDevice, cs));
+    if (n_chunks && (rc = pxg_h2d_big(ctx, sp.zchunks.p, chunks, (size_t)n_chunks * sizeof(pxg_z_chunk), cs))) return rc;
     if ((rc = pxg_h2d_meta(ctx, 0, 0, sp.offsets.p, raw_offsets, (size_t)(n_reads + 1) * sizeof(int64_t), cs)) ||
         (rc = pxg_h2d_meta(ctx, 0, 1, sp.calib.p, calib, (size_t)n_reads * sizeof(pxg_calib), cs)))
         return rc;
@@ -939,6 +939,58 @@ int pxg_d2h_sync(pxg_ctx* ctx, void* dst, const void* src, size_t bytes)
     return PXG_OK;
 }
 
+// Host -> device of a big array on stream `st` (returns once `src` may be reused, like a pageable hipMemcpyAsync).
+// A page-locked source (hipHostRegister by the caller, hipHostMalloc) is one asynchronous DMA.  A PAGEABLE source of
+// 1 MB or more is NOT handed to the runtime: ROCm 7.2 page-locks the caller's range in place for such a copy
+// ("Locking to pool ... hostMem = <user address>", hsa_amd_memory_lock) and lets the SDMA engine read the user's
+// pages, and when that range lies in the brk heap and overlaps pages that were hipHostRegister'ed and
+// unregistered earlier in the process, the engine faults inside the just-locked range -- "Memory access fault by
+// GPU ... on address <heap address>. Reason: Unknown.", the whole process gone (caught with the runtime's API /
+// copy log in round 5: profiles/r05/fault_hunt.md; round 4's one unexplained fault has this signature).  So the
+// bytes travel through two page-locked chunks of the context: the GPU never addresses pageable user memory.
+#define PXG_UP_CHUNK (8u << 20)
+int pxg_h2d_big(pxg_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+    if (!bytes) return PXG_OK;
+    // (PXG_H2D_RUNTIME_LOCKS=1: the round-4 behaviour, for tools/heap_pin_fault.py to show what it leads to)
+    if (bytes < (512u << 10) || getenv("PXG_H2D_RUNTIME_LOCKS")) {       // staged by the runtime through ITS page-locked buffer
+        PXG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+        return PXG_OK;
+    }
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, src) == hipSuccess) {
+        if (at.type == hipMemoryTypeHost) {             // page-locked by the caller
+            PXG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+            return PXG_OK;
+        }
+    } else {
+        (void)hipGetLastError();                        // (an unknown pointer is an error state of the runtime: clear it)
+    }
+    std::lock_guard<std::mutex> up_lock(ctx->mt_up);
+    for (int k = 0; k < 2; k++) {
+        if (ctx->h_up[k]) continue;
+        if (hipHostMalloc(&ctx->h_up[k], PXG_UP_CHUNK, hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_up[k], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(ctx, PXG_E_NOMEM, "page-locked upload chunks");
+        }
+        ctx->up_busy[k] = false;
+    }
+    size_t done = 0;
+    int k = 0;
+    while (done < bytes) {
+        const size_t len = std::min<size_t>(PXG_UP_CHUNK, bytes - done);
+        if (ctx->up_busy[k]) PXG_HIP(ctx, hipEventSynchronize(ctx->ev_up[k]));
+        memcpy(ctx->h_up[k], (const char*)src + done, len);
+        PXG_HIP(ctx, hipMemcpyAsync((char*)dst + done, ctx->h_up[k], len, hipMemcpyHostToDevice, st));
+        PXG_HIP(ctx, hipEventRecord(ctx->ev_up[k], st));
+        ctx->up_busy[k] = true;
+        done += len;
+        k ^= 1;
+    }
+    return PXG_OK;
+}
+
 int pxg_h2d_meta(pxg_ctx* ctx, int set, int which, void* dst, const void* src, size_t bytes, hipStream_t st)
 {
     if (!bytes) return PXG_OK;
@@ -1126,8 +1178,8 @@ static int merged_process(pxg_ctx* ctx, pxg_ctx::MergeItem& mine, uint32_t stage
             } else if (it->n_chunks) {
                 // an encoded call: its bytes and chunk records behind the others', decoded with ITS bases into its
                 // stretch of the arena (whole reads: the prefix rule is for calls that come alone)
-                if ((it->z_bytes && hipMemcpyAsync(sp.z.p + z0, it->z, (size_t)it->z_bytes, hipMemcpyHostToDevice, cs) != hipSuccess) ||
-                    hipMemcpyAsync(sp.zchunks.p + c0, it->chunks, (size_t)it->n_chunks * sizeof(pxg_z_chunk), hipMemcpyHostToDevice, cs) != hipSuccess) {
+                if ((it->z_bytes && pxg_h2d_big(ctx, sp.z.p + z0, it->z, (size_t)it->z_bytes, cs) != PXG_OK) ||
+                    pxg_h2d_big(ctx, sp.zchunks.p + c0, it->chunks, (size_t)it->n_chunks * sizeof(pxg_z_chunk), cs) != PXG_OK) {
                     rc = fail(ctx, PXG_E_HIP, "merged stage: copy of encoded samples");
                     break;
                 }
@@ -1275,6 +1327,7 @@ extern "C" int pxg_process_batch_ex(pxg_ctx* ctx, int64_t n_reads, const int16_t
 // stage hooks: host arrays in, host arrays out, through the same kernels
 // ---------------------------------------------------------------------------
 struct Scratch {               // RAII device temporaries for the hooks
+    pxg_ctx* ctx = nullptr;
     std::vector<void*> ptrs;
     ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
     template <typename T>
@@ -1289,7 +1342,8 @@ struct Scratch {               // RAII device temporaries for the hooks
     T* put(const T* src, size_t n, hipStream_t s)
     {
         T* d = alloc<T>(n);
-        if (d && n) (void)hipMemcpyAsync(d, src, n * sizeof(T), hipMemcpyHostToDevice, s);
+        // (a big pageable array of the caller never reaches the runtime: pxg_h2d_big; a failed copy reads as a failed allocation)
+        if (d && n && pxg_h2d_big(ctx, d, src, n * sizeof(T), s) != PXG_OK) return nullptr;
         return d;
     }
 };
@@ -1342,7 +1396,8 @@ struct ScanStreamScope {
 #define HOOK_BEGIN                                           \
     if (!ctx) return PXG_E_INVALID;                          \
     PXG_HIP(ctx, hipSetDevice(ctx->device));                 \
-    Scratch S;
+    Scratch S;                                               \
+    S.ctx = ctx;
 #define HOOK_CHECK(p) if (!(p)) return fail(ctx, PXG_E_NOMEM, "hook scratch allocation failed")
 #define HOOK_GET(dst, src, n)                                                                         \
     do {                                                                                              \

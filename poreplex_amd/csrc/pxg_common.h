@@ -386,6 +386,11 @@ struct pxg_ctx {
     void* h_bounce = nullptr;
     size_t h_bounce_bytes = 0;
     std::mutex mt_bounce;        // the stage hooks take no other lock: two threads may download at once
+    // two page-locked chunks every big PAGEABLE host -> device copy goes through (pxg_h2d_big)
+    void* h_up[2] = { nullptr, nullptr };
+    hipEvent_t ev_up[2] = { nullptr, nullptr };
+    bool up_busy[2] = { false, false };
+    std::mutex mt_up;
     // ... and the small host arrays of a batch (offsets, calibration, injected scaling, chunk-record-free metadata)
     // are copied into page-locked mirrors first and sent from there: [0] the staging calls (one stage at a time:
     // mt_stage / the caller's own order), [1] pxg_batch_upload.
@@ -501,6 +506,7 @@ int pxg_launch_scaler_lstm_q8(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, 
 int pxg_q8_scaler_trajectory(pxg_ctx* ctx);   // zero-input states of the scaler network (prefix skip), once per context
 int pxg_launch_demux_lstm_q8(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, const int32_t* count,
                              const float* win, float* bidir, float* probs, int timer_a, int timer_b);
+int pxg_h2d_big(pxg_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st);
 int pxg_polya_supported(pxg_ctx* ctx);
 int pxg_launch_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t* off,
                      const pxg_calib* cal, const float* ss, const int32_t* status,

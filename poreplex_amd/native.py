@@ -555,24 +555,26 @@ def _ptr(a):
 
 
 def page_exclusive(n, dtype, fill=None):
-    """An array of n items that shares no memory page with any other allocation (whole pages of an over-sized
-    buffer): what a caller should hand to NativeContext.pin() when the array is small enough to come from the
-    malloc heap -- hipHostRegister works on pages, and a page-locked page that ALSO holds the start of somebody
-    else's array makes the runtime treat that array as page-locked too."""
+    """An array of n items on pages of its own, from an ANONYMOUS MAPPING -- what a caller hands to
+    NativeContext.pin().  Never from the malloc heap: hipHostRegister works on pages (a page-locked page that also holds
+    somebody else's array makes the runtime treat that array as page-locked too), and a brk-heap range that was
+    registered and unregistered once must not be page-locked again -- ROCm 7.2 locks a big pageable source of a copy
+    in place, and when that lock lands on such pages the DMA engine faults inside the range (profiles/r05/fault_hunt.md).
+    A mapping goes back to the kernel with the array; the heap's pages stay what they are."""
+    import mmap
     dtype = np.dtype(dtype)
     nbytes = int(n) * dtype.itemsize
-    page = 4096
-    raw = np.empty(nbytes + 2 * page, dtype=np.uint8)
-    start = (-raw.ctypes.data) % page
-    out = raw[start:start + nbytes].view(dtype)
+    m = mmap.mmap(-1, max(nbytes, 1), flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)      # (page-aligned, whole pages)
+    out = np.frombuffer(m, dtype=np.uint8)[:nbytes].view(dtype)
     if fill is not None:
         out[...] = fill
-    return out          # (out.base keeps `raw` alive)
+    return out          # (the .base chain keeps the mapping alive)
 
 
 def pinnable(array):
-    """`array` itself when it is large enough to have its own pages (glibc maps allocations above 32 MB on their
-    own), otherwise a page_exclusive() copy of it: what to page-lock instead of a small heap array."""
+    """`array` itself when it is large enough to have been mapped on its own (glibc maps allocations above 32 MB
+    whatever its dynamic threshold says), otherwise a page_exclusive() copy of it: what to page-lock instead of an
+    array that may live in the malloc heap."""
     if array.nbytes >= (64 << 20) or array.nbytes == 0:
         return array
     out = page_exclusive(array.size, array.dtype).reshape(array.shape)
