@@ -219,3 +219,32 @@ def test_process_batch_ex_from_threads_equals_the_split_calls(ctx, oracle):
                                   N.STAGE_SEGMENT | N.STAGE_POLYA, want_spikes=True)
     assert_spikes_equal(got['spikes'], w, wsp)
     assert len(got['spikes'][0]) > 2 * 6 + 1024
+
+
+def test_big_pageable_uploads_go_through_the_contexts_own_chunks(ctx):
+    """pxg_h2d_big (profiles/r05/fault_hunt.md): a pageable sample arena of 512 KB or more never reaches the runtime's
+    in-place page lock -- it travels through two 8 MB page-locked chunks of the context.  Arenas just below, at and
+    above one and two chunks, from pageable memory, from a page-locked mapping and (round 4's form) handed to the
+    runtime as they are: the same records."""
+    base = SY.synth_batch(200, seed=31, samples_per_read=44000, jitter=0.05)
+    lens = np.diff(base['offsets'])
+    for total in ((8 << 20) // 2 - 3, (8 << 20) // 2, (8 << 20) // 2 + 1, (16 << 20) // 2 + 5):
+        # whole reads up to `total` samples, the last one cut so that the arena has exactly that many
+        k = int(np.searchsorted(np.cumsum(lens), total)) + 1
+        off = np.concatenate([[0], np.cumsum(lens[:k])]).astype(np.int64)
+        off[-1] = total                                           # (a short last read is just a short read)
+        assert off[-1] > off[-2] and len(base['arena']) > total
+        arena = np.array(base['arena'][:total])                   # pageable
+        cal = base['calib'][:k]
+        got = ctx.process_batch(arena, off, cal)
+        locked = N.page_exclusive(total, np.int16)
+        locked[:] = arena
+        ctx.pin(locked)
+        try:
+            assert ctx.process_batch(locked, off, cal).tobytes() == got.tobytes(), total
+        finally:
+            ctx.unpin(locked)
+        ctx.upload(arena, off, cal)
+        ctx.run(N.STAGE_ALL_DEMUX)
+        assert ctx.download().tobytes() == got.tobytes(), total
+    assert (got['status'] == 0).sum() > 80
