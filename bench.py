@@ -516,19 +516,19 @@ def fast5_ingest_leg(args, base, which, n_reads=2048):
 def end_to_end_legs(args):
     """The session driver from files, as part of the DEFAULT line (so that the driver's own run
     carries it): `bench.py --end-to-end` in a child process, once from an encoded read bundle and once
-    from uncompressed multi-read FAST5 (12 batches each: fill and drain included -- the first two batches of a
+    from uncompressed multi-read FAST5 (12 and 20 batches: fill and drain included -- the first two batches of a
     session load into staging arenas nobody has touched yet, the last one drains alone; `loader_ms_per_batch` is
     the median of the loader thread's time per batch from the third batch on; longer runs are in profiles/).
     Errors are reported, never hidden."""
     import subprocess
     out = {'batch_reads': 10000}
     for name, reads, flags in (('encoded_bundle', 120000, ['--compressed-bundle']),
-                               ('fast5_uncompressed', 120000, ['--from-fast5', 'none'])):
+                               ('fast5_uncompressed', 200000, ['--from-fast5', 'none'])):
         cmd = [sys.executable, os.path.abspath(__file__), '--end-to-end', '--reads', str(reads), '--batch-reads', '10000',
                '--samples', str(args.samples), '--seed', str(args.seed), '--cpu-sample', '0', '--cpu-all-cores-sample', '0'] + flags
         env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
         try:
-            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
             line = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
             timing = line['extra']['session_timing_rank0']
             steady = sorted(timing.get('load_ms', [])[2:])
