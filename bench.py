@@ -56,7 +56,7 @@ PEAK_HBM = 8.0e12              # B/s
 # the only throughput the reference publishes (Poreplex 0.1, whole
 # pipeline incl. FAST5 I/O, 2x Xeon E5-2687W v3 = 20 cores): 1 339 070 reads in 1 h 37 min
 PUBLISHED_READS_PER_S = 1339070 / (97 * 60.0)
-TRAFFIC_FILE = os.path.join('profiles', 'r05', 'h_hbm_traffic.json')
+TRAFFIC_FILE = os.path.join('profiles', 'r05', 'k_hbm_traffic.json')
 # PXG_BENCH_SHARE_GPU=1: every rank of a torchrun launch uses GPU 0 and the collectives go over gloo --
 # the real multi-process path (sharding, barriers, max over ranks, label gather, NUMA binding, the
 # host-side legs on all ranks at once) with the real kernels on a ONE-GPU box.  A plumbing check:
@@ -670,8 +670,8 @@ def strong_leg(args, ctx, dist, rank, world, mask, standin, force_dist, barrier)
 FLIPS_FILE = os.path.join('profiles', 'r04', 'decision_flips.json')
 FLIPS_GPU_FILE = os.path.join('profiles', 'r05', 'decision_flips_gpu_160k_reads.json')
 BOUNDS_FILE = os.path.join('profiles', 'r05', 'full_kernel_bounds.json')
-ROCPROF_STATS = {'demux': os.path.join('profiles', 'r05', 'h_demux_kernel_stats.csv'),
-                 'full': os.path.join('profiles', 'r05', 'h_full_kernel_stats.csv')}
+ROCPROF_STATS = {'demux': os.path.join('profiles', 'r05', 'k_demux_kernel_stats.csv'),
+                 'full': os.path.join('profiles', 'r05', 'k_full_kernel_stats.csv')}
 
 
 def unpinned_rows_block():
