@@ -628,9 +628,6 @@ int64_t pxg_h5_events(const pxg_h5* file, int64_t i, int64_t cap_rows, int32_t* 
 int pxg_h5_load_signals(int64_t n, const pxg_h5* const* files, const int64_t* index,
                         const int64_t* dst_start, const int64_t* n_samples, int16_t* arena,
                         int32_t threads, int32_t* status);
-/* First touch of a freshly allocated host arena on `threads` host threads (a zero byte per 4 KB page): what a
- * caller does to a staging arena before it page-locks it and lets the loader fill it. */
-int pxg_host_touch(void* p, int64_t bytes, int32_t threads);
 /* sequences, quality strings and move tables of many reads into columnar arenas (lengths from
  * pxg_h5_info: bc_seq_len, bc_n_moves) */
 int pxg_h5_basecall_many(int64_t n, const pxg_h5* const* files, const int64_t* index,

@@ -1519,22 +1519,6 @@ static void run_pool(int64_t n, int threads, Fn fn, int64_t grain)
 // The int16 samples of many reads (any mix of open files), decoded on `threads` host threads
 // straight into `arena` (the caller's staging buffer): read k = (files[k], index[k]) goes to
 // arena[dst_start[k] .. dst_start[k] + n_samples[k]).  status[k] = 0 or that read's own error code.
-// First touch of a fresh staging arena on the reader's threads: one byte written per 4 KB page, 2 MB of pages per
-// queue access.  The session does this (and the page lock) BEFORE its loader starts: 330 000 first touches taken
-// inside the first two batches' copies -- beside the file mappings' own faults and the page lock of the other arena --
-// cost 40-55 ms per arena on a 16-core host, here 6-9 (tools/measure_round.sh: e2e_fast5_per_batch.txt).
-extern "C" int pxg_host_touch(void* p, int64_t bytes, int32_t threads)
-{
-    if (bytes < 0 || (bytes && !p)) return PXG_E_INVALID;
-    const int64_t piece = 2 << 20, n = (bytes + piece - 1) / piece;
-    volatile uint8_t* b = (volatile uint8_t*)p;
-    run_pool(n, threads, [&](int64_t k) {
-        const int64_t end = std::min(bytes, (k + 1) * piece);
-        for (int64_t at = k * piece; at < end; at += 4096) b[at] = 0;
-    });
-    return PXG_OK;
-}
-
 extern "C" int pxg_h5_load_signals(int64_t n, const pxg_h5* const* files, const int64_t* index,
                                    const int64_t* dst_start, const int64_t* n_samples, int16_t* arena,
                                    int32_t threads, int32_t* status)

@@ -380,7 +380,6 @@ _TEXT_SIGNATURES = {      # libpxghost.so: host-only helpers (sink text, sample 
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     'pxg_h5_load_signals': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int32, C.c_void_p]),
-    'pxg_host_touch': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32]),
     'pxg_h5_basecall_many': (C.c_int, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
 }
@@ -570,14 +569,6 @@ def page_exclusive(n, dtype, fill=None):
     if fill is not None:
         out[...] = fill
     return out          # (the .base chain keeps the mapping alive)
-
-
-def touch_pages(array, threads=None):
-    """First touch of a fresh array (page_exclusive) on the FAST5 reader's host threads."""
-    if array.nbytes:
-        from .fast5_file import host_threads
-        load_text_library().pxg_host_touch(array.ctypes.data, array.nbytes, threads or host_threads())
-    return array
 
 
 def pinnable(array):

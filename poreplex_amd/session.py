@@ -78,12 +78,6 @@ class _Staging:
             self.buf, self.pinned = native.page_exclusive(int(n_samples * 1.1) + 4096, np.int16), False
         return self.buf
 
-    def warm(self, n_samples):
-        """Allocate for n_samples, touch the pages on the reader's threads and page-lock them (session thread,
-        before the loader starts)."""
-        native.touch_pages(self.reserve(n_samples))
-        self.settle()
-
     def settle(self):
         for old in self.retired:
             self.ctx.unpin(old)
@@ -125,7 +119,7 @@ class GpuSession:
                        'load_phases_ms': [],
                        # the run outside the batch loop: before the loader starts, the loop itself, releasing the
                        # staging arenas / closing the sinks, the final collectives + stitching
-                       'setup_s': 0.0, 'warm_s': 0.0, 'loop_s': 0.0, 'teardown_s': 0.0, 'finish_s': 0.0}               # per batch: FAST5 walk, signals, text (all threads' calls), wait for the prefetch, prepare
+                       'setup_s': 0.0, 'loop_s': 0.0, 'teardown_s': 0.0, 'finish_s': 0.0}               # per batch: FAST5 walk, signals, text (all threads' calls), wait for the prefetch, prepare
 
     # ---- loader thread: batch k+1 is opened and packed while batch k computes ---------
     def _produce(self, batches, slots, out, stop):
@@ -271,15 +265,6 @@ class GpuSession:
             self.loader.pin_bundle()      # batches of consecutive bundle reads are staged in place
             for s_ in stagings:
                 slots.put(s_)
-            # FAST5 input: both arenas allocated for the first batch's size, touched and page-locked up front -- inside
-            # the first two batches' copies that costs 40-55 ms per arena, here ~10
-            if batches and not any(len(s_.buf) for s_ in stagings) and hasattr(self.loader, 'peek_samples'):
-                t0 = time.perf_counter()
-                first = self.loader.peek_samples(batches[0])
-                if first:
-                    for s_ in stagings:
-                        s_.warm(first)
-                self.timing['warm_s'] = time.perf_counter() - t0
             # every rank takes part in the same number of rounds (one abort agreement per round)
             n_rounds = D.agree_max(len(batches), self.dist)
             thread = threading.Thread(target=self._produce, args=(batches, slots, ready, stop), daemon=True)

@@ -556,18 +556,6 @@ class SignalLoader:
             except Exception:             # noqa: BLE001
                 pass
 
-    def peek_samples(self, reads):
-        """Total samples of a batch that will come out of FAST5 files in file order (its files are opened and their
-        metadata read: the work prefetch_files does anyway), or None -- bundle reads (staged in place), a request
-        prepare_fast5 will take read by read."""
-        if not reads or (self.bundle is not None and self.bundle.has_file(reads[0][0])):
-            return None
-        self.prefetch_files(reads)
-        runs = self.fast5_runs(reads)
-        if runs is None:
-            return None
-        return int(sum(int(f.info['n_samples'][first:first + count].sum()) for f, _, first, count in runs))
-
     def prepare_fast5(self, reads, where, table, reserve=None):
         """The FAST5 half of prepare_many.  Only when the table holds no bundle rows yet (a
         table has one column source)."""

@@ -69,9 +69,6 @@ def test_page_exclusive_arrays_own_their_pages():
             base = base.base
         assert isinstance(getattr(base, 'obj', base), mmap.mmap), type(base)
         a.view(np.uint8)[...] = 1                     # writable
-    big = N.page_exclusive(3 * (2 << 20) // 2 + 77, np.int16)          # first touch on the reader's threads: zeros, all pages
-    assert N.touch_pages(big, threads=4) is big and not big.any()
-    assert N.touch_pages(N.page_exclusive(0, np.int16)).size == 0
     small = np.arange(1000, dtype=np.int16)
     p = N.pinnable(small)
     assert p is not small and np.array_equal(p, small) and p.ctypes.data % 4096 == 0
