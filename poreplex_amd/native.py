@@ -565,6 +565,11 @@ def page_exclusive(n, dtype, fill=None):
     dtype = np.dtype(dtype)
     nbytes = int(n) * dtype.itemsize
     m = mmap.mmap(-1, max(nbytes, 1), flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)      # (page-aligned, whole pages)
+    if nbytes >= (8 << 20) and hasattr(mmap, 'MADV_HUGEPAGE') and not os.environ.get('PXG_NO_HUGE_PAGES'):
+        try:                    # a staging arena: 650 first touches of 2 MB instead of 330 000 of 4 KB
+            m.madvise(mmap.MADV_HUGEPAGE)
+        except OSError:
+            pass
     out = np.frombuffer(m, dtype=np.uint8)[:nbytes].view(dtype)
     if fill is not None:
         out[...] = fill
