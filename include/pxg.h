@@ -358,6 +358,11 @@ int pxg_batch_upload_tiled(pxg_ctx* ctx, int64_t n_reads, int64_t base_n, int64_
                            const int16_t* base_arena, const int64_t* base_offsets,
                            const pxg_calib* base_calib, const float* base_scale_shift_or_null);
 int pxg_batch_swap(pxg_ctx* ctx);
+/* Page-lock / release a host array for DMA transfers.  Optional: a host -> device copy of 512 KB or more from an
+ * array that is NOT page-locked travels through page-locked chunks of the context (the GPU never addresses pageable
+ * memory of the caller; the runtime's own in-place lock of such a source is what took the process down in round 4:
+ * INTEGRATION.md section 2).  Register MAPPED pages of their own (mmap), never a slice of a malloc'ed block: a
+ * brk-heap range that was page-locked once must not be page-locked again later in the process. */
 int pxg_host_register(pxg_ctx* ctx, void* ptr, size_t bytes);
 int pxg_host_unregister(pxg_ctx* ctx, void* ptr);
 int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask);
