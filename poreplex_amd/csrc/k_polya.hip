@@ -123,28 +123,35 @@ __device__ __forceinline__ float filtered_at(const WindowSrc& S, int64_t j, int 
 #define PA_WAVES_PER_EU 3        // 4 reads per wave: 10 000 reads = 2500 waves must be co-resident
 #endif
 #define PA_GL (64 / PXG_PA_LANES) // lanes per read
+#ifndef PA_EVC
 #define PA_EVC 16                // event rows in the LDS chunk cache
+#endif
 #define PA_XS 64                 // scaled-sample ring (needs filled-3 .. filled+2*PA_GL+3)
 #define PA_OVER_HEAD 4            // words in front of the read ids of the overflow list (polya_over)
 #define PA_PRE 128               // prefix-sum ring (needs i-31 .. i+31+16 around a 16-sample chunk)
 struct GroupLds {
-    double2 pre[PA_PRE];         // pre[k & 127] = (sum, sum of squares) of filtered samples [0, k)
-    float fbuf[PA_GL];           // filtered samples of the chunk being accumulated
-    float tb[2][PA_GL];          // t-statistics of the chunk being scanned
-    Ev evc[PA_EVC];              // consecutive event rows (chunk cache of the event passes)
-    float xs[PA_XS];             // scaled samples ring: xs[k & 63] = sample k of the window
-    union {                      // never live at the same time (4 KB per read keeps 10 waves per CU)
-        struct {                 // detector: event boundaries found in the chunk being scanned
-            double2 bsum[2 * PA_GL + 1];     // prefix sums ...
+    float fbuf[PA_GL];           // filtered samples of the chunk being accumulated (detector) / summed (reductions)
+    // The detector's rings and what runs behind the detector are never live at the same time (detect_events_group
+    // leaves nothing in LDS that polya_one_read reads afterwards: the event rows are in HBM, its resume point in
+    // registers and HBM; ev_at's chunk cache is dropped after every detector call).  3 168 bytes per read instead of
+    // 3 648: twelve 4-read waves per CU instead of ten, 3 072 blocks per launch round instead of 2 560.
+    union {
+        struct {                 // ---- detect_events_group
+            double2 pre[PA_PRE];             // pre[k & 127] = (sum, sum of squares) of filtered samples [0, k)
+            float tb[2][PA_GL];              // t-statistics of the chunk being scanned
+            float xs[PA_XS];                 // scaled samples ring: xs[k & 63] = sample k of the window
+            double2 bsum[2 * PA_GL + 1];     // event boundaries found in the chunk being scanned: prefix sums ...
             unsigned bpos[2 * PA_GL + 1];    // ... and positions; [0] = the last one before the chunk
         };
-        struct {                 // reductions: one leaf block of a NumPy pairwise sum + its
-            float vb[128];       // recursion stack (depth <= log2(n / 64))
-            int sk_base[24], sk_n[24], sk_st[24];
+        struct {                 // ---- everything behind it
+            Ev evc[PA_EVC];                  // consecutive event rows (chunk cache of the event passes)
+            float vb[128];                   // reductions: one leaf block of a NumPy pairwise sum + its
+            int sk_base[24], sk_n[24], sk_st[24];    // recursion stack (depth <= log2(n / 64))
             float sk_acc[24];
         };
     };
 };
+static_assert(sizeof(GroupLds) <= 3200, "GroupLds grew: 12 waves per CU need <= 3 328 bytes per read");
 
 // Resume point of the detector for open-end retries (polya.py:81-85: same window
 // start, longer window): the group-uniform registers at the start of the last
