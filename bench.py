@@ -572,13 +572,16 @@ def pcie_legs(ctx, base, inject, step, n_local, args, kernel_rate):
     fail to scale (host DRAM, NUMA, PCIe roots) while the kernels scale trivially."""
     out = {}
     nbytes_in = base['arena'].nbytes
-    ctx.pin(base['arena'])
+    # what gets page-locked is an array on mapped pages of its own (native.pinnable: a copy when the array may live in
+    # the malloc heap -- profiles/r05/fault_hunt.md)
+    arena = N.pinnable(base['arena'])
+    ctx.pin(arena)
     n_over = min(args.steps, 5)
     ctx.sync()
     o0 = time.perf_counter()
     for _ in range(n_over):
         step()
-        ctx.stage(base['arena'], base['offsets'], base['calib'], inject)
+        ctx.stage(arena, base['offsets'], base['calib'], inject)
         ctx.download()
         ctx.swap()
     ctx.sync()
@@ -586,14 +589,16 @@ def pcie_legs(ctx, base, inject, step, n_local, args, kernel_rate):
     out['pcie_overlapped_reads_per_s'] = n_local / o_s
     h0 = time.perf_counter()
     for _ in range(2):
-        ctx.stage(base['arena'], base['offsets'], base['calib'], inject)
+        ctx.stage(arena, base['offsets'], base['calib'], inject)
         ctx.swap()                      # waits for the staged copies
     h_s = (time.perf_counter() - h0) / 2
     out['h2d_GBps'] = nbytes_in / h_s / 1e9
     out['pcie_bound_reads_per_s'] = n_local / h_s
     out['pcie_overlap_efficiency'] = (n_local / o_s) / min(n_local / h_s, kernel_rate)
-    ctx.unpin(base['arena'])
+    ctx.unpin(arena)
+    del arena
     z, chunks, _ = N.z_encode(base['arena'], base['offsets'])        # offline step, not timed
+    z, chunks = N.pinnable(z), N.pinnable(chunks)
     enc = N.EncodedSamples(z, chunks, 0, 0, len(base['arena']))
     ctx.pin(z)
     ctx.pin(chunks)

@@ -651,6 +651,7 @@ def test_staged_double_buffered_batches(ctx, oracle):
     batches = [synth_batch(n, seed=600 + n, samples_per_read=9000, jitter=0.3)
                for n in (96, 33, 150, 1, 64)]
     want = [oracle.process_batch(b['arena'], b['offsets'], b['calib']) for b in batches]
+    batches[2]['arena'] = N.pinnable(batches[2]['arena'])       # (mapped pages of its own: never page-lock heap memory)
     pinned = ctx.pin(batches[2]['arena'])           # one of them page-locked
     try:
         ctx.upload(batches[0]['arena'], batches[0]['offsets'], batches[0]['calib'])
