@@ -3,6 +3,8 @@
 #include <math.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
@@ -316,7 +318,7 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     if (ctx->d_sigtab) (void)hipFree(ctx->d_sigtab);
     if (ctx->d_lsetab) (void)hipFree(ctx->d_lsetab);
     if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < 16; k++) {
         if (ctx->ev_up[k]) { (void)hipEventSynchronize(ctx->ev_up[k]); (void)hipEventDestroy(ctx->ev_up[k]); }
         if (ctx->h_up[k]) (void)hipHostFree(ctx->h_up[k]);
     }
@@ -948,7 +950,11 @@ int pxg_d2h_sync(pxg_ctx* ctx, void* dst, const void* src, size_t bytes)
 // GPU ... on address <heap address>. Reason: Unknown.", the whole process gone (caught with the runtime's API /
 // copy log in round 5: profiles/r05/fault_hunt.md; round 4's one unexplained fault has this signature).  So the
 // bytes travel through two page-locked chunks of the context: the GPU never addresses pageable user memory.
+#ifndef PXG_UP_CHUNK
 #define PXG_UP_CHUNK (8u << 20)
+#endif
+#define PXG_UP_THREADS 2
+#define PXG_UP_MAX_THREADS 8
 int pxg_h2d_big(pxg_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st)
 {
     if (!bytes) return PXG_OK;
@@ -967,7 +973,11 @@ int pxg_h2d_big(pxg_ctx* ctx, void* dst, const void* src, size_t bytes, hipStrea
         (void)hipGetLastError();                        // (an unknown pointer is an error state of the runtime: clear it)
     }
     std::lock_guard<std::mutex> up_lock(ctx->mt_up);
-    for (int k = 0; k < 2; k++) {
+    // a big array (a whole batch's samples) is cut into PXG_UP_THREADS stretches, each filled by a host thread of
+    // its own through its own pair of chunks: one thread's memcpy runs at ~13 GB/s, the link takes 57
+    static const int want_threads = [] { const char* e = getenv("PXG_UP_THREADS"); const int v = e ? atoi(e) : PXG_UP_THREADS; return v < 1 ? 1 : (v > PXG_UP_MAX_THREADS ? PXG_UP_MAX_THREADS : v); }();
+    const int nt = bytes >= (64u << 20) ? want_threads : 1;
+    for (int k = 0; k < 2 * nt; k++) {
         if (ctx->h_up[k]) continue;
         if (hipHostMalloc(&ctx->h_up[k], PXG_UP_CHUNK, hipHostMallocDefault) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_up[k], hipEventDisableTiming) != hipSuccess) {
@@ -976,17 +986,39 @@ int pxg_h2d_big(pxg_ctx* ctx, void* dst, const void* src, size_t bytes, hipStrea
         }
         ctx->up_busy[k] = false;
     }
-    size_t done = 0;
-    int k = 0;
-    while (done < bytes) {
-        const size_t len = std::min<size_t>(PXG_UP_CHUNK, bytes - done);
-        if (ctx->up_busy[k]) PXG_HIP(ctx, hipEventSynchronize(ctx->ev_up[k]));
-        memcpy(ctx->h_up[k], (const char*)src + done, len);
-        PXG_HIP(ctx, hipMemcpyAsync((char*)dst + done, ctx->h_up[k], len, hipMemcpyHostToDevice, st));
-        PXG_HIP(ctx, hipEventRecord(ctx->ev_up[k], st));
-        ctx->up_busy[k] = true;
-        done += len;
-        k ^= 1;
+    std::atomic<int> failed{ 0 };
+    auto stretch = [&](int t) {
+        (void)hipSetDevice(ctx->device);
+        const size_t part = ((bytes + nt - 1) / nt + 4095) & ~(size_t)4095;
+        const size_t lo = std::min(bytes, part * (size_t)t), hi = std::min(bytes, lo + part);
+        size_t done = lo;
+        int k = 2 * t;
+        while (done < hi && !failed.load()) {
+            const size_t len = std::min<size_t>(PXG_UP_CHUNK, hi - done);
+            if (ctx->up_busy[k] && hipEventSynchronize(ctx->ev_up[k]) != hipSuccess) { failed.store(1); break; }
+            memcpy(ctx->h_up[k], (const char*)src + done, len);
+            if (hipMemcpyAsync((char*)dst + done, ctx->h_up[k], len, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipEventRecord(ctx->ev_up[k], st) != hipSuccess) { failed.store(1); break; }
+            ctx->up_busy[k] = true;
+            done += len;
+            k = 2 * t + ((k + 1) & 1);
+        }
+    };
+    if (nt == 1) {
+        stretch(0);
+    } else {
+        std::vector<std::thread> workers;
+        try {
+            for (int t = 1; t < nt; t++) workers.emplace_back(stretch, t);
+        } catch (const std::exception&) {
+            failed.store(2);                           // (no thread to be had: the stretches nobody took are not copied)
+        }
+        stretch(0);
+        for (auto& w : workers) w.join();
+    }
+    if (failed.load()) {
+        (void)hipGetLastError();
+        return fail(ctx, PXG_E_HIP, "chunked host -> device copy");
     }
     return PXG_OK;
 }

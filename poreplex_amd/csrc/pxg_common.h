@@ -386,10 +386,10 @@ struct pxg_ctx {
     void* h_bounce = nullptr;
     size_t h_bounce_bytes = 0;
     std::mutex mt_bounce;        // the stage hooks take no other lock: two threads may download at once
-    // two page-locked chunks every big PAGEABLE host -> device copy goes through (pxg_h2d_big)
-    void* h_up[2] = { nullptr, nullptr };
-    hipEvent_t ev_up[2] = { nullptr, nullptr };
-    bool up_busy[2] = { false, false };
+    // page-locked chunks every big PAGEABLE host -> device copy goes through (pxg_h2d_big: a pair per copying thread)
+    void* h_up[16] = {};
+    hipEvent_t ev_up[16] = {};
+    bool up_busy[16] = {};
     std::mutex mt_up;
     // ... and the small host arrays of a batch (offsets, calibration, injected scaling, chunk-record-free metadata)
     // are copied into page-locked mirrors first and sent from there: [0] the staging calls (one stage at a time:

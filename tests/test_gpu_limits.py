@@ -248,3 +248,16 @@ def test_big_pageable_uploads_go_through_the_contexts_own_chunks(ctx):
         ctx.run(N.STAGE_ALL_DEMUX)
         assert ctx.download().tobytes() == got.tobytes(), total
     assert (got['status'] == 0).sum() > 80
+    # 64 MB and more: four host threads, each through its own pair of chunks
+    reps = 5
+    arena = np.tile(base['arena'], reps)[:len(base['arena']) * reps - 3]
+    off = np.concatenate([[0]] + [base['offsets'][1:] + k * len(base['arena']) for k in range(reps)]).astype(np.int64)
+    off[-1] = len(arena)
+    cal = np.tile(base['calib'], reps)
+    assert arena.nbytes > (64 << 20) + (8 << 20)
+    got = ctx.process_batch(arena, off, cal)
+    n0 = len(base['offsets']) - 1
+    first = ctx.process_batch(np.array(base['arena']), base['offsets'], base['calib'])
+    for k in range(reps - 1):                       # every copy of the base reads: the records of the base reads
+        assert got[k * n0:(k + 1) * n0].tobytes() == first.tobytes(), k
+    assert got[(reps - 1) * n0:-1].tobytes() == first[:-1].tobytes()
