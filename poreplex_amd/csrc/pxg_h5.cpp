@@ -1222,6 +1222,16 @@ static void basecall_of(const pxg_h5* h, const pxg_h5_read& r, pxg_h5_read_info&
     }
 }
 
+// Metadata text that ends up in ASCII columns downstream (read id, channel number, run id): printable ASCII or the
+// read is an error of its own -- a flipped byte must not surface as a decoding exception of a whole batch
+// (tools/h5_fuzz.py found that one in round 5).  sample_id is free text: any bytes, decoded leniently by the caller.
+static const std::string& ascii_text(const std::string& s, const char* what)
+{
+    for (unsigned char c : s)
+        if (c < 32 || c > 126) fail(PXG_E_INVALID, std::string("FAST5: ") + what + " holds bytes that are not printable ASCII");
+    return s;
+}
+
 static void info_of(const pxg_h5* h, const pxg_h5_read& r, pxg_h5_read_info& o)
 {
     memset(&o, 0, sizeof(o));
@@ -1230,15 +1240,15 @@ static void info_of(const pxg_h5* h, const pxg_h5_read& r, pxg_h5_read_info& o)
     const Object raw = h->object(r.raw_obj);
     o.duration = h->attr_int(h->need(raw, "duration"));
     o.start_time = h->attr_int(h->need(raw, "start_time"));
-    put(o.read_id, sizeof(o.read_id), h->attr_string(h->need(raw, "read_id")));
+    put(o.read_id, sizeof(o.read_id), ascii_text(h->attr_string(h->need(raw, "read_id")), "read_id"));
     const Object ch = h->object(r.channel_obj);
-    put(o.channel_number, sizeof(o.channel_number), h->attr_string(h->need(ch, "channel_number")));
+    put(o.channel_number, sizeof(o.channel_number), ascii_text(h->attr_string(h->need(ch, "channel_number")), "channel_number"));
     o.calib.digitisation = h->attr_double(h->need(ch, "digitisation"));
     o.calib.offset = h->attr_double(h->need(ch, "offset"));
     o.calib.range = h->attr_double(h->need(ch, "range"));
     o.calib.sampling_rate = h->attr_double(h->need(ch, "sampling_rate"));
     const Object tr = h->object(r.tracking_obj);
-    put(o.run_id, sizeof(o.run_id), h->attr_string(h->need(tr, "run_id")));
+    put(o.run_id, sizeof(o.run_id), ascii_text(h->attr_string(h->need(tr, "run_id")), "run_id"));
     put(o.sample_id, sizeof(o.sample_id), h->attr_string(h->need(tr, "sample_id")));
     const Object sig = h->object(r.signal_obj);
     if (!sig.has_dataset || sig.ds.type.cls != 0 || sig.ds.type.size != 2)

@@ -355,7 +355,7 @@ class Fast5File:
             buf = C.create_string_buffer(max(need, 1))
             if self.lib.pxg_h5_read_ids(self.handle, buf, need) != need:
                 raise Fast5Error('pxg_h5_read_ids failed')
-            ids = buf.raw[:need].decode().split('\n')[:-1] if need else []
+            ids = buf.raw[:need].decode(errors='replace').split('\n')[:-1] if need else []
             self._ids = ids
             self._index = {r: i for i, r in enumerate(ids)}
         return self._ids
@@ -542,13 +542,13 @@ def _text_column(col, encoding):
     """Fixed-width bytes column -> str column (a run's run id / sample id columns hold one
     value: decoded once)."""
     if len(col) and (col == col[0]).all():
-        return np.full(len(col), col[0].decode(encoding))
+        return np.full(len(col), col[0].decode(encoding, errors='replace'))
     if encoding == 'ascii':
         try:
             return col.astype('U{}'.format(max(col.dtype.itemsize, 1)))      # (raises on a byte above 127)
         except UnicodeDecodeError:
             pass
-    return np.asarray([b.decode(encoding) for b in col.tolist()])
+    return np.asarray([b.decode(encoding, errors='replace') for b in col.tolist()])
 
 
 class Fast5Batch:
@@ -696,7 +696,7 @@ class Fast5Reader:
         cal = info['calib']
         self.digitization, self.offset = float(cal['digitisation']), float(cal['offset'])
         self.range, self.sampling_rate = float(cal['range']), float(cal['sampling_rate'])
-        self.run_id, self.sample_id = info['run_id'].decode(), info['sample_id'].decode()
+        self.run_id, self.sample_id = info['run_id'].decode(), info['sample_id'].decode(errors='replace')
 
     def close(self):
         self.file = None

@@ -496,6 +496,24 @@ def test_corrupt_files_are_errors(inputs, tmp_path):
             pass
     with pytest.raises(KeyError):
         F5.Fast5Reader(src, 'no-such-read')
+    # a byte of a read's metadata text that is not printable ASCII: that read's own error, the batch of the others
+    # decodes (it used to end as a UnicodeDecodeError of the whole batch: tools/h5_fuzz.py, round 5)
+    victim = [i for i in range(len(t['ids'])) if os.path.join(top, t['where'][i]) == src][1]
+    needle = t['ids'][victim].encode()
+    at = [k for k in range(len(blob)) if blob.startswith(needle, k)]
+    assert at
+    b = bytearray(blob)
+    for k in at:                                   # (group name and attribute: both copies)
+        b[k + 3] = 0xF4
+    p = tmp_path / 'nonascii.fast5'
+    p.write_bytes(bytes(b))
+    f = F5.Fast5File(str(p))
+    info = f.info
+    bad = np.nonzero(info['status'] != 0)[0]
+    assert len(bad) == 1 and b'printable ASCII' in info['error'][bad[0]]
+    ok = np.nonzero(info['status'] == 0)[0]
+    bundle = F5.Fast5Batch([f] * len(ok), ok, ['x'] * len(ok)).as_bundle(threads=2)
+    assert not bundle.signal_status.any() and not bundle.basecall_status.any() and len(ok) == f.n - 1
 
 
 def session_outputs(outdir, batch_reads, **source):

@@ -43,6 +43,8 @@ for trial in range(int(sys.argv[2]) if len(sys.argv)>2 else 1500):
         for i in ok[:3]:
             try: f.basecall(int(i))
             except OSError: pass
+        if len(ok):      # the batch decoder: basecall text by the byte ranges the metadata pass noted
+            F5.Fast5Batch([f] * len(ok), ok, ['x'] * len(ok)).as_bundle(threads=2)
     except OSError:
         n_fail+=1
 print('trials done; opened', n_open, 'refused', n_fail)
