@@ -905,6 +905,74 @@ int pxg_polya_supported(pxg_ctx* ctx)
 #define PA_SPIKES_PER_READ 2       // spike rows of the first pass, per read of the batch (the arena grows on demand)
 #define PA_RETRY_BYTES (1ll << 31) // event scratch of one retry launch
 
+// ---------------------------------------------------------------------------
+// First pass in the order of the work: reads sorted by the length of their segmented poly(A) state, longest first
+// (1 024 classes of two 15-sample blocks; a counting sort on the device).  The four reads of a wave run in lockstep --
+// a wave takes as long as its longest window -- and all waves of a 10 000-read batch are resident at once, three to
+// a SIMD: in batch order a wave's four windows are 1.4 k - 3.4 k samples at random and some SIMD holds three long
+// waves; in this order a wave's windows are alike and a SIMD's three waves (blocks b, b + 1 024, b + 2 048 of the
+// launch) are a long, a middling and a short one.  k_polya takes the order as the `subset` it already knows from
+// the retry pass; every record is a function of its read alone.  PXG_POLYA_INPUT_ORDER=1: batch order (round 4).
+#define PA_ORD_CLASSES 1024
+__device__ __forceinline__ int polya_work_class(const PolyaParams& P, const int32_t* status, const int32_t* segs, int64_t r)
+{
+    if (status[r] != PXG_ST_OKAY) return PA_ORD_CLASSES - 1;                     // nothing to do: last
+    const int32_t* first = segs + r * 2 * PXG_N_SEGMENTS;
+    const int32_t* last = first + PXG_N_SEGMENTS;
+    if (P.adapter_state < 0 || first[P.adapter_state] < 0) return PA_ORD_CLASSES - 1;
+    if (P.polya_state < 0 || first[P.polya_state] < 0) return 0;                  // open end: windows grow by retries, first
+    const int len = last[P.polya_state] - first[P.polya_state] + 1;
+    const int c = len / 2;
+    return PA_ORD_CLASSES - 2 - (c < 0 ? 0 : (c > PA_ORD_CLASSES - 3 ? PA_ORD_CLASSES - 3 : c));
+}
+
+__global__ __launch_bounds__(1024) void k_polya_order_count(int64_t n, PolyaParams P, const int32_t* __restrict__ status,
+                                                            const int32_t* __restrict__ segs, int32_t* __restrict__ hist)
+{
+    __shared__ int h[PA_ORD_CLASSES];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (r < n) atomicAdd(&h[polya_work_class(P, status, segs, r)], 1);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(1024) void k_polya_order_starts(int32_t* __restrict__ hist)
+{
+    __shared__ int a[2][PA_ORD_CLASSES];
+    const int t = threadIdx.x;
+    const int own = hist[t];
+    a[0][t] = own;
+    __syncthreads();
+    int cur = 0;
+    for (int d = 1; d < PA_ORD_CLASSES; d <<= 1) {
+        a[cur ^ 1][t] = a[cur][t] + (t >= d ? a[cur][t - d] : 0);
+        cur ^= 1;
+        __syncthreads();
+    }
+    hist[t] = a[cur][t] - own;
+}
+
+__global__ __launch_bounds__(1024) void k_polya_order_place(int64_t n, PolyaParams P, const int32_t* __restrict__ status,
+                                                            const int32_t* __restrict__ segs, int32_t* __restrict__ cursor,
+                                                            int32_t* __restrict__ order)
+{
+    __shared__ int h[PA_ORD_CLASSES], base[PA_ORD_CLASSES];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    int cls = 0, rank = 0;
+    if (r < n) {
+        cls = polya_work_class(P, status, segs, r);
+        rank = atomicAdd(&h[cls], 1);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (r < n) order[base[cls] + rank] = (int32_t)r;
+}
+
 static void launch_polya(pxg_ctx* ctx, int64_t n, int cap, const int32_t* subset, const int16_t* raw,
                          const int64_t* off, const pxg_calib* cal, const float* ss, const int32_t* status,
                          const int32_t* segs, int32_t* pout, DevBuf<pxg_polya_spike>& spikes)
@@ -959,7 +1027,19 @@ int pxg_launch_polya(pxg_ctx* ctx, int64_t n, const int16_t* raw, const int64_t*
     if ((rc = pxg_reserve(ctx, ctx->polya_over, (size_t)n + PA_OVER_HEAD))) return rc;
     if ((rc = pxg_reserve(ctx, spikes, (size_t)n * PA_SPIKES_PER_READ + 1024))) return rc;
     PXG_HIP(ctx, hipMemsetAsync(ctx->polya_over.p, 0, PA_OVER_HEAD * sizeof(int32_t), ctx->stream));
-    launch_polya(ctx, n, PA_EV_CAP, nullptr, raw, off, cal, ss, status, segs, pout, spikes);
+    const int32_t* order = nullptr;
+    if (!getenv("PXG_POLYA_INPUT_ORDER")) {             // (read per call: the tests take both orders)
+        if ((rc = pxg_reserve(ctx, ctx->polya_order, (size_t)n + PA_ORD_CLASSES))) return rc;
+        int32_t* hist = ctx->polya_order.p + n;
+        PXG_HIP(ctx, hipMemsetAsync(hist, 0, PA_ORD_CLASSES * sizeof(int32_t), ctx->stream));
+        const PolyaParams P = make_params(ctx->cfg, PA_EV_CAP, ctx->cfg.polya_median_pre_filter);
+        const unsigned blocks = (unsigned)((n + 1023) / 1024);
+        hipLaunchKernelGGL(k_polya_order_count, dim3(blocks), dim3(1024), 0, ctx->stream, n, P, status, segs, hist);
+        hipLaunchKernelGGL(k_polya_order_starts, dim3(1), dim3(1024), 0, ctx->stream, hist);
+        hipLaunchKernelGGL(k_polya_order_place, dim3(blocks), dim3(1024), 0, ctx->stream, n, P, status, segs, hist, ctx->polya_order.p);
+        order = ctx->polya_order.p;
+    }
+    launch_polya(ctx, n, PA_EV_CAP, order, raw, off, cal, ss, status, segs, pout, spikes);
     return PXG_OK;
 }
 

@@ -303,7 +303,7 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
     release(ctx->lstm_q); release(ctx->lstm_state); release(ctx->lstm_err);
     release(ctx->demux_q); release(ctx->demux_state);
     release(ctx->spare.raw); release(ctx->spare.offsets); release(ctx->spare.calib); release(ctx->spare.inject);
-    release(ctx->results); release(ctx->spare.z); release(ctx->spare.zchunks); release(ctx->unsplit_q); release(ctx->vit_bp); release(ctx->polya_ev); release(ctx->polya_over); release(ctx->polya_retry); release(ctx->polya_out); release(ctx->spikes);
+    release(ctx->results); release(ctx->spare.z); release(ctx->spare.zchunks); release(ctx->unsplit_q); release(ctx->vit_bp); release(ctx->polya_ev); release(ctx->polya_over); release(ctx->polya_retry); release(ctx->polya_order); release(ctx->polya_out); release(ctx->spikes);
     release(ctx->ev_tstart); release(ctx->ev_first); release(ctx->ev_off); release(ctx->ev_mean); release(ctx->ev_scaled);
     release(ctx->unsplit_scr); release(ctx->unsplit_iv); release(ctx->unsplit_cnt); release(ctx->unsplit_ivoff);
     release(ctx->unsplit_cand); release(ctx->unit_off); release(ctx->n_win);

@@ -348,6 +348,7 @@ struct pxg_ctx {
     DevBuf<char> polya_ev;       // event scratch, [wave][event][lane]
     DevBuf<int32_t> polya_over;  // [0] reads to re-run, [1] most event rows asked for, [2] spike rows handed out, [4..] their ids
     DevBuf<int32_t> polya_retry; // the ids a retry launch works through
+    DevBuf<int32_t> polya_order; // first pass: reads by poly(A) length class, longest first (+ 1 024 class cursors behind them)
     bool polya_unsettled = false;   // K6 ran and its overflow list has not been looked at yet
     uint32_t last_stage_mask = 0;
     DevBuf<int32_t> polya_out;   // n x 8: called, n_spikes, dwell, begin lo/hi, end lo/hi, first spike row

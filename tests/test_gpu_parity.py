@@ -280,6 +280,26 @@ def test_polya_synthetic_vs_oracle(ctx, oracle, seed, noise, dwell):
     assert got['polya_called'].sum() > 60
 
 
+def test_polya_first_pass_in_work_order_equals_batch_order(ctx, oracle, monkeypatch):
+    """K6's first pass takes the reads by poly(A) length class, longest first (k_polya_order_*, the `subset` path of
+    k_polya); PXG_POLYA_INPUT_ORDER=1 takes them in batch order as until round 4.  Same records and spike rows either
+    way, equal to the oracle's -- ragged reads, short reads, reads whose tail is not called."""
+    mask = N.STAGE_SEGMENT | N.STAGE_POLYA
+    b = synth_batch(333, seed=951, samples_per_read=30000, jitter=0.6, sample_noise=1.4, mean_dwell=9.0, short_fraction=0.08)
+    want, wspk = oracle.process_batch(b['arena'], b['offsets'], b['calib'], b['scale_shift'], stage_mask=mask, want_spikes=True)
+    for batch_order in (False, True):
+        if batch_order:
+            monkeypatch.setenv('PXG_POLYA_INPUT_ORDER', '1')
+        else:
+            monkeypatch.delenv('PXG_POLYA_INPUT_ORDER', raising=False)
+        ctx.upload(b['arena'], b['offsets'], b['calib'], b['scale_shift'])
+        ctx.run(mask)
+        got, spikes = ctx.download(), ctx.download_spikes()
+        assert_records_equal(got, want, ctxmsg='polya order %s' % batch_order)
+        assert_spikes_equal(spikes, want, wspk)
+    assert got['polya_called'].sum() > 100 and (got['polya_called'] == 0).sum() >= 5
+
+
 # ---- whole path ------------------------------------------------------------------
 def test_process_batch_golden_bundle(ctx, oracle, bundle):
     for inject in (None, bundle['true_scale_shift']):
