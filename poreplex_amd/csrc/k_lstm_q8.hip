@@ -407,6 +407,53 @@ void q8_scaler_fragments(std::vector<int8_t>& out, const Q8Mat& m1, const Q8Mat&
     }
 }
 
+// The latency form's eight fragments per gate tile (k_lstm_q8_lat.hip): k position 16 g + b of block 0 = unit 16 g + b
+// of h1 (g < 3) or unit b of h2 (g = 3); block 1' = h2 units 16-47 twice: its first two k groups under weight digit
+// (2 | 0), its last two under digit (1 | none).
+void q8_scaler_lat_fragments(std::vector<int8_t>& out, const Q8Mat& m1, const Q8Mat& m2)
+{
+    for (int nt = 0; nt < 3; nt++) {
+        for (int d = 2; d >= 0; d--)          // 0-2: layer 1 over block 0 (zero at the h2 group)
+            q8_fragment_kmap(out, m1, 48, 12, nt, [&](int k, int& row, int& digit) {
+                row = k < 48 ? k : -1; digit = d; });
+        for (int d = 2; d >= 0; d--)          // 3-5: layer 2 over block 0: W2 rows at h1, U2 rows 0-15 at the h2 group
+            q8_fragment_kmap(out, m2, 48, 12, nt, [&](int k, int& row, int& digit) {
+                row = k < 48 ? k : 48 + (k - 48); digit = d; });
+        for (int f = 0; f < 2; f++)           // 6: [w2 | w2 | w1 | w1], 7: [w0 | w0 | 0 | 0] over h2 units 16-47
+            q8_fragment_kmap(out, m2, 48, 12, nt, [&](int k, int& row, int& digit) {
+                const int half = k >> 5;
+                row = (f == 1 && half == 1) ? -1 : 48 + 16 + (k & 31);
+                digit = f == 0 ? 2 - half : 0; });
+    }
+}
+
+// K5a's latency form: [direction][gate tile][w2, w1, w0]: k position = unit (48 of 64 used)
+void q8_bidir_lat_fragments(std::vector<int8_t>& out, const Q8Mat& mf, const Q8Mat& mb)
+{
+    for (int dir = 0; dir < 2; dir++)
+        for (int nt = 0; nt < 3; nt++)
+            for (int d = 2; d >= 0; d--)
+                q8_fragment_kmap(out, dir ? mb : mf, 48, 12, nt, [&](int k, int& row, int& digit) {
+                    row = k < 48 ? k : -1; digit = d; });
+}
+
+// K5b's latency form: [gate tile 0-3][8]: block 0 = hf 0-47 | hb 0-15, block 1 = hb 16-47 | h 0-31 (w2, w1, w0 each),
+// then the half block h 32-63 as [w2 | w1] and [w0 | 0].  Rows of m3: 0-47 hf, 48-95 hb, 96-159 the cell's own h.
+void q8_top_lat_fragments(std::vector<int8_t>& out, const Q8Mat& m3)
+{
+    for (int nt = 0; nt < 4; nt++) {
+        for (int d = 2; d >= 0; d--)
+            q8_fragment_kmap(out, m3, 64, 16, nt, [&](int k, int& row, int& digit) { row = k; digit = d; });
+        for (int d = 2; d >= 0; d--)
+            q8_fragment_kmap(out, m3, 64, 16, nt, [&](int k, int& row, int& digit) { row = 64 + k; digit = d; });
+        for (int f = 0; f < 2; f++)
+            q8_fragment_kmap(out, m3, 64, 16, nt, [&](int k, int& row, int& digit) {
+                const int half = k >> 5;
+                row = (f == 1 && half == 1) ? -1 : 128 + (k & 31);
+                digit = f == 0 ? 2 - half : 0; });
+    }
+}
+
 template <typename T>
 int q8_to_device(pxg_ctx* ctx, T** dst, const std::vector<T>& src)
 {
@@ -429,6 +476,9 @@ int pxg_q8_upload(pxg_ctx* ctx)
         std::vector<int8_t> f;
         q8_scaler_fragments(f, m1, m2);
         if ((rc = q8_to_device(ctx, &ctx->q8.scaler_frag, f))) return rc;
+        std::vector<int8_t> fl;
+        q8_scaler_lat_fragments(fl, m1, m2);
+        if ((rc = q8_to_device(ctx, &ctx->q8.scaler_frag_lat, fl))) return rc;
         m1.scales(ctx->q8.s_scaler1);
         m2.scales(ctx->q8.s_scaler2);
     }
@@ -438,6 +488,9 @@ int pxg_q8_upload(pxg_ctx* ctx)
         q8_fragments(f, mf, 0, 12, 48, 48, 12, 3);
         q8_fragments(f, mb, 0, 12, 48, 48, 12, 3);
         if ((rc = q8_to_device(ctx, &ctx->q8.bidir_frag, f))) return rc;
+        std::vector<int8_t> fl;
+        q8_bidir_lat_fragments(fl, mf, mb);
+        if ((rc = q8_to_device(ctx, &ctx->q8.bidir_frag_lat, fl))) return rc;
         mf.scales(ctx->q8.s_fwd);
         mb.scales(ctx->q8.s_bwd);
     }
@@ -448,6 +501,9 @@ int pxg_q8_upload(pxg_ctx* ctx)
         q8_fragments(f, m3, 48, 12, 48, 64, 16, 4);
         q8_fragments(f, m3, 96, 16, 64, 64, 16, 4);
         if ((rc = q8_to_device(ctx, &ctx->q8.top_frag, f))) return rc;
+        std::vector<int8_t> fl;
+        q8_top_lat_fragments(fl, m3);
+        if ((rc = q8_to_device(ctx, &ctx->q8.top_frag_lat, fl))) return rc;
         m3.scales(ctx->q8.s_top);
     }
     return PXG_OK;
@@ -458,7 +514,11 @@ void pxg_q8_free(pxg_ctx* ctx)
     if (ctx->q8.scaler_frag) (void)hipFree(ctx->q8.scaler_frag);
     if (ctx->q8.bidir_frag) (void)hipFree(ctx->q8.bidir_frag);
     if (ctx->q8.top_frag) (void)hipFree(ctx->q8.top_frag);
+    if (ctx->q8.scaler_frag_lat) (void)hipFree(ctx->q8.scaler_frag_lat);
+    if (ctx->q8.bidir_frag_lat) (void)hipFree(ctx->q8.bidir_frag_lat);
+    if (ctx->q8.top_frag_lat) (void)hipFree(ctx->q8.top_frag_lat);
     ctx->q8.scaler_frag = ctx->q8.bidir_frag = ctx->q8.top_frag = nullptr;
+    ctx->q8.scaler_frag_lat = ctx->q8.bidir_frag_lat = ctx->q8.top_frag_lat = nullptr;
     if (ctx->scaler_traj.p) (void)hipFree(ctx->scaler_traj.p);
     ctx->scaler_traj.p = nullptr;
     ctx->scaler_traj.cap = 0;
@@ -492,6 +552,10 @@ int pxg_q8_scaler_trajectory(pxg_ctx* ctx)
 int pxg_launch_scaler_lstm_q8(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, const int32_t* count,
                               const float* head, float* pred, const int64_t* off)
 {
+    // small batches: 4-read tiles on four times as many CUs (k_lstm_q8_lat.hip); PXG_K2_LAT_MAX = 0 switches it off
+    const char* lat_env = getenv("PXG_K2_LAT_MAX");
+    const int64_t lat_max = lat_env ? atoll(lat_env) : 8 * (int64_t)ctx->n_cu;
+    if (n_rows <= lat_max) return pxg_launch_scaler_lstm_q8_lat(ctx, n_rows, idx, count, head, pred);
     return q8_scaler_launch(ctx, n_rows, idx, count, head, pred, off, nullptr);
 }
 

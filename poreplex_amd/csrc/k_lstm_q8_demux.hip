@@ -367,6 +367,11 @@ int pxg_launch_demux_lstm_q8(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, c
                              const float* win, float* bidir, float* probs, int timer_a, int timer_b)
 {
     if (n_rows <= 0) return PXG_OK;
+    {   // small batches: 4-read tiles on four times as many CUs (k_lstm_q8_lat.hip); PXG_K5_LAT_MAX = 0 switches it off
+        const char* lat_env = getenv("PXG_K5_LAT_MAX");
+        const int64_t lat_max = lat_env ? atoll(lat_env) : 8 * (int64_t)ctx->n_cu;
+        if (n_rows <= lat_max) return pxg_launch_demux_lstm_q8_lat(ctx, n_rows, idx, count, win, bidir, probs, timer_a, timer_b);
+    }
     const int T = ctx->cfg.signal_trim_length;
     const int64_t tiles = (n_rows + 15) / 16, slots = 2 * (int64_t)ctx->n_cu;
     const int64_t grid = std::min(tiles, slots);

@@ -279,6 +279,9 @@ struct pxg_ctx {
         int8_t* scaler_frag = nullptr;   // A-fragment order (k_lstm_q8.hip), 16 bytes per thread and fragment
         int8_t* bidir_frag = nullptr;
         int8_t* top_frag = nullptr;
+        int8_t* scaler_frag_lat = nullptr;   // K2's latency form (k_lstm_q8_lat.hip): 8 fragments per gate tile
+        int8_t* bidir_frag_lat = nullptr;    // K5a's: [direction][gate tile][3]
+        int8_t* top_frag_lat = nullptr;      // K5b's: [gate tile][8]
         float s_scaler1[4] = {}, s_scaler2[4] = {}, s_fwd[4] = {}, s_bwd[4] = {}, s_top[4] = {};   // g * 2^(-p-14) per layer and gate block
         int forced_block_steps = 0;      // host copy of K2's steps-per-task override (trajectory recording, tuning knob)
     } q8;
@@ -504,6 +507,10 @@ int pxg_q8_upload(pxg_ctx* ctx);
 void pxg_q8_free(pxg_ctx* ctx);
 int pxg_launch_scaler_lstm_q8(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, const int32_t* count,
                               const float* head, float* pred, const int64_t* off);
+int pxg_launch_scaler_lstm_q8_lat(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, const int32_t* count,
+                                  const float* head, float* pred);      // <= 4 x #CU reads (k_lstm_q8_lat.hip)
+int pxg_launch_demux_lstm_q8_lat(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, const int32_t* count,
+                                 const float* win, float* bidir, float* probs, int timer_a, int timer_b);
 int pxg_q8_scaler_trajectory(pxg_ctx* ctx);   // zero-input states of the scaler network (prefix skip), once per context
 int pxg_launch_demux_lstm_q8(pxg_ctx* ctx, int64_t n_rows, const int32_t* idx, const int32_t* count,
                              const float* win, float* bidir, float* probs, int timer_a, int timer_b);

@@ -85,6 +85,27 @@ def test_scaler_lstm_bit_exact(ctx, oracle, stages, n):
     assert np.array_equal(got, want), np.abs(got - want).max()
 
 
+@pytest.mark.parametrize('n', [3, 4, 5, 127, 1025, 2047, 2048, 2049])
+def test_scaler_lstm_latency_form_equals_tile_form(ctx, oracle, stages, n, arith):
+    """Up to 8 x #CU reads K2 runs its latency form (4-read tiles, digit planes in the idle MFMA columns,
+    k_lstm_q8_lat.hip): same bits as the 16-read-tile kernel (PXG_K2_LAT_MAX=0) and as the oracle."""
+    heads = stages['scaler_in']
+    rng = np.random.default_rng(100 + n)
+    rows = np.stack([heads[i % len(heads)] for i in range(n)])
+    rows = rows + rng.normal(0, 1.5, (n, 1)).astype(np.float32)
+    rows[::7, :rng.integers(1, 1900)] = 0.0            # left zero padding of short reads
+    got = ctx.scaler_lstm(rows)
+    os.environ['PXG_K2_LAT_MAX'] = '0'
+    try:
+        tiled = ctx.scaler_lstm(rows)
+    finally:
+        del os.environ['PXG_K2_LAT_MAX']
+    assert np.array_equal(got, tiled), np.abs(got - tiled).max()
+    pick = rng.choice(n, min(n, 12), replace=False)
+    want = np.stack([oracle.scaler_forward(rows[i]) for i in pick])
+    assert np.array_equal(got[pick], want)
+
+
 @pytest.mark.parametrize('n', [8200, 9999, 13000])
 def test_scaler_lstm_time_sliced_equals_static(ctx, oracle, stages, n):
     """Between 1 and 2 read tiles per resident workgroup K2 runs time-sliced (tile
@@ -183,6 +204,27 @@ def test_demux_lstm_bit_exact(ctx, oracle, stages, n):
     assert np.abs(got - want).max() <= 1e-4          # north_star bound
     assert np.array_equal(got, want), np.abs(got - want).max()
     assert np.array_equal(got.argmax(1), want.argmax(1))
+
+
+@pytest.mark.parametrize('n', [2, 4, 5, 130, 1025, 2047, 2048, 2049])
+def test_demux_lstm_latency_form_equals_tile_form(ctx, oracle, stages, n, arith):
+    """Up to 8 x #CU reads K5a / K5b run their latency forms (4-read tiles, k_lstm_q8_lat.hip): same bits as
+    the 16-read-tile kernels (PXG_K5_LAT_MAX=0) and as the oracle."""
+    wins = stages['demux_in']
+    rng = np.random.default_rng(200 + n)
+    rows = np.stack([wins[i % len(wins)] for i in range(n)])
+    rows = rows + rng.normal(0, 0.05, (n, 1)).astype(np.float32)
+    rows[::5] = np.roll(rows[::5], 7, axis=1)
+    got = ctx.demux_lstm(rows)
+    os.environ['PXG_K5_LAT_MAX'] = '0'
+    try:
+        tiled = ctx.demux_lstm(rows)
+    finally:
+        del os.environ['PXG_K5_LAT_MAX']
+    assert np.array_equal(got, tiled), np.abs(got - tiled).max()
+    pick = rng.choice(n, min(n, 12), replace=False)
+    want = np.stack([oracle.demux_forward(rows[i]) for i in pick])
+    assert np.array_equal(got[pick], want)
 
 
 @pytest.mark.parametrize('n', [8200, 9898, 13000, 20001])
