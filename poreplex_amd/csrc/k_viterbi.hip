@@ -74,7 +74,14 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-#define EM_STRIDE (VIT_CHUNK * PXG_MAX_STATES + 8)   // +8 doubles: spread reads over banks
+// Emission tile of one chunk: em[read][state][step], a state's 16 steps + 1 double of padding, a read's 8 states
+// = 136 doubles.  Round 6: step-minor.  (It was [read][step][state]: the 64 producer lanes of one state's store sat
+// 64 bytes apart -- four bank positions, a 16-way conflict on every ds_write_b64, 75 % of K3's LDS cycles -- and the
+// recurrence wave's reads queued behind them.)  Now a producer wave is lane = 4 step + read: a half wave's stores
+// cover 32 distinct bank pairs (2 step + 16 read), and the recurrence lane (read, state) reads consecutive doubles
+// from its own row, bank pairs 16 read + 34 state (mod 64) -- all distinct within a half wave.
+#define EM_ROW (VIT_CHUNK + 1)
+#define EM_STRIDE (PXG_MAX_STATES * EM_ROW)
 
 // value of the lane `k` below inside a 16-lane row (DPP row_shr:k).  bound_ctrl: a lane
 // whose source falls outside the row reads 0 -- such a lane has no edge of that span
@@ -213,10 +220,9 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
 
     if (wv > 0) {
         // ================= emission producers (waves 1 and 2) ==========================
-        // lane -> (read, step) of a chunk: 64 lanes = 4 reads x 16 steps;
-        // consecutive lanes pool consecutive 15-sample blocks (coalesced)
-        const int item = (wv - 1) * 64 + lane;
-        const int prr = item / VIT_CHUNK, ptt = item % VIT_CHUNK;
+        // lane -> (read, step) of a chunk: 64 lanes = 16 steps x 4 reads, read-minor (see EM_ROW);
+        // the 16 lanes of a read pool consecutive 15-sample blocks
+        const int prr = (wv - 1) * 4 + (lane & 3), ptt = lane >> 2;
         const int64_t pslot = blockIdx.x * (int64_t)VIT_READS + prr;
         const int64_t pr = pslot < n_reads ? (ord ? ord[pslot] : pslot) : n_reads;
         const bool pvalid = pr < n_reads && (status == nullptr || status[pr] == PXG_ST_OKAY);
@@ -239,10 +245,10 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
         }
         auto publish = [&](int c, float x) {
             const double xd = (double)x;
-            double* dst = &em[c & 1][prr * EM_STRIDE + ptt * PXG_MAX_STATES];
+            double* dst = &em[c & 1][prr * EM_STRIDE + ptt];
 #pragma unroll
             for (int q = 0; q < PXG_MAX_STATES; q++)
-                if (q < S) dst[q] = hmm_emission(H, lsetab, q, xd);
+                if (q < S) dst[q * EM_ROW] = hmm_emission(H, lsetab, q, xd);
         };
         if (RAW && POOL == 15) {
             // the 15 samples of chunk c+1 are requested before chunk c is worked on: one
@@ -392,10 +398,17 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
 #pragma unroll
             for (int k = 1; k < PXG_MAX_STATES; k++) {
                 if ((SPANS >> k) & 1u) {
+                    // (round 6) the running best is a v_max_f64 chain: add -> max -> max -> add per step; the
+                    // comparisons that choose the span and flag ties hang off that chain instead of sitting in
+                    // it (v_cmp -> SGPR pair -> two v_cndmask per span was 4 of its 7 dependent stages).  Without
+                    // a tie max(best, cand) IS the strict-greater select; a chunk with a tie is replayed exactly.
                     ties |= __ballot(cand[k] == best) & live;
-                    const bool take = cand[k] > best;
-                    best = take ? cand[k] : best;
-                    bd = take ? (unsigned)k : bd;
+                    bd = cand[k] > best ? (unsigned)k : bd;
+#ifdef VIT_NO_MAX
+                    best = cand[k] > best ? cand[k] : best;
+#else
+                    best = pxg_max_f64(best, cand[k]);
+#endif
                 }
             }
         }
@@ -411,14 +424,17 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
             vfin = pxg_sel_f64(__ballot(T == 1), vfin, v);
             tt = 1;
         }
-#pragma unroll 1
-        for (; tt < tend; tt++) step(exact, c0 + tt, emc[tt * PXG_MAX_STATES], ties, fields);
+#ifndef VIT_UNROLL
+#define VIT_UNROLL 1
+#endif
+#pragma unroll VIT_UNROLL
+        for (; tt < tend; tt++) step(exact, c0 + tt, emc[tt], ties, fields);
         return (BT)(fields << ((VIT_CHUNK - tend) * FB));      // a short last chunk: step tt still sits at field 15 - tt
     };
 
     lds_barrier();                  // chunk 0 is in em[0]
     for (int c0 = 0; c0 < Tmax; c0 += VIT_CHUNK) {
-        const double* emc = em[(c0 / VIT_CHUNK) & 1] + rr * EM_STRIDE + es;
+        const double* emc = em[(c0 / VIT_CHUNK) & 1] + rr * EM_STRIDE + es * EM_ROW;
         const int tend = (Tmax - c0) < VIT_CHUNK ? (Tmax - c0) : VIT_CHUNK;
         const double v0 = v, vfin0 = vfin;
         unsigned long long ties = 0ull, unused = 0ull;

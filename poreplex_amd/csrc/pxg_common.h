@@ -159,6 +159,14 @@ __device__ __forceinline__ float pxg_sel_f32(unsigned long long take, float if0,
 {
     return __uint_as_float(pxg_sel_u32(take, __float_as_uint(if0), __float_as_uint(if1)));
 }
+// max of two doubles, one v_max_f64 (no NaN can reach the callers: log-probabilities, -inf included)
+__device__ __forceinline__ double pxg_max_f64(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ double pxg_sel_f64(unsigned long long take, double if0, double if1)
 {
     const unsigned lo = pxg_sel_u32(take, (unsigned)__double2loint(if0), (unsigned)__double2loint(if1));
