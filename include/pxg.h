@@ -444,7 +444,11 @@ int pxg_batch_event_table(pxg_ctx* ctx, const int64_t* first_sample, const int64
  * exceeds cap_intervals only the first cap_intervals were written: call again
  * with a larger buffer).  A window keeps as many candidates as its length and the duration
  * cut-offs of the config allow (the slots are sized from them): no fixed limit.  Everything between the H2D of the two per-read arrays
- * and the final D2H is enqueued without a host synchronisation. */
+ * and the final D2H is enqueued without a host synchronisation.
+ * Threading: the scan calls are stage hooks of the RESIDENT batch -- for their duration the context enqueues on its
+ * scan stream (beside K6 when the last run had the poly(A) stage).  They must not overlap any other call on the same
+ * context: a caller that shares the context between threads holds pxg_ctx_lock(ctx, 1) around run + scans + downloads
+ * (pxg_process_batch_ex does). */
 int pxg_batch_unsplit_scan(pxg_ctx* ctx, const int64_t* first_sample, const int64_t* n_blocks,
                            int32_t block_stride, int64_t cap_intervals, int64_t* out_intervals,
                            int32_t* out_count, int64_t* out_total);

@@ -768,7 +768,14 @@ extern "C" int pxg_host_register(pxg_ctx* ctx, void* ptr, size_t bytes)
 
 extern "C" int pxg_host_unregister(pxg_ctx* ctx, void* ptr)
 {
-    if (!ctx || !ptr) return PXG_E_INVALID;
+    if (!ptr) return PXG_E_INVALID;
+    // (page locks are process-global: a range can be released after the context that registered it is gone --
+    //  a session that outlives its context must not leave a registration behind on memory it is about to unmap)
+    if (!ctx) {
+        if (hipHostUnregister(ptr) == hipSuccess) return PXG_OK;
+        (void)hipGetLastError();
+        return PXG_E_HIP;
+    }
     PXG_HIP(ctx, hipHostUnregister(ptr));
     return PXG_OK;
 }
@@ -941,8 +948,10 @@ int pxg_d2h_sync(pxg_ctx* ctx, void* dst, const void* src, size_t bytes)
     return PXG_OK;
 }
 
-// Host -> device of a big array on stream `st` (returns once `src` may be reused, like a pageable hipMemcpyAsync).
-// A page-locked source (hipHostRegister by the caller, hipHostMalloc) is one asynchronous DMA.  A PAGEABLE source of
+// Host -> device of a big array on stream `st`.  Completion semantics: a PAGEABLE source has been consumed when the call
+// returns (like a pageable hipMemcpyAsync); a page-locked source (hipHostRegister by the caller, hipHostMalloc) is ONE
+// asynchronous DMA and must stay untouched until `st` has passed it -- every caller of this function waits for its
+// stream (or records an event on it) before the source is reused.  A PAGEABLE source of
 // 1 MB or more is NOT handed to the runtime: ROCm 7.2 page-locks the caller's range in place for such a copy
 // ("Locking to pool ... hostMem = <user address>", hsa_amd_memory_lock) and lets the SDMA engine read the user's
 // pages, and when that range lies in the brk heap and overlaps pages that were hipHostRegister'ed and
@@ -963,11 +972,26 @@ int pxg_h2d_big(pxg_ctx* ctx, void* dst, const void* src, size_t bytes, hipStrea
         PXG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
         return PXG_OK;
     }
-    hipPointerAttribute_t at;
+    // Page-locked means the WHOLE range [src, src + bytes) lies in one registration: a range that starts inside a
+    // registered block and runs past its end would reach the runtime as one DMA over pageable pages -- the
+    // in-place-lock path this function exists to avoid.  Both ends are asked; a device or managed source is the
+    // runtime's own business (plain asynchronous copy).
+    hipPointerAttribute_t at, at_end;
     if (hipPointerGetAttributes(&at, src) == hipSuccess) {
-        if (at.type == hipMemoryTypeHost) {             // page-locked by the caller
-            PXG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+        if (at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged) {
+            PXG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st));
             return PXG_OK;
+        }
+        if (at.type == hipMemoryTypeHost) {             // page-locked by the caller -- at its first byte
+            bool whole = false;
+            if (hipPointerGetAttributes(&at_end, (const char*)src + bytes - 1) == hipSuccess)
+                whole = at_end.type == hipMemoryTypeHost;
+            else
+                (void)hipGetLastError();
+            if (whole) {
+                PXG_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+                return PXG_OK;
+            }
         }
     } else {
         (void)hipGetLastError();                        // (an unknown pointer is an error state of the runtime: clear it)
@@ -1890,8 +1914,10 @@ extern "C" int pxg_batch_unsplit_scan_events(pxg_ctx* ctx, const int64_t* n_even
         return rc;
     PXG_HIP(ctx, hipMemsetAsync(ctx->ev_first.p, 0, (size_t)n * sizeof(int64_t), ctx->stream));
     if ((rc = pxg_h2d_meta(ctx, 2, 1, ctx->ev_off.p, eoff.data(), ((size_t)n + 1) * sizeof(int64_t), ctx->stream)) ||
-        (ne_all && ((rc = pxg_h2d_meta(ctx, 2, 2, ctx->ev_tstart.p, ev_start, ne_all * sizeof(int64_t), ctx->stream)) ||
-                    (rc = pxg_h2d_meta(ctx, 2, 3, ctx->ev_mean.p, ev_mean, ne_all * sizeof(float), ctx->stream)))))
+        // the per-EVENT columns (8 + 4 bytes x ~4 000 events per read) go in bounded page-locked chunks, not through a
+        // mirror of their own size (pxg_h2d_meta is for the O(n_reads) arrays)
+        (ne_all && ((rc = pxg_h2d_big(ctx, ctx->ev_tstart.p, ev_start, ne_all * sizeof(int64_t), ctx->stream)) ||
+                    (rc = pxg_h2d_big(ctx, ctx->ev_mean.p, ev_mean, ne_all * sizeof(float), ctx->stream)))))
         return rc;
     StreamSyncOnError guard(ctx->stream);
     pxg_timer_begin(ctx, PXG_T_EVENT_MEANS);

@@ -25,8 +25,13 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#if defined(__x86_64__)
 #include <emmintrin.h>
 #include <tmmintrin.h>
+#define PXG_H5_X86 1
+#else
+#define PXG_H5_X86 0      // (no vector paths: memcpy and the scalar VBZ loop)
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -173,11 +178,16 @@ struct SvbTable {
 };
 static bool svb_simd_ok()
 {
+#if PXG_H5_X86
     static const bool ok = !getenv("PXG_H5_SCALAR") && __builtin_cpu_supports("ssse3");
     return ok;
+#else
+    return false;
+#endif
 }
 // groups [0, n_groups) of `keys` / `data` -> o16; returns the data bytes used, or (size_t)-1 when the stream ends
 // inside a group.  `data` must be readable 16 bytes past every group start (the caller pads its buffer).
+#if PXG_H5_X86
 __attribute__((target("ssse3")))
 static size_t svb1_groups_ssse3(const uint8_t* keys, const uint8_t* data, size_t n_data, uint64_t n_groups, bool zig,
                                 uint16_t* o16, uint32_t& prev_io)
@@ -204,6 +214,9 @@ static size_t svb1_groups_ssse3(const uint8_t* keys, const uint8_t* data, size_t
     prev_io = (uint32_t)(uint16_t)_mm_extract_epi16(prev, 0);
     return pos;
 }
+#else
+static size_t svb1_groups_ssse3(const uint8_t*, const uint8_t*, size_t, uint64_t, bool, uint16_t*, uint32_t&) { return (size_t)-1; }
+#endif
 
 }  // namespace
 
@@ -262,7 +275,10 @@ struct pxg_h5 {
     void copy_out(uint8_t* out, uint64_t off, uint64_t len) const
     {
         const uint8_t* src = at(off, len);
-        const int mode = len >= (64u << 10) ? copy_mode() : 0;
+        int mode = len >= (64u << 10) ? copy_mode() : 0;
+#if !PXG_H5_X86
+        if (mode >= 2) mode = 1;                       // the non-temporal paths are x86 code: plain pread instead
+#endif
         if (mode == 1 && fd >= 0) {
             uint64_t done = 0;
             while (done < len) {
@@ -274,6 +290,7 @@ struct pxg_h5 {
             if (done < len) memcpy(out + done, src + done, (size_t)(len - done));
             return;
         }
+#if PXG_H5_X86
         if (mode == 3 && fd >= 0) {
             // pread into a buffer that stays in this core's L2, then non-temporal stores: the destination is
             // never read for ownership (two passes over memory instead of three)
@@ -329,6 +346,7 @@ struct pxg_h5 {
             memcpy(out + i, src + i, (size_t)len - i);
             return;
         }
+#endif
         memcpy(out, src, (size_t)len);
     }
     static uint64_t rd(const uint8_t* q, int bytes)
@@ -814,12 +832,19 @@ struct pxg_h5 {
                 const uint8_t* data = svb.data() + keys;
                 const size_t n_data = got - keys;
                 uint16_t* o16 = (uint16_t*)(last_stage ? out : dst.data());
+                // a stream that turns out corrupt half way must not leave part of a signal in the caller's arena
+                // (the read's status says "failed": its slot reads as zeros, as when nothing had been written)
+                auto corrupt = [&](const char* what) {
+                    if (last_stage) memset(out, 0, (size_t)want);
+                    fail(PXG_E_INVALID, what);
+                };
+                if (last_stage && (want & 1)) out[want - 1] = 0;    // (an odd byte count: the byte no sample covers)
                 size_t pos = 0;
                 uint32_t prev = 0;
                 uint64_t i = 0;
                 if (version == 1 && svb_simd_ok()) {
                     pos = svb1_groups_ssse3(svb.data(), data, n_data, n / 8, zig != 0, o16, prev);
-                    if (pos == (size_t)-1) fail(PXG_E_INVALID, "VBZ: stream ends inside a sample");
+                    if (pos == (size_t)-1) corrupt("VBZ: stream ends inside a sample");
                     i = n / 8 * 8;
                 } else if (version == 1) {
                     // eight samples per control byte; the byte offsets inside the group come from
@@ -827,7 +852,7 @@ struct pxg_h5 {
                     for (; i + 8 <= n; i += 8) {
                         const unsigned key = svb[i >> 3];
                         const size_t group = 8 + (size_t)__builtin_popcount(key);
-                        if (pos + group > n_data) fail(PXG_E_INVALID, "VBZ: stream ends inside a sample");
+                        if (pos + group > n_data) corrupt("VBZ: stream ends inside a sample");
                         const uint8_t* g = data + pos;
                         unsigned at_ = 0;
                         for (unsigned q = 0; q < 8; q++) {
@@ -843,7 +868,7 @@ struct pxg_h5 {
                 }
                 for (; i < n; i++) {
                     const unsigned nb = version ? 1 + ((svb[i >> 3] >> (i & 7)) & 1) : 1 + ((svb[i >> 2] >> (2 * (i & 3))) & 3);
-                    if (pos + nb > n_data) fail(PXG_E_INVALID, "VBZ: stream ends inside a sample");
+                    if (pos + nb > n_data) corrupt("VBZ: stream ends inside a sample");
                     uint32_t v = 0;
                     for (unsigned b = 0; b < nb; b++) v |= (uint32_t)data[pos++] << (8 * b);
                     if (zig) v = (v >> 1) ^ (0u - (v & 1));

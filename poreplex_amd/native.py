@@ -752,6 +752,9 @@ class NativeContext:
 
     def close(self):
         if getattr(self, 'handle', None):
+            for addr in list(getattr(self, '_pinned', {})):       # whatever is still page-locked through this context
+                self.lib.pxg_host_unregister(self.handle, C.c_void_p(addr))
+            self._pinned = {}
             self.lib.pxg_destroy(self.handle)
             self.handle = None
 
@@ -861,10 +864,17 @@ class NativeContext:
         """Page-lock a NumPy array so stage() copies are DMA transfers; returns it."""
         self._check(self.lib.pxg_host_register(self.handle, _ptr(array), array.nbytes),
                     'pxg_host_register')
+        self._pinned = getattr(self, '_pinned', {})
+        self._pinned[_ptr(array).value] = array       # (kept alive until it is released)
         return array
 
     def unpin(self, array):
-        self._check(self.lib.pxg_host_unregister(self.handle, _ptr(array)), 'pxg_host_unregister')
+        """Release a page lock.  Works after close() too (page locks are process-global): a staging arena
+        that outlives its context is released, not left registered on memory about to be unmapped."""
+        getattr(self, '_pinned', {}).pop(_ptr(array).value, None)
+        rc = self.lib.pxg_host_unregister(self.handle if getattr(self, 'handle', None) else None, _ptr(array))
+        if rc != 0:
+            raise PxgError('pxg_host_unregister failed ({})'.format(rc))
 
     def run(self, stage_mask=STAGE_ALL_DEMUX):
         self._check(self.lib.pxg_batch_run(self.handle, stage_mask), 'pxg_batch_run')

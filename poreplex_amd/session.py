@@ -87,10 +87,14 @@ class _Staging:
             self.pinned = True
 
     def release(self):
-        self.settle()
-        if self.pinned:
-            self.ctx.unpin(self.buf)
-        self.buf, self.pinned = np.empty(0, dtype=np.int16), False
+        """Take every page lock off (works with a context that has been closed: NativeContext.unpin)."""
+        bufs = self.retired + ([self.buf] if self.pinned else [])
+        self.retired, self.pinned = [], False
+        try:
+            for b in bufs:
+                self.ctx.unpin(b)
+        finally:
+            self.buf = np.empty(0, dtype=np.int16)
 
 
 class GpuSession:
@@ -381,6 +385,13 @@ class GpuSession:
 
     def __del__(self):
         self.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def _check_early_stop(self, seen):
         """pipeline.py:250-260: stop when reads keep arriving without basecalls."""
