@@ -170,6 +170,147 @@ def test_vbz_decoder_vector_and_scalar(tmp_path):
     assert out.stdout.split() == ['0', str(int((flat.astype(np.int64) * (1 + np.arange(len(flat)) % 11)).sum()))]
 
 
+# ---- VBZ pinned to ONT's published stream format, not to this repo's encoder ----------------------
+# ONT vbz_compression (filter 32020, version 1, 16-bit integers), restated from its public format notes:
+#   1. delta: d[i] = x[i] - x[i-1] in 16-bit two's complement, x[-1] = 0
+#   2. zig-zag: z = (d << 1) ^ (d >> 15), an unsigned 16-bit value
+#   3. StreamVByte-16: one control BIT per value, least significant bit first, 8 per key byte, ceil(n / 8) key
+#      bytes in front; bit set = the value takes two data bytes (little endian), clear = one byte (z < 256)
+#   4. one zstd frame over keys + data, optionally behind a 4-byte little-endian size word
+# The encoder below is a scalar loop written from those four sentences (no NumPy tricks shared with
+# fast5_write.vbz_encode, nothing from csrc/pxg_zcodec.cpp); the zstd frames are assembled BY HAND from RFC 8878
+# (magic, single-segment frame header, raw blocks of at most 128 KB): no compressor is involved at all.
+def _vbz_by_the_book(samples):
+    keys, data = bytearray((len(samples) + 7) // 8), bytearray()
+    prev = 0
+    for i, x in enumerate(int(v) for v in samples):
+        d = (x - prev) & 0xFFFF
+        prev = x
+        d = d - 0x10000 if d & 0x8000 else d            # 16-bit two's complement
+        z = ((d << 1) ^ (d >> 15)) & 0xFFFF
+        if z > 0xFF:
+            keys[i >> 3] |= 1 << (i & 7)
+            data += bytes((z & 0xFF, z >> 8))
+        else:
+            data.append(z)
+    return bytes(keys) + bytes(data)
+
+
+def _zstd_raw_frame(payload, size_word=False):
+    """RFC 8878: magic 0xFD2FB528; frame header descriptor 0xA0 = single segment + 4-byte content size;
+    blocks with a 3-byte header (bit 0 last block, bits 1-2 type 0 = raw, bits 3-23 size)."""
+    out = bytearray(b'\x28\xb5\x2f\xfd\xa0') + len(payload).to_bytes(4, 'little')
+    pieces = [payload[i:i + 0x20000] for i in range(0, len(payload), 0x20000)] or [b'']
+    for k, piece in enumerate(pieces):
+        out += ((len(piece) << 3) | (1 if k == len(pieces) - 1 else 0)).to_bytes(3, 'little') + piece
+    return (len(payload).to_bytes(4, 'little') if size_word else b'') + bytes(out)
+
+
+VBZ_EDGE_CASES = {
+    'one sample': [123],
+    'seven (short last group)': [5, 6, 7, 6, 5, 4, 3],
+    'eight (exactly one group)': [0, 1, 2, 3, 4, 5, 6, 7],
+    'nine (one group + 1)': [10, 9, 8, 7, 6, 5, 4, 3, 2],
+    'all one-byte codes': [500 + (k % 5) * 20 - 40 for k in range(1023)],
+    'all two-byte codes': [(-1) ** k * 20000 for k in range(1024)],
+    'delta of +2^15 and back': [0, -32768, 0, -32768, 0],
+    'full swings 32767 <-> -32768': [32767, -32768, 32767, -32768, 32767, -32768, 32767],
+    'deltas of exactly +-127 / +-128 (code-width boundary)': [0, 127, 0, -128, 0, 128, 0, -127, 1, 1, 129],
+    'constant -32768': [-32768] * 17,
+    'constant 32767': [32767] * 15,
+    'mixed widths across a key byte': [0, 300, 301, -300, -299, 5000, 5001, 5002, 4000, 4001],
+}
+
+
+def test_vbz_by_the_book_known_answer():
+    """The book encoder against a stream worked out by hand (the arithmetic is in the comments)."""
+    x = [1, -1, 300, 300, -32768, 32767, 0, 5, 7]
+    # deltas      1   -2  301    0  32468    -1  -32767   5  2      (16-bit wrap: -32768 - 300 = -33068 = 32468)
+    # zig-zag     2    3  602    0  64936     1   65533  10  4
+    # two bytes?  .    .   x     .    x       .     x     .  | .    -> keys 0b01010100 = 0x54, 0x00
+    want = bytes.fromhex('5400' '02' '03' '5a02' '00' 'a8fd' '01' 'fdff' '0a' '04')
+    assert _vbz_by_the_book(x) == want
+    assert _zstd_raw_frame(want) == bytes.fromhex('28b52ffd' 'a0' '0e000000' '710000') + want
+
+
+@pytest.mark.skipif(not have_zstd(), reason='libzstd is not on this host')
+@pytest.mark.parametrize('size_word', [False, True])
+def test_vbz_reader_against_streams_written_from_the_format_description(tmp_path, monkeypatch, size_word):
+    """The native reader (vector and scalar decoder) on VBZ chunks that NOTHING of this repository encoded:
+    StreamVByte-16 + zig-zag by the scalar book encoder above, wrapped in hand-assembled raw-block zstd frames,
+    with and without ONT's size word; plus a 70 000-sample read whose stream spans two zstd blocks."""
+    from poreplex_amd import fast5_write
+    rng = np.random.default_rng(77)
+    cases = dict(VBZ_EDGE_CASES)
+    big = np.where(rng.random(70000) < 0.5, rng.integers(-32768, 32768, 70000), 400 + rng.integers(-30, 31, 70000))
+    cases['70 000 samples, two zstd blocks'] = big.tolist()
+    monkeypatch.setattr(fast5_write, 'vbz_encode',
+                        lambda part, level=1: _zstd_raw_frame(_vbz_by_the_book(np.asarray(part).tolist()), size_word))
+    cal = np.zeros(1, dtype=N.CALIB_DTYPE)
+    cal['range'], cal['digitisation'], cal['offset'], cal['sampling_rate'] = 1400.0, 8192.0, 5.0, 3012.0
+    path = str(tmp_path / 'book.fast5')
+    with Fast5Writer(path) as w:
+        for j, (name, x) in enumerate(cases.items()):
+            w.add_read('b%02d' % j, np.asarray(x, dtype=np.int16), cal[0], compression='vbz', chunk=None)
+    f = F5.Fast5File(path)
+    ns = f.info['n_samples'].astype(np.int64)
+    assert ns.tolist() == [len(x) for x in cases.values()]
+    dst = np.concatenate([[0], np.cumsum(ns)[:-1]]).astype(np.int64)
+    flat = np.concatenate([np.asarray(x, dtype=np.int16) for x in cases.values()])
+    arena = np.full(int(ns.sum()), 77, dtype=np.int16)
+    assert not F5.load_signals([f] * f.n, np.arange(f.n), ns, arena, dst, threads=2).any()
+    for j, name in enumerate(cases):
+        assert np.array_equal(arena[dst[j]:dst[j] + ns[j]], flat[dst[j]:dst[j] + ns[j]]), name
+    code = ('import sys, numpy as np; sys.path.insert(0, %r); from poreplex_amd import fast5_file as F5\n'
+            'f = F5.Fast5File(%r); ns = f.info["n_samples"].astype(np.int64)\n'
+            'dst = np.concatenate([[0], np.cumsum(ns)[:-1]]).astype(np.int64); a = np.zeros(int(ns.sum()), dtype=np.int16)\n'
+            'st = F5.load_signals([f] * f.n, np.arange(f.n), ns, a, dst, threads=1)\n'
+            'print(int(st.any()), int((a.astype(np.int64) * (1 + np.arange(len(a)) %% 11)).sum()))' % (ROOT, path))
+    out = subprocess.run([os.sys.executable, '-c', code], env=dict(os.environ, PXG_H5_SCALAR='1'),
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ['0', str(int((flat.astype(np.int64) * (1 + np.arange(len(flat)) % 11)).sum()))]
+    # and the repo's own writer produces the same StreamVByte bytes as the book (its zstd frame differs: compressed)
+    for name, x in VBZ_EDGE_CASES.items():
+        blob = vbz_encode(np.asarray(x, dtype=np.int16))
+        lib = fast5_write._libzstd()
+        import ctypes as C
+        lib.ZSTD_decompress.restype = C.c_size_t
+        lib.ZSTD_decompress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        buf = C.create_string_buffer(4 * len(x) + 64)
+        got = lib.ZSTD_decompress(buf, len(buf), blob, len(blob))
+        assert buf.raw[:got] == _vbz_by_the_book(x), name
+
+
+@pytest.mark.skipif(not have_zstd(), reason='libzstd is not on this host')
+def test_vbz_corrupt_stream_leaves_a_clean_slot(tmp_path, monkeypatch):
+    """A stream that ends inside a sample is an error for that read alone, and its slot of the caller's arena reads
+    as zeros (the last pipeline stage decodes in place: ADVICE r5)."""
+    from poreplex_amd import fast5_write
+    good = [(-1) ** k * 15000 for k in range(64)]
+    state = {'n': 0}
+
+    def enc(part, level=1):
+        state['n'] += 1
+        svb = _vbz_by_the_book(np.asarray(part).tolist())
+        return _zstd_raw_frame(svb[:-9] if state['n'] == 2 else svb)     # the second read loses its last bytes
+    monkeypatch.setattr(fast5_write, 'vbz_encode', enc)
+    cal = np.zeros(1, dtype=N.CALIB_DTYPE)
+    cal['range'], cal['digitisation'], cal['offset'], cal['sampling_rate'] = 1400.0, 8192.0, 5.0, 3012.0
+    path = str(tmp_path / 'cut.fast5')
+    with Fast5Writer(path) as w:
+        for j in range(3):
+            w.add_read('c%02d' % j, np.asarray(good, dtype=np.int16), cal[0], compression='vbz', chunk=None)
+    f = F5.Fast5File(path)
+    ns = f.info['n_samples'].astype(np.int64)
+    dst = np.concatenate([[0], np.cumsum(ns)[:-1]]).astype(np.int64)
+    arena = np.full(int(ns.sum()), 77, dtype=np.int16)
+    st = F5.load_signals([f] * f.n, np.arange(f.n), ns, arena, dst, threads=1)
+    assert st.astype(bool).tolist() == [False, True, False]
+    assert np.array_equal(arena[:64], good) and np.array_equal(arena[128:], good)
+    assert not arena[64:128].any()
+
+
 def test_reader_threads_are_shared_between_calls_and_survive_a_fork(tmp_path):
     """The reader's worker threads are started once per process (pxg_h5.cpp run_pool).  Calls that overlap
     (two loader threads: one gets the workers, the other starts threads of its own), a child forked after the

@@ -10,9 +10,14 @@ What is real reference code here:
     worker_persistence,utils}.py imported from /root/reference through a
     shadow package of symlinks (the tree is read-only);
   * poreplex.csupport compiled from /root/reference/src (setup.py:34-37 flags).
-What is NOT available (no TensorFlow / pomegranate, no network): the two
-third-party engines are replaced by stubs that call the ORACLE restatement
-(oracle/libpxo.so) -- Keras `model.predict` and pomegranate `viterbi`.  So
+What is NOT available in this image (no TensorFlow / pomegranate, no network):
+the two third-party engines.  `--engines auto` (default) tries to import them
+and replaces ONLY what raises ImportError by a stub that calls the ORACLE
+restatement (oracle/libpxo.so) -- Keras `model.predict` and pomegranate
+`viterbi`; `--engines real` insists on the libraries, `--engines stub` on the
+stand-ins (tools/golden_engines.py).  A set made with a real engine goes to
+tests/golden/real/ (tolerance tests: tests/test_real_engines.py); every set
+records what made it in engines.json.  With the stand-ins
 these goldens pin everything the reference itself computes (pA conversion,
 pooling, padding, de-standardisation + QC, run-length summary, window rules,
 robust z-score, thresholds, phred lookup, poly(A) logic, status/label logic,
@@ -42,6 +47,8 @@ from poreplex_amd import native as N  # noqa: E402
 from poreplex_amd.config import default_config  # noqa: E402
 from poreplex_amd.synth import synth_batch  # noqa: E402
 from oracle.pxo import Oracle, reference_detect_events  # noqa: E402
+sys.path.insert(0, os.path.join(REPO, 'tools'))
+import golden_engines as GE  # noqa: E402
 
 # The reference targets h5py 2.x, where string attributes come back as bytes
 # (it calls .decode() on them: fast5_file.py:102-120, signal_loader.py:55-58).
@@ -63,6 +70,8 @@ ARITH = sys.argv[sys.argv.index('--arith') + 1] if '--arith' in sys.argv else 'f
 assert ARITH in ('f32', 'q8')
 os.environ['PXG_LSTM_ARITH'] = ARITH
 OUT = os.path.join(REPO, 'tests', 'golden') if ARITH == 'f32' else os.path.join(REPO, 'tests', 'golden', 'q8')
+ENGINE_MODE = GE.parse_mode(sys.argv)
+ENGINES = None      # set by install_engines(): {'keras': 'real' | 'oracle-stub', 'hmm': ...}
 # `make_golden.py --only batch0` rewrites just the fixtures whose name starts with that prefix.
 # Every fixture is an (inputs, outputs-of-the-real-reference) pair that carries its own inputs,
 # so sets made by different revisions of the synthetic generator can coexist: unit / polya /
@@ -176,12 +185,14 @@ class _FakeKerasModel:
         return out
 
 
-def install_stubs():
+def install_hmm_stub():
     pom = types.ModuleType('pomegranate')
     pom.HiddenMarkovModel, pom.GeneralMixtureModel = _HMM, _GMM
     pom.State, pom.NormalDistribution = _State, _Normal
     sys.modules['pomegranate'] = pom
 
+
+def install_keras_stub():
     tf = types.ModuleType('tensorflow')
     tf.get_logger = lambda: types.SimpleNamespace(setLevel=lambda *_: None)
     keras = types.ModuleType('tensorflow.keras')
@@ -199,6 +210,41 @@ def install_stubs():
                         'tensorflow.keras.backend': backend,
                         'tensorflow.keras.losses': losses,
                         'tensorflow.keras.metrics': metrics})
+
+
+class _LoggedKerasModel:
+    """A REAL Keras model whose predict() calls are logged like the stand-in's (the stage fixtures are the
+    inputs / outputs of those calls)."""
+
+    def __init__(self, model, path):
+        self._model = model
+        self.kind = 'scaler' if 'scaler' in os.path.basename(path) else 'demux'
+
+    def __getattr__(self, name):
+        return getattr(self._model, name)
+
+    def predict(self, x, *a, **kw):
+        out = np.asarray(self._model.predict(x, *a, **kw), dtype=np.float32)
+        PREDICT_LOG.append((self.kind, np.asarray(x, dtype=np.float32)[:, :, 0].copy(), out.copy()))
+        return out
+
+
+def wrap_real_keras(tf):
+    real_load = tf.keras.models.load_model
+    tf.keras.models.load_model = lambda p, *a, **kw: _LoggedKerasModel(real_load(p, *a, **kw), p)
+
+
+def install_engines():
+    """tools/golden_engines.py: real TensorFlow / pomegranate where they import, oracle stand-ins where they do not."""
+    global ENGINES, OUT
+    ENGINES = GE.select(ENGINE_MODE, install_keras_stub, install_hmm_stub, wrap_real_keras)
+    if GE.any_real(ENGINES):
+        # a set with a real engine never replaces the bit-exact sets: tolerance tests read it from its own place
+        if ONLY:
+            raise SystemExit('--only rewrites fixtures of the bit-exact sets: use --engines stub with it')
+        OUT = os.path.join(REPO, 'tests', 'golden', 'real') if ARITH == 'f32' else os.path.join(REPO, 'tests', 'golden', 'real', 'q8')
+        os.makedirs(OUT, exist_ok=True)
+    print('engines:', ENGINES, '->', OUT, file=sys.stderr)
 
 
 # --------------------------------------------------------------------------
@@ -350,7 +396,7 @@ def build_read_set(rng):
 def main():
     global ORACLE
     build_shadow()
-    install_stubs()
+    install_engines()
     cfg_mine = default_config()
     ORACLE = Oracle(cfg_mine)
 
@@ -949,6 +995,7 @@ def main():
         pol.append({'index': i, 'read_id': rid, 'polya': res.get('polya')})
     with open(os.path.join(OUT, 'polya.json'), 'w') as fh:
         json.dump(jsonable(pol), fh, indent=1)
+    GE.write(OUT, ENGINES, {'arith': ARITH, 'python': sys.version.split()[0], 'numpy': np.__version__})
     print('wrote goldens to', OUT, {f: os.path.getsize(os.path.join(OUT, f))
                                      for f in sorted(os.listdir(OUT))})
 
@@ -958,6 +1005,6 @@ if __name__ == '__main__':
     if ONLY:
         import shutil
         for name in sorted(os.listdir(OUT)):
-            if name.startswith(ONLY):
+            if name.startswith(ONLY) or name == 'engines.json':
                 shutil.copy(os.path.join(OUT, name), os.path.join(_FINAL, name))
                 print('kept', name)
