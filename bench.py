@@ -137,10 +137,15 @@ def parse(argv=None):
                          '--total-reads sharded over the ranks) that the line carries as configs4_strong')
     ap.add_argument('--strong-base-reads', type=int, default=2048,
                     help='distinct reads of the configs4_strong leg (tiled on the device)')
-    ap.add_argument('--context-factory', default=None,
-                    help='TEST SEAM (module:attr): CPU rendezvous tests of the multi-rank driver '
-                         'inject a stand-in context; the line then says data=TEST-STANDIN, value=null')
     return ap.parse_args(argv)
+
+
+# The CPU rendezvous tests of the multi-rank driver (tests/test_distributed_cpu.py) run this file's main() through
+# tests/bench_standin.py, which sets the two names below to a stand-in context class and to its own path.  bench.py
+# itself has no way to set them -- no flag, no environment variable: the file that prints the headline can only
+# build the HIP context (a line made with a stand-in says data = TEST-STANDIN and value = null).
+CONTEXT_CLASS = None
+ENTRY_SCRIPT = os.path.abspath(__file__)
 
 
 def respawn_ranks(args):
@@ -152,7 +157,7 @@ def respawn_ranks(args):
         port = s.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
            '--nproc-per-node={}'.format(args.gpus), '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           '--master-port', str(port), ENTRY_SCRIPT] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     sys.stdout.flush()
     os.execvpe(cmd[0], cmd, env)
@@ -248,9 +253,7 @@ def end_to_end(args, config, rank, local_rank, world, dist, standin, base, which
     from poreplex_amd.synth import synth_basecalls
     from poreplex_amd.worker_persistence import WorkerPersistenceStorage
     if standin:
-        import importlib
-        mod, attr = args.context_factory.split(':')
-        N.NativeContext = getattr(importlib.import_module(mod), attr)
+        N.NativeContext = CONTEXT_CLASS
     work = tempfile.mkdtemp(prefix='pxg_e2e_r{}_'.format(rank))
     # the output directory is shared by the ranks (rank 0 stitches their part files)
     outdir = os.path.join(tempfile.gettempdir(), 'pxg_e2e_out_{}_{}'.format(
@@ -852,6 +855,49 @@ def f32_leg(args, config, local_rank, base, inject, mask, res_q8, stage_ms_q8):
     }
 
 
+def latency_leg(ctx, base, inject, mask, n_small=1024, reps=4):
+    """Small resident batches: the stage times of an `n_small`-read batch with the latency forms of
+    K2 / K5a / K5b (k_lstm_q8_lat.hip: 4-read tiles on four times as many CUs, chosen by the launchers up to 8 x #CU
+    reads) and with the 16-read-tile kernels forced on the same batch (PXG_K2_LAT_MAX = PXG_K5_LAT_MAX = 0); the
+    records of the two runs must be identical."""
+    n_small = min(n_small, len(base['offsets']) - 1)
+    o = base['offsets']
+    arena, off = base['arena'][:o[n_small]], o[:n_small + 1]
+    cal = base['calib'][:n_small]
+    ctx.upload(arena, off, cal, None if inject is None else inject[:n_small])
+    out = {'reads': int(n_small), 'best_of': reps}
+    recs = {}
+    saved = {k: os.environ.get(k) for k in ('PXG_K2_LAT_MAX', 'PXG_K5_LAT_MAX')}
+    try:
+        for mode in ('tile_form', 'latency_form'):
+            for k in saved:
+                if mode == 'tile_form':
+                    os.environ[k] = '0'
+                else:
+                    os.environ.pop(k, None)
+            best = None
+            for _ in range(reps):
+                ctx.run(mask)
+                ctx.sync()
+                ms, _n = ctx.stage_times()
+                if best is None or ms['total'] < best['total']:
+                    best = ms
+            recs[mode] = ctx.download()
+            out[mode] = {k: round(best[k], 4) for k in ('scaler_lstm', 'segment', 'demux_bidir', 'demux_top', 'total')}
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    out['records_identical'] = bool(all(np.array_equal(recs['tile_form'][f], recs['latency_form'][f], equal_nan=True)
+                                        for f in recs['tile_form'].dtype.names))
+    out['speedup_K2'] = round(out['tile_form']['scaler_lstm'] / out['latency_form']['scaler_lstm'], 3) if out['latency_form']['scaler_lstm'] else None
+    out['speedup_batch'] = round(out['tile_form']['total'] / out['latency_form']['total'], 3) if out['latency_form']['total'] else None
+    out['K2_cycles_per_step_at_2.2GHz'] = round(out['latency_form']['scaler_lstm'] * 1e-3 / 2001 * 2.2e9)
+    return out
+
+
 def full_leg(args, ctx, base, lens, inject, orc, n_check=64, big_reads=100000):
     """BASELINE configs[3] inside the default line: the demux stages + poly(A) (K6) + the Guppy block means (K7a) + the
     pseudo-fusion window scan (K7b) on the SAME resident 10 000-read batch, timed like the headline (kernels + D2H of
@@ -978,10 +1024,8 @@ def full_leg(args, ctx, base, lens, inject, orc, n_check=64, big_reads=100000):
 
 
 def make_context(args, config, local_rank):
-    if args.context_factory:
-        import importlib
-        mod, attr = args.context_factory.split(':')
-        return getattr(importlib.import_module(mod), attr)(config, device_id=local_rank)
+    if CONTEXT_CLASS is not None:
+        return CONTEXT_CLASS(config, device_id=local_rank)
     return N.NativeContext(config, device_id=local_rank)
 
 
@@ -1001,7 +1045,7 @@ def main():
     if args.gpus != world:
         raise SystemExit('bench.py: --gpus {} but WORLD_SIZE {} (launch with --nproc-per-node {} '
                          'or without a launcher)'.format(args.gpus, world, args.gpus))
-    standin = args.context_factory is not None
+    standin = CONTEXT_CLASS is not None
     config = default_config()
     if args.lstm_arith:
         os.environ.pop('PXG_LSTM_ARITH', None)
@@ -1456,6 +1500,60 @@ def main():
     if not standin and world == 1 and not args.no_e2e_leg and not n_base and not use_inject and \
             args.workload == 'demux' and not SHARE_GPU and not force_dist:
         extra['end_to_end'] = end_to_end_legs(args)
+
+    # ---- what the driver keeps: `parsed.roofline` whole (it drops `extra`).  Everything somebody needs to answer "what
+    # did configs[3] do, which kernel is furthest from its roof, what does a small batch get" goes in here; LIVE
+    # figures (this box, HIP events of this run) and STATIC ones (committed rocprofv3 files) in separate sub-dicts ----
+    if roofline is not None and not standin and world == 1 and args.workload == 'demux':
+        live = {'source': 'HIP events on the context stream, this run, this box', 'kernel_ms': roofline.get('kernel_ms'),
+                'achieved': roofline.get('achieved'), 'frac': roofline.get('frac'), 'device': info['name'],
+                'clock_khz_reported': info.get('clock_khz')}
+        static = {k: roofline.get(k) for k in ('rocprof_avg_ms', 'rocprof_launches', 'frac_at_rocprof_avg', 'rocprof_source',
+                                               'clock_GHz_in_profile', 'clock_source', 'traffic', 'traffic_source') if k in roofline}
+        roofline['live'], roofline['static'] = live, static
+        n_demux = int(res['bc_pushed'].sum())
+        kern = []
+
+        def krow(name, ms, bound, work, peak, unit, what):
+            row = {'name': name, 'ms': round(ms, 4), 'bound': bound, 'what': what, 'counters_source': 'live HIP events (this run)'}
+            if ms and work:
+                row.update({'achieved': work / (ms * 1e-3) / (1e9 if bound == 'hbm' else 1e12), 'peak': peak / (1e9 if bound == 'hbm' else 1e12),
+                            'unit': unit, 'frac': work / (ms * 1e-3) / peak})
+            kern.append(row)
+        head_bytes = float(np.minimum(lens, 30000).sum() * 2 + n_local * 2000 * 4)
+        krow('k_head_pool (K1)', stage_ms['head_pool'], 'hbm', head_bytes, PEAK_HBM, 'GB/s', 'first 30 000 samples in, 2 000 block means out')
+        krow('k_scaler_lstm_q8 (K2)', stage_ms['scaler_lstm'], 'mfma', n_scaled * OPS_SCALER_Q8 if arith == 'q8' else n_scaled * FLOP_SCALER,
+             PEAK_I8_MFMA if arith == 'q8' else PEAK_FP32_MFMA, 'TOP/s (int8)' if arith == 'q8' else 'TFLOP/s', 'scaler LSTM: the dominant kernel')
+        krow('k_viterbi_ltr (K3)', stage_ms['segment'], 'hbm', float(np.minimum(lens, 100000).sum() * 2 + n_local * 88), PEAK_HBM, 'GB/s',
+             'pool + scale + 6-state Viterbi + run-length summary: fp64 VALU issue (producers + recurrence), not HBM')
+        krow('k_barcode_window_raw (K4)', stage_ms['barcode_window'], 'hbm', float(n_local * (300 * 15 * 2 + 1200)), PEAK_HBM, 'GB/s', 'wave per read: latency')
+        krow('k_demux_bidir_q8 (K5a)', stage_ms['demux_bidir'], 'mfma', n_demux * Q8_PRODUCTS * 2.0 * 300 * 2 * (48 * 192) if arith == 'q8' else n_demux * FLOP_BIDIR,
+             PEAK_I8_MFMA if arith == 'q8' else PEAK_FP32_MFMA, 'TOP/s (int8)' if arith == 'q8' else 'TFLOP/s', 'bidirectional layer of the demux net')
+        krow('k_demux_top_q8 (K5b)', stage_ms['demux_top'], 'mfma', n_demux * Q8_PRODUCTS * 2.0 * 300 * (160 * 256) if arith == 'q8' else n_demux * FLOP_TOP,
+             PEAK_I8_MFMA if arith == 'q8' else PEAK_FP32_MFMA, 'TOP/s (int8)' if arith == 'q8' else 'TFLOP/s', 'top cell + dense + softmax')
+        roofline['kernels'] = kern
+        fracs = [(k['frac'], k['name']) for k in kern if k.get('frac')]
+        if fracs:
+            roofline['furthest_from_its_roof'] = min(fracs)[1]
+        if isinstance(extra.get('full'), dict) and 'reads_per_s' in extra['full']:
+            fl = extra['full']
+            roofline['full'] = {'config': 'BASELINE configs[3]: + poly(A) (K6) + Guppy block means (K7a) + pseudo-fusion scan (K7b), same resident batch',
+                                'reads_per_s': fl['reads_per_s'], 'ms_per_step': fl['ms_per_step'],
+                                'stage_ms': {k: fl['stage_ms'].get(k) for k in ('polya', 'event_means', 'unsplit', 'finalize', 'total')},
+                                'at_100000_reads': fl.get('at_100000_reads'),
+                                'concordance_ok': (fl.get('concordance') or {}).get('all_fields_bit_exact') if fl.get('concordance') else None,
+                                'unsplit_candidate_mismatch': (fl.get('concordance') or {}).get('unsplit_candidate_mismatch')}
+        try:
+            lat = latency_leg(ctx, base, inject, mask)
+            if api is not None and 'reference_batch_size_128' in api:
+                r128 = api['reference_batch_size_128']
+                lat['process_batch_128_read_calls'] = {'reads_per_s_32_threads': r128['reads_per_s'],
+                                                       'reads_per_s_one_call_at_a_time': r128['one_call_at_a_time_reads_per_s'],
+                                                       'mean_phase_ms_per_call': r128.get('mean_phase_ms_per_call'),
+                                                       'merge_stats': r128.get('merge_stats')}
+            roofline['latency_form'] = lat
+        except Exception as exc:                       # reported, never hidden
+            roofline['latency_form'] = {'error': '{}: {}'.format(type(exc).__name__, exc)}
 
     line = {
         'metric': wl_metric,

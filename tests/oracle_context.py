@@ -3,7 +3,7 @@
 Test infrastructure only: it lets the CPU suite drive the HOST logic that sits on top of the
 GPU context (facade ordering / status rules, the session driver, bench.py's multi-rank
 plumbing over gloo) in a container without a GPU.  Nothing under poreplex_amd/ imports it;
-tests inject it (monkeypatch, or bench.py's --context-factory test seam, whose JSON line is
+tests inject it (monkeypatch, or tests/bench_standin.py around bench.py's main(), whose JSON line is
 then marked TEST-STANDIN and carries no value).
 """
 import numpy as np

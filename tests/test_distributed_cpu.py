@@ -101,7 +101,7 @@ def test_bench_self_spawns_two_ranks_over_gloo():
     itself under torch.distributed.run, both ranks take part (counted by the collective),
     the label records of the whole run arrive on rank 0 with a GLOBAL, duplicate-free
     read_index, and stdout carries exactly one JSON line.  The GPU context is replaced by the
-    oracle test double through bench.py's test seam (the line is marked TEST-STANDIN)."""
+    oracle test double by tests/bench_standin.py (bench.py itself has no such seam; the line is marked TEST-STANDIN)."""
     import json
     env = {k: v for k, v in os.environ.items()
            if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
@@ -109,9 +109,9 @@ def test_bench_self_spawns_two_ranks_over_gloo():
     for scaling, extra, total in (('weak', ['--reads', '12', '--total-reads', '31', '--strong-base-reads', '5'], 24),
                                   ('strong', ['--total-reads', '25', '--base-reads', '7'], 25)):
         out = subprocess.run(
-            [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2',
+            [sys.executable, os.path.join(ROOT, 'tests', 'bench_standin.py'), '--gpus', '2', '--steps', '2',
              '--warmup', '1', '--samples', '12000', '--cpu-sample', '0', '--cpu-all-cores-sample', '0',
-             '--scaling', scaling, '--context-factory', 'oracle_context:OracleBackedContext'] + extra,
+             '--scaling', scaling] + extra,
             env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
         assert out.returncode == 0, out.stdout + out.stderr
         lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
@@ -149,9 +149,8 @@ def test_bench_end_to_end_two_ranks_over_gloo():
            if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
     env['PYTHONPATH'] = os.path.join(ROOT, 'tests') + os.pathsep + env.get('PYTHONPATH', '')
     out = subprocess.run(
-        [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--end-to-end', '--reads', '14',
-         '--batch-reads', '5', '--samples', '12000', '--cpu-sample', '0', '--cpu-all-cores-sample', '0',
-         '--context-factory', 'oracle_context:OracleBackedContext'],
+        [sys.executable, os.path.join(ROOT, 'tests', 'bench_standin.py'), '--gpus', '2', '--end-to-end', '--reads', '14',
+         '--batch-reads', '5', '--samples', '12000', '--cpu-sample', '0', '--cpu-all-cores-sample', '0'],
         env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
@@ -192,6 +191,22 @@ def test_bench_two_ranks_sharing_the_gpu_with_real_kernels():
         assert x['pcie_over_ranks'][key]['min'] > 0
     c = line['concordance']
     assert c is None or (c['status_mismatch'] == 0 and c['all_fields_bit_exact'])
+    # BASELINE configs[4] as the headline of its own line: --scaling strong, ONE seeded run of 1 501 reads
+    # over the two ranks -- an odd total, so the shards are uneven (751 + 750) --, each rank bound to the NUMA node
+    # of its GPU, every label arriving once with its global read_index
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+         '--scaling', 'strong', '--total-reads', '1501', '--base-reads', '96', '--samples', '20000',
+         '--cpu-sample', '0', '--cpu-all-cores-sample', '0'],
+        env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.strip()][0])
+    x = line['extra']
+    assert line['n_gpus'] == 2 and line['scaling'] == 'strong' and line['value'] > 0
+    assert sorted(line['config']['reads_per_gpu']) == [750, 751] and line['config']['total_reads_per_step'] == 1501
+    assert 'configs[4]' in line['config']['workload']
+    assert x['ranks_counted_by_collective'] == 2 and x['labels_gathered'] == 1501 and x['labels_read_index_unique'] is True
+    assert 'numa' in x and 'numa_node' in x['numa']
     # the session driver, two ranks, one GPU: loader threads, staging, sinks, label gather, count all-reduce
     out = subprocess.run(
         [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--end-to-end', '--reads', '300',

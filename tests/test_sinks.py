@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from poreplex_amd import io as SINK
+from poreplex_amd import sinks as SINK
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
