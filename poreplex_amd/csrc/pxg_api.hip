@@ -210,6 +210,8 @@ extern "C" int pxg_create(const pxg_config* cfg, pxg_ctx** out)
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
             hipStreamCreateWithFlags(&ctx->scan_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipStreamCreateWithFlags(&ctx->polya_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_polya_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_segmented, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_scan_gate, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->ev_scan_done, hipEventDisableTiming) != hipSuccess ||
@@ -256,6 +258,7 @@ extern "C" int pxg_create(const pxg_config* cfg, pxg_ctx** out)
         ctx->length_order = getenv("PXG_NO_LENGTH_ORDER") == nullptr;
         ctx->prefix_skip = getenv("PXG_NO_PREFIX_SKIP") == nullptr;
         ctx->scan_overlap = getenv("PXG_NO_SCAN_OVERLAP") == nullptr;
+        ctx->polya_overlap = getenv("PXG_NO_POLYA_OVERLAP") == nullptr;
         ctx->merge_small_calls = getenv("PXG_NO_CALL_MERGE") == nullptr;
         if (cfg->lstm_arith == PXG_LSTM_Q8 && (rc = pxg_q8_scaler_trajectory(ctx))) break;
     } while (0);
@@ -333,6 +336,8 @@ extern "C" void pxg_destroy(pxg_ctx* ctx)
         (void)hipStreamDestroy(ctx->stream);
         if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
         if (ctx->scan_stream) (void)hipStreamDestroy(ctx->scan_stream);
+        if (ctx->polya_stream) (void)hipStreamDestroy(ctx->polya_stream);
+        if (ctx->ev_polya_done) (void)hipEventDestroy(ctx->ev_polya_done);
         if (ctx->ev_scan_gate) (void)hipEventDestroy(ctx->ev_scan_gate);
         if (ctx->ev_segmented) (void)hipEventDestroy(ctx->ev_segmented);
         if (ctx->ev_scan_done) (void)hipEventDestroy(ctx->ev_scan_done);
@@ -780,6 +785,8 @@ extern "C" int pxg_host_unregister(pxg_ctx* ctx, void* ptr)
     return PXG_OK;
 }
 
+#define PXG_POLYA_BESIDE_MAX 20000
+
 extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
 {
     if (!ctx) return PXG_E_INVALID;
@@ -837,8 +844,38 @@ extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
         if ((rc = pxg_launch_segment_raw(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p,
                                          head, ctx->status.p, ctx->segs.p, order))) return rc;
         pxg_timer_end(ctx, PXG_T_SEGMENT);
-        if (ctx->scan_overlap && (stage_mask & PXG_STAGE_POLYA))     // (the block means of a scan call may be taken from here on)
+        if (stage_mask & PXG_STAGE_POLYA)     // (the block means of a scan call, and K6 itself, may be taken from here on)
             PXG_HIP(ctx, hipEventRecord(ctx->ev_segmented, ctx->stream));
+    }
+    ctx->polya_ran = false;
+    ctx->scan_gate_set = false;
+    // K6 beside the barcode kernels: everything it reads (samples, scaling, status, segments) is final behind K3
+    // (measured, profiles/r06/ab_k6_beside_k5*.txt: 10 000 reads -- K6's 2 500 waves are one launch round, the kernel
+    //  lasts as long as its longest windows and that tail now hides under K5a / K5b: `full` 14.8 -> 14.5-14.6 ms; at
+    //  100 000 reads K6 is throughput-bound and the issue-bound LSTM kernels lose more than K6 gains: 120 -> 123 ms --
+    //  so only batches of up to PXG_POLYA_BESIDE_MAX reads take the second stream)
+    const bool polya_beside = (stage_mask & PXG_STAGE_POLYA) && (stage_mask & PXG_STAGE_BARCODE) && ctx->polya_overlap &&
+                              ctx->polya_stream != nullptr && n <= PXG_POLYA_BESIDE_MAX;
+    auto run_polya = [&]() -> int {
+        int prc;
+        if ((prc = pxg_reserve(ctx, ctx->polya_out, (size_t)n * 8))) return prc;
+        pxg_timer_begin(ctx, PXG_T_POLYA);
+        if ((prc = pxg_launch_polya(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p,
+                                    ctx->status.p, ctx->segs.p, ctx->polya_out.p, ctx->spikes))) return prc;
+        pxg_timer_end(ctx, PXG_T_POLYA);
+        ctx->polya_ran = true;
+        return PXG_OK;
+    };
+    if (polya_beside) {
+        hipStream_t main = ctx->stream;
+        if (hipStreamWaitEvent(ctx->polya_stream, ctx->ev_segmented, 0) != hipSuccess) return fail(ctx, PXG_E_HIP, "poly(A) stream: wait");
+        ctx->stream = ctx->polya_stream;       // (every launch helper and timer takes ctx->stream; the caller holds the run lock)
+        rc = run_polya();
+        const hipError_t e = rc == PXG_OK ? hipEventRecord(ctx->ev_polya_done, ctx->polya_stream) : hipSuccess;
+        if (rc != PXG_OK) (void)hipStreamSynchronize(ctx->polya_stream);
+        ctx->stream = main;
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(ctx, PXG_E_HIP, "poly(A) stream: event");
     }
     if (stage_mask & PXG_STAGE_BARCODE) {
         pxg_timer_begin(ctx, PXG_T_BARCODE_WINDOW);
@@ -850,19 +887,16 @@ extern "C" int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask)
                                         ctx->bidir.p, ctx->probs.p, PXG_T_DEMUX_BIDIR,
                                         PXG_T_DEMUX_TOP))) return rc;
     }
-    ctx->polya_ran = false;
-    ctx->scan_gate_set = false;
     if (stage_mask & PXG_STAGE_POLYA) {
-        if ((rc = pxg_reserve(ctx, ctx->polya_out, (size_t)n * 8))) return rc;
-        if (ctx->scan_overlap) {        // a window scan called next may start here, beside K6 (pxg_common.h scan_stream)
+        if (ctx->scan_overlap) {        // a window scan called next may start here: behind the barcode kernels, beside K6 (or its tail)
             PXG_HIP(ctx, hipEventRecord(ctx->ev_scan_gate, ctx->stream));
             ctx->scan_gate_set = true;
         }
-        pxg_timer_begin(ctx, PXG_T_POLYA);
-        if ((rc = pxg_launch_polya(ctx, n, ctx->raw.p, ctx->offsets.p, ctx->calib.p, ctx->ss.p,
-                                   ctx->status.p, ctx->segs.p, ctx->polya_out.p, ctx->spikes))) return rc;
-        pxg_timer_end(ctx, PXG_T_POLYA);
-        ctx->polya_ran = true;
+        if (!polya_beside) {
+            if ((rc = run_polya())) return rc;
+        } else {
+            PXG_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_polya_done, 0));      // the records need K6's output
+        }
     }
     ctx->polya_unsettled = ctx->polya_ran;
     ctx->last_stage_mask = stage_mask;

@@ -328,6 +328,12 @@ struct pxg_ctx {
     hipStream_t scan_stream = nullptr;
     hipEvent_t ev_segmented = nullptr, ev_scan_gate = nullptr, ev_scan_done = nullptr;
     bool scan_gate_set = false, scan_overlap = true;
+    // round 6: K6 (poly(A)) needs nothing the barcode stage writes -- with both stages in a run it starts behind K3 on a
+    // stream of its own, beside K4 / K5a / K5b, and the main stream waits for it before the records are built
+    // (PXG_NO_POLYA_OVERLAP=1: behind K5b on the main stream, as until round 5)
+    hipStream_t polya_stream = nullptr;
+    hipEvent_t ev_polya_done = nullptr;
+    bool polya_overlap = true;
     hipEvent_t ev_staged = nullptr;
     hipEvent_t ev_run_done[2] = { nullptr, nullptr };   // last run on the resident / the spare inputs
     bool run_recorded[2] = { false, false };
