@@ -415,6 +415,8 @@ def process_batch_leg(args, base, which, lo, mask, local_rank, compressed, resid
                     verdict['same'] = verdict['same'] and r == first
                     verdict['last'] = r
             return k
+        if os.environ.get('PXG_BENCH_SWITCH_INTERVAL'):       # (experiment knob: the interpreter's GIL hand-over interval)
+            sys.setswitchinterval(float(os.environ['PXG_BENCH_SWITCH_INTERVAL']))
         with ThreadPoolExecutor(max(args.in_flight, 1)) as pool:
             t0 = time.perf_counter()
             list(pool.map(one_call, range(calls)))

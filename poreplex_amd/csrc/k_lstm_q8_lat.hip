@@ -26,6 +26,7 @@
 // Same integers, same float32 operations per cell as k_scaler_lstm_q8 and the oracle: bit-exact by construction
 // (tests/test_gpu_parity.py scaler hooks run this kernel for every n <= 8 x #CU).  No time-slicing and no zero-pad
 // prefix table: every tile is resident and takes all T + 1 iterations.
+#include <type_traits>
 #include "k_lstm_q8.h"
 
 #define QL_STRIP 384                    // one k group of one hidden vector: [6 positions][4 reads][16 bytes]
@@ -38,6 +39,10 @@
 #define DPP_ROW_SHR(n) (0x110 + (n))
 #define DPP_ROW_ROR(n) (0x120 + (n))
 
+// (Tried: the w1 / w0 fragments as DPP-shifted copies of the w2 fragment -- the lane's slot then holds what slot - N
+//  of it holds, zero-filled -- instead of further ds_read_b128 of the same bytes: K2 1.58 -> 1.75 ms at 1 024 reads, the
+//  last fragment of the half block alone 1.58 -> 1.65 (profiles/r06/ab_lat_forms.txt).  The step is bound by its
+//  dependent chain, not by LDS bandwidth: independent reads arrive back to back, the moves wait for the first.)
 // level l in slot l of every 16-lane row -> V = A0 256 + A1 in slot 1, U = A2 256 + A3 in slot 3
 __device__ __forceinline__ int ql_words(int acc)
 {
@@ -78,7 +83,7 @@ __global__ __launch_bounds__(QL_THREADS) void k_scaler_lstm_q8_lat(
     int* ridx = reinterpret_cast<int*>(xb + 2 * 4 * QL_XS);                            // [4]
 
     const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3;
-    const bool l1 = tid < 256;                  // waves 0-3: layer 1, waves 4-7: layer 2
+    const bool l1 = __builtin_amdgcn_readfirstlane(tid) < 256;      // waves 0-3: layer 1, waves 4-7: layer 2 (wave-uniform: scalar branches)
     const int ftid = tid & 255;                 // (the fragments are laid out for 4 waves)
     const int rd = lane & 3, slot = (lane >> 2) & 3, a = lane >> 4, kg = lane >> 4;
 
@@ -126,7 +131,10 @@ __global__ __launch_bounds__(QL_THREADS) void k_scaler_lstm_q8_lat(
     float k65536;                              // (kept in a register: the DPP forms take no literal)
     asm volatile("v_mov_b32 %0, 0x47800000" : "=v"(k65536));
     const v4i z = {0, 0, 0, 0};
-    for (int t = 0; t <= T; t++) {
+    // one iteration; ACT: this wave's layer runs a step in it (layer 1: t < T, layer 2: t >= 1 -- wave-uniform, and
+    // false only in the first / last iteration, which are peeled so that the T - 1 steady-state steps carry no select)
+    auto step = [&](int t, auto act_c) {
+        constexpr bool ACT = decltype(act_c)::value;
         const unsigned char* hr = hv + (t & 1) * QL_HV;
         unsigned char* hw = hv + ((t + 1) & 1) * QL_HV;
         const int tc = t & (XCH - 1);
@@ -142,9 +150,13 @@ __global__ __launch_bounds__(QL_THREADS) void k_scaler_lstm_q8_lat(
         for (int nt = 0; nt < 3; nt++) acc[nt] = mfma8(wq[nt][1], f1, acc[nt]);
 #pragma unroll
         for (int nt = 0; nt < 3; nt++) acc[nt] = mfma8(wq[nt][2], f0, acc[nt]);
-        float x = 0.0f;
+        f32x4 u[1];
         if (l1) {
-            x = xb[((t / XCH) & 1) * 4 * QL_XS + rd * QL_XS + tc];
+            const float x = xb[((t / XCH) & 1) * 4 * QL_XS + rd * QL_XS + tc];
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                u[0][r] = __builtin_fmaf(ql_levels3(acc[0][r], acc[1][r], acc[2][r], k65536), sc[r],
+                                         __builtin_fmaf(x, stW[r], stB[r]));
         } else {
             const v4i f4 = *reinterpret_cast<const v4i*>(hr + off4);
             const v4i f5 = *reinterpret_cast<const v4i*>(hr + off5);
@@ -152,19 +164,17 @@ __global__ __launch_bounds__(QL_THREADS) void k_scaler_lstm_q8_lat(
             for (int nt = 0; nt < 3; nt++) acc[nt] = mfma8(wq[nt][3], f4, acc[nt]);
 #pragma unroll
             for (int nt = 0; nt < 3; nt++) acc[nt] = mfma8(wq[nt][4], f5, acc[nt]);
-        }
-        f32x4 u[1];
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-            u[0][r] = __builtin_fmaf(ql_levels3(acc[0][r], acc[1][r], acc[2][r], k65536), sc[r],
-                                     __builtin_fmaf(x, stW[r], stB[r]));
-        // layer 1 runs step t (t < T), layer 2 step t - 1 (t >= 1): an idle cell keeps its state and publishes zeros
-        const bool act = l1 ? (t < T) : (t >= 1);
-        float Cn[1] = {C}, hn[1];
-        cells_update<1>(tab, u, Cn, hn);
-        C = act ? Cn[0] : C;
-        unsigned q = q8_biased(hn[0]) ^ 0x00808080u;
-        q = act ? q : 0u;
+            for (int r = 0; r < 4; r++)
+                u[0][r] = __builtin_fmaf(ql_levels3(acc[0][r], acc[1][r], acc[2][r], k65536), sc[r], stB[r]);
+        }
+        unsigned q = 0u;                        // an idle cell keeps its state and publishes zeros
+        if (ACT) {
+            float Cn[1] = {C}, hn[1];
+            cells_update<1>(tab, u, Cn, hn);
+            C = Cn[0];
+            q = q8_biased(hn[0]) ^ 0x00808080u;
+        }
         if (publishes) {
             hw[pub + 128] = (unsigned char)(q >> 16);
             hw[pub + 192] = (unsigned char)(q >> 8);
@@ -172,7 +182,11 @@ __global__ __launch_bounds__(QL_THREADS) void k_scaler_lstm_q8_lat(
         }
         if (l1 && tc == XCH - 1) xb[(((t / XCH) + 1) & 1) * 4 * QL_XS + xrow * QL_XS + xcol] = xnext;
         __syncthreads();
-    }
+    };
+    // layer 1 runs step t in iteration t (t < T), layer 2 step t - 1 (t >= 1)
+    if (l1) step(0, std::true_type()); else step(0, std::false_type());
+    for (int t = 1; t < T; t++) step(t, std::true_type());
+    if (T >= 1) { if (l1) step(T, std::false_type()); else step(T, std::true_type()); }
 
     // ---- Dense(2): fma chain over k = 0..47 from the bias, on h = q * 2^-22 ----------
     const unsigned char* hf = hv + ((T + 1) & 1) * QL_HV;

@@ -54,7 +54,8 @@ def step_loop(body):
                     cur['header'] = h.group(1)
                 continue
             cur['lines'].append(ln)
-    owner = next(b['header'] for b in blocks if any('v_mfma' in x for x in b['lines']))
+    owners = collections.Counter(b['header'] for b in blocks if b['header'] and any('v_mfma' in x for x in b['lines']))
+    owner = owners.most_common(1)[0][0]         # (peeled first / last iterations hold MFMAs outside any loop)
     return [x for b in blocks if b['header'] == owner for x in b['lines']]
 
 
