@@ -123,6 +123,44 @@ def lat_groups(ops):
     ]
 
 
+def clamp_bounds():
+    """where can the host PROVE that a look-up never leaves the table, so that its v_med3 clamp is a
+    no-op?  Vector-input layers only (|h| <= 1 for every input): |u| <= g (sum |W_col| + sum |U_col| + |b|)."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from poreplex_amd.config import default_config
+    from poreplex_amd import native as N
+    nc = N.NativeConfig(default_config(), 0)        # (owns the weight arrays the struct points at)
+    st = nc.struct
+    print('=' * 100)
+    print('(a) clamp-free look-ups: provable bound of |u| (table units; the clamp is at [-512, 511.99997]) per gate block i, f, g, o')
+    for name, kernel in (('scaler_lstm1', 'K2 layer 1'), ('scaler_lstm2', 'K2 layer 2'), ('demux_fwd', 'K5a forward'),
+                         ('demux_bwd', 'K5a backward'), ('demux_top', 'K5b')):
+        L = getattr(st, name)
+        H, I = L.units, L.input_dim
+        G = 4 * H
+        k = np.ctypeslib.as_array(L.kernel, shape=(I * G,)).reshape(I, G)
+        r = np.ctypeslib.as_array(L.recurrent, shape=(H * G,)).reshape(H, G)
+        b = np.ctypeslib.as_array(L.bias, shape=(G,))
+        scale = np.repeat([16.0, 16.0, 32.0, 16.0], H)
+        if I == 1:
+            print('  {:14s} {:13s} scalar input x is unbounded: no bound (recurrent part alone: {})'.format(
+                name, kernel, [round(float(((np.abs(r).sum(0) + np.abs(b)) * scale)[g * H:(g + 1) * H].max()), 1) for g in range(4)]))
+            continue
+        tu = (np.abs(k).sum(0) + np.abs(r).sum(0) + np.abs(b)) * scale
+        bounds = [round(float(tu[g * H:(g + 1) * H].max()), 1) for g in range(4)]
+        print('  {:14s} {:13s} {}  -> provable for gate blocks {}'.format(name, kernel, bounds, [g for g in range(4) if bounds[g] < 511.99]))
+    print('  => with the shipped weights only layer 2 of K2 has provable blocks, and only i and f (511.9 and 503.2: by a hair):'
+          ' 6 of its 463 VALU per wave and step (1.3 %); K5b none.  Not built: a kernel variant per provable block for < 1 % of K2.')
+    print('(b) the v_lshl_add of a look-up IS its address computation ((segment + 512) * 16 bytes): there is no separate add to fold; '
+          'ds_read_b128 takes a byte address register + a 16-bit immediate, no scaled index.')
+    print('(c) digits of q: already v_perm_b32 (one per digit plane and cell pair) on q + 0x808080 -- 2 VALU per cell '
+          '(fma to the biased integer, one integer add) + 3 v_perm + 3 v_xor per three cells: no subtract / divide chain exists.')
+    print('(d) a quadratic spline would save one fma per look-up (30 of 463) but needs ~4 096 segments for the cubic\'s 1e-8 '
+          '(error ~ h^3 max|f\'\'\'| / (9 sqrt 3): 2e-6 at h = 1/16), a 64 KB table against 16 KB: K2 runs two workgroups of 81.5 KB per CU '
+          'of 160 KB -- no room.  Not taken.')
+
+
 if __name__ == '__main__':
     print('LSTM step-loop instruction budgets, from the ISA of this tree (tools/valu_budget.py; hipcc ' +
           subprocess.run(['/opt/rocm/bin/hipcc', '--version'], capture_output=True, text=True).stdout.splitlines()[0] + ')')
@@ -135,3 +173,4 @@ if __name__ == '__main__':
            ('-mllvm', '-amdgpu-sched-strategy=iterative-ilp'))
     report('K5b k_demux_top_q8 (16-read tile, 64-unit top cell)', 'k_lstm_q8_demux.hip', 'k_demux_top_q8i', k2_groups,
            ('-mllvm', '-amdgpu-sched-strategy=iterative-ilp'))
+    clamp_bounds()
