@@ -56,7 +56,7 @@ PEAK_HBM = 8.0e12              # B/s
 # the only throughput the reference publishes (Poreplex 0.1, whole
 # pipeline incl. FAST5 I/O, 2x Xeon E5-2687W v3 = 20 cores): 1 339 070 reads in 1 h 37 min
 PUBLISHED_READS_PER_S = 1339070 / (97 * 60.0)
-TRAFFIC_FILE = os.path.join('profiles', 'r05', 'k_hbm_traffic.json')
+TRAFFIC_FILE = os.path.join('profiles', 'r06', 'k_hbm_traffic.json')
 # PXG_BENCH_SHARE_GPU=1: every rank of a torchrun launch uses GPU 0 and the collectives go over gloo --
 # the real multi-process path (sharding, barriers, max over ranks, label gather, NUMA binding, the
 # host-side legs on all ranks at once) with the real kernels on a ONE-GPU box.  A plumbing check:
@@ -137,6 +137,8 @@ def parse(argv=None):
                          '--total-reads sharded over the ranks) that the line carries as configs4_strong')
     ap.add_argument('--strong-base-reads', type=int, default=2048,
                     help='distinct reads of the configs4_strong leg (tiled on the device)')
+    ap.add_argument('--no-latency-leg', action='store_true',
+                    help='skip the small-batch leg (roofline.latency_form: a 1 024-read batch with and without the latency forms of K2 / K5)')
     return ap.parse_args(argv)
 
 
@@ -680,9 +682,9 @@ def strong_leg(args, ctx, dist, rank, world, mask, standin, force_dist, barrier)
 
 FLIPS_FILE = os.path.join('profiles', 'r04', 'decision_flips.json')
 FLIPS_GPU_FILE = os.path.join('profiles', 'r05', 'decision_flips_gpu_160k_reads.json')
-BOUNDS_FILE = os.path.join('profiles', 'r05', 'full_kernel_bounds.json')
-ROCPROF_STATS = {'demux': os.path.join('profiles', 'r05', 'k_demux_kernel_stats.csv'),
-                 'full': os.path.join('profiles', 'r05', 'k_full_kernel_stats.csv')}
+BOUNDS_FILE = os.path.join('profiles', 'r06', 'full_kernel_bounds.json')
+ROCPROF_STATS = {'demux': os.path.join('profiles', 'r06', 'k_demux_kernel_stats.csv'),
+                 'full': os.path.join('profiles', 'r06', 'k_full_kernel_stats.csv')}
 
 
 def unpinned_rows_block():
@@ -995,7 +997,7 @@ def full_leg(args, ctx, base, lens, inject, orc, n_check=64, big_reads=100000):
             ('k_polya (K6)', 'polya', None, 'serial peak FSM + interval DP per read (16 lanes per read): issue / latency bound'),
             ('k_guppy_event_means (K7a)', 'event_means', samples * 2 + blocks * 4,
              'every int16 sample in once, one float32 block mean out; fp64 pA conversion: VALU issue at HBM rate'),
-            ('k_unsplit_scan (K7b)', 'unsplit', None, 'fp64 Viterbi recurrence, one window per lane, ~6 overlapping windows per read: fp64 issue + LDS latency at one wave per SIMD')):
+            ('k_unsplit_scan_w (K7b)', 'unsplit', None, 'fp64 Viterbi recurrence, one window per lane, ~6 overlapping windows per read: fp64 issue + LDS latency at one wave per SIMD')):
         ms = stage_ms[timer]
         row = {'kernel': name, 'bound': 'hbm' if alg_bytes else 'issue', 'kernel_ms': round(ms, 4), 'what': what}
         if alg_bytes and ms:
@@ -1488,10 +1490,10 @@ def main():
             with open(os.path.join(ROOT, BOUNDS_FILE)) as fh:
                 kb = json.load(fh)['kernels']
             extra['kernel_bounds'] = {
-                'source': 'static: {} (rocprofv3 PMC passes of --workload full)'.format(BOUNDS_FILE),
+                'source': 'static: {} (rocprofv3 PMC passes of --workload full, scan and poly(A) behind the run: PXG_NO_SCAN_OVERLAP=1 PXG_NO_POLYA_OVERLAP=1)'.format(BOUNDS_FILE),
                 'k_polya': dict(kb['k_polya'], bound='latency / divergence of a per-read FSM: 40 % of the SIMD cycles issue '
                                 'VALU, a third of the instructions are scalar, waves wait 45 % of their cycles'),
-                'k_unsplit_scan': dict(kb['k_unsplit_scan'], bound='one window per lane (round 5): fp64 issue + LDS round trips at one '
+                'k_unsplit_scan_w': dict(kb.get('k_unsplit_scan_w') or kb['k_unsplit_scan'], bound='one window per lane (round 5): fp64 issue + LDS round trips at one '
                                        'wave per SIMD (the 8-lane kernel of round 4: 70 % VALU issue, 2.95 ms)'),
                 'k_guppy_event_means': dict(kb['k_guppy_event_means'], bound='VALU issue 98 % (fp64 pA conversion, median-of-5 '
                                             'network) at 3.1 TB/s of HBM traffic'),
@@ -1546,6 +1548,8 @@ def main():
                                 'concordance_ok': (fl.get('concordance') or {}).get('all_fields_bit_exact') if fl.get('concordance') else None,
                                 'unsplit_candidate_mismatch': (fl.get('concordance') or {}).get('unsplit_candidate_mismatch')}
         try:
+            if args.no_latency_leg:
+                raise N.PxgError('skipped (--no-latency-leg)')
             lat = latency_leg(ctx, base, inject, mask)
             if api is not None and 'reference_batch_size_128' in api:
                 r128 = api['reference_batch_size_128']

@@ -3,7 +3,7 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 for rep in 1 2; do for lib in "$@"; do
   for wl in segment demux; do
-  PXG_LIBRARY=$PWD/$lib python bench.py --workload $wl --steps 10 --warmup 3 --cpu-sample ${AB_CPU_SAMPLE:-32} --cpu-all-cores-sample 0 --no-overlap-test --no-api-leg --no-fast5-leg --no-e2e-leg --no-f32-leg --no-run-shaped-leg --no-full-leg 2>/dev/null | python -c "
+  PXG_LIBRARY=$PWD/$lib python bench.py --workload $wl --steps 10 --warmup 3 --cpu-sample ${AB_CPU_SAMPLE:-32} --cpu-all-cores-sample 0 --no-overlap-test --no-api-leg --no-fast5-leg --no-e2e-leg --no-f32-leg --no-run-shaped-leg --no-full-leg --no-latency-leg 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 s=d['extra']['stage_ms']

@@ -5,7 +5,7 @@ TAG=${1:-refresh}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
-B="python bench.py --cpu-sample 0 --cpu-all-cores-sample 0 --no-api-leg --no-fast5-leg --no-e2e-leg --no-f32-leg --no-run-shaped-leg --no-full-leg"
+B="python bench.py --cpu-sample 0 --cpu-all-cores-sample 0 --no-api-leg --no-fast5-leg --no-e2e-leg --no-f32-leg --no-run-shaped-leg --no-full-leg --no-latency-leg"
 python bench.py --steps 20 --warmup 5 > $OUT/bench_demux.json 2> $OUT/bench_demux.err
 for w in polya chimera full; do $B --workload $w --steps 10 --warmup 3 > $OUT/bench_$w.json 2> $OUT/bench_$w.err; done
 PXG_NO_SCAN_OVERLAP=1 $B --workload full --steps 10 --warmup 3 > $OUT/bench_full_scan_behind_run.json 2>> $OUT/bench_full.err
@@ -13,7 +13,7 @@ $B --workload full --reads 100000 --steps 5 --warmup 2 > $OUT/bench_full_100k_re
 $B --length-dist lognormal --workload full --steps 10 --warmup 3 > $OUT/bench_full_lognormal.json 2>> $OUT/bench_full.err
 $B --end-to-end --workload full --reads 120000 --batch-reads 10000 > $OUT/bench_end_to_end_full.json 2> $OUT/e2e.err
 $B --end-to-end --compressed-bundle --workload full --reads 120000 --batch-reads 10000 > $OUT/bench_end_to_end_full_compressed.json 2>> $OUT/e2e.err
-python bench.py --api process_batch --workload full --in-flight 5 --api-calls 12 --cpu-sample 0 --cpu-all-cores-sample 0 --no-overlap-test --no-full-leg --no-fast5-leg --no-e2e-leg > $OUT/bench_api_process_batch_full.json 2> $OUT/api.err
+python bench.py --api process_batch --workload full --in-flight 5 --api-calls 12 --cpu-sample 0 --cpu-all-cores-sample 0 --no-overlap-test --no-full-leg --no-latency-leg --no-fast5-leg --no-e2e-leg > $OUT/bench_api_process_batch_full.json 2> $OUT/api.err
 PXG_NO_SCAN_OVERLAP=1 bash tools/prof.sh ${TAG}_full_serial --workload full > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out/prof_${TAG}_full_overlap

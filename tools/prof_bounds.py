@@ -34,8 +34,8 @@ for sec in re.finditer(r'== PMC \S+\n(.*?)(?=\n== |\Z)', txt, re.S):
             cnt.setdefault(cur, {})[v.group(1)] = float(v.group(2))
 out = {'_note': __doc__.split('Derivations')[1].strip(), '_source': sys.argv[1], 'kernels': {}}
 for k in want:
-    name = next((n for n in avg if n == k or n.startswith(k + '<') or n.startswith(k + '(')), None)
-    c = next((cnt[n] for n in cnt if n == k or n.startswith(k + '<') or n.startswith(k + '(')), None)
+    name = k if k in avg else next((n for n in avg if n.startswith(k + '<') or n.startswith(k + '(')), None)
+    c = cnt[k] if k in cnt else next((cnt[n] for n in cnt if n.startswith(k + '<') or n.startswith(k + '(')), None)
     if name is None or c is None:
         continue
     ns, calls = avg[name]

@@ -17,7 +17,7 @@ def short(name):
     name = name.split('(')[0]
     for k in ('k_scaler_lstm_q8_lat', 'k_demux_bidir_q8_lat', 'k_demux_top_q8_lat', 'k_scaler_lstm_q8', 'k_demux_bidir_q8', 'k_demux_top_q8', 'k_scaler_lstm_q', 'k_scaler_lstm', 'k_demux_bidir', 'k_demux_top', 'k_viterbi_ltr', 'k_head_pool',
               'k_barcode_window_raw', 'k_finalize', 'k_compact_ok', 'k_scaler_transform',
-              'k_mark_pushed', 'k_polya', 'k_events', 'k_guppy_event_means', 'k_unsplit_scan_w', 'k_unsplit_scan',
+              'k_mark_pushed', 'k_polya_order_count', 'k_polya_order_starts', 'k_polya_order_place', 'k_polya', 'k_events', 'k_guppy_event_means', 'k_unsplit_scan_w', 'k_unsplit_scan',
               'k_pool_scale', 'k_raw_to_pa', 'k_barcode_window_f32', 'k_detect_events'):
         if k in name:
             return k
