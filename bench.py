@@ -683,6 +683,7 @@ def strong_leg(args, ctx, dist, rank, world, mask, standin, force_dist, barrier)
 FLIPS_FILE = os.path.join('profiles', 'r04', 'decision_flips.json')
 FLIPS_GPU_FILE = os.path.join('profiles', 'r05', 'decision_flips_gpu_160k_reads.json')
 BOUNDS_FILE = os.path.join('profiles', 'r06', 'full_kernel_bounds.json')
+BOUNDS_DEMUX_FILE = os.path.join('profiles', 'r06', 'demux_kernel_bounds.json')      # PMC passes of the default workload
 ROCPROF_STATS = {'demux': os.path.join('profiles', 'r06', 'k_demux_kernel_stats.csv'),
                  'full': os.path.join('profiles', 'r06', 'k_full_kernel_stats.csv')}
 
@@ -1280,11 +1281,16 @@ def main():
             roofline['rocprof_source'] = 'static: ' + ROCPROF_STATS[args.workload if args.workload == 'full' else 'demux']
             # the clock the kernel really ran at in the committed PMC pass (GRBM_GUI_ACTIVE / 8 XCDs / duration): the
             # nominal peaks are quoted at 2.4 GHz
-            with open(os.path.join(ROOT, BOUNDS_FILE)) as fh:
+            bounds_file = BOUNDS_FILE if args.workload == 'full' else BOUNDS_DEMUX_FILE
+            with open(os.path.join(ROOT, bounds_file)) as fh:
                 kb_ = json.load(fh)['kernels'].get(roofline['kernel'], {})
             if kb_.get('clock_GHz'):
                 roofline['clock_GHz_in_profile'] = kb_['clock_GHz']
-                roofline['clock_source'] = 'static: ' + BOUNDS_FILE + ' (PMC pass of --workload full)'
+                roofline['clock_source'] = 'static: ' + bounds_file + ' (PMC pass of this workload: GRBM_GUI_ACTIVE / 8 XCDs / duration)'
+                for key in ('valu_issue_frac_of_simd_cycles', 'mfma_busy_frac_of_simd_cycles', 'lds_busy_frac',
+                            'lds_bank_conflict_frac_of_lds_cycles', 'wait_any_frac_of_wave_cycles'):
+                    if key in kb_:
+                        roofline.setdefault('counters_in_profile', {})[key] = kb_[key]
         except (OSError, KeyError, StopIteration, ValueError):
             pass
     # HBM bytes per launch of that kernel: NOT measured by this run (PMC counters need
@@ -1513,7 +1519,7 @@ def main():
                 'achieved': roofline.get('achieved'), 'frac': roofline.get('frac'), 'device': info['name'],
                 'clock_khz_reported': info.get('clock_khz')}
         static = {k: roofline.get(k) for k in ('rocprof_avg_ms', 'rocprof_launches', 'frac_at_rocprof_avg', 'rocprof_source',
-                                               'clock_GHz_in_profile', 'clock_source', 'traffic', 'traffic_source') if k in roofline}
+                                               'clock_GHz_in_profile', 'clock_source', 'counters_in_profile', 'traffic', 'traffic_source') if k in roofline}
         roofline['live'], roofline['static'] = live, static
         n_demux = int(res['bc_pushed'].sum())
         kern = []
@@ -1535,6 +1541,17 @@ def main():
              PEAK_I8_MFMA if arith == 'q8' else PEAK_FP32_MFMA, 'TOP/s (int8)' if arith == 'q8' else 'TFLOP/s', 'bidirectional layer of the demux net')
         krow('k_demux_top_q8 (K5b)', stage_ms['demux_top'], 'mfma', n_demux * Q8_PRODUCTS * 2.0 * 300 * (160 * 256) if arith == 'q8' else n_demux * FLOP_TOP,
              PEAK_I8_MFMA if arith == 'q8' else PEAK_FP32_MFMA, 'TOP/s (int8)' if arith == 'q8' else 'TFLOP/s', 'top cell + dense + softmax')
+        try:            # the committed counters of each kernel beside its live time (static, named)
+            with open(os.path.join(ROOT, BOUNDS_DEMUX_FILE)) as fh:
+                kb_all = json.load(fh)['kernels']
+            for row in kern:
+                st = kb_all.get(row['name'].split(' ')[0])
+                if st:
+                    row['static'] = {k: st[k] for k in ('avg_ms', 'clock_GHz', 'valu_issue_frac_of_simd_cycles', 'mfma_busy_frac_of_simd_cycles',
+                                                        'lds_bank_conflict_frac_of_lds_cycles', 'wait_any_frac_of_wave_cycles', 'hbm_GBps') if k in st}
+                    row['static_source'] = BOUNDS_DEMUX_FILE
+        except (OSError, KeyError, ValueError):
+            pass
         roofline['kernels'] = kern
         fracs = [(k['frac'], k['name']) for k in kern if k.get('frac')]
         if fracs:

@@ -64,7 +64,26 @@ __device__ __forceinline__ float ql_levels3(int a0, int a1, int a2, float k65536
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(t1), __float_as_int(t2), DPP_ROW_SHL(4), 0xF, 0x4, false));
 }
 
-__global__ __launch_bounds__(QL_THREADS) void k_scaler_lstm_q8_lat(
+// two accumulators of one gate row -> t of tile 0 in slot 3, of tile 1 in slot 0 (slots 1, 2: don't care)
+__device__ __forceinline__ float ql_levels2(int a0, int a1, float k65536)
+{
+    int r1 = ql_words(a0);
+    r1 = __builtin_amdgcn_update_dpp(r1, ql_words(a1), DPP_ROW_ROR(4), 0xF, 0x5, false);
+    const float f1 = (float)r1;
+    const float v1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f1), DPP_ROW_ROR(8), 0xF, 0xF, false));
+    return __builtin_fmaf(v1, k65536, f1);
+}
+
+template <int NTW>
+__device__ __forceinline__ float ql_levels(const v4i (&acc)[NTW], int r, float k65536)
+{
+    if constexpr (NTW == 3) return ql_levels3(acc[0][r], acc[1][r], acc[2][r], k65536);
+    else return ql_levels2(acc[0][r], acc[1][r], k65536);
+}
+
+// NTW: gate tiles per wave -- 3 (8 waves: 4 per layer; slots 3, 0, 2) or 2 (12 waves: 6 per layer; slots 3, 0)
+template <int NTW>
+__global__ __launch_bounds__(NTW == 3 ? 512 : 768) void k_scaler_lstm_q8_lat(
     int n_rows, const int32_t* __restrict__ idx, const int32_t* __restrict__ count, int T,
     const float* __restrict__ head, const float* __restrict__ sigtab, const v4i* __restrict__ frag,
     const float* __restrict__ W1 /* scalar-input kernel, table units */, const float* __restrict__ b1,
@@ -82,30 +101,33 @@ __global__ __launch_bounds__(QL_THREADS) void k_scaler_lstm_q8_lat(
     float* xb = reinterpret_cast<float*>(hv + 2 * QL_HV);                              // [2 chunks][4 reads][QL_XS]
     int* ridx = reinterpret_cast<int*>(xb + 2 * 4 * QL_XS);                            // [4]
 
-    const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3;
-    const bool l1 = __builtin_amdgcn_readfirstlane(tid) < 256;      // waves 0-3: layer 1, waves 4-7: layer 2 (wave-uniform: scalar branches)
-    const int ftid = tid & 255;                 // (the fragments are laid out for 4 waves)
+    constexpr int WPL = 12 / NTW, THREADS = 2 * WPL * 64;            // waves per layer, threads per workgroup
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid) >> 6;
+    const bool l1 = wv < WPL;                  // the first WPL waves: layer 1, the others: layer 2 (wave-uniform: scalar branches)
+    const int wl = l1 ? wv : wv - WPL;         // this wave's gate tiles of its layer: NTW * wl + i (tile g = units 4 g .. 4 g + 3)
     const int rd = lane & 3, slot = (lane >> 2) & 3, a = lane >> 4, kg = lane >> 4;
 
-    for (int i = tid; i < PXG_SIG_NSEG; i += QL_THREADS) tab[i] = reinterpret_cast<const float4*>(sigtab)[i];
-    v4i wq[3][5];                               // weight fragments of this wave's three gate tiles, in VGPRs throughout
+    for (int i = tid; i < PXG_SIG_NSEG; i += THREADS) tab[i] = reinterpret_cast<const float4*>(sigtab)[i];
+    v4i wq[NTW][5];                             // weight fragments of this wave's gate tiles, in VGPRs throughout
 #pragma unroll
-    for (int nt = 0; nt < 3; nt++) {
-        const v4i* f = frag + (size_t)nt * QL_FRAGS * LSTM_THREADS + ftid;
+    for (int i = 0; i < NTW; i++) {
+        const int g = NTW * wl + i;             // (the fragments are laid out for 4 waves x 3 tiles: tile g = wave g / 3, nt g % 3)
+        const v4i* f = frag + (size_t)(g % 3) * QL_FRAGS * LSTM_THREADS + (g / 3) * 64 + lane;
 #pragma unroll
-        for (int d = 0; d < 5; d++) wq[nt][d] = f[(l1 ? (d > 2 ? 2 : d) : 3 + d) * LSTM_THREADS];
+        for (int d = 0; d < 5; d++) wq[i][d] = f[(l1 ? (d > 2 ? 2 : d) : 3 + d) * LSTM_THREADS];
     }
-    for (int i = tid; i < 2 * QL_HV / 4; i += QL_THREADS) reinterpret_cast<unsigned*>(hv)[i] = 0u;
+    for (int i = tid; i < 2 * QL_HV / 4; i += THREADS) reinterpret_cast<unsigned*>(hv)[i] = 0u;
     if (tid < 4) {
         const int row = row_base + tid;
         ridx[tid] = row < lim ? (idx ? idx[row] : row) : -1;
     }
     __syncthreads();
 
-    // the gate tile a slot carries after ql_levels3: slot 3 -> tile 0, slot 0 -> tile 1, slot 2 -> tile 2, slot 1 idle
+    // the gate tile a slot carries after ql_levels3 / ql_levels2: slot 3 -> tile 0, slot 0 -> tile 1, slot 2 -> tile 2 (NTW = 3)
     const int nt_of_slot = slot == 3 ? 0 : (slot == 0 ? 1 : 2);
-    const bool publishes = slot != 1;
-    const int unit = 12 * w + 4 * nt_of_slot + a;
+    const bool publishes = NTW == 3 ? slot != 1 : (slot == 3 || slot == 0);
+    const int unit = 4 * (NTW * wl + (nt_of_slot < NTW ? nt_of_slot : 0)) + a;
     float stW[4], stB[4], sc[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -120,14 +142,16 @@ __global__ __launch_bounds__(QL_THREADS) void k_scaler_lstm_q8_lat(
     const int pub = ((l1 ? 0 : 3) + (unit >> 4)) * QL_STRIP + rd * 16 + (unit & 15);           // + 64 x (4 - digit)
 
     // x: one float per thread of waves 0-3 and 64-step chunk, the next chunk in flight under the current one
-    const int xrow = ftid >> 6, xcol = ftid & 63;
+    const bool xs = tid < 256;                  // (the first four waves stage x: layer-1 waves in both forms)
+    const int xrow = (tid >> 6) & 3, xcol = tid & 63;
     const int xrd = ridx[xrow];
     const float* xsrc = head + (size_t)(xrd < 0 ? 0 : xrd) * T;
-    if (l1) xb[xrow * QL_XS + xcol] = (xrd >= 0 && xcol < T) ? xsrc[xcol] : 0.0f;
+    if (xs) xb[xrow * QL_XS + xcol] = (xrd >= 0 && xcol < T) ? xsrc[xcol] : 0.0f;
     float xnext = 0.0f;
     __syncthreads();
 
     float C = 0.0f;
+    if (!l1) __builtin_amdgcn_s_setprio(2);      // the layer-2 wave has the longer chain (15 against 9 MFMAs): it issues first when both are ready (-3 % at 128 reads)
     float k65536;                              // (kept in a register: the DPP forms take no literal)
     asm volatile("v_mov_b32 %0, 0x47800000" : "=v"(k65536));
     const v4i z = {0, 0, 0, 0};
@@ -138,35 +162,35 @@ __global__ __launch_bounds__(QL_THREADS) void k_scaler_lstm_q8_lat(
         const unsigned char* hr = hv + (t & 1) * QL_HV;
         unsigned char* hw = hv + ((t + 1) & 1) * QL_HV;
         const int tc = t & (XCH - 1);
-        if (l1 && tc == 0) xnext = (xrd >= 0 && t + XCH + xcol < T) ? xsrc[t + XCH + xcol] : 0.0f;
+        if (xs && tc == 0) xnext = (xrd >= 0 && t + XCH + xcol < T) ? xsrc[t + XCH + xcol] : 0.0f;
 
         const v4i f2 = *reinterpret_cast<const v4i*>(hr + offF + 128);
         const v4i f1 = *reinterpret_cast<const v4i*>(hr + offF + 64);
         const v4i f0 = *reinterpret_cast<const v4i*>(hr + offF);
-        v4i acc[3];
+        v4i acc[NTW];
 #pragma unroll
-        for (int nt = 0; nt < 3; nt++) acc[nt] = mfma8(wq[nt][0], f2, z);
+        for (int nt = 0; nt < NTW; nt++) acc[nt] = mfma8(wq[nt][0], f2, z);
 #pragma unroll
-        for (int nt = 0; nt < 3; nt++) acc[nt] = mfma8(wq[nt][1], f1, acc[nt]);
+        for (int nt = 0; nt < NTW; nt++) acc[nt] = mfma8(wq[nt][1], f1, acc[nt]);
 #pragma unroll
-        for (int nt = 0; nt < 3; nt++) acc[nt] = mfma8(wq[nt][2], f0, acc[nt]);
+        for (int nt = 0; nt < NTW; nt++) acc[nt] = mfma8(wq[nt][2], f0, acc[nt]);
         f32x4 u[1];
         if (l1) {
             const float x = xb[((t / XCH) & 1) * 4 * QL_XS + rd * QL_XS + tc];
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                u[0][r] = __builtin_fmaf(ql_levels3(acc[0][r], acc[1][r], acc[2][r], k65536), sc[r],
+                u[0][r] = __builtin_fmaf(ql_levels<NTW>(acc, r, k65536), sc[r],
                                          __builtin_fmaf(x, stW[r], stB[r]));
         } else {
             const v4i f4 = *reinterpret_cast<const v4i*>(hr + off4);
             const v4i f5 = *reinterpret_cast<const v4i*>(hr + off5);
 #pragma unroll
-            for (int nt = 0; nt < 3; nt++) acc[nt] = mfma8(wq[nt][3], f4, acc[nt]);
+            for (int nt = 0; nt < NTW; nt++) acc[nt] = mfma8(wq[nt][3], f4, acc[nt]);
 #pragma unroll
-            for (int nt = 0; nt < 3; nt++) acc[nt] = mfma8(wq[nt][4], f5, acc[nt]);
+            for (int nt = 0; nt < NTW; nt++) acc[nt] = mfma8(wq[nt][4], f5, acc[nt]);
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                u[0][r] = __builtin_fmaf(ql_levels3(acc[0][r], acc[1][r], acc[2][r], k65536), sc[r], stB[r]);
+                u[0][r] = __builtin_fmaf(ql_levels<NTW>(acc, r, k65536), sc[r], stB[r]);
         }
         unsigned q = 0u;                        // an idle cell keeps its state and publishes zeros
         if (ACT) {
@@ -180,7 +204,7 @@ __global__ __launch_bounds__(QL_THREADS) void k_scaler_lstm_q8_lat(
             hw[pub + 192] = (unsigned char)(q >> 8);
             hw[pub + 256] = (unsigned char)q;
         }
-        if (l1 && tc == XCH - 1) xb[(((t / XCH) + 1) & 1) * 4 * QL_XS + xrow * QL_XS + xcol] = xnext;
+        if (xs && tc == XCH - 1) xb[(((t / XCH) + 1) & 1) * 4 * QL_XS + xrow * QL_XS + xcol] = xnext;
         __syncthreads();
     };
     // layer 1 runs step t in iteration t (t < T), layer 2 step t - 1 (t >= 1)
@@ -203,16 +227,6 @@ __global__ __launch_bounds__(QL_THREADS) void k_scaler_lstm_q8_lat(
             pred[(size_t)rdg * 2 + o] = acc;
         }
     }
-}
-
-// two accumulators of one gate row -> t of tile 0 in slot 3, of tile 1 in slot 0 (slots 1, 2: don't care)
-__device__ __forceinline__ float ql_levels2(int a0, int a1, float k65536)
-{
-    int r1 = ql_words(a0);
-    r1 = __builtin_amdgcn_update_dpp(r1, ql_words(a1), DPP_ROW_ROR(4), 0xF, 0x5, false);
-    const float f1 = (float)r1;
-    const float v1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(f1), DPP_ROW_ROR(8), 0xF, 0xF, false));
-    return __builtin_fmaf(v1, k65536, f1);
 }
 
 // ===========================================================================
@@ -486,9 +500,18 @@ int pxg_launch_scaler_lstm_q8_lat(pxg_ctx* ctx, int64_t n_rows, const int32_t* i
     const size_t lds = sizeof(float) * 4 * PXG_SIG_NSEG + 2 * QL_HV + sizeof(float) * 2 * 4 * QL_XS + sizeof(int) * 4;
     const PxgLstmDev &l1 = ctx->scaler1, &l2 = ctx->scaler2;
     const Q8Scale s1 = q8_scale(ctx->q8.s_scaler1), s2 = q8_scale(ctx->q8.s_scaler2);
-    hipLaunchKernelGGL(k_scaler_lstm_q8_lat, dim3((unsigned)grid), dim3(QL_THREADS), lds, ctx->stream, (int)n_rows, idx,
-                       count, T, head, ctx->d_sigtab, reinterpret_cast<const v4i*>(ctx->q8.scaler_frag_lat), l1.kernel,
-                       l1.bias, l2.bias, s1, s2, ctx->scaler_dense.kernel, ctx->scaler_dense.bias, pred);
+    // PXG_K2_LAT_WAVES=12: two gate tiles per wave on 12 waves -- shorter dependent chains per step, but more gate math on
+    // half-used lanes: measured SLOWER (1 024 reads 1.59 -> 1.70 ms, 2 048 reads 2.33 -> 3.25: profiles/r06/ab_lat_forms.txt);
+    // kept selectable, tested in both forms
+    static const bool twelve = [] { const char* e = getenv("PXG_K2_LAT_WAVES"); return e && atoi(e) == 12; }();
+    if (twelve)
+        hipLaunchKernelGGL(k_scaler_lstm_q8_lat<2>, dim3((unsigned)grid), dim3(768), lds, ctx->stream, (int)n_rows, idx,
+                           count, T, head, ctx->d_sigtab, reinterpret_cast<const v4i*>(ctx->q8.scaler_frag_lat), l1.kernel,
+                           l1.bias, l2.bias, s1, s2, ctx->scaler_dense.kernel, ctx->scaler_dense.bias, pred);
+    else
+        hipLaunchKernelGGL(k_scaler_lstm_q8_lat<3>, dim3((unsigned)grid), dim3(512), lds, ctx->stream, (int)n_rows, idx,
+                           count, T, head, ctx->d_sigtab, reinterpret_cast<const v4i*>(ctx->q8.scaler_frag_lat), l1.kernel,
+                           l1.bias, l2.bias, s1, s2, ctx->scaler_dense.kernel, ctx->scaler_dense.bias, pred);
     PXG_HIP(ctx, hipGetLastError());
     return PXG_OK;
 }

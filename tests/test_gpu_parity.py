@@ -6,6 +6,8 @@ LSTM arithmetic is canonical (DESIGN.md), bit-exact for the float outputs too;
 the 1e-4 softmax tolerance is kept as the documented fallback bound.
 """
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -14,6 +16,8 @@ from conftest import assert_spikes_equal
 
 from poreplex_amd import native as N
 from poreplex_amd.synth import synth_batch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
@@ -104,6 +108,23 @@ def test_scaler_lstm_latency_form_equals_tile_form(ctx, oracle, stages, n, arith
     pick = rng.choice(n, min(n, 12), replace=False)
     want = np.stack([oracle.scaler_forward(rows[i]) for i in pick])
     assert np.array_equal(got[pick], want)
+
+
+@pytest.mark.gpu
+def test_scaler_lstm_latency_form_on_twelve_waves():
+    """The 12-wave variant of K2's latency form (two gate tiles per wave, PXG_K2_LAT_WAVES=12; read once per process,
+    hence a child process): same bits as the default 8-wave form."""
+    code = ('import sys, numpy as np; sys.path.insert(0, %r)\n'
+            'from poreplex_amd import native as N; from poreplex_amd.config import default_config\n'
+            'rng = np.random.default_rng(5); rows = rng.normal(0, 1, (37, 2000)).astype(np.float32); rows[::3, :700] = 0\n'
+            'c = N.NativeContext(default_config(), 0); print(c.scaler_lstm(rows).tobytes().hex())' % ROOT)
+    outs = []
+    for waves in ('8', '12'):
+        p = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, PXG_K2_LAT_WAVES=waves, PXG_LSTM_ARITH='q8'),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr
+        outs.append(p.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and len(outs[0]) == 37 * 2 * 4 * 2
 
 
 @pytest.mark.parametrize('n', [8200, 9999, 13000])
