@@ -137,6 +137,8 @@ def parse(argv=None):
                          '--total-reads sharded over the ranks) that the line carries as configs4_strong')
     ap.add_argument('--strong-base-reads', type=int, default=2048,
                     help='distinct reads of the configs4_strong leg (tiled on the device)')
+    ap.add_argument('--no-worker-processes-leg', action='store_true',
+                    help='API leg: skip the 128-read calls from 8 / 16 worker PROCESSES (the reference\'s ProcessPoolExecutor pattern)')
     ap.add_argument('--no-latency-leg', action='store_true',
                     help='skip the small-batch leg (roofline.latency_form: a 1 024-read batch with and without the latency forms of K2 / K5)')
     return ap.parse_args(argv)
@@ -464,6 +466,58 @@ def process_batch_leg(args, base, which, lo, mask, local_rank, compressed, resid
                 diff += int(r.get('barcode') != (label[j] if called[j] else None))
             out['barcode_or_status_mismatch_vs_resident_records'] = diff
         WorkerPersistenceStorage.reset()
+        return out
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def worker_processes_leg(args, base, which, lo, mask, local_rank, workers=(8, 16), calls_per_worker=40, n=128):
+    """The reference's OWN call pattern for its per-read processor (pipeline.py:96,193-205): a ProcessPoolExecutor of
+    `parallel` worker processes, each running process_batch(batchid, reads, config) on 128-read batches
+    (commandline.py:402) and handing the list of result dicts back through the executor's pipe.  Every worker process
+    has its own interpreter and its own context on the ONE GPU (WorkerPersistenceStorage in that process); a
+    128-read batch takes the latency forms of the LSTM kernels on 32 of the 256 CUs, so the workers' kernels run side by
+    side.  Every worker builds its context in the pool's initializer and 20 x workers warm-up calls are served before the
+    clock starts; timed: `calls_per_worker` x workers calls submitted at once, the result lists arriving in the parent
+    (pickling included)."""
+    import multiprocessing as mp
+    import shutil
+    import tempfile
+    from concurrent.futures import ProcessPoolExecutor
+    from poreplex_amd.fast5_file import write_bundle
+    from poreplex_amd.signal_analyzer import process_batch       # (the pool pickles it by name: the workers import the package)
+    from poreplex_amd.synth import synth_basecalls
+    from poreplex_amd.worker_persistence import warm_up
+    work = tempfile.mkdtemp(prefix='pxg_wp_')
+    out = {'reads_per_call': n, 'calls_per_worker': calls_per_worker,
+           'pattern': 'ProcessPoolExecutor(workers).submit(process_batch, batchid, reads, config): pipeline.py:96,204-205'}
+    try:
+        o = base['offsets']
+        arena, off = N.pack_reads([base['arena'][o[b]:o[b + 1]] for b in which[:n]])
+        names = ['wp/read{:07d}.fast5'.format(lo + j) for j in range(n)]
+        ids = ['{:08x}-0000-4000-8000-{:012x}'.format(args.seed, lo + j) for j in range(n)]
+        path = os.path.join(work, 'wp.pxr.npz')
+        write_bundle(path, arena, off, base['calib'][which[:n]], names, ids,
+                     basecalls=synth_basecalls({'offsets': off}, seed=args.seed), compress=False)
+        cfg = default_config(inputdir=work, outputdir=work, read_bundle=path, barcoding=bool(mask & N.STAGE_BARCODE),
+                             measure_polya=bool(mask & N.STAGE_POLYA), filter_unsplit_reads=False, device_id=local_rank)
+        reads = list(zip(names, ids))
+        for w in workers:
+            t_start = time.perf_counter()
+            with ProcessPoolExecutor(w, mp_context=mp.get_context('spawn'), initializer=warm_up, initargs=(cfg,)) as pool:
+                warm = [pool.submit(process_batch, 1000000 + k, reads, cfg) for k in range(20 * w)]
+                first = [f.result(timeout=300) for f in warm][0]
+                if isinstance(first, tuple):
+                    raise N.PxgError('process_batch failed in a worker process: {}'.format(first[1]))
+                t_up = time.perf_counter() - t_start
+                t0 = time.perf_counter()
+                futs = [pool.submit(process_batch, k, reads, cfg) for k in range(calls_per_worker * w)]
+                got = [f.result(timeout=300) for f in futs]
+                wall = time.perf_counter() - t0
+            same = all(isinstance(g, list) and len(g) == len(first) and g[0] == first[0] and g[-1] == first[-1] for g in got)
+            out['{}_workers'.format(w)] = {'reads_per_s': len(futs) * n / wall, 'calls': len(futs), 'ms_per_call': wall / len(futs) * 1e3,
+                                          'pool_start_and_warm_up_s': round(t_up, 2), 'dicts_per_call': len(first),
+                                          'results_identical_across_calls': bool(same)}
         return out
     finally:
         shutil.rmtree(work, ignore_errors=True)
@@ -1478,6 +1532,11 @@ def main():
                 small.in_flight, small.api_calls = 32, 320
                 api['reference_batch_size_128'] = process_batch_leg(small, base, which[:128], lo, mask, local_rank, False, res[:128])
                 extra['process_batch_128_read_calls_reads_per_s'] = api['reference_batch_size_128']['reads_per_s']
+                if not args.no_worker_processes_leg:
+                    try:
+                        api['reference_batch_size_128']['worker_processes'] = worker_processes_leg(args, base, which, lo, mask, local_rank)
+                    except Exception as exc:               # reported, never hidden
+                        api['reference_batch_size_128']['worker_processes'] = {'error': '{}: {}'.format(type(exc).__name__, exc)}
         except Exception as exc:                       # reported, never hidden
             extra['process_batch_reads_per_s'] = None
             extra['process_batch_error'] = '{}: {}'.format(type(exc).__name__, exc)
@@ -1573,7 +1632,8 @@ def main():
                 lat['process_batch_128_read_calls'] = {'reads_per_s_32_threads': r128['reads_per_s'],
                                                        'reads_per_s_one_call_at_a_time': r128['one_call_at_a_time_reads_per_s'],
                                                        'mean_phase_ms_per_call': r128.get('mean_phase_ms_per_call'),
-                                                       'merge_stats': r128.get('merge_stats')}
+                                                       'merge_stats': r128.get('merge_stats'),
+                                                       'worker_processes': r128.get('worker_processes')}
             roofline['latency_form'] = lat
         except Exception as exc:                       # reported, never hidden
             roofline['latency_form'] = {'error': '{}: {}'.format(type(exc).__name__, exc)}

@@ -77,3 +77,12 @@ class WorkerPersistenceStorage:
             if 'loader' in mod.storage:
                 mod.storage['loader'].unpin_bundle()
             mod.storage['ctx'].close()
+
+
+def warm_up(config):
+    """Build this worker process's persistent objects NOW: what the first process_batch call of a fresh worker would do
+    (context on the GPU, models, the read bundle).  For a pool initializer --
+    `ProcessPoolExecutor(workers, initializer=warm_up, initargs=(config,))` -- so that no batch pays for it."""
+    class _Sink:
+        pass
+    WorkerPersistenceStorage(config).retrieve_objects(_Sink())
