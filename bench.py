@@ -421,6 +421,11 @@ def process_batch_leg(args, base, which, lo, mask, local_rank, compressed, resid
             return k
         if os.environ.get('PXG_BENCH_SWITCH_INTERVAL'):       # (experiment knob: the interpreter's GIL hand-over interval)
             sys.setswitchinterval(float(os.environ['PXG_BENCH_SWITCH_INTERVAL']))
+        if os.environ.get('PXG_BENCH_GC_OFF'):                 # (experiment knob: no cyclic collections under the worker threads)
+            import gc
+            gc.collect()
+            gc.freeze()
+            gc.disable()
         with ThreadPoolExecutor(max(args.in_flight, 1)) as pool:
             t0 = time.perf_counter()
             list(pool.map(one_call, range(calls)))

@@ -18,6 +18,7 @@ GPU surfaces as the ``(-1, msg, traceback)`` tuple the pipeline treats as fatal
 import multiprocessing as mp
 import os
 import sys
+import threading
 import time
 import traceback
 from contextlib import AbstractContextManager
@@ -32,6 +33,25 @@ from .utils import union_intervals  # noqa: F401  (re-exported like the referenc
 from .worker_persistence import WorkerPersistenceStorage
 
 __all__ = ['SignalAnalyzer', 'SignalAnalysis', 'process_batch']
+
+# Worker calls from many THREADS of one process (a thread pool in place of the reference's process pool, so that small
+# calls share one context and one GPU batch): the two Python phases of a call -- open the reads into a table; status
+# rules + result dicts -- are short (~0.1 ms each per 128 reads) but run under the interpreter lock, and a dozen
+# threads contending for it turn each phase into milliseconds of waiting (measured: prepare 0.09 -> 5 ms, dicts
+# 0.13 -> 1.4 ms at 32 threads, growing with the square of the thread count).  The phases therefore QUEUE on one plain
+# lock: a thread waiting for it sleeps outside the interpreter lock instead of fighting for it, and the one thread that
+# holds it runs its phase undisturbed.  The GPU pass in between holds neither.  (PXG_NO_HOST_PHASE_LOCK=1: off.)
+_HOST_PHASE = threading.Lock()
+_USE_HOST_PHASE = os.environ.get('PXG_NO_HOST_PHASE_LOCK') is None
+
+
+class _NoLock:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
 
 CALL_TRACE = None     # a list: (start, prepared, GPU pass done, dicts built) of every process() call
 
@@ -123,12 +143,15 @@ class SignalAnalyzer(AbstractContextManager):
     def process(self, reads):
         """Result list of signal_analyzer.py:82-134: whatever was decided before the GPU
         pass first (encounter order), then every read that entered it (input order)."""
+        phase = _HOST_PHASE if _USE_HOST_PHASE else _NoLock()
         t0 = time.perf_counter()
-        batch = self.prepare(reads, ReadTable())    # a table of its own: calls may overlap (threads)
+        with phase:
+            batch = self.prepare(reads, ReadTable())    # a table of its own: calls may overlap (threads)
         t1 = time.perf_counter()
         self.loader.fit_scalers(batch.table)     # scaling parameters AND every other numeric stage
         t2 = time.perf_counter()
-        results = self.finish(batch)
+        with phase:
+            results = self.finish(batch)
         if CALL_TRACE is not None:               # bench.py: where a worker call spends its time
             CALL_TRACE.append((t0, t1, t2, time.perf_counter()))
         return results
