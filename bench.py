@@ -1617,7 +1617,7 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         roofline['kernels'] = kern
-        fracs = [(k['frac'], k['name']) for k in kern if k.get('frac')]
+        fracs = [(k['frac'], k['name']) for k in kern if k.get('frac') and k['ms'] >= 0.03 * stage_ms['total']]     # (kernels worth >= 3 % of the step)
         if fracs:
             roofline['furthest_from_its_roof'] = min(fracs)[1]
         if isinstance(extra.get('full'), dict) and 'reads_per_s' in extra['full']:

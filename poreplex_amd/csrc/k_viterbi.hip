@@ -366,9 +366,14 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
     // operations per span in the middle of that chain.  `ties` collects the live lanes that
     // saw an equality; a chunk that saw one is run again with EXACT = true (the first chunk,
     // while states are still unreachable at -inf, and practically never after it).
-    auto step = [&](auto exact, int t, double e, unsigned long long& ties, BT& fields) {
-        constexpr bool EXACT = decltype(exact)::value;
-        const unsigned long long live = __ballot(t < T) & state_lanes;
+    // INNER (round 6): a chunk in which no lane's read ends -- every lane is live for all of its steps or dead for all of
+    // them, so the live mask is the chunk's (`live_c`, a loop-invariant scalar pair) and nobody's last column has to be
+    // kept: one v_cmp + one scalar AND (a VALU -> SALU round trip in an in-order wave) and a v_cmp + two v_cndmask
+    // less per step, in all but <= 8 of a block's ~250 chunks.
+    unsigned long long live_c = 0ull;
+    auto step = [&](auto exact, auto inner, int t, double e, unsigned long long& ties, BT& fields) {
+        constexpr bool EXACT = decltype(exact)::value, INNER = decltype(inner)::value;
+        const unsigned long long live = INNER ? live_c : (__ballot(t < T) & state_lanes);
         double cand[PXG_MAX_STATES];
 #pragma unroll
         for (int k = 1; k < PXG_MAX_STATES; k++)
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
                     // comparisons that choose the span and flag ties hang off that chain instead of sitting in
                     // it (v_cmp -> SGPR pair -> two v_cndmask per span was 4 of its 7 dependent stages).  Without
                     // a tie max(best, cand) IS the strict-greater select; a chunk with a tie is replayed exactly.
-                    ties |= __ballot(cand[k] == best) & live;
+                    ties |= INNER ? __ballot(cand[k] == best) : (__ballot(cand[k] == best) & live);      // (INNER: masked once, after the chunk)
                     bd = cand[k] > best ? (unsigned)k : bd;
 #ifdef VIT_NO_MAX
                     best = cand[k] > best ? cand[k] : best;
@@ -413,10 +418,10 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
             }
         }
         v = best + e;
-        vfin = pxg_sel_f64(__ballot(t == T - 1), vfin, v);
+        if (!INNER) vfin = pxg_sel_f64(__ballot(t == T - 1), vfin, v);
         fields = (fields << FB) | (BT)bd;          // steps at or after T leave fields nobody reads
     };
-    auto run_chunk = [&](auto exact, const double* emc, int c0, int tend, unsigned long long& ties) {
+    auto run_chunk = [&](auto exact, auto inner, const double* emc, int c0, int tend, unsigned long long& ties) {
         BT fields = 0;
         int tt = 0;
         if (c0 == 0) {              // t = 0: out of the silent start state, no back-pointer
@@ -427,8 +432,9 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
 #ifndef VIT_UNROLL
 #define VIT_UNROLL 1
 #endif
+        const int n_steps = __builtin_amdgcn_readfirstlane(tend);      // (a scalar trip count: the compiler kept it in a vector register)
 #pragma unroll VIT_UNROLL
-        for (; tt < tend; tt++) step(exact, c0 + tt, emc[tt], ties, fields);
+        for (; tt < n_steps; tt++) step(exact, inner, c0 + tt, emc[tt], ties, fields);
         return (BT)(fields << ((VIT_CHUNK - tend) * FB));      // a short last chunk: step tt still sits at field 15 - tt
     };
 
@@ -438,11 +444,19 @@ __global__ __launch_bounds__(VIT_THREADS) void k_viterbi_ltr(
         const int tend = (Tmax - c0) < VIT_CHUNK ? (Tmax - c0) : VIT_CHUNK;
         const double v0 = v, vfin0 = vfin;
         unsigned long long ties = 0ull, unused = 0ull;
-        BT fields = run_chunk(std::false_type(), emc, c0, tend, ties);
+        live_c = __ballot(c0 < T) & state_lanes;
+        const bool inner = c0 > 0 && __ballot(T - 1 >= c0 && T - 1 < c0 + tend) == 0ull;
+        BT fields;
+        if (inner) {
+            fields = run_chunk(std::false_type(), std::true_type(), emc, c0, tend, ties);
+            ties &= live_c;
+        } else {
+            fields = run_chunk(std::false_type(), std::false_type(), emc, c0, tend, ties);
+        }
         if (ties != 0ull) {
             v = v0;
             vfin = vfin0;
-            fields = run_chunk(std::true_type(), emc, c0, tend, unused);
+            fields = run_chunk(std::true_type(), std::false_type(), emc, c0, tend, unused);
         }
         bpw[(size_t)(c0 / VIT_CHUNK) * 64] = fields;
         lds_barrier();              // this chunk is consumed; the next one is published
