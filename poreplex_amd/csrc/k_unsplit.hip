@@ -13,6 +13,7 @@
 // reference's append order and compact the candidates of all reads into one CSR
 // list.  The unsplit HMM is not left-to-right, so this Viterbi keeps real back
 // pointers (see k_unsplit_scan).
+#include <type_traits>
 #include "pxg_common.h"
 
 #define UN_READS 8
@@ -606,7 +607,16 @@ __device__ __forceinline__ void un_emission_round(const double* par, int n_mix, 
 // XC = steps per round.  4: 264 VGPRs, one wave per SIMD -- the faster kernel while a batch has no more 64-window
 // groups than the chip has SIMDs (10 000 reads: 940; 2.0 ms against 2.85); 2: 234 VGPRs, two waves per SIMD, which is
 // what a bigger batch needs to hide the LDS round trips (100 000 reads: 14.0 ms against 19.6).  Chosen at launch.
-template <int XC>
+// EDGES (round 6): bit q * UD_S + i = the model has an edge rank i -> rank q.  The dense form adds -inf for every
+// missing edge (36 add / compare / select / max groups per step); the shipped model has 16 edges, and a kernel
+// specialised for ITS topology computes those alone -- a missing edge can never win and never ties (-inf > best is
+// false, max(best, -inf) = best), so skipping it is the same arithmetic.  The host compares the model's topology with
+// UNSPLIT_SHIPPED_EDGES and launches the specialised kernel on a match, the dense one (all bits set) otherwise
+// (PXG_UNSPLIT_DENSE=1 forces it; both tested).
+#define UNSPLIT_ALL_EDGES ((1ull << (UD_S * UD_S)) - 1ull)
+#define UNSPLIT_SHIPPED_EDGES 0xa5027d983ull      // presets/rna-r941.cfg unsplit_read_detection_model, ranks in name order
+
+template <int XC, unsigned long long EDGES>
 __global__ __launch_bounds__(64) void k_unsplit_scan_w(
     int64_t n_reads, int tmax, UnsplitDense D, UnsplitParams P, const pxg_calib* __restrict__ cal,
     const int32_t* __restrict__ status, const int32_t* __restrict__ segs,
@@ -690,9 +700,9 @@ __global__ __launch_bounds__(64) void k_unsplit_scan_w(
         const int t_last = T > 0 ? T - 1 : 0;
 
         // ---- forward pass: the lane's states in its own registers -------------------
-        double v[NS];
+        double v[NS], vfin[NS];          // vfin: the column of the lane's last step (inner rounds run on past it)
 #pragma unroll
-        for (int q = 0; q < NS; q++) v[q] = -__builtin_inf();
+        for (int q = 0; q < NS; q++) v[q] = vfin[q] = -__builtin_inf();
         float xn[XC];
 #pragma unroll
         for (int j = 0; j < XC; j++) xn[j] = x[j < t_last ? j : t_last];
@@ -708,32 +718,54 @@ __global__ __launch_bounds__(64) void k_unsplit_scan_w(
             double em[XC][NS];
 #pragma unroll
             for (int q = 0; q < NS; q++) un_emission_round<XC, NS>(par, D.n_mix[q], lsetab, q, xc, em);
+            // an INNER round: no lane's window ends in it and it is not the first -- every lane is either inside its
+            // window for all XC steps or past its end (then it computes on, on means nobody reads back, into rows of its
+            // own column nobody reads back; its last column is safe in vfin): no per-step selects at all
+            const bool inner = c0 > 0 && __ballot(T - 1 >= c0 && T - 1 < c0 + XC) == 0ull;
+            auto round = [&](auto inner_c) {
+                constexpr bool INNER = decltype(inner_c)::value;
 #pragma unroll
-            for (int j = 0; j < XC; j++) {
-                const int t = c0 + j;
-                const bool act = t < T;                // (a round runs to its end: steps behind T change nothing)
-                asm volatile("" ::: "memory");         // At is read HERE, once per step (broadcast reads), not kept across steps
-                double nv[NS];
-                unsigned tbl = 0u;
+                for (int j = 0; j < XC; j++) {
+                    const int t = c0 + j;
+                    const bool act = t < T;                // (a round runs to its end: steps behind T change nothing)
+                    asm volatile("" ::: "memory");         // At is read HERE, once per step (broadcast reads), not kept across steps
+                    double nv[NS];
+                    unsigned tbl = 0u;
 #pragma unroll
-                for (int q = 0; q < NS; q++) {
-                    double best = -__builtin_inf();
-                    unsigned arg = 7u;
+                    for (int q = 0; q < NS; q++) {
+                        double best = -__builtin_inf();
+                        unsigned arg = 7u;
 #pragma unroll
-                    for (int i = 0; i < NS; i++) {
-                        const double cand_v = v[i] + At[q * NS + i];
-                        arg = cand_v > best ? (unsigned)i : arg;          // strict: the first of equal candidates stays
-                        best = __builtin_fmax(best, cand_v);               // (no NaN can arise: nothing is +inf)
+                        for (int i = 0; i < NS; i++) {
+                            if (((EDGES >> (q * NS + i)) & 1ull) != 0ull) {        // (folded once the loops are unrolled)
+                                const double cand_v = v[i] + At[q * NS + i];
+                                arg = cand_v > best ? (unsigned)i : arg;          // strict: the first of equal candidates stays
+                                best = __builtin_fmax(best, cand_v);               // (no NaN can arise: nothing is +inf)
+                            }
+                        }
+                        if (INNER) {
+                            nv[q] = best + em[j][q];
+                        } else {
+                            const double stepped = (t == 0) ? (D.start[q] + em[j][q]) : (best + em[j][q]);
+                            nv[q] = act ? stepped : v[q];
+                        }
+                        tbl |= arg << (3 * q);
                     }
-                    const double stepped = (t == 0) ? (D.start[q] + em[j][q]) : (best + em[j][q]);
-                    nv[q] = act ? stepped : v[q];
-                    tbl |= arg << (3 * q);
-                }
 #pragma unroll
-                for (int q = 0; q < NS; q++) v[q] = nv[q];
-                if (act) bpm[(size_t)t * 64] = tbl;    // 64 lanes, 256 contiguous bytes
-            }
+                    for (int q = 0; q < NS; q++) v[q] = nv[q];
+                    if (INNER) {
+                        bpm[(size_t)t * 64] = tbl;         // 64 lanes, 256 contiguous bytes (t < Tmax <= tmax rows)
+                    } else {
+                        if (act) bpm[(size_t)t * 64] = tbl;
+#pragma unroll
+                        for (int q = 0; q < NS; q++) vfin[q] = (t == T - 1) ? v[q] : vfin[q];
+                    }
+                }
+            };
+            if (inner) round(std::true_type()); else round(std::false_type());
         }
+#pragma unroll
+        for (int q = 0; q < NS; q++) v[q] = vfin[q];
         // ---- termination: ranks in order = the name-sorted order ---------------------
         double bestv = -__builtin_inf();
         int cur = 0;
@@ -947,14 +979,19 @@ int pxg_launch_unsplit_scan(pxg_ctx* ctx, int64_t n, int64_t units_bound, int tm
         const UnsplitDense D = unsplit_dense(ctx->hmm[1], P);
         // (units_bound is the host's upper bound, about 1.4 x the windows a batch really has: 10 000 reads of ~4 000
         //  blocks = 86 000 by the bound, 60 000 on the device = 940 groups for 1 024 SIMDs)
-        if ((units_bound + 63) / 64 <= (int64_t)ctx->n_cu * 6)
-            hipLaunchKernelGGL(k_unsplit_scan_w<4>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, n, tmax, D, P, cal, status,
-                               segs, first_sample, ev_off, ev_start, unit_off, scaled, bp, cand, cand_cnt, wcand,
-                               ctx->d_lsetab, ctx->unsplit_q.p);
-        else
-            hipLaunchKernelGGL(k_unsplit_scan_w<2>, dim3((unsigned)waves), dim3(64), 0, ctx->stream, n, tmax, D, P, cal, status,
-                               segs, first_sample, ev_off, ev_start, unit_off, scaled, bp, cand, cand_cnt, wcand,
-                               ctx->d_lsetab, ctx->unsplit_q.p);
+        unsigned long long edges = 0ull;            // the model's topology in rank space
+        for (int i = 0; i < UD_S; i++)
+            for (int q = 0; q < UD_S; q++)
+                if (D.A[i][q] > -__builtin_inf()) edges |= 1ull << (q * UD_S + i);
+        const bool shipped = edges == UNSPLIT_SHIPPED_EDGES && !getenv("PXG_UNSPLIT_DENSE");
+        const bool four = (units_bound + 63) / 64 <= (int64_t)ctx->n_cu * 6;
+#define SCANW(XC, E)                                                                                                          \
+        hipLaunchKernelGGL((k_unsplit_scan_w<XC, E>), dim3((unsigned)waves), dim3(64), 0, ctx->stream, n, tmax, D, P, cal, status, \
+                           segs, first_sample, ev_off, ev_start, unit_off, scaled, bp, cand, cand_cnt, wcand,                  \
+                           ctx->d_lsetab, ctx->unsplit_q.p)
+        if (four) { if (shipped) SCANW(4, UNSPLIT_SHIPPED_EDGES); else SCANW(4, UNSPLIT_ALL_EDGES); }
+        else      { if (shipped) SCANW(2, UNSPLIT_SHIPPED_EDGES); else SCANW(2, UNSPLIT_ALL_EDGES); }
+#undef SCANW
     } else {
         if (nin <= 2) SCAN(k_unsplit_scan, 2);
         else if (nin <= 3) SCAN(k_unsplit_scan, 3);

@@ -610,6 +610,14 @@ def test_unsplit_scan_synthetic_vs_oracle(ctx, oracle, config):
     finally:
         del os.environ['PXG_UNSPLIT_8_LANES']
     assert np.array_equal(cnt3, cnt) and np.array_equal(iv3, iv) and np.array_equal(start3, start)
+    # the one-window-per-lane kernel is specialised for the shipped model's 16 edges (round 6); PXG_UNSPLIT_DENSE sends the
+    # model through the dense form any other topology takes: same lists
+    os.environ['PXG_UNSPLIT_DENSE'] = '1'
+    try:
+        iv5, cnt5, start5 = ctx.unsplit_scan(first, nb)
+    finally:
+        del os.environ['PXG_UNSPLIT_DENSE']
+    assert np.array_equal(cnt5, cnt) and np.array_equal(iv5, iv) and np.array_equal(start5, start)
     _, cnt4, _ = ctx.unsplit_scan(first, np.zeros_like(nb))
     assert not cnt4.any()
     for i in np.nonzero(keep)[0]:
