@@ -146,7 +146,7 @@ class SignalAnalyzer(AbstractContextManager):
         phase = _HOST_PHASE if _USE_HOST_PHASE else _NoLock()
         t0 = time.perf_counter()
         with phase:
-            batch = self.prepare(reads, ReadTable())    # a table of its own: calls may overlap (threads)
+            batch = self.prepare(reads, ReadTable(len(reads)))    # a table of its own: calls may overlap (threads)
         t1 = time.perf_counter()
         self.loader.fit_scalers(batch.table)     # scaling parameters AND every other numeric stage
         t2 = time.perf_counter()

@@ -59,21 +59,23 @@ class ReadTable:
                ('polya_lazy', np.bool_), ('polya_begin', np.int64), ('polya_end', np.int64),
                ('polya_dwell_time', np.float64), ('polya_spike_count', np.int32))
 
-    def __init__(self):
+    def __init__(self, capacity=0):
+        """`capacity`: rows to make room for up front (a worker call knows how many reads it brings: the columns are
+        then allocated once instead of grown from nothing)."""
         self.n = 0
         for name, dtype in self.NUMERIC:
-            setattr(self, name, np.zeros(0, dtype=dtype))
-        self.scale_shift = np.zeros((0, 2), dtype=np.float32)
-        self.calib = np.zeros(0, dtype=native.CALIB_DTYPE)
+            setattr(self, name, np.zeros(capacity, dtype=dtype))
+        self.scale_shift = np.zeros((capacity, 2), dtype=np.float32)
+        self.calib = np.zeros(capacity, dtype=native.CALIB_DTYPE)
         # per-row Python objects
         self.filename, self.read_id, self.source = [], [], []
         self.channel, self.run_id, self.sample_id = [], [], []
         self.raw, self.sequence, self.error_message, self.polya = [], [], [], []
         self.unsplit = []
         # rows that came out of a read bundle: the bundle and the read's index in it
-        self.bundle, self.bundle_index = None, np.zeros(0, dtype=np.int64)
+        self.bundle, self.bundle_index = None, np.zeros(capacity, dtype=np.int64)
         # attached by the GPU pass
-        self.gpu_row = np.zeros(0, dtype=np.int64)      # row -> index in `records`, -1 if not run
+        self.gpu_row = np.zeros(capacity, dtype=np.int64)      # row -> index in `records`, -1 if not run
         self.records = None
         self.adapter_dump = None      # --dump-adapter-signals: (values, offsets) by GPU row
         self.event_frame = self.event_dump = None   # --dump-basecalls: frames by GPU row, columns by block stride
@@ -115,10 +117,11 @@ class ReadTable:
         k, d = len(idx), bundle.d
         lo, hi = self.n, self.n + k
         self.n = hi
-        for name, _ in self.NUMERIC:
-            setattr(self, name, _grown(getattr(self, name), hi))
-        for name in ('scale_shift', 'calib', 'gpu_row', 'bundle_index'):
-            setattr(self, name, _grown(getattr(self, name), hi))
+        if hi > len(self.status):               # (a table made with room for its batch skips this)
+            for name, _ in self.NUMERIC:
+                setattr(self, name, _grown(getattr(self, name), hi))
+            for name in ('scale_shift', 'calib', 'gpu_row', 'bundle_index'):
+                setattr(self, name, _grown(getattr(self, name), hi))
         rows = np.arange(lo, hi)
         self.status[rows], self.label[rows], self.gpu_row[rows] = _OKAY, _NO_LABEL, -1
         self.bundle, self.bundle_index[rows] = bundle, idx
@@ -481,7 +484,9 @@ class SignalLoader:
         self._pinned = []
 
     def clear(self):
-        self.table = ReadTable()
+        t = self.table
+        if t.n or t.records is not None or t._opened:      # (an untouched table is as good as a new one)
+            self.table = ReadTable()
 
     def exists(self, filename):
         if self.bundle is not None and self.bundle.has_file(filename):
