@@ -362,7 +362,9 @@ int pxg_batch_swap(pxg_ctx* ctx);
  * array that is NOT page-locked travels through page-locked chunks of the context (the GPU never addresses pageable
  * memory of the caller; the runtime's own in-place lock of such a source is what took the process down in round 4:
  * INTEGRATION.md section 2).  Register MAPPED pages of their own (mmap), never a slice of a malloc'ed block: a
- * brk-heap range that was page-locked once must not be page-locked again later in the process. */
+ * brk-heap range that was page-locked once must not be page-locked again later in the process.
+ * pxg_host_unregister accepts ctx == NULL: page locks are process-wide, and a range may have to be released after the
+ * context that registered it is gone (a staging arena must not be unmapped while it is still registered). */
 int pxg_host_register(pxg_ctx* ctx, void* ptr, size_t bytes);
 int pxg_host_unregister(pxg_ctx* ctx, void* ptr);
 int pxg_batch_run(pxg_ctx* ctx, uint32_t stage_mask);

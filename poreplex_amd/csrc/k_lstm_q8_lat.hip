@@ -43,6 +43,7 @@
 //  of it holds, zero-filled -- instead of further ds_read_b128 of the same bytes: K2 1.58 -> 1.75 ms at 1 024 reads, the
 //  last fragment of the half block alone 1.58 -> 1.65 (profiles/r06/ab_lat_forms.txt).  The step is bound by its
 //  dependent chain, not by LDS bandwidth: independent reads arrive back to back, the moves wait for the first.)
+
 // level l in slot l of every 16-lane row -> V = A0 256 + A1 in slot 1, U = A2 256 + A3 in slot 3
 __device__ __forceinline__ int ql_words(int acc)
 {
