@@ -36,6 +36,7 @@ def default_config(preset=DEFAULT_PRESET, **overrides):
         'barcoding': True,
         'measure_polya': False,
         'trim_adapter': False,
+        'trim_adapter_as_intended': False,      # NOT a reference option: see SignalAnalysis.trim_adapter
         'filter_unsplit_reads': False,
         'minimum_sequence_length': 10,
         'albacore_onthefly': False,

@@ -249,8 +249,8 @@ class SignalAnalyzer(AbstractContextManager):
         flagged -- is left to the per-read path, which raises exactly as before."""
         cfg = self.config
         settled = np.zeros(len(rows), dtype=bool)
-        if t.bundle is None or cfg['albacore_onthefly']:
-            return settled
+        if t.bundle is None or cfg['albacore_onthefly'] or (cfg['trim_adapter'] and cfg.get('trim_adapter_as_intended')):
+            return settled      # (the opt-in trimming walks every read's event table: the per-read path)
         bi = t.bundle_index[rows]
         pick = np.nonzero(todo & (bi >= 0))[0]
         if not len(pick):
@@ -529,7 +529,7 @@ class SignalAnalysis:
         bcall = self.npread.load_fast5_events()
         if self.npread.scaling_params is None:
             raise Exception('Signal scaling is not available yet.')
-        if not self.config['filter_unsplit_reads']:
+        if not self.config['filter_unsplit_reads'] and not (self.config['trim_adapter'] and self.config.get('trim_adapter_as_intended')):
             return bcall            # nothing downstream reads the table itself
         return self.event_frame(bcall)
 
@@ -557,10 +557,27 @@ class SignalAnalysis:
                 'p_model_state': pms}
 
     def trim_adapter(self, events, segments, elspan):
-        # signal_analyzer.py:328-331 returns as soon as a sequence is present, which is
-        # always the case after load_events: --trim-adapter is a no-op in this revision of
-        # the reference and stays one here.
-        return
+        """signal_analyzer.py:328-344.  The reference returns as soon as a sequence IS present (:329-331) -- which is
+        always the case after load_events: `--trim-adapter` is a no-op in this revision of the reference (SURVEY section
+        0), and stays one here by default.  `config['trim_adapter_as_intended'] = True` (not a reference option) runs
+        what the rest of that function was written to do, with the test the other way round: the basecalled length of
+        the adapter = moves of the events that start at or before the adapter's last sample + the k-mer's leading
+        half, recorded as the read's trimming length; longer than the sequence: 'basecall_table_incomplete'."""
+        if not self.config.get('trim_adapter_as_intended'):
+            return
+        sequence = self.npread.sequence
+        if sequence is None or 'adapter' not in segments:
+            return
+        adapter_end = segments['adapter'][1] * elspan
+        kmer_lead_size = self.analyzer.kmersize // 2
+        in_adapter = np.asarray(events['start']) <= adapter_end          # (:334, row by row: an albacore table need not be sorted)
+        if not in_adapter.any():
+            return
+        adapter_basecall_length = int(np.asarray(events['move'], dtype=np.int64)[in_adapter].sum()) + kmer_lead_size
+        if adapter_basecall_length > len(sequence[0]):
+            raise SignalAnalysisError('basecall_table_incomplete')
+        if adapter_basecall_length > 0:
+            self.npread.set_adapter_trimming_length(adapter_basecall_length)
 
     def detect_unsplit_read(self, events, segments, elspan):
         """Decision rule of :420-443 over the in-read adapter candidates the GPU window
