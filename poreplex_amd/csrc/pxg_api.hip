@@ -1947,13 +1947,13 @@ extern "C" int pxg_batch_unsplit_scan_events(pxg_ctx* ctx, const int64_t* n_even
         (rc = pxg_reserve(ctx, ctx->unsplit_cand, pxg_unsplit_cand_bytes(units_bound, wcand))))
         return rc;
     PXG_HIP(ctx, hipMemsetAsync(ctx->ev_first.p, 0, (size_t)n * sizeof(int64_t), ctx->stream));
+    StreamSyncOnError guard(ctx->stream);       // (from the first copy that may read the caller's arrays asynchronously)
     if ((rc = pxg_h2d_meta(ctx, 2, 1, ctx->ev_off.p, eoff.data(), ((size_t)n + 1) * sizeof(int64_t), ctx->stream)) ||
         // the per-EVENT columns (8 + 4 bytes x ~4 000 events per read) go in bounded page-locked chunks, not through a
         // mirror of their own size (pxg_h2d_meta is for the O(n_reads) arrays)
         (ne_all && ((rc = pxg_h2d_big(ctx, ctx->ev_tstart.p, ev_start, ne_all * sizeof(int64_t), ctx->stream)) ||
                     (rc = pxg_h2d_big(ctx, ctx->ev_mean.p, ev_mean, ne_all * sizeof(float), ctx->stream)))))
         return rc;
-    StreamSyncOnError guard(ctx->stream);
     pxg_timer_begin(ctx, PXG_T_EVENT_MEANS);
     if ((rc = pxg_launch_scale_event_means(ctx, n, (int64_t)ne_all, ctx->ev_off.p, ctx->ss.p, ctx->ev_mean.p, ctx->ev_scaled.p)))
         return rc;
