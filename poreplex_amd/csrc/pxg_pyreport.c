@@ -13,11 +13,23 @@
  * interpreter version), tests/test_facade.py compares the two on randomised tables.
  *
  *   _pxgpy.report(columns: dict, rows: int64 buffer) -> list of dict
+ *   _pxgpy.report_run(bundle columns: dict, first, n, records, adapter, barcoding, min_seq_len,
+ *                     status_names, label_names) -> list of dict
+ *
+ * report_run is the whole host side of the USUAL worker call behind the GPU pass -- consecutive reads of a read
+ * bundle, every one of them with a regular basecall summary (signal_analyzer.SignalAnalyzer.process_plain_run checks
+ * that before the pass) --: the status / label rules of SignalAnalysis.process (signal_analyzer.py:230-286) and of
+ * BarcodeDemultiplexer.predict (barcoding.py:108-118) applied to the pxg_read_result records, and the result dicts
+ * built from the bundle's own columns, in one pass per read and without a batch table in between.  The general path
+ * (ReadTable + SignalAnalyzer.judge + report) stays the definition; tests/test_plain_run.py holds the two against
+ * each other on the golden batches and on randomised ones.
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
 #include <string.h>
+
+#include "pxg.h"                  /* pxg_read_result, enum pxg_status: the records report_run reads */
 
 #if PY_VERSION_HEX >= 0x030d0000 || !defined(_PyDict_NewPresized)
 PyAPI_FUNC(PyObject*) _PyDict_NewPresized(Py_ssize_t minused);   /* exported by libpython, not in every public header */
@@ -303,8 +315,173 @@ done:
     return out;
 }
 
+
+/* a str from one element of a NumPy '<U' column: the characters before the trailing NULs (what ndarray.tolist() gives) */
+static PyObject* ucs4_item(const Buf* col, Py_ssize_t i)
+{
+    const Py_ssize_t width = col->view.itemsize / 4;
+    const Py_UCS4* p = (const Py_UCS4*)((const char*)col->view.buf + i * col->view.itemsize);
+    Py_ssize_t len = width;
+    while (len > 0 && p[len - 1] == 0) len--;
+    return PyUnicode_FromKindAndData(PyUnicode_4BYTE_KIND, p, len);
+}
+
+static int get_ucs4(PyObject* cols, const char* name, Buf* b, Py_ssize_t n_reads)
+{
+    b->held = 0;
+    memset(&b->view, 0, sizeof(b->view));
+    PyObject* o = PyDict_GetItemString(cols, name);
+    if (!o) { PyErr_Format(PyExc_KeyError, "report_run: column '%s' is missing", name); return -1; }
+    if (PyObject_GetBuffer(o, &b->view, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) < 0) return -1;
+    b->held = 1;
+    /* NumPy exports '<U8' as format "8w" (UCS4 code points) */
+    if (!b->view.format || !strchr(b->view.format, 'w') || b->view.itemsize % 4 || b->view.itemsize <= 0 ||
+        b->view.len / b->view.itemsize < n_reads) {
+        PyErr_Format(PyExc_TypeError, "report_run: column '%s' must be a contiguous unicode array with a row per read", name);
+        return -1;
+    }
+    return 0;
+}
+
+static int need_rows(const Buf* b, const char* name, Py_ssize_t rows)
+{
+    if (b->view.len / b->view.itemsize >= rows) return 0;
+    PyErr_Format(PyExc_IndexError, "report_run: column '%s' is shorter than the bundle", name);
+    return -1;
+}
+
+static PyObject* report_run(PyObject* self, PyObject* args)
+{
+    PyObject *cols, *rec_obj, *status_names, *label_names;
+    Py_ssize_t first, n;
+    int adapter, barcoding;
+    long long min_seq_len;
+    if (!PyArg_ParseTuple(args, "O!nnOipLO!O!", &PyDict_Type, &cols, &first, &n, &rec_obj, &adapter, &barcoding,
+                          &min_seq_len, &PyTuple_Type, &status_names, &PyTuple_Type, &label_names))
+        return NULL;
+    if (first < 0 || n < 0 || adapter < 0 || adapter >= PXG_N_SEGMENTS || PyTuple_GET_SIZE(status_names) < PXG_N_STATUS ||
+        PyTuple_GET_SIZE(label_names) < 2) {
+        PyErr_SetString(PyExc_ValueError, "report_run: bad arguments");
+        return NULL;
+    }
+    Buf rec, start_time, duration, calib, present, seq_len, qscore, n_events, seq_off, seq_arena, qual_arena, channel,
+        run_id, sample_id;
+    Buf* all[] = { &rec, &start_time, &duration, &calib, &present, &seq_len, &qscore, &n_events, &seq_off, &seq_arena,
+                   &qual_arena, &channel, &run_id, &sample_id };
+    for (size_t k = 0; k < sizeof(all) / sizeof(all[0]); k++) all[k]->held = 0;
+    PyObject* out = NULL;
+    const Py_ssize_t last = first + n;         /* reads [first, last) of the bundle */
+    if (PyObject_GetBuffer(rec_obj, &rec.view, PyBUF_C_CONTIGUOUS) < 0) return NULL;
+    rec.held = 1;
+    if (rec.view.itemsize != (Py_ssize_t)sizeof(pxg_read_result) || rec.view.len / rec.view.itemsize < n) {
+        PyErr_SetString(PyExc_TypeError, "report_run: records must be pxg_read_result items, one per read");
+        goto done;
+    }
+    if (get_buf(cols, "start_time", &start_time, 8, 0) || get_buf(cols, "duration", &duration, 8, 0) ||
+        get_buf(cols, "calib", &calib, 32, 0) || get_buf(cols, "bc_present", &present, 1, 0) ||
+        get_buf(cols, "bc_sequence_length", &seq_len, 8, 0) || get_buf(cols, "bc_mean_qscore", &qscore, 8, 0) ||
+        get_buf(cols, "bc_num_events", &n_events, 8, 0) || get_buf(cols, "seq_offsets", &seq_off, 8, 0) ||
+        get_buf(cols, "seq_arena", &seq_arena, 1, 0) || get_buf(cols, "qual_arena", &qual_arena, 1, 0) ||
+        get_ucs4(cols, "channel_number", &channel, last) || get_ucs4(cols, "run_id", &run_id, last) ||
+        get_ucs4(cols, "sample_id", &sample_id, last))
+        goto done;
+    if (need_rows(&start_time, "start_time", last) || need_rows(&duration, "duration", last) ||
+        need_rows(&calib, "calib", last) || need_rows(&present, "bc_present", last) ||
+        need_rows(&seq_len, "bc_sequence_length", last) || need_rows(&qscore, "bc_mean_qscore", last) ||
+        need_rows(&n_events, "bc_num_events", last) || need_rows(&seq_off, "seq_offsets", last + 1))
+        goto done;
+    PyObject *filenames = get_list(cols, "filenames", 0), *read_ids = get_list(cols, "read_ids", 0);
+    if (!filenames || !read_ids) goto done;
+    out = PyList_New(n);
+    if (!out) goto done;
+    {
+        const pxg_read_result* R = (const pxg_read_result*)rec.view.buf;
+        const int64_t* so = (const int64_t*)seq_off.view.buf;
+        PyObject* zero = PyLong_FromLong(0);
+        if (!zero) { Py_CLEAR(out); goto done; }
+        for (Py_ssize_t k = 0; k < n; k++) {
+            const Py_ssize_t b = first + k;
+            const pxg_read_result* r = R + k;
+            /* the rules, in the order the general path applies them (signal_loader.attach_records,
+             * SignalAnalyzer.judge, BarcodeDemultiplexer.assign, SignalAnalyzer.bulk_base_space) */
+            int status = PXG_ST_OKAY, label = -1, called = 0, summary = 0;
+            if (r->status == PXG_ST_SCALING_QC_FAIL) {
+                status = PXG_ST_SCALING_QC_FAIL;                     /* (:108-109: stops without a label) */
+            } else if (r->seg_first[adapter] < 0) {
+                status = PXG_ST_ADAPTER_NOT_DETECTED, label = 1;     /* 'fail' */
+            } else {
+                called = barcoding && r->bc_pushed && r->bc_called;
+                if (!((const uint8_t*)present.view.buf)[b]) {
+                    status = PXG_ST_NOT_BASECALLED, label = 1;
+                } else {
+                    summary = 1;
+                    if (so[b + 1] - so[b] < min_seq_len) status = PXG_ST_SEQUENCE_TOO_SHORT, label = 1;
+                    else label = 0;                                  /* 'pass' */
+                }
+            }
+            PyObject* d = _PyDict_NewPresized(20);
+            PyObject* o;
+            if (!d) goto fail_row;
+            if (!(o = item(filenames, b))) goto fail_row;
+            SET_BORROWED(d, KEYS[K_FILENAME], o);
+            if (!(o = item(read_ids, b))) goto fail_row;
+            SET_BORROWED(d, KEYS[K_READ_ID], o);
+            SET_BORROWED(d, KEYS[K_STATUS], PyTuple_GET_ITEM(status_names, status));
+            SET(d, KEYS[K_CHANNEL], ucs4_item(&channel, b));
+            {
+                const double rate = ((const double*)calib.view.buf)[4 * b + 3];       /* pxg_calib.sampling_rate */
+                if (rate == 0.0) { PyErr_SetString(PyExc_ZeroDivisionError, "float division by zero"); goto fail_row; }
+                SET(d, KEYS[K_START_TIME], round3((double)((const int64_t*)start_time.view.buf)[b] / rate));
+            }
+            SET(d, KEYS[K_RUN_ID], ucs4_item(&run_id, b));
+            SET(d, KEYS[K_SAMPLE_ID], ucs4_item(&sample_id, b));
+            SET(d, KEYS[K_DURATION], PyLong_FromLongLong(((const int64_t*)duration.view.buf)[b]));
+            if (summary) {
+                SET(d, KEYS[K_NUM_EVENTS], PyLong_FromLongLong(((const int64_t*)n_events.view.buf)[b]));
+                SET(d, KEYS[K_SEQUENCE_LENGTH], PyLong_FromLongLong(((const int64_t*)seq_len.view.buf)[b]));
+                /* the table keeps the summary's float32 in a float64 column */
+                SET(d, KEYS[K_MEAN_QSCORE], PyFloat_FromDouble((double)(float)((const double*)qscore.view.buf)[b]));
+                const int64_t lo = so[b], hi = so[b + 1];
+                if (lo < 0 || hi < lo || hi > seq_arena.view.len || hi > qual_arena.view.len) {
+                    PyErr_SetString(PyExc_IndexError, "report_run: sequence offsets outside the arena");
+                    goto fail_row;
+                }
+                PyObject* s = PyUnicode_DecodeASCII((const char*)seq_arena.view.buf + lo, hi - lo, NULL);
+                PyObject* q = s ? PyUnicode_DecodeASCII((const char*)qual_arena.view.buf + lo, hi - lo, NULL) : NULL;
+                PyObject* t = q ? PyTuple_Pack(3, s, q, zero) : NULL;
+                Py_XDECREF(s); Py_XDECREF(q);
+                if (t) PyObject_GC_UnTrack(t);          /* (str, str, int): see report() */
+                SET(d, KEYS[K_SEQUENCE], t);
+            } else {
+                SET_BORROWED(d, KEYS[K_NUM_EVENTS], zero);
+                SET_BORROWED(d, KEYS[K_SEQUENCE_LENGTH], zero);
+                SET_BORROWED(d, KEYS[K_MEAN_QSCORE], zero);
+            }
+            if (label >= 0) SET_BORROWED(d, KEYS[K_LABEL], PyTuple_GET_ITEM(label_names, label));
+            if (called) {
+                SET(d, KEYS[K_BARCODE], PyLong_FromLong(r->bc_label));
+                SET(d, KEYS[K_BARCODE_GUESS], PyLong_FromLong(r->bc_label));
+                SET(d, KEYS[K_BARCODE_SCORE], PyLong_FromLong(r->bc_phred));
+            }
+            PyList_SET_ITEM(out, k, d);
+            continue;
+        fail_row:
+            Py_XDECREF(d);
+            Py_CLEAR(out);
+            break;
+        }
+        Py_DECREF(zero);
+    }
+done:
+    for (size_t k = 0; k < sizeof(all) / sizeof(all[0]); k++)
+        if (all[k]->held) PyBuffer_Release(&all[k]->view);
+    return out;
+}
+
 static PyMethodDef METHODS[] = {
     { "report", report, METH_VARARGS, "report(columns, rows) -> list of result dicts (signal_loader.py:165-198)" },
+    { "report_run", report_run, METH_VARARGS,
+      "report_run(bundle columns, first, n, records, adapter, barcoding, min_seq_len, status names, label names) -> list of result dicts" },
     { NULL, NULL, 0, NULL }
 };
 

@@ -183,6 +183,44 @@ class ReadBundle:
         run = self.samples_run(i, i + 1)
         return run if isinstance(run, np.ndarray) else run.decode()
 
+    def plain_run_columns(self, scaler_cfg):
+        """What the worker call's short path needs of the bundle (signal_analyzer.process_plain_run, csrc/pxg_pyreport.c
+        report_run), made once: the columns as contiguous arrays of the types the extension reads, and `ok` -- the
+        reads a call may take that path with: long enough for the scaler (the gate of load_padded_signal_head,
+        signal_loader.py:212-222) and either without a basecall or with a summary whose Guppy frame fits the raw signal
+        (SignalAnalyzer.bulk_base_space's `regular', the part of it that does not depend on the GPU pass).  None if the
+        bundle cannot take the path at all."""
+        key = (scaler_cfg['length'], scaler_cfg['stride'], scaler_cfg['min_length'])
+        cached = getattr(self, '_plain', None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        d = self.d
+        plain = None
+        n = len(self.filenames)
+        text = [np.ascontiguousarray(d[name]) for name in ('channel_number', 'run_id', 'sample_id')]
+        if all(a.dtype.kind == 'U' and a.dtype.isnative and a.ndim == 1 and len(a) == n for a in text) \
+                and (d['calib']['sampling_rate'] != 0).all():
+            o = np.ascontiguousarray(d['offsets'], dtype=np.int64)
+            n_raw = np.diff(o)
+            usable = np.minimum(np.minimum(scaler_cfg['length'], d['duration']), n_raw)
+            long_enough = usable - usable % scaler_cfg['stride'] >= scaler_cfg['min_length']
+            first, stride, n_moves = d['bc_first_sample'], d['bc_block_stride'].astype(np.int64), d['bc_n_moves']
+            covered = np.maximum(np.minimum(first + stride * n_moves, n_raw) - first, 0)
+            kind = d['bc_table']
+            regular = ((kind == 1) | (kind == 2)) & (n_moves >= 0) & (stride > 0) & \
+                (-(-covered // np.maximum(stride, 1)) == n_moves)
+            plain = {'ok': long_enough & (~d['bc_present'].astype(bool) | regular), 'offsets': o,
+                     'filenames': self.filenames, 'read_ids': self.read_ids,
+                     'channel_number': text[0], 'run_id': text[1], 'sample_id': text[2],
+                     'calib': np.ascontiguousarray(d['calib'])}
+            for name, dtype in (('start_time', np.int64), ('duration', np.int64), ('bc_present', np.bool_),
+                                ('bc_sequence_length', np.int64), ('bc_mean_qscore', np.float64),
+                                ('bc_num_events', np.int64), ('seq_offsets', np.int64), ('seq_arena', np.uint8),
+                                ('qual_arena', np.uint8)):
+                plain[name] = np.ascontiguousarray(d[name], dtype=dtype)
+        self._plain = (key, plain)
+        return plain
+
     def has_file(self, filename):
         return filename in self.by_file or filename in self.broken
 

@@ -15,6 +15,7 @@ basecall group run per read.  There is no CPU fallback: a missing library or
 GPU surfaces as the ``(-1, msg, traceback)`` tuple the pipeline treats as fatal
 (pipeline.py:207-213).
 """
+import gc
 import multiprocessing as mp
 import os
 import sys
@@ -28,7 +29,7 @@ from weakref import proxy
 import numpy as np
 
 from . import native
-from .signal_loader import NanoporeRead, ReadTable, SignalAnalysisError
+from .signal_loader import LABELS, NanoporeRead, ReadTable, SignalAnalysisError
 from .utils import union_intervals  # noqa: F401  (re-exported like the reference)
 from .worker_persistence import WorkerPersistenceStorage
 
@@ -43,6 +44,8 @@ __all__ = ['SignalAnalyzer', 'SignalAnalysis', 'process_batch']
 # holds it runs its phase undisturbed.  The GPU pass in between holds neither.  (PXG_NO_HOST_PHASE_LOCK=1: off.)
 _HOST_PHASE = threading.Lock()
 _USE_HOST_PHASE = os.environ.get('PXG_NO_HOST_PHASE_LOCK') is None
+# (A/B and tests: PXG_NO_PLAIN_RUN=1 sends every call through the batch table)
+_PLAIN_RUN = os.environ.get('PXG_NO_PLAIN_RUN') is None
 
 
 class _NoLock:
@@ -144,6 +147,10 @@ class SignalAnalyzer(AbstractContextManager):
         """Result list of signal_analyzer.py:82-134: whatever was decided before the GPU
         pass first (encounter order), then every read that entered it (input order)."""
         phase = _HOST_PHASE if _USE_HOST_PHASE else _NoLock()
+        if _PLAIN_RUN:
+            results = self.process_plain_run(reads, phase)
+            if results is not None:
+                return results
         t0 = time.perf_counter()
         with phase:
             batch = self.prepare(reads, ReadTable(len(reads)))    # a table of its own: calls may overlap (threads)
@@ -153,6 +160,56 @@ class SignalAnalyzer(AbstractContextManager):
         with phase:
             results = self.finish(batch)
         if CALL_TRACE is not None:               # bench.py: where a worker call spends its time
+            CALL_TRACE.append((t0, t1, t2, time.perf_counter()))
+        return results
+
+    def process_plain_run(self, reads, phase):
+        """process() for the usual worker call, without a batch table: `reads` is a run of consecutive reads of the
+        read bundle, all of them long enough for the scaler and regular in their basecall summary
+        (ReadBundle.plain_run_columns), and the configuration asks for nothing that walks a read (dumps, poly(A),
+        the chimera scan, on-the-fly basecalling, the opt-in adapter trimming).  The samples go to the GPU as the
+        bundle's own arena, the records come back, and csrc/pxg_pyreport.c report_run applies the status / label rules
+        and builds the dicts in one pass: ~0.1 ms of Python for 128 reads where prepare + judge + report take 0.35 --
+        the interpreter lock is what bounds worker threads that feed the GPU in reference-sized calls.
+        None = not such a call: the general path takes it, and defines what this one must return
+        (tests/test_plain_run.py)."""
+        loader, cfg = self.loader, self.config
+        b = loader.bundle
+        if b is None or self.dump_adapter or self.dump_events or loader.scan_unsplit or cfg['measure_polya'] \
+                or cfg['albacore_onthefly'] or (cfg['trim_adapter'] and cfg.get('trim_adapter_as_intended')) \
+                or type(reads) is not list or not reads or type(reads[0]) is not tuple:
+            return None
+        fast = native.load_pyhost()
+        if fast is None or not hasattr(fast, 'report_run'):
+            return None
+        t0 = time.perf_counter()
+        with phase:
+            plain = b.plain_run_columns(loader.scaler_cfg)
+            if plain is None:
+                return None
+            n = len(reads)
+            first = b.index.get(reads[0], -1)
+            if first < 0 or b.keys[first:first + n] != reads or not plain['ok'][first:first + n].all():
+                return None
+            if b.broken and any(key[0] in b.broken for key in reads):      # (files that exist but cannot be opened)
+                return None
+            o = plain['offsets'][first:first + n + 1]
+            arena, offsets, calib = b.samples_run(first, first + n), o - o[0], plain['calib'][first:first + n]
+        loader.pin_bundle()
+        t1 = time.perf_counter()
+        records = loader.records_of_run(arena, offsets, calib)
+        t2 = time.perf_counter()
+        with phase:
+            was_on = gc.isenabled()          # (nothing report_run builds can be part of a cycle: ReadTable.report)
+            gc.disable()
+            try:
+                results = fast.report_run(plain, first, n, records, self.ctx.state_names.index('adapter'),
+                                          bool(cfg['barcoding']), int(cfg['minimum_sequence_length']),
+                                          tuple(native.STATUS_NAMES), tuple(LABELS))
+            finally:
+                if was_on:
+                    gc.enable()
+        if CALL_TRACE is not None:
             CALL_TRACE.append((t0, t1, t2, time.perf_counter()))
         return results
 

@@ -831,6 +831,38 @@ class SignalLoader:
         finally:
             unlock(1)
 
+    def records_of_run(self, arena, offsets, calib):
+        """The GPU pass of fit_scalers for a batch that needs nothing but its records (no scan, no dumps, no spikes):
+        the one native call, or -- a context double of the CPU tests -- the same steps under the same two locks."""
+        ctx = self.ctx
+        if hasattr(ctx, 'process_batch_ex'):
+            return ctx.process_batch_ex(arena, offsets, calib, self.stage_mask)['records']
+        native_locks = hasattr(ctx, 'lock')
+        lock = ctx.lock if native_locks else (lambda w: (self._run_lock if w else self._stage_lock).acquire())
+        unlock = ctx.unlock if native_locks else (lambda w: (self._run_lock if w else self._stage_lock).release())
+        lock(0)
+        try:
+            limit = {}
+            if hasattr(ctx, 'prefix_limit_for'):
+                limit = {'prefix_limit': ctx.prefix_limit_for(self.stage_mask, False)}
+            if isinstance(arena, native.EncodedSamples):
+                ctx.stage_z(arena, offsets, calib, **limit)
+            else:
+                ctx.stage(arena, offsets, calib, **limit)
+            lock(1)
+            try:
+                ctx.swap()
+            except BaseException:
+                unlock(1)
+                raise
+        finally:
+            unlock(0)
+        try:
+            ctx.run(self.stage_mask)
+            return ctx.download()
+        finally:
+            unlock(1)
+
     def has_own_event_tables(self, table, rows):
         """Does any read of the batch carry an albacore Events table (its own event boundaries)?"""
         t = table

@@ -1,0 +1,310 @@
+"""The worker call's short path (SignalAnalyzer.process_plain_run + csrc/pxg_pyreport.c report_run) against the path
+that defines it (ReadTable + SignalAnalyzer.judge + ReadTable.report): CPU only, no GPU involved -- both paths take
+the SAME records, from a context double.
+
+  * randomised bundles and crafted records (every status the rules can give, every barcode combination): the two
+    paths return equal objects -- same keys in the same order, same value types, same values;
+  * the calls the short path must decline (a short read in the run, an irregular basecall summary, a shuffled or
+    foreign request, lists instead of tuples, options that walk a read) -- it returns None and the general path runs;
+  * stretches of the golden batch, through the oracle-backed double: the short path's dicts equal the REAL
+    reference's (tests/golden/batch0.results.json).
+"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_context
+from poreplex_amd import native as N
+from poreplex_amd import signal_analyzer as SA
+from poreplex_amd.config import default_config
+from poreplex_amd.fast5_file import ReadBundle, write_bundle
+from poreplex_amd.worker_persistence import WorkerPersistenceStorage
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+pytestmark = pytest.mark.skipif(N.load_pyhost() is None or not hasattr(N.load_pyhost(), 'report_run'),
+                                reason='csrc/_pxgpy is not built for this interpreter')
+
+
+def worker_objects():
+    return sys.modules[WorkerPersistenceStorage.STORAGE_NAME].storage
+
+
+def same(a, b, where='result'):
+    """a and b are equal objects of equal types, recursively; dicts also agree in key order"""
+    assert type(a) is type(b), (where, type(a), type(b))
+    if isinstance(a, dict):
+        assert list(a) == list(b), (where, list(a), list(b))
+        for k in a:
+            same(a[k], b[k], '{}[{!r}]'.format(where, k))
+    elif isinstance(a, (list, tuple)):
+        assert len(a) == len(b), (where, len(a), len(b))
+        for k, (x, y) in enumerate(zip(a, b)):
+            same(x, y, '{}[{}]'.format(where, k))
+    elif isinstance(a, float):
+        assert (a == b and math.copysign(1, a) == math.copysign(1, b)) or (a != a and b != b), (where, a, b)
+    else:
+        assert a == b, (where, a, b)
+
+
+class CraftedRecords(oracle_context.OracleBackedContext):
+    """Context double whose GPU pass returns records made up per read (the read is recognised by its calibration
+    offset, which the bundle below numbers)."""
+    table = None
+
+    def process_batch_ex(self, samples, offsets, calib, stage_mask=N.STAGE_ALL_DEMUX, scale_shift=None, unsplit=None,
+                         want_spikes=False):
+        which = np.asarray(calib)['offset'].astype(np.int64)
+        assert len(which) == len(offsets) - 1
+        return {'records': CraftedRecords.table[which].copy()}
+
+
+def crafted_bundle(tmp_path, n, seed):
+    """A bundle of n reads (read k has calibration offset k) and one crafted record per read."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(9600, 12000, n)
+    short = rng.random(n) < 0.04
+    lens[short] = rng.integers(100, 8000, int(short.sum()))              # (the scaler needs 9 000 samples)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    arena = rng.integers(300, 900, int(off[-1])).astype(np.int16)
+    cal = np.zeros(n, dtype=N.CALIB_DTYPE)
+    cal['range'], cal['digitisation'] = 1400.0, 8192.0
+    cal['offset'] = np.arange(n)
+    cal['sampling_rate'] = rng.choice([3012.0, 4000.0, 3012.5], n)
+    names = ['run{}/f{:03d}.fast5'.format(k // 50, k // 4) for k in range(n)]
+    ids = ['{:08x}-0000-4000-8000-{:012x}'.format(seed, k) for k in range(n)]
+    basecalls = []
+    for k in range(n):
+        u = rng.random()
+        if u < 0.12:
+            basecalls.append(None)                                       # not basecalled
+            continue
+        n_blocks = int(lens[k]) // 15
+        n_bases = int(rng.integers(3, 9)) if u < 0.24 else int(rng.integers(12, 60))      # some below the minimum length
+        move = np.zeros(n_blocks, dtype=np.uint8)
+        move[rng.choice(n_blocks, size=n_bases - 4 if n_bases > 4 else 1, replace=False)] = 1
+        n_bases = int(move.sum()) + 4
+        bc = {'sequence': ''.join('ACGU'[i] for i in rng.integers(0, 4, n_bases)),
+              'qstring': ''.join(chr(33 + q) for q in rng.integers(5, 25, n_bases)), 'block_stride': 15,
+              'sequence_length': n_bases, 'mean_qscore': float(rng.uniform(5, 14)),      # (a float64 the table rounds to float32)
+              'num_events': n_blocks, 'first_sample_template': 0, 'table': 'move', 'move': move}
+        if 0.24 <= u < 0.27:
+            bc['move'] = move[:-3]                                       # a frame that does not fit the raw signal: irregular
+        basecalls.append(bc)
+    path = str(tmp_path / 'crafted{}.pxr.npz'.format(seed))
+    write_bundle(path, arena, off, cal, names, ids, basecalls=basecalls)
+    rec = np.zeros(n, dtype=N.RESULT_DTYPE)
+    rec['seg_first'], rec['seg_last'] = -1, -1
+    adapter = 0                                                          # filled in by the caller (state order of the model)
+    rec['status'] = np.where(rng.random(n) < 0.1, N.STATUS_CODE['scaling_qc_fail'], 0)
+    rec['scale'], rec['shift'] = rng.uniform(0.7, 1.2, n), rng.uniform(-10, 20, n)
+    rec['bc_pushed'] = rng.random(n) < 0.8
+    rec['bc_called'] = rng.random(n) < 0.7
+    rec['bc_label'] = rng.integers(0, 4, n)
+    rec['bc_phred'] = rng.integers(0, 60, n)
+    found = rng.random(n) >= 0.1
+    return path, rec, found, short, adapter
+
+
+@pytest.fixture()
+def crafted(monkeypatch):
+    WorkerPersistenceStorage.reset()
+    monkeypatch.setattr(N, 'NativeContext', CraftedRecords)
+    yield
+    WorkerPersistenceStorage.reset()
+    CraftedRecords.table = None
+
+
+def spy_on_the_short_path(monkeypatch):
+    taken = []
+    real = SA.SignalAnalyzer.process_plain_run
+
+    def spy(self, reads, phase):
+        out = real(self, reads, phase)
+        taken.append(out is not None)
+        return out
+    monkeypatch.setattr(SA.SignalAnalyzer, 'process_plain_run', spy)
+    return taken
+
+
+@pytest.mark.parametrize('barcoding', [True, False])
+@pytest.mark.parametrize('seed', [1, 2])
+def test_short_path_equals_the_general_path(crafted, monkeypatch, tmp_path, seed, barcoding):
+    n = 400
+    path, rec, found, short, _ = crafted_bundle(tmp_path, n, seed)
+    cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path), read_bundle=path, barcoding=barcoding,
+                         minimum_sequence_length=10)
+    # one call to make the worker's objects (the context knows where the model keeps its adapter state)
+    keys = ReadBundle(path).keys
+    CraftedRecords.table = rec
+    first = SA.process_batch(0, keys[:1], cfg)
+    assert isinstance(first, list), first
+    adapter = worker_objects()['ctx'].state_names.index('adapter')
+    ok = ReadBundle(path).plain_run_columns(worker_objects()['loader'].scaler_cfg)['ok']
+    rec['seg_first'][:, adapter] = np.where(found, 40, -1)
+    rec['seg_last'][:, adapter] = np.where(found, 90, -1)
+    rng = np.random.default_rng(100 + seed)
+    taken = spy_on_the_short_path(monkeypatch)
+    statuses, keysets, n_taken = set(), set(), 0
+    windows = [(0, n)] + [(int(a), int(rng.integers(1, 70))) for a in rng.integers(0, n - 1, 60)]
+    for lo, k in windows:
+        reads = keys[lo:lo + k]
+        monkeypatch.setattr(SA, '_PLAIN_RUN', True)
+        del taken[:]
+        fast = SA.process_batch(1, list(reads), cfg)
+        took = taken == [True]
+        monkeypatch.setattr(SA, '_PLAIN_RUN', False)
+        general = SA.process_batch(1, list(reads), cfg)
+        assert isinstance(general, list), general
+        assert took == bool(ok[lo:lo + k].all()), (lo, k)
+        if took:
+            n_taken += 1
+            same(fast, general, 'reads[{}:{}]'.format(lo, lo + k))
+            statuses |= {r['status'] for r in fast}
+            keysets |= {tuple(r) for r in fast}
+        else:
+            assert [r['read_id'] for r in fast if 'read_id' in r] == [r['read_id'] for r in general if 'read_id' in r]
+    assert n_taken >= 15
+    assert statuses == {'okay', 'scaling_qc_fail', 'adapter_not_detected', 'not_basecalled', 'sequence_too_short'}
+    assert any('barcode' in ks for ks in keysets) == barcoding and any('sequence' not in ks for ks in keysets)
+
+
+def test_calls_the_short_path_declines(crafted, monkeypatch, tmp_path):
+    path, rec, found, short, _ = crafted_bundle(tmp_path, 120, 7)
+    CraftedRecords.table = rec
+    b = ReadBundle(path)
+    cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path), read_bundle=path, barcoding=True)
+    ok = b.plain_run_columns({'length': 30000, 'stride': 15, 'min_length': 9000})['ok']
+    assert not ok[short].any() and ok.sum() > 60
+    # a stretch of plain reads
+    run = max((j - i, i, j) for i in range(120) for j in range(i + 1, 121) if ok[i:j].all())
+    lo, hi = run[1], run[2]
+    assert hi - lo >= 5
+    good = b.keys[lo:hi]
+    taken = spy_on_the_short_path(monkeypatch)
+
+    def call(reads, **kw):
+        del taken[:]
+        out = SA.process_batch(3, reads, dict(cfg, **kw))
+        assert kw or isinstance(out, list), out          # (with other options on, the double's answers may not do)
+        return taken[-1], out
+    assert call(list(good))[0] is True
+    assert call(list(good[:1]))[0] is True
+    reference = call(list(good))[1]
+    for reads in (list(reversed(good)),                         # not in bundle order
+                  [list(k) for k in good],                      # lists: the general path takes any sequence of pairs
+                  tuple(good),
+                  list(good) + [('elsewhere/x.fast5', 'nobody')],
+                  list(good[:2]) + list(good[3:])):             # a gap
+        took, out = call(reads)
+        assert took is False and len(out) == len(reads)
+    took, out = call([list(k) for k in good])
+    same(out, reference)
+    for option in ({'measure_polya': True}, {'filter_unsplit_reads': True}, {'dump_adapter_signals': True},
+                   {'trim_adapter': True, 'trim_adapter_as_intended': True}):
+        WorkerPersistenceStorage.reset()
+        assert call(list(good), **option)[0] is False, option
+    WorkerPersistenceStorage.reset()
+    bad = int(np.nonzero(~ok)[0][0])                            # a run with one read that is not plain in it
+    took, out = call(b.keys[max(bad - 2, 0):bad + 3])
+    assert took is False
+    # nothing to do is not a run either
+    assert call([])[1] == [] and taken == [False]
+
+
+def test_short_path_against_the_real_reference(monkeypatch):
+    """Stretches of the golden batch that are plain runs, through the oracle-backed double: the REAL reference's
+    dicts (poly(A) apart: the path is for calls without that stage)."""
+    import test_facade as TF
+    WorkerPersistenceStorage.reset()
+    monkeypatch.setattr(N, 'NativeContext', TF.OracleBackedContext)
+    try:
+        with open(os.path.join(GOLDEN, 'batch0.results.json')) as fh:
+            ref = json.load(fh)
+        cfg = TF.facade_config(ref, measure_polya=False)
+        want = {(r['filename'], r.get('read_id')): r for r in ref['results']}
+        b = ReadBundle(TF.BUNDLE)
+        ok = b.plain_run_columns({'length': 30000, 'stride': 15, 'min_length': 9000})['ok']
+        reads = [tuple(r) for r in ref['reads']]
+        at = [b.index.get(k, -1) for k in reads]
+        taken = spy_on_the_short_path(monkeypatch)
+        covered, pos = 0, 0
+        while pos < len(reads):
+            end = pos
+            while end < len(reads) and at[end] >= 0 and ok[at[end]] and at[end] == at[pos] + (end - pos) and \
+                    reads[end][0] not in b.broken:
+                end += 1
+            if end == pos:
+                pos += 1
+                continue
+            got = SA.process_batch(ref['batchid'], reads[pos:end], cfg)
+            assert taken[-1] is True and isinstance(got, list)
+            TF.compare_results(got, [want[k] for k in reads[pos:end]], check_polya=False)
+            covered += end - pos
+            pos = end
+        assert covered >= 24, covered
+    finally:
+        WorkerPersistenceStorage.reset()
+
+
+def test_short_path_from_many_threads(crafted, monkeypatch, tmp_path):
+    """Worker threads sharing the context (the reference keeps `parallel` calls in flight, pipeline.py:96): every call
+    gets the dicts of its own reads."""
+    from concurrent.futures import ThreadPoolExecutor
+    path, rec, found, short, _ = crafted_bundle(tmp_path, 400, 11)
+    CraftedRecords.table = rec
+    cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path), read_bundle=path, barcoding=True)
+    keys = ReadBundle(path).keys
+    assert isinstance(SA.process_batch(0, keys[:1], cfg), list)
+    adapter = worker_objects()['ctx'].state_names.index('adapter')
+    rec['seg_first'][:, adapter] = np.where(found, 40, -1)
+    ok = worker_objects()['loader'].bundle.plain_run_columns(worker_objects()['loader'].scaler_cfg)['ok']
+    rng = np.random.default_rng(5)
+    windows = [(int(a), int(rng.integers(1, 40))) for a in rng.integers(0, 399, 200)]
+    monkeypatch.setattr(SA, '_PLAIN_RUN', False)
+    want = [SA.process_batch(k, keys[lo:lo + n], cfg) for k, (lo, n) in enumerate(windows)]
+    monkeypatch.setattr(SA, '_PLAIN_RUN', True)
+    taken = spy_on_the_short_path(monkeypatch)
+    with ThreadPoolExecutor(8) as pool:
+        got = list(pool.map(lambda kw: SA.process_batch(kw[0], keys[kw[1][0]:kw[1][0] + kw[1][1]], cfg), enumerate(windows)))
+    assert sum(taken) == sum(bool(ok[lo:lo + n].all()) for lo, n in windows) > 20
+    for g, w, (lo, n) in zip(got, want, windows):
+        if ok[lo:lo + n].all():
+            same(g, w)
+        else:
+            assert isinstance(g, list) and len(g) == len(w)
+
+
+@pytest.mark.gpu
+def test_short_path_equals_the_general_path_on_the_gpu(monkeypatch, tmp_path):
+    """The same comparison with the real context: a synthetic bundle, 128-read calls, from threads as well."""
+    from concurrent.futures import ThreadPoolExecutor
+    from poreplex_amd.synth import synth_basecalls, synth_batch
+    n = 384
+    sb = synth_batch(n, seed=31, samples_per_read=20000)
+    names = ['a/r{:05d}.fast5'.format(i) for i in range(n)]
+    ids = ['{:08x}-0000-4000-8000-{:012x}'.format(31, i) for i in range(n)]
+    path = str(tmp_path / 'gpu.pxr.npz')
+    write_bundle(path, sb['arena'], sb['offsets'], sb['calib'], names, ids, basecalls=synth_basecalls(sb, seed=31))
+    cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path), read_bundle=path, barcoding=True)
+    keys = list(zip(names, ids))
+    WorkerPersistenceStorage.reset()
+    try:
+        monkeypatch.setattr(SA, '_PLAIN_RUN', False)
+        want = [SA.process_batch(k, keys[lo:lo + 128], cfg) for k, lo in enumerate(range(0, n, 128))]
+        assert all(isinstance(w, list) for w in want), want
+        monkeypatch.setattr(SA, '_PLAIN_RUN', True)
+        taken = spy_on_the_short_path(monkeypatch)
+        got = [SA.process_batch(k, keys[lo:lo + 128], cfg) for k, lo in enumerate(range(0, n, 128))]
+        assert taken == [True] * 3
+        same(got, want)
+        assert {r['status'] for w in want for r in w} >= {'okay'}
+        with ThreadPoolExecutor(6) as pool:
+            again = list(pool.map(lambda lo: SA.process_batch(9, keys[lo:lo + 128], cfg), list(range(0, n, 128)) * 4))
+        same(again, want * 4)
+    finally:
+        WorkerPersistenceStorage.reset()

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""What the HOST side of reference-sized worker calls can sustain, without a GPU.
+
+`process_batch` is called with 128 consecutive reads of a read bundle, one call at a time and from 8 / 32 / 64 threads
+of one interpreter, over a stand-in context whose GPU pass is `time.sleep(--gpu-ms)` (interpreter lock released, like
+the real call) and whose records are made up.  The GPU pass overlaps freely here, so the figure at 32 threads is what
+the interpreter lock allows -- the ceiling the measured GPU figure (profiles/r06/api_128_read_calls.txt) sits under --
+and the one-at-a-time figure minus the sleep is the Python cost of a call.
+
+    python tools/dev/host_cap.py                  # the shipped path
+    PXG_NO_PLAIN_RUN=1 python tools/dev/host_cap.py      # every call through the batch table (the path before)
+"""
+import argparse
+import os
+import sys
+import tempfile
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
+from poreplex_amd import native as N                                      # noqa: E402
+from poreplex_amd import signal_analyzer as SA                            # noqa: E402
+from poreplex_amd.config import default_config                            # noqa: E402
+from poreplex_amd.fast5_file import write_bundle                          # noqa: E402
+from poreplex_amd.synth import synth_basecalls, synth_batch               # noqa: E402
+from poreplex_amd.worker_persistence import WorkerPersistenceStorage      # noqa: E402
+
+
+class SleepingContext:
+    """Stand-in for native.NativeContext: the one native call of a worker batch, answered after a sleep."""
+    gpu_ms = 3.0
+    records = None
+
+    def __init__(self, config, device_id=0):
+        self.ncfg = N.NativeConfig(config)
+        self.cfg = self.ncfg.struct
+        self.state_names = self.ncfg.state_names
+
+    def pin(self, array):
+        return array
+
+    def unpin(self, array):
+        pass
+
+    def close(self):
+        pass
+
+    def process_batch_ex(self, samples, offsets, calib, stage_mask=N.STAGE_ALL_DEMUX, scale_shift=None, unsplit=None,
+                         want_spikes=False):
+        time.sleep(self.gpu_ms * 1e-3)
+        return {'records': SleepingContext.records[:len(offsets) - 1].copy()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--reads', type=int, default=128)
+    ap.add_argument('--gpu-ms', type=float, default=3.0)
+    ap.add_argument('--calls', type=int, default=640)
+    ap.add_argument('--repeats', type=int, default=4)
+    args = ap.parse_args()
+    n = args.reads
+    sb = synth_batch(n, seed=924, samples_per_read=20000)
+    work = tempfile.mkdtemp(prefix='pxg_hostcap_')
+    names = ['a/r%07d.fast5' % i for i in range(n)]
+    ids = ['%08x-0000-4000-8000-%012x' % (924, i) for i in range(n)]
+    path = os.path.join(work, 'b.pxr.npz')
+    write_bundle(path, sb['arena'], sb['offsets'], sb['calib'], names, ids, basecalls=synth_basecalls(sb, seed=924))
+    cfg = default_config(inputdir=work, outputdir=work, read_bundle=path, barcoding=True)
+    SleepingContext.gpu_ms = args.gpu_ms
+    N.NativeContext = SleepingContext
+    WorkerPersistenceStorage.reset()
+    rng = np.random.default_rng(924)
+    rec = np.zeros(n, dtype=N.RESULT_DTYPE)                 # mostly passing reads with a barcode, like a good run
+    adapter = N.NativeConfig(cfg).state_names.index('adapter')
+    rec['seg_first'], rec['seg_last'] = -1, -1
+    rec['seg_first'][:, adapter], rec['seg_last'][:, adapter] = np.where(rng.random(n) < 0.95, 30, -1), 80
+    rec['scale'], rec['shift'] = 1.0, 0.0
+    rec['bc_pushed'], rec['bc_called'] = rng.random(n) < 0.95, rng.random(n) < 0.8
+    rec['bc_label'], rec['bc_phred'] = rng.integers(0, 4, n), rng.integers(10, 50, n)
+    SleepingContext.records = rec
+    reads = list(zip(names, ids))
+    first = SA.process_batch(0, reads, cfg)
+    assert isinstance(first, list) and len(first) == n, first
+    print('path: %s' % ('batch table (PXG_NO_PLAIN_RUN)' if not SA._PLAIN_RUN else 'plain run'))
+    t0 = time.perf_counter()
+    for k in range(50):
+        SA.process_batch(1 + k, reads, cfg)
+    one = (time.perf_counter() - t0) / 50
+    print('one call at a time: %.3f ms per call, %.1f ms of it the sleep -> %.3f ms of Python per %d-read call'
+          % (one * 1e3, args.gpu_ms, one * 1e3 - args.gpu_ms, n))
+    for threads in (8, 32, 64):
+        rates = []
+        for _ in range(args.repeats):          # (a shared development host is noisy: every repeat is printed)
+            with ThreadPoolExecutor(threads) as pool:
+                t0 = time.perf_counter()
+                list(pool.map(lambda k: len(SA.process_batch(100 + k, reads, cfg)), range(args.calls)))
+                rates.append(args.calls / (time.perf_counter() - t0))
+        print('%2d threads: best %5.0f calls/s = %6.0f reads/s (%.3f ms of wall clock per call); all: %s'
+              % (threads, max(rates), max(rates) * n, 1e3 / max(rates), ' '.join('%.0f' % r for r in rates)))
+    WorkerPersistenceStorage.reset()
+
+
+if __name__ == '__main__':
+    main()
