@@ -14,7 +14,7 @@
  *
  *   _pxgpy.report(columns: dict, rows: int64 buffer) -> list of dict
  *   _pxgpy.report_run(bundle columns: dict, first, n, records, adapter, barcoding, min_seq_len,
- *                     status_names, label_names) -> list of dict
+ *                     status_names, label_names[, measure_polya, spike rows, spike offsets]) -> list of dict
  *
  * report_run is the whole host side of the USUAL worker call behind the GPU pass -- consecutive reads of a read
  * bundle, every one of them with a regular basecall summary (signal_analyzer.SignalAnalyzer.process_plain_run checks
@@ -117,6 +117,39 @@ static PyObject* item(PyObject* seq, Py_ssize_t i)         /* borrowed; list or 
     }
     if (i < 0 || i >= PyTuple_GET_SIZE(seq)) { PyErr_SetString(PyExc_IndexError, "report: row outside a column"); return NULL; }
     return PyTuple_GET_ITEM(seq, i);
+}
+
+/* the dict of polya.py:116-121 from a called tail: begin, end, dwell time, and one (length, before, spike, after) tuple per
+ * spike row; new reference, NULL with an exception set */
+static PyObject* polya_dict(long long begin, long long end, double dwell_time, Py_ssize_t ns, const float* rows)
+{
+    PyObject* p = PyDict_New();
+    if (!p) return NULL;
+    PyObject* v;
+    int bad = 0;
+    bad |= !(v = PyLong_FromLongLong(begin)) || PyDict_SetItem(p, KEYS[K_BEGIN], v) < 0;
+    Py_XDECREF(v);
+    bad |= !(v = PyLong_FromLongLong(end)) || PyDict_SetItem(p, KEYS[K_END], v) < 0;
+    Py_XDECREF(v);
+    bad |= !(v = PyFloat_FromDouble(dwell_time)) || PyDict_SetItem(p, KEYS[K_DWELL_TIME], v) < 0;
+    Py_XDECREF(v);
+    PyObject* lst = PyList_New(ns);
+    bad |= !lst;
+    for (Py_ssize_t s = 0; lst && s < ns; s++) {
+        const float* row = rows + (size_t)s * 4;
+        PyObject* t = Py_BuildValue("(dddd)", (double)row[0], (double)row[1], (double)row[2], (double)row[3]);
+        if (!t) { bad = 1; break; }
+        PyObject_GC_UnTrack(t);                  /* four floats */
+        PyList_SET_ITEM(lst, s, t);
+    }
+    if (lst && !bad) bad |= PyDict_SetItem(p, KEYS[K_SPIKES], lst) < 0;
+    Py_XDECREF(lst);
+    if (bad) { Py_DECREF(p); return NULL; }
+    /* dict -> (empty) list: nothing a cycle can run through as built, and a dict tracks itself again the moment
+     * somebody stores a container in it.  Dicts that hold a NON-empty spike list stay tracked: the list is, and a
+     * caller who ties it into a cycle must still be able to have that cycle collected. */
+    if (ns == 0) PyObject_GC_UnTrack(p);
+    return p;
 }
 
 static PyObject* report(PyObject* self, PyObject* args)
@@ -259,16 +292,6 @@ static PyObject* report(PyObject* self, PyObject* args)
             if (o != Py_None) {
                 SET_BORROWED(d, KEYS[K_POLYA], o);
             } else if (((const uint8_t*)polya_lazy.view.buf)[i]) {
-                PyObject* p = PyDict_New();
-                if (!p) goto fail_row;
-                PyObject* v;
-                int bad = 0;
-                bad |= !(v = PyLong_FromLongLong(((const int64_t*)pa_begin.view.buf)[i])) || PyDict_SetItem(p, KEYS[K_BEGIN], v) < 0;
-                Py_XDECREF(v);
-                bad |= !(v = PyLong_FromLongLong(((const int64_t*)pa_end.view.buf)[i])) || PyDict_SetItem(p, KEYS[K_END], v) < 0;
-                Py_XDECREF(v);
-                bad |= !(v = PyFloat_FromDouble(((const double*)pa_dwell.view.buf)[i])) || PyDict_SetItem(p, KEYS[K_DWELL_TIME], v) < 0;
-                Py_XDECREF(v);
                 Py_ssize_t ns = ((const int32_t*)pa_nspk.view.buf)[i];
                 const int64_t g = ((const int64_t*)gpu_row.view.buf)[i];
                 int64_t at = 0;
@@ -276,30 +299,12 @@ static PyObject* report(PyObject* self, PyObject* args)
                 else at = ((const int64_t*)spike_off.view.buf)[g];
                 if (ns < 0 || at < 0 || at + ns > spike_rows) {
                     PyErr_SetString(PyExc_IndexError, "report: spike rows outside the table");
-                    Py_DECREF(p);
                     goto fail_row;
                 }
-                PyObject* lst = PyList_New(ns);
-                bad |= !lst;
-                for (Py_ssize_t s = 0; lst && s < ns; s++) {
-                    const float* row = (const float*)spikes.view.buf + ((size_t)at + s) * 4;
-                    PyObject* t = Py_BuildValue("(dddd)", (double)row[0], (double)row[1], (double)row[2], (double)row[3]);
-                    if (!t) { bad = 1; break; }
-                    PyObject_GC_UnTrack(t);                  /* four floats */
-                    PyList_SET_ITEM(lst, s, t);
-                }
-                if (lst) bad |= PyDict_SetItem(p, KEYS[K_SPIKES], lst) < 0;
-                Py_XDECREF(lst);
-                if (bad) { Py_DECREF(p); goto fail_row; }
-                SET(d, KEYS[K_POLYA], p);
-                /* dict -> dict -> (empty) list: nothing a cycle can run through as built, and a dict tracks
-                 * itself again the moment somebody stores a container in it.  Dicts that hold a NON-empty
-                 * spike list stay tracked: the list is, and a caller who ties it into a cycle must still be
-                 * able to have that cycle collected. */
-                if (ns == 0) {
-                    PyObject_GC_UnTrack(p);
-                    PyObject_GC_UnTrack(d);
-                }
+                SET(d, KEYS[K_POLYA], polya_dict(((const int64_t*)pa_begin.view.buf)[i], ((const int64_t*)pa_end.view.buf)[i],
+                                                 ((const double*)pa_dwell.view.buf)[i], ns,
+                                                 ns ? (const float*)spikes.view.buf + (size_t)at * 4 : NULL));
+                if (ns == 0) PyObject_GC_UnTrack(d);      /* (see polya_dict: nothing in it a cycle can run through) */
             }
             PyList_SET_ITEM(out, k, d);
             continue;
@@ -352,12 +357,13 @@ static int need_rows(const Buf* b, const char* name, Py_ssize_t rows)
 
 static PyObject* report_run(PyObject* self, PyObject* args)
 {
-    PyObject *cols, *rec_obj, *status_names, *label_names;
+    PyObject *cols, *rec_obj, *status_names, *label_names, *spikes_obj = Py_None, *spike_off_obj = Py_None;
     Py_ssize_t first, n;
-    int adapter, barcoding;
+    int adapter, barcoding, polya = 0;
     long long min_seq_len;
-    if (!PyArg_ParseTuple(args, "O!nnOipLO!O!", &PyDict_Type, &cols, &first, &n, &rec_obj, &adapter, &barcoding,
-                          &min_seq_len, &PyTuple_Type, &status_names, &PyTuple_Type, &label_names))
+    if (!PyArg_ParseTuple(args, "O!nnOipLO!O!|pOO", &PyDict_Type, &cols, &first, &n, &rec_obj, &adapter, &barcoding,
+                          &min_seq_len, &PyTuple_Type, &status_names, &PyTuple_Type, &label_names, &polya, &spikes_obj,
+                          &spike_off_obj))
         return NULL;
     if (first < 0 || n < 0 || adapter < 0 || adapter >= PXG_N_SEGMENTS || PyTuple_GET_SIZE(status_names) < PXG_N_STATUS ||
         PyTuple_GET_SIZE(label_names) < 2) {
@@ -365,9 +371,9 @@ static PyObject* report_run(PyObject* self, PyObject* args)
         return NULL;
     }
     Buf rec, start_time, duration, calib, present, seq_len, qscore, n_events, seq_off, seq_arena, qual_arena, channel,
-        run_id, sample_id;
+        run_id, sample_id, spikes, spike_off;
     Buf* all[] = { &rec, &start_time, &duration, &calib, &present, &seq_len, &qscore, &n_events, &seq_off, &seq_arena,
-                   &qual_arena, &channel, &run_id, &sample_id };
+                   &qual_arena, &channel, &run_id, &sample_id, &spikes, &spike_off };
     for (size_t k = 0; k < sizeof(all) / sizeof(all[0]); k++) all[k]->held = 0;
     PyObject* out = NULL;
     const Py_ssize_t last = first + n;         /* reads [first, last) of the bundle */
@@ -390,6 +396,17 @@ static PyObject* report_run(PyObject* self, PyObject* args)
         need_rows(&seq_len, "bc_sequence_length", last) || need_rows(&qscore, "bc_mean_qscore", last) ||
         need_rows(&n_events, "bc_num_events", last) || need_rows(&seq_off, "seq_offsets", last + 1))
         goto done;
+    /* poly(A): the spike rows of all records back to back, rows of record k = [off[k], off[k + 1]) */
+    if (polya && spikes_obj != Py_None && spike_off_obj != Py_None) {
+        if (PyObject_GetBuffer(spikes_obj, &spikes.view, PyBUF_C_CONTIGUOUS) < 0) goto done;
+        spikes.held = 1;
+        if (PyObject_GetBuffer(spike_off_obj, &spike_off.view, PyBUF_C_CONTIGUOUS) < 0) goto done;
+        spike_off.held = 1;
+        if (spikes.view.itemsize != 4 || spike_off.view.itemsize != 8 || spike_off.view.len / 8 < n + 1) {
+            PyErr_SetString(PyExc_TypeError, "report_run: spikes must be float32 rows of four, spike offsets int64 [n + 1]");
+            goto done;
+        }
+    }
     PyObject *filenames = get_list(cols, "filenames", 0), *read_ids = get_list(cols, "read_ids", 0);
     if (!filenames || !read_ids) goto done;
     out = PyList_New(n);
@@ -404,13 +421,14 @@ static PyObject* report_run(PyObject* self, PyObject* args)
             const pxg_read_result* r = R + k;
             /* the rules, in the order the general path applies them (signal_loader.attach_records,
              * SignalAnalyzer.judge, BarcodeDemultiplexer.assign, SignalAnalyzer.bulk_base_space) */
-            int status = PXG_ST_OKAY, label = -1, called = 0, summary = 0;
+            int status = PXG_ST_OKAY, label = -1, called = 0, summary = 0, tail = 0;
             if (r->status == PXG_ST_SCALING_QC_FAIL) {
                 status = PXG_ST_SCALING_QC_FAIL;                     /* (:108-109: stops without a label) */
             } else if (r->seg_first[adapter] < 0) {
                 status = PXG_ST_ADAPTER_NOT_DETECTED, label = 1;     /* 'fail' */
             } else {
                 called = barcoding && r->bc_pushed && r->bc_called;
+                tail = polya && r->polya_called;                     /* (both decided before anything base-space can fail) */
                 if (!((const uint8_t*)present.view.buf)[b]) {
                     status = PXG_ST_NOT_BASECALLED, label = 1;
                 } else {
@@ -462,6 +480,23 @@ static PyObject* report_run(PyObject* self, PyObject* args)
                 SET(d, KEYS[K_BARCODE], PyLong_FromLong(r->bc_label));
                 SET(d, KEYS[K_BARCODE_GUESS], PyLong_FromLong(r->bc_label));
                 SET(d, KEYS[K_BARCODE_SCORE], PyLong_FromLong(r->bc_phred));
+            }
+            if (tail) {
+                const double rate = ((const double*)calib.view.buf)[4 * b + 3];
+                Py_ssize_t ns = 0;
+                int64_t at = 0;
+                if (spikes.held) {                                   /* (no spike table: tails without their spikes) */
+                    const Py_ssize_t spike_rows = spikes.view.len / 16;
+                    ns = r->polya_n_spikes;
+                    at = ((const int64_t*)spike_off.view.buf)[k];
+                    if (!spike_rows) ns = 0, at = 0;
+                    if (ns < 0 || at < 0 || at + ns > spike_rows) {
+                        PyErr_SetString(PyExc_IndexError, "report_run: spike rows outside the table");
+                        goto fail_row;
+                    }
+                }
+                SET(d, KEYS[K_POLYA], polya_dict(r->polya_begin, r->polya_end, (double)r->polya_dwell_samples / rate, ns,
+                                                 ns ? (const float*)spikes.view.buf + (size_t)at * 4 : NULL));
             }
             PyList_SET_ITEM(out, k, d);
             continue;

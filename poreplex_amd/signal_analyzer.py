@@ -166,8 +166,8 @@ class SignalAnalyzer(AbstractContextManager):
     def process_plain_run(self, reads, phase):
         """process() for the usual worker call, without a batch table: `reads` is a run of consecutive reads of the
         read bundle, all of them long enough for the scaler and regular in their basecall summary
-        (ReadBundle.plain_run_columns), and the configuration asks for nothing that walks a read (dumps, poly(A),
-        the chimera scan, on-the-fly basecalling, the opt-in adapter trimming).  The samples go to the GPU as the
+        (ReadBundle.plain_run_columns), and the configuration asks for nothing that walks a read (dumps, the chimera scan,
+        on-the-fly basecalling, the opt-in adapter trimming).  The samples go to the GPU as the
         bundle's own arena, the records come back, and csrc/pxg_pyreport.c report_run applies the status / label rules
         and builds the dicts in one pass: ~0.1 ms of Python for 128 reads where prepare + judge + report take 0.35 --
         the interpreter lock is what bounds worker threads that feed the GPU in reference-sized calls.
@@ -175,8 +175,8 @@ class SignalAnalyzer(AbstractContextManager):
         (tests/test_plain_run.py)."""
         loader, cfg = self.loader, self.config
         b = loader.bundle
-        if b is None or self.dump_adapter or self.dump_events or loader.scan_unsplit or cfg['measure_polya'] \
-                or cfg['albacore_onthefly'] or (cfg['trim_adapter'] and cfg.get('trim_adapter_as_intended')) \
+        if b is None or self.dump_adapter or self.dump_events or loader.scan_unsplit or cfg['albacore_onthefly'] \
+                or (cfg['trim_adapter'] and cfg.get('trim_adapter_as_intended')) \
                 or type(reads) is not list or not reads or type(reads[0]) is not tuple:
             return None
         fast = native.load_pyhost()
@@ -197,7 +197,7 @@ class SignalAnalyzer(AbstractContextManager):
             arena, offsets, calib = b.samples_run(first, first + n), o - o[0], plain['calib'][first:first + n]
         loader.pin_bundle()
         t1 = time.perf_counter()
-        records = loader.records_of_run(arena, offsets, calib)
+        records, spikes = loader.records_of_run(arena, offsets, calib)
         t2 = time.perf_counter()
         with phase:
             was_on = gc.isenabled()          # (nothing report_run builds can be part of a cycle: ReadTable.report)
@@ -205,7 +205,9 @@ class SignalAnalyzer(AbstractContextManager):
             try:
                 results = fast.report_run(plain, first, n, records, self.ctx.state_names.index('adapter'),
                                           bool(cfg['barcoding']), int(cfg['minimum_sequence_length']),
-                                          tuple(native.STATUS_NAMES), tuple(LABELS))
+                                          tuple(native.STATUS_NAMES), tuple(LABELS), bool(cfg['measure_polya']),
+                                          None if spikes is None else np.ascontiguousarray(spikes[0], dtype=np.float32),
+                                          None if spikes is None else np.ascontiguousarray(spikes[1], dtype=np.int64))
             finally:
                 if was_on:
                     gc.enable()

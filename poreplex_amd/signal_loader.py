@@ -832,11 +832,14 @@ class SignalLoader:
             unlock(1)
 
     def records_of_run(self, arena, offsets, calib):
-        """The GPU pass of fit_scalers for a batch that needs nothing but its records (no scan, no dumps, no spikes):
-        the one native call, or -- a context double of the CPU tests -- the same steps under the same two locks."""
+        """The GPU pass of fit_scalers for a batch that needs nothing but its records and -- with the poly(A) stage --
+        its spike rows (no scan, no dumps): (records, (spike rows, offsets) or None) from the one native call, or -- a
+        context double of the CPU tests -- from the same steps under the same two locks."""
         ctx = self.ctx
+        polya = bool(self.stage_mask & native.STAGE_POLYA)
         if hasattr(ctx, 'process_batch_ex'):
-            return ctx.process_batch_ex(arena, offsets, calib, self.stage_mask)['records']
+            got = ctx.process_batch_ex(arena, offsets, calib, self.stage_mask, want_spikes=polya)
+            return got['records'], got.get('spikes')
         native_locks = hasattr(ctx, 'lock')
         lock = ctx.lock if native_locks else (lambda w: (self._run_lock if w else self._stage_lock).acquire())
         unlock = ctx.unlock if native_locks else (lambda w: (self._run_lock if w else self._stage_lock).release())
@@ -859,7 +862,8 @@ class SignalLoader:
             unlock(0)
         try:
             ctx.run(self.stage_mask)
-            return ctx.download()
+            rec = ctx.download()
+            return rec, (ctx.download_spikes(rec) if polya else None)
         finally:
             unlock(1)
 

@@ -60,7 +60,16 @@ class CraftedRecords(oracle_context.OracleBackedContext):
                          want_spikes=False):
         which = np.asarray(calib)['offset'].astype(np.int64)
         assert len(which) == len(offsets) - 1
-        return {'records': CraftedRecords.table[which].copy()}
+        rec = CraftedRecords.table[which].copy()
+        out = {'records': rec}
+        if want_spikes:                    # every spike row of the batch, CSR by record (pxg_batch_download_spikes)
+            counts = np.where(rec['polya_called'] != 0, rec['polya_n_spikes'], 0)
+            off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+            rows = np.random.default_rng(int(which[0])).uniform(1, 90, (int(off[-1]), 4)).astype(np.float32)
+            for k in np.nonzero(counts)[0].tolist():      # the rows of a read do not depend on the call it came in
+                rows[off[k]:off[k + 1]] = np.random.default_rng(1000 + int(which[k])).uniform(1, 90, (int(counts[k]), 4))
+            out['spikes'] = (rows, off)
+        return out
 
 
 def crafted_bundle(tmp_path, n, seed):
@@ -106,6 +115,11 @@ def crafted_bundle(tmp_path, n, seed):
     rec['bc_called'] = rng.random(n) < 0.7
     rec['bc_label'] = rng.integers(0, 4, n)
     rec['bc_phred'] = rng.integers(0, 60, n)
+    rec['polya_called'] = rng.random(n) < 0.6
+    rec['polya_n_spikes'] = np.where(rng.random(n) < 0.5, 0, rng.integers(1, 5, n))
+    rec['polya_dwell_samples'] = rng.integers(50, 9000, n)
+    rec['polya_begin'] = rng.integers(100, 5000, n)
+    rec['polya_end'] = rec['polya_begin'] + rng.integers(60, 4000, n)
     found = rng.random(n) >= 0.1
     return path, rec, found, short, adapter
 
@@ -131,13 +145,13 @@ def spy_on_the_short_path(monkeypatch):
     return taken
 
 
-@pytest.mark.parametrize('barcoding', [True, False])
+@pytest.mark.parametrize('barcoding,polya', [(True, False), (False, False), (True, True), (False, True)])
 @pytest.mark.parametrize('seed', [1, 2])
-def test_short_path_equals_the_general_path(crafted, monkeypatch, tmp_path, seed, barcoding):
+def test_short_path_equals_the_general_path(crafted, monkeypatch, tmp_path, seed, barcoding, polya):
     n = 400
     path, rec, found, short, _ = crafted_bundle(tmp_path, n, seed)
     cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path), read_bundle=path, barcoding=barcoding,
-                         minimum_sequence_length=10)
+                         measure_polya=polya, minimum_sequence_length=10)
     # one call to make the worker's objects (the context knows where the model keeps its adapter state)
     keys = ReadBundle(path).keys
     CraftedRecords.table = rec
@@ -171,6 +185,7 @@ def test_short_path_equals_the_general_path(crafted, monkeypatch, tmp_path, seed
     assert n_taken >= 15
     assert statuses == {'okay', 'scaling_qc_fail', 'adapter_not_detected', 'not_basecalled', 'sequence_too_short'}
     assert any('barcode' in ks for ks in keysets) == barcoding and any('sequence' not in ks for ks in keysets)
+    assert any('polya' in ks for ks in keysets) == polya
 
 
 def test_calls_the_short_path_declines(crafted, monkeypatch, tmp_path):
@@ -204,7 +219,7 @@ def test_calls_the_short_path_declines(crafted, monkeypatch, tmp_path):
         assert took is False and len(out) == len(reads)
     took, out = call([list(k) for k in good])
     same(out, reference)
-    for option in ({'measure_polya': True}, {'filter_unsplit_reads': True}, {'dump_adapter_signals': True},
+    for option in ({'filter_unsplit_reads': True}, {'dump_adapter_signals': True},
                    {'trim_adapter': True, 'trim_adapter_as_intended': True}):
         WorkerPersistenceStorage.reset()
         assert call(list(good), **option)[0] is False, option
@@ -218,14 +233,14 @@ def test_calls_the_short_path_declines(crafted, monkeypatch, tmp_path):
 
 def test_short_path_against_the_real_reference(monkeypatch):
     """Stretches of the golden batch that are plain runs, through the oracle-backed double: the REAL reference's
-    dicts (poly(A) apart: the path is for calls without that stage)."""
+    dicts, poly(A) tails and their spike rows included."""
     import test_facade as TF
     WorkerPersistenceStorage.reset()
     monkeypatch.setattr(N, 'NativeContext', TF.OracleBackedContext)
     try:
         with open(os.path.join(GOLDEN, 'batch0.results.json')) as fh:
             ref = json.load(fh)
-        cfg = TF.facade_config(ref, measure_polya=False)
+        cfg = TF.facade_config(ref)
         want = {(r['filename'], r.get('read_id')): r for r in ref['results']}
         b = ReadBundle(TF.BUNDLE)
         ok = b.plain_run_columns({'length': 30000, 'stride': 15, 'min_length': 9000})['ok']
@@ -243,7 +258,7 @@ def test_short_path_against_the_real_reference(monkeypatch):
                 continue
             got = SA.process_batch(ref['batchid'], reads[pos:end], cfg)
             assert taken[-1] is True and isinstance(got, list)
-            TF.compare_results(got, [want[k] for k in reads[pos:end]], check_polya=False)
+            TF.compare_results(got, [want[k] for k in reads[pos:end]], check_polya=True)
             covered += end - pos
             pos = end
         assert covered >= 24, covered
@@ -280,7 +295,8 @@ def test_short_path_from_many_threads(crafted, monkeypatch, tmp_path):
 
 
 @pytest.mark.gpu
-def test_short_path_equals_the_general_path_on_the_gpu(monkeypatch, tmp_path):
+@pytest.mark.parametrize('polya', [False, True])
+def test_short_path_equals_the_general_path_on_the_gpu(monkeypatch, tmp_path, polya):
     """The same comparison with the real context: a synthetic bundle, 128-read calls, from threads as well."""
     from concurrent.futures import ThreadPoolExecutor
     from poreplex_amd.synth import synth_basecalls, synth_batch
@@ -290,7 +306,8 @@ def test_short_path_equals_the_general_path_on_the_gpu(monkeypatch, tmp_path):
     ids = ['{:08x}-0000-4000-8000-{:012x}'.format(31, i) for i in range(n)]
     path = str(tmp_path / 'gpu.pxr.npz')
     write_bundle(path, sb['arena'], sb['offsets'], sb['calib'], names, ids, basecalls=synth_basecalls(sb, seed=31))
-    cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path), read_bundle=path, barcoding=True)
+    cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path), read_bundle=path, barcoding=True,
+                         measure_polya=polya)
     keys = list(zip(names, ids))
     WorkerPersistenceStorage.reset()
     try:
@@ -303,6 +320,7 @@ def test_short_path_equals_the_general_path_on_the_gpu(monkeypatch, tmp_path):
         assert taken == [True] * 3
         same(got, want)
         assert {r['status'] for w in want for r in w} >= {'okay'}
+        assert any('polya' in r for w in want for r in w) == polya
         with ThreadPoolExecutor(6) as pool:
             again = list(pool.map(lambda lo: SA.process_batch(9, keys[lo:lo + 128], cfg), list(range(0, n, 128)) * 4))
         same(again, want * 4)
