@@ -404,6 +404,7 @@ def process_batch_leg(args, base, which, lo, mask, local_rank, compressed, resid
         calls = max(args.api_calls, 1)
         from poreplex_amd import signal_analyzer as SA
         SA.CALL_TRACE = trace = []
+        plain_before = getattr(SA, 'PLAIN_RUN_CALLS', 0)
         # results are checked and DROPPED as they arrive, like a pipeline that hands them to its sinks
         # (holding on to millions of dicts is not the API's cost: it makes the cyclic collector walk
         # them all, under the GIL every worker thread needs)
@@ -445,6 +446,8 @@ def process_batch_leg(args, base, which, lo, mask, local_rank, compressed, resid
                'compressed_bundle': bool(compressed), 'dicts_returned': len(last),
                'dict_builder': 'csrc/_pxgpy' if N.load_pyhost() is not None else 'python loop',
                'results_identical_across_calls': bool(verdict['same']),
+               # calls judged and reported in one C pass, without a batch table (SignalAnalyzer.process_plain_run)
+               'calls_on_the_plain_run_path': getattr(SA, 'PLAIN_RUN_CALLS', 0) - plain_before,
                'mean_phase_ms_per_call': {k: (round(v, 2) if v is not None else None) for k, v in phases.items()}}
         try:                               # small calls that met in the pipeline ran as one batch (include/pxg.h)
             probe = SA.SignalAnalyzer(cfg, 0)

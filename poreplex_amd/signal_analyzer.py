@@ -46,6 +46,7 @@ _HOST_PHASE = threading.Lock()
 _USE_HOST_PHASE = os.environ.get('PXG_NO_HOST_PHASE_LOCK') is None
 # (A/B and tests: PXG_NO_PLAIN_RUN=1 sends every call through the batch table)
 _PLAIN_RUN = os.environ.get('PXG_NO_PLAIN_RUN') is None
+PLAIN_RUN_CALLS = 0         # worker calls that took SignalAnalyzer.process_plain_run (bench.py reports it)
 
 
 class _NoLock:
@@ -211,6 +212,8 @@ class SignalAnalyzer(AbstractContextManager):
             finally:
                 if was_on:
                     gc.enable()
+            global PLAIN_RUN_CALLS
+            PLAIN_RUN_CALLS += 1
         if CALL_TRACE is not None:
             CALL_TRACE.append((t0, t1, t2, time.perf_counter()))
         return results
