@@ -209,6 +209,8 @@ class SignalAnalyzer(AbstractContextManager):
                                           tuple(native.STATUS_NAMES), tuple(LABELS), bool(cfg['measure_polya']),
                                           None if spikes is None else np.ascontiguousarray(spikes[0], dtype=np.float32),
                                           None if spikes is None else np.ascontiguousarray(spikes[1], dtype=np.int64))
+            except (IndexError, TypeError, KeyError, ValueError):
+                return None                  # columns it cannot read as they are: the batch table takes the call
             finally:
                 if was_on:
                     gc.enable()
