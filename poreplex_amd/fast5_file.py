@@ -209,7 +209,19 @@ class ReadBundle:
             kind = d['bc_table']
             regular = ((kind == 1) | (kind == 2)) & (n_moves >= 0) & (stride > 0) & \
                 (-(-covered // np.maximum(stride, 1)) == n_moves)
-            plain = {'ok': long_enough & (~d['bc_present'].astype(bool) | regular), 'offsets': o,
+            present = d['bc_present'].astype(bool)
+            # the chimera scan (signal_loader.unsplit_frames, SignalAnalyzer.bulk_base_space): the Guppy block frame of
+            # every regular read, the one block stride they share (None: none or several -- no short path with the
+            # scan), and the reads whose Move table has the k-mer size the event frame needs
+            frame = np.zeros((n, 3), dtype=np.int64)
+            fits = present & regular
+            frame[fits] = np.stack([first, n_moves, stride], axis=1)[fits]
+            strides = np.unique(frame[frame[:, 1] > 0, 2])
+            kmer = (d['seq_offsets'][1:] - d['seq_offsets'][:-1]) - d['bc_move_sum'] + 1
+            plain = {'ok': long_enough & (~present | regular), 'offsets': o,
+                     'frame_first': np.ascontiguousarray(frame[:, 0]), 'frame_blocks': np.ascontiguousarray(frame[:, 1]),
+                     'frame_stride': int(strides[0]) if len(strides) == 1 else None,
+                     'kmer_ok': ~fits | (kind == 2) | (kmer == 5) | (kmer == 1),
                      'filenames': self.filenames, 'read_ids': self.read_ids,
                      'channel_number': text[0], 'run_id': text[1], 'sample_id': text[2],
                      'calib': np.ascontiguousarray(d['calib'])}

@@ -167,8 +167,8 @@ class SignalAnalyzer(AbstractContextManager):
     def process_plain_run(self, reads, phase):
         """process() for the usual worker call, without a batch table: `reads` is a run of consecutive reads of the
         read bundle, all of them long enough for the scaler and regular in their basecall summary
-        (ReadBundle.plain_run_columns), and the configuration asks for nothing that walks a read (dumps, the chimera scan,
-        on-the-fly basecalling, the opt-in adapter trimming).  The samples go to the GPU as the
+        (ReadBundle.plain_run_columns), and the configuration asks for nothing that walks every read (dumps, on-the-fly
+        basecalling, the opt-in adapter trimming).  The samples go to the GPU as the
         bundle's own arena, the records come back, and csrc/pxg_pyreport.c report_run applies the status / label rules
         and builds the dicts in one pass: ~0.1 ms of Python for 128 reads where prepare + judge + report take 0.35 --
         the interpreter lock is what bounds worker threads that feed the GPU in reference-sized calls.
@@ -176,9 +176,10 @@ class SignalAnalyzer(AbstractContextManager):
         (tests/test_plain_run.py)."""
         loader, cfg = self.loader, self.config
         b = loader.bundle
-        if b is None or self.dump_adapter or self.dump_events or loader.scan_unsplit or cfg['albacore_onthefly'] \
+        if b is None or self.dump_adapter or self.dump_events or cfg['albacore_onthefly'] \
                 or (cfg['trim_adapter'] and cfg.get('trim_adapter_as_intended')) \
-                or type(reads) is not list or not reads or type(reads[0]) is not tuple:
+                or type(reads) is not list or not reads or type(reads[0]) is not tuple \
+                or (loader.scan_unsplit and not hasattr(self.ctx, 'process_batch_ex')):
             return None
         fast = native.load_pyhost()
         if fast is None or not hasattr(fast, 'report_run'):
@@ -194,31 +195,61 @@ class SignalAnalyzer(AbstractContextManager):
                 return None
             if b.broken and any(key[0] in b.broken for key in reads):      # (files that exist but cannot be opened)
                 return None
+            scan = sel = None
+            if loader.scan_unsplit:
+                # the window scan over the same resident batch (signal_loader.fit_scalers); a Move table of another
+                # k-mer size or a bundle with several block strides: the general path
+                blocks = plain['frame_blocks'][first:first + n]
+                sel = blocks > 0
+                if not plain['kmer_ok'][first:first + n].all() or (plain['frame_stride'] is None and sel.any()):
+                    return None
+                if sel.any():
+                    scan = (plain['frame_first'][first:first + n], blocks, plain['frame_stride'])
             o = plain['offsets'][first:first + n + 1]
             arena, offsets, calib = b.samples_run(first, first + n), o - o[0], plain['calib'][first:first + n]
         loader.pin_bundle()
         t1 = time.perf_counter()
-        records, spikes = loader.records_of_run(arena, offsets, calib)
+        got = loader.records_of_run(arena, offsets, calib, scan)
         t2 = time.perf_counter()
         with phase:
-            was_on = gc.isenabled()          # (nothing report_run builds can be part of a cycle: ReadTable.report)
-            gc.disable()
-            try:
-                results = fast.report_run(plain, first, n, records, self.ctx.state_names.index('adapter'),
-                                          bool(cfg['barcoding']), int(cfg['minimum_sequence_length']),
-                                          tuple(native.STATUS_NAMES), tuple(LABELS), bool(cfg['measure_polya']),
-                                          None if spikes is None else np.ascontiguousarray(spikes[0], dtype=np.float32),
-                                          None if spikes is None else np.ascontiguousarray(spikes[1], dtype=np.int64))
-            except (IndexError, TypeError, KeyError, ValueError):
-                return None                  # columns it cannot read as they are: the batch table takes the call
-            finally:
-                if was_on:
-                    gc.enable()
+            if scan is not None and got['unsplit'][1].any():
+                # in-read adapter candidates (or a scan that failed) somewhere in the call: those reads are judged one
+                # by one over their event tables -- the batch table, with the pass that has already run
+                results = self.finish_from_pass(reads, got, sel)
+            else:
+                spikes = got.get('spikes')
+                was_on = gc.isenabled()      # (nothing report_run builds can be part of a cycle: ReadTable.report)
+                gc.disable()
+                try:
+                    results = fast.report_run(plain, first, n, got['records'], self.ctx.state_names.index('adapter'),
+                                              bool(cfg['barcoding']), int(cfg['minimum_sequence_length']),
+                                              tuple(native.STATUS_NAMES), tuple(LABELS), bool(cfg['measure_polya']),
+                                              None if spikes is None else np.ascontiguousarray(spikes[0], dtype=np.float32),
+                                              None if spikes is None else np.ascontiguousarray(spikes[1], dtype=np.int64))
+                except (IndexError, TypeError, KeyError, ValueError):
+                    results = self.finish_from_pass(reads, got, sel)      # columns it cannot read as they are
+                finally:
+                    if was_on:
+                        gc.enable()
             global PLAIN_RUN_CALLS
             PLAIN_RUN_CALLS += 1
         if CALL_TRACE is not None:
             CALL_TRACE.append((t0, t1, t2, time.perf_counter()))
         return results
+
+    def finish_from_pass(self, reads, got, scanned):
+        """The batch table for a plain run whose GPU pass has been made (process_plain_run): open the reads, attach the
+        records / spike rows / scan candidates as fit_scalers would have, judge and report."""
+        loader = self.loader
+        batch = self.prepare(reads, ReadTable(len(reads)))
+        table = batch.table
+        rows = loader.pack(table)[0]                 # (a run of bundle reads: nothing is copied)
+        if len(rows) != len(got['records']):
+            raise RuntimeError('plain run: {} reads entered the pass, {} records came back'.format(len(rows), len(got['records'])))
+        loader.attach_records(table, rows, got['records'], got.get('spikes'))
+        if scanned is not None and got.get('unsplit') is not None:
+            loader.attach_unsplit(table, rows, scanned, got['unsplit'])
+        return self.finish(batch)
 
     def prepare(self, reads, table=None, reserve=None):
         """Host-only first phase: open every read into a batch table.  The session driver

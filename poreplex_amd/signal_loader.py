@@ -831,15 +831,17 @@ class SignalLoader:
         finally:
             unlock(1)
 
-    def records_of_run(self, arena, offsets, calib):
-        """The GPU pass of fit_scalers for a batch that needs nothing but its records and -- with the poly(A) stage --
-        its spike rows (no scan, no dumps): (records, (spike rows, offsets) or None) from the one native call, or -- a
-        context double of the CPU tests -- from the same steps under the same two locks."""
+    def records_of_run(self, arena, offsets, calib, scan=None):
+        """The GPU pass of fit_scalers for a batch that needs nothing but its records, -- with the poly(A) stage -- its
+        spike rows and -- `scan` = (first sample, blocks, block stride) -- the candidates of the chimera window scan (no
+        dumps): {'records', 'spikes': (rows, offsets), 'unsplit': (intervals, count, start)} from the one native call,
+        or -- a context double of the CPU tests, without a scan -- from the same steps under the same two locks."""
         ctx = self.ctx
         polya = bool(self.stage_mask & native.STAGE_POLYA)
         if hasattr(ctx, 'process_batch_ex'):
-            got = ctx.process_batch_ex(arena, offsets, calib, self.stage_mask, want_spikes=polya)
-            return got['records'], got.get('spikes')
+            return ctx.process_batch_ex(arena, offsets, calib, self.stage_mask, unsplit=scan, want_spikes=polya)
+        if scan is not None:
+            raise ValueError('a scan needs the one-call form of the context')
         native_locks = hasattr(ctx, 'lock')
         lock = ctx.lock if native_locks else (lambda w: (self._run_lock if w else self._stage_lock).acquire())
         unlock = ctx.unlock if native_locks else (lambda w: (self._run_lock if w else self._stage_lock).release())
@@ -863,7 +865,7 @@ class SignalLoader:
         try:
             ctx.run(self.stage_mask)
             rec = ctx.download()
-            return rec, (ctx.download_spikes(rec) if polya else None)
+            return {'records': rec, 'spikes': ctx.download_spikes(rec) if polya else None}
         finally:
             unlock(1)
 

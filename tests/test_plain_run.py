@@ -55,6 +55,7 @@ class CraftedRecords(oracle_context.OracleBackedContext):
     """Context double whose GPU pass returns records made up per read (the read is recognised by its calibration
     offset, which the bundle below numbers)."""
     table = None
+    candidate_every = 40
 
     def process_batch_ex(self, samples, offsets, calib, stage_mask=N.STAGE_ALL_DEMUX, scale_shift=None, unsplit=None,
                          want_spikes=False):
@@ -69,6 +70,16 @@ class CraftedRecords(oracle_context.OracleBackedContext):
             for k in np.nonzero(counts)[0].tolist():      # the rows of a read do not depend on the call it came in
                 rows[off[k]:off[k + 1]] = np.random.default_rng(1000 + int(which[k])).uniform(1, 90, (int(counts[k]), 4))
             out['spikes'] = (rows, off)
+        if unsplit is not None:            # in-read adapter candidates of the window scan: some calls have none at all
+            first_sample, n_blocks, stride = unsplit
+            assert len(first_sample) == len(which) and len(n_blocks) == len(which) and stride == 15
+            cnt = np.where((np.asarray(n_blocks) > 0) & (which % CraftedRecords.candidate_every == 3), 1 + which % 2, 0).astype(np.int32)
+            start = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+            iv = np.zeros((int(start[-1]), 2), dtype=np.int64)
+            for k in np.nonzero(cnt)[0].tolist():
+                for j in range(int(cnt[k])):
+                    iv[start[k] + j] = (3000 + 2000 * j + int(which[k]), 3600 + 2000 * j + int(which[k]))
+            out['unsplit'] = (iv, cnt, start)
         return out
 
 
@@ -145,24 +156,31 @@ def spy_on_the_short_path(monkeypatch):
     return taken
 
 
-@pytest.mark.parametrize('barcoding,polya', [(True, False), (False, False), (True, True), (False, True)])
+@pytest.mark.parametrize('barcoding,polya,chimera', [(True, False, False), (False, False, False), (True, True, False),
+                                                     (False, True, False), (True, True, True), (True, False, True)])
 @pytest.mark.parametrize('seed', [1, 2])
-def test_short_path_equals_the_general_path(crafted, monkeypatch, tmp_path, seed, barcoding, polya):
+def test_short_path_equals_the_general_path(crafted, monkeypatch, tmp_path, seed, barcoding, polya, chimera):
     n = 400
     path, rec, found, short, _ = crafted_bundle(tmp_path, n, seed)
     cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path), read_bundle=path, barcoding=barcoding,
-                         measure_polya=polya, minimum_sequence_length=10)
+                         measure_polya=polya, filter_unsplit_reads=chimera, minimum_sequence_length=10)
     # one call to make the worker's objects (the context knows where the model keeps its adapter state)
     keys = ReadBundle(path).keys
     CraftedRecords.table = rec
     first = SA.process_batch(0, keys[:1], cfg)
     assert isinstance(first, list), first
     adapter = worker_objects()['ctx'].state_names.index('adapter')
-    ok = ReadBundle(path).plain_run_columns(worker_objects()['loader'].scaler_cfg)['ok']
+    plain = ReadBundle(path).plain_run_columns(worker_objects()['loader'].scaler_cfg)
+    # (with the scan on, a Move table of another k-mer size also sends the call to the batch table)
+    ok = plain['ok'] & plain['kmer_ok'] if chimera else plain['ok']
     rec['seg_first'][:, adapter] = np.where(found, 40, -1)
     rec['seg_last'][:, adapter] = np.where(found, 90, -1)
     rng = np.random.default_rng(100 + seed)
     taken = spy_on_the_short_path(monkeypatch)
+    fell_back = []
+    real_finish = SA.SignalAnalyzer.finish_from_pass
+    monkeypatch.setattr(SA.SignalAnalyzer, 'finish_from_pass',
+                        lambda self, *a: fell_back.append(1) or real_finish(self, *a))
     statuses, keysets, n_taken = set(), set(), 0
     windows = [(0, n)] + [(int(a), int(rng.integers(1, 70))) for a in rng.integers(0, n - 1, 60)]
     for lo, k in windows:
@@ -183,7 +201,12 @@ def test_short_path_equals_the_general_path(crafted, monkeypatch, tmp_path, seed
         else:
             assert [r['read_id'] for r in fast if 'read_id' in r] == [r['read_id'] for r in general if 'read_id' in r]
     assert n_taken >= 15
-    assert statuses == {'okay', 'scaling_qc_fail', 'adapter_not_detected', 'not_basecalled', 'sequence_too_short'}
+    # (with the scan on, a read with candidates is judged over its event table, on the batch table the call falls back to)
+    assert statuses - {'unsplit_read'} == {'okay', 'scaling_qc_fail', 'adapter_not_detected', 'not_basecalled',
+                                           'sequence_too_short'}
+    assert ('unsplit_read' in statuses) == chimera
+    # calls with candidates finished on the batch table with the pass they had made, the others in the C pass
+    assert (0 < len(fell_back) < n_taken) if chimera else not fell_back
     assert any('barcode' in ks for ks in keysets) == barcoding and any('sequence' not in ks for ks in keysets)
     assert any('polya' in ks for ks in keysets) == polya
 
@@ -219,7 +242,7 @@ def test_calls_the_short_path_declines(crafted, monkeypatch, tmp_path):
         assert took is False and len(out) == len(reads)
     took, out = call([list(k) for k in good])
     same(out, reference)
-    for option in ({'filter_unsplit_reads': True}, {'dump_adapter_signals': True},
+    for option in ({'dump_adapter_signals': True}, {'dump_basecalls': True},
                    {'trim_adapter': True, 'trim_adapter_as_intended': True}):
         WorkerPersistenceStorage.reset()
         assert call(list(good), **option)[0] is False, option
@@ -295,8 +318,8 @@ def test_short_path_from_many_threads(crafted, monkeypatch, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('polya', [False, True])
-def test_short_path_equals_the_general_path_on_the_gpu(monkeypatch, tmp_path, polya):
+@pytest.mark.parametrize('polya,chimera', [(False, False), (True, False), (True, True)])
+def test_short_path_equals_the_general_path_on_the_gpu(monkeypatch, tmp_path, polya, chimera):
     """The same comparison with the real context: a synthetic bundle, 128-read calls, from threads as well."""
     from concurrent.futures import ThreadPoolExecutor
     from poreplex_amd.synth import synth_basecalls, synth_batch
@@ -307,7 +330,7 @@ def test_short_path_equals_the_general_path_on_the_gpu(monkeypatch, tmp_path, po
     path = str(tmp_path / 'gpu.pxr.npz')
     write_bundle(path, sb['arena'], sb['offsets'], sb['calib'], names, ids, basecalls=synth_basecalls(sb, seed=31))
     cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path), read_bundle=path, barcoding=True,
-                         measure_polya=polya)
+                         measure_polya=polya, filter_unsplit_reads=chimera)
     keys = list(zip(names, ids))
     WorkerPersistenceStorage.reset()
     try:
