@@ -261,15 +261,19 @@ class ReadBundle:
         return (self.d['seq_arena'][o[i]:o[i + 1]].tobytes().decode('ascii'),
                 self.d['qual_arena'][o[i]:o[i + 1]].tobytes().decode('ascii'))
 
-    def basecall_of(self, i):
-        """get_basecall()-style dict of read i from the columns; None if not basecalled."""
+    def basecall_of(self, i, move_as_array=False):
+        """get_basecall()-style dict of read i from the columns; None if not basecalled.  `move_as_array`: the Move
+        column as a uint8 view of the bundle's arena instead of a list (the facade's per-read rules turn it into an
+        array again: 4 000 blocks through a Python list cost more than the rules themselves)."""
         d = self.d
         if not d['bc_present'][i]:
             return None
         seq, qual = self.sequence_of(i)
         kind = TABLE_KINDS[int(d['bc_table'][i])] or None
         mo = d['move_offsets']
-        move = d['move_arena'][mo[i]:mo[i + 1]].tolist() if d['bc_n_moves'][i] >= 0 else None
+        move = d['move_arena'][mo[i]:mo[i + 1]] if d['bc_n_moves'][i] >= 0 else None
+        if move is not None and not move_as_array:
+            move = move.tolist()
         pms = None
         if 'bc_p_model_state' in d and str(d['bc_p_model_state'][i]):
             pms = json.loads(str(d['bc_p_model_state'][i]))
@@ -315,7 +319,7 @@ class _Fast5BatchBundle(ReadBundle):
                 self._by_file.setdefault(f, []).append(i)
         return self._by_file
 
-    def basecall_of(self, i):
+    def basecall_of(self, i, move_as_array=False):
         """The per-read path (chimera candidates, Events tables): straight from the file, so a
         p_model_state column comes along."""
         return self.batch.files[i].basecall(int(self.batch.index[i]))
@@ -345,9 +349,9 @@ class BundleReader:
     def get_raw_int16(self):
         return self.bundle.samples(self.i)
 
-    def get_basecall(self):
+    def get_basecall(self, move_as_array=False):
         """Summary of Analyses/Basecall_1D_* (fast5_file.py:133-164); None if absent."""
-        return self.bundle.basecall_of(self.i)
+        return self.bundle.basecall_of(self.i, move_as_array)
 
 
 class Fast5Error(OSError):

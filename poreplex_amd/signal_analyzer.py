@@ -636,20 +636,23 @@ class SignalAnalysis:
             return albacore_frame(bcall)
         first, n_blocks, stride = self.npread.guppy_event_geometry(bcall=bcall)
         moves = np.asarray(bcall['move'], dtype=np.uint8)
+        pos = np.cumsum(moves)
         if bcall.get('table') == 'guppy_events':         # Events table: the column is stored
             if bcall.get('p_model_state') is None:
                 raise KeyError('p_model_state')
             pms = np.asarray(bcall['p_model_state'], dtype=np.float64)
         else:                                            # Move table: from the quality string
-            lead = {5: 2, 1: 0}.get(len(bcall['sequence']) - int(moves.sum()) + 1)
+            lead = {5: 2, 1: 0}.get(len(bcall['sequence']) - (int(pos[-1]) if len(pos) else 0) + 1)
             if lead is None:
                 raise Exception('Move table is encoded with an unknown kmer-size.')
             phred = np.frombuffer(bcall['qstring'].encode(), 'B') - 33
-            pms = (1 - 10 ** -(phred / 10))[moves.cumsum() - 1 + lead]
+            pms = (1 - 10 ** -(phred / 10))[pos - 1 + lead]
         start = first + stride * np.arange(n_blocks, dtype=np.int64)
-        end = np.append(start[1:], start[-1:] + 1) if n_blocks else start
-        return {'start': start, 'end': end, 'move': moves, 'pos': np.cumsum(moves),
-                'p_model_state': pms}
+        end = start
+        if n_blocks:                                     # (the next event's start; one sample for the last)
+            end = np.empty(n_blocks, dtype=np.int64)
+            end[:-1], end[-1] = start[1:], start[-1] + 1
+        return {'start': start, 'end': end, 'move': moves, 'pos': pos, 'p_model_state': pms}
 
     def trim_adapter(self, events, segments, elspan):
         """signal_analyzer.py:328-344.  The reference returns as soon as a sequence IS present (:329-331) -- which is
@@ -713,7 +716,10 @@ class SignalAnalysis:
                 hq.append(0)
                 continue
             p = pos[a:b]
-            heads = np.nonzero(np.r_[True, p[1:] != p[:-1]])[0]
+            first_of_base = np.empty(b - a, dtype=bool)          # (np.r_[True, p[1:] != p[:-1]] without the index trick)
+            first_of_base[0] = True
+            np.not_equal(p[1:], p[:-1], out=first_of_base[1:])
+            heads = np.nonzero(first_of_base)[0]
             # (a float32 column is compared in float32, as pandas / NumPy 1.x compare it with a Python float)
             limit = pms.dtype.type(limits['basecount_quality_limit'])
             hq.append(int((np.maximum.reduceat(pms[a:b], heads) > limit).sum()))

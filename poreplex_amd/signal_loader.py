@@ -420,7 +420,10 @@ class NanoporeRead:
         t, i = self.table, self.row
         if t.source_of(i) is None:
             raise Exception('Fast5 must be open for getting events.')
-        bcall = t.source[i].get_basecall()
+        source = t.source[i]
+        # (a bundle row hands its Move column over as an array: nothing below needs the list)
+        bcall = source.get_basecall(move_as_array=True) if t.bundle_index[i] >= 0 and t.bundle is not None \
+            else source.get_basecall()
         if bcall is None:
             raise SignalAnalysisError('not_basecalled')
         kind = bcall.get('table', 'move' if bcall.get('move') is not None else None)
