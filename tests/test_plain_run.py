@@ -254,9 +254,11 @@ def test_calls_the_short_path_declines(crafted, monkeypatch, tmp_path):
     assert call([])[1] == [] and taken == [False]
 
 
-def test_short_path_against_the_real_reference(monkeypatch):
+@pytest.mark.parametrize('encoded', [False, True])
+def test_short_path_against_the_real_reference(monkeypatch, tmp_path, encoded):
     """Stretches of the golden batch that are plain runs, through the oracle-backed double: the REAL reference's
-    dicts, poly(A) tails and their spike rows included."""
+    dicts, poly(A) tails and their spike rows included -- from the bundle as committed and from the same bundle with
+    its samples encoded (the call then hands the encoded bytes of its reads to the context)."""
     import test_facade as TF
     WorkerPersistenceStorage.reset()
     monkeypatch.setattr(N, 'NativeContext', TF.OracleBackedContext)
@@ -264,8 +266,17 @@ def test_short_path_against_the_real_reference(monkeypatch):
         with open(os.path.join(GOLDEN, 'batch0.results.json')) as fh:
             ref = json.load(fh)
         cfg = TF.facade_config(ref)
+        bundle_path = TF.BUNDLE
+        if encoded:
+            d = dict(ReadBundle(TF.BUNDLE).d)
+            z, chunks, chunk_base = N.z_encode(d.pop('arena'), d['offsets'])
+            d.update(arena_z=z, z_chunks=chunks, z_chunk_base=chunk_base, bundle_version=np.int64(3))
+            bundle_path = str(tmp_path / 'batch0_encoded.pxr.npz')
+            np.savez(bundle_path, **d)
+            cfg = dict(cfg, read_bundle=bundle_path)
         want = {(r['filename'], r.get('read_id')): r for r in ref['results']}
-        b = ReadBundle(TF.BUNDLE)
+        b = ReadBundle(bundle_path)
+        assert b.compressed == encoded
         ok = b.plain_run_columns({'length': 30000, 'stride': 15, 'min_length': 9000})['ok']
         reads = [tuple(r) for r in ref['reads']]
         at = [b.index.get(k, -1) for k in reads]
