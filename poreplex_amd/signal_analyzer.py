@@ -46,6 +46,7 @@ _HOST_PHASE = threading.Lock()
 _USE_HOST_PHASE = os.environ.get('PXG_NO_HOST_PHASE_LOCK') is None
 # (A/B and tests: PXG_NO_PLAIN_RUN=1 sends every call through the batch table)
 _PLAIN_RUN = os.environ.get('PXG_NO_PLAIN_RUN') is None
+_BULK_UNSPLIT = os.environ.get('PXG_NO_BULK_UNSPLIT') is None      # (A/B and tests: candidates judged read by read)
 PLAIN_RUN_CALLS = 0         # worker calls that took SignalAnalyzer.process_plain_run (bench.py reports it)
 
 
@@ -331,6 +332,8 @@ class SignalAnalyzer(AbstractContextManager):
             for k in np.nonzero(~broken)[0].tolist():
                 broken[k] = not self._guarded(t, rows[k], self.queue_event_dump, t, rows[k], rec[k])
         settled = self.bulk_base_space(t, rows, ~broken)
+        if _BULK_UNSPLIT and cfg['filter_unsplit_reads']:
+            settled |= self.bulk_unsplit_rule(t, rows, rec, ~broken & ~settled)
         for k in np.nonzero(~broken & ~settled)[0].tolist():
             broken[k] = not self._guarded(t, rows[k], self.base_space_checks, t, rows[k], rec[k])
         done = rows[~broken & ~t.stopped[rows]]
@@ -374,6 +377,79 @@ class SignalAnalyzer(AbstractContextManager):
         short = (so[okb + 1] - so[okb]) < cfg['minimum_sequence_length']      # trimming is a no-op
         t.halt(ok[short], 'sequence_too_short', 'fail')
         settled[pick[regular]] = True
+        return settled
+
+    def bulk_unsplit_rule(self, t, rows, rec, todo):
+        """base_space_checks for the rows bulk_base_space left because the chimera scan found candidates in them: bundle
+        reads whose basecall is a Guppy MOVE table with a regular frame and 5-mer or 1-mer states.  The reference's rule
+        (signal_analyzer.py:420-443; SignalAnalysis.detect_unsplit_read is its restatement and stays the definition,
+        tests/test_plain_run.py holds the two against each other) counts, per stretch between candidates, the bases
+        whose best p_model_state among their events clears a limit.  For a Move table that probability is a function of
+        the base's quality character alone (event_frame: 1 - 10^(-phred / 10) of the base the event sits on), the events
+        start `block_stride` apart, and a base's events are the run between two moves -- so a stretch's count is a
+        difference of prefix sums over the read's Move column and its event range comes from two divisions, without the
+        event table.  Returns the mask of the rows settled here; Events tables, failed scans and
+        everything irregular stay with the per-read path."""
+        cfg = self.config
+        settled = np.zeros(len(rows), dtype=bool)
+        b = t.bundle
+        if b is None or cfg['albacore_onthefly'] or (cfg['trim_adapter'] and cfg.get('trim_adapter_as_intended')) \
+                or 'move_arena' not in b.d:
+            return settled
+        d, bi = b.d, t.bundle_index[rows]
+        pick = np.nonzero(todo & (bi >= 0) & (t.unsplit_count[rows] > 0))[0]
+        if not len(pick):
+            return settled
+        r, x = rows[pick], bi[pick]
+        first, stride, n_moves = d['bc_first_sample'][x], d['bc_block_stride'][x].astype(np.int64), d['bc_n_moves'][x]
+        covered = np.maximum(np.minimum(first + stride * n_moves, t.n_raw[r]) - first, 0)
+        kmer = (d['seq_offsets'][x + 1] - d['seq_offsets'][x]) - d['bc_move_sum'][x] + 1
+        fits = d['bc_present'][x].astype(bool) & (d['bc_table'][x] == 1) & (n_moves > 0) & (stride > 0) & \
+            (-(-covered // np.maximum(stride, 1)) == n_moves) & t.has_scaling[r] & ((kmer == 5) | (kmer == 1)) & \
+            (d['move_offsets'][x + 1] - d['move_offsets'][x] == n_moves)
+        if not fits.any():
+            return settled
+        limits = cfg['unsplit_read_detection']
+        # quality character -> does its base clear the limit: the expression of event_frame over every byte value
+        phred = np.arange(256, dtype=np.uint8) - 33
+        good_char = (1 - 10 ** -(phred / 10)) > np.float64(limits['basecount_quality_limit'])
+        adapter = self.ctx.state_names.index('adapter')
+        elspan = cfg['signal_processing']['rough_signal_stride']
+        mo, so, moves, quals = d['move_offsets'], d['seq_offsets'], d['move_arena'], d['qual_arena']
+        unsplit = np.zeros(len(pick), dtype=bool)
+        for k in np.nonzero(fits)[0].tolist():
+            row, i = int(r[k]), int(x[k])
+            f0, st, n = int(first[k]), int(stride[k]), int(n_moves[k])
+            mv = moves[mo[i]:mo[i + 1]]
+            lead = 2 if kmer[k] == 5 else 0                              # (event_frame: the k-mer's leading half)
+            if lead == 0 and mv[0] == 0:
+                fits[k] = False           # an event before the first base of a 1-mer table: the per-read path's error
+                continue
+            pos = np.cumsum(mv, dtype=np.int64)
+            good = good_char[quals[so[i]:so[i + 1]]][pos - 1 + lead]     # event -> the quality of the base it sits on
+            changes = np.cumsum(good & (mv != 0))                        # bases that start at or before an event, good ones
+            merged = union_intervals(t.unsplit[row])
+            begins = [(int(rec['seg_last'][pick[k], adapter]) + 1) * elspan] + [iv[1] for iv in merged]
+            ends = [iv[0] for iv in merged] + [None]
+            hq = []
+            for lo_at, hi_at in zip(begins, ends):
+                # events whose start lies in [lo_at, hi_at]: start of event j = f0 + st * j
+                lo = min(max(-(-(lo_at - f0) // st), 0), n)
+                hi = n if hi_at is None else min(max((hi_at - f0) // st + 1, 0), n)
+                hq.append(0 if hi <= lo else int(good[lo]) + int(changes[hi - 1] - changes[lo]))
+            later = sum(hq[1:])
+            unsplit[k] = later > limits['subread_basecount_limit'] or \
+                (later + 1) / (hq[0] + 1) > limits['subread_baseratio_limit']
+        # the summary load_fast5_events stores before the rule runs, then the rule's verdict, then the length rule
+        ok, okb = r[fits], x[fits]
+        t.sequence_length[ok], t.mean_qscore[ok] = d['bc_sequence_length'][okb], d['bc_mean_qscore'][okb].astype(np.float32)
+        t.num_events[ok], t.has_summary[ok] = d['bc_num_events'][okb], True
+        t.seq_lazy[ok] = True
+        t.halt(r[fits & unsplit], 'unsplit_read', 'artifact')
+        rest = fits & ~unsplit
+        short = (so[x[rest] + 1] - so[x[rest]]) < cfg['minimum_sequence_length']
+        t.halt(r[rest][short], 'sequence_too_short', 'fail')
+        settled[pick[fits]] = True
         return settled
 
     def _guarded(self, t, row, fn, *args):

@@ -73,12 +73,14 @@ class CraftedRecords(oracle_context.OracleBackedContext):
         if unsplit is not None:            # in-read adapter candidates of the window scan: some calls have none at all
             first_sample, n_blocks, stride = unsplit
             assert len(first_sample) == len(which) and len(n_blocks) == len(which) and stride == 15
-            cnt = np.where((np.asarray(n_blocks) > 0) & (which % CraftedRecords.candidate_every == 3), 1 + which % 2, 0).astype(np.int32)
+            cnt = np.where((np.asarray(n_blocks) > 0) & (which % CraftedRecords.candidate_every == 3 % CraftedRecords.candidate_every), 1 + which % 4, 0).astype(np.int32)
             start = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
             iv = np.zeros((int(start[-1]), 2), dtype=np.int64)
             for k in np.nonzero(cnt)[0].tolist():
-                for j in range(int(cnt[k])):
-                    iv[start[k] + j] = (3000 + 2000 * j + int(which[k]), 3600 + 2000 * j + int(which[k]))
+                # anywhere from before the payload to behind the read's last sample, overlapping, in no order
+                g = np.random.default_rng(5000 + int(which[k]))
+                begin = g.integers(0, 13000, int(cnt[k]))
+                iv[start[k]:start[k + 1]] = np.stack([begin, begin + g.integers(1, 3000, int(cnt[k]))], axis=1)
             out['unsplit'] = (iv, cnt, start)
         return out
 
@@ -106,7 +108,7 @@ def crafted_bundle(tmp_path, n, seed):
         n_blocks = int(lens[k]) // 15
         n_bases = int(rng.integers(3, 9)) if u < 0.24 else int(rng.integers(12, 60))      # some below the minimum length
         move = np.zeros(n_blocks, dtype=np.uint8)
-        move[rng.choice(n_blocks, size=n_bases - 4 if n_bases > 4 else 1, replace=False)] = 1
+        move[rng.choice(n_blocks, size=min(n_bases - 4 if n_bases > 4 else 1, n_blocks), replace=False)] = 1
         n_bases = int(move.sum()) + 4
         bc = {'sequence': ''.join('ACGU'[i] for i in rng.integers(0, 4, n_bases)),
               'qstring': ''.join(chr(33 + q) for q in rng.integers(5, 25, n_bases)), 'block_stride': 15,
@@ -360,3 +362,46 @@ def test_short_path_equals_the_general_path_on_the_gpu(monkeypatch, tmp_path, po
         same(again, want * 4)
     finally:
         WorkerPersistenceStorage.reset()
+
+
+@pytest.mark.parametrize('seed', [3, 4])
+def test_candidate_reads_in_bulk_equal_the_per_read_rule(crafted, monkeypatch, tmp_path, seed):
+    """SignalAnalyzer.bulk_unsplit_rule (prefix sums over the Move column) against SignalAnalysis.detect_unsplit_read
+    (the event table, read by read), on the batch table: every third read has candidates, anywhere in the read."""
+    n = 300
+    path, rec, found, short, _ = crafted_bundle(tmp_path, n, seed)
+    rec['status'] = 0
+    cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path), read_bundle=path, barcoding=True,
+                         filter_unsplit_reads=True, minimum_sequence_length=10)
+    keys = ReadBundle(path).keys
+    CraftedRecords.table = rec
+    monkeypatch.setattr(CraftedRecords, 'candidate_every', 3)
+    assert isinstance(SA.process_batch(0, keys[:1], cfg), list)
+    adapter = worker_objects()['ctx'].state_names.index('adapter')
+    rng = np.random.default_rng(seed)
+    rec['seg_first'][:, adapter] = 20
+    rec['seg_last'][:, adapter] = rng.integers(30, 500, n)              # payload starts at 15 x (that + 1)
+    monkeypatch.setattr(SA, '_PLAIN_RUN', False)
+    settled_in_bulk = []
+    real = SA.SignalAnalyzer.bulk_unsplit_rule
+
+    def counting(self, *a):
+        settled = real(self, *a)
+        settled_in_bulk.append(int(settled.sum()))
+        return settled
+    monkeypatch.setattr(SA.SignalAnalyzer, 'bulk_unsplit_rule', counting)
+    per_read = []
+    real_checks = SA.SignalAnalyzer.base_space_checks
+    monkeypatch.setattr(SA.SignalAnalyzer, 'base_space_checks',
+                        lambda self, t, row, record: per_read.append(row) or real_checks(self, t, row, record))
+    monkeypatch.setattr(SA, '_BULK_UNSPLIT', True)
+    bulk = SA.process_batch(1, keys, cfg)
+    in_bulk, left = sum(settled_in_bulk), len(per_read)
+    monkeypatch.setattr(SA, '_BULK_UNSPLIT', False)
+    del per_read[:]
+    one_by_one = SA.process_batch(1, keys, cfg)
+    assert isinstance(bulk, list) and isinstance(one_by_one, list)
+    same(bulk, one_by_one)
+    assert in_bulk >= 40 and len(per_read) == in_bulk + left
+    verdicts = [r['status'] for r in bulk]
+    assert verdicts.count('unsplit_read') >= 10 and verdicts.count('okay') >= 100
