@@ -1641,6 +1641,10 @@ def main():
                                                        'reads_per_s_one_call_at_a_time': r128['one_call_at_a_time_reads_per_s'],
                                                        'mean_phase_ms_per_call': r128.get('mean_phase_ms_per_call'),
                                                        'merge_stats': r128.get('merge_stats'),
+                                                       # (of the timed calls: judged + reported in one C pass)
+                                                       'calls_on_the_plain_run_path': r128.get('calls_on_the_plain_run_path'),
+                                                       'barcode_or_status_mismatch_vs_resident_records':
+                                                           r128.get('barcode_or_status_mismatch_vs_resident_records'),
                                                        'worker_processes': r128.get('worker_processes')}
             roofline['latency_form'] = lat
         except Exception as exc:                       # reported, never hidden
