@@ -405,3 +405,21 @@ def test_candidate_reads_in_bulk_equal_the_per_read_rule(crafted, monkeypatch, t
     assert in_bulk >= 40 and len(per_read) == in_bulk + left
     verdicts = [r['status'] for r in bulk]
     assert verdicts.count('unsplit_read') >= 10 and verdicts.count('okay') >= 100
+
+
+def test_without_the_extension_every_call_takes_the_batch_table(crafted, monkeypatch, tmp_path):
+    """csrc/_pxgpy is optional (another interpreter version, PXG_NO_PYHOST=1): the short path then declines and the
+    Python report loop returns the same dicts."""
+    path, rec, found, short, _ = crafted_bundle(tmp_path, 120, 13)
+    CraftedRecords.table = rec
+    cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path), read_bundle=path, barcoding=True)
+    b = ReadBundle(path)
+    ok = b.plain_run_columns({'length': 30000, 'stride': 15, 'min_length': 9000})['ok']
+    run = max((j - i, i, j) for i in range(120) for j in range(i + 1, 121) if ok[i:j].all())
+    reads = b.keys[run[1]:run[2]]
+    with_extension = SA.process_batch(0, list(reads), cfg)
+    taken = spy_on_the_short_path(monkeypatch)
+    monkeypatch.setattr(N, 'load_pyhost', lambda: None)
+    without = SA.process_batch(0, list(reads), cfg)
+    assert taken == [False]
+    same(without, with_extension)
