@@ -47,10 +47,21 @@ class SleepingContext:
     def close(self):
         pass
 
+    candidates_every = 0          # --full: every n-th read comes back from the chimera scan with a candidate
+
     def process_batch_ex(self, samples, offsets, calib, stage_mask=N.STAGE_ALL_DEMUX, scale_shift=None, unsplit=None,
                          want_spikes=False):
         time.sleep(self.gpu_ms * 1e-3)
-        return {'records': SleepingContext.records[:len(offsets) - 1].copy()}
+        k = len(offsets) - 1
+        out = {'records': SleepingContext.records[:k].copy()}
+        if want_spikes:
+            out['spikes'] = (np.zeros((0, 4), np.float32), np.zeros(k + 1, np.int64))
+        if unsplit is not None:
+            every = SleepingContext.candidates_every
+            cnt = (np.arange(k) % every == 0).astype(np.int32) if every else np.zeros(k, np.int32)
+            start = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+            out['unsplit'] = (np.tile(np.array([[5000, 5200]], np.int64), (int(cnt.sum()), 1)), cnt, start)
+        return out
 
 
 def main():
@@ -59,7 +70,12 @@ def main():
     ap.add_argument('--gpu-ms', type=float, default=3.0)
     ap.add_argument('--calls', type=int, default=640)
     ap.add_argument('--repeats', type=int, default=4)
+    ap.add_argument('--full', action='store_true',
+                    help='configs[3]-shaped calls (poly(A) + chimera scan), one at a time, no sleep: Python per read')
+    ap.add_argument('--candidates-every', type=int, default=0, help='--full: every n-th read has a chimera candidate')
     args = ap.parse_args()
+    if args.full:
+        return full_calls(args)
     n = args.reads
     sb = synth_batch(n, seed=924, samples_per_read=20000)
     work = tempfile.mkdtemp(prefix='pxg_hostcap_')
@@ -99,6 +115,45 @@ def main():
                 rates.append(args.calls / (time.perf_counter() - t0))
         print('%2d threads: best %5.0f calls/s = %6.0f reads/s (%.3f ms of wall clock per call); all: %s'
               % (threads, max(rates), max(rates) * n, 1e3 / max(rates), ' '.join('%.0f' % r for r in rates)))
+    WorkerPersistenceStorage.reset()
+
+
+def full_calls(args):
+    """Python per read of calls with the poly(A) stage and the chimera scan on, 2 000 reads each (no sleep)."""
+    n = max(args.reads, 2000)
+    sb = synth_batch(n, seed=924, samples_per_read=12000)
+    work = tempfile.mkdtemp(prefix='pxg_hostcap_')
+    names = ['a/r%07d.fast5' % i for i in range(n)]
+    ids = ['%08x-0000-4000-8000-%012x' % (924, i) for i in range(n)]
+    path = os.path.join(work, 'b.pxr.npz')
+    write_bundle(path, sb['arena'], sb['offsets'], sb['calib'], names, ids, basecalls=synth_basecalls(sb, seed=924))
+    cfg = default_config(inputdir=work, outputdir=work, read_bundle=path, barcoding=True, measure_polya=True,
+                         filter_unsplit_reads=True)
+    SleepingContext.gpu_ms, SleepingContext.candidates_every = 0.0, args.candidates_every
+    N.NativeContext = SleepingContext
+    WorkerPersistenceStorage.reset()
+    rec = np.zeros(n, dtype=N.RESULT_DTYPE)
+    adapter = N.NativeConfig(cfg).state_names.index('adapter')
+    rec['seg_first'], rec['seg_last'] = -1, -1
+    rec['seg_first'][:, adapter], rec['seg_last'][:, adapter] = 30, 80
+    rec['bc_pushed'] = rec['bc_called'] = 1
+    rec['polya_called'], rec['polya_dwell_samples'] = 1, 500
+    SleepingContext.records = rec
+    reads = list(zip(names, ids))
+    out = SA.process_batch(0, reads, cfg)
+    assert isinstance(out, list), out
+    statuses = {}
+    for r in out:
+        statuses[r['status']] = statuses.get(r['status'], 0) + 1
+    best = 1e9
+    for _ in range(max(args.repeats, 3)):
+        t0 = time.perf_counter()
+        SA.process_batch(1, reads, cfg)
+        best = min(best, time.perf_counter() - t0)
+    print('%s, %s, candidates in every %s read: %.2f ms per %d-read call = %.2f us of Python per read; statuses %s'
+          % ('plain run' if SA._PLAIN_RUN else 'batch table (PXG_NO_PLAIN_RUN)',
+             'candidates from the Move column' if SA._BULK_UNSPLIT else 'candidates through the event table (PXG_NO_BULK_UNSPLIT)',
+             args.candidates_every or 'no', best * 1e3, n, best / n * 1e6, statuses))
     WorkerPersistenceStorage.reset()
 
 
