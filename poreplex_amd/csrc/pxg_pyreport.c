@@ -14,7 +14,7 @@
  *
  *   _pxgpy.report(columns: dict, rows: int64 buffer) -> list of dict
  *   _pxgpy.report_run(bundle columns: dict, first, n, records, adapter, barcoding, min_seq_len,
- *                     status_names, label_names[, measure_polya, spike rows, spike offsets]) -> list of dict
+ *                     status_names, label_names[, measure_polya, spike rows, spike offsets, skip]) -> list of dict
  *
  * report_run is the whole host side of the USUAL worker call behind the GPU pass -- consecutive reads of a read
  * bundle, every one of them with a regular basecall summary (signal_analyzer.SignalAnalyzer.process_plain_run checks
@@ -363,13 +363,13 @@ static int need_rows(const Buf* b, const char* name, Py_ssize_t rows)
 
 static PyObject* report_run(PyObject* self, PyObject* args)
 {
-    PyObject *cols, *rec_obj, *status_names, *label_names, *spikes_obj = Py_None, *spike_off_obj = Py_None;
+    PyObject *cols, *rec_obj, *status_names, *label_names, *spikes_obj = Py_None, *spike_off_obj = Py_None, *skip_obj = Py_None;
     Py_ssize_t first, n;
     int adapter, barcoding, polya = 0;
     long long min_seq_len;
-    if (!PyArg_ParseTuple(args, "O!nnOipLO!O!|pOO", &PyDict_Type, &cols, &first, &n, &rec_obj, &adapter, &barcoding,
+    if (!PyArg_ParseTuple(args, "O!nnOipLO!O!|pOOO", &PyDict_Type, &cols, &first, &n, &rec_obj, &adapter, &barcoding,
                           &min_seq_len, &PyTuple_Type, &status_names, &PyTuple_Type, &label_names, &polya, &spikes_obj,
-                          &spike_off_obj))
+                          &spike_off_obj, &skip_obj))
         return NULL;
     if (first < 0 || n < 0 || adapter < 0 || adapter >= PXG_N_SEGMENTS || PyTuple_GET_SIZE(status_names) < PXG_N_STATUS ||
         PyTuple_GET_SIZE(label_names) < 2) {
@@ -377,9 +377,9 @@ static PyObject* report_run(PyObject* self, PyObject* args)
         return NULL;
     }
     Buf rec, start_time, duration, calib, present, seq_len, qscore, n_events, seq_off, seq_arena, qual_arena, channel,
-        run_id, sample_id, spikes, spike_off;
+        run_id, sample_id, spikes, spike_off, skip;
     Buf* all[] = { &rec, &start_time, &duration, &calib, &present, &seq_len, &qscore, &n_events, &seq_off, &seq_arena,
-                   &qual_arena, &channel, &run_id, &sample_id, &spikes, &spike_off };
+                   &qual_arena, &channel, &run_id, &sample_id, &spikes, &spike_off, &skip };
     for (size_t k = 0; k < sizeof(all) / sizeof(all[0]); k++) all[k]->held = 0;
     PyObject* out = NULL;
     const Py_ssize_t last = first + n;         /* reads [first, last) of the bundle */
@@ -413,6 +413,15 @@ static PyObject* report_run(PyObject* self, PyObject* args)
             goto done;
         }
     }
+    /* reads somebody else reports (the chimera scan found candidates in them): their slots are left None */
+    if (skip_obj != Py_None) {
+        if (PyObject_GetBuffer(skip_obj, &skip.view, PyBUF_C_CONTIGUOUS) < 0) goto done;
+        skip.held = 1;
+        if (skip.view.itemsize != 1 || skip.view.len < n) {
+            PyErr_SetString(PyExc_TypeError, "report_run: skip must be a bool per read");
+            goto done;
+        }
+    }
     PyObject *filenames = get_list(cols, "filenames", 0), *read_ids = get_list(cols, "read_ids", 0);
     if (!filenames || !read_ids) goto done;
     out = PyList_New(n);
@@ -425,6 +434,11 @@ static PyObject* report_run(PyObject* self, PyObject* args)
         for (Py_ssize_t k = 0; k < n; k++) {
             const Py_ssize_t b = first + k;
             const pxg_read_result* r = R + k;
+            if (skip.held && ((const uint8_t*)skip.view.buf)[k]) {
+                Py_INCREF(Py_None);
+                PyList_SET_ITEM(out, k, Py_None);
+                continue;
+            }
             /* the rules, in the order the general path applies them (signal_loader.attach_records,
              * SignalAnalyzer.judge, BarcodeDemultiplexer.assign, SignalAnalyzer.bulk_base_space) */
             int status = PXG_ST_OKAY, label = -1, called = 0, summary = 0, tail = 0;

@@ -213,11 +213,16 @@ class SignalAnalyzer(AbstractContextManager):
         got = loader.records_of_run(arena, offsets, calib, scan)
         t2 = time.perf_counter()
         with phase:
-            if scan is not None and got['unsplit'][1].any():
-                # in-read adapter candidates (or a scan that failed) somewhere in the call: those reads are judged one
-                # by one over their event tables -- the batch table, with the pass that has already run
+            some = np.nonzero(got['unsplit'][1])[0] if scan is not None else ()
+            if len(some) > n // 4:
+                # in-read adapter candidates (or failed scans) all over the call: the batch table, with the pass that has
+                # already run
                 results = self.finish_from_pass(reads, got, sel)
             else:
+                skip = None
+                if len(some):            # a few reads with candidates: a table of just those, the rest in the C pass
+                    skip = np.zeros(n, dtype=np.bool_)
+                    skip[some] = True
                 spikes = got.get('spikes')
                 was_on = gc.isenabled()      # (nothing report_run builds can be part of a cycle: ReadTable.report)
                 gc.disable()
@@ -226,7 +231,11 @@ class SignalAnalyzer(AbstractContextManager):
                                               bool(cfg['barcoding']), int(cfg['minimum_sequence_length']),
                                               tuple(native.STATUS_NAMES), tuple(LABELS), bool(cfg['measure_polya']),
                                               None if spikes is None else np.ascontiguousarray(spikes[0], dtype=np.float32),
-                                              None if spikes is None else np.ascontiguousarray(spikes[1], dtype=np.int64))
+                                              None if spikes is None else np.ascontiguousarray(spikes[1], dtype=np.int64),
+                                              skip)
+                    if skip is not None:
+                        for at, report in zip(some.tolist(), self.finish_some_from_pass(b, first, some, got)):
+                            results[at] = report
                 except (IndexError, TypeError, KeyError, ValueError):
                     results = self.finish_from_pass(reads, got, sel)      # columns it cannot read as they are
                 finally:
@@ -251,6 +260,24 @@ class SignalAnalyzer(AbstractContextManager):
         if scanned is not None and got.get('unsplit') is not None:
             loader.attach_unsplit(table, rows, scanned, got['unsplit'])
         return self.finish(batch)
+
+    def finish_some_from_pass(self, bundle, first, some, got):
+        """Result dicts of the reads `some` (positions in a plain run that starts at bundle read `first`) through a batch
+        table of their own: the reads the chimera scan found candidates in, judged by the table's rules over the
+        records, spike rows and candidate lists of the pass the whole run has made (process_plain_run)."""
+        loader = self.loader
+        table = ReadTable(len(some))
+        rows = table.extend_from_bundle(bundle, first + some)
+        table.pending[rows] = False                  # (the samples have been to the GPU)
+        loader.attach_records(table, rows, got['records'], got.get('spikes'), gpu_rows=some)
+        intervals, count, start = got['unsplit']
+        table.unsplit_count[rows] = count[some]
+        for k, at in enumerate(some.tolist()):
+            if count[at] > 0:
+                table.unsplit[rows[k]] = intervals[start[at]:start[at + 1]].tolist()
+        self.judge(rows, table)
+        table.release(rows)
+        return table.report(rows)
 
     def prepare(self, reads, table=None, reserve=None):
         """Host-only first phase: open every read into a batch table.  The session driver

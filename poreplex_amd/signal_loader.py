@@ -725,13 +725,18 @@ class SignalLoader:
                 self.attach_unsplit(table, rows, n_events > 0, self.ctx.unsplit_scan_events(n_events, starts, means))
                 table.own_table_scanned = set(rows[n_events > 0].tolist())
 
-    def attach_records(self, table, rows, rec, spikes):
+    def attach_records(self, table, rows, rec, spikes, gpu_rows=None):
         """The GPU's records (and spike rows) become the batch table's: scaling-QC verdicts
-        (:108-109) and scaling parameters are set here, everything else is judged later."""
+        (:108-109) and scaling parameters are set here, everything else is judged later.
+        `gpu_rows`: the records of `rows` when the table holds only some of the pass's reads."""
         t = table
         t.records = rec
         t.spikes, t.spike_offsets = spikes if spikes is not None else (None, None)
-        t.gpu_row[rows] = np.arange(len(rows))
+        if gpu_rows is None:
+            t.gpu_row[rows] = np.arange(len(rows))
+        else:
+            t.gpu_row[rows] = gpu_rows
+            rec = rec[gpu_rows]
         qc_failed = rec['status'] == native.STATUS_CODE['scaling_qc_fail']
         t.halt(rows[qc_failed], 'scaling_qc_fail')
         good = rows[~qc_failed]
