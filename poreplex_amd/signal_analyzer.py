@@ -169,10 +169,11 @@ class SignalAnalyzer(AbstractContextManager):
         """process() for the usual worker call, without a batch table: `reads` is a run of consecutive reads of the
         read bundle, all of them long enough for the scaler and regular in their basecall summary
         (ReadBundle.plain_run_columns), and the configuration asks for nothing that walks every read (dumps, on-the-fly
-        basecalling, the opt-in adapter trimming).  The samples go to the GPU as the
-        bundle's own arena, the records come back, and csrc/pxg_pyreport.c report_run applies the status / label rules
-        and builds the dicts in one pass: ~0.1 ms of Python for 128 reads where prepare + judge + report take 0.35 --
-        the interpreter lock is what bounds worker threads that feed the GPU in reference-sized calls.
+        basecalling, the opt-in adapter trimming).  The samples go to the GPU as the bundle's own arena, the records
+        (spike rows, scan candidates) come back, and csrc/pxg_pyreport.c report_run applies the status / label rules and
+        builds the dicts in one pass: ~0.1 ms of Python for 128 reads where prepare + judge + report take 0.35 -- the
+        interpreter lock is what bounds worker threads that feed the GPU in reference-sized calls.  Reads
+        the chimera scan found candidates in are judged by the batch table's rules (finish_some_from_pass).
         None = not such a call: the general path takes it, and defines what this one must return
         (tests/test_plain_run.py)."""
         loader, cfg = self.loader, self.config
