@@ -621,6 +621,13 @@ int pxg_h5_read_id(const pxg_h5* file, int64_t i, char* out, int64_t cap);
 int64_t pxg_h5_read_ids(const pxg_h5* file, char* out, int64_t cap);
 int pxg_h5_info(const pxg_h5* file, int64_t first, int64_t n, pxg_h5_read_info* out);
 int pxg_h5_info_mt(const pxg_h5* file, int64_t first, int64_t n, pxg_h5_read_info* out, int32_t threads);
+/* Many files at once, on `threads` host threads (a directory of single-read FAST5: fast5_file.py:60-96 once per read):
+ * files[k] / rc[k] as pxg_h5_open leaves them (NULL + the error code; its text in error[160 k .. 160 k + 159] when
+ * `error` is given), n_reads[k], multi[k], and -- for a file that holds exactly one read in the single-read layout --
+ * first_info[k] as pxg_h5_info(files[k], 0, 1, ..) fills it.  pxg_h5_close_many closes what is not NULL. */
+int pxg_h5_open_many(int64_t n, const char* const* paths, int32_t threads, pxg_h5** files, int32_t* rc,
+                     int64_t* n_reads, int32_t* multi, pxg_h5_read_info* first_info, char* error_or_null);
+void pxg_h5_close_many(int64_t n, pxg_h5* const* files);
 /* text = sequence '\n' quality string; move = the Move table / the Events table's move column */
 int pxg_h5_basecall(const pxg_h5* file, int64_t i, int64_t text_cap, char* text, int64_t move_cap,
                     uint8_t* move, double* p_model_state_or_null, int32_t* has_p_model_state);

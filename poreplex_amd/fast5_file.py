@@ -394,9 +394,24 @@ class Fast5File:
         self._keys = {}
         self.size = 0
 
+    @classmethod
+    def from_handle(cls, path, handle, n, multi, info=None, owner=None):
+        """A Fast5File over a file that open_many has opened (`owner`: the OpenedFiles that closes it)."""
+        from . import native
+        import ctypes as C
+        self = cls.__new__(cls)
+        self.lib = native.load_text_library()
+        self.path, self.handle, self.owner = path, C.c_void_p(int(handle)), owner
+        self.n, self.multi = int(n), bool(multi)
+        self._ids = self._index = self._ids_array = None
+        self._info = info
+        self._keys = {}
+        self.size = 0
+        return self
+
     def close(self):
         handle, self.handle = getattr(self, 'handle', None), None
-        if handle:
+        if handle and getattr(self, 'owner', None) is None:
             self.lib.pxg_h5_close(handle)
 
     __del__ = close
@@ -512,7 +527,16 @@ class Fast5File:
 
 
 _OPEN, _OPEN_LOCK, _OPEN_MAX = OrderedDict(), threading.Lock(), 128
+_OPEN_BYTES = 0                      # mapped bytes of the files in _OPEN
 _OPEN_MAX_BYTES = int(os.environ.get('PXG_FAST5_CACHE_BYTES', 8 << 30))     # mapped file bytes kept open
+
+
+def clear_open_cache():
+    """Forget every cached Fast5File (tools that time a cold reader; files in use stay open through their references)."""
+    global _OPEN_BYTES
+    with _OPEN_LOCK:
+        _OPEN.clear()
+        _OPEN_BYTES = 0
 
 
 def open_fast5(path):
@@ -527,26 +551,77 @@ def open_fast5(path):
             return f
     f = Fast5File(path)
     f.size = st.st_size
+    global _OPEN_BYTES
     with _OPEN_LOCK:
+        if key not in _OPEN:
+            _OPEN_BYTES += f.size
         _OPEN[key] = f
         # a run walks its files once: what stays open (= mapped) is bounded in files and in bytes,
         # the most recent ones first (a batch in flight keeps its own references)
-        total = sum(g.size for g in _OPEN.values())
-        while len(_OPEN) > _OPEN_MAX or (total > _OPEN_MAX_BYTES and len(_OPEN) > 2):
-            total -= _OPEN.popitem(last=False)[1].size
+        while len(_OPEN) > _OPEN_MAX or (_OPEN_BYTES > _OPEN_MAX_BYTES and len(_OPEN) > 2):
+            _OPEN_BYTES -= _OPEN.popitem(last=False)[1].size
     return f
+
+
+class OpenedFiles:
+    """Many FAST5 files opened by ONE native call (pxg_h5_open_many: a directory of single-read files costs a worker
+    batch thousands of opens): handles, per-file outcome and -- for files that hold one read in the single-read layout --
+    that read's pxg_h5_read_info.  Closes what it opened when the last reference goes."""
+
+    def __init__(self, paths, threads=None):
+        from . import native
+        import ctypes as C
+        import time
+        self.lib = native.load_text_library()
+        self.paths = list(paths)
+        n = self.n = len(self.paths)
+        self.handles = np.zeros(n, dtype=np.uintp)
+        self.rc = np.zeros(n, dtype=np.int32)
+        self.n_reads = np.zeros(n, dtype=np.int64)
+        self.multi = np.zeros(n, dtype=np.int32)
+        self.info = np.zeros(n, dtype=native.H5_INFO_DTYPE)
+        self.error = np.zeros(n, dtype='S160')
+        encoded = [os.fsencode(p) for p in self.paths]
+        argv = (C.c_char_p * max(n, 1))(*encoded)
+        t0 = time.perf_counter()
+        rc = self.lib.pxg_h5_open_many(n, argv, threads or host_threads(), self.handles.ctypes.data, self.rc.ctypes.data,
+                                       self.n_reads.ctypes.data, self.multi.ctypes.data, self.info.ctypes.data,
+                                       self.error.ctypes.data)
+        _timed('walk_s', t0)
+        if rc:
+            self.close()
+            raise Fast5Error('pxg_h5_open_many failed ({})'.format(rc))
+
+    def file(self, k):
+        """Fast5File of file k (it does not own the handle: this object does)."""
+        one = self.info[k:k + 1] if (not self.multi[k] and self.n_reads[k] == 1) else None
+        return Fast5File.from_handle(self.paths[k], self.handles[k], self.n_reads[k], self.multi[k], one, owner=self)
+
+    def close(self):
+        handles, self.handles = getattr(self, 'handles', None), None
+        if handles is not None and len(handles):
+            self.lib.pxg_h5_close_many(len(handles), handles.ctypes.data)
+
+    __del__ = close
+
+
+_HOST_CORES = None
 
 
 def host_threads():
     """Threads for the batch decoders: the cores this process may use, capped by a cgroup quota."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    try:
-        with open('/sys/fs/cgroup/cpu.max') as fh:
-            q, period = fh.read().split()
-        if q != 'max':
-            n = min(n, max(int(float(q) / float(period)), 1))
-    except (OSError, ValueError):
-        pass
+    global _HOST_CORES
+    if _HOST_CORES is None:          # (asked once per process: a batch of single-read files used to ask twice per file)
+        n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        try:
+            with open('/sys/fs/cgroup/cpu.max') as fh:
+                q, period = fh.read().split()
+            if q != 'max':
+                n = min(n, max(int(float(q) / float(period)), 1))
+        except (OSError, ValueError):
+            pass
+        _HOST_CORES = n
+    n = _HOST_CORES
     # several ranks on one host (torchrun sets LOCAL_WORLD_SIZE) share its cores: an equal share
     # each, so that N loader pools do not oversubscribe the sockets they were pinned to
     local = int(os.environ.get('LOCAL_WORLD_SIZE', 1) or 1)
@@ -647,11 +722,27 @@ class Fast5Batch:
         self.id_array = np.concatenate([f.read_ids_array[i0:i0 + count] for f, _, i0, count in runs])
         return self
 
+    @classmethod
+    def from_opened(cls, opened, which, names, read_ids):
+        """The batch of the single-read files `which` of an OpenedFiles (one read each: read 0), without a Python
+        object per file."""
+        self = cls.__new__(cls)
+        self.runs, self._files, self.opened, self.which = None, None, opened, np.asarray(which, dtype=np.int64)
+        self.index = np.zeros(len(self.which), dtype=np.int64)
+        self.info = opened.info[self.which]
+        self.names, self.read_ids = list(names), list(read_ids)
+        self.handles = np.ascontiguousarray(opened.handles[self.which])
+        self.name_array = self.id_array = None
+        return self
+
     @property
     def files(self):
         """The Fast5File of every read (kept alive by the batch either way)."""
         if self._files is None:
-            self._files = [f for f, _, _, count in self.runs for _ in range(count)]
+            if self.runs is None:
+                self._files = [self.opened.file(int(k)) for k in self.which]
+            else:
+                self._files = [f for f, _, _, count in self.runs for _ in range(count)]
         return self._files
 
     def as_bundle(self, reserve=None, threads=None):

@@ -374,6 +374,9 @@ _TEXT_SIGNATURES = {      # libpxghost.so: host-only helpers (sink text, sample 
     'pxg_h5_read_ids': (C.c_int64, [C.c_void_p, C.c_char_p, C.c_int64]),
     'pxg_h5_info': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     'pxg_h5_info_mt': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32]),
+    'pxg_h5_open_many': (C.c_int, [C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    'pxg_h5_close_many': (None, [C.c_int64, C.c_void_p]),
     'pxg_h5_basecall': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_char_p, C.c_int64, C.c_void_p,
                                   C.c_void_p, C.POINTER(C.c_int32)]),
     'pxg_h5_events': (C.c_int64, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -330,7 +330,7 @@ def test_reader_threads_are_shared_between_calls_and_survive_a_fork(tmp_path):
     dst = np.concatenate([[0], np.cumsum(ns)[:-1]]).astype(np.int64)
 
     def one_pass(threads):
-        F5._OPEN.clear()
+        F5.clear_open_cache()
         f = F5.Fast5File(path)                           # the read groups: a pool job of its own
         arena = np.zeros(int(ns.sum()), dtype=np.int16)
         st = F5.load_signals([f] * len(lens), np.arange(len(lens)), ns, arena, dst, threads=threads)
@@ -485,7 +485,7 @@ def test_open_file_cache_is_bounded_in_bytes(inputs, monkeypatch):
     paths = sorted({os.path.join(top, t['where'][i]) for i in range(len(t['ids']))})
     assert len(paths) >= 4
     monkeypatch.setattr(F5, '_OPEN_MAX_BYTES', 1)
-    F5._OPEN.clear()
+    F5.clear_open_cache()
     first = F5.open_fast5(paths[0])
     ids = list(first.read_ids)
     for p in paths[1:]:
@@ -494,7 +494,7 @@ def test_open_file_cache_is_bounded_in_bytes(inputs, monkeypatch):
     assert first.handle and list(F5.Fast5File(paths[0]).read_ids) == ids and first.info['status'][0] == 0
     again = F5.open_fast5(paths[0])                      # opened afresh, the same content
     assert again is not first and list(again.read_ids) == ids
-    F5._OPEN.clear()
+    F5.clear_open_cache()
 
 
 def test_host_threads_is_a_share_of_the_host(monkeypatch):

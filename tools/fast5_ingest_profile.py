@@ -44,7 +44,7 @@ def loader_call(path, count, arena):
     reads = [(name, 'r%06d' % j) for j in range(count)]
     best = None
     for _ in range(3):
-        F5._OPEN.clear()
+        F5.clear_open_cache()
         t0 = time.perf_counter()
         where = loader.prepare_many(reads, ReadTable(), reserve=lambda k: arena[:k])
         dt = time.perf_counter() - t0
@@ -61,7 +61,7 @@ for mode in MODES:
         for j in range(count):
             w.add_read('r%06d' % j, base['arena'][o[j]:o[j + 1]], base['calib'][j], basecall=bcs[j], compression=mode)
     for threads in (1, 4, 8, 16, 32):
-        F5._OPEN.clear()
+        F5.clear_open_cache()
         t0 = time.perf_counter()
         f = F5.Fast5File(path)
         t1 = time.perf_counter()

@@ -34,6 +34,11 @@ for trial in range(int(sys.argv[2]) if len(sys.argv)>2 else 1500):
             blob[pos:pos+8] = rng.choice([b'\xff'*8, b'\x00'*8, (2**63-1).to_bytes(8,'little'), int(rng.integers(0,2**40)).to_bytes(8,'little')])
     p = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'pxg_h5_fuzz.fast5'); open(p,'wb').write(bytes(blob))
     try:
+        many = F5.OpenedFiles([p, p + '.absent', p], threads=2)      # the batch open: same outcome per file, as data
+        assert many.rc[1] != 0 and many.rc[0] == many.rc[2]
+        if many.rc[0] == 0 and many.n_reads[0] == 1 and not many.multi[0] and many.info['status'][0] == 0:
+            F5.Fast5Batch.from_opened(many, [0, 2], ['a', 'b'], ['x', 'y']).as_bundle(threads=2)
+        many.close()
         f = F5.Fast5File(p); n_open+=1
         info = f.info
         ok = np.nonzero(info['status']==0)[0]
