@@ -28,7 +28,7 @@ try:  # optional: only for files the native reader declines
 except ImportError:  # pragma: no cover
     h5py = None
 
-__all__ = ['get_read_ids', 'open_read', 'ReadBundle', 'Fast5Reader', 'Fast5File', 'Fast5Batch', 'write_bundle']
+__all__ = ['get_read_ids', 'get_read_ids_many', 'open_read', 'ReadBundle', 'Fast5Reader', 'Fast5File', 'Fast5Batch', 'write_bundle']
 
 
 TABLE_KINDS = ('', 'move', 'guppy_events', 'albacore', 'unsupported')   # '' = no event table
@@ -958,6 +958,32 @@ def get_read_ids(filename, basedir, bundle=None):
             except KeyError:
                 return []
         return [(filename, node[5:]) for node in f5 if node.startswith('read_')]
+
+
+def get_read_ids_many(filenames, basedir, chunk=4096):
+    """get_read_ids for many files, in their order: the files are opened `chunk` at a time by one native call
+    (OpenedFiles) and a file that holds one read in the single-read layout answers from there -- a directory of
+    single-read files is listed without a Python round per file; every other file (multi-read, unreadable, odd) goes
+    through get_read_ids itself, which answers or raises as before."""
+    out = []
+    filenames = list(filenames)
+    for lo in range(0, len(filenames), chunk):
+        names = filenames[lo:lo + chunk]
+        opened = OpenedFiles([os.path.join(basedir, n) if basedir is not None else n for n in names])
+        try:
+            single = (opened.rc == 0) & (opened.multi == 0) & (opened.n_reads == 1) & (opened.info['status'] == 0)
+            ids = opened.info['read_id'].tolist()
+            for k, name in enumerate(names):
+                if single[k]:
+                    try:
+                        out.append((name, ids[k].decode('ascii')))
+                        continue
+                    except UnicodeDecodeError:
+                        pass
+                out.extend(get_read_ids(name, basedir))
+        finally:
+            opened.close()
+    return out
 
 
 def open_read(fullpath, filename, read_id, bundle=None):

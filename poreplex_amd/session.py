@@ -47,20 +47,21 @@ class SessionAborted(RuntimeError):
 def enumerate_reads(config, bundle=None):
     """Every (filename, read_id) of the run, in a deterministic order: the bundle's own
     order, or a sorted recursive walk of inputdir (pipeline.py:303-337 without the inotify
-    branch) with fast5_file.get_read_ids per file."""
-    from .fast5_file import get_read_ids
+    branch) with fast5_file.get_read_ids per file (single-read files: by the thousand in one native
+    call, get_read_ids_many)."""
+    from .fast5_file import get_read_ids_many
     if bundle is not None:
         d = bundle.d
         return [(str(f), str(r)) for f, r in zip(d['filename'], d['read_id'])], d.get('duration')
-    found = []
+    files = []
     top = config['inputdir']
     for dirpath, dirnames, filenames in os.walk(top):
         dirnames[:] = sorted(n for n in dirnames if not n.startswith('.'))
         for name in sorted(filenames):
             if name.startswith('.') or not name.lower().endswith('.fast5'):
                 continue
-            found.extend(get_read_ids(os.path.relpath(os.path.join(dirpath, name), top), top))
-    return found, None
+            files.append(os.path.relpath(os.path.join(dirpath, name), top))
+    return get_read_ids_many(files, top), None
 
 
 class _Staging:

@@ -148,3 +148,29 @@ def test_opened_files_reports_each_file(directory):
     del f
     got.close()
     got.close()                                              # (idempotent)
+
+
+def test_listing_a_directory(directory, tmp_path):
+    """get_read_ids_many == get_read_ids file by file, for single-read files, a multi-read file among them and files it
+    must leave to get_read_ids (which raises for what cannot be opened)."""
+    from poreplex_amd.fast5_file import get_read_ids, get_read_ids_many
+    top, names, ids, rec = directory
+    with Fast5Writer(str(top / 'multi.fast5')) as w:
+        sb = synth_batch(3, seed=5, samples_per_read=12000)
+        for j in range(3):
+            w.add_read('m-{}'.format(j), sb['arena'][sb['offsets'][j]:sb['offsets'][j + 1]], sb['calib'][j])
+    files = names[:7] + ['multi.fast5'] + names[7:]
+    want = [pair for f in files for pair in get_read_ids(f, str(top))]
+    assert get_read_ids_many(files, str(top)) == want and len(want) == 43
+    assert get_read_ids_many(files, str(top), chunk=5) == want
+    assert get_read_ids_many([], str(top)) == []
+    with open(str(top / names[4]), 'wb') as fh:
+        fh.write(b'not an HDF5 file at all, whatever its name says ' * 8)
+    with pytest.raises(OSError):
+        get_read_ids(names[4], str(top))
+    with pytest.raises(OSError):
+        get_read_ids_many(files, str(top))
+    from poreplex_amd.session import enumerate_reads
+    os.remove(str(top / names[4]))
+    listed, _ = enumerate_reads({'inputdir': str(top)})
+    assert sorted(listed) == sorted(p for p in want if p[0] != names[4])
