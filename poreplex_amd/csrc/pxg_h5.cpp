@@ -22,6 +22,7 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -1346,6 +1347,16 @@ extern "C" int pxg_h5_open_many(int64_t n, const char* const* paths, int32_t thr
                                 int64_t* n_reads, int32_t* multi, pxg_h5_read_info* first_info, char* error)
 {
     if (n < 0 || (n && (!paths || !files || !rc || !n_reads || !multi || !first_info))) return PXG_E_INVALID;
+    // A worker batch of single-read files is thousands of files open at once, and a process may hold ~1 000 descriptors
+    // (RLIMIT_NOFILE's usual soft limit): beyond a share of the limit a file keeps its MAPPING and gives its descriptor
+    // back (copy_out then copies from the map instead of pread: slower for big stretches, never wrong).
+    int64_t fd_budget = 256;
+    {
+        struct rlimit lim;
+        if (getrlimit(RLIMIT_NOFILE, &lim) == 0)
+            fd_budget = lim.rlim_cur == RLIM_INFINITY ? (int64_t)1 << 40 : std::max<int64_t>((int64_t)lim.rlim_cur / 4, 16);
+    }
+    std::atomic<int64_t> kept{ 0 };
     run_pool(n, threads, [&](int64_t k) {
         files[k] = nullptr;
         n_reads[k] = 0;
@@ -1364,6 +1375,10 @@ extern "C" int pxg_h5_open_many(int64_t n, const char* const* paths, int32_t thr
         n_reads[k] = (int64_t)files[k]->reads.size();
         multi[k] = files[k]->multi ? 1 : 0;
         if (!files[k]->multi && n_reads[k] == 1) (void)pxg_h5_info_mt(files[k], 0, 1, &first_info[k], 1);
+        if (kept.fetch_add(1) >= fd_budget && files[k]->fd >= 0) {
+            close(files[k]->fd);
+            files[k]->fd = -1;
+        }
     }, 4);
     return PXG_OK;
 }

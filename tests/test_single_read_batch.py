@@ -174,3 +174,30 @@ def test_listing_a_directory(directory, tmp_path):
     os.remove(str(top / names[4]))
     listed, _ = enumerate_reads({'inputdir': str(top)})
     assert sorted(listed) == sorted(p for p in want if p[0] != names[4])
+
+
+def test_a_batch_open_under_a_small_descriptor_limit(directory):
+    """200 opens of 40 files under RLIMIT_NOFILE = 80: beyond a share of the limit a file keeps its mapping and gives its
+    descriptor back, every one of them opens and decodes to the same samples."""
+    import subprocess
+    top, names, ids, rec = directory
+    script = '''
+import resource, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+from poreplex_amd import fast5_file as F5
+names = {names!r}
+want = F5.OpenedFiles([{top!r} + '/' + n for n in names])
+ns = want.info['n_samples'].astype(np.int64)
+ref = F5.load_signals(want.handles, np.zeros(len(names), np.int64), ns)
+hard = resource.getrlimit(resource.RLIMIT_NOFILE)[1]
+resource.setrlimit(resource.RLIMIT_NOFILE, (80, hard))
+many = F5.OpenedFiles([{top!r} + '/' + n for n in names] * 5, threads=4)
+assert (many.rc == 0).all(), many.rc
+got = F5.load_signals(many.handles, np.zeros(len(names) * 5, np.int64), np.tile(ns, 5), threads=4)
+for k, a in enumerate(got):
+    assert np.array_equal(a, ref[k % len(names)]), k
+print('ok', len(got))
+'''.format(root=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), names=names, top=str(top))
+    out = subprocess.run([sys.executable, '-c', script], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == 'ok 200', (out.stdout, out.stderr[-2000:])
