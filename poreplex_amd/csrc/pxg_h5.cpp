@@ -1580,6 +1580,8 @@ static Pool* the_pool()
     return p;
 }
 
+static const int64_t kSmallJob = 512;
+
 // fn(k) for k in [0, n) on `threads` host threads, `grain` consecutive k per queue access
 template <typename Fn>
 static void run_pool(int64_t n, int threads, Fn fn, int64_t grain)
@@ -1594,6 +1596,10 @@ static void run_pool(int64_t n, int threads, Fn fn, int64_t grain)
     j.grain = grain;
     if (nt == 1) { j.drain(); return; }
     if (!getenv("PXG_H5_SPAWN_THREADS") && the_pool()->run(j, nt)) return;
+    // the workers are busy with another caller's job.  A small job (a reference-sized worker call: 128 reads, one of
+    // dozens in flight on other threads) runs on its caller alone -- the parallelism is between the calls, and
+    // starting threads of its own would cost more than its share of the work; a big one starts them as before
+    if (n <= kSmallJob && !getenv("PXG_H5_SPAWN_THREADS")) { j.drain(); return; }
     std::vector<std::thread> own;
     own.reserve((size_t)nt);
     for (int t = 1; t < nt; t++) {

@@ -47,6 +47,7 @@ _USE_HOST_PHASE = os.environ.get('PXG_NO_HOST_PHASE_LOCK') is None
 # (A/B and tests: PXG_NO_PLAIN_RUN=1 sends every call through the batch table)
 _PLAIN_RUN = os.environ.get('PXG_NO_PLAIN_RUN') is None
 _BULK_UNSPLIT = os.environ.get('PXG_NO_BULK_UNSPLIT') is None      # (A/B and tests: candidates judged read by read)
+_PLAIN_RUN_FAST5 = os.environ.get('PXG_NO_PLAIN_RUN_FAST5') is None    # (A/B: only bundle reads take the short path)
 PLAIN_RUN_CALLS = 0         # worker calls that took SignalAnalyzer.process_plain_run (bench.py reports it)
 
 
@@ -143,31 +144,41 @@ class SignalAnalyzer(AbstractContextManager):
             | (native.STAGE_BARCODE if config['barcoding'] else 0)
             | (native.STAGE_POLYA if config['measure_polya'] else 0))
         self.loader.scan_unsplit = bool(config.get('filter_unsplit_reads'))
+        self.prebuilt = None        # (reads, their per-call FAST5 bundle) between process_plain_run and prepare
+        self.call_arena = None      # that bundle's sample arena, the loader's to have back (process)
 
     # ---- batch driver --------------------------------------------------------
     def process(self, reads):
         """Result list of signal_analyzer.py:82-134: whatever was decided before the GPU
         pass first (encounter order), then every read that entered it (input order)."""
         phase = _HOST_PHASE if _USE_HOST_PHASE else _NoLock()
-        if _PLAIN_RUN:
-            results = self.process_plain_run(reads, phase)
-            if results is not None:
-                return results
-        t0 = time.perf_counter()
-        with phase:
-            batch = self.prepare(reads, ReadTable(len(reads)))    # a table of its own: calls may overlap (threads)
-        t1 = time.perf_counter()
-        self.loader.fit_scalers(batch.table)     # scaling parameters AND every other numeric stage
-        t2 = time.perf_counter()
-        with phase:
-            results = self.finish(batch)
-        if CALL_TRACE is not None:               # bench.py: where a worker call spends its time
-            CALL_TRACE.append((t0, t1, t2, time.perf_counter()))
-        return results
+        try:
+            if _PLAIN_RUN:
+                results = self.process_plain_run(reads, phase)
+                if results is not None:
+                    return results
+            t0 = time.perf_counter()
+            with phase:
+                batch = self.prepare(reads, ReadTable(len(reads)))    # a table of its own: calls may overlap (threads)
+            t1 = time.perf_counter()
+            self.loader.fit_scalers(batch.table)     # scaling parameters AND every other numeric stage
+            t2 = time.perf_counter()
+            with phase:
+                results = self.finish(batch)
+            if CALL_TRACE is not None:               # bench.py: where a worker call spends its time
+                CALL_TRACE.append((t0, t1, t2, time.perf_counter()))
+            return results
+        finally:
+            # the sample arena of a per-call FAST5 bundle (process_plain_run) goes back to the loader's pool once the
+            # call is over, whichever path reported: nothing a call returns points into it
+            arena, self.call_arena, self.prebuilt = self.call_arena, None, None
+            if arena is not None:
+                self.loader.call_arenas.give(arena)
 
     def process_plain_run(self, reads, phase):
         """process() for the usual worker call, without a batch table: `reads` is a run of consecutive reads of the
-        read bundle, all of them long enough for the scaler and regular in their basecall summary
+        read bundle -- or of multi-read FAST5 files, in file order: the per-call bundle the native reader makes of them
+        (SignalLoader.fast5_run_bundle) --, all of them long enough for the scaler and regular in their basecall summary
         (ReadBundle.plain_run_columns), and the configuration asks for nothing that walks every read (dumps, on-the-fly
         basecalling, the opt-in adapter trimming).  The samples go to the GPU as the bundle's own arena, the records
         (spike rows, scan candidates) come back, and csrc/pxg_pyreport.c report_run applies the status / label rules and
@@ -175,28 +186,45 @@ class SignalAnalyzer(AbstractContextManager):
         interpreter lock is what bounds worker threads that feed the GPU in reference-sized calls.  Reads
         the chimera scan found candidates in are judged by the batch table's rules (finish_some_from_pass).
         None = not such a call: the general path takes it, and defines what this one must return
-        (tests/test_plain_run.py)."""
+        (tests/test_plain_run.py); a per-call bundle that was built on the way is left in self.prebuilt for it."""
         loader, cfg = self.loader, self.config
         b = loader.bundle
-        if b is None or self.dump_adapter or self.dump_events or cfg['albacore_onthefly'] \
+        if self.dump_adapter or self.dump_events or cfg['albacore_onthefly'] \
                 or (cfg['trim_adapter'] and cfg.get('trim_adapter_as_intended')) \
                 or type(reads) is not list or not reads or type(reads[0]) is not tuple \
                 or (loader.scan_unsplit and not hasattr(self.ctx, 'process_batch_ex')):
+            return None
+        from_files = b is None or not b.has_file(reads[0][0])
+        if from_files and not _PLAIN_RUN_FAST5:
             return None
         fast = native.load_pyhost()
         if fast is None or not hasattr(fast, 'report_run'):
             return None
         t0 = time.perf_counter()
+        if from_files:
+            # (outside the phase lock: most of it is the native reader at work, without the interpreter lock)
+            b, self.call_arena = loader.fast5_run_bundle(reads)
+            if b is None:
+                return None
+            self.prebuilt = (reads, b)                    # (whoever declines from here on has the files read already)
         with phase:
-            plain = b.plain_run_columns(loader.scaler_cfg)
-            if plain is None:
-                return None
             n = len(reads)
-            first = b.index.get(reads[0], -1)
-            if first < 0 or b.keys[first:first + n] != reads or not plain['ok'][first:first + n].all():
-                return None
-            if b.broken and any(key[0] in b.broken for key in reads):      # (files that exist but cannot be opened)
-                return None
+            if from_files:
+                if b.signal_status.any() or b.basecall_status.any():
+                    return None
+                first = 0
+                plain = b.plain_run_columns(loader.scaler_cfg)
+                if plain is None or not plain['ok'].all():
+                    return None
+            else:
+                plain = b.plain_run_columns(loader.scaler_cfg)
+                if plain is None:
+                    return None
+                first = b.index.get(reads[0], -1)
+                if first < 0 or b.keys[first:first + n] != reads or not plain['ok'][first:first + n].all():
+                    return None
+                if b.broken and any(key[0] in b.broken for key in reads):      # (files that exist but cannot be opened)
+                    return None
             scan = sel = None
             if loader.scan_unsplit:
                 # the window scan over the same resident batch (signal_loader.fit_scalers); a Move table of another
@@ -209,15 +237,16 @@ class SignalAnalyzer(AbstractContextManager):
                     scan = (plain['frame_first'][first:first + n], blocks, plain['frame_stride'])
             o = plain['offsets'][first:first + n + 1]
             arena, offsets, calib = b.samples_run(first, first + n), o - o[0], plain['calib'][first:first + n]
-        loader.pin_bundle()
+        if not from_files:
+            loader.pin_bundle()
         t1 = time.perf_counter()
         got = loader.records_of_run(arena, offsets, calib, scan)
         t2 = time.perf_counter()
         with phase:
             some = np.nonzero(got['unsplit'][1])[0] if scan is not None else ()
             if len(some) > n // 4:
-                # in-read adapter candidates (or failed scans) all over the call: the batch table, with the pass that has
-                # already run
+                # in-read adapter candidates (or failed scans) all over the call: the batch table, with the pass that
+                # has already run
                 results = self.finish_from_pass(reads, got, sel)
             else:
                 skip = None
@@ -287,8 +316,10 @@ class SignalAnalyzer(AbstractContextManager):
         loader = self.loader
         table = loader.table if table is None else table
         batch = _Batch(table)
+        prebuilt, self.prebuilt = self.prebuilt, None
+        prebuilt = prebuilt[1] if prebuilt is not None and prebuilt[0] is reads else None
         reads = [tuple(r) for r in reads]
-        where = loader.prepare_many(reads, table, reserve)   # bundle / FAST5 reads: column appends
+        where = loader.prepare_many(reads, table, reserve, prebuilt)   # bundle / FAST5 reads: column appends
         bulk = np.nonzero(where >= 0)[0]
         stopped = table.stopped[where[bulk]]
         for position in np.nonzero(where < 0)[0].tolist():     # everything else, read by read

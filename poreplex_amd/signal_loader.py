@@ -460,6 +460,30 @@ class NanoporeRead:
         return first, n_blocks, stride
 
 
+class CallArenas:
+    """int16 sample arenas for the per-call bundles of worker calls that read FAST5 files (SignalLoader.fast5_run_bundle):
+    a 128-read call decodes ~8 MB of samples, and memory that comes fresh from the allocator costs a page fault per
+    4 KB on the way in (0.72 -> 0.55 ms for the samples of such a call on the development host).  A call takes one,
+    gives it back when its records are down; calls on other threads find it there.  At most `keep` arenas wait."""
+
+    def __init__(self, keep=64):
+        self.free, self.keep, self.lock = [], keep, threading.Lock()
+
+    def take(self, n_samples):
+        with self.lock:
+            for k in range(len(self.free) - 1, -1, -1):          # the one given back last is the warmest
+                if len(self.free[k]) >= n_samples:
+                    return self.free.pop(k)
+            if self.free:
+                self.free.pop(0)                                  # (too small for today's calls: make room for one that fits)
+        return np.empty(max(int(n_samples) + int(n_samples) // 4, 1 << 20), dtype=np.int16)
+
+    def give(self, arena):
+        with self.lock:
+            if len(self.free) < self.keep:
+                self.free.append(arena)
+
+
 class SignalLoader:
     """Opens reads into a ReadTable and runs the GPU pass over it.  `self.table` is the
     batch the reference-style calls (prepare_loading / fit_scalers) work on; the session
@@ -485,6 +509,7 @@ class SignalLoader:
         # to the download of its records
         self._stage_lock, self._run_lock = threading.Lock(), threading.Lock()
         self._pinned = []
+        self.call_arenas = CallArenas()
 
     def clear(self):
         t = self.table
@@ -514,7 +539,7 @@ class SignalLoader:
             t.raw[row], t.pending[row] = raw, True
         return NanoporeRead(t, row)
 
-    def prepare_many(self, reads, table, reserve=None):
+    def prepare_many(self, reads, table, reserve=None, prebuilt=None):
         """Bulk form of prepare_loading: reads that live in the read bundle are one column
         append; reads that live in FAST5 files become the same columns through the native
         reader (fast5_file.Fast5Batch: metadata per file, signals and basecall text decoded on
@@ -527,7 +552,7 @@ class SignalLoader:
         if not len(reads):
             return where
         if b is None or not b.has_file(reads[0][0]):
-            return self.prepare_fast5(reads, where, table, reserve)
+            return self.prepare_fast5(reads, where, table, reserve, prebuilt)
         index, broken = b.index, b.broken
         # the usual worker batch is a run of consecutive bundle reads: one list comparison
         # instead of a dictionary lookup per read
@@ -567,12 +592,14 @@ class SignalLoader:
             except Exception:             # noqa: BLE001
                 pass
 
-    def prepare_fast5(self, reads, where, table, reserve=None):
+    def prepare_fast5(self, reads, where, table, reserve=None, prebuilt=None):
         """The FAST5 half of prepare_many.  Only when the table holds no bundle rows yet (a
-        table has one column source)."""
+        table has one column source).  `prebuilt`: the bundle fast5_run_bundle has made of exactly these reads."""
         from .fast5_file import Fast5Batch, Fast5Error, open_fast5
         if table.n or table.bundle is not None:
             return where
+        if prebuilt is not None and len(prebuilt.filenames) == len(reads):
+            return self.enter_fast5_bundle(prebuilt, prebuilt.filenames, np.arange(len(reads)), where, table)
         runs = self.fast5_runs(reads)
         if runs is not None:
             bundle = Fast5Batch.from_runs(runs).as_bundle(reserve)
@@ -667,6 +694,29 @@ class SignalLoader:
             runs.append((f, name, first, count))
             pos += count
         return runs
+
+    def fast5_run_bundle(self, reads):
+        """(bundle, arena) of a worker call that is stretches of multi-read FAST5 files in file order (fast5_runs): the
+        per-call read bundle of SignalAnalyzer.process_plain_run, its samples decoded into an arena of the loader's
+        pool (`call_arenas`: memory a call before it has touched; the caller gives it back).  (None, None): not such
+        a call."""
+        from .fast5_file import Fast5Batch
+        if self.bundle is not None and any(self.bundle.has_file(name) for name in {key[0] for key in reads}):
+            return None, None                  # (a call that mixes bundle reads and files: the general path sorts it out)
+        runs = self.fast5_runs(reads)
+        if runs is None:
+            return None, None
+        taken = []
+
+        def reserve(n_samples):
+            taken.append(self.call_arenas.take(n_samples))
+            return taken[0]
+        try:
+            return Fast5Batch.from_runs(runs).as_bundle(reserve), taken[0]
+        except BaseException:
+            if taken:
+                self.call_arenas.give(taken[0])
+            raise
 
     def enter_fast5_bundle(self, bundle, names, at, where, table):
         """Rows for the reads of a Fast5Batch bundle (request positions `at`), the length gate and the reads whose

@@ -335,6 +335,119 @@ def test_short_path_from_many_threads(crafted, monkeypatch, tmp_path):
             assert isinstance(g, list) and len(g) == len(w)
 
 
+def crafted_fast5_files(tmp_path, bundle_path, reads_per_file=37):
+    """The reads of a crafted bundle as multi-read FAST5 files under tmp_path/f5: [(filename, read_id)] in the order a
+    batch maker lists them (file by file, each file's reads in the file's own order) and the bundle index of each."""
+    from poreplex_amd.fast5_file import get_read_ids
+    from poreplex_amd.fast5_write import Fast5Writer
+    b = ReadBundle(bundle_path)
+    top = tmp_path / 'f5'
+    top.mkdir()
+    n = len(b.keys)
+    by_id = {}
+    for lo in range(0, n, reads_per_file):
+        with Fast5Writer(str(top / 'multi{:03d}.fast5'.format(lo // reads_per_file))) as w:
+            for i in range(lo, min(lo + reads_per_file, n)):
+                by_id[b.read_ids[i]] = i
+                w.add_read(b.read_ids[i], b.samples(i), b.d['calib'][i], start_time=int(b.d['start_time'][i]),
+                           channel_number=str(b.d['channel_number'][i]), run_id=str(b.d['run_id'][i]),
+                           sample_id=str(b.d['sample_id'][i]), basecall=b.basecall_of(i))
+    keys = []
+    for lo in range(0, n, reads_per_file):
+        keys += get_read_ids('multi{:03d}.fast5'.format(lo // reads_per_file), str(top))
+    assert len(keys) == n
+    return str(top), keys, np.array([by_id[r] for _, r in keys])
+
+
+@pytest.mark.parametrize('barcoding,polya,chimera', [(True, False, False), (True, True, True), (False, True, False)])
+def test_short_path_from_fast5_files_equals_the_general_path(crafted, monkeypatch, tmp_path, barcoding, polya, chimera):
+    """Worker calls whose reads live in multi-read FAST5 files (the reference's own input, no read bundle): a call
+    that is a stretch of the files' reads in file order -- across file boundaries too -- takes the short path over the
+    per-call bundle the native reader makes of it, and returns what the batch table returns; everything else (a short
+    or irregular read in the call, a shuffled call) declines AFTER the files were read, and the general path takes the
+    bundle that was built instead of reading them again."""
+    from poreplex_amd import fast5_file as F5
+    n, seed = 300, 5
+    path, rec, found, short, _ = crafted_bundle(tmp_path, n, seed)
+    top, keys, which = crafted_fast5_files(tmp_path, path)
+    cfg = default_config(inputdir=top, outputdir=str(tmp_path), barcoding=barcoding, measure_polya=polya,
+                         filter_unsplit_reads=chimera, minimum_sequence_length=10)
+    CraftedRecords.table = rec
+    first = SA.process_batch(0, keys[:1], cfg)
+    assert isinstance(first, list), first
+    assert worker_objects()['loader'].bundle is None
+    adapter = worker_objects()['ctx'].state_names.index('adapter')
+    plain = ReadBundle(path).plain_run_columns(worker_objects()['loader'].scaler_cfg)
+    ok = (plain['ok'] & plain['kmer_ok'] if chimera else plain['ok'])[which]
+    rec['seg_first'][:, adapter] = np.where(found, 40, -1)
+    rec['seg_last'][:, adapter] = np.where(found, 90, -1)
+    taken = spy_on_the_short_path(monkeypatch)
+    decodes = []
+    real_as_bundle = F5.Fast5Batch.as_bundle
+    monkeypatch.setattr(F5.Fast5Batch, 'as_bundle', lambda self, *a, **kw: decodes.append(1) or real_as_bundle(self, *a, **kw))
+    rng = np.random.default_rng(100 + seed)
+    windows = [(0, n), (30, 20)] + [(int(a), int(rng.integers(1, 90 if j < 15 else 25))) for j, a in enumerate(rng.integers(0, n - 1, 70))]
+    statuses, n_taken, arenas = set(), 0, worker_objects()['loader'].call_arenas
+    for lo, k in windows:
+        reads = keys[lo:lo + k]
+        monkeypatch.setattr(SA, '_PLAIN_RUN', True)
+        del taken[:], decodes[:]
+        fast = SA.process_batch(1, list(reads), cfg)
+        took = taken == [True]
+        assert decodes == [1], (lo, k, decodes)              # the files are read once, whichever path reports
+        monkeypatch.setattr(SA, '_PLAIN_RUN', False)
+        general = SA.process_batch(1, list(reads), cfg)
+        assert isinstance(general, list), general
+        assert took == bool(ok[lo:lo + k].all()), (lo, k)
+        same(fast, general, 'reads[{}:{}]'.format(lo, lo + k))
+        if took:
+            n_taken += 1
+            statuses |= {r['status'] for r in fast}
+    assert n_taken >= 12
+    assert statuses - {'unsplit_read'} == {'okay', 'scaling_qc_fail', 'adapter_not_detected', 'not_basecalled',
+                                           'sequence_too_short'}
+    assert 1 <= len(arenas.free) <= 2                         # the calls took turns with the same sample arena
+    # a shuffled call is not a run: the general path, as before
+    monkeypatch.setattr(SA, '_PLAIN_RUN', True)
+    del taken[:]
+    back = SA.process_batch(2, list(reversed(keys[40:60])), cfg)
+    monkeypatch.setattr(SA, '_PLAIN_RUN', False)
+    same(back, SA.process_batch(2, list(reversed(keys[40:60])), cfg))
+    assert taken == [False]
+    # and with PXG_NO_PLAIN_RUN_FAST5 only bundle reads take the short path
+    monkeypatch.setattr(SA, '_PLAIN_RUN', True)
+    monkeypatch.setattr(SA, '_PLAIN_RUN_FAST5', False)
+    run = next((lo, k) for lo, k in windows[1:] if ok[lo:lo + k].all())
+    del taken[:]
+    SA.process_batch(3, list(keys[run[0]:run[0] + run[1]]), cfg)
+    assert taken == [False]
+
+
+def test_short_path_from_fast5_files_on_many_threads(crafted, monkeypatch, tmp_path):
+    """Calls over FAST5 files from worker threads that share the loader: each gets the dicts of its own reads, and the
+    sample arenas go round."""
+    from concurrent.futures import ThreadPoolExecutor
+    path, rec, found, short, _ = crafted_bundle(tmp_path, 300, 13)
+    top, keys, which = crafted_fast5_files(tmp_path, path, reads_per_file=64)
+    CraftedRecords.table = rec
+    cfg = default_config(inputdir=top, outputdir=str(tmp_path), barcoding=True, measure_polya=True, minimum_sequence_length=10)
+    assert isinstance(SA.process_batch(0, keys[:1], cfg), list)
+    adapter = worker_objects()['ctx'].state_names.index('adapter')
+    rec['seg_first'][:, adapter] = np.where(found, 40, -1)
+    rng = np.random.default_rng(6)
+    windows = [(int(a), int(rng.integers(1, 50))) for a in rng.integers(0, 299, 150)]
+    monkeypatch.setattr(SA, '_PLAIN_RUN', False)
+    want = [SA.process_batch(k, keys[lo:lo + k_], cfg) for k, (lo, k_) in enumerate(windows)]
+    monkeypatch.setattr(SA, '_PLAIN_RUN', True)
+    taken = spy_on_the_short_path(monkeypatch)
+    with ThreadPoolExecutor(8) as pool:
+        got = list(pool.map(lambda kw: SA.process_batch(kw[0], keys[kw[1][0]:kw[1][0] + kw[1][1]], cfg), enumerate(windows)))
+    assert sum(taken) > 20
+    for g, w in zip(got, want):
+        same(g, w)
+    assert 1 <= len(worker_objects()['loader'].call_arenas.free) <= 8
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('polya,chimera', [(False, False), (True, False), (True, True)])
 def test_short_path_equals_the_general_path_on_the_gpu(monkeypatch, tmp_path, polya, chimera):
@@ -365,6 +478,76 @@ def test_short_path_equals_the_general_path_on_the_gpu(monkeypatch, tmp_path, po
         with ThreadPoolExecutor(6) as pool:
             again = list(pool.map(lambda lo: SA.process_batch(9, keys[lo:lo + 128], cfg), list(range(0, n, 128)) * 4))
         same(again, want * 4)
+    finally:
+        WorkerPersistenceStorage.reset()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('polya,chimera,compression', [(False, False, None), (True, True, None), (True, False, 'vbz')])
+def test_short_path_from_fast5_files_on_the_gpu(monkeypatch, tmp_path, polya, chimera, compression):
+    """128-read calls over multi-read FAST5 files with the real context (no read bundle): the short path over the
+    per-call bundle, its samples in a recycled arena that is NOT page-locked (the library's bounded chunks carry them),
+    against the batch table -- one call at a time and from threads -- and against the same reads served from a read
+    bundle."""
+    from concurrent.futures import ThreadPoolExecutor
+    from poreplex_amd.fast5_file import get_read_ids
+    from poreplex_amd.fast5_write import Fast5Writer, vbz_encode
+    from poreplex_amd.synth import synth_basecalls, synth_batch
+    if compression == 'vbz':
+        try:
+            vbz_encode(np.zeros(8, np.int16))
+        except OSError as exc:
+            pytest.skip('no libzstd on this host: {}'.format(exc))
+    n = 384
+    sb = synth_batch(n, seed=37, samples_per_read=20000)
+    bcs = synth_basecalls(sb, seed=37)
+    ids = ['{:08x}-0000-4000-8000-{:012x}'.format(37, i) for i in range(n)]
+    top = tmp_path / 'f5'
+    top.mkdir()
+    o = sb['offsets']
+    for lo in range(0, n, 150):                              # calls cross file boundaries
+        with Fast5Writer(str(top / 'm{}.fast5'.format(lo // 150))) as w:
+            for j in range(lo, min(lo + 150, n)):
+                w.add_read(ids[j], sb['arena'][o[j]:o[j + 1]], sb['calib'][j], start_time=j, channel_number=str(1 + j % 512),
+                           basecall=bcs[j], compression=compression)
+    keys = []
+    for lo in range(0, n, 150):
+        keys += get_read_ids('m{}.fast5'.format(lo // 150), str(top))
+    order = [ids.index(r) for _, r in keys]
+    cfg = default_config(inputdir=str(top), outputdir=str(tmp_path), barcoding=True, measure_polya=polya,
+                         filter_unsplit_reads=chimera)
+    WorkerPersistenceStorage.reset()
+    try:
+        monkeypatch.setattr(SA, '_PLAIN_RUN', False)
+        want = [SA.process_batch(k, keys[lo:lo + 128], cfg) for k, lo in enumerate(range(0, n, 128))]
+        assert all(isinstance(w, list) for w in want), want
+        monkeypatch.setattr(SA, '_PLAIN_RUN', True)
+        taken = spy_on_the_short_path(monkeypatch)
+        got = [SA.process_batch(k, keys[lo:lo + 128], cfg) for k, lo in enumerate(range(0, n, 128))]
+        assert taken == [True] * 3
+        same(got, want)
+        assert {r['status'] for w in want for r in w} >= {'okay'}
+        with ThreadPoolExecutor(6) as pool:
+            again = list(pool.map(lambda lo: SA.process_batch(9, keys[lo:lo + 128], cfg), list(range(0, n, 128)) * 4))
+        same(again, want * 4)
+        assert 1 <= len(worker_objects()['loader'].call_arenas.free) <= 6
+    finally:
+        WorkerPersistenceStorage.reset()
+    # the same reads from a read bundle: the records do not depend on where the samples came from
+    path = str(tmp_path / 'same.pxr.npz')
+    names = ['x/r{:05d}.fast5'.format(i) for i in range(n)]
+    write_bundle(path, sb['arena'], sb['offsets'], sb['calib'], names, ids, basecalls=bcs,
+                 start_time=np.arange(n), channel_number=np.array([str(1 + j % 512) for j in range(n)]))
+    try:
+        from_bundle = SA.process_batch(0, list(zip(names, ids)), dict(cfg, inputdir=str(tmp_path), read_bundle=path))
+        assert isinstance(from_bundle, list), from_bundle
+        by_id = {r['read_id']: r for r in from_bundle}
+        for w in want:
+            for r in w:
+                other = dict(by_id[r['read_id']], filename=r['filename'])
+                assert {k: v for k, v in other.items() if k not in ('run_id', 'sample_id')} == \
+                    {k: v for k, v in r.items() if k not in ('run_id', 'sample_id')}, r['read_id']
+        assert order
     finally:
         WorkerPersistenceStorage.reset()
 

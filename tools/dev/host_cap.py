@@ -73,9 +73,14 @@ def main():
     ap.add_argument('--full', action='store_true',
                     help='configs[3]-shaped calls (poly(A) + chimera scan), one at a time, no sleep: Python per read')
     ap.add_argument('--candidates-every', type=int, default=0, help='--full: every n-th read has a chimera candidate')
+    ap.add_argument('--fast5', choices=('none', 'vbz'), default=None,
+                    help='the calls read a multi-read FAST5 file (the reference\'s real input) instead of a read bundle')
+    ap.add_argument('--file-reads', type=int, default=4000, help='--fast5: reads in the file the calls walk through')
     args = ap.parse_args()
     if args.full:
         return full_calls(args)
+    if args.fast5:
+        return fast5_calls(args)
     n = args.reads
     sb = synth_batch(n, seed=924, samples_per_read=20000)
     work = tempfile.mkdtemp(prefix='pxg_hostcap_')
@@ -112,6 +117,58 @@ def main():
             with ThreadPoolExecutor(threads) as pool:
                 t0 = time.perf_counter()
                 list(pool.map(lambda k: len(SA.process_batch(100 + k, reads, cfg)), range(args.calls)))
+                rates.append(args.calls / (time.perf_counter() - t0))
+        print('%2d threads: best %5.0f calls/s = %6.0f reads/s (%.3f ms of wall clock per call); all: %s'
+              % (threads, max(rates), max(rates) * n, 1e3 / max(rates), ' '.join('%.0f' % r for r in rates)))
+    WorkerPersistenceStorage.reset()
+
+
+def fast5_calls(args):
+    """Reference-sized calls over a multi-read FAST5 file: consecutive 128-read slices of its read list, as the
+    reference's batch maker hands them out (commandline.py:398-402)."""
+    from poreplex_amd.fast5_write import Fast5Writer
+    n, total = args.reads, args.file_reads
+    sb = synth_batch(total, seed=924, samples_per_read=20000)
+    bcs = synth_basecalls(sb, seed=924)
+    work = tempfile.mkdtemp(prefix='pxg_hostcap_')
+    ids = ['%08x-0000-4000-8000-%012x' % (924, i) for i in range(total)]
+    o = sb['offsets']
+    with Fast5Writer(os.path.join(work, 'run.fast5')) as w:
+        for j in range(total):
+            w.add_read(ids[j], sb['arena'][o[j]:o[j + 1]], sb['calib'][j], start_time=j, channel_number=str(1 + j % 512),
+                       basecall=bcs[j], compression=None if args.fast5 == 'none' else args.fast5)
+    cfg = default_config(inputdir=work, outputdir=work, barcoding=True)
+    SleepingContext.gpu_ms = args.gpu_ms
+    N.NativeContext = SleepingContext
+    WorkerPersistenceStorage.reset()
+    rng = np.random.default_rng(924)
+    rec = np.zeros(n, dtype=N.RESULT_DTYPE)
+    adapter = N.NativeConfig(cfg).state_names.index('adapter')
+    rec['seg_first'], rec['seg_last'] = -1, -1
+    rec['seg_first'][:, adapter], rec['seg_last'][:, adapter] = np.where(rng.random(n) < 0.95, 30, -1), 80
+    rec['scale'], rec['shift'] = 1.0, 0.0
+    rec['bc_pushed'], rec['bc_called'] = rng.random(n) < 0.95, rng.random(n) < 0.8
+    rec['bc_label'], rec['bc_phred'] = rng.integers(0, 4, n), rng.integers(10, 50, n)
+    SleepingContext.records = rec
+    calls = [[('run.fast5', r) for r in ids[k:k + n]] for k in range(0, total - n + 1, n)]
+    first = SA.process_batch(0, calls[0], cfg)
+    assert isinstance(first, list) and len(first) == n, first
+    print('FAST5 (%s), %d calls of %d reads; path: %s' % (args.fast5, len(calls), n,
+          'batch table (PXG_NO_PLAIN_RUN)' if not SA._PLAIN_RUN else 'plain run where it applies'))
+    best = 1e9
+    for _ in range(max(args.repeats, 3)):
+        t0 = time.perf_counter()
+        for k, reads in enumerate(calls):
+            SA.process_batch(1 + k, reads, cfg)
+        best = min(best, (time.perf_counter() - t0) / len(calls))
+    print('one call at a time: %.3f ms per call, %.1f ms of it the sleep -> %.3f ms of host work per %d-read call '
+          '(plain-run calls so far: %d)' % (best * 1e3, args.gpu_ms, best * 1e3 - args.gpu_ms, n, SA.PLAIN_RUN_CALLS))
+    for threads in (8, 32):
+        rates = []
+        for _ in range(args.repeats):
+            with ThreadPoolExecutor(threads) as pool:
+                t0 = time.perf_counter()
+                list(pool.map(lambda k: len(SA.process_batch(100 + k, calls[k % len(calls)], cfg)), range(args.calls)))
                 rates.append(args.calls / (time.perf_counter() - t0))
         print('%2d threads: best %5.0f calls/s = %6.0f reads/s (%.3f ms of wall clock per call); all: %s'
               % (threads, max(rates), max(rates) * n, 1e3 / max(rates), ' '.join('%.0f' % r for r in rates)))
