@@ -464,24 +464,44 @@ class CallArenas:
     """int16 sample arenas for the per-call bundles of worker calls that read FAST5 files (SignalLoader.fast5_run_bundle):
     a 128-read call decodes ~8 MB of samples, and memory that comes fresh from the allocator costs a page fault per
     4 KB on the way in (0.72 -> 0.55 ms for the samples of such a call on the development host).  A call takes one,
-    gives it back when its records are down; calls on other threads find it there.  At most `keep` arenas wait."""
+    gives it back when its records are down; calls on other threads find it there.  At most `keep` arenas wait.
+    With `ctx` (PXG_PIN_CALL_ARENAS=1, an experiment that has not been on a GPU yet: off by default) the arenas are
+    mappings of their own, page-locked once, so a call's samples cross PCIe as one DMA transfer instead of through the
+    context's 8 MB chunks; release() takes the page locks off."""
 
-    def __init__(self, keep=64):
+    def __init__(self, keep=64, ctx=None):
         self.free, self.keep, self.lock = [], keep, threading.Lock()
+        self.ctx, self.locked = ctx, []
 
     def take(self, n_samples):
         with self.lock:
             for k in range(len(self.free) - 1, -1, -1):          # the one given back last is the warmest
                 if len(self.free[k]) >= n_samples:
                     return self.free.pop(k)
-            if self.free:
+            if self.free and self.ctx is None:
                 self.free.pop(0)                                  # (too small for today's calls: make room for one that fits)
-        return np.empty(max(int(n_samples) + int(n_samples) // 4, 1 << 20), dtype=np.int16)
+        size = max(int(n_samples) + int(n_samples) // 4, 1 << 20)
+        if self.ctx is None:
+            return np.empty(size, dtype=np.int16)
+        arena = native.page_exclusive(size, np.int16)
+        self.ctx.pin(arena)
+        with self.lock:
+            self.locked.append(arena)
+        return arena
 
     def give(self, arena):
         with self.lock:
-            if len(self.free) < self.keep:
+            if len(self.free) < self.keep or self.ctx is not None:      # (a page-locked arena is never just dropped)
                 self.free.append(arena)
+
+    def release(self):
+        with self.lock:
+            locked, self.locked, self.free = self.locked, [], []
+        for arena in locked:
+            try:
+                self.ctx.unpin(arena)
+            except Exception:             # noqa: BLE001  (the context is on its way out)
+                pass
 
 
 class SignalLoader:
@@ -509,7 +529,7 @@ class SignalLoader:
         # to the download of its records
         self._stage_lock, self._run_lock = threading.Lock(), threading.Lock()
         self._pinned = []
-        self.call_arenas = CallArenas()
+        self.call_arenas = CallArenas(ctx=ctx if os.environ.get('PXG_PIN_CALL_ARENAS') and hasattr(ctx, 'pin') else None)
 
     def clear(self):
         t = self.table
@@ -860,6 +880,7 @@ class SignalLoader:
             self._pinned = pinned
 
     def unpin_bundle(self):
+        self.call_arenas.release()
         pinned, self._pinned = self._pinned, []
         for a in pinned:
             self.ctx.unpin(a)

@@ -76,6 +76,8 @@ def main():
     ap.add_argument('--fast5', choices=('none', 'vbz'), default=None,
                     help='the calls read a multi-read FAST5 file (the reference\'s real input) instead of a read bundle')
     ap.add_argument('--file-reads', type=int, default=4000, help='--fast5: reads in the file the calls walk through')
+    ap.add_argument('--real', action='store_true',
+                    help='--fast5: the real GPU context instead of the sleeping stand-in (on the GPU box: the figure itself)')
     args = ap.parse_args()
     if args.full:
         return full_calls(args)
@@ -139,7 +141,8 @@ def fast5_calls(args):
                        basecall=bcs[j], compression=None if args.fast5 == 'none' else args.fast5)
     cfg = default_config(inputdir=work, outputdir=work, barcoding=True)
     SleepingContext.gpu_ms = args.gpu_ms
-    N.NativeContext = SleepingContext
+    if not args.real:
+        N.NativeContext = SleepingContext
     WorkerPersistenceStorage.reset()
     rng = np.random.default_rng(924)
     rec = np.zeros(n, dtype=N.RESULT_DTYPE)
@@ -153,7 +156,7 @@ def fast5_calls(args):
     calls = [[('run.fast5', r) for r in ids[k:k + n]] for k in range(0, total - n + 1, n)]
     first = SA.process_batch(0, calls[0], cfg)
     assert isinstance(first, list) and len(first) == n, first
-    print('FAST5 (%s), %d calls of %d reads; path: %s' % (args.fast5, len(calls), n,
+    print('%s; FAST5 (%s), %d calls of %d reads; path: %s' % ('REAL context' if args.real else 'sleeping stand-in', args.fast5, len(calls), n,
           'batch table (PXG_NO_PLAIN_RUN)' if not SA._PLAIN_RUN else 'plain run where it applies'))
     best = 1e9
     for _ in range(max(args.repeats, 3)):
