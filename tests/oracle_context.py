@@ -152,3 +152,29 @@ class OracleBackedContext:
 
     def close(self):
         pass
+
+
+class OneCallOracleContext(OracleBackedContext):
+    """The double with the ONE-CALL form of a worker batch (native.NativeContext.process_batch_ex: stage, swap, run,
+    downloads and the window scan behind one call), so that the CPU suite drives the host code the way the GPU does:
+    SignalLoader.fit_scalers' first branch and SignalAnalyzer.process_plain_run with the chimera scan on."""
+
+    calls = 0
+
+    def process_batch_ex(self, samples, offsets, calib, stage_mask=N.STAGE_ALL_DEMUX, scale_shift=None, unsplit=None,
+                         want_spikes=False):
+        import threading
+        lock = self.__dict__.setdefault('_one_call', threading.Lock())
+        with lock:                                    # (the double keeps ONE resident batch)
+            type(self).calls += 1
+            if isinstance(samples, N.EncodedSamples):
+                samples = samples.decode()
+            self.upload(np.array(samples, dtype=np.int16), np.array(offsets, dtype=np.int64), np.array(calib), scale_shift)
+            self.run(stage_mask)
+            out = {'records': np.array(self.download())}
+            if want_spikes:
+                out['spikes'] = self.download_spikes(out['records'])
+            if unsplit is not None:
+                out['unsplit'] = self.unsplit_scan(np.asarray(unsplit[0]), np.asarray(unsplit[1]), int(unsplit[2]))
+            return out
+

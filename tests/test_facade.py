@@ -58,7 +58,7 @@ def compare_results(got, want, check_polya):
             assert g[k] == w[k], (g.get('read_id'), k, g[k], w[k])
 
 
-from oracle_context import OracleBackedContext  # noqa: E402  (tests/oracle_context.py)
+from oracle_context import OneCallOracleContext, OracleBackedContext  # noqa: E402  (tests/oracle_context.py)
 
 
 @pytest.fixture()
@@ -66,6 +66,18 @@ def oracle_backed(monkeypatch):
     WorkerPersistenceStorage.reset()
     monkeypatch.setattr(N, 'NativeContext', OracleBackedContext)
     yield
+    WorkerPersistenceStorage.reset()
+
+
+@pytest.fixture()
+def one_call_double(monkeypatch):
+    """The double that answers a worker batch in ONE call, as the library does: the host code then takes the branches
+    it takes on the GPU (fit_scalers' one-call form; the plain-run path with the chimera scan on)."""
+    WorkerPersistenceStorage.reset()
+    monkeypatch.setattr(N, 'NativeContext', OneCallOracleContext)
+    before = OneCallOracleContext.calls
+    yield
+    assert OneCallOracleContext.calls > before
     WorkerPersistenceStorage.reset()
 
 
@@ -443,6 +455,70 @@ def test_filter_unsplit_reads_host_logic_vs_reference(oracle_backed, arith):
     ref, cfg = chimera_case()
     assert cfg['filter_unsplit_reads']
     check_chimera(process_batch(ref['batchid'], [tuple(r) for r in ref['reads']], cfg), ref)
+
+
+def test_filter_unsplit_reads_one_call_form_vs_reference(one_call_double, arith, monkeypatch):
+    """The same batch the way the GPU context serves it -- records, spike rows and scan candidates from one call --:
+    as one worker call (a plain run of bundle reads with candidates in some of them: a table of just those beside the C
+    pass), in reference-sized slices, and with everything on the batch table."""
+    from poreplex_amd import signal_analyzer as SA
+    ref, cfg = chimera_case()
+    reads = [tuple(r) for r in ref['reads']]
+    before = SA.PLAIN_RUN_CALLS
+    check_chimera(SA.process_batch(ref['batchid'], reads, cfg), ref)
+    parts = []
+    for lo in range(0, len(reads), 5):
+        parts += SA.process_batch(ref['batchid'], reads[lo:lo + 5], cfg)
+    check_chimera(parts, ref)
+    if SA._PLAIN_RUN and N.load_pyhost() is not None:
+        assert SA.PLAIN_RUN_CALLS > before
+    monkeypatch.setattr(SA, '_PLAIN_RUN', False)
+    check_chimera(SA.process_batch(ref['batchid'], reads, cfg), ref)
+    monkeypatch.setattr(SA, '_BULK_UNSPLIT', False)
+    check_chimera(SA.process_batch(ref['batchid'], reads, cfg), ref)
+
+
+def test_golden_batch_one_call_form_vs_reference(one_call_double, ref_results, tmp_path):
+    """The golden batch through the one-call double: from the bundle, and from FAST5 files."""
+    from poreplex_amd.signal_analyzer import process_batch
+    reads = [tuple(r) for r in ref_results['reads']]
+    compare_results(process_batch(ref_results['batchid'], reads, facade_config(ref_results)), ref_results['results'],
+                    check_polya=True)
+    WorkerPersistenceStorage.reset()
+    golden_batch_as_fast5(str(tmp_path), ref_results)
+    cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path / 'out'), **dict(ref_results['config_flags']))
+    compare_results(process_batch(ref_results['batchid'], reads, cfg), ref_results['results'], check_polya=True)
+
+
+def test_filter_unsplit_reads_from_multi_read_fast5_one_call_form(one_call_double, tmp_path, arith):
+    """--filter-chimera with the chimera batch as ONE multi-read FAST5 file, served in the file's own read order in
+    reference-sized calls: the plain-run path over per-call bundles with the scan on (what an unchanged caller of the
+    GPU build gets), against the real reference's verdicts read by read."""
+    from poreplex_amd import signal_analyzer as SA
+    from poreplex_amd.fast5_file import ReadBundle, get_read_ids
+    from poreplex_amd.fast5_write import Fast5Writer
+    ref, _ = chimera_case()
+    b = ReadBundle(chimera_bundle())
+    with Fast5Writer(str(tmp_path / 'all.fast5')) as w:
+        for i in range(len(b.read_ids)):
+            bc = b.basecall_of(i)
+            if bc is not None:
+                bc['move'] = np.asarray(bc['move'], dtype=np.uint8)
+            w.add_read(b.read_ids[i], b.samples(i), b.d['calib'][i], start_time=int(b.d['start_time'][i]),
+                       channel_number=str(b.d['channel_number'][i]), run_id=str(b.d['run_id'][i]),
+                       sample_id=str(b.d['sample_id'][i]), basecall=bc)
+    keys = get_read_ids('all.fast5', str(tmp_path))
+    cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path / 'out'), **ref['config_flags'])
+    want = {r['read_id']: r for r in ref['results']}
+    before = SA.PLAIN_RUN_CALLS
+    got = []
+    for lo in range(0, len(keys), 7):
+        got += SA.process_batch(ref['batchid'], keys[lo:lo + 7], cfg)
+    assert len(got) == len(want)
+    compare_results(got, [dict(want[r['read_id']], filename='all.fast5') for r in got], check_polya=True)
+    assert sum(r['status'] == 'unsplit_read' for r in got) >= 5
+    if SA._PLAIN_RUN and N.load_pyhost() is not None:
+        assert SA.PLAIN_RUN_CALLS > before
 
 
 def chimera_from_fast5(tmp_path):
