@@ -479,6 +479,88 @@ def process_batch_leg(args, base, which, lo, mask, local_rank, compressed, resid
         shutil.rmtree(work, ignore_errors=True)
 
 
+def fast5_calls_leg(args, base, which, lo, mask, local_rank, resident_records, n=128, file_reads=1024, threads=32,
+                    calls=256):
+    """The reference's batch size over the reference's INPUT: `file_reads` reads of the batch in one multi-read FAST5
+    file (no read bundle), served as consecutive `n`-read process_batch calls in the file's read order -- one at a time
+    and from `threads` worker threads that share the context.  Every call opens its reads through the native reader
+    (a per-call bundle: SignalLoader.fast5_run_bundle), copies the samples to the GPU, runs every stage and builds the
+    dicts; the dicts of the first pass are checked against the records of the resident loop."""
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from poreplex_amd import signal_analyzer as SA
+    from poreplex_amd.fast5_file import get_read_ids
+    from poreplex_amd.fast5_write import Fast5Writer
+    from poreplex_amd.synth import synth_basecalls
+    from poreplex_amd.worker_persistence import WorkerPersistenceStorage
+    work = tempfile.mkdtemp(prefix='pxg_api_f5_')
+    try:
+        total = min(file_reads, len(which)) // n * n
+        if total < n:
+            raise N.PxgError('fewer than {} reads in the batch'.format(n))
+        o = base['offsets']
+        raws = [base['arena'][o[b]:o[b + 1]] for b in which[:total]]
+        bcs = synth_basecalls({'offsets': np.concatenate([[0], np.cumsum([len(r) for r in raws])])}, seed=args.seed)
+        ids = ['{:08x}-0000-4000-8000-{:012x}'.format(args.seed, lo + j) for j in range(total)]
+        t0 = time.perf_counter()
+        with Fast5Writer(os.path.join(work, 'run.fast5')) as w:
+            for j in range(total):
+                w.add_read(ids[j], raws[j], base['calib'][which[j]], start_time=j, channel_number=str(1 + j % 512),
+                           basecall=bcs[j])
+        t_write = time.perf_counter() - t0
+        cfg = default_config(inputdir=work, outputdir=work, barcoding=bool(mask & N.STAGE_BARCODE),
+                             measure_polya=bool(mask & N.STAGE_POLYA),
+                             filter_unsplit_reads=args.workload in ('chimera', 'full'), device_id=local_rank)
+        keys = get_read_ids('run.fast5', work)
+        slices = [keys[k:k + n] for k in range(0, total, n)]
+        WorkerPersistenceStorage.reset()
+        first = [SA.process_batch(k, reads, cfg) for k, reads in enumerate(slices)]     # context + file open: once per worker
+        bad = [r for r in first if isinstance(r, tuple)]
+        if bad:
+            raise N.PxgError('process_batch failed: {}'.format(bad[0][1]))
+        plain_before = SA.PLAIN_RUN_CALLS
+        t0 = time.perf_counter()
+        for k, reads in enumerate(slices):
+            SA.process_batch(100 + k, reads, cfg)
+        serial = total / (time.perf_counter() - t0)
+        failed = []
+
+        def one_call(k):
+            r = SA.process_batch(200 + k, slices[k % len(slices)], cfg)
+            if isinstance(r, tuple) or len(r) != n:
+                failed.append(r)
+            return k
+        with ThreadPoolExecutor(threads) as pool:
+            t0 = time.perf_counter()
+            list(pool.map(one_call, range(calls)))
+            wall = time.perf_counter() - t0
+        if failed:
+            raise N.PxgError('process_batch failed: {}'.format(failed[0][1] if isinstance(failed[0], tuple) else 'short result'))
+        out = {'reads_per_s': calls * n / wall, 'one_call_at_a_time_reads_per_s': serial, 'calls': calls, 'threads': threads,
+               'reads_per_call': n, 'reads_in_the_file': total, 'file_MB': round(os.path.getsize(os.path.join(work, 'run.fast5')) / 1e6, 1),
+               'file_write_s': round(t_write, 2), 'compression': 'none',
+               'calls_on_the_plain_run_path': SA.PLAIN_RUN_CALLS - plain_before, 'timed_calls': len(slices) + calls}
+        if resident_records is not None and len(resident_records) >= total:
+            at = {r: j for j, r in enumerate(ids)}
+            st = [N.STATUS_NAMES[c] for c in resident_records['status'][:total].tolist()]
+            called, label = resident_records['bc_called'][:total].tolist(), resident_records['bc_label'][:total].tolist()
+            diff = 0
+            for part in first:
+                for r in part:
+                    j = at[r['read_id']]
+                    if st[j] != 'okay':
+                        diff += int(r['status'] != st[j])
+                    else:
+                        diff += int(r['status'] in ('scaler_signal_too_short', 'scaling_qc_fail'))
+                    diff += int(r.get('barcode') != (label[j] if called[j] else None))
+            out['barcode_or_status_mismatch_vs_resident_records'] = diff
+        WorkerPersistenceStorage.reset()
+        return out
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def worker_processes_leg(args, base, which, lo, mask, local_rank, workers=(8, 16), calls_per_worker=40, n=128):
     """The reference's OWN call pattern for its per-read processor (pipeline.py:96,193-205): a ProcessPoolExecutor of
     `parallel` worker processes, each running process_batch(batchid, reads, config) on 128-read batches
@@ -1540,6 +1622,10 @@ def main():
                 small.in_flight, small.api_calls = 32, 320
                 api['reference_batch_size_128'] = process_batch_leg(small, base, which[:128], lo, mask, local_rank, False, res[:128])
                 extra['process_batch_128_read_calls_reads_per_s'] = api['reference_batch_size_128']['reads_per_s']
+                try:            # ... and over the reference's input: the reads in a multi-read FAST5 file, no bundle
+                    api['reference_batch_size_128']['from_fast5'] = fast5_calls_leg(args, base, which, lo, mask, local_rank, res)
+                except Exception as exc:                   # reported, never hidden
+                    api['reference_batch_size_128']['from_fast5'] = {'error': '{}: {}'.format(type(exc).__name__, exc)}
                 if not args.no_worker_processes_leg:
                     try:
                         api['reference_batch_size_128']['worker_processes'] = worker_processes_leg(args, base, which, lo, mask, local_rank)
@@ -1645,7 +1731,9 @@ def main():
                                                        'calls_on_the_plain_run_path': r128.get('calls_on_the_plain_run_path'),
                                                        'barcode_or_status_mismatch_vs_resident_records':
                                                            r128.get('barcode_or_status_mismatch_vs_resident_records'),
-                                                       'worker_processes': r128.get('worker_processes')}
+                                                       'worker_processes': r128.get('worker_processes'),
+                                                       # the same calls with the reads in a multi-read FAST5 file (no bundle)
+                                                       'from_fast5': r128.get('from_fast5')}
             roofline['latency_form'] = lat
         except Exception as exc:                       # reported, never hidden
             roofline['latency_form'] = {'error': '{}: {}'.format(type(exc).__name__, exc)}
