@@ -1648,7 +1648,8 @@ extern "C" int pxg_h5_basecall_many(int64_t n, const pxg_h5* const* files, const
 {
     if (n < 0 || (n && (!files || !index || !seq_start || !seq_len || !move_start || !n_moves || !status)))
         return PXG_E_INVALID;
-    run_pool(n, threads, [&](int64_t k) {
+    // (a few KB of text per read: a reference-sized call's worth is cheaper copied than handed to other threads)
+    run_pool(n, n <= 256 ? 1 : threads, [&](int64_t k) {
         status[k] = PXG_OK;
         if (seq_len[k] <= 0 && n_moves[k] <= 0) return;
         try {

@@ -424,6 +424,16 @@ static PyObject* report_run(PyObject* self, PyObject* args)
     }
     PyObject *filenames = get_list(cols, "filenames", 0), *read_ids = get_list(cols, "read_ids", 0);
     if (!filenames || !read_ids) goto done;
+    /* `seq_base`: the text arenas hold the reads of THIS call only (a run of a FAST5 file whose other columns describe the
+     * whole file, fast5_file.FileRunColumns): sequence offsets count from the run's first read */
+    long long seq_base = 0;
+    {
+        PyObject* sb = PyDict_GetItemString(cols, "seq_base");           /* borrowed */
+        if (sb && sb != Py_None) {
+            seq_base = PyLong_AsLongLong(sb);
+            if (seq_base == -1 && PyErr_Occurred()) goto done;
+        }
+    }
     out = PyList_New(n);
     if (!out) goto done;
     {
@@ -479,7 +489,7 @@ static PyObject* report_run(PyObject* self, PyObject* args)
                 SET(d, KEYS[K_SEQUENCE_LENGTH], PyLong_FromLongLong(((const int64_t*)seq_len.view.buf)[b]));
                 /* the table keeps the summary's float32 in a float64 column */
                 SET(d, KEYS[K_MEAN_QSCORE], PyFloat_FromDouble((double)(float)((const double*)qscore.view.buf)[b]));
-                const int64_t lo = so[b], hi = so[b + 1];
+                const int64_t lo = so[b] - seq_base, hi = so[b + 1] - seq_base;
                 if (lo < 0 || hi < lo || hi > seq_arena.view.len || hi > qual_arena.view.len) {
                     PyErr_SetString(PyExc_IndexError, "report_run: sequence offsets outside the arena");
                     goto fail_row;
@@ -533,7 +543,100 @@ done:
     return out;
 }
 
+/* ---- decode_and_run: the two native halves of a worker call over FAST5 files behind ONE release of the interpreter lock ----
+ *
+ * A reference-sized call (128 reads) over FAST5 files is three native calls with a little Python between them -- the
+ * samples (pxg_h5_load_signals), the basecall text (pxg_h5_basecall_many), the GPU pass (pxg_process_batch_ex) -- and
+ * every return from one of them queues for the interpreter lock again: from three worker threads on, the calls spend
+ * more time waiting for it than working (tools/dev/host_cap.py --fast5: 700 calls/s with two threads, 500 with eight).
+ * Here the three run back to back without the lock.  The functions come as ADDRESSES (this module links neither library;
+ * native.py takes them from the libraries it has loaded) and are called through the prototypes of include/pxg.h; the
+ * arrays come through the buffer protocol and stay exported for the duration of the call.
+ *
+ *   decode_and_run(load_signals, basecall_many, run_or_0, threads,
+ *                  files, index, dst_start, n_samples, arena, signal_status,
+ *                  seq_start, seq_len, seq_arena, qual_arena, move_start, n_moves, move_arena, basecall_status,
+ *                  ctx, offsets, calib, stage_mask, extras_address, records) -> (decoded, rc)
+ *
+ * decoded: every read's samples and text arrived (both status arrays all zero); only then is the pass run.  rc: what
+ * pxg_process_batch_ex returned, None when it was not called (run_or_0 == 0, or not decoded). */
+typedef __typeof__(&pxg_h5_load_signals) load_signals_fn;
+typedef __typeof__(&pxg_h5_basecall_many) basecall_many_fn;
+typedef __typeof__(&pxg_process_batch_ex) run_batch_fn;
+
+static PyObject* decode_and_run(PyObject* self, PyObject* args)
+{
+    unsigned long long a_signals, a_text, a_run, a_ctx, a_extras;
+    int threads;
+    unsigned int stage_mask;
+    Py_buffer files, index, dst_start, n_samples, arena, sig_status, seq_start, seq_len, seq_arena, qual_arena, move_start,
+        n_moves, move_arena, bc_status, offsets, calib, records;
+    if (!PyArg_ParseTuple(args, "KKKiy*y*y*y*w*w*y*y*w*w*y*y*w*w*Ky*y*IKw*", &a_signals, &a_text, &a_run, &threads, &files, &index,
+                          &dst_start, &n_samples, &arena, &sig_status, &seq_start, &seq_len, &seq_arena, &qual_arena,
+                          &move_start, &n_moves, &move_arena, &bc_status, &a_ctx, &offsets, &calib, &stage_mask, &a_extras,
+                          &records))
+        return NULL;
+    Py_buffer* all[] = { &files, &index, &dst_start, &n_samples, &arena, &sig_status, &seq_start, &seq_len, &seq_arena,
+                         &qual_arena, &move_start, &n_moves, &move_arena, &bc_status, &offsets, &calib, &records };
+    PyObject* out = NULL;
+    const Py_ssize_t n = index.len / 8;
+    int64_t need_samples = 0, need_text = 0, need_moves = 0;
+    /* every array has a row per read, and the arenas hold what the layout says (the native readers trust the layout) */
+    if (!a_signals || !a_text || files.len != n * (Py_ssize_t)sizeof(void*) || index.len != n * 8 || dst_start.len != n * 8 ||
+        n_samples.len != n * 8 || sig_status.len != n * 4 || seq_start.len != n * 8 || seq_len.len != n * 8 ||
+        move_start.len != n * 8 || n_moves.len != n * 8 || bc_status.len != n * 4 || offsets.len != (n + 1) * 8 ||
+        calib.len != n * (Py_ssize_t)sizeof(pxg_calib) || records.len < n * (Py_ssize_t)sizeof(pxg_read_result) ||
+        qual_arena.len != seq_arena.len || (a_run && !a_ctx)) {
+        PyErr_SetString(PyExc_ValueError, "decode_and_run: the arrays do not describe one batch");
+        goto done;
+    }
+    for (Py_ssize_t k = 0; k < n; k++) {
+        const int64_t d = ((const int64_t*)dst_start.buf)[k], c = ((const int64_t*)n_samples.buf)[k];
+        const int64_t s = ((const int64_t*)seq_start.buf)[k], sl = ((const int64_t*)seq_len.buf)[k];
+        const int64_t m = ((const int64_t*)move_start.buf)[k], ml = ((const int64_t*)n_moves.buf)[k];
+        if (d < 0 || c < 0 || s < 0 || sl < 0 || m < 0 || ml < 0) { need_samples = -1; break; }
+        if (d + c > need_samples) need_samples = d + c;
+        if (s + sl > need_text) need_text = s + sl;
+        if (m + ml > need_moves) need_moves = m + ml;
+    }
+    if (need_samples < 0 || need_samples > arena.len / 2 || need_text > seq_arena.len || need_moves > move_arena.len ||
+        (n && ((const int64_t*)offsets.buf)[n] > arena.len / 2)) {
+        PyErr_SetString(PyExc_ValueError, "decode_and_run: a read lies outside its arena");
+        goto done;
+    }
+    {
+        int decoded = 1, rc = 0, ran = 0;
+        Py_BEGIN_ALLOW_THREADS
+        if (n) {
+            ((load_signals_fn)(uintptr_t)a_signals)((int64_t)n, (const pxg_h5* const*)files.buf, (const int64_t*)index.buf,
+                                                    (const int64_t*)dst_start.buf, (const int64_t*)n_samples.buf,
+                                                    (int16_t*)arena.buf, threads, (int32_t*)sig_status.buf);
+            ((basecall_many_fn)(uintptr_t)a_text)((int64_t)n, (const pxg_h5* const*)files.buf, (const int64_t*)index.buf,
+                                                  (const int64_t*)seq_start.buf, (const int64_t*)seq_len.buf,
+                                                  (uint8_t*)seq_arena.buf, (uint8_t*)qual_arena.buf,
+                                                  (const int64_t*)move_start.buf, (const int64_t*)n_moves.buf,
+                                                  (uint8_t*)move_arena.buf, threads, (int32_t*)bc_status.buf);
+        }
+        for (Py_ssize_t k = 0; k < n; k++)
+            if (((const int32_t*)sig_status.buf)[k] || ((const int32_t*)bc_status.buf)[k]) { decoded = 0; break; }
+        if (decoded && a_run) {
+            rc = ((run_batch_fn)(uintptr_t)a_run)((pxg_ctx*)(uintptr_t)a_ctx, (int64_t)n, (const int16_t*)arena.buf,
+                                                  (const int64_t*)offsets.buf, (const pxg_calib*)calib.buf, stage_mask,
+                                                  (pxg_batch_extras*)(uintptr_t)a_extras, (pxg_read_result*)records.buf);
+            ran = 1;
+        }
+        Py_END_ALLOW_THREADS
+        out = ran ? Py_BuildValue("(Oi)", decoded ? Py_True : Py_False, rc)
+                  : Py_BuildValue("(OO)", decoded ? Py_True : Py_False, Py_None);
+    }
+done:
+    for (size_t k = 0; k < sizeof(all) / sizeof(all[0]); k++) PyBuffer_Release(all[k]);
+    return out;
+}
+
 static PyMethodDef METHODS[] = {
+    { "decode_and_run", decode_and_run, METH_VARARGS,
+      "decode_and_run(native function addresses, the batch's arrays) -> (decoded, rc): FAST5 decode + GPU pass without the interpreter lock" },
     { "report", report, METH_VARARGS, "report(columns, rows) -> list of result dicts (signal_loader.py:165-198)" },
     { "report_run", report_run, METH_VARARGS,
       "report_run(bundle columns, first, n, records, adapter, barcoding, min_seq_len, status names, label names) -> list of result dicts" },

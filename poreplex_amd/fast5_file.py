@@ -680,6 +680,27 @@ def _text_column(col, encoding):
     return np.asarray([b.decode(encoding, errors='replace') for b in col.tolist()])
 
 
+def decode_layout(p, threads=None):
+    """Samples and basecall text of the reads of layout `p` (Fast5Batch.plan, FileRunColumns.layout) into its arenas, on
+    host threads (two native calls)."""
+    from . import native
+    lib = native.load_text_library()
+    if not p['n']:
+        return
+    import time
+    threads = threads or host_threads()
+    t0 = time.perf_counter()
+    lib.pxg_h5_load_signals(p['n'], p['handles'].ctypes.data, p['index'].ctypes.data, p['dst'].ctypes.data,
+                            p['n_samples'].ctypes.data, p['arena'].ctypes.data, threads, p['signal_status'].ctypes.data)
+    _timed('signals_s', t0)
+    t0 = time.perf_counter()
+    lib.pxg_h5_basecall_many(p['n'], p['handles'].ctypes.data, p['index'].ctypes.data, p['seq_start'].ctypes.data,
+                             p['seq_len'].ctypes.data, p['seq_arena'].ctypes.data, p['qual_arena'].ctypes.data,
+                             p['move_start'].ctypes.data, p['n_moves'].ctypes.data, p['move_arena'].ctypes.data, threads,
+                             p['basecall_status'].ctypes.data)
+    _timed('text_s', t0)
+
+
 class Fast5Batch:
     """Many FAST5 reads as COLUMNS: what ReadBundle holds for a bundle's reads, built for one
     worker batch from the files themselves -- metadata by one native call per file, signals and
@@ -745,42 +766,50 @@ class Fast5Batch:
                 self._files = [f for f, _, _, count in self.runs for _ in range(count)]
         return self._files
 
-    def as_bundle(self, reserve=None, threads=None):
-        """ReadBundle over the batch (reads whose info failed must have been left out by the
-        caller).  `reserve(n_samples)` -> int16 arena to decode into (a staging buffer)."""
-        from . import native
-        lib = native.load_text_library()
+    def plan(self, reserve=None, arenas=True):
+        """The layout of the batch's bundle -- where every read's samples, sequence, quality string and moves go, in
+        arenas made here (`reserve(n_samples)` -> the int16 arena: a staging buffer) -- from the metadata alone, before
+        anything is decoded.  decode() fills the arenas, bundle() is the ReadBundle over them.  arenas=False: the
+        layout alone (empty arenas: FileRunColumns describes a whole file this way)."""
         info, n = self.info, len(self.index)
-        files = self.handles if self.handles is not None else self.files
+        handles = self.handles if self.handles is not None else \
+            np.array([f.handle.value for f in self.files], dtype=np.uintp)
         ns = info['n_samples'].astype(np.int64)
         offsets = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(ns, out=offsets[1:])
-        arena = reserve(int(offsets[-1])) if reserve is not None else np.empty(int(offsets[-1]), dtype=np.int16)
-        status = load_signals(files, self.index, ns, arena, offsets[:-1], threads)
-        seq_len = np.where(info['bc_present'] != 0, info['bc_seq_len'], 0).astype(np.int64)
-        n_moves = np.where(info['bc_present'] != 0, np.maximum(info['bc_n_moves'], 0), 0).astype(np.int64)
+        if not arenas:
+            arena = np.zeros(0, dtype=np.int16)
+        else:
+            arena = reserve(int(offsets[-1])) if reserve is not None else np.empty(int(offsets[-1]), dtype=np.int16)
+        present = info['bc_present'] != 0
+        seq_len = np.where(present, info['bc_seq_len'], 0).astype(np.int64)
+        n_moves = np.where(present, np.maximum(info['bc_n_moves'], 0), 0).astype(np.int64)
         seq_off = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(seq_len, out=seq_off[1:])
         move_off = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(n_moves, out=move_off[1:])
-        seq_arena = np.zeros(int(seq_off[-1]), dtype=np.uint8)
-        qual_arena = np.zeros(int(seq_off[-1]), dtype=np.uint8)
-        move_arena = np.zeros(int(move_off[-1]), dtype=np.uint8)
-        bstatus = np.zeros(n, dtype=np.int32)
-        if n:
-            idx = np.ascontiguousarray(self.index)
-            s0, m0 = np.ascontiguousarray(seq_off[:-1]), np.ascontiguousarray(move_off[:-1])
-            import time
-            t0 = time.perf_counter()
-            lib.pxg_h5_basecall_many(n, _handles(files), idx.ctypes.data, s0.ctypes.data, seq_len.ctypes.data,
-                                     seq_arena.ctypes.data, qual_arena.ctypes.data, m0.ctypes.data,
-                                     n_moves.ctypes.data, move_arena.ctypes.data, threads or host_threads(),
-                                     bstatus.ctypes.data)
-            _timed('text_s', t0)
+        return {'n': n, 'handles': np.ascontiguousarray(handles), 'index': np.ascontiguousarray(self.index), 'n_samples': ns,
+                'offsets': offsets, 'dst': np.ascontiguousarray(offsets[:-1]), 'arena': arena, 'present': present,
+                'signal_status': np.zeros(n, dtype=np.int32), 'basecall_status': np.zeros(n, dtype=np.int32),
+                'seq_len': seq_len, 'n_moves': n_moves, 'seq_off': seq_off, 'move_off': move_off,
+                'seq_start': np.ascontiguousarray(seq_off[:-1]), 'move_start': np.ascontiguousarray(move_off[:-1]),
+                'seq_arena': np.zeros(int(seq_off[-1]) if arenas else 0, dtype=np.uint8),
+                'qual_arena': np.zeros(int(seq_off[-1]) if arenas else 0, dtype=np.uint8),
+                'move_arena': np.zeros(int(move_off[-1]) if arenas else 0, dtype=np.uint8)}
+
+    def decode(self, p, threads=None):
+        """Samples and basecall text of the batch into the arenas of plan `p`, on host threads (two native calls)."""
+        decode_layout(p, threads)
+
+    def bundle(self, p):
+        """The ReadBundle over plan `p` (its columns are made of the metadata; the arenas are p's, decoded or about to be)."""
+        from . import native
+        info, n, offsets = self.info, p['n'], p['offsets']
+        present = p['present']
         calib = np.zeros(n, dtype=native.CALIB_DTYPE)
         for name in ('range', 'digitisation', 'offset', 'sampling_rate'):
             calib[name] = info['calib'][name]
-        d = {'arena': arena[:offsets[-1]], 'offsets': offsets, 'calib': calib,
+        d = {'arena': p['arena'][:offsets[-1]] if len(p['arena']) else p['arena'], 'offsets': offsets, 'calib': calib,
              'filename': self.name_array if self.name_array is not None else np.asarray(self.names),
              'read_id': self.id_array if self.id_array is not None else (
                  np.asarray(self.read_ids) if self.read_ids is not None else _text_column(info['read_id'], 'ascii')),
@@ -789,18 +818,67 @@ class Fast5Batch:
              'run_id': _text_column(info['run_id'], 'ascii'),
              'sample_id': _text_column(info['sample_id'], 'utf-8'),
              'broken_files': np.array([], dtype='<U1'), 'bundle_version': np.int64(2),
-             'bc_present': info['bc_present'] != 0, 'bc_sequence_length': info['bc_sequence_length'].astype(np.int64),
+             'bc_present': present, 'bc_sequence_length': info['bc_sequence_length'].astype(np.int64),
              'bc_mean_qscore': info['bc_mean_qscore'].astype(np.float64),
              'bc_num_events': info['bc_num_events'].astype(np.int64),
              'bc_first_sample': info['bc_first_sample'].astype(np.int64),
              'bc_block_stride': info['bc_block_stride'].astype(np.int32), 'bc_table': info['bc_table'].astype(np.int8),
-             'bc_n_moves': np.where(info['bc_present'] != 0, info['bc_n_moves'], -1).astype(np.int64),
+             'bc_n_moves': np.where(present, info['bc_n_moves'], -1).astype(np.int64),
              'bc_move_sum': info['bc_move_sum'].astype(np.int64),
-             'seq_offsets': seq_off, 'seq_arena': seq_arena, 'qual_arena': qual_arena,
-             'move_offsets': move_off, 'move_arena': move_arena}
+             'seq_offsets': p['seq_off'], 'seq_arena': p['seq_arena'], 'qual_arena': p['qual_arena'],
+             'move_offsets': p['move_off'], 'move_arena': p['move_arena']}
         bundle = _Fast5BatchBundle(d, self)
-        bundle.signal_status, bundle.basecall_status = status, bstatus
+        bundle.signal_status, bundle.basecall_status = p['signal_status'], p['basecall_status']
         return bundle
+
+    def as_bundle(self, reserve=None, threads=None):
+        """ReadBundle over the batch (reads whose info failed must have been left out by the
+        caller).  `reserve(n_samples)` -> int16 arena to decode into (a staging buffer)."""
+        p = self.plan(reserve)
+        self.decode(p, threads)
+        return self.bundle(p)
+
+
+class FileRunColumns:
+    """What worker calls that are runs of ONE multi-read file share, made once per (file, name under which it is asked
+    for): the file's metadata as the columns of a read bundle over ALL its reads (no samples, no text: `meta`), hence
+    its plain-run columns (ReadBundle.plain_run_columns), and the layout every call's arenas follow.  A call over reads
+    [i0, i0 + n) then costs a dozen slices (layout) instead of the ~70 small NumPy operations that build a bundle of
+    its own -- the interpreter lock is what bounds worker threads in reference-sized calls."""
+
+    def __init__(self, f, name):
+        batch = Fast5Batch.from_runs([(f, name, 0, f.n)])
+        self.whole = batch.plan(arenas=False)
+        self.meta = batch.bundle(self.whole)
+        self.handle = f.handle.value
+
+    def plain(self, scaler_cfg):
+        return self.meta.plain_run_columns(scaler_cfg)
+
+    def layout(self, i0, n, reserve):
+        """Fast5Batch.plan's dict for the reads [i0, i0 + n) of the file: arenas of the call's own, positions counted from
+        its first read."""
+        w, run = self.whole, slice(i0, i0 + n)
+        offsets = w['offsets'][i0:i0 + n + 1] - w['offsets'][i0]
+        seq_off = w['seq_off'][i0:i0 + n + 1] - w['seq_off'][i0]
+        move_off = w['move_off'][i0:i0 + n + 1] - w['move_off'][i0]
+        return {'n': n, 'handles': np.full(n, self.handle, dtype=np.uintp), 'index': np.arange(i0, i0 + n, dtype=np.int64),
+                'n_samples': w['n_samples'][run], 'offsets': offsets, 'dst': offsets[:-1],
+                'arena': reserve(int(offsets[-1])), 'present': w['present'][run],
+                'signal_status': np.zeros(n, dtype=np.int32), 'basecall_status': np.zeros(n, dtype=np.int32),
+                'seq_len': w['seq_len'][run], 'n_moves': w['n_moves'][run], 'seq_off': seq_off, 'move_off': move_off,
+                'seq_start': seq_off[:-1], 'move_start': move_off[:-1],
+                'seq_arena': np.zeros(int(seq_off[-1]), dtype=np.uint8), 'qual_arena': np.zeros(int(seq_off[-1]), dtype=np.uint8),
+                'move_arena': np.zeros(int(move_off[-1]), dtype=np.uint8)}
+
+
+def file_run_columns(f, name):
+    """The FileRunColumns of multi-read file `f` asked for as `name` (kept with the open file)."""
+    cache = f.__dict__.setdefault('_run_columns', {})
+    cols = cache.get(name)
+    if cols is None:
+        cols = cache[name] = FileRunColumns(f, name)
+    return cols
 
 
 class Fast5Reader:

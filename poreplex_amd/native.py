@@ -736,6 +736,59 @@ def pack_reads(signals):
     return arena, offsets
 
 
+class BatchExCall:
+    """One pxg_process_batch_ex call prepared for somebody else to make (NativeContext.batch_ex_call): the extras
+    struct, the output arrays it points at, the function's address and the context handle.  After the call:
+    result(rc) -- the dict process_batch_ex returns --, or None when a variable-size output outgrew its buffer
+    (PXG_E_NOMEM with the totals set: the caller goes through process_batch_ex, whose loop sizes them)."""
+
+    def __init__(self, ctx, n, stage_mask, unsplit, want_spikes):
+        self.ctx, self.n, self.stage_mask = ctx, n, stage_mask
+        self.function = C.cast(ctx.lib.pxg_process_batch_ex, C.c_void_p).value
+        self.handle = ctx.handle.value if hasattr(ctx.handle, 'value') else int(ctx.handle)
+        x = self.x = PxgBatchExtras()
+        x.struct_bytes = C.sizeof(PxgBatchExtras)
+        self.records = np.zeros(n, dtype=RESULT_DTYPE)
+        self.keep = []
+        self.cnt = self.iv = self.rows = self.spike_off = None
+        if unsplit is not None:
+            first = np.ascontiguousarray(unsplit[0], dtype=np.int64)
+            nb = np.ascontiguousarray(unsplit[1], dtype=np.int64)
+            if len(first) != n or len(nb) != n:
+                raise ValueError('one first_sample / n_blocks entry per read')
+            self.keep += [first, nb]
+            self.cnt = np.zeros(n, dtype=np.int32)
+            x.unsplit_first_sample, x.unsplit_n_blocks = first.ctypes.data, nb.ctypes.data
+            x.unsplit_block_stride = int(unsplit[2])
+            x.unsplit_count = self.cnt.ctypes.data
+            self.iv_cap = max(getattr(ctx, '_unsplit_cap', 0), n // 4 + 1024)
+            self.iv = np.empty((self.iv_cap, 2), dtype=np.int64)
+            x.unsplit_cap, x.unsplit_intervals = self.iv_cap, self.iv.ctypes.data
+        if want_spikes:
+            self.spike_cap = max(getattr(ctx, '_spike_cap', 0), 2 * n + 1024)
+            self.spike_off = np.zeros(n + 1, dtype=np.int64)
+            self.rows = np.zeros((self.spike_cap, 4), dtype=np.float32)
+            x.spike_cap, x.spikes, x.spike_offsets = self.spike_cap, self.rows.ctypes.data, self.spike_off.ctypes.data
+        self.extras = C.addressof(x)
+
+    def result(self, rc):
+        x = self.x
+        if rc == PXG_E_NOMEM and ((self.iv is not None and x.unsplit_total > self.iv_cap) or
+                                  (self.rows is not None and x.spike_total > self.spike_cap)):
+            return None
+        self.ctx._check(rc, 'pxg_process_batch_ex')
+        res = {'records': self.records}
+        if self.rows is not None:
+            self.ctx._spike_cap = self.spike_cap
+            res['spikes'] = (self.rows[:int(x.spike_total)], self.spike_off)
+        if self.iv is not None:
+            self.ctx._unsplit_cap = self.iv_cap
+            start = np.zeros(self.n + 1, dtype=np.int64)
+            np.cumsum(np.maximum(self.cnt, 0), out=start[1:])
+            res['unsplit'] = (self.iv[:int(x.unsplit_total)], self.cnt, start)
+        return res
+
+
 class NativeContext:
     """One pxg_ctx: models resident on one GPU for the life of a worker
     (the role of WorkerPersistenceStorage, worker_persistence.py:46-90)."""
@@ -912,6 +965,12 @@ class NativeContext:
                 continue
             self._check(rc, 'pxg_batch_download_spikes')
             return rows, off
+
+    def batch_ex_call(self, n, stage_mask=STAGE_ALL_DEMUX, unsplit=None, want_spikes=False):
+        """The arguments of ONE pxg_process_batch_ex call over n reads with plain int16 samples, laid out for a caller
+        that makes the call itself -- csrc/pxg_pyreport.c decode_and_run, which runs the FAST5 decode and this call behind
+        one release of the interpreter lock.  See BatchExCall; process_batch_ex is the same call made from here."""
+        return BatchExCall(self, n, stage_mask, unsplit, want_spikes)
 
     def process_batch_ex(self, samples, offsets, calib, stage_mask=STAGE_ALL_DEMUX, scale_shift=None,
                          unsplit=None, want_spikes=False):

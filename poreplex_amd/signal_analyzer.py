@@ -29,6 +29,7 @@ from weakref import proxy
 import numpy as np
 
 from . import native
+from .fast5_file import decode_layout
 from .signal_loader import LABELS, NanoporeRead, ReadTable, SignalAnalysisError
 from .utils import union_intervals  # noqa: F401  (re-exported like the reference)
 from .worker_persistence import WorkerPersistenceStorage
@@ -48,6 +49,7 @@ _USE_HOST_PHASE = os.environ.get('PXG_NO_HOST_PHASE_LOCK') is None
 _PLAIN_RUN = os.environ.get('PXG_NO_PLAIN_RUN') is None
 _BULK_UNSPLIT = os.environ.get('PXG_NO_BULK_UNSPLIT') is None      # (A/B and tests: candidates judged read by read)
 _PLAIN_RUN_FAST5 = os.environ.get('PXG_NO_PLAIN_RUN_FAST5') is None    # (A/B: only bundle reads take the short path)
+_FUSED_CALL = os.environ.get('PXG_NO_FUSED_CALL') is None         # (A/B: FAST5 decode and GPU pass as separate native calls)
 PLAIN_RUN_CALLS = 0         # worker calls that took SignalAnalyzer.process_plain_run (bench.py reports it)
 
 
@@ -201,21 +203,16 @@ class SignalAnalyzer(AbstractContextManager):
         if fast is None or not hasattr(fast, 'report_run'):
             return None
         t0 = time.perf_counter()
-        if from_files:
-            # (outside the phase lock: most of it is the native reader at work, without the interpreter lock)
-            b, self.call_arena = loader.fast5_run_bundle(reads)
-            if b is None:
-                return None
-            self.prebuilt = (reads, b)                    # (whoever declines from here on has the files read already)
+        batch = None
         with phase:
             n = len(reads)
             if from_files:
-                if b.signal_status.any() or b.basecall_status.any():
+                # the per-call bundle: laid out and described from the files' cached metadata; nothing is decoded yet
+                batch = loader.fast5_run_plan(reads)
+                if batch is None:
                     return None
-                first = 0
-                plain = b.plain_run_columns(loader.scaler_cfg)
-                if plain is None or not plain['ok'].all():
-                    return None
+                self.call_arena, layout, plain, first = batch.arena, batch.layout, batch.plain, batch.first
+                fits = plain is not None and bool(plain['ok'][first:first + n].all())
             else:
                 plain = b.plain_run_columns(loader.scaler_cfg)
                 if plain is None:
@@ -225,23 +222,51 @@ class SignalAnalyzer(AbstractContextManager):
                     return None
                 if b.broken and any(key[0] in b.broken for key in reads):      # (files that exist but cannot be opened)
                     return None
+                fits = True
             scan = sel = None
-            if loader.scan_unsplit:
+            if fits and loader.scan_unsplit:
                 # the window scan over the same resident batch (signal_loader.fit_scalers); a Move table of another
                 # k-mer size or a bundle with several block strides: the general path
                 blocks = plain['frame_blocks'][first:first + n]
                 sel = blocks > 0
                 if not plain['kmer_ok'][first:first + n].all() or (plain['frame_stride'] is None and sel.any()):
-                    return None
-                if sel.any():
+                    fits = False
+                elif sel.any():
                     scan = (plain['frame_first'][first:first + n], blocks, plain['frame_stride'])
-            o = plain['offsets'][first:first + n + 1]
-            arena, offsets, calib = b.samples_run(first, first + n), o - o[0], plain['calib'][first:first + n]
-        if not from_files:
+            if fits:
+                o = plain['offsets'][first:first + n + 1]
+                offsets, calib = o - o[0], plain['calib'][first:first + n]
+                arena = b.samples_run(first, first + n) if batch is None else layout['arena'][:offsets[-1]]
+                call = None
+                if batch is not None and _FUSED_CALL and hasattr(fast, 'decode_and_run') and hasattr(self.ctx, 'batch_ex_call'):
+                    call = self.ctx.batch_ex_call(n, loader.stage_mask, scan, bool(loader.stage_mask & native.STAGE_POLYA))
+        if batch is not None:
+            # decode (+ the GPU pass, when this call makes it itself) without the interpreter lock; whoever declines from
+            # here on has the files read already: self.prebuilt
+            with loader.decoding() as threads:
+                if fits and call is not None:
+                    t1 = time.perf_counter()
+                    decoded, rc = loader.decode_and_run(fast, layout, threads, call, offsets, calib)
+                    t2 = time.perf_counter()
+                else:
+                    decode_layout(layout, threads)
+                    decoded = not (layout['signal_status'].any() or layout['basecall_status'].any())
+            self.prebuilt = (reads, batch)
+            if not (fits and decoded):
+                return None
+        elif not fits:
+            return None
+        else:
             loader.pin_bundle()
-        t1 = time.perf_counter()
-        got = loader.records_of_run(arena, offsets, calib, scan)
-        t2 = time.perf_counter()
+        if batch is None or call is None:
+            t1 = time.perf_counter()
+            got = loader.records_of_run(arena, offsets, calib, scan)
+            t2 = time.perf_counter()
+        else:
+            got = call.result(rc)
+            if got is None:          # (a variable-size output outgrew its buffer: the wrapper's loop sizes it)
+                got = loader.records_of_run(arena, offsets, calib, scan)
+                t2 = time.perf_counter()
         with phase:
             some = np.nonzero(got['unsplit'][1])[0] if scan is not None else ()
             if len(some) > n // 4:
@@ -264,7 +289,8 @@ class SignalAnalyzer(AbstractContextManager):
                                               None if spikes is None else np.ascontiguousarray(spikes[1], dtype=np.int64),
                                               skip)
                     if skip is not None:
-                        for at, report in zip(some.tolist(), self.finish_some_from_pass(b, first, some, got)):
+                        held, held_first = (b, first) if batch is None else (batch.bundle(), 0)
+                        for at, report in zip(some.tolist(), self.finish_some_from_pass(held, held_first, some, got)):
                             results[at] = report
                 except (IndexError, TypeError, KeyError, ValueError):
                     results = self.finish_from_pass(reads, got, sel)      # columns it cannot read as they are

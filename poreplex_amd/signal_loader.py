@@ -504,6 +504,38 @@ class CallArenas:
                 pass
 
 
+class CallBundle:
+    """The reads of one worker call over FAST5 files (SignalLoader.fast5_run_plan): `layout` -- where their samples and
+    text go (fast5_file.Fast5Batch.plan) --, `plain` -- the columns the short path reads, the call's reads at rows
+    [first, first + n) --, `arena` -- the pooled sample arena --, and bundle(): the ReadBundle over exactly these reads,
+    made when somebody needs one (the batch table of a call that declines, reads with chimera candidates)."""
+
+    def __init__(self, runs, layout, plain, first, arena):
+        self.runs, self.layout, self.plain, self.first, self.arena = runs, layout, plain, first, arena
+        self.made = None
+
+    def bundle(self):
+        if self.made is None:
+            from .fast5_file import Fast5Batch
+            self.made = Fast5Batch.from_runs(self.runs).bundle(self.layout)
+        return self.made
+
+
+class _Decoding:
+    def __init__(self, loader):
+        self.loader = loader
+
+    def __enter__(self):
+        with self.loader._stage_lock:
+            self.loader._decoding += 1
+            return None if self.loader._decoding == 1 else 1
+
+    def __exit__(self, *exc):
+        with self.loader._stage_lock:
+            self.loader._decoding -= 1
+        return False
+
+
 class SignalLoader:
     """Opens reads into a ReadTable and runs the GPU pass over it.  `self.table` is the
     batch the reference-style calls (prepare_loading / fit_scalers) work on; the session
@@ -529,6 +561,7 @@ class SignalLoader:
         # to the download of its records
         self._stage_lock, self._run_lock = threading.Lock(), threading.Lock()
         self._pinned = []
+        self._decoding = 0             # worker calls inside fast5_run_bundle right now
         self.call_arenas = CallArenas(ctx=ctx if os.environ.get('PXG_PIN_CALL_ARENAS') and hasattr(ctx, 'pin') else None)
 
     def clear(self):
@@ -614,11 +647,12 @@ class SignalLoader:
 
     def prepare_fast5(self, reads, where, table, reserve=None, prebuilt=None):
         """The FAST5 half of prepare_many.  Only when the table holds no bundle rows yet (a
-        table has one column source).  `prebuilt`: the bundle fast5_run_bundle has made of exactly these reads."""
+        table has one column source).  `prebuilt`: the decoded CallBundle of exactly these reads (fast5_run_plan)."""
         from .fast5_file import Fast5Batch, Fast5Error, open_fast5
         if table.n or table.bundle is not None:
             return where
-        if prebuilt is not None and len(prebuilt.filenames) == len(reads):
+        if prebuilt is not None and prebuilt.layout['n'] == len(reads):
+            prebuilt = prebuilt.bundle()
             return self.enter_fast5_bundle(prebuilt, prebuilt.filenames, np.arange(len(reads)), where, table)
         runs = self.fast5_runs(reads)
         if runs is not None:
@@ -715,28 +749,66 @@ class SignalLoader:
             pos += count
         return runs
 
-    def fast5_run_bundle(self, reads):
-        """(bundle, arena) of a worker call that is stretches of multi-read FAST5 files in file order (fast5_runs): the
-        per-call read bundle of SignalAnalyzer.process_plain_run, its samples decoded into an arena of the loader's
-        pool (`call_arenas`: memory a call before it has touched; the caller gives it back).  (None, None): not such
-        a call."""
-        from .fast5_file import Fast5Batch
+    def fast5_run_plan(self, reads):
+        """The per-call read bundle of a worker call that is stretches of multi-read FAST5 files in file order
+        (fast5_runs), laid out from the files' cached metadata with NOTHING decoded yet -- a CallBundle, its sample arena
+        from the loader's pool (`call_arenas`: memory a call before it has touched; the caller gives it back); None: not
+        such a call.  A run of ONE file (all but the calls that cross a file boundary) is a dozen slices of columns kept
+        with the open file (fast5_file.FileRunColumns); several files: a bundle of the call's own."""
+        from .fast5_file import Fast5Batch, file_run_columns
         if self.bundle is not None and any(self.bundle.has_file(name) for name in {key[0] for key in reads}):
-            return None, None                  # (a call that mixes bundle reads and files: the general path sorts it out)
+            return None                        # (a call that mixes bundle reads and files: the general path sorts it out)
         runs = self.fast5_runs(reads)
         if runs is None:
-            return None, None
+            return None
         taken = []
 
         def reserve(n_samples):
             taken.append(self.call_arenas.take(n_samples))
             return taken[0]
         try:
-            return Fast5Batch.from_runs(runs).as_bundle(reserve), taken[0]
+            if len(runs) == 1:
+                f, name, i0, count = runs[0]
+                cols = file_run_columns(f, name)
+                layout = cols.layout(i0, count, reserve)
+                plain = cols.plain(self.scaler_cfg)
+                if plain is not None:          # the file's columns, the call's text
+                    plain = dict(plain, seq_arena=layout['seq_arena'], qual_arena=layout['qual_arena'],
+                                 seq_base=int(cols.whole['seq_off'][i0]))
+                return CallBundle(runs, layout, plain, i0, taken[0])
+            batch = Fast5Batch.from_runs(runs)
+            layout = batch.plan(reserve)
+            call = CallBundle(runs, layout, None, 0, taken[0])
+            call.made = batch.bundle(layout)
+            call.plain = call.made.plain_run_columns(self.scaler_cfg)
+            return call
         except BaseException:
             if taken:
                 self.call_arenas.give(taken[0])
             raise
+
+    def decoding(self):
+        """`with loader.decoding() as threads:` around the decode of a worker call's FAST5 reads.  threads: all of the
+        host's (None) for a call that is alone in the loader -- its latency --, one -- its own -- when other calls are
+        decoding too: the parallelism is then between the calls, and a shared pool that every call wakes up for a
+        millisecond of work costs each of them more than it gives."""
+        return _Decoding(self)
+
+    def decode_and_run(self, fast, layout, threads, call, offsets, calib):
+        """(decoded, rc): the samples and the basecall text of `layout` decoded and -- when all of it arrived -- the
+        prepared pxg_process_batch_ex `call` made over them, behind ONE release of the interpreter lock
+        (csrc/pxg_pyreport.c decode_and_run: the native functions by address)."""
+        import ctypes as C
+        from .fast5_file import host_threads
+        lib = native.load_text_library()
+        p = layout
+        return fast.decode_and_run(
+            C.cast(lib.pxg_h5_load_signals, C.c_void_p).value, C.cast(lib.pxg_h5_basecall_many, C.c_void_p).value,
+            call.function, int(threads or host_threads()),
+            p['handles'], p['index'], p['dst'], p['n_samples'], p['arena'], p['signal_status'],
+            p['seq_start'], p['seq_len'], p['seq_arena'], p['qual_arena'], p['move_start'], p['n_moves'], p['move_arena'],
+            p['basecall_status'], call.handle, np.ascontiguousarray(offsets, dtype=np.int64),
+            np.ascontiguousarray(calib, dtype=native.CALIB_DTYPE), int(call.stage_mask), call.extras, call.records)
 
     def enter_fast5_bundle(self, bundle, names, at, where, table):
         """Rows for the reads of a Fast5Batch bundle (request positions `at`), the length gate and the reads whose

@@ -178,3 +178,83 @@ class OneCallOracleContext(OracleBackedContext):
                 out['unsplit'] = self.unsplit_scan(np.asarray(unsplit[0]), np.asarray(unsplit[1]), int(unsplit[2]))
             return out
 
+
+class NativeEntryMixin:
+    """Gives a double that has process_batch_ex the NATIVE face of that call: a C function pointer with
+    pxg_process_batch_ex's prototype (a ctypes callback) behind `lib.pxg_process_batch_ex`, and a `handle`, so that
+    native.BatchExCall and csrc/pxg_pyreport.c decode_and_run drive it exactly as they drive the library: raw pointers
+    in, records / spike rows / candidate intervals written through the extras struct, PXG_E_NOMEM with the totals set
+    when a buffer is too small."""
+
+    PROTOTYPE = None
+    native_calls = 0
+
+    def install_native_entry(self):
+        import ctypes as C
+        import types
+        cls = NativeEntryMixin
+        if cls.PROTOTYPE is None:
+            cls.PROTOTYPE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                        C.c_void_p, C.c_void_p)
+        self._entry = cls.PROTOTYPE(self._native_entry)            # (kept alive with the double)
+        self.lib = types.SimpleNamespace(pxg_process_batch_ex=self._entry)
+        self.handle = C.c_void_p(0x5eed)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise N.PxgError('{} failed ({})'.format(what, rc))
+
+    def batch_ex_call(self, n, stage_mask=N.STAGE_ALL_DEMUX, unsplit=None, want_spikes=False):
+        if not hasattr(self, '_entry'):
+            self.install_native_entry()
+        return N.BatchExCall(self, n, stage_mask, unsplit, want_spikes)
+
+    def _native_entry(self, handle, n, arena_p, offsets_p, calib_p, mask, extras_p, out_p):
+        import ctypes as C
+        try:
+            assert handle == 0x5eed
+
+            def view(address, count, dtype):
+                dtype = np.dtype(dtype)
+                if not count:
+                    return np.zeros(0, dtype=dtype)
+                return np.frombuffer((C.c_char * (count * dtype.itemsize)).from_address(address), dtype=dtype)
+            offsets = view(offsets_p, n + 1, np.int64).copy()
+            arena = view(arena_p, int(offsets[-1]), np.int16)
+            calib = view(calib_p, n, N.CALIB_DTYPE)
+            x = N.PxgBatchExtras.from_address(extras_p)
+            assert x.struct_bytes == C.sizeof(N.PxgBatchExtras) and not x.z and not x.scale_shift_or_null
+            unsplit = None
+            if x.unsplit_first_sample:
+                unsplit = (view(x.unsplit_first_sample, n, np.int64), view(x.unsplit_n_blocks, n, np.int64),
+                           int(x.unsplit_block_stride))
+            res = self.process_batch_ex(arena, offsets, calib, mask, unsplit=unsplit, want_spikes=bool(x.spike_cap))
+            view(out_p, n, N.RESULT_DTYPE)[:] = res['records']
+            rc = 0
+            if x.spike_cap:
+                rows, off = res['spikes']
+                x.spike_total = len(rows)
+                view(x.spike_offsets, n + 1, np.int64)[:] = off
+                if len(rows) > x.spike_cap:
+                    rc = N.PXG_E_NOMEM
+                else:
+                    view(x.spikes, 4 * len(rows), np.float32)[:] = np.asarray(rows, dtype=np.float32).ravel()
+            if unsplit is not None:
+                iv, cnt, _ = res['unsplit']
+                x.unsplit_total = len(iv)
+                view(x.unsplit_count, n, np.int32)[:] = cnt
+                if len(iv) > x.unsplit_cap:
+                    rc = N.PXG_E_NOMEM
+                else:
+                    view(x.unsplit_intervals, 2 * len(iv), np.int64)[:] = np.asarray(iv, dtype=np.int64).ravel()
+            type(self).native_calls += 1
+            return rc
+        except BaseException:             # noqa: BLE001  (nothing may leave a C callback)
+            import traceback
+            traceback.print_exc()
+            return -1
+
+
+class NativeOneCallOracleContext(NativeEntryMixin, OneCallOracleContext):
+    """OneCallOracleContext that can also be called the way the library is (see NativeEntryMixin)."""
+

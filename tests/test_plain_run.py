@@ -51,7 +51,7 @@ def same(a, b, where='result'):
         assert a == b, (where, a, b)
 
 
-class CraftedRecords(oracle_context.OracleBackedContext):
+class CraftedRecords(oracle_context.NativeEntryMixin, oracle_context.OracleBackedContext):
     """Context double whose GPU pass returns records made up per read (the read is recognised by its calibration
     offset, which the bundle below numbers)."""
     table = None
@@ -335,6 +335,17 @@ def test_short_path_from_many_threads(crafted, monkeypatch, tmp_path):
             assert isinstance(g, list) and len(g) == len(w)
 
 
+def count_decodes(monkeypatch, decodes):
+    """decodes gets a 1 for every pass of the native reader over a call's reads: separate calls (fast5_file.decode_layout,
+    behind as_bundle too) or inside the fused call (SignalLoader.decode_and_run)."""
+    from poreplex_amd import fast5_file as F5
+    from poreplex_amd import signal_loader as SL
+    real_decode, real_fused = F5.decode_layout, SL.SignalLoader.decode_and_run
+    monkeypatch.setattr(F5, 'decode_layout', lambda *a, **kw: decodes.append(1) or real_decode(*a, **kw))
+    monkeypatch.setattr(SA, 'decode_layout', F5.decode_layout)
+    monkeypatch.setattr(SL.SignalLoader, 'decode_and_run', lambda self, *a, **kw: decodes.append(1) or real_fused(self, *a, **kw))
+
+
 def crafted_fast5_files(tmp_path, bundle_path, reads_per_file=37):
     """The reads of a crafted bundle as multi-read FAST5 files under tmp_path/f5: [(filename, read_id)] in the order a
     batch maker lists them (file by file, each file's reads in the file's own order) and the bundle index of each."""
@@ -383,8 +394,7 @@ def test_short_path_from_fast5_files_equals_the_general_path(crafted, monkeypatc
     rec['seg_last'][:, adapter] = np.where(found, 90, -1)
     taken = spy_on_the_short_path(monkeypatch)
     decodes = []
-    real_as_bundle = F5.Fast5Batch.as_bundle
-    monkeypatch.setattr(F5.Fast5Batch, 'as_bundle', lambda self, *a, **kw: decodes.append(1) or real_as_bundle(self, *a, **kw))
+    count_decodes(monkeypatch, decodes)
     rng = np.random.default_rng(100 + seed)
     windows = [(0, n), (30, 20)] + [(int(a), int(rng.integers(1, 90 if j < 15 else 25))) for j, a in enumerate(rng.integers(0, n - 1, 70))]
     statuses, n_taken, arenas = set(), 0, worker_objects()['loader'].call_arenas
@@ -407,6 +417,20 @@ def test_short_path_from_fast5_files_equals_the_general_path(crafted, monkeypatc
     assert statuses - {'unsplit_read'} == {'okay', 'scaling_qc_fail', 'adapter_not_detected', 'not_basecalled',
                                            'sequence_too_short'}
     assert 1 <= len(arenas.free) <= 2                         # the calls took turns with the same sample arena
+    # the taken calls made their GPU pass from inside csrc/pxg_pyreport.c decode_and_run (decode + pass behind one
+    # release of the interpreter lock), through the double's C entry point; with PXG_NO_FUSED_CALL they decode first
+    # and call the context afterwards -- same dicts
+    assert CraftedRecords.native_calls >= n_taken
+    before = CraftedRecords.native_calls
+    monkeypatch.setattr(SA, '_PLAIN_RUN', True)
+    monkeypatch.setattr(SA, '_FUSED_CALL', False)
+    lo, k = next((lo, k) for lo, k in windows[1:] if ok[lo:lo + k].all() and k > 3)
+    del taken[:]
+    unfused = SA.process_batch(1, list(keys[lo:lo + k]), cfg)
+    monkeypatch.setattr(SA, '_FUSED_CALL', True)
+    fused = SA.process_batch(1, list(keys[lo:lo + k]), cfg)
+    assert taken == [True, True] and CraftedRecords.native_calls == before + 1
+    same(unfused, fused)
     # a shuffled call is not a run: the general path, as before
     monkeypatch.setattr(SA, '_PLAIN_RUN', True)
     del taken[:]
@@ -421,6 +445,75 @@ def test_short_path_from_fast5_files_equals_the_general_path(crafted, monkeypatc
     del taken[:]
     SA.process_batch(3, list(keys[run[0]:run[0] + run[1]]), cfg)
     assert taken == [False]
+
+
+def test_fast5_call_with_an_undecodable_read_and_with_buffers_too_small(crafted, monkeypatch, tmp_path):
+    """Two exits of the fused decode + pass (csrc/pxg_pyreport.c decode_and_run): a read whose samples cannot be decoded
+    -- the pass is not made, the call goes to the batch table with the bundle it has, and that read alone is an
+    'unknown_error' as on the general path --, and a variable-size output that outgrows the buffer of the prepared call
+    (PXG_E_NOMEM with the totals set): the wrapper's loop makes the pass again."""
+    import zlib
+    from poreplex_amd.fast5_file import clear_open_cache, get_read_ids
+    from poreplex_amd.fast5_write import Fast5Writer
+    n = 24
+    path, rec, found, short, _ = crafted_bundle(tmp_path, n, 21)
+    b = ReadBundle(path)
+    plain_ok = b.plain_run_columns({'length': 30000, 'stride': 15, 'min_length': 9000})['ok']
+    good = [i for i in range(n) if plain_ok[i]][:12]
+    assert len(good) == 12
+    top = tmp_path / 'f5'
+    top.mkdir()
+    with Fast5Writer(str(top / 'z.fast5')) as w:
+        for i in good:
+            w.add_read(b.read_ids[i], b.samples(i), b.d['calib'][i], basecall=b.basecall_of(i), compression='gzip')
+    keys = get_read_ids('z.fast5', str(top))
+    victim = good[[r for _, r in keys].index(b.read_ids[good[5]])]
+    CraftedRecords.table = rec
+    rec['status'] = 0
+    rec['polya_called'], rec['polya_n_spikes'] = 1, 3
+    cfg = default_config(inputdir=str(top), outputdir=str(tmp_path), barcoding=True, measure_polya=True, minimum_sequence_length=10)
+    assert isinstance(SA.process_batch(0, keys[:1], cfg), list)
+    adapter = worker_objects()['ctx'].state_names.index('adapter')
+    rec['seg_first'][:, adapter], rec['seg_last'][:, adapter] = 40, 90
+    taken = spy_on_the_short_path(monkeypatch)
+    whole = SA.process_batch(1, list(keys), cfg)
+    assert taken == [True] and all(r['status'] != 'unknown_error' for r in whole)
+    # --- buffers too small: the prepared call comes back with PXG_E_NOMEM, the wrapper's loop sizes them
+    class Tight(N.BatchExCall):
+        def __init__(self, *a):
+            super().__init__(*a)
+            self.spike_cap = self.x.spike_cap = 2
+    monkeypatch.setattr(N, 'BatchExCall', Tight)
+    before = CraftedRecords.native_calls
+    del taken[:]
+    again = SA.process_batch(1, list(keys), cfg)
+    assert taken == [True] and CraftedRecords.native_calls == before + 1
+    same(again, whole)
+    monkeypatch.undo()
+    monkeypatch.setattr(N, 'NativeContext', CraftedRecords)
+    # --- one read's compressed samples damaged on disk (the deflate stream of its chunk)
+    blob = zlib.compress(b.samples(victim).astype('<i2').tobytes(), 1)
+    data = bytearray((top / 'z.fast5').read_bytes())
+    at = data.find(blob)
+    assert at > 0 and len(blob) > 64
+    data[at + 20:at + 40] = bytes(20)
+    (top / 'z.fast5').write_bytes(bytes(data))
+    clear_open_cache()
+    WorkerPersistenceStorage.reset()
+    taken = spy_on_the_short_path(monkeypatch)
+    decodes = []
+    count_decodes(monkeypatch, decodes)
+    before = CraftedRecords.native_calls
+    hurt = SA.process_batch(2, list(keys), cfg)
+    assert taken == [False] and decodes == [1] and CraftedRecords.native_calls == before      # no pass from the fused call
+    monkeypatch.setattr(SA, '_PLAIN_RUN', False)
+    same(hurt, SA.process_batch(2, list(keys), cfg))
+    bad = [r for r in hurt if r['status'] == 'unknown_error']
+    assert len(bad) == 1 and bad[0]['read_id'] == b.read_ids[victim] and 'cannot be decoded' in bad[0]['error_message']
+    healthy = {r['read_id']: r for r in whole}
+    for r in hurt:
+        if r['status'] != 'unknown_error':
+            same(r, healthy[r['read_id']])
 
 
 def test_short_path_from_fast5_files_on_many_threads(crafted, monkeypatch, tmp_path):

@@ -49,6 +49,22 @@ class SleepingContext:
 
     candidates_every = 0          # --full: every n-th read comes back from the chimera scan with a candidate
 
+    # the NATIVE face of the one call (native.BatchExCall, csrc/pxg_pyreport.c decode_and_run): libc's usleep stands in
+    # for pxg_process_batch_ex -- its first argument, the context handle, is the microseconds to sleep; the other seven
+    # are ignored -- so the sleep happens without the interpreter lock and without any Python, like the real pass
+    def batch_ex_call(self, n, stage_mask=N.STAGE_ALL_DEMUX, unsplit=None, want_spikes=False):
+        import ctypes as C
+        import types
+        if not hasattr(self, 'lib'):
+            self.lib = types.SimpleNamespace(pxg_process_batch_ex=C.CDLL(None).usleep)
+        self.handle = C.c_void_p(max(int(self.gpu_ms * 1000), 1))
+        call = N.BatchExCall(self, n, stage_mask, unsplit, want_spikes)
+        call.records[:] = SleepingContext.records[:n]
+        return call
+
+    def _check(self, rc, what):
+        assert rc == 0, (what, rc)
+
     def process_batch_ex(self, samples, offsets, calib, stage_mask=N.STAGE_ALL_DEMUX, scale_shift=None, unsplit=None,
                          want_spikes=False):
         time.sleep(self.gpu_ms * 1e-3)

@@ -15,8 +15,8 @@ timeout 900 python bench.py > $OUT/bench_demux.json 2> $OUT/bench_demux.err
 echo "driver form: $(( $(date +%s) - T0 )) s" | tee $OUT/wallclock.txt
 (API_FL="1 32" tools/dev/api128.sh PXG_NO_PLAIN_RUN=1; API_FL="1 32" tools/dev/api128.sh PXG_X=1) > $OUT/api_128_read_calls_plain_run.txt 2>&1
 cat $OUT/api_128_read_calls_plain_run.txt
-# 128-read worker calls over multi-read FAST5 files (no bundle), real context: batch table / plain run / page-locked call arenas
-(for env in PXG_NO_PLAIN_RUN_FAST5=1 PXG_X=1 PXG_PIN_CALL_ARENAS=1; do echo "## $env"; env $env timeout 600 python tools/dev/host_cap.py --fast5 none --real --file-reads 4096 2>&1 | tail -4; done
+# 128-read worker calls over multi-read FAST5 files (no bundle), real context: batch table / plain run / + fused decode and pass (shipped) / + page-locked call arenas
+(for env in PXG_NO_PLAIN_RUN_FAST5=1 PXG_NO_FUSED_CALL=1 PXG_X=1 PXG_PIN_CALL_ARENAS=1; do echo "## $env"; env $env timeout 600 python tools/dev/host_cap.py --fast5 none --real --file-reads 4096 2>&1 | tail -4; done
  echo "## vbz"; timeout 600 python tools/dev/host_cap.py --fast5 vbz --real --file-reads 4096 2>&1 | tail -4) > $OUT/api_128_read_calls_fast5.txt 2>&1
 cat $OUT/api_128_read_calls_fast5.txt
 B="python bench.py --cpu-sample 0 --cpu-all-cores-sample 0 --no-api-leg --no-fast5-leg --no-e2e-leg --no-f32-leg --no-run-shaped-leg --no-full-leg --no-latency-leg"
