@@ -850,7 +850,8 @@ class FileRunColumns:
         batch = Fast5Batch.from_runs([(f, name, 0, f.n)])
         self.whole = batch.plan(arenas=False)
         self.meta = batch.bundle(self.whole)
-        self.handle = f.handle.value
+        self.meta.batch = None             # (kept with the open file: no reference back to it, it closes when its last user lets go)
+        self.handle = f.handle.value       # (a call holds the file itself for as long as it uses the handle: CallBundle.runs)
 
     def plain(self, scaler_cfg):
         return self.meta.plain_run_columns(scaler_cfg)
