@@ -89,6 +89,7 @@ def main():
     ap.add_argument('--full', action='store_true',
                     help='configs[3]-shaped calls (poly(A) + chimera scan), one at a time, no sleep: Python per read')
     ap.add_argument('--candidates-every', type=int, default=0, help='--full: every n-th read has a chimera candidate')
+    ap.add_argument('--single', action='store_true', help='--fast5: one single-read file per read (the classic input)')
     ap.add_argument('--fast5', choices=('none', 'vbz'), default=None,
                     help='the calls read a multi-read FAST5 file (the reference\'s real input) instead of a read bundle')
     ap.add_argument('--file-reads', type=int, default=4000, help='--fast5: reads in the file the calls walk through')
@@ -151,10 +152,18 @@ def fast5_calls(args):
     work = tempfile.mkdtemp(prefix='pxg_hostcap_')
     ids = ['%08x-0000-4000-8000-%012x' % (924, i) for i in range(total)]
     o = sb['offsets']
-    with Fast5Writer(os.path.join(work, 'run.fast5')) as w:
+    if args.single:
+        from poreplex_amd.fast5_write import write_single_read
+        os.makedirs(os.path.join(work, 'd'))
         for j in range(total):
-            w.add_read(ids[j], sb['arena'][o[j]:o[j + 1]], sb['calib'][j], start_time=j, channel_number=str(1 + j % 512),
-                       basecall=bcs[j], compression=None if args.fast5 == 'none' else args.fast5)
+            write_single_read(os.path.join(work, 'd', 'r%06d.fast5' % j), ids[j], sb['arena'][o[j]:o[j + 1]], sb['calib'][j],
+                              start_time=j, channel_number=str(1 + j % 512), basecall=bcs[j],
+                              compression=None if args.fast5 == 'none' else args.fast5)
+    else:
+        with Fast5Writer(os.path.join(work, 'run.fast5')) as w:
+            for j in range(total):
+                w.add_read(ids[j], sb['arena'][o[j]:o[j + 1]], sb['calib'][j], start_time=j, channel_number=str(1 + j % 512),
+                           basecall=bcs[j], compression=None if args.fast5 == 'none' else args.fast5)
     cfg = default_config(inputdir=work, outputdir=work, barcoding=True)
     SleepingContext.gpu_ms = args.gpu_ms
     if not args.real:
@@ -170,6 +179,8 @@ def fast5_calls(args):
     rec['bc_label'], rec['bc_phred'] = rng.integers(0, 4, n), rng.integers(10, 50, n)
     SleepingContext.records = rec
     calls = [[('run.fast5', r) for r in ids[k:k + n]] for k in range(0, total - n + 1, n)]
+    if args.single:
+        calls = [[('d/r%06d.fast5' % j, ids[j]) for j in range(k, k + n)] for k in range(0, total - n + 1, n)]
     first = SA.process_batch(0, calls[0], cfg)
     assert isinstance(first, list) and len(first) == n, first
     print('%s; FAST5 (%s), %d calls of %d reads; path: %s' % ('REAL context' if args.real else 'sleeping stand-in', args.fast5, len(calls), n,
