@@ -393,6 +393,7 @@ class Fast5File:
         self._ids = self._info = self._index = self._ids_array = None
         self._keys = {}
         self.size = 0
+        self._lazy = threading.Lock()        # worker threads share an open file: its lazy columns are made once
 
     @classmethod
     def from_handle(cls, path, handle, n, multi, info=None, owner=None):
@@ -407,6 +408,7 @@ class Fast5File:
         self._info = info
         self._keys = {}
         self.size = 0
+        self._lazy = threading.Lock()
         return self
 
     def close(self):
@@ -419,14 +421,16 @@ class Fast5File:
     @property
     def read_ids(self):
         if self._ids is None:
-            import ctypes as C
-            need = int(self.lib.pxg_h5_read_ids(self.handle, None, 0))
-            buf = C.create_string_buffer(max(need, 1))
-            if self.lib.pxg_h5_read_ids(self.handle, buf, need) != need:
-                raise Fast5Error('pxg_h5_read_ids failed')
-            ids = buf.raw[:need].decode(errors='replace').split('\n')[:-1] if need else []
-            self._ids = ids
-            self._index = {r: i for i, r in enumerate(ids)}
+            with self._lazy:
+                if self._ids is None:
+                    import ctypes as C
+                    need = int(self.lib.pxg_h5_read_ids(self.handle, None, 0))
+                    buf = C.create_string_buffer(max(need, 1))
+                    if self.lib.pxg_h5_read_ids(self.handle, buf, need) != need:
+                        raise Fast5Error('pxg_h5_read_ids failed')
+                    ids = buf.raw[:need].decode(errors='replace').split('\n')[:-1] if need else []
+                    self._index = {r: i for i, r in enumerate(ids)}
+                    self._ids = ids
         return self._ids
 
     def index_of(self, read_id):
@@ -445,22 +449,28 @@ class Fast5File:
         worker batch that asks for a stretch of the file in this order is recognised by ONE list comparison."""
         keys = self._keys.get(name)
         if keys is None:
-            keys = self._keys[name] = list(zip([name] * self.n, self.read_ids))
+            ids = self.read_ids
+            with self._lazy:
+                keys = self._keys.get(name)
+                if keys is None:
+                    keys = self._keys[name] = list(zip([name] * self.n, ids))
         return keys
 
     @property
     def info(self):
         """pxg_h5_read_info of every read of the file (one native call, cached)."""
         if self._info is None:
-            from . import native
-            out = np.zeros(self.n, dtype=native.H5_INFO_DTYPE)
-            import time
-            t0 = time.perf_counter()
-            rc = self.lib.pxg_h5_info_mt(self.handle, 0, self.n, out.ctypes.data, host_threads())
-            _timed('walk_s', t0)
-            if rc:
-                raise Fast5Error('pxg_h5_info failed ({})'.format(rc))
-            self._info = out
+            with self._lazy:
+                if self._info is None:
+                    from . import native
+                    out = np.zeros(self.n, dtype=native.H5_INFO_DTYPE)
+                    import time
+                    t0 = time.perf_counter()
+                    rc = self.lib.pxg_h5_info_mt(self.handle, 0, self.n, out.ctypes.data, host_threads())
+                    _timed('walk_s', t0)
+                    if rc:
+                        raise Fast5Error('pxg_h5_info failed ({})'.format(rc))
+                    self._info = out
         return self._info
 
     def signal(self, i):
@@ -528,6 +538,7 @@ class Fast5File:
 
 _OPEN, _OPEN_LOCK, _OPEN_MAX = OrderedDict(), threading.Lock(), 128
 _OPEN_BYTES = 0                      # mapped bytes of the files in _OPEN
+_OPENING = {}                        # key -> Event: files some thread is opening right now (open_fast5)
 _OPEN_MAX_BYTES = int(os.environ.get('PXG_FAST5_CACHE_BYTES', 8 << 30))     # mapped file bytes kept open
 
 
@@ -544,23 +555,34 @@ def open_fast5(path):
     keyed by path + mtime + size so that a rewritten file is opened again)."""
     st = os.stat(path)
     key = (path, st.st_mtime_ns, st.st_size)
-    with _OPEN_LOCK:
-        f = _OPEN.get(key)
-        if f is not None:
-            _OPEN.move_to_end(key)
-            return f
-    f = Fast5File(path)
-    f.size = st.st_size
     global _OPEN_BYTES
-    with _OPEN_LOCK:
-        if key not in _OPEN:
-            _OPEN_BYTES += f.size
-        _OPEN[key] = f
-        # a run walks its files once: what stays open (= mapped) is bounded in files and in bytes,
-        # the most recent ones first (a batch in flight keeps its own references)
-        while len(_OPEN) > _OPEN_MAX or (_OPEN_BYTES > _OPEN_MAX_BYTES and len(_OPEN) > 2):
-            _OPEN_BYTES -= _OPEN.popitem(last=False)[1].size
-    return f
+    while True:
+        with _OPEN_LOCK:
+            f = _OPEN.get(key)
+            if f is not None:
+                _OPEN.move_to_end(key)
+                return f
+            busy = _OPENING.get(key)
+            if busy is None:                  # this thread opens it; worker threads that reach the same file meanwhile wait
+                _OPENING[key] = busy = threading.Event()      # (32 of them walking a 4 000-read file at once is 32 walks)
+                break
+        busy.wait()
+    try:
+        f = Fast5File(path)
+        f.size = st.st_size
+        with _OPEN_LOCK:
+            if key not in _OPEN:
+                _OPEN_BYTES += f.size
+            _OPEN[key] = f
+            # a run walks its files once: what stays open (= mapped) is bounded in files and in bytes,
+            # the most recent ones first (a batch in flight keeps its own references)
+            while len(_OPEN) > _OPEN_MAX or (_OPEN_BYTES > _OPEN_MAX_BYTES and len(_OPEN) > 2):
+                _OPEN_BYTES -= _OPEN.popitem(last=False)[1].size
+        return f
+    finally:                                  # (an open that failed: the waiting threads try -- and fail -- themselves)
+        with _OPEN_LOCK:
+            _OPENING.pop(key, None)
+        busy.set()
 
 
 class OpenedFiles:
@@ -878,7 +900,11 @@ def file_run_columns(f, name):
     cache = f.__dict__.setdefault('_run_columns', {})
     cols = cache.get(name)
     if cols is None:
-        cols = cache[name] = FileRunColumns(f, name)
+        f.read_ids, f.info                     # (each takes the file's lock itself)
+        with f._lazy:
+            cols = cache.get(name)
+            if cols is None:
+                cols = cache[name] = FileRunColumns(f, name)
     return cols
 
 
@@ -1017,14 +1043,51 @@ class H5pyFast5Reader:
                 'table': table, 'move': move, 'p_model_state': pms}
 
 
-def get_read_ids(filename, basedir, bundle=None):
-    """(filename, read_id) pairs of one input file (fast5_file.py:37-58)."""
+_WARM = {'pid': None, 'pool': None}
+
+
+def warm_file(f, name):
+    """Have what worker calls need of multi-read file `f` (asked for as `name`) made in the background: its metadata
+    columns (~6 us per read) and its run columns.  A 4 000-read file takes 15-40 ms to describe, and worker threads reach
+    a new file together: whoever lists the input ahead of them -- the reference's scanner calls get_read_ids file by
+    file (pipeline.py:321-324) -- starts this, and the first call on the file finds it done or nearly so.  One helper
+    thread per process (a forked child starts its own)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with _OPEN_LOCK:
+        if _WARM['pid'] != os.getpid():
+            _WARM['pid'], _WARM['pool'] = os.getpid(), ThreadPoolExecutor(1, thread_name_prefix='pxg-warm')
+        pool = _WARM['pool']
+
+    def job():
+        try:
+            f.info
+            f.keys_for(name)
+            file_run_columns(f, name)
+        except Exception:             # noqa: BLE001  (the call that needs them reports what is wrong with the file)
+            pass
+    try:
+        return pool.submit(job)
+    except RuntimeError:              # (interpreter shutting down)
+        return None
+
+
+def get_read_ids(filename, basedir, bundle=None, warm=None):
+    """(filename, read_id) pairs of one input file (fast5_file.py:37-58).  `warm`: start warm_file for a multi-read
+    file; by default when this process runs worker calls itself (a thread pool in place of the reference's process pool:
+    INTEGRATION.md section 6) -- in a parent of worker PROCESSES nobody would use what it makes."""
     if bundle is not None and bundle.has_file(filename):
         return bundle.read_ids_of(filename)
     path = os.path.join(basedir, filename) if basedir is not None else filename
     try:
         f = open_fast5(path)
-        return [(filename, rid) for rid in f.read_ids]
+        if not f.multi:
+            return [(filename, rid) for rid in f.read_ids]
+        if warm is None:
+            import sys
+            warm = f.n >= 64 and '__poreplex_amd_persistence' in sys.modules and not os.environ.get('PXG_NO_FILE_WARMUP')
+        if warm:
+            warm_file(f, filename)
+        return list(f.keys_for(filename))      # (the tuples worker calls are compared with: fast5_runs)
     except Fast5Error as exc:
         if getattr(exc, 'code', 0) != -6 or h5py is None:
             raise OSError(str(exc))
@@ -1059,7 +1122,7 @@ def get_read_ids_many(filenames, basedir, chunk=4096):
                         continue
                     except UnicodeDecodeError:
                         pass
-                out.extend(get_read_ids(name, basedir))
+                out.extend(get_read_ids(name, basedir, warm=False))      # (a listing of the whole run: nothing to warm yet)
         finally:
             opened.close()
     return out

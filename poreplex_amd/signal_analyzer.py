@@ -204,11 +204,15 @@ class SignalAnalyzer(AbstractContextManager):
             return None
         t0 = time.perf_counter()
         batch = None
+        if from_files:
+            runs = loader.fast5_call_runs(reads)      # (may open a file: not under the phase lock)
+            if runs is None:
+                return None
         with phase:
             n = len(reads)
             if from_files:
                 # the per-call bundle: laid out and described from the files' cached metadata; nothing is decoded yet
-                batch = loader.fast5_run_plan(reads)
+                batch = loader.fast5_run_plan(reads, runs)
                 if batch is None:
                     return None
                 self.call_arena, layout, plain, first = batch.arena, batch.layout, batch.plain, batch.first

@@ -749,16 +749,28 @@ class SignalLoader:
             pos += count
         return runs
 
-    def fast5_run_plan(self, reads):
+    def fast5_call_runs(self, reads):
+        """fast5_runs for a worker call, with everything that is made once per FILE made now: the open itself (a
+        4 000-read file takes 15-20 ms to walk), its read ids and metadata, its run columns and their plain-run view.
+        SignalAnalyzer.process_plain_run calls this OUTSIDE the host phase lock, so that the thread that meets a new
+        file first pays for it alone (open_fast5 lets the others that reach the file meanwhile wait for that one walk)."""
+        from .fast5_file import file_run_columns
+        if self.bundle is not None and any(self.bundle.has_file(name) for name in {key[0] for key in reads}):
+            return None                        # (a call that mixes bundle reads and files: the general path sorts it out)
+        runs = self.fast5_runs(reads)
+        if runs is not None and len(runs) == 1:
+            file_run_columns(runs[0][0], runs[0][1]).plain(self.scaler_cfg)
+        return runs
+
+    def fast5_run_plan(self, reads, runs=None):
         """The per-call read bundle of a worker call that is stretches of multi-read FAST5 files in file order
         (fast5_runs), laid out from the files' cached metadata with NOTHING decoded yet -- a CallBundle, its sample arena
         from the loader's pool (`call_arenas`: memory a call before it has touched; the caller gives it back); None: not
         such a call.  A run of ONE file (all but the calls that cross a file boundary) is a dozen slices of columns kept
         with the open file (fast5_file.FileRunColumns); several files: a bundle of the call's own."""
         from .fast5_file import Fast5Batch, file_run_columns
-        if self.bundle is not None and any(self.bundle.has_file(name) for name in {key[0] for key in reads}):
-            return None                        # (a call that mixes bundle reads and files: the general path sorts it out)
-        runs = self.fast5_runs(reads)
+        if runs is None:
+            runs = self.fast5_call_runs(reads)
         if runs is None:
             return None
         taken = []

@@ -745,3 +745,85 @@ def test_two_thousand_fast5_reads_through_the_gpu_session(tmp_path):
         assert files_a[name] == files_b[name], name
     assert a['labels'].tobytes() == b['labels'].tobytes() and np.array_equal(a['counts'], b['counts'])
     assert files_a['sequencing_summary.txt'].count(b'\n') > 1500
+
+
+def test_worker_threads_that_reach_a_new_file_together_open_it_once(tmp_path):
+    """open_fast5 from many threads at once: one of them walks the file, the others wait for it; the file's lazy columns
+    (read ids, metadata, the run columns of worker calls) are made once as well."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    path = str(tmp_path / 'm.fast5')
+    rng = np.random.default_rng(3)
+    cal = np.zeros(1, dtype=N.CALIB_DTYPE)
+    cal['range'], cal['digitisation'], cal['sampling_rate'] = 1400.0, 8192.0, 3012.0
+    with Fast5Writer(path) as w:
+        for j in range(40):
+            w.add_read('{:036d}'.format(j), rng.integers(300, 900, 9000).astype(np.int16), cal[0], start_time=j)
+    F5.clear_open_cache()
+    opened, described = [], []
+    real_init, real_cols = F5.Fast5File.__init__, F5.FileRunColumns.__init__
+
+    def init(self, p):
+        opened.append(p)
+        real_init(self, p)
+
+    def cols(self, f, name):
+        described.append(name)
+        real_cols(self, f, name)
+    F5.Fast5File.__init__, F5.FileRunColumns.__init__ = init, cols
+    try:
+        gate = threading.Barrier(16)
+
+        def worker(k):
+            gate.wait()
+            f = F5.open_fast5(path)
+            c = F5.file_run_columns(f, 'm.fast5')
+            return id(f), id(c), len(f.read_ids), int(f.info['n_samples'].sum())
+        with ThreadPoolExecutor(16) as pool:
+            got = list(pool.map(worker, range(16)))
+    finally:
+        F5.Fast5File.__init__, F5.FileRunColumns.__init__ = real_init, real_cols
+        F5.clear_open_cache()
+    assert len(set(got)) == 1 and got[0][2:] == (40, 40 * 9000)
+    assert opened == [path] and described == ['m.fast5']
+    # a file that cannot be opened: every thread gets the error, nobody waits forever
+    bad = str(tmp_path / 'bad.fast5')
+    with open(bad, 'wb') as fh:
+        fh.write(b'not an HDF5 file')
+
+    def failing(k):
+        try:
+            F5.open_fast5(bad)
+        except (OSError, F5.Fast5Error) as exc:
+            return type(exc).__name__
+        return None
+    with ThreadPoolExecutor(8) as pool:
+        assert all(pool.map(failing, range(8)))
+
+
+def test_listing_a_file_warms_it_for_the_worker_threads_of_the_same_process(tmp_path, monkeypatch):
+    """get_read_ids in a process that runs worker calls itself (the worker storage exists) starts warm_file: the file's
+    metadata and run columns are there before the first call asks; in any other process, and from get_read_ids_many
+    (a listing of the whole run), nothing is started."""
+    import sys
+    import types
+    path = str(tmp_path / 'm.fast5')
+    cal = np.zeros(1, dtype=N.CALIB_DTYPE)
+    cal['range'], cal['digitisation'], cal['sampling_rate'] = 1400.0, 8192.0, 3012.0
+    rng = np.random.default_rng(4)
+    with Fast5Writer(path) as w:
+        for j in range(70):
+            w.add_read('{:036d}'.format(j), rng.integers(300, 900, 9000).astype(np.int16), cal[0], start_time=j)
+    F5.clear_open_cache()
+    monkeypatch.delitem(sys.modules, WorkerPersistenceStorage.STORAGE_NAME, raising=False)
+    keys = F5.get_read_ids('m.fast5', str(tmp_path))
+    assert len(keys) == 70 and keys[3] == ('m.fast5', '{:036d}'.format(3))
+    f = F5.open_fast5(path)
+    assert f._info is None and '_run_columns' not in f.__dict__
+    assert F5.get_read_ids_many(['m.fast5'], str(tmp_path)) == keys and f._info is None
+    monkeypatch.setitem(sys.modules, WorkerPersistenceStorage.STORAGE_NAME, types.ModuleType('x'))
+    assert F5.get_read_ids('m.fast5', str(tmp_path)) == keys
+    F5._WARM['pool'].submit(lambda: None).result(timeout=30)         # (one helper thread: behind the warm-up job)
+    assert f._info is not None and 'm.fast5' in f.__dict__['_run_columns']
+    assert keys[5] is f.keys_for('m.fast5')[5]                       # the tuples worker calls are compared with
+    F5.clear_open_cache()

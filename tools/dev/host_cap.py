@@ -89,6 +89,8 @@ def main():
     ap.add_argument('--full', action='store_true',
                     help='configs[3]-shaped calls (poly(A) + chimera scan), one at a time, no sleep: Python per read')
     ap.add_argument('--candidates-every', type=int, default=0, help='--full: every n-th read has a chimera candidate')
+    ap.add_argument('--files', type=int, default=1, help='--fast5: the reads in this many multi-read files, every timed pass '
+                    'with the reader\'s file cache emptied first (a run meets new files all the time)')
     ap.add_argument('--single', action='store_true', help='--fast5: one single-read file per read (the classic input)')
     ap.add_argument('--fast5', choices=('none', 'vbz'), default=None,
                     help='the calls read a multi-read FAST5 file (the reference\'s real input) instead of a read bundle')
@@ -160,10 +162,12 @@ def fast5_calls(args):
                               start_time=j, channel_number=str(1 + j % 512), basecall=bcs[j],
                               compression=None if args.fast5 == 'none' else args.fast5)
     else:
-        with Fast5Writer(os.path.join(work, 'run.fast5')) as w:
-            for j in range(total):
-                w.add_read(ids[j], sb['arena'][o[j]:o[j + 1]], sb['calib'][j], start_time=j, channel_number=str(1 + j % 512),
-                           basecall=bcs[j], compression=None if args.fast5 == 'none' else args.fast5)
+        per_file = -(-total // args.files // n) * n
+        for lo in range(0, total, per_file):
+            with Fast5Writer(os.path.join(work, 'run.fast5' if args.files == 1 else 'run%03d.fast5' % (lo // per_file))) as w:
+                for j in range(lo, min(lo + per_file, total)):
+                    w.add_read(ids[j], sb['arena'][o[j]:o[j + 1]], sb['calib'][j], start_time=j, channel_number=str(1 + j % 512),
+                               basecall=bcs[j], compression=None if args.fast5 == 'none' else args.fast5)
     cfg = default_config(inputdir=work, outputdir=work, barcoding=True)
     SleepingContext.gpu_ms = args.gpu_ms
     if not args.real:
@@ -181,6 +185,8 @@ def fast5_calls(args):
     calls = [[('run.fast5', r) for r in ids[k:k + n]] for k in range(0, total - n + 1, n)]
     if args.single:
         calls = [[('d/r%06d.fast5' % j, ids[j]) for j in range(k, k + n)] for k in range(0, total - n + 1, n)]
+    elif args.files > 1:
+        calls = [[('run%03d.fast5' % (k // per_file), r) for r in ids[k:k + n]] for k in range(0, total - n + 1, n)]
     first = SA.process_batch(0, calls[0], cfg)
     assert isinstance(first, list) and len(first) == n, first
     print('%s; FAST5 (%s), %d calls of %d reads; path: %s' % ('REAL context' if args.real else 'sleeping stand-in', args.fast5, len(calls), n,
@@ -196,10 +202,23 @@ def fast5_calls(args):
     for threads in (8, 32):
         rates = []
         for _ in range(args.repeats):
+            if args.files > 1:
+                from poreplex_amd.fast5_file import clear_open_cache
+                clear_open_cache()
             with ThreadPoolExecutor(threads) as pool:
                 t0 = time.perf_counter()
-                list(pool.map(lambda k: len(SA.process_batch(100 + k, calls[k % len(calls)], cfg)), range(args.calls)))
-                rates.append(args.calls / (time.perf_counter() - t0))
+                if args.files > 1:
+                    # as the reference's pipeline does it (pipeline.py:321-324): the scanner lists a file, then the calls
+                    # over its reads are handed to the workers -- here threads of this process
+                    from poreplex_amd.fast5_file import get_read_ids
+                    futures = []
+                    for name in sorted({c[0][0] for c in calls}):
+                        listed = get_read_ids(name, work)
+                        futures += [pool.submit(SA.process_batch, 100 + k, listed[k:k + n], cfg) for k in range(0, len(listed), n)]
+                    assert all(len(f.result()) == n for f in futures) and len(futures) == len(calls)
+                else:
+                    list(pool.map(lambda k: len(SA.process_batch(100 + k, calls[k % len(calls)], cfg)), range(args.calls)))
+                rates.append((len(calls) if args.files > 1 else args.calls) / (time.perf_counter() - t0))
         print('%2d threads: best %5.0f calls/s = %6.0f reads/s (%.3f ms of wall clock per call); all: %s'
               % (threads, max(rates), max(rates) * n, 1e3 / max(rates), ' '.join('%.0f' % r for r in rates)))
     WorkerPersistenceStorage.reset()
