@@ -180,7 +180,7 @@ class SignalAnalyzer(AbstractContextManager):
     def process_plain_run(self, reads, phase):
         """process() for the usual worker call, without a batch table: `reads` is a run of consecutive reads of the
         read bundle -- or of multi-read FAST5 files, in file order: the per-call bundle the native reader makes of them
-        (SignalLoader.fast5_run_bundle) --, all of them long enough for the scaler and regular in their basecall summary
+        (SignalLoader.fast5_run_plan) --, all of them long enough for the scaler and regular in their basecall summary
         (ReadBundle.plain_run_columns), and the configuration asks for nothing that walks every read (dumps, on-the-fly
         basecalling, the opt-in adapter trimming).  The samples go to the GPU as the bundle's own arena, the records
         (spike rows, scan candidates) come back, and csrc/pxg_pyreport.c report_run applies the status / label rules and
@@ -205,14 +205,20 @@ class SignalAnalyzer(AbstractContextManager):
         t0 = time.perf_counter()
         batch = None
         if from_files:
-            runs = loader.fast5_call_runs(reads)      # (may open a file: not under the phase lock)
+            try:
+                runs = loader.fast5_call_runs(reads)      # (may open a file: not under the phase lock)
+            except Exception:             # noqa: BLE001  (an odd file: the general path says what is wrong with it, per read)
+                runs = None
             if runs is None:
                 return None
         with phase:
             n = len(reads)
             if from_files:
                 # the per-call bundle: laid out and described from the files' cached metadata; nothing is decoded yet
-                batch = loader.fast5_run_plan(reads, runs)
+                try:
+                    batch = loader.fast5_run_plan(reads, runs)
+                except Exception:         # noqa: BLE001
+                    batch = None
                 if batch is None:
                     return None
                 self.call_arena, layout, plain, first = batch.arena, batch.layout, batch.plain, batch.first
