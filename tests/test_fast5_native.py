@@ -827,3 +827,40 @@ def test_listing_a_file_warms_it_for_the_worker_threads_of_the_same_process(tmp_
     assert f._info is not None and 'm.fast5' in f.__dict__['_run_columns']
     assert keys[5] is f.keys_for('m.fast5')[5]                       # the tuples worker calls are compared with
     F5.clear_open_cache()
+
+
+def test_batch_columns_from_the_files_run_columns_equal_the_batchs_own(tmp_path, monkeypatch):
+    """Fast5Batch.bundle for stretches of multi-read files takes its metadata columns as slices of FileRunColumns
+    (made once per file); the same batch described from its own metadata (PXG_NO_RUN_COLUMNS_IN_BATCHES) has equal
+    columns, one run or several."""
+    sb = synth_batch(90, seed=8, samples_per_read=9000)
+    bcs = synth_basecalls(sb, seed=8)
+    o = sb['offsets']
+    files = []
+    for k, (lo, hi) in enumerate([(0, 50), (50, 90)]):
+        path = str(tmp_path / 'f{}.fast5'.format(k))
+        with Fast5Writer(path) as w:
+            for j in range(lo, hi):
+                w.add_read('{:08x}-{:027d}'.format(8, j), sb['arena'][o[j]:o[j + 1]], sb['calib'][j], start_time=7 * j,
+                           channel_number=str(1 + j % 3), run_id='run{}'.format(k), sample_id='s',
+                           basecall=None if j % 11 == 5 else bcs[j])
+        files.append(F5.open_fast5(path))
+    for runs in ([(files[0], 'a/f0.fast5', 10, 25)], [(files[0], 'a/f0.fast5', 40, 10), (files[1], 'f1.fast5', 0, 33)]):
+        monkeypatch.setattr(F5, '_RUN_COLUMNS_IN_BATCHES', True)
+        fast = F5.Fast5Batch.from_runs(runs).as_bundle()
+        monkeypatch.setattr(F5, '_RUN_COLUMNS_IN_BATCHES', False)
+        own = F5.Fast5Batch.from_runs(runs).as_bundle()
+        assert set(fast.d) == set(own.d)
+        for key in own.d:
+            a, b = np.asarray(fast.d[key]), np.asarray(own.d[key])
+            assert a.shape == b.shape and a.dtype.kind == b.dtype.kind, key
+            assert a.tobytes() == b.tobytes() if a.dtype.kind not in 'US' else a.tolist() == b.tolist(), key
+        cfg = {'length': 30000, 'stride': 15, 'min_length': 4500}
+        pf, po = fast.plain_run_columns(cfg), own.plain_run_columns(cfg)
+        assert pf is not None and set(pf) == set(po)
+        for key in po:
+            if isinstance(po[key], np.ndarray):
+                assert np.asarray(pf[key]).tolist() == po[key].tolist(), key
+            else:
+                assert pf[key] == po[key], key
+    F5.clear_open_cache()
