@@ -630,7 +630,7 @@ class SignalLoader:
         """Open the FAST5 files of a coming batch (handle, read ids, metadata columns: all cached by
         fast5_file.open_fast5) -- the session's loader thread runs this beside the batch it is
         decoding.  Errors are left to prepare_many, which reports them per read."""
-        from .fast5_file import open_fast5
+        from .fast5_file import file_run_columns, open_fast5
         if not reads or (self.bundle is not None and self.bundle.has_file(reads[0][0])):
             return
         files = dict.fromkeys(key[0] for key in reads)
@@ -642,6 +642,7 @@ class SignalLoader:
                 f.read_ids, f.info
                 if f.multi:
                     f.read_ids_array, f.keys_for(filename)
+                    file_run_columns(f, filename)            # (what the batch's bundle slices its metadata columns from)
             except Exception:             # noqa: BLE001
                 pass
 
