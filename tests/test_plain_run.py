@@ -704,3 +704,44 @@ def test_without_the_extension_every_call_takes_the_batch_table(crafted, monkeyp
     without = SA.process_batch(0, list(reads), cfg)
     assert taken == [False]
     same(without, with_extension)
+
+
+def test_call_arenas_pool():
+    """SignalLoader's pool of sample arenas: the warmest arena that fits comes back, one that is too small makes room,
+    at most `keep` wait; with a context the arenas are page-locked mappings of their own, never dropped, released once."""
+    from poreplex_amd.signal_loader import CallArenas
+    pool = CallArenas(keep=2)
+    a = pool.take(1000)
+    assert a.dtype == np.int16 and len(a) >= 1 << 20
+    pool.give(a)
+    assert pool.take(10) is a                      # the one given back last
+    big = pool.take(3 << 20)
+    assert len(big) >= 3 << 20 and big is not a
+    pool.give(a)
+    pool.give(big)
+    third = np.empty(8, np.int16)
+    pool.give(third)
+    assert len(pool.free) == 2                     # (keep = 2)
+    assert pool.take(2 << 20) is big and pool.take(5) is a
+    pool.give(a)
+    huge = pool.take(8 << 20)                      # nothing fits: the small one makes room
+    assert len(huge) >= 8 << 20 and pool.free == []
+
+    class Ctx:
+        pinned, unpinned = [], []
+
+        def pin(self, arr):
+            self.pinned.append(arr.ctypes.data)
+
+        def unpin(self, arr):
+            self.unpinned.append(arr.ctypes.data)
+    ctx = Ctx()
+    locked = CallArenas(keep=1, ctx=ctx)
+    x, y = locked.take(100), locked.take(100)
+    assert x.ctypes.data % 4096 == 0 and len(ctx.pinned) == 2
+    locked.give(x)
+    locked.give(y)
+    assert len(locked.free) == 2                   # a page-locked arena is never just dropped
+    assert locked.take(50) is y
+    locked.release()
+    assert sorted(ctx.unpinned) == sorted(ctx.pinned) and locked.free == [] and locked.locked == []
