@@ -319,6 +319,21 @@ class _Fast5BatchBundle(ReadBundle):
                 self._by_file.setdefault(f, []).append(i)
         return self._by_file
 
+    def text_lists(self, idx):
+        """(channel numbers, run ids, sample ids) of ALL the bundle's reads as Python lists, when `idx` asks for all of
+        them in order and the batch is stretches of multi-read files: slices of lists kept with the open files
+        (FileRunColumns.texts) instead of three .tolist() of 10 000 fresh strings per batch.  None: the columns."""
+        runs = getattr(self.batch, 'runs', None)
+        n = len(self.filenames)
+        if runs is None or not _RUN_COLUMNS_IN_BATCHES or len(idx) != n or (n and (idx[0] != 0 or idx[-1] != n - 1)):
+            return None
+        out = ([], [], [])
+        for f, name, i0, count in runs:
+            lists = file_run_columns(f, name).texts()
+            for k in range(3):
+                out[k].extend(lists[k][i0:i0 + count])
+        return out
+
     def basecall_of(self, i, move_as_array=False):
         """The per-read path (chimera candidates, Events tables): straight from the file, so a
         p_model_state column comes along."""
@@ -744,7 +759,13 @@ class Fast5Batch:
                 e += 1
             info[k:e] = f.info[self.index[k:e]]
             k = e
-        self.info = info
+        self._info = info
+
+    @property
+    def info(self):
+        if self._info is None:
+            self._info = np.concatenate([f.info[i0:i0 + count] for f, _, i0, count in self.runs])
+        return self._info
 
     @classmethod
     def from_runs(cls, runs):
@@ -755,7 +776,7 @@ class Fast5Batch:
         self.runs, self._files = list(runs), None
         lens = [count for _, _, _, count in runs]
         self.index = np.concatenate([np.arange(i0, i0 + count, dtype=np.int64) for _, _, i0, count in runs])
-        self.info = np.concatenate([f.info[i0:i0 + count] for f, _, i0, count in runs])
+        self._info = None                  # (info: the metadata records of the batch's reads, copied when somebody asks)
         self.names, self.read_ids = [], []
         for f, name, i0, count in runs:
             self.names += [name] * count
@@ -778,7 +799,7 @@ class Fast5Batch:
         self = cls.__new__(cls)
         self.runs, self._files, self.opened, self.which = None, None, opened, np.asarray(which, dtype=np.int64)
         self.index = np.zeros(len(self.which), dtype=np.int64)
-        self.info = opened.info[self.which]
+        self._info = opened.info[self.which]
         self.names, self.read_ids = list(names), list(read_ids)
         self.handles = np.ascontiguousarray(opened.handles[self.which])
         self.name_array = self.id_array = None
@@ -799,19 +820,28 @@ class Fast5Batch:
         arenas made here (`reserve(n_samples)` -> the int16 arena: a staging buffer) -- from the metadata alone, before
         anything is decoded.  decode() fills the arenas, bundle() is the ReadBundle over them.  arenas=False: the
         layout alone (empty arenas: FileRunColumns describes a whole file this way)."""
-        info, n = self.info, len(self.index)
+        n = len(self.index)
         handles = self.handles if self.handles is not None else \
             np.array([f.handle.value for f in self.files], dtype=np.uintp)
-        ns = info['n_samples'].astype(np.int64)
+        if self.runs is not None and arenas and _RUN_COLUMNS_IN_BATCHES and len(self.runs) <= 64:
+            # (stretches of multi-read files: the lengths are slices of what is kept with every open file)
+            wholes = [(file_run_columns(f, name).whole, i0, count) for f, name, i0, count in self.runs]
+            ns, present, seq_len, n_moves = (
+                np.concatenate([w[key][i0:i0 + count] for w, i0, count in wholes]) if len(wholes) > 1 else
+                np.ascontiguousarray(wholes[0][0][key][wholes[0][1]:wholes[0][1] + wholes[0][2]])
+                for key in ('n_samples', 'present', 'seq_len', 'n_moves'))
+        else:
+            info = self.info
+            ns = info['n_samples'].astype(np.int64)
+            present = info['bc_present'] != 0
+            seq_len = np.where(present, info['bc_seq_len'], 0).astype(np.int64)
+            n_moves = np.where(present, np.maximum(info['bc_n_moves'], 0), 0).astype(np.int64)
         offsets = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(ns, out=offsets[1:])
         if not arenas:
             arena = np.zeros(0, dtype=np.int16)
         else:
             arena = reserve(int(offsets[-1])) if reserve is not None else np.empty(int(offsets[-1]), dtype=np.int16)
-        present = info['bc_present'] != 0
-        seq_len = np.where(present, info['bc_seq_len'], 0).astype(np.int64)
-        n_moves = np.where(present, np.maximum(info['bc_n_moves'], 0), 0).astype(np.int64)
         seq_off = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(seq_len, out=seq_off[1:])
         move_off = np.zeros(n + 1, dtype=np.int64)
@@ -832,7 +862,7 @@ class Fast5Batch:
     def bundle(self, p):
         """The ReadBundle over plan `p` (its columns are made of the metadata; the arenas are p's, decoded or about to be)."""
         from . import native
-        info, n, offsets = self.info, p['n'], p['offsets']
+        n, offsets = p['n'], p['offsets']
         present = p['present']
         if self.runs is not None and not p.get('whole_file') and _RUN_COLUMNS_IN_BATCHES and len(self.runs) <= 64:
             # a batch of stretches of multi-read files (the session's, a worker call's that crosses a file boundary): the
@@ -849,6 +879,7 @@ class Fast5Batch:
             bundle = _Fast5BatchBundle(d, self)
             bundle.signal_status, bundle.basecall_status = p['signal_status'], p['basecall_status']
             return bundle
+        info = self.info
         calib = np.zeros(n, dtype=native.CALIB_DTYPE)
         for name in ('range', 'digitisation', 'offset', 'sampling_rate'):
             calib[name] = info['calib'][name]
@@ -907,6 +938,14 @@ class FileRunColumns:
 
     def plain(self, scaler_cfg):
         return self.meta.plain_run_columns(scaler_cfg)
+
+    def texts(self):
+        """(channel numbers, run ids, sample ids) of the file's reads as Python lists (made once)."""
+        lists = self.__dict__.get('_texts')
+        if lists is None:
+            d = self.meta.d
+            lists = self._texts = tuple(d[name].tolist() for name in ('channel_number', 'run_id', 'sample_id'))
+        return lists
 
     def layout(self, i0, n, reserve):
         """Fast5Batch.plan's dict for the reads [i0, i0 + n) of the file: arenas of the call's own, positions counted from

@@ -136,9 +136,15 @@ class ReadTable:
         else:
             self.filename += [bundle.filenames[i] for i in idx.tolist()]
             self.read_id += [bundle.read_ids[i] for i in idx.tolist()]
-        self.channel += d['channel_number'][idx].tolist()
-        self.run_id += d['run_id'][idx].tolist()
-        self.sample_id += d['sample_id'][idx].tolist()
+        texts = bundle.text_lists(idx) if hasattr(bundle, 'text_lists') else None
+        if texts is not None:             # (the lists kept with the open files: no new str per read and batch)
+            self.channel += texts[0]
+            self.run_id += texts[1]
+            self.sample_id += texts[2]
+        else:
+            self.channel += d['channel_number'][idx].tolist()
+            self.run_id += d['run_id'][idx].tolist()
+            self.sample_id += d['sample_id'][idx].tolist()
         self.pending[rows] = True            # samples wait in the bundle arena (raw stays None)
         for col in (self.raw, self.source, self.sequence, self.error_message, self.polya, self.unsplit):
             col.extend([None] * k)
