@@ -123,14 +123,17 @@ class ReadTable:
             for name in ('scale_shift', 'calib', 'gpu_row', 'bundle_index'):
                 setattr(self, name, _grown(getattr(self, name), hi))
         rows = np.arange(lo, hi)
-        self.status[rows], self.label[rows], self.gpu_row[rows] = _OKAY, _NO_LABEL, -1
-        self.bundle, self.bundle_index[rows] = bundle, idx
-        self.start_time[rows], self.duration[rows] = d['start_time'][idx], d['duration'][idx]
-        self.calib[rows] = d['calib'][idx]
-        self.sampling_rate[rows] = d['calib']['sampling_rate'][idx]
+        run = bool(k and idx[-1] - idx[0] == k - 1 and (k == 1 or (np.diff(idx) == 1).all()))
+        # (a run of the bundle's reads -- the usual batch -- is slices on both sides, not 10 000-element index arrays)
+        at, src = (slice(lo, hi), slice(int(idx[0]), int(idx[0]) + k)) if run else (rows, idx)
+        self.status[at], self.label[at], self.gpu_row[at] = _OKAY, _NO_LABEL, -1
+        self.bundle, self.bundle_index[at] = bundle, idx
+        self.start_time[at], self.duration[at] = d['start_time'][src], d['duration'][src]
+        self.calib[at] = d['calib'][src]
+        self.sampling_rate[at] = d['calib']['sampling_rate'][src]
         o = d['offsets']
-        self.n_raw[rows] = o[idx + 1] - o[idx]
-        if k and idx[-1] - idx[0] == k - 1 and (k == 1 or (np.diff(idx) == 1).all()):
+        self.n_raw[at] = (o[int(idx[0]) + 1:int(idx[0]) + k + 1] - o[int(idx[0]):int(idx[0]) + k]) if run else o[idx + 1] - o[idx]
+        if run:
             self.filename += bundle.filenames[int(idx[0]):int(idx[-1]) + 1]
             self.read_id += bundle.read_ids[int(idx[0]):int(idx[-1]) + 1]
         else:
@@ -145,7 +148,7 @@ class ReadTable:
             self.channel += d['channel_number'][idx].tolist()
             self.run_id += d['run_id'][idx].tolist()
             self.sample_id += d['sample_id'][idx].tolist()
-        self.pending[rows] = True            # samples wait in the bundle arena (raw stays None)
+        self.pending[at] = True              # samples wait in the bundle arena (raw stays None)
         for col in (self.raw, self.source, self.sequence, self.error_message, self.polya, self.unsplit):
             col.extend([None] * k)
         return rows
