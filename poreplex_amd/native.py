@@ -744,7 +744,9 @@ class BatchExCall:
 
     def __init__(self, ctx, n, stage_mask, unsplit, want_spikes):
         self.ctx, self.n, self.stage_mask = ctx, n, stage_mask
-        self.function = C.cast(ctx.lib.pxg_process_batch_ex, C.c_void_p).value
+        self.function = ctx.__dict__.get('_batch_ex_address')
+        if self.function is None:
+            self.function = ctx._batch_ex_address = C.cast(ctx.lib.pxg_process_batch_ex, C.c_void_p).value
         self.handle = ctx.handle.value if hasattr(ctx.handle, 'value') else int(ctx.handle)
         x = self.x = PxgBatchExtras()
         x.struct_bytes = C.sizeof(PxgBatchExtras)

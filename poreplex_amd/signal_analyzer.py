@@ -50,6 +50,7 @@ _PLAIN_RUN = os.environ.get('PXG_NO_PLAIN_RUN') is None
 _BULK_UNSPLIT = os.environ.get('PXG_NO_BULK_UNSPLIT') is None      # (A/B and tests: candidates judged read by read)
 _PLAIN_RUN_FAST5 = os.environ.get('PXG_NO_PLAIN_RUN_FAST5') is None    # (A/B: only bundle reads take the short path)
 _FUSED_CALL = os.environ.get('PXG_NO_FUSED_CALL') is None         # (A/B: FAST5 decode and GPU pass as separate native calls)
+_WORKER_IDS = {}            # process name -> the 16 hex digits dump files carry (signal_analyzer.py:163)
 PLAIN_RUN_CALLS = 0         # worker calls that took SignalAnalyzer.process_plain_run (bench.py reports it)
 
 
@@ -139,7 +140,8 @@ class SignalAnalyzer(AbstractContextManager):
         self.dump_adapter = bool(config.get('dump_adapter_signals'))
         self.loader.dump_adapter = self.dump_adapter
         self.dump_events = self.loader.dump_events = bool(config.get('dump_basecalls'))
-        self.workerid = sha1(mp.current_process().name.encode()).hexdigest()[:16]
+        name = mp.current_process().name
+        self.workerid = _WORKER_IDS.get(name) or _WORKER_IDS.setdefault(name, sha1(name.encode()).hexdigest()[:16])
         self.begin_dumps(batchid)
         self.loader.stage_mask = (
             native.STAGE_SCALER | native.STAGE_SEGMENT

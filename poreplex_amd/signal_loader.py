@@ -820,12 +820,16 @@ class SignalLoader:
         """(decoded, rc): the samples and the basecall text of `layout` decoded and -- when all of it arrived -- the
         prepared pxg_process_batch_ex `call` made over them, behind ONE release of the interpreter lock
         (csrc/pxg_pyreport.c decode_and_run: the native functions by address)."""
-        import ctypes as C
         from .fast5_file import host_threads
-        lib = native.load_text_library()
+        entry = self.__dict__.get('_decode_entry')
+        if entry is None:                 # the two readers' addresses: looked up once
+            import ctypes as C
+            lib = native.load_text_library()
+            entry = self._decode_entry = (C.cast(lib.pxg_h5_load_signals, C.c_void_p).value,
+                                          C.cast(lib.pxg_h5_basecall_many, C.c_void_p).value)
         p = layout
         return fast.decode_and_run(
-            C.cast(lib.pxg_h5_load_signals, C.c_void_p).value, C.cast(lib.pxg_h5_basecall_many, C.c_void_p).value,
+            entry[0], entry[1],
             call.function, int(threads or host_threads()),
             p['handles'], p['index'], p['dst'], p['n_samples'], p['arena'], p['signal_status'],
             p['seq_start'], p['seq_len'], p['seq_arena'], p['qual_arena'], p['move_start'], p['n_moves'], p['move_arena'],
