@@ -363,13 +363,14 @@ static int need_rows(const Buf* b, const char* name, Py_ssize_t rows)
 
 static PyObject* report_run(PyObject* self, PyObject* args)
 {
-    PyObject *cols, *rec_obj, *status_names, *label_names, *spikes_obj = Py_None, *spike_off_obj = Py_None, *skip_obj = Py_None;
+    PyObject *cols, *rec_obj, *status_names, *label_names, *spikes_obj = Py_None, *spike_off_obj = Py_None, *skip_obj = Py_None,
+             *short_obj = Py_None;
     Py_ssize_t first, n;
     int adapter, barcoding, polya = 0;
     long long min_seq_len;
-    if (!PyArg_ParseTuple(args, "O!nnOipLO!O!|pOOO", &PyDict_Type, &cols, &first, &n, &rec_obj, &adapter, &barcoding,
+    if (!PyArg_ParseTuple(args, "O!nnOipLO!O!|pOOOO", &PyDict_Type, &cols, &first, &n, &rec_obj, &adapter, &barcoding,
                           &min_seq_len, &PyTuple_Type, &status_names, &PyTuple_Type, &label_names, &polya, &spikes_obj,
-                          &spike_off_obj, &skip_obj))
+                          &spike_off_obj, &skip_obj, &short_obj))
         return NULL;
     if (first < 0 || n < 0 || adapter < 0 || adapter >= PXG_N_SEGMENTS || PyTuple_GET_SIZE(status_names) < PXG_N_STATUS ||
         PyTuple_GET_SIZE(label_names) < 2) {
@@ -377,9 +378,9 @@ static PyObject* report_run(PyObject* self, PyObject* args)
         return NULL;
     }
     Buf rec, start_time, duration, calib, present, seq_len, qscore, n_events, seq_off, seq_arena, qual_arena, channel,
-        run_id, sample_id, spikes, spike_off, skip;
+        run_id, sample_id, spikes, spike_off, skip, too_short;
     Buf* all[] = { &rec, &start_time, &duration, &calib, &present, &seq_len, &qscore, &n_events, &seq_off, &seq_arena,
-                   &qual_arena, &channel, &run_id, &sample_id, &spikes, &spike_off, &skip };
+                   &qual_arena, &channel, &run_id, &sample_id, &spikes, &spike_off, &skip, &too_short };
     for (size_t k = 0; k < sizeof(all) / sizeof(all[0]); k++) all[k]->held = 0;
     PyObject* out = NULL;
     const Py_ssize_t last = first + n;         /* reads [first, last) of the bundle */
@@ -422,6 +423,16 @@ static PyObject* report_run(PyObject* self, PyObject* args)
             goto done;
         }
     }
+    /* reads too short for the scaler (the gate of load_padded_signal_head, signal_loader.py:212-222, decided on the host
+     * from the read's metadata): 'scaler_signal_too_short', whatever the pass made of their samples */
+    if (short_obj != Py_None) {
+        if (PyObject_GetBuffer(short_obj, &too_short.view, PyBUF_C_CONTIGUOUS) < 0) goto done;
+        too_short.held = 1;
+        if (too_short.view.itemsize != 1 || too_short.view.len < n) {
+            PyErr_SetString(PyExc_TypeError, "report_run: short must be a bool per read");
+            goto done;
+        }
+    }
     PyObject *filenames = get_list(cols, "filenames", 0), *read_ids = get_list(cols, "read_ids", 0);
     if (!filenames || !read_ids) goto done;
     /* `seq_base`: the text arenas hold the reads of THIS call only (a run of a FAST5 file whose other columns describe the
@@ -452,7 +463,9 @@ static PyObject* report_run(PyObject* self, PyObject* args)
             /* the rules, in the order the general path applies them (signal_loader.attach_records,
              * SignalAnalyzer.judge, BarcodeDemultiplexer.assign, SignalAnalyzer.bulk_base_space) */
             int status = PXG_ST_OKAY, label = -1, called = 0, summary = 0, tail = 0;
-            if (r->status == PXG_ST_SCALING_QC_FAIL) {
+            if (too_short.held && ((const uint8_t*)too_short.view.buf)[k]) {
+                status = PXG_ST_SCALER_SIGNAL_TOO_SHORT;             /* (:220-222: stops before the scaler, without a label) */
+            } else if (r->status == PXG_ST_SCALING_QC_FAIL) {
                 status = PXG_ST_SCALING_QC_FAIL;                     /* (:108-109: stops without a label) */
             } else if (r->seg_first[adapter] < 0) {
                 status = PXG_ST_ADAPTER_NOT_DETECTED, label = 1;     /* 'fail' */

@@ -219,6 +219,9 @@ class ReadBundle:
             strides = np.unique(frame[frame[:, 1] > 0, 2])
             kmer = (d['seq_offsets'][1:] - d['seq_offsets'][:-1]) - d['bc_move_sum'] + 1
             plain = {'ok': long_enough & (~present | regular), 'offsets': o,
+                     # (the two halves of `ok`: a read too short for the scaler may sit in a plain run -- its dict says so and
+                     #  comes first, as the reference returns it --, an irregular basecall summary may not)
+                     'long_enough': long_enough, 'regular': ~present | regular,
                      'frame_first': np.ascontiguousarray(frame[:, 0]), 'frame_blocks': np.ascontiguousarray(frame[:, 1]),
                      'frame_stride': int(strides[0]) if len(strides) == 1 else None,
                      'kmer_ok': ~fits | (kind == 2) | (kmer == 5) | (kmer == 1),

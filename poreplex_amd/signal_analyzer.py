@@ -49,6 +49,9 @@ _USE_HOST_PHASE = os.environ.get('PXG_NO_HOST_PHASE_LOCK') is None
 _PLAIN_RUN = os.environ.get('PXG_NO_PLAIN_RUN') is None
 _BULK_UNSPLIT = os.environ.get('PXG_NO_BULK_UNSPLIT') is None      # (A/B and tests: candidates judged read by read)
 _PLAIN_RUN_FAST5 = os.environ.get('PXG_NO_PLAIN_RUN_FAST5') is None    # (A/B: only bundle reads take the short path)
+# reads too short for the scaler inside a plain run: True (they ride along), False (such a call takes the batch table:
+# PXG_NO_SHORT_IN_RUN=1, the behaviour until then)
+_SHORT_IN_RUN = os.environ.get('PXG_NO_SHORT_IN_RUN') is None
 _FUSED_CALL = os.environ.get('PXG_NO_FUSED_CALL') is None         # (A/B: FAST5 decode and GPU pass as separate native calls)
 _WORKER_IDS = {}            # process name -> the 16 hex digits dump files carry (signal_analyzer.py:163)
 PLAIN_RUN_CALLS = 0         # worker calls that took SignalAnalyzer.process_plain_run (bench.py reports it)
@@ -224,24 +227,35 @@ class SignalAnalyzer(AbstractContextManager):
                 if batch is None:
                     return None
                 self.call_arena, layout, plain, first = batch.arena, batch.layout, batch.plain, batch.first
-                fits = plain is not None and bool(plain['ok'][first:first + n].all())
+                fits = plain is not None and bool(plain['regular'][first:first + n].all())
             else:
                 plain = b.plain_run_columns(loader.scaler_cfg)
                 if plain is None:
                     return None
                 first = b.index.get(reads[0], -1)
-                if first < 0 or b.keys[first:first + n] != reads or not plain['ok'][first:first + n].all():
+                if first < 0 or b.keys[first:first + n] != reads or not plain['regular'][first:first + n].all():
                     return None
                 if b.broken and any(key[0] in b.broken for key in reads):      # (files that exist but cannot be opened)
                     return None
                 fits = True
-            scan = sel = None
+            scan = sel = short = None
+            if fits and _SHORT_IN_RUN is not None and not plain['ok'][first:first + n].all():
+                # reads too short for the scaler among them (a few per cent of a real run: most 128-read calls have one):
+                # they travel with the run -- the pass gives them up at its own gate --, are reported as what the host's
+                # gate says, and come FIRST in the result list, as the reference returns what stopped before the pass
+                if not _SHORT_IN_RUN:
+                    fits = False
+                else:
+                    short = ~plain['long_enough'][first:first + n]
             if fits and loader.scan_unsplit:
                 # the window scan over the same resident batch (signal_loader.fit_scalers); a Move table of another
                 # k-mer size or a bundle with several block strides: the general path
                 blocks = plain['frame_blocks'][first:first + n]
+                kmer_ok = plain['kmer_ok'][first:first + n]
+                if short is not None:                         # (a read that stops before the scaler is not scanned)
+                    blocks, kmer_ok = np.where(short, 0, blocks), kmer_ok | short
                 sel = blocks > 0
-                if not plain['kmer_ok'][first:first + n].all() or (plain['frame_stride'] is None and sel.any()):
+                if not kmer_ok.all() or (plain['frame_stride'] is None and sel.any()):
                     fits = False
                 elif sel.any():
                     scan = (plain['frame_first'][first:first + n], blocks, plain['frame_stride'])
@@ -252,7 +266,14 @@ class SignalAnalyzer(AbstractContextManager):
                 call = None
                 if batch is not None and _FUSED_CALL and hasattr(fast, 'decode_and_run') and hasattr(self.ctx, 'batch_ex_call'):
                     call = self.ctx.batch_ex_call(n, loader.stage_mask, scan, bool(loader.stage_mask & native.STAGE_POLYA))
-        if batch is not None:
+        none_enters = fits and batch is None and short is not None and bool(short.all())
+        if none_enters:
+            # nothing of this call reaches the scaler: no pass (the general path would not make one either; reads from
+            # files are decoded all the same -- a read that cannot be is that read's 'unknown_error', short or not)
+            got = {'records': np.zeros(n, dtype=native.RESULT_DTYPE), 'spikes': None}
+            scan, t1 = None, time.perf_counter()
+            t2 = t1
+        elif batch is not None:
             # decode (+ the GPU pass, when this call makes it itself) without the interpreter lock; whoever declines from
             # here on has the files read already: self.prebuilt
             with loader.decoding() as threads:
@@ -270,7 +291,9 @@ class SignalAnalyzer(AbstractContextManager):
             return None
         else:
             loader.pin_bundle()
-        if batch is None or call is None:
+        if none_enters:
+            pass
+        elif batch is None or call is None:
             t1 = time.perf_counter()
             got = loader.records_of_run(arena, offsets, calib, scan)
             t2 = time.perf_counter()
@@ -284,6 +307,8 @@ class SignalAnalyzer(AbstractContextManager):
             if len(some) > n // 4:
                 # in-read adapter candidates (or failed scans) all over the call: the batch table, with the pass that
                 # has already run
+                if short is not None:
+                    return None           # (... which has records of reads the table would not have sent: the general path)
                 results = self.finish_from_pass(reads, got, sel)
             else:
                 skip = None
@@ -299,16 +324,21 @@ class SignalAnalyzer(AbstractContextManager):
                                               tuple(native.STATUS_NAMES), tuple(LABELS), bool(cfg['measure_polya']),
                                               None if spikes is None else np.ascontiguousarray(spikes[0], dtype=np.float32),
                                               None if spikes is None else np.ascontiguousarray(spikes[1], dtype=np.int64),
-                                              skip)
+                                              skip, None if short is None else np.ascontiguousarray(short))
                     if skip is not None:
                         held, held_first = (b, first) if batch is None else (batch.bundle(), 0)
                         for at, report in zip(some.tolist(), self.finish_some_from_pass(held, held_first, some, got)):
                             results[at] = report
                 except (IndexError, TypeError, KeyError, ValueError):
+                    if short is not None:
+                        return None
                     results = self.finish_from_pass(reads, got, sel)      # columns it cannot read as they are
                 finally:
                     if was_on:
                         gc.enable()
+                if short is not None:     # what stopped before the pass first (encounter order), then the rest (input order)
+                    flags = short.tolist()
+                    results = [r for r, s_ in zip(results, flags) if s_] + [r for r, s_ in zip(results, flags) if not s_]
             global PLAIN_RUN_CALLS
             PLAIN_RUN_CALLS += 1
         if CALL_TRACE is not None:

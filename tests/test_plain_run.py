@@ -115,7 +115,7 @@ def crafted_bundle(tmp_path, n, seed):
               'sequence_length': n_bases, 'mean_qscore': float(rng.uniform(5, 14)),      # (a float64 the table rounds to float32)
               'num_events': n_blocks, 'first_sample_template': 0, 'table': 'move', 'move': move}
         if 0.24 <= u < 0.27:
-            bc['move'] = move[:-3]                                       # a frame that does not fit the raw signal: irregular
+            bc['move'] = np.concatenate([move, np.zeros(5, dtype=np.uint8)])      # a frame longer than the raw signal: irregular
         basecalls.append(bc)
     path = str(tmp_path / 'crafted{}.pxr.npz'.format(seed))
     write_bundle(path, arena, off, cal, names, ids, basecalls=basecalls)
@@ -173,8 +173,10 @@ def test_short_path_equals_the_general_path(crafted, monkeypatch, tmp_path, seed
     assert isinstance(first, list), first
     adapter = worker_objects()['ctx'].state_names.index('adapter')
     plain = ReadBundle(path).plain_run_columns(worker_objects()['loader'].scaler_cfg)
-    # (with the scan on, a Move table of another k-mer size also sends the call to the batch table)
-    ok = plain['ok'] & plain['kmer_ok'] if chimera else plain['ok']
+    # (with the scan on, a Move table of another k-mer size also sends the call to the batch table; reads too short for
+    #  the scaler ride along: their dicts come first, as on the general path)
+    ok = plain['regular'] & (plain['kmer_ok'] | ~plain['long_enough']) if chimera else plain['regular']
+    assert not plain['ok'].all() and not plain['regular'].all() and (plain['regular'] & ~plain['long_enough']).any()
     rec['seg_first'][:, adapter] = np.where(found, 40, -1)
     rec['seg_last'][:, adapter] = np.where(found, 90, -1)
     rng = np.random.default_rng(100 + seed)
@@ -209,7 +211,7 @@ def test_short_path_equals_the_general_path(crafted, monkeypatch, tmp_path, seed
     assert n_taken >= 15
     # (with the scan on, a read with candidates is judged over its event table, on the batch table the call falls back to)
     assert statuses - {'unsplit_read'} == {'okay', 'scaling_qc_fail', 'adapter_not_detected', 'not_basecalled',
-                                           'sequence_too_short'}
+                                           'sequence_too_short', 'scaler_signal_too_short'}
     assert ('unsplit_read' in statuses) == chimera
     # a few reads with candidates in a call: a table of just those beside the C pass; many (a quarter of a small call):
     # the whole call on the batch table with the pass it had made; none: the C pass alone
@@ -223,8 +225,10 @@ def test_calls_the_short_path_declines(crafted, monkeypatch, tmp_path):
     CraftedRecords.table = rec
     b = ReadBundle(path)
     cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path), read_bundle=path, barcoding=True)
-    ok = b.plain_run_columns({'length': 30000, 'stride': 15, 'min_length': 9000})['ok']
-    assert not ok[short].any() and ok.sum() > 60
+    columns = b.plain_run_columns({'length': 30000, 'stride': 15, 'min_length': 9000})
+    assert not columns['ok'][short].any() and columns['ok'].sum() > 60
+    ok = columns['regular']              # (reads too short for the scaler ride along; an irregular basecall summary does not)
+    assert not ok.all()
     # a stretch of plain reads
     run = max((j - i, i, j) for i in range(120) for j in range(i + 1, 121) if ok[i:j].all())
     lo, hi = run[1], run[2]
@@ -257,6 +261,15 @@ def test_calls_the_short_path_declines(crafted, monkeypatch, tmp_path):
     bad = int(np.nonzero(~ok)[0][0])                            # a run with one read that is not plain in it
     took, out = call(b.keys[max(bad - 2, 0):bad + 3])
     assert took is False
+    # a run with a read too short for the scaler in it is taken -- unless PXG_NO_SHORT_IN_RUN says otherwise
+    tiny = next(i for i in np.nonzero(short)[0].tolist() if ok[max(i - 2, 0):i + 3].all())
+    took, with_short = call(b.keys[max(tiny - 2, 0):tiny + 3])
+    assert took is True and with_short[0]['status'] == 'scaler_signal_too_short' and with_short[0]['read_id'] == b.read_ids[tiny]
+    monkeypatch.setattr(SA, '_SHORT_IN_RUN', False)
+    took, table_says = call(b.keys[max(tiny - 2, 0):tiny + 3])
+    assert took is False
+    same(with_short, table_says)
+    monkeypatch.setattr(SA, '_SHORT_IN_RUN', True)
     # nothing to do is not a run either
     assert call([])[1] == [] and taken == [False]
 
@@ -284,7 +297,7 @@ def test_short_path_against_the_real_reference(monkeypatch, tmp_path, encoded):
         want = {(r['filename'], r.get('read_id')): r for r in ref['results']}
         b = ReadBundle(bundle_path)
         assert b.compressed == encoded
-        ok = b.plain_run_columns({'length': 30000, 'stride': 15, 'min_length': 9000})['ok']
+        ok = b.plain_run_columns({'length': 30000, 'stride': 15, 'min_length': 9000})['regular']
         reads = [tuple(r) for r in ref['reads']]
         at = [b.index.get(k, -1) for k in reads]
         taken = spy_on_the_short_path(monkeypatch)
@@ -299,7 +312,11 @@ def test_short_path_against_the_real_reference(monkeypatch, tmp_path, encoded):
                 continue
             got = SA.process_batch(ref['batchid'], reads[pos:end], cfg)
             assert taken[-1] is True and isinstance(got, list)
-            TF.compare_results(got, [want[k] for k in reads[pos:end]], check_polya=True)
+            expect = [want[k] for k in reads[pos:end]]
+            # (what stopped before the pass comes first, in encounter order -- signal_analyzer.py:82-134 -- then the rest)
+            expect = [r for r in expect if r['status'] == 'scaler_signal_too_short'] + \
+                [r for r in expect if r['status'] != 'scaler_signal_too_short']
+            TF.compare_results(got, expect, check_polya=True)
             covered += end - pos
             pos = end
         assert covered >= 24, covered
@@ -318,7 +335,7 @@ def test_short_path_from_many_threads(crafted, monkeypatch, tmp_path):
     assert isinstance(SA.process_batch(0, keys[:1], cfg), list)
     adapter = worker_objects()['ctx'].state_names.index('adapter')
     rec['seg_first'][:, adapter] = np.where(found, 40, -1)
-    ok = worker_objects()['loader'].bundle.plain_run_columns(worker_objects()['loader'].scaler_cfg)['ok']
+    ok = worker_objects()['loader'].bundle.plain_run_columns(worker_objects()['loader'].scaler_cfg)['regular']
     rng = np.random.default_rng(5)
     windows = [(int(a), int(rng.integers(1, 40))) for a in rng.integers(0, 399, 200)]
     monkeypatch.setattr(SA, '_PLAIN_RUN', False)
@@ -389,7 +406,7 @@ def test_short_path_from_fast5_files_equals_the_general_path(crafted, monkeypatc
     assert worker_objects()['loader'].bundle is None
     adapter = worker_objects()['ctx'].state_names.index('adapter')
     plain = ReadBundle(path).plain_run_columns(worker_objects()['loader'].scaler_cfg)
-    ok = (plain['ok'] & plain['kmer_ok'] if chimera else plain['ok'])[which]
+    ok = (plain['regular'] & (plain['kmer_ok'] | ~plain['long_enough']) if chimera else plain['regular'])[which]
     rec['seg_first'][:, adapter] = np.where(found, 40, -1)
     rec['seg_last'][:, adapter] = np.where(found, 90, -1)
     taken = spy_on_the_short_path(monkeypatch)
@@ -415,7 +432,7 @@ def test_short_path_from_fast5_files_equals_the_general_path(crafted, monkeypatc
             statuses |= {r['status'] for r in fast}
     assert n_taken >= 12
     assert statuses - {'unsplit_read'} == {'okay', 'scaling_qc_fail', 'adapter_not_detected', 'not_basecalled',
-                                           'sequence_too_short'}
+                                           'sequence_too_short', 'scaler_signal_too_short'}
     assert 1 <= len(arenas.free) <= 2                         # the calls took turns with the same sample arena
     # the taken calls made their GPU pass from inside csrc/pxg_pyreport.c decode_and_run (decode + pass behind one
     # release of the interpreter lock), through the double's C entry point; with PXG_NO_FUSED_CALL they decode first
@@ -458,7 +475,7 @@ def test_fast5_call_with_an_undecodable_read_and_with_buffers_too_small(crafted,
     n = 24
     path, rec, found, short, _ = crafted_bundle(tmp_path, n, 21)
     b = ReadBundle(path)
-    plain_ok = b.plain_run_columns({'length': 30000, 'stride': 15, 'min_length': 9000})['ok']
+    plain_ok = b.plain_run_columns({'length': 30000, 'stride': 15, 'min_length': 9000})['ok']      # (long enough and regular)
     good = [i for i in range(n) if plain_ok[i]][:12]
     assert len(good) == 12
     top = tmp_path / 'f5'
@@ -695,7 +712,7 @@ def test_without_the_extension_every_call_takes_the_batch_table(crafted, monkeyp
     CraftedRecords.table = rec
     cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path), read_bundle=path, barcoding=True)
     b = ReadBundle(path)
-    ok = b.plain_run_columns({'length': 30000, 'stride': 15, 'min_length': 9000})['ok']
+    ok = b.plain_run_columns({'length': 30000, 'stride': 15, 'min_length': 9000})['regular']
     run = max((j - i, i, j) for i in range(120) for j in range(i + 1, 121) if ok[i:j].all())
     reads = b.keys[run[1]:run[2]]
     with_extension = SA.process_batch(0, list(reads), cfg)
@@ -745,3 +762,22 @@ def test_call_arenas_pool():
     assert locked.take(50) is y
     locked.release()
     assert sorted(ctx.unpinned) == sorted(ctx.pinned) and locked.free == [] and locked.locked == []
+
+
+def test_a_call_of_nothing_but_short_reads_makes_no_pass(crafted, monkeypatch, tmp_path):
+    """Reads too short for the scaler only: the short path reports them without a GPU pass, like the batch table."""
+    path, rec, found, short, _ = crafted_bundle(tmp_path, 200, 17)
+    CraftedRecords.table = rec
+    b = ReadBundle(path)
+    cfg = default_config(inputdir=str(tmp_path), outputdir=str(tmp_path), read_bundle=path, barcoding=True)
+    assert isinstance(SA.process_batch(0, b.keys[:1], cfg), list)
+    i = int(np.nonzero(short)[0][0])
+    taken = spy_on_the_short_path(monkeypatch)
+    passes = []
+    real = CraftedRecords.process_batch_ex
+    monkeypatch.setattr(CraftedRecords, 'process_batch_ex', lambda self, *a, **kw: passes.append(1) or real(self, *a, **kw))
+    got = SA.process_batch(1, b.keys[i:i + 1], cfg)
+    assert taken == [True] and passes == [] and got[0]['status'] == 'scaler_signal_too_short'
+    monkeypatch.setattr(SA, '_PLAIN_RUN', False)
+    same(got, SA.process_batch(1, b.keys[i:i + 1], cfg))
+    assert passes == []
