@@ -566,6 +566,12 @@ def test_short_path_equals_the_general_path_on_the_gpu(monkeypatch, tmp_path, po
     from poreplex_amd.synth import synth_basecalls, synth_batch
     n = 384
     sb = synth_batch(n, seed=31, samples_per_read=20000)
+    # a few reads too short for the scaler in every call (and an empty one): they ride along in the plain run, the pass
+    # gives them up at its own gate, the dicts say what the host's gate says and come first
+    o = sb['offsets']
+    cut = {5: 3000, 6: 0, 130: 8999, 255: 14, 256: 4000, 383: 1}
+    parts = [sb['arena'][o[j]:o[j + 1]][:cut.get(j, 1 << 30)] for j in range(n)]
+    sb = dict(sb, arena=np.concatenate(parts), offsets=np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.int64))
     names = ['a/r{:05d}.fast5'.format(i) for i in range(n)]
     ids = ['{:08x}-0000-4000-8000-{:012x}'.format(31, i) for i in range(n)]
     path = str(tmp_path / 'gpu.pxr.npz')
@@ -583,7 +589,8 @@ def test_short_path_equals_the_general_path_on_the_gpu(monkeypatch, tmp_path, po
         got = [SA.process_batch(k, keys[lo:lo + 128], cfg) for k, lo in enumerate(range(0, n, 128))]
         assert taken == [True] * 3
         same(got, want)
-        assert {r['status'] for w in want for r in w} >= {'okay'}
+        assert {r['status'] for w in want for r in w} >= {'okay', 'scaler_signal_too_short'}
+        assert [r['read_id'] for r in want[0][:2]] == [ids[5], ids[6]] and want[2][0]['read_id'] == ids[256]
         assert any('polya' in r for w in want for r in w) == polya
         with ThreadPoolExecutor(6) as pool:
             again = list(pool.map(lambda lo: SA.process_batch(9, keys[lo:lo + 128], cfg), list(range(0, n, 128)) * 4))
